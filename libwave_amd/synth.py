@@ -1,0 +1,84 @@
+"""Deterministic synthetic scenes for BASELINE.json's configs.
+
+Scene S(n, seed): 40 % ground (x in [-50,50], y in [-30,30], z ~ N(0, 0.01^2)),
+30 % on the four walls of the 100 x 60 m box (z in [0, 8]), 30 % on 200 random
+boxes (<= 4 x 2 x 2 m).  float32 XYZ.  Pair modes: 'copy' (target = T_gt * ref,
+mirrors wave_matching/tests/icp_tests.cpp:31) and 'resample' (target = T_gt *
+S(n, seed+1) + N(0, 0.01^2)) so the MSE floor is non-zero.
+"""
+import numpy as np
+
+
+def rpy_to_R(roll, pitch, yaw):
+    cr, sr, cp, sp, cy, sy = (np.cos(roll), np.sin(roll), np.cos(pitch), np.sin(pitch),
+                              np.cos(yaw), np.sin(yaw))
+    Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def make_T(t=(0.2, -0.1, 0.05), rpy=(0.01, -0.02, 0.03)):
+    T = np.eye(4)
+    T[:3, :3] = rpy_to_R(*rpy)
+    T[:3, 3] = t
+    return T
+
+
+T_GT = make_T()
+
+
+def scene(n, seed=42):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n_ground = int(0.4 * n)
+    n_wall = int(0.3 * n)
+    n_box = n - n_ground - n_wall
+    g = np.empty((n_ground, 3))
+    g[:, 0] = rng.uniform(-50, 50, n_ground)
+    g[:, 1] = rng.uniform(-30, 30, n_ground)
+    g[:, 2] = rng.normal(0, 0.01, n_ground)
+    w = np.empty((n_wall, 3))
+    side = rng.integers(0, 4, n_wall)
+    u = rng.uniform(0, 1, n_wall)
+    w[:, 2] = rng.uniform(0, 8, n_wall)
+    w[:, 0] = np.where(side == 0, -50, np.where(side == 1, 50, -50 + 100 * u))
+    w[:, 1] = np.where(side == 2, -30, np.where(side == 3, 30, -30 + 60 * u))
+    # 200 boxes; a fixed sub-generator so the box layout depends on the seed only
+    brng = np.random.Generator(np.random.PCG64(seed * 7919 + 1))
+    nb = 200
+    centre = np.stack([brng.uniform(-45, 45, nb), brng.uniform(-25, 25, nb)], axis=1)
+    size = np.stack([brng.uniform(0.5, 4, nb), brng.uniform(0.5, 2, nb), brng.uniform(0.5, 2, nb)], axis=1)
+    which = rng.integers(0, nb, n_box)
+    face = rng.integers(0, 5, n_box)  # 4 sides + top
+    a = rng.uniform(-0.5, 0.5, n_box)
+    b = rng.uniform(-0.5, 0.5, n_box)
+    sx, sy, sz = size[which, 0], size[which, 1], size[which, 2]
+    bx = np.where(face == 0, -0.5 * sx, np.where(face == 1, 0.5 * sx, a * sx))
+    by = np.where(face == 2, -0.5 * sy, np.where(face == 3, 0.5 * sy, np.where(face < 2, a * sy, b * sy)))
+    bz = np.where(face == 4, sz, (b + 0.5) * sz)
+    bpts = np.stack([centre[which, 0] + bx, centre[which, 1] + by, bz], axis=1)
+    pts = np.concatenate([g, w, bpts], axis=0)
+    pts = pts[rng.permutation(len(pts))]
+    return np.ascontiguousarray(pts, dtype=np.float32)
+
+
+def transform_points(xyz, T):
+    """pcl::transformPointCloud(in, out, Affine3d): double arithmetic, float store."""
+    p = xyz.astype(np.float64)
+    return np.ascontiguousarray((p @ T[:3, :3].T + T[:3, 3]).astype(np.float32))
+
+
+def pair(n, seed=42, mode="resample", T=None, noise=0.01):
+    """Returns (ref, target, T_gt) with target ~= T_gt * ref."""
+    T = T_GT if T is None else T
+    ref = scene(n, seed)
+    if mode == "copy":
+        tgt = transform_points(ref, T)
+    elif mode == "resample":
+        other = scene(n, seed + 1).astype(np.float64)
+        rng = np.random.Generator(np.random.PCG64(seed + 1000003))
+        other = other + rng.normal(0, noise, other.shape)
+        tgt = transform_points(other.astype(np.float32), T)
+    else:
+        raise ValueError(mode)
+    return ref, tgt, T
