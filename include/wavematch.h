@@ -1,0 +1,162 @@
+/*
+ * wavematch.h -- C ABI of libwavematch_hip.so: the MI355X (gfx950) registration
+ * back end behind libwave's wave::Matcher<PCLPointCloudPtr> API.
+ *
+ * The reference (wavelab/libwave) has no FFI boundary on this path: its
+ * ICPMatcher / GICPMatcher / NDTMatcher call PCL C++ templates directly.  Each
+ * entry point below names the reference call (file:line under /root/reference)
+ * whose work it replaces; the C++ shim in include/wave/matching maps the
+ * reference's classes onto these calls.
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = WM_OK, >0 = algorithmic
+ *     "no result" (the reference's match() == false), <0 = error.  No C++
+ *     exceptions cross this boundary.
+ *   - clouds are arrays of points with a caller-given byte stride whose first
+ *     12 bytes are float x, y, z (pcl::PointXYZ is stride 16; packed XYZ is 12).
+ *     `mem` says where the array lives: WM_MEM_HOST (copied H2D by the call) or
+ *     WM_MEM_DEVICE (an HBM pointer, e.g. a torch tensor's data_ptr()).
+ *     The library never retains a caller pointer past the call.
+ *   - 4x4 transforms and 6x6 matrices are row-major doubles.
+ *   - a wm_ctx is thread-compatible (one thread at a time); distinct contexts
+ *     are fully concurrent (own HIP stream).  One ctx == one reference matcher
+ *     object (it carries PCL's per-object state, e.g. the convergence
+ *     criteria's previous MSE).
+ */
+#ifndef WAVEMATCH_H
+#define WAVEMATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WM_OK 0
+#define WM_NOT_CONVERGED 1            /* pcl hasConverged() == false */
+#define WM_TOO_FEW_CORRESPONDENCES 2  /* PCL: "Not enough correspondences found" */
+#define WM_ERR_ARG (-1)
+#define WM_ERR_HIP (-2)
+#define WM_ERR_RCCL (-3)
+#define WM_ERR_STATE (-4) /* e.g. align before set_source/set_target */
+#define WM_ERR_NOMEM (-5)
+
+enum { WM_MEM_HOST = 0, WM_MEM_DEVICE = 1 };
+
+typedef struct wm_ctx wm_ctx;
+
+/* ------------------------------------------------------------- lifecycle */
+/* Replaces the PCL member objects a matcher constructs (icp.hpp:100-102,
+ * gicp.hpp:61-62, ndt.hpp:72).  `device` is the HIP device ordinal. */
+int wm_ctx_create(wm_ctx **out, int device);
+void wm_ctx_destroy(wm_ctx *ctx);
+const char *wm_strerror(int status);
+/* last HIP/RCCL error text recorded on this ctx ("" if none) */
+const char *wm_last_error(const wm_ctx *ctx);
+/* library / build identification, e.g. "wavematch-hip 0.1 gfx950" */
+const char *wm_version(void);
+
+/* ---------------------------------------------------------------- clouds */
+/* wave `ref` == PCL source (the cloud that is moved / queried):
+ *   icp.setInputSource  wave_matching/src/icp.cpp:87,110,125
+ *   gicp.setInputSource wave_matching/src/gicp.cpp:44
+ *   ndt.setInputSource  wave_matching/src/ndt.cpp:50
+ * Uploads, drops non-finite points, and Morton-orders the cloud in HBM. */
+int wm_set_source(wm_ctx *ctx, const void *pts, size_t n, size_t stride_bytes, int mem);
+/* wave `target` == PCL target (the cloud that is indexed):
+ *   icp.setInputTarget  wave_matching/src/icp.cpp:91,114,124
+ *   gicp.setInputTarget wave_matching/src/gicp.cpp:54
+ *   ndt.setInputTarget  wave_matching/src/ndt.cpp:55
+ * Replaces the FLANN kd-tree build in pcl::Registration::initCompute with a
+ * cell-sorted uniform grid in HBM.  grid_cell = 0 picks the cell size from the
+ * measured point density. */
+int wm_set_target(wm_ctx *ctx, const void *pts, size_t n, size_t stride_bytes, int mem);
+int wm_set_grid_cell(wm_ctx *ctx, float grid_cell);
+/* number of points currently held (after dropping non-finite ones) */
+int wm_cloud_sizes(const wm_ctx *ctx, size_t *n_source, size_t *n_target);
+
+/* ------------------------------------------------------------------- ICP */
+enum { WM_ICP_SVD = 0, WM_ICP_GN6 = 1 };
+enum { WM_NN_AUTO = 0, WM_NN_GRID = 1, WM_NN_BRUTE = 2 };
+enum { /* pcl::registration::DefaultConvergenceCriteria::ConvergenceState */
+       WM_CONV_NOT_CONVERGED = 0,
+       WM_CONV_ITERATIONS = 1,
+       WM_CONV_TRANSFORM = 2,
+       WM_CONV_ABS_MSE = 3,
+       WM_CONV_REL_MSE = 4,
+       WM_CONV_NO_CORRESPONDENCES = 5,
+       WM_CONV_FORCED = 6 };
+
+typedef struct {
+    double max_corr;      /* ICPMatcherParams::max_corr, icp.hpp:35 -> icp.cpp:47 */
+    int max_iter;         /* ICPMatcherParams::max_iter, icp.hpp:37 -> icp.cpp:48 */
+    double t_eps;         /* ICPMatcherParams::t_eps,    icp.hpp:41 -> icp.cpp:49 */
+    double fit_eps;       /* ICPMatcherParams::fit_eps,  icp.hpp:43 -> icp.cpp:50 */
+    int force_iterations; /* >0: run exactly this many iterations (bench; no stop tests) */
+    int mode;             /* WM_ICP_SVD: PCL's Umeyama step (parity default);
+                             WM_ICP_GN6: 6x6 J^T J / J^T r Gauss-Newton step */
+    int nn_method;        /* WM_NN_AUTO | WM_NN_GRID | WM_NN_BRUTE */
+    int carry_state;      /* 1: seed the criteria's previous MSE from the ctx (PCL keeps
+                             it across align() calls on one object); 0: fresh */
+    int profile;          /* 1: time each kernel class with HIP events (slower loop) */
+    int reserved;
+} wm_icp_params;
+
+typedef struct {
+    int converged;  /* hasConverged() */
+    int iterations; /* nr_iterations_ */
+    int state;      /* WM_CONV_* */
+    int n_corr;     /* correspondences of the last iteration */
+    double mse;     /* mean d^2 of the last iteration's correspondences */
+    double prev_mse;
+    /* measurement (HIP events on the ctx stream; ms) */
+    float align_ms;      /* whole wm_icp_align call, device side */
+    float nn_ms;         /* sum over correspondence-search launches (profile=1) */
+    float stats_ms;      /* sum over statistic-reduction launches (profile=1) */
+    float solve_ms;      /* sum over reduce+solve launches (profile=1) */
+    int nn_launches;     /* level-0 correspondence launches timed in nn_ms */
+    int nn_levels;       /* grid levels used */
+    uint64_t deferred;   /* queries that needed a coarser grid level (profile=1) */
+    float grid_cell;     /* level-0 cell size used */
+} wm_icp_stats;
+
+void wm_icp_default_params(wm_icp_params *p);
+
+/* pcl::IterativeClosestPoint::align + hasConverged + getFinalTransformation
+ * (wave_matching/src/icp.cpp:95-101,116-119,126-129).  T_out maps source->target.
+ * Returns WM_OK when converged, WM_NOT_CONVERGED / WM_TOO_FEW_CORRESPONDENCES
+ * otherwise (T_out then untouched, as ICPMatcher leaves `result`). */
+int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_stats *stats);
+
+/* PCL's icp.correspondences_ after align (read by estimateLUM / estimateCensi,
+ * icp_pcl_functions.cpp:191, icp.cpp:213): per source point (caller's order)
+ * the matched target index (caller's order; -1 = none) and squared distance. */
+int wm_get_correspondences(wm_ctx *ctx, int32_t *match_idx, float *d2, size_t cap);
+
+/* One correspondence pass with a caller-given transform (kernel-level parity
+ * and roofline measurement): CorrespondenceEstimation::determineCorrespondences
+ * [PCL registration/impl/correspondence_estimation.hpp] as driven by
+ * icp.align (icp.cpp:126).  kernel_ms (may be NULL) receives the device time
+ * of the level-0 correspondence kernel. */
+int wm_nn_search(wm_ctx *ctx, const double T[16], double max_corr, int nn_method,
+                 int32_t *match_idx, float *d2, size_t cap, float *kernel_ms);
+
+/* The sufficient statistics one ICP iteration reduces to (what crosses xGMI in
+ * the multi-GPU path).  SVD mode: stats[0]=n, [1..3]=sum p, [4..6]=sum q,
+ * [7..15]=sum q p^T (row-major), [16]=sum d2.  GN6 mode: [0]=n, [1]=sum d2,
+ * [2..22]=upper triangle of J^T J (row-major), [23..28]=J^T r.  Uses the
+ * correspondences of the last wm_nn_search / align iteration. */
+#define WM_STATS_LEN 32
+int wm_icp_stats_for(wm_ctx *ctx, const double T[16], int mode, double stats[WM_STATS_LEN]);
+
+/* Host-only solvers on those statistics (no GPU touched; used by every rank
+ * after the all-reduce).  Tk_out is the incremental transform of one step:
+ * TransformationEstimationSVD / pcl::umeyama [PCL transformation_estimation_svd.hpp]. */
+int wm_umeyama_from_stats(const double stats[WM_STATS_LEN], double Tk_out[16]);
+int wm_gn6_from_stats(const double stats[WM_STATS_LEN], double Tk_out[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVEMATCH_H */

@@ -1,0 +1,218 @@
+"""ctypes binding of libwavematch_hip.so (the C ABI declared in include/wavematch.h).
+
+This is plumbing for tests / bench.py; the product is the shared library.  The
+library is built in-tree by `__graft_entry__.build()` (hipcc, gfx950).  There is
+no CPU fallback: if the library is missing, or no HIP device is present when a
+context is created, the call fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwavematch_hip.so")
+
+WM_OK, WM_NOT_CONVERGED, WM_TOO_FEW = 0, 1, 2
+WM_MEM_HOST, WM_MEM_DEVICE = 0, 1
+WM_ICP_SVD, WM_ICP_GN6 = 0, 1
+WM_NN_AUTO, WM_NN_GRID, WM_NN_BRUTE = 0, 1, 2
+WM_STATS_LEN = 32
+CONV_NAMES = {0: "NOT_CONVERGED", 1: "ITERATIONS", 2: "TRANSFORM", 3: "ABS_MSE", 4: "REL_MSE",
+              5: "NO_CORRESPONDENCES", 6: "FORCED"}
+
+
+class WmError(RuntimeError):
+    pass
+
+
+class IcpParams(C.Structure):
+    _fields_ = [("max_corr", C.c_double), ("max_iter", C.c_int), ("t_eps", C.c_double),
+                ("fit_eps", C.c_double), ("force_iterations", C.c_int), ("mode", C.c_int),
+                ("nn_method", C.c_int), ("carry_state", C.c_int), ("profile", C.c_int),
+                ("reserved", C.c_int)]
+
+
+class IcpStats(C.Structure):
+    _fields_ = [("converged", C.c_int), ("iterations", C.c_int), ("state", C.c_int),
+                ("n_corr", C.c_int), ("mse", C.c_double), ("prev_mse", C.c_double),
+                ("align_ms", C.c_float), ("nn_ms", C.c_float), ("stats_ms", C.c_float),
+                ("solve_ms", C.c_float), ("nn_launches", C.c_int), ("nn_levels", C.c_int),
+                ("deferred", C.c_uint64), ("grid_cell", C.c_float)]
+
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+_LIB = None
+
+
+def lib():
+    """Load the shared library (raises if it has not been built)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise WmError("libwavematch_hip.so is not built: run `python -c 'import "
+                          "__graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950)")
+        L = C.CDLL(LIB_PATH)
+        L.wm_version.restype = C.c_char_p
+        L.wm_strerror.restype = C.c_char_p
+        L.wm_strerror.argtypes = [C.c_int]
+        L.wm_last_error.restype = C.c_char_p
+        L.wm_last_error.argtypes = [C.c_void_p]
+        L.wm_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.wm_ctx_destroy.argtypes = [C.c_void_p]
+        L.wm_ctx_destroy.restype = None
+        L.wm_set_source.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+        L.wm_set_target.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+        L.wm_set_grid_cell.argtypes = [C.c_void_p, C.c_float]
+        L.wm_cloud_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.wm_icp_default_params.argtypes = [C.POINTER(IcpParams)]
+        L.wm_icp_default_params.restype = None
+        L.wm_icp_align.argtypes = [C.c_void_p, C.POINTER(IcpParams), _dp, C.POINTER(IcpStats)]
+        L.wm_get_correspondences.argtypes = [C.c_void_p, _ip, _fp, C.c_size_t]
+        L.wm_nn_search.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int, _ip, _fp, C.c_size_t, _fp]
+        L.wm_icp_stats_for.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
+        L.wm_umeyama_from_stats.argtypes = [_dp, _dp]
+        L.wm_gn6_from_stats.argtypes = [_dp, _dp]
+        _LIB = L
+    return _LIB
+
+
+def declared_symbols(header=None):
+    """Every function name declared in include/*.h (used by the export test)."""
+    import re
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    names = []
+    for fn in sorted(os.listdir(inc)):
+        if not fn.endswith(".h"):
+            continue
+        txt = open(os.path.join(inc, fn)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names += re.findall(r"\b(wm_[a-z0-9_]+)\s*\(", txt)
+    return sorted(set(names))
+
+
+def icp_params(**kw):
+    p = IcpParams()
+    lib().wm_icp_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def _cloud_arg(a):
+    """-> (pointer, n, stride, mem, keepalive).  Accepts a float32 numpy array
+    (n, 3|4) on the host or a torch tensor (n, 3|4) float32 on a HIP device."""
+    if isinstance(a, np.ndarray):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        assert a.ndim == 2 and a.shape[1] in (3, 4)
+        return a.ctypes.data, a.shape[0], a.shape[1] * 4, WM_MEM_HOST, a
+    import torch
+    assert isinstance(a, torch.Tensor) and a.dtype == torch.float32 and a.dim() == 2
+    a = a.contiguous()
+    mem = WM_MEM_DEVICE if a.is_cuda else WM_MEM_HOST
+    return a.data_ptr(), a.shape[0], a.shape[1] * 4, mem, a
+
+
+class Context:
+    """One wm_ctx == one reference matcher object."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        rc = lib().wm_ctx_create(C.byref(self._h), int(device))
+        if rc != WM_OK:
+            raise WmError("wm_ctx_create(device=%d) failed: %s -- a HIP device is required; "
+                          "there is no CPU fallback" % (device, lib().wm_strerror(rc).decode()))
+        self.device = device
+        self.n_src = self.n_tgt = 0
+
+    def close(self):
+        if self._h:
+            lib().wm_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise WmError("%s: %s [%s]" % (what, lib().wm_strerror(rc).decode(),
+                                           lib().wm_last_error(self._h).decode()))
+        return rc
+
+    def set_source(self, cloud):
+        ptr, n, stride, mem, keep = _cloud_arg(cloud)
+        self._check(lib().wm_set_source(self._h, C.c_void_p(ptr), n, stride, mem), "wm_set_source")
+        self.n_src = n
+
+    def set_target(self, cloud):
+        ptr, n, stride, mem, keep = _cloud_arg(cloud)
+        self._check(lib().wm_set_target(self._h, C.c_void_p(ptr), n, stride, mem), "wm_set_target")
+        self.n_tgt = n
+
+    def set_grid_cell(self, h):
+        self._check(lib().wm_set_grid_cell(self._h, float(h)), "wm_set_grid_cell")
+
+    def sizes(self):
+        a, b = C.c_size_t(), C.c_size_t()
+        lib().wm_cloud_sizes(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def icp_align(self, params=None, **kw):
+        p = params or icp_params(**kw)
+        T = np.zeros((4, 4), np.float64)
+        s = IcpStats()
+        rc = self._check(lib().wm_icp_align(self._h, C.byref(p), T.ctypes.data_as(_dp),
+                                            C.byref(s)), "wm_icp_align")
+        return dict(rc=rc, T=T if rc == WM_OK else None, converged=bool(s.converged),
+                    iterations=s.iterations, state=CONV_NAMES.get(s.state, s.state),
+                    n_corr=s.n_corr, mse=s.mse, prev_mse=s.prev_mse, align_ms=s.align_ms,
+                    nn_ms=s.nn_ms, stats_ms=s.stats_ms, solve_ms=s.solve_ms,
+                    nn_launches=s.nn_launches, nn_levels=s.nn_levels, deferred=s.deferred,
+                    grid_cell=s.grid_cell)
+
+    def correspondences(self):
+        idx = np.empty(self.n_src, np.int32)
+        d2 = np.empty(self.n_src, np.float32)
+        self._check(lib().wm_get_correspondences(self._h, idx.ctypes.data_as(_ip),
+                                                 d2.ctypes.data_as(_fp), self.n_src),
+                    "wm_get_correspondences")
+        return idx, d2
+
+    def nn_search(self, T=None, max_corr=3.0, nn_method=WM_NN_AUTO, want=True, timed=False):
+        T = np.ascontiguousarray(np.eye(4) if T is None else T, np.float64)
+        idx = np.empty(self.n_src, np.int32) if want else None
+        d2 = np.empty(self.n_src, np.float32) if want else None
+        ms = C.c_float(0)
+        self._check(lib().wm_nn_search(self._h, T.ctypes.data_as(_dp), float(max_corr),
+                                       int(nn_method), idx.ctypes.data_as(_ip) if want else None,
+                                       d2.ctypes.data_as(_fp) if want else None, self.n_src,
+                                       C.byref(ms) if timed else None), "wm_nn_search")
+        return (idx, d2, ms.value) if timed else (idx, d2)
+
+    def icp_stats_for(self, T, mode=WM_ICP_SVD):
+        T = np.ascontiguousarray(T, np.float64)
+        st = np.zeros(WM_STATS_LEN, np.float64)
+        self._check(lib().wm_icp_stats_for(self._h, T.ctypes.data_as(_dp), int(mode),
+                                           st.ctypes.data_as(_dp)), "wm_icp_stats_for")
+        return st
+
+
+def umeyama_from_stats(stats):
+    st = np.ascontiguousarray(stats, np.float64)
+    T = np.zeros((4, 4))
+    rc = lib().wm_umeyama_from_stats(st.ctypes.data_as(_dp), T.ctypes.data_as(_dp))
+    return rc, T
+
+
+def gn6_from_stats(stats):
+    st = np.ascontiguousarray(stats, np.float64)
+    T = np.zeros((4, 4))
+    rc = lib().wm_gn6_from_stats(st.ctypes.data_as(_dp), T.ctypes.data_as(_dp))
+    return rc, T

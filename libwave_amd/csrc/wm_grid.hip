@@ -1,0 +1,481 @@
+// wm_grid.hip -- building the HBM-resident spatial index that replaces PCL's FLANN
+// kd-tree (pcl::Registration::initCompute -> KdTreeFLANN::setInputCloud, triggered
+// by icp.align at wave_matching/src/icp.cpp:95,116,126):
+//   pack (AoS stride -> float4 + index, non-finite filter)  -> bbox reduction
+//   -> cell histogram -> exclusive scan -> scatter (counting sort by cell)
+// Target levels are sorted x-fastest so that x-adjacent cells are contiguous in
+// memory; the source cloud is counting-sorted by a Morton cell code so that a
+// wavefront's 64 consecutive queries stay spatially compact under any rigid T.
+#include "wm_internal.hpp"
+
+#include <math.h>
+#include <string.h>
+
+namespace wm {
+
+// ------------------------------------------------------------------ pack
+__global__ void __launch_bounds__(kBlock) k_pack(const unsigned char *in, size_t n, size_t stride,
+                                                  float4 *out) {
+    size_t i = (size_t) blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float *p = reinterpret_cast<const float *>(in + i * stride);
+    float x = p[0], y = p[1], z = p[2];
+    if (!(isfinite(x) && isfinite(y) && isfinite(z))) {
+        x = y = z = __builtin_nanf("");
+    }
+    out[i] = make_float4(x, y, z, __uint_as_float((unsigned) i));
+}
+
+int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, float4 *out) {
+    if (n == 0) return WM_OK;
+    const unsigned char *dptr = nullptr;
+    if (mem == WM_MEM_HOST) {
+        WM_HIP(ctx, ctx->staging.reserve(n * stride));
+        WM_HIP(ctx, hipMemcpyAsync(ctx->staging.p, pts, n * stride, hipMemcpyHostToDevice,
+                                   ctx->stream));
+        dptr = ctx->staging.as<unsigned char>();
+    } else {
+        dptr = static_cast<const unsigned char *>(pts);
+    }
+    unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(kBlock), 0, ctx->stream, dptr, n, stride, out);
+    WM_HIP(ctx, hipGetLastError());
+    return WM_OK;
+}
+
+// ------------------------------------------------------------------ bbox
+__device__ inline unsigned f2ord(float f) {  // order-preserving float -> uint
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+inline float ord2f(unsigned u) {
+    unsigned v = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    float f;
+    memcpy(&f, &v, 4);
+    return f;
+}
+
+// out[0..2] = min (ordered uint), out[3..5] = max, out[6] = valid count
+__global__ void __launch_bounds__(kBlock) k_bbox(const float4 *pts, size_t n, unsigned *out) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    unsigned cnt = 0;
+    for (size_t i = (size_t) blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += (size_t) gridDim.x * kBlock) {
+        float4 p = pts[i];
+        if (p.x == p.x) {  // not NaN
+            lo[0] = fminf(lo[0], p.x);
+            lo[1] = fminf(lo[1], p.y);
+            lo[2] = fminf(lo[2], p.z);
+            hi[0] = fmaxf(hi[0], p.x);
+            hi[1] = fmaxf(hi[1], p.y);
+            hi[2] = fmaxf(hi[2], p.z);
+            ++cnt;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = fminf(lo[d], __shfl_down(lo[d], off));
+            hi[d] = fmaxf(hi[d], __shfl_down(hi[d], off));
+        }
+        cnt += __shfl_down(cnt, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        for (int d = 0; d < 3; ++d) {
+            atomicMin(&out[d], f2ord(lo[d]));
+            atomicMax(&out[3 + d], f2ord(hi[d]));
+        }
+        atomicAdd(&out[6], cnt);
+    }
+}
+
+int compute_bbox(wm_ctx *ctx, const float4 *pts, size_t n, Bbox *out, size_t *n_valid) {
+    unsigned init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0, 0};
+    WM_HIP(ctx, ctx->bbox_buf.reserve(sizeof(init)));
+    WM_HIP(ctx, hipMemcpyAsync(ctx->bbox_buf.p, init, sizeof(init), hipMemcpyHostToDevice,
+                               ctx->stream));
+    if (n > 0) {
+        unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, n,
+                           ctx->bbox_buf.as<unsigned>());
+        WM_HIP(ctx, hipGetLastError());
+    }
+    unsigned res[8];
+    WM_HIP(ctx, hipMemcpyAsync(res, ctx->bbox_buf.p, sizeof(res), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int d = 0; d < 3; ++d) {
+        out->lo[d] = ord2f(res[d]);
+        out->hi[d] = ord2f(res[3 + d]);
+    }
+    *n_valid = res[6];
+    if (res[6] == 0)
+        for (int d = 0; d < 3; ++d) out->lo[d] = out->hi[d] = 0.f;
+    return WM_OK;
+}
+
+// -------------------------------------------------- counting sort by cell
+struct LinearKey {  // x-fastest dense cell index (target levels)
+    float ox, oy, oz, inv_h;
+    int nx, ny, nz;
+    __device__ unsigned operator()(const float4 &p) const {
+        int cx = (int) floorf((p.x - ox) * inv_h);
+        int cy = (int) floorf((p.y - oy) * inv_h);
+        int cz = (int) floorf((p.z - oz) * inv_h);
+        cx = min(max(cx, 0), nx - 1);
+        cy = min(max(cy, 0), ny - 1);
+        cz = min(max(cz, 0), nz - 1);
+        return (unsigned) ((cz * ny + cy) * nx + cx);
+    }
+};
+
+__device__ inline unsigned spread3(unsigned v) {  // 10 bits -> every third bit
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+struct MortonKey {  // Morton code of a 2^bits-per-axis cell (source ordering)
+    float ox, oy, oz, sx, sy, sz;
+    int cells;  // 2^bits
+    __device__ unsigned operator()(const float4 &p) const {
+        int cx = min(max((int) ((p.x - ox) * sx), 0), cells - 1);
+        int cy = min(max((int) ((p.y - oy) * sy), 0), cells - 1);
+        int cz = min(max((int) ((p.z - oz) * sz), 0), cells - 1);
+        return spread3((unsigned) cx) | (spread3((unsigned) cy) << 1) |
+               (spread3((unsigned) cz) << 2);
+    }
+};
+
+template <class KeyFn>
+__global__ void __launch_bounds__(kBlock) k_count(const float4 *pts, size_t n, KeyFn key,
+                                                   unsigned *cell_of, unsigned *counts) {
+    size_t i = (size_t) blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float4 p = pts[i];
+    unsigned c = kNoIdx;
+    if (p.x == p.x) {
+        c = key(p);
+        atomicAdd(&counts[c], 1u);
+    }
+    cell_of[i] = c;
+}
+
+__global__ void __launch_bounds__(kBlock) k_scatter(const float4 *pts, size_t n,
+                                                     const unsigned *cell_of,
+                                                     const unsigned *cell_start, unsigned *fill,
+                                                     float4 *out) {
+    size_t i = (size_t) blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    unsigned c = cell_of[i];
+    if (c == kNoIdx) return;
+    unsigned pos = cell_start[c] + atomicAdd(&fill[c], 1u);
+    out[pos] = pts[i];
+}
+
+// Within a cell the scatter order depends on atomic arrival; restore ascending
+// original index so that every downstream sum runs in a reproducible order.
+__global__ void __launch_bounds__(kBlock) k_sort_cells(const unsigned *cell_start, size_t ncells,
+                                                        float4 *pts) {
+    size_t c = (size_t) blockIdx.x * kBlock + threadIdx.x;
+    if (c >= ncells) return;
+    unsigned s = cell_start[c], e = cell_start[c + 1];
+    if (e - s < 2 || e - s > 128) return;  // huge cells: keep arrival order (rounding only)
+    for (unsigned i = s + 1; i < e; ++i) {  // insertion sort; cells hold a handful of points
+        float4 v = pts[i];
+        unsigned vi = __float_as_uint(v.w);
+        unsigned j = i;
+        while (j > s && __float_as_uint(pts[j - 1].w) > vi) {
+            pts[j] = pts[j - 1];
+            --j;
+        }
+        pts[j] = v;
+    }
+}
+
+// ------------------------------------------------------- exclusive scan
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kBlock * kScanItems;  // 2048
+
+__device__ inline unsigned block_exclusive_scan(unsigned v, unsigned *total, unsigned *lds) {
+    // wave-level inclusive scan
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    unsigned base = 0, tot = 0;
+    for (int w = 0; w < kBlock / 64; ++w) {
+        unsigned s = lds[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// pass 1: per-tile local exclusive scan (in place into out) + tile sums
+__global__ void __launch_bounds__(kBlock) k_scan_tiles(const unsigned *in, size_t n, unsigned *out,
+                                                        unsigned *tile_sums) {
+    __shared__ unsigned lds[kBlock / 64];
+    size_t base = (size_t) blockIdx.x * kScanTile + (size_t) threadIdx.x * kScanItems;
+    unsigned v[kScanItems], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0u;
+        sum += v[k];
+    }
+    unsigned total;
+    unsigned ex = block_exclusive_scan(sum, &total, lds);
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        if (base + k < n) out[base + k] = ex;
+        ex += v[k];
+    }
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+// pass 2: single block scans the tile sums (exclusive), carries across chunks
+__global__ void __launch_bounds__(kBlock) k_scan_sums(unsigned *tile_sums, size_t ntiles,
+                                                       unsigned *grand_total) {
+    __shared__ unsigned lds[kBlock / 64];
+    __shared__ unsigned carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (size_t c0 = 0; c0 < ntiles; c0 += kBlock) {
+        size_t i = c0 + threadIdx.x;
+        unsigned v = (i < ntiles) ? tile_sums[i] : 0u;
+        unsigned total;
+        unsigned ex = block_exclusive_scan(v, &total, lds);
+        unsigned carry = carry_s;
+        if (i < ntiles) tile_sums[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *grand_total = carry_s;
+}
+
+// pass 3: add tile offsets; also writes out[n] = grand total
+__global__ void __launch_bounds__(kBlock) k_scan_add(unsigned *out, size_t n,
+                                                      const unsigned *tile_sums,
+                                                      const unsigned *grand_total) {
+    size_t base = (size_t) blockIdx.x * kScanTile + (size_t) threadIdx.x * kScanItems;
+    unsigned add = tile_sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+        if (base + k < n) out[base + k] += add;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *grand_total;
+}
+
+// out must hold n+1 entries
+static int exclusive_scan(wm_ctx *ctx, const unsigned *in, size_t n, unsigned *out) {
+    size_t ntiles = (n + kScanTile - 1) / kScanTile;
+    WM_HIP(ctx, ctx->block_sums.reserve((ntiles + 2) * sizeof(unsigned)));
+    unsigned *sums = ctx->block_sums.as<unsigned>();
+    unsigned *grand = sums + ntiles;
+    hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned) ntiles), dim3(kBlock), 0, ctx->stream, in, n,
+                       out, sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, ctx->stream, sums, ntiles, grand);
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned) ntiles), dim3(kBlock), 0, ctx->stream, out, n,
+                       sums, grand);
+    WM_HIP(ctx, hipGetLastError());
+    return WM_OK;
+}
+
+template <class KeyFn>
+static int counting_sort(wm_ctx *ctx, const float4 *pts, size_t n, KeyFn key, size_t ncells,
+                         unsigned *cell_start /* ncells+1 */, float4 *out, bool sort_cells) {
+    WM_HIP(ctx, ctx->cell_of.reserve(n * sizeof(unsigned)));
+    WM_HIP(ctx, ctx->counts.reserve(ncells * sizeof(unsigned)));
+    unsigned *counts = ctx->counts.as<unsigned>();
+    unsigned *cell_of = ctx->cell_of.as<unsigned>();
+    WM_HIP(ctx, hipMemsetAsync(counts, 0, ncells * sizeof(unsigned), ctx->stream));
+    unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_count<KeyFn>), dim3(blocks), dim3(kBlock), 0, ctx->stream,
+                       pts, n, key, cell_of, counts);
+    WM_HIP(ctx, hipGetLastError());
+    WM_TRY(exclusive_scan(ctx, counts, ncells, cell_start));
+    WM_HIP(ctx, hipMemsetAsync(counts, 0, ncells * sizeof(unsigned), ctx->stream));
+    hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, n, cell_of,
+                       cell_start, counts, out);
+    WM_HIP(ctx, hipGetLastError());
+    if (sort_cells) {
+        unsigned cblocks = (unsigned) ((ncells + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_sort_cells, dim3(cblocks), dim3(kBlock), 0, ctx->stream, cell_start,
+                           ncells, out);
+        WM_HIP(ctx, hipGetLastError());
+    }
+    return WM_OK;
+}
+
+// occupied-cell count (for choosing the level-0 cell size)
+__global__ void __launch_bounds__(kBlock) k_count_occupied(const unsigned *cell_start,
+                                                            size_t ncells, unsigned *out) {
+    unsigned c = 0;
+    for (size_t i = (size_t) blockIdx.x * kBlock + threadIdx.x; i < ncells;
+         i += (size_t) gridDim.x * kBlock)
+        c += (cell_start[i + 1] != cell_start[i]);
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+static void grid_dims(const Bbox &bb, float h, int *nx, int *ny, int *nz) {
+    *nx = (int) floor((bb.hi[0] - bb.lo[0]) / h) + 1;
+    *ny = (int) floor((bb.hi[1] - bb.lo[1]) / h) + 1;
+    *nz = (int) floor((bb.hi[2] - bb.lo[2]) / h) + 1;
+}
+
+int build_grid_level(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, float h,
+                     GridLevel *lvl, double *avg_occupancy) {
+    int nx, ny, nz;
+    grid_dims(bb, h, &nx, &ny, &nz);
+    uint64_t ncells = (uint64_t) nx * ny * nz;
+    lvl->ncells = ncells;
+    WM_HIP(ctx, lvl->pts.reserve((n > 0 ? n : 1) * sizeof(float4)));
+    WM_HIP(ctx, lvl->cell_start.reserve((ncells + 1) * sizeof(unsigned)));
+    LinearKey key{bb.lo[0], bb.lo[1], bb.lo[2], 1.0f / h, nx, ny, nz};
+    if (n > 0) {
+        WM_TRY(counting_sort(ctx, pts, n, key, ncells, lvl->cell_start.as<unsigned>(),
+                             lvl->pts.as<float4>(), false));
+    } else {
+        WM_HIP(ctx, hipMemsetAsync(lvl->cell_start.p, 0, (ncells + 1) * sizeof(unsigned),
+                                   ctx->stream));
+    }
+    // float cell assignment can be off by the rounding of (p - origin) * inv_h:
+    // keep a cell-unit margin in every geometric bound that relies on it.
+    float extent = fmaxf(fmaxf(bb.hi[0] - bb.lo[0], bb.hi[1] - bb.lo[1]), bb.hi[2] - bb.lo[2]);
+    float amax = 0;
+    for (int d = 0; d < 3; ++d) amax = fmaxf(amax, fmaxf(fabsf(bb.lo[d]), fabsf(bb.hi[d])));
+    float ulp = fmaxf(amax, extent) * 1.2e-7f;
+    lvl->d.ox = bb.lo[0];
+    lvl->d.oy = bb.lo[1];
+    lvl->d.oz = bb.lo[2];
+    lvl->d.h = h;
+    lvl->d.inv_h = 1.0f / h;
+    lvl->d.slack = fmaxf(1e-3f, 8.0f * ulp / h);
+    lvl->d.nx = nx;
+    lvl->d.ny = ny;
+    lvl->d.nz = nz;
+    lvl->d.pts = lvl->pts.as<float4>();
+    lvl->d.cell_start = lvl->cell_start.as<unsigned>();
+    lvl->built = true;
+    if (avg_occupancy) {
+        unsigned zero = 0, occ = 0;
+        unsigned *d_occ = ctx->bbox_buf.as<unsigned>() + 7;
+        WM_HIP(ctx, hipMemcpyAsync(d_occ, &zero, 4, hipMemcpyHostToDevice, ctx->stream));
+        unsigned blocks = (unsigned) ((ncells + kBlock - 1) / kBlock);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_count_occupied, dim3(blocks), dim3(kBlock), 0, ctx->stream,
+                           lvl->cell_start.as<unsigned>(), (size_t) ncells, d_occ);
+        WM_HIP(ctx, hipMemcpyAsync(&occ, d_occ, 4, hipMemcpyDeviceToHost, ctx->stream));
+        WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        *avg_occupancy = occ ? (double) n / occ : 0.0;
+    }
+    return WM_OK;
+}
+
+int morton_sort(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, float4 *out,
+                size_t *n_valid) {
+    if (n == 0) {
+        *n_valid = 0;
+        return WM_OK;
+    }
+    int bits = (int) ceil(log2(cbrt((double) n)));
+    if (bits < 3) bits = 3;
+    if (bits > 8) bits = 8;
+    int cells = 1 << bits;
+    size_t ncells = (size_t) 1 << (3 * bits);
+    float ext[3];
+    for (int d = 0; d < 3; ++d) ext[d] = fmaxf(bb.hi[d] - bb.lo[d], 1e-6f);
+    MortonKey key{bb.lo[0], bb.lo[1], bb.lo[2], cells / ext[0], cells / ext[1], cells / ext[2],
+                  cells};
+    DevBuf &cs = ctx->corr_tmp_idx;  // scratch for the transient cell_start
+    WM_HIP(ctx, cs.reserve((ncells + 1) * sizeof(unsigned)));
+    WM_TRY(counting_sort(ctx, pts, n, key, ncells, cs.as<unsigned>(), out, true));
+    unsigned total = 0;
+    WM_HIP(ctx, hipMemcpyAsync(&total, cs.as<unsigned>() + ncells, 4, hipMemcpyDeviceToHost,
+                               ctx->stream));
+    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_valid = total;
+    return WM_OK;
+}
+
+// Level 0: cell size from the measured density (a few points per occupied cell).
+// Levels >= 1: cell size x4 per level until one ring of cells covers max_corr.
+static int build_level0(wm_ctx *ctx) {
+    const float4 *pts = ctx->tgt_orig.as<float4>();
+    const Bbox &bb = ctx->tgt_bbox;
+    const size_t n = ctx->n_tgt_input;
+    double ext[3], vol = 1;
+    for (int d = 0; d < 3; ++d) {
+        ext[d] = fmax((double) bb.hi[d] - bb.lo[d], 1e-3);
+        vol *= ext[d];
+    }
+    const uint64_t kMaxCells = 96ull << 20;
+    auto clamp_h = [&](double h) {
+        for (;;) {
+            int nx, ny, nz;
+            grid_dims(bb, (float) h, &nx, &ny, &nz);
+            if ((uint64_t) nx * ny * nz <= kMaxCells) return h;
+            h *= 1.26;
+        }
+    };
+    double h;
+    if (ctx->grid_cell_override > 0) {
+        h = clamp_h(ctx->grid_cell_override);
+        return build_grid_level(ctx, pts, n, bb, (float) h, &ctx->levels[0], nullptr);
+    }
+    const double target_occ = 3.0;
+    // first guess assumes points spread over surfaces: occupancy ~ h^2
+    h = clamp_h(fmax(cbrt(vol / fmax((double) ctx->n_tgt, 1.0)) * 1.5, 1e-4));
+    double occ = 0;
+    for (int it = 0; it < 3; ++it) {
+        WM_TRY(build_grid_level(ctx, pts, n, bb, (float) h, &ctx->levels[0], &occ));
+        if (occ <= 0) break;
+        if (occ > target_occ * 0.6 && occ < target_occ * 1.6) break;
+        double scale = sqrt(target_occ / occ);
+        if (scale > 4) scale = 4;
+        if (scale < 0.25) scale = 0.25;
+        double nh = clamp_h(h * scale);
+        if (fabs(nh - h) < 0.05 * h) break;
+        h = nh;
+    }
+    if (!ctx->levels[0].built || ctx->levels[0].d.h != (float) h)
+        WM_TRY(build_grid_level(ctx, pts, n, bb, (float) h, &ctx->levels[0], nullptr));
+    return WM_OK;
+}
+
+int ensure_levels(wm_ctx *ctx, double max_corr) {
+    if (!ctx->levels[0].built) {
+        WM_TRY(build_level0(ctx));
+        ctx->n_levels = 1;
+        ctx->levels_max_corr = -1;
+    }
+    if (ctx->levels_max_corr == max_corr) return WM_OK;
+    const float4 *pts = ctx->tgt_orig.as<float4>();
+    double h = ctx->levels[0].d.h;
+    int L = 1;
+    // one ring at the last level must cover max_corr (plus the float margin)
+    while (h * (1.0 - 2.0 * ctx->levels[L - 1].d.slack) < max_corr && L < kMaxLevels) {
+        const double need = max_corr * 1.02 / (1.0 - 2.0 * ctx->levels[L - 1].d.slack);
+        double nh = h * 4.0;
+        if (nh > need || L == kMaxLevels - 1) nh = fmax(need, h * 1.5);
+        WM_TRY(build_grid_level(ctx, pts, ctx->n_tgt_input, ctx->tgt_bbox, (float) nh,
+                                &ctx->levels[L], nullptr));
+        h = nh;
+        ++L;
+    }
+    ctx->n_levels = L;
+    ctx->levels_max_corr = max_corr;
+    return WM_OK;
+}
+
+}  // namespace wm

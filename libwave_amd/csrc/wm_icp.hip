@@ -1,0 +1,654 @@
+// wm_icp.hip -- the ICP iteration on device + the C ABI entry points.
+//
+// One iteration of pcl::IterativeClosestPoint::computeTransformation
+// [PCL registration/impl/icp.hpp], as driven by libwave's ICPMatcher::match()
+// (wave_matching/src/icp.cpp:95,116,126), is three kernel classes:
+//   1. correspondence search (wm_nn.hip)                 -> 8-byte key per source point
+//   2. k_icp_stats: streaming reduction of the matched pairs to 17 doubles
+//      per workgroup (n, sum p, sum q, sum q p^T, sum d2  |  GN: n, sum p,
+//      A^T A, J^T r, sum d2)
+//   3. k_reduce_solve: fixed-order sum of the partials, the 3x3 SVD (Umeyama) or
+//      6x6 solve (Gauss-Newton), T <- T_k T, and PCL's DefaultConvergenceCriteria,
+//      all by one workgroup, so the whole registration runs with the host out of
+//      the loop.  In the multi-GPU path the 32-double statistics block is what
+//      the RCCL all-reduce carries between (2) and (3).
+#include "wm_internal.hpp"
+
+#include <float.h>
+#include <math.h>
+#include <string.h>
+
+#include <new>
+
+namespace wm {
+
+constexpr int kAcc = 17;
+constexpr int kMaxStatBlocks = 1024;
+
+__device__ __forceinline__ void xform_pt(const float *T, const float4 &p, float &x, float &y,
+                                         float &z) {
+    x = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[0], p.x), __fmul_rn(T[1], p.y)),
+                            __fmul_rn(T[2], p.z)), T[3]);
+    y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[4], p.x), __fmul_rn(T[5], p.y)),
+                            __fmul_rn(T[6], p.z)), T[7]);
+    z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[8], p.x), __fmul_rn(T[9], p.y)),
+                            __fmul_rn(T[10], p.z)), T[11]);
+}
+
+// Per-workgroup partial sums, written as partials[block][kAcc].
+template <int MODE>
+__global__ void __launch_bounds__(kBlock)
+    k_icp_stats(const float4 *__restrict__ src, unsigned n,
+                const unsigned long long *__restrict__ keys, const float4 *__restrict__ tgt,
+                const IcpDevState *__restrict__ st, double *__restrict__ partials) {
+    if (st->done) return;
+    double a[kAcc];
+#pragma unroll
+    for (int k = 0; k < kAcc; ++k) a[k] = 0.0;
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const unsigned long long key = keys[i];
+        const unsigned idx = (unsigned) key;
+        if (idx == kNoIdx) continue;
+        const float4 p4 = src[i];
+        float fx, fy, fz;
+        xform_pt(st->Tf, p4, fx, fy, fz);
+        const float4 q4 = tgt[idx];
+        const double px = fx, py = fy, pz = fz, qx = q4.x, qy = q4.y, qz = q4.z;
+        const double d2 = (double) __uint_as_float((unsigned) (key >> 32));
+        a[0] += 1.0;
+        a[1] += px;
+        a[2] += py;
+        a[3] += pz;
+        if (MODE == WM_ICP_SVD) {
+            a[4] += qx;
+            a[5] += qy;
+            a[6] += qz;
+            a[7] += qx * px;
+            a[8] += qx * py;
+            a[9] += qx * pz;
+            a[10] += qy * px;
+            a[11] += qy * py;
+            a[12] += qy * pz;
+            a[13] += qz * px;
+            a[14] += qz * py;
+            a[15] += qz * pz;
+        } else {
+            const double rx = px - qx, ry = py - qy, rz = pz - qz;
+            a[4] += py * py + pz * pz;  // (A^T A)(0,0)
+            a[5] += -px * py;           // (0,1)
+            a[6] += -px * pz;           // (0,2)
+            a[7] += px * px + pz * pz;  // (1,1)
+            a[8] += -py * pz;           // (1,2)
+            a[9] += px * px + py * py;  // (2,2)
+            a[10] += rx;
+            a[11] += ry;
+            a[12] += rz;
+            a[13] += py * rz - pz * ry;  // p x r
+            a[14] += pz * rx - px * rz;
+            a[15] += px * ry - py * rx;
+        }
+        a[16] += d2;
+    }
+    // wave reduction (fixed xor-tree order), then across the 4 waves through LDS
+#pragma unroll
+    for (int k = 0; k < kAcc; ++k)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a[k] += __shfl_down(a[k], off);
+    __shared__ double lds[kBlock / 64][kAcc];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < kAcc; ++k) lds[wave][k] = a[k];
+    __syncthreads();
+    if (threadIdx.x < kAcc) {
+        double s = 0;
+        for (int w = 0; w < kBlock / 64; ++w) s += lds[w][threadIdx.x];
+        partials[(size_t) blockIdx.x * kAcc + threadIdx.x] = s;
+    }
+}
+
+// expand the 17 compact accumulators to the public 32-slot layout
+__device__ __host__ inline void expand_stats(int mode, const double *a, double *st) {
+    for (int k = 0; k < kStatsLen; ++k) st[k] = 0.0;
+    if (mode == WM_ICP_SVD) {
+        st[kSvdN] = a[0];
+        for (int k = 0; k < 3; ++k) st[kSvdSp + k] = a[1 + k];
+        for (int k = 0; k < 3; ++k) st[kSvdSq + k] = a[4 + k];
+        for (int k = 0; k < 9; ++k) st[kSvdSqp + k] = a[7 + k];
+        st[kSvdSd2] = a[16];
+    } else {
+        const double n = a[0], sx = a[1], sy = a[2], sz = a[3];
+        double H[36];
+        for (int k = 0; k < 36; ++k) H[k] = 0;
+        H[0] = H[7] = H[14] = n;
+        H[0 * 6 + 4] = sz;
+        H[0 * 6 + 5] = -sy;
+        H[1 * 6 + 3] = -sz;
+        H[1 * 6 + 5] = sx;
+        H[2 * 6 + 3] = sy;
+        H[2 * 6 + 4] = -sx;
+        H[3 * 6 + 3] = a[4];
+        H[3 * 6 + 4] = a[5];
+        H[3 * 6 + 5] = a[6];
+        H[4 * 6 + 4] = a[7];
+        H[4 * 6 + 5] = a[8];
+        H[5 * 6 + 5] = a[9];
+        st[kGnN] = n;
+        st[kGnSd2] = a[16];
+        int k = 0;
+        for (int i = 0; i < 6; ++i)
+            for (int j = i; j < 6; ++j) st[kGnH + k++] = H[i * 6 + j];
+        for (int i = 0; i < 6; ++i) st[kGnG + i] = a[10 + i];
+    }
+}
+
+// PHASE 1: sum partials -> st->stats.   PHASE 2: solve + criteria from st->stats.
+// Single GPU launches <1|2>; the sharded path launches <1>, all-reduces
+// st->stats over RCCL, then launches <2>.
+template <int PHASES>
+__global__ void __launch_bounds__(kBlock)
+    k_reduce_solve(const double *__restrict__ partials, int nblocks, IcpDevState *st) {
+    if (st->done) return;
+    __shared__ double lds[kBlock / 32][32];
+    if (PHASES & 1) {
+        const int c = threadIdx.x & 31, slice = threadIdx.x >> 5;  // 8 slices x 32 comps
+        double s = 0;
+        if (c < kAcc)
+            for (int b = slice; b < nblocks; b += kBlock / 32) s += partials[(size_t) b * kAcc + c];
+        lds[slice][c] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a[kAcc];
+            for (int k = 0; k < kAcc; ++k) {
+                double t = 0;
+                for (int sl = 0; sl < kBlock / 32; ++sl) t += lds[sl][k];
+                a[k] = t;
+            }
+            expand_stats(st->mode, a, st->stats);
+        }
+    }
+    if (!(PHASES & 2)) return;
+    if (threadIdx.x != 0) return;
+
+    const double n = st->stats[0];
+    const double sd2 = st->mode == WM_ICP_SVD ? st->stats[kSvdSd2] : st->stats[kGnSd2];
+    const double mse = n > 0 ? sd2 / n : 0.0;
+    st->n_corr = (int) n;
+    st->mse = mse;
+    // bookkeeping for the next iteration's queues
+    st->deferred_total += st->queue_count[1];
+    for (int l = 0; l <= kMaxLevels; ++l) st->queue_count[l] = 0;
+    if (n < 3.0) {  // PCL: min_number_correspondences_ = 3
+        st->state = WM_CONV_NO_CORRESPONDENCES;
+        st->converged = 0;
+        st->done = 1;
+        return;
+    }
+    double Tk[16];
+    if (st->mode == WM_ICP_SVD)
+        umeyama_from_stats(st->stats, Tk);
+    else
+        gn6_from_stats(st->stats, Tk);
+    double Tn[16];
+    mat4_mul(Tk, st->T, Tn);
+    for (int k = 0; k < 16; ++k) {
+        st->T[k] = Tn[k];
+        st->Tk[k] = Tk[k];
+    }
+    for (int k = 0; k < 12; ++k) st->Tf[k] = (float) Tn[k];
+    const int iter = ++st->iter;
+
+    // pcl::registration::DefaultConvergenceCriteria::hasConverged()
+    if (st->forced) {
+        if (iter >= st->max_iter) {
+            st->converged = 1;
+            st->state = WM_CONV_FORCED;
+            st->done = 1;
+        }
+        st->prev_mse = mse;
+        return;
+    }
+    if (iter >= st->max_iter) {
+        st->converged = 1;
+        st->state = WM_CONV_ITERATIONS;
+        st->done = 1;
+        return;
+    }
+    const double cos_angle = 0.5 * (Tk[0] + Tk[5] + Tk[10] - 1.0);
+    const double tsq = Tk[3] * Tk[3] + Tk[7] * Tk[7] + Tk[11] * Tk[11];
+    if (cos_angle >= st->rot_thr && tsq <= st->trans_thr) {
+        st->converged = 1;
+        st->state = WM_CONV_TRANSFORM;
+        st->done = 1;
+        return;
+    }
+    if (fabs(mse - st->prev_mse) < 1e-12) {
+        st->converged = 1;
+        st->state = WM_CONV_ABS_MSE;
+        st->done = 1;
+        return;
+    }
+    if (fabs(mse - st->prev_mse) / st->prev_mse < st->fit_eps) {
+        st->converged = 1;
+        st->state = WM_CONV_REL_MSE;
+        st->done = 1;
+        return;
+    }
+    st->prev_mse = mse;
+}
+
+// keys (source-sorted order) -> caller-order (match index, d2)
+__global__ void __launch_bounds__(kBlock)
+    k_unpack_corr(const float4 *__restrict__ src, unsigned n,
+                  const unsigned long long *__restrict__ keys, int *__restrict__ match,
+                  float *__restrict__ d2) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const unsigned orig = __float_as_uint(src[i].w);
+    const unsigned long long key = keys[i];
+    const unsigned idx = (unsigned) key;
+    match[orig] = idx == kNoIdx ? -1 : (int) idx;
+    d2[orig] = __uint_as_float((unsigned) (key >> 32));
+}
+
+// ------------------------------------------------------------------ host
+static int stat_blocks(size_t n) {
+    size_t b = (n + kBlock - 1) / kBlock;
+    if (b > kMaxStatBlocks) b = kMaxStatBlocks;
+    if (b < 1) b = 1;
+    return (int) b;
+}
+
+static int launch_stats(wm_ctx *ctx, int mode) {
+    const unsigned n = (unsigned) ctx->n_src;
+    const int nb = stat_blocks(n);
+    const IcpDevState *st = ctx->d_state.as<IcpDevState>();
+    if (mode == WM_ICP_SVD)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_stats<WM_ICP_SVD>), dim3(nb), dim3(kBlock), 0,
+                           ctx->stream, ctx->src_sorted.as<float4>(), n,
+                           ctx->keys.as<unsigned long long>(), ctx->tgt_orig.as<float4>(), st,
+                           ctx->partials.as<double>());
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_stats<WM_ICP_GN6>), dim3(nb), dim3(kBlock), 0,
+                           ctx->stream, ctx->src_sorted.as<float4>(), n,
+                           ctx->keys.as<unsigned long long>(), ctx->tgt_orig.as<float4>(), st,
+                           ctx->partials.as<double>());
+    WM_HIP(ctx, hipGetLastError());
+    return WM_OK;
+}
+
+static int prepare_work(wm_ctx *ctx) {
+    const size_t n = ctx->n_src > 0 ? ctx->n_src : 1;
+    WM_HIP(ctx, ctx->keys.reserve(n * sizeof(unsigned long long)));
+    WM_HIP(ctx, ctx->queue_a.reserve(n * sizeof(unsigned)));
+    WM_HIP(ctx, ctx->queue_b.reserve(n * sizeof(unsigned)));
+    WM_HIP(ctx, ctx->partials.reserve((size_t) kMaxStatBlocks * kAcc * sizeof(double)));
+    WM_HIP(ctx, ctx->d_state.reserve(sizeof(IcpDevState)));
+    if (!ctx->h_state)
+        WM_HIP(ctx, hipHostMalloc((void **) &ctx->h_state, sizeof(IcpDevState), hipHostMallocDefault));
+    return WM_OK;
+}
+
+static void init_state(IcpDevState *s, const double *T, const wm_icp_params *p, double prev_mse) {
+    memset(s, 0, sizeof(*s));
+    for (int k = 0; k < 16; ++k) s->T[k] = T[k];
+    for (int k = 0; k < 12; ++k) s->Tf[k] = (float) T[k];
+    mat4_identity(s->Tk);
+    s->prev_mse = prev_mse;
+    if (p) {
+        s->forced = p->force_iterations > 0;
+        s->max_iter = s->forced ? p->force_iterations : p->max_iter;
+        s->mode = p->mode;
+        s->rot_thr = 1.0 - p->t_eps;
+        s->trans_thr = p->t_eps;
+        s->fit_eps = p->fit_eps;
+    }
+}
+
+static int upload_state(wm_ctx *ctx) {
+    WM_HIP(ctx, hipMemcpyAsync(ctx->d_state.p, ctx->h_state, sizeof(IcpDevState),
+                               hipMemcpyHostToDevice, ctx->stream));
+    return WM_OK;
+}
+
+static int download_state(wm_ctx *ctx) {
+    WM_HIP(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state.p, sizeof(IcpDevState),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WM_OK;
+}
+
+static bool use_brute(const wm_ctx *ctx, int nn_method) {
+    if (nn_method == WM_NN_BRUTE) return true;
+    if (nn_method == WM_NN_GRID) return false;
+    // all-pairs is cheaper than indexing below ~4M pair tests
+    return (double) ctx->n_src * (double) ctx->n_tgt_input <= 4.0e6;
+}
+
+static hipEvent_t get_event(wm_ctx *ctx, size_t k) {
+    while (ctx->ev_pool.size() <= k) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        ctx->ev_pool.push_back(e);
+    }
+    return ctx->ev_pool[k];
+}
+
+}  // namespace wm
+
+using namespace wm;
+
+// =============================================================== C ABI
+extern "C" {
+
+const char *wm_version(void) { return "wavematch-hip 0.1 (gfx950, HIP)"; }
+
+const char *wm_strerror(int s) {
+    switch (s) {
+        case WM_OK: return "ok";
+        case WM_NOT_CONVERGED: return "registration did not converge";
+        case WM_TOO_FEW_CORRESPONDENCES: return "not enough correspondences";
+        case WM_ERR_ARG: return "invalid argument";
+        case WM_ERR_HIP: return "HIP runtime error (see wm_last_error)";
+        case WM_ERR_RCCL: return "RCCL error (see wm_last_error)";
+        case WM_ERR_STATE: return "call sequence error (missing source/target cloud)";
+        case WM_ERR_NOMEM: return "out of memory";
+        default: return "unknown status";
+    }
+}
+
+const char *wm_last_error(const wm_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int wm_ctx_create(wm_ctx **out, int device) {
+    if (!out) return WM_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return WM_ERR_HIP;
+    wm_ctx *ctx = new (std::nothrow) wm_ctx();
+    if (!ctx) return WM_ERR_NOMEM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev_a) != hipSuccess || hipEventCreate(&ctx->ev_b) != hipSuccess) {
+        delete ctx;
+        return WM_ERR_HIP;
+    }
+    *out = ctx;
+    return WM_OK;
+}
+
+void wm_ctx_destroy(wm_ctx *ctx) {
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->src_sorted, &ctx->tgt_orig, &ctx->staging, &ctx->cell_of, &ctx->counts,
+                      &ctx->block_sums, &ctx->bbox_buf, &ctx->keys, &ctx->queue_a, &ctx->queue_b,
+                      &ctx->partials, &ctx->corr_tmp_idx, &ctx->corr_tmp_d2, &ctx->d_state};
+    for (DevBuf *b : bufs) b->release();
+    for (auto &l : ctx->levels) {
+        l.pts.release();
+        l.cell_start.release();
+    }
+    if (ctx->h_state) (void) hipHostFree(ctx->h_state);
+    for (hipEvent_t e : ctx->ev_pool) (void) hipEventDestroy(e);
+    if (ctx->ev_a) (void) hipEventDestroy(ctx->ev_a);
+    if (ctx->ev_b) (void) hipEventDestroy(ctx->ev_b);
+    if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int wm_set_grid_cell(wm_ctx *ctx, float grid_cell) {
+    if (!ctx || !(grid_cell >= 0)) return WM_ERR_ARG;
+    ctx->grid_cell_override = grid_cell;
+    for (auto &l : ctx->levels) l.built = false;
+    ctx->n_levels = 0;
+    ctx->levels_max_corr = -1;
+    return WM_OK;
+}
+
+int wm_cloud_sizes(const wm_ctx *ctx, size_t *n_source, size_t *n_target) {
+    if (!ctx) return WM_ERR_ARG;
+    if (n_source) *n_source = ctx->n_src;
+    if (n_target) *n_target = ctx->n_tgt;
+    return WM_OK;
+}
+
+int wm_set_source(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem) {
+    if (!ctx || (n > 0 && !pts) || stride < 12 || (stride & 3) || n > 0x7FFFFFF0u) return WM_ERR_ARG;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->have_corr = false;
+    ctx->n_src_input = n;
+    ctx->n_src = 0;
+    if (n == 0) return WM_OK;
+    // pack into scratch, then Morton-order into src_sorted
+    DevBuf &tmp = ctx->corr_tmp_d2;
+    WM_HIP(ctx, tmp.reserve(n * sizeof(float4)));
+    WM_HIP(ctx, ctx->src_sorted.reserve(n * sizeof(float4)));
+    WM_TRY(pack_cloud(ctx, pts, n, stride, mem, tmp.as<float4>()));
+    Bbox bb;
+    size_t valid = 0;
+    WM_TRY(compute_bbox(ctx, tmp.as<float4>(), n, &bb, &valid));
+    size_t sorted = 0;
+    WM_TRY(morton_sort(ctx, tmp.as<float4>(), n, bb, ctx->src_sorted.as<float4>(), &sorted));
+    ctx->n_src = sorted;
+    return WM_OK;
+}
+
+int wm_set_target(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem) {
+    if (!ctx || (n > 0 && !pts) || stride < 12 || (stride & 3) || n > 0x7FFFFFF0u) return WM_ERR_ARG;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->have_corr = false;
+    ctx->n_tgt_input = n;
+    ctx->n_tgt = 0;
+    for (auto &l : ctx->levels) l.built = false;
+    ctx->n_levels = 0;
+    ctx->levels_max_corr = -1;
+    if (n == 0) return WM_OK;
+    WM_HIP(ctx, ctx->tgt_orig.reserve(n * sizeof(float4)));
+    WM_TRY(pack_cloud(ctx, pts, n, stride, mem, ctx->tgt_orig.as<float4>()));
+    size_t valid = 0;
+    WM_TRY(compute_bbox(ctx, ctx->tgt_orig.as<float4>(), n, &ctx->tgt_bbox, &valid));
+    ctx->n_tgt = valid;
+    if (valid > 0) WM_TRY(ensure_levels(ctx, -1.0));  // level 0 now; coarser levels at align
+    return WM_OK;
+}
+
+void wm_icp_default_params(wm_icp_params *p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->max_corr = 3;    // icp.hpp:35
+    p->max_iter = 100;  // icp.hpp:37
+    p->t_eps = 1e-8;    // icp.hpp:41
+    p->fit_eps = 1e-2;  // icp.hpp:43
+    p->mode = WM_ICP_SVD;
+    p->nn_method = WM_NN_AUTO;
+    p->carry_state = 1;
+}
+
+int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_stats *stats) {
+    if (!ctx || !p || !T_out) return WM_ERR_ARG;
+    if (!(p->max_corr > 0) || (p->mode != WM_ICP_SVD && p->mode != WM_ICP_GN6)) return WM_ERR_ARG;
+    if (p->force_iterations <= 0 && p->max_iter <= 0) return WM_ERR_ARG;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (ctx->n_src_input == 0 || ctx->n_tgt_input == 0) {
+        // PCL: empty input -> "Not enough correspondences"; match() returns false
+        if (stats) stats->state = WM_CONV_NO_CORRESPONDENCES;
+        return ctx->n_tgt_input == 0 && ctx->n_src_input == 0 ? WM_ERR_STATE
+                                                               : WM_TOO_FEW_CORRESPONDENCES;
+    }
+    if (ctx->n_src == 0 || ctx->n_tgt == 0) {
+        if (stats) stats->state = WM_CONV_NO_CORRESPONDENCES;
+        return WM_TOO_FEW_CORRESPONDENCES;
+    }
+    WM_TRY(prepare_work(ctx));
+    const bool brute = use_brute(ctx, p->nn_method);
+    if (!brute) WM_TRY(ensure_levels(ctx, p->max_corr));
+    const float thr = threshold_d2(p->max_corr);
+    double I[16];
+    mat4_identity(I);
+    const double prev = (p->carry_state && ctx->prev_mse >= 0) ? ctx->prev_mse : DBL_MAX;
+    init_state(ctx->h_state, I, p, prev);
+    WM_TRY(upload_state(ctx));
+
+    const int max_it = p->force_iterations > 0 ? p->force_iterations : p->max_iter;
+    const int nb = stat_blocks(ctx->n_src);
+    IcpDevState *dst = ctx->d_state.as<IcpDevState>();
+    WM_HIP(ctx, hipEventRecord(ctx->ev_a, ctx->stream));
+    int launched = 0;
+    size_t ev_used = 0;
+    while (launched < max_it) {
+        const int batch = p->force_iterations > 0 ? max_it : ((max_it - launched) < 8 ? (max_it - launched) : 8);
+        for (int b = 0; b < batch; ++b) {
+            hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+            if (p->profile) {
+                e0 = get_event(ctx, ev_used++);
+                e1 = get_event(ctx, ev_used++);
+                e2 = get_event(ctx, ev_used++);
+                e3 = get_event(ctx, ev_used++);
+            }
+            if (brute)
+                WM_TRY(launch_nn_brute(ctx, thr, e0, e1));
+            else
+                WM_TRY(launch_nn_grid(ctx, thr, e0, e1));
+            WM_TRY(launch_stats(ctx, p->mode));
+            if (e2) WM_HIP(ctx, hipEventRecord(e2, ctx->stream));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<3>), dim3(1), dim3(kBlock), 0,
+                               ctx->stream, ctx->partials.as<double>(), nb, dst);
+            if (e3) WM_HIP(ctx, hipEventRecord(e3, ctx->stream));
+        }
+        WM_HIP(ctx, hipGetLastError());
+        launched += batch;
+        WM_TRY(download_state(ctx));
+        if (ctx->h_state->done) break;
+    }
+    WM_HIP(ctx, hipEventRecord(ctx->ev_b, ctx->stream));
+    WM_HIP(ctx, hipEventSynchronize(ctx->ev_b));
+    const IcpDevState &s = *ctx->h_state;
+    ctx->prev_mse = s.prev_mse;
+    ctx->have_corr = true;
+    memcpy(ctx->corr_T, s.T, sizeof(s.T));
+    if (stats) {
+        stats->converged = s.converged;
+        stats->iterations = s.iter;
+        stats->state = s.state;
+        stats->n_corr = s.n_corr;
+        stats->mse = s.mse;
+        stats->prev_mse = s.prev_mse;
+        stats->nn_levels = brute ? 0 : ctx->n_levels;
+        stats->grid_cell = brute ? 0.f : ctx->levels[0].d.h;
+        stats->deferred = s.deferred_total;
+        (void) hipEventElapsedTime(&stats->align_ms, ctx->ev_a, ctx->ev_b);
+        if (p->profile) {
+            // iterations that ran (the rest of the last batch were no-ops)
+            const int ran = s.iter + (s.state == WM_CONV_NO_CORRESPONDENCES ? 1 : 0);
+            for (int it = 0; it < ran && (size_t) (4 * it + 3) < ev_used; ++it) {
+                float a = 0, b = 0, c = 0;
+                (void) hipEventElapsedTime(&a, ctx->ev_pool[4 * it], ctx->ev_pool[4 * it + 1]);
+                (void) hipEventElapsedTime(&b, ctx->ev_pool[4 * it + 1], ctx->ev_pool[4 * it + 2]);
+                (void) hipEventElapsedTime(&c, ctx->ev_pool[4 * it + 2], ctx->ev_pool[4 * it + 3]);
+                stats->nn_ms += a;
+                stats->stats_ms += b;
+                stats->solve_ms += c;
+                stats->nn_launches += 1;
+            }
+        }
+    }
+    if (s.state == WM_CONV_NO_CORRESPONDENCES) return WM_TOO_FEW_CORRESPONDENCES;
+    if (!s.converged) return WM_NOT_CONVERGED;
+    memcpy(T_out, s.T, sizeof(s.T));
+    return WM_OK;
+}
+
+static int unpack_correspondences(wm_ctx *ctx, int32_t *match_idx, float *d2, size_t cap) {
+    const size_t n_in = ctx->n_src_input;
+    if (cap < n_in) return WM_ERR_ARG;
+    if (n_in == 0) return WM_OK;
+    WM_HIP(ctx, ctx->corr_tmp_idx.reserve(n_in * sizeof(int)));
+    WM_HIP(ctx, ctx->corr_tmp_d2.reserve(n_in * sizeof(float)));
+    // dropped (non-finite) source points keep "no match"
+    WM_HIP(ctx, hipMemsetAsync(ctx->corr_tmp_idx.p, 0xFF, n_in * sizeof(int), ctx->stream));
+    WM_HIP(ctx, hipMemsetAsync(ctx->corr_tmp_d2.p, 0, n_in * sizeof(float), ctx->stream));
+    const unsigned n = (unsigned) ctx->n_src;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_unpack_corr, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                           ctx->stream, ctx->src_sorted.as<float4>(), n,
+                           ctx->keys.as<unsigned long long>(), ctx->corr_tmp_idx.as<int>(),
+                           ctx->corr_tmp_d2.as<float>());
+        WM_HIP(ctx, hipGetLastError());
+    }
+    if (match_idx)
+        WM_HIP(ctx, hipMemcpyAsync(match_idx, ctx->corr_tmp_idx.p, n_in * sizeof(int),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    if (d2)
+        WM_HIP(ctx, hipMemcpyAsync(d2, ctx->corr_tmp_d2.p, n_in * sizeof(float),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WM_OK;
+}
+
+int wm_get_correspondences(wm_ctx *ctx, int32_t *match_idx, float *d2, size_t cap) {
+    if (!ctx) return WM_ERR_ARG;
+    if (!ctx->have_corr) return WM_ERR_STATE;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    return unpack_correspondences(ctx, match_idx, d2, cap);
+}
+
+int wm_nn_search(wm_ctx *ctx, const double T[16], double max_corr, int nn_method,
+                 int32_t *match_idx, float *d2, size_t cap, float *kernel_ms) {
+    if (!ctx || !T || !(max_corr > 0)) return WM_ERR_ARG;
+    if (ctx->n_src_input == 0 || ctx->n_tgt_input == 0) return WM_ERR_STATE;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_TRY(prepare_work(ctx));
+    const bool brute = use_brute(ctx, nn_method) || ctx->n_tgt == 0;
+    if (!brute) WM_TRY(ensure_levels(ctx, max_corr));
+    init_state(ctx->h_state, T, nullptr, DBL_MAX);
+    WM_TRY(upload_state(ctx));
+    const float thr = threshold_d2(max_corr);
+    hipEvent_t e0 = kernel_ms ? ctx->ev_a : nullptr, e1 = kernel_ms ? ctx->ev_b : nullptr;
+    if (brute)
+        WM_TRY(launch_nn_brute(ctx, thr, e0, e1));
+    else
+        WM_TRY(launch_nn_grid(ctx, thr, e0, e1));
+    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (kernel_ms) (void) hipEventElapsedTime(kernel_ms, ctx->ev_a, ctx->ev_b);
+    ctx->have_corr = true;
+    memcpy(ctx->corr_T, T, sizeof(double) * 16);
+    if (match_idx || d2) return unpack_correspondences(ctx, match_idx, d2, cap);
+    return WM_OK;
+}
+
+int wm_icp_stats_for(wm_ctx *ctx, const double T[16], int mode, double stats[WM_STATS_LEN]) {
+    if (!ctx || !T || !stats || (mode != WM_ICP_SVD && mode != WM_ICP_GN6)) return WM_ERR_ARG;
+    if (!ctx->have_corr) return WM_ERR_STATE;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_TRY(prepare_work(ctx));
+    wm_icp_params p;
+    wm_icp_default_params(&p);
+    p.mode = mode;
+    init_state(ctx->h_state, T, &p, DBL_MAX);
+    WM_TRY(upload_state(ctx));
+    WM_TRY(launch_stats(ctx, mode));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<1>), dim3(1), dim3(kBlock), 0, ctx->stream,
+                       ctx->partials.as<double>(), stat_blocks(ctx->n_src),
+                       ctx->d_state.as<IcpDevState>());
+    WM_HIP(ctx, hipGetLastError());
+    WM_TRY(download_state(ctx));
+    memcpy(stats, ctx->h_state->stats, sizeof(double) * WM_STATS_LEN);
+    return WM_OK;
+}
+
+int wm_umeyama_from_stats(const double stats[WM_STATS_LEN], double Tk_out[16]) {
+    if (!stats || !Tk_out) return WM_ERR_ARG;
+    if (!(stats[0] >= 3.0)) return WM_TOO_FEW_CORRESPONDENCES;
+    umeyama_from_stats(stats, Tk_out);
+    return WM_OK;
+}
+
+int wm_gn6_from_stats(const double stats[WM_STATS_LEN], double Tk_out[16]) {
+    if (!stats || !Tk_out) return WM_ERR_ARG;
+    if (!(stats[0] >= 3.0)) return WM_TOO_FEW_CORRESPONDENCES;
+    return gn6_from_stats(stats, Tk_out) ? WM_OK : WM_NOT_CONVERGED;
+}
+
+}  // extern "C"

@@ -1,0 +1,154 @@
+// wm_internal.hpp -- context, device-side structs and helpers shared by the
+// HIP translation units of libwavematch_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/wavematch.h"
+#include "wm_math.hpp"
+
+namespace wm {
+
+constexpr int kMaxLevels = 6;
+constexpr int kBlock = 256;
+constexpr unsigned kNoIdx = 0xFFFFFFFFu;
+
+// ----------------------------------------------------------- error handling
+#define WM_HIP(ctx, call)                                                              \
+    do {                                                                               \
+        hipError_t _e = (call);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(_e);     \
+            return WM_ERR_HIP;                                                         \
+        }                                                                              \
+    } while (0)
+
+#define WM_TRY(expr)                \
+    do {                            \
+        int _s = (expr);            \
+        if (_s != WM_OK) return _s; \
+    } while (0)
+
+// ----------------------------------------------------------- device buffers
+// Growable device allocation cached on the context (hipMalloc is far too slow
+// to sit inside match()).
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void) hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void) hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T *as() const {
+        return reinterpret_cast<T *>(p);
+    }
+};
+
+// ------------------------------------------------------------ uniform grid
+// One level of the target index: points cell-sorted (x fastest) in HBM, so the
+// three x-adjacent cells of a query's neighbourhood are ONE contiguous run.
+struct GridDev {
+    float ox, oy, oz;  // origin (min corner)
+    float h, inv_h;    // cell size
+    float slack;       // cell-unit safety margin for float cell assignment
+    int nx, ny, nz;
+    const float4 *pts;          // cell-sorted, .w = original index bits
+    const uint32_t *cell_start; // nx*ny*nz + 1
+};
+
+struct GridLevel {
+    GridDev d{};
+    DevBuf pts, cell_start;
+    uint64_t ncells = 0;
+    bool built = false;
+};
+
+// ----------------------------------------------------- ICP state in HBM
+// Lives in device memory so that a whole registration runs without the host
+// in the loop; mirrored to pinned host memory when the host needs to look.
+struct IcpDevState {
+    double T[16];   // cumulative source->target
+    float Tf[12];   // float rows 0..2 of T (what the correspondence kernel applies)
+    double Tk[16];  // last incremental step
+    double stats[kStatsLen];
+    double mse, prev_mse;
+    int iter, done, converged, state, n_corr, max_iter, forced, mode;
+    double rot_thr, trans_thr, fit_eps;
+    unsigned queue_count[kMaxLevels + 1];
+    unsigned long long deferred_total;
+};
+
+struct Bbox {
+    float lo[3], hi[3];
+};
+
+}  // namespace wm
+
+// The opaque C handle.
+struct wm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+
+    // source (wave `ref`): Morton-ordered float4, .w = caller's index
+    size_t n_src = 0, n_src_input = 0;
+    wm::DevBuf src_sorted;
+
+    // target (wave `target`)
+    size_t n_tgt = 0, n_tgt_input = 0;
+    wm::DevBuf tgt_orig;  // float4 in caller order, .w = index; non-finite -> NaN
+    wm::Bbox tgt_bbox{};
+    wm::GridLevel levels[wm::kMaxLevels];
+    int n_levels = 0;
+    double levels_max_corr = -1;
+    float grid_cell_override = 0;
+
+    // scratch
+    wm::DevBuf staging, cell_of, counts, block_sums, bbox_buf;
+    wm::DevBuf keys, queue_a, queue_b, partials, corr_tmp_idx, corr_tmp_d2;
+    wm::DevBuf d_state;
+    wm::IcpDevState *h_state = nullptr;  // pinned
+    bool have_corr = false;
+    double corr_T[16];
+
+    // carried PCL object state
+    double prev_mse = -1;
+
+    // events for profile mode
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+};
+
+namespace wm {
+
+// ---- wm_grid.hip
+int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, float4 *out);
+int compute_bbox(wm_ctx *ctx, const float4 *pts, size_t n, Bbox *out, size_t *n_valid);
+int build_grid_level(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, float h,
+                     GridLevel *lvl, double *avg_occupancy);
+int morton_sort(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, float4 *out,
+                size_t *n_valid);
+int ensure_levels(wm_ctx *ctx, double max_corr);
+
+// ---- wm_nn.hip
+int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1);
+int launch_nn_brute(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1);
+float threshold_d2(double max_corr);
+
+}  // namespace wm
