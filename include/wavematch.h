@@ -99,7 +99,8 @@ typedef struct {
     int nn_method;        /* WM_NN_AUTO | WM_NN_GRID | WM_NN_BRUTE */
     int carry_state;      /* 1: seed the criteria's previous MSE from the ctx (PCL keeps
                              it across align() calls on one object); 0: fresh */
-    int profile;          /* 1: time each kernel class with HIP events (slower loop) */
+    int profile;          /* HIP-event timing on the ctx stream: 1 = the level-0
+                             correspondence kernel only; 2 = every kernel class */
     int reserved;
 } wm_icp_params;
 
@@ -112,7 +113,8 @@ typedef struct {
     double prev_mse;
     /* measurement (HIP events on the ctx stream; ms) */
     float align_ms;      /* whole wm_icp_align call, device side */
-    float nn_ms;         /* sum over correspondence-search launches (profile=1) */
+    float nn_ms;         /* sum over level-0 correspondence-kernel launches (profile=1) */
+    float coarse_ms;     /* sum over the coarser-level launches for deferred queries */
     float stats_ms;      /* sum over statistic-reduction launches (profile=1) */
     float solve_ms;      /* sum over reduce+solve launches (profile=1) */
     int nn_launches;     /* level-0 correspondence launches timed in nn_ms */

@@ -36,7 +36,8 @@ class IcpParams(C.Structure):
 class IcpStats(C.Structure):
     _fields_ = [("converged", C.c_int), ("iterations", C.c_int), ("state", C.c_int),
                 ("n_corr", C.c_int), ("mse", C.c_double), ("prev_mse", C.c_double),
-                ("align_ms", C.c_float), ("nn_ms", C.c_float), ("stats_ms", C.c_float),
+                ("align_ms", C.c_float), ("nn_ms", C.c_float), ("coarse_ms", C.c_float),
+                ("stats_ms", C.c_float),
                 ("solve_ms", C.c_float), ("nn_launches", C.c_int), ("nn_levels", C.c_int),
                 ("deferred", C.c_uint64), ("grid_cell", C.c_float)]
 
@@ -173,7 +174,7 @@ class Context:
         return dict(rc=rc, T=T if rc == WM_OK else None, converged=bool(s.converged),
                     iterations=s.iterations, state=CONV_NAMES.get(s.state, s.state),
                     n_corr=s.n_corr, mse=s.mse, prev_mse=s.prev_mse, align_ms=s.align_ms,
-                    nn_ms=s.nn_ms, stats_ms=s.stats_ms, solve_ms=s.solve_ms,
+                    nn_ms=s.nn_ms, coarse_ms=s.coarse_ms, stats_ms=s.stats_ms, solve_ms=s.solve_ms,
                     nn_launches=s.nn_launches, nn_levels=s.nn_levels, deferred=s.deferred,
                     grid_cell=s.grid_cell)
 

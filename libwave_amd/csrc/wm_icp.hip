@@ -109,6 +109,7 @@ __global__ void __launch_bounds__(kBlock)
 
 // expand the 17 compact accumulators to the public 32-slot layout
 __device__ __host__ inline void expand_stats(int mode, const double *a, double *st) {
+#pragma unroll
     for (int k = 0; k < kStatsLen; ++k) st[k] = 0.0;
     if (mode == WM_ICP_SVD) {
         st[kSvdN] = a[0];
@@ -119,6 +120,7 @@ __device__ __host__ inline void expand_stats(int mode, const double *a, double *
     } else {
         const double n = a[0], sx = a[1], sy = a[2], sz = a[3];
         double H[36];
+#pragma unroll
         for (int k = 0; k < 36; ++k) H[k] = 0;
         H[0] = H[7] = H[14] = n;
         H[0 * 6 + 4] = sz;
@@ -136,8 +138,12 @@ __device__ __host__ inline void expand_stats(int mode, const double *a, double *
         st[kGnN] = n;
         st[kGnSd2] = a[16];
         int k = 0;
+#pragma unroll
         for (int i = 0; i < 6; ++i)
-            for (int j = i; j < 6; ++j) st[kGnH + k++] = H[i * 6 + j];
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (j >= i) st[kGnH + k++] = H[i * 6 + j];
+#pragma unroll
         for (int i = 0; i < 6; ++i) st[kGnG + i] = a[10 + i];
     }
 }
@@ -149,34 +155,54 @@ template <int PHASES>
 __global__ void __launch_bounds__(kBlock)
     k_reduce_solve(const double *__restrict__ partials, int nblocks, IcpDevState *st) {
     if (st->done) return;
-    __shared__ double lds[kBlock / 32][32];
+    constexpr int kRows = 15;  // 15 row-lanes x 17 components = 255 active threads
+    __shared__ double lds[kRows][kAcc];
     if (PHASES & 1) {
-        const int c = threadIdx.x & 31, slice = threadIdx.x >> 5;  // 8 slices x 32 comps
-        double s = 0;
-        if (c < kAcc)
-            for (int b = slice; b < nblocks; b += kBlock / 32) s += partials[(size_t) b * kAcc + c];
-        lds[slice][c] = s;
+        const int c = threadIdx.x % kAcc, r = threadIdx.x / kAcc;
+        if (r < kRows) {
+            // 8 independent accumulators: keeps 8 loads in flight instead of one
+            // dependent load->add chain per partial (which costs a memory latency each)
+            double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int b = r;
+            for (; b + 7 * kRows < nblocks; b += 8 * kRows) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s[u] += partials[(size_t) (b + u * kRows) * kAcc + c];
+            }
+            for (int u = 0; b < nblocks; b += kRows, ++u) s[u] += partials[(size_t) b * kAcc + c];
+            lds[r][c] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             double a[kAcc];
+#pragma unroll
             for (int k = 0; k < kAcc; ++k) {
                 double t = 0;
-                for (int sl = 0; sl < kBlock / 32; ++sl) t += lds[sl][k];
+#pragma unroll
+                for (int sl = 0; sl < kRows; ++sl) t += lds[sl][k];
                 a[k] = t;
             }
-            expand_stats(st->mode, a, st->stats);
+            double ex[kStatsLen];
+            expand_stats(st->mode, a, ex);
+#pragma unroll
+            for (int k = 0; k < kStatsLen; ++k) st->stats[k] = ex[k];
         }
     }
     if (!(PHASES & 2)) return;
     if (threadIdx.x != 0) return;
 
-    const double n = st->stats[0];
-    const double sd2 = st->mode == WM_ICP_SVD ? st->stats[kSvdSd2] : st->stats[kGnSd2];
+    // work on a register copy: every st-> access is a global round trip
+    double stats[kStatsLen];
+#pragma unroll
+    for (int k = 0; k < kStatsLen; ++k) stats[k] = st->stats[k];
+    const int mode = st->mode;
+    const double n = stats[0];
+    const double sd2 = mode == WM_ICP_SVD ? stats[kSvdSd2] : stats[kGnSd2];
     const double mse = n > 0 ? sd2 / n : 0.0;
     st->n_corr = (int) n;
     st->mse = mse;
     // bookkeeping for the next iteration's queues
     st->deferred_total += st->queue_count[1];
+#pragma unroll
     for (int l = 0; l <= kMaxLevels; ++l) st->queue_count[l] = 0;
     if (n < 3.0) {  // PCL: min_number_correspondences_ = 3
         st->state = WM_CONV_NO_CORRESPONDENCES;
@@ -184,23 +210,28 @@ __global__ void __launch_bounds__(kBlock)
         st->done = 1;
         return;
     }
-    double Tk[16];
-    if (st->mode == WM_ICP_SVD)
-        umeyama_from_stats(st->stats, Tk);
+    double Tk[16], Tc[16], Tn[16];
+    if (mode == WM_ICP_SVD)
+        umeyama_from_stats(stats, Tk);
     else
-        gn6_from_stats(st->stats, Tk);
-    double Tn[16];
-    mat4_mul(Tk, st->T, Tn);
+        gn6_from_stats(stats, Tk);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Tc[k] = st->T[k];
+    mat4_mul(Tk, Tc, Tn);
+#pragma unroll
     for (int k = 0; k < 16; ++k) {
         st->T[k] = Tn[k];
         st->Tk[k] = Tk[k];
     }
+#pragma unroll
     for (int k = 0; k < 12; ++k) st->Tf[k] = (float) Tn[k];
-    const int iter = ++st->iter;
+    const int iter = st->iter + 1;
+    st->iter = iter;
+    const int max_iter = st->max_iter;
 
     // pcl::registration::DefaultConvergenceCriteria::hasConverged()
     if (st->forced) {
-        if (iter >= st->max_iter) {
+        if (iter >= max_iter) {
             st->converged = 1;
             st->state = WM_CONV_FORCED;
             st->done = 1;
@@ -208,29 +239,25 @@ __global__ void __launch_bounds__(kBlock)
         st->prev_mse = mse;
         return;
     }
-    if (iter >= st->max_iter) {
+    if (iter >= max_iter) {
         st->converged = 1;
         st->state = WM_CONV_ITERATIONS;
         st->done = 1;
         return;
     }
+    const double prev_mse = st->prev_mse;
     const double cos_angle = 0.5 * (Tk[0] + Tk[5] + Tk[10] - 1.0);
     const double tsq = Tk[3] * Tk[3] + Tk[7] * Tk[7] + Tk[11] * Tk[11];
-    if (cos_angle >= st->rot_thr && tsq <= st->trans_thr) {
+    int state = WM_CONV_NOT_CONVERGED;
+    if (cos_angle >= st->rot_thr && tsq <= st->trans_thr)
+        state = WM_CONV_TRANSFORM;
+    else if (fabs(mse - prev_mse) < 1e-12)
+        state = WM_CONV_ABS_MSE;
+    else if (fabs(mse - prev_mse) / prev_mse < st->fit_eps)
+        state = WM_CONV_REL_MSE;
+    if (state != WM_CONV_NOT_CONVERGED) {
         st->converged = 1;
-        st->state = WM_CONV_TRANSFORM;
-        st->done = 1;
-        return;
-    }
-    if (fabs(mse - st->prev_mse) < 1e-12) {
-        st->converged = 1;
-        st->state = WM_CONV_ABS_MSE;
-        st->done = 1;
-        return;
-    }
-    if (fabs(mse - st->prev_mse) / st->prev_mse < st->fit_eps) {
-        st->converged = 1;
-        st->state = WM_CONV_REL_MSE;
+        st->state = state;
         st->done = 1;
         return;
     }
@@ -500,17 +527,25 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
     while (launched < max_it) {
         const int batch = p->force_iterations > 0 ? max_it : ((max_it - launched) < 8 ? (max_it - launched) : 8);
         for (int b = 0; b < batch; ++b) {
-            hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
-            if (p->profile) {
+            hipEvent_t e0 = nullptr, e1 = nullptr, e1b = nullptr, e2 = nullptr, e3 = nullptr;
+            if (p->profile) {  // 5 pool slots per iteration; level 1 only fills the first two
                 e0 = get_event(ctx, ev_used++);
                 e1 = get_event(ctx, ev_used++);
-                e2 = get_event(ctx, ev_used++);
-                e3 = get_event(ctx, ev_used++);
+                if (p->profile >= 2) {
+                    e1b = get_event(ctx, ev_used++);
+                    e2 = get_event(ctx, ev_used++);
+                    e3 = get_event(ctx, ev_used++);
+                } else {
+                    ev_used += 3;
+                    (void) get_event(ctx, ev_used - 1);
+                }
             }
-            if (brute)
+            if (brute) {
                 WM_TRY(launch_nn_brute(ctx, thr, e0, e1));
-            else
-                WM_TRY(launch_nn_grid(ctx, thr, e0, e1));
+                if (e1b) WM_HIP(ctx, hipEventRecord(e1b, ctx->stream));
+            } else {
+                WM_TRY(launch_nn_grid(ctx, thr, e0, e1, e1b));
+            }
             WM_TRY(launch_stats(ctx, p->mode));
             if (e2) WM_HIP(ctx, hipEventRecord(e2, ctx->stream));
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<3>), dim3(1), dim3(kBlock), 0,
@@ -542,12 +577,17 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
         if (p->profile) {
             // iterations that ran (the rest of the last batch were no-ops)
             const int ran = s.iter + (s.state == WM_CONV_NO_CORRESPONDENCES ? 1 : 0);
-            for (int it = 0; it < ran && (size_t) (4 * it + 3) < ev_used; ++it) {
-                float a = 0, b = 0, c = 0;
-                (void) hipEventElapsedTime(&a, ctx->ev_pool[4 * it], ctx->ev_pool[4 * it + 1]);
-                (void) hipEventElapsedTime(&b, ctx->ev_pool[4 * it + 1], ctx->ev_pool[4 * it + 2]);
-                (void) hipEventElapsedTime(&c, ctx->ev_pool[4 * it + 2], ctx->ev_pool[4 * it + 3]);
+            for (int it = 0; it < ran && (size_t) (5 * it + 4) < ev_used; ++it) {
+                float a = 0, a2 = 0, b = 0, c = 0;
+                hipEvent_t *e = &ctx->ev_pool[5 * it];
+                (void) hipEventElapsedTime(&a, e[0], e[1]);
+                if (p->profile >= 2) {
+                    (void) hipEventElapsedTime(&a2, e[1], e[2]);
+                    (void) hipEventElapsedTime(&b, e[2], e[3]);
+                    (void) hipEventElapsedTime(&c, e[3], e[4]);
+                }
                 stats->nn_ms += a;
+                stats->coarse_ms += a2;
                 stats->stats_ms += b;
                 stats->solve_ms += c;
                 stats->nn_launches += 1;
@@ -609,7 +649,7 @@ int wm_nn_search(wm_ctx *ctx, const double T[16], double max_corr, int nn_method
     if (brute)
         WM_TRY(launch_nn_brute(ctx, thr, e0, e1));
     else
-        WM_TRY(launch_nn_grid(ctx, thr, e0, e1));
+        WM_TRY(launch_nn_grid(ctx, thr, e0, e1, nullptr));
     WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (kernel_ms) (void) hipEventElapsedTime(kernel_ms, ctx->ev_a, ctx->ev_b);
     ctx->have_corr = true;

@@ -147,7 +147,7 @@ int morton_sort(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, float4
 int ensure_levels(wm_ctx *ctx, double max_corr);
 
 // ---- wm_nn.hip
-int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1);
+int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2);
 int launch_nn_brute(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1);
 float threshold_d2(double max_corr);
 

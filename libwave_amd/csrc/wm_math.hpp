@@ -21,17 +21,22 @@ constexpr int kSvdN = 0, kSvdSp = 1, kSvdSq = 4, kSvdSqp = 7, kSvdSd2 = 16;
 constexpr int kGnN = 0, kGnSd2 = 1, kGnH = 2, kGnG = 23;
 
 WM_HD void mat4_identity(double *T) {
+#pragma unroll
     for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
 }
 
 WM_HD void mat4_mul(const double *A, const double *B, double *C) {
     double t[16];
+#pragma unroll
     for (int i = 0; i < 4; ++i)
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
             double s = 0;
+#pragma unroll
             for (int k = 0; k < 4; ++k) s += A[i * 4 + k] * B[k * 4 + j];
             t[i * 4 + j] = s;
         }
+#pragma unroll
     for (int i = 0; i < 16; ++i) C[i] = t[i];
 }
 
@@ -41,92 +46,160 @@ WM_HD double det3(const double *m) {
 }
 
 // One-sided Jacobi SVD of a 3x3 matrix: A = U diag(S) V^T, S descending, U
-// completed to an orthonormal basis when A is rank deficient.
+// completed to an orthonormal basis when A is rank deficient.  Written with
+// compile-time indices only (every loop fully unrolled) so that on the GPU the
+// working set lives in registers, not scratch.
+namespace detail {
+template <int I, int J>
+WM_HD bool jacobi_pair(double *W, double *V) {
+    double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        alpha += W[k * 3 + I] * W[k * 3 + I];
+        beta += W[k * 3 + J] * W[k * 3 + J];
+        gamma += W[k * 3 + I] * W[k * 3 + J];
+    }
+    if (fabs(gamma) <= 1e-300 || fabs(gamma) <= 2.3e-16 * sqrt(alpha * beta)) return false;
+    const double zeta = (beta - alpha) / (2.0 * gamma);
+    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double wi = W[k * 3 + I], wj = W[k * 3 + J];
+        W[k * 3 + I] = c * wi - s * wj;
+        W[k * 3 + J] = s * wi + c * wj;
+        const double vi = V[k * 3 + I], vj = V[k * 3 + J];
+        V[k * 3 + I] = c * vi - s * vj;
+        V[k * 3 + J] = s * vi + c * vj;
+    }
+    return true;
+}
+template <int I, int J>
+WM_HD void swap_cols_if_less(double *sv, double *W, double *V) {  // ensure sv[I] >= sv[J]
+    if (sv[J] > sv[I]) {
+        double t = sv[I];
+        sv[I] = sv[J];
+        sv[J] = t;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            t = W[k * 3 + I];
+            W[k * 3 + I] = W[k * 3 + J];
+            W[k * 3 + J] = t;
+            t = V[k * 3 + I];
+            V[k * 3 + I] = V[k * 3 + J];
+            V[k * 3 + J] = t;
+        }
+    }
+}
+}  // namespace detail
+
 WM_HD void svd3(const double *A, double *U, double *S, double *V) {
     double W[9];
+#pragma unroll
     for (int i = 0; i < 9; ++i) {
         W[i] = A[i];
         V[i] = (i % 4 == 0) ? 1.0 : 0.0;
     }
     for (int sweep = 0; sweep < 60; ++sweep) {
-        bool rotated = false;
-        for (int i = 0; i < 2; ++i)
-            for (int j = i + 1; j < 3; ++j) {
-                double alpha = 0, beta = 0, gamma = 0;
-                for (int k = 0; k < 3; ++k) {
-                    alpha += W[k * 3 + i] * W[k * 3 + i];
-                    beta += W[k * 3 + j] * W[k * 3 + j];
-                    gamma += W[k * 3 + i] * W[k * 3 + j];
-                }
-                if (fabs(gamma) <= 1e-300 || fabs(gamma) <= 2.3e-16 * sqrt(alpha * beta)) continue;
-                rotated = true;
-                double zeta = (beta - alpha) / (2.0 * gamma);
-                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-                for (int k = 0; k < 3; ++k) {
-                    double wi = W[k * 3 + i], wj = W[k * 3 + j];
-                    W[k * 3 + i] = c * wi - s * wj;
-                    W[k * 3 + j] = s * wi + c * wj;
-                    double vi = V[k * 3 + i], vj = V[k * 3 + j];
-                    V[k * 3 + i] = c * vi - s * vj;
-                    V[k * 3 + j] = s * vi + c * vj;
-                }
-            }
-        if (!rotated) break;
+        bool r0 = detail::jacobi_pair<0, 1>(W, V);
+        bool r1 = detail::jacobi_pair<0, 2>(W, V);
+        bool r2 = detail::jacobi_pair<1, 2>(W, V);
+        if (!(r0 || r1 || r2)) break;
     }
     double sv[3];
-    int ord[3] = {0, 1, 2};
-    double smax = 0;
-    for (int j = 0; j < 3; ++j) {
-        sv[j] = sqrt(W[j] * W[j] + W[3 + j] * W[3 + j] + W[6 + j] * W[6 + j]);
-        if (sv[j] > smax) smax = sv[j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) sv[j] = sqrt(W[j] * W[j] + W[3 + j] * W[3 + j] + W[6 + j] * W[6 + j]);
+    detail::swap_cols_if_less<0, 1>(sv, W, V);
+    detail::swap_cols_if_less<0, 2>(sv, W, V);
+    detail::swap_cols_if_less<1, 2>(sv, W, V);
+    const double smax = sv[0];
+    const bool h0 = (sv[0] > 1e-300);
+    const bool h1 = h0 && (sv[1] > 1e-300 && sv[1] > 1e-14 * smax);
+    const bool h2 = h1 && (sv[2] > 1e-300 && sv[2] > 1e-14 * smax);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        S[k] = sv[k];
+        U[k * 3 + 0] = h0 ? W[k * 3 + 0] / sv[0] : 0.0;
+        U[k * 3 + 1] = h1 ? W[k * 3 + 1] / sv[1] : 0.0;
+        U[k * 3 + 2] = h2 ? W[k * 3 + 2] / sv[2] : 0.0;
     }
-    for (int i = 0; i < 2; ++i)
-        for (int j = i + 1; j < 3; ++j)
-            if (sv[ord[j]] > sv[ord[i]]) {
-                int t = ord[i];
-                ord[i] = ord[j];
-                ord[j] = t;
-            }
-    double Vt[9];
-    for (int i = 0; i < 9; ++i) Vt[i] = V[i];
-    bool have[3];
-    for (int j = 0; j < 3; ++j) {
-        int o = ord[j];
-        S[j] = sv[o];
-        have[j] = (sv[o] > 1e-300 && sv[o] > 1e-14 * smax);
-        for (int k = 0; k < 3; ++k) {
-            V[k * 3 + j] = Vt[k * 3 + o];
-            U[k * 3 + j] = have[j] ? W[k * 3 + o] / sv[o] : 0.0;
-        }
-    }
-    // complete U (cross products / canonical fallbacks)
-    if (!have[0]) {  // zero matrix
+    if (!h0) {  // zero matrix
+#pragma unroll
         for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.0 : 0.0;
         return;
     }
-    if (!have[1]) {
-        // any unit vector orthogonal to u0
-        double u0[3] = {U[0], U[3], U[6]};
-        int m = 0;
-        if (fabs(u0[1]) < fabs(u0[m])) m = 1;
-        if (fabs(u0[2]) < fabs(u0[m])) m = 2;
-        double e[3] = {0, 0, 0};
-        e[m] = 1;
-        double d = u0[m];
-        double v[3] = {e[0] - d * u0[0], e[1] - d * u0[1], e[2] - d * u0[2]};
-        double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-        U[1] = v[0] / n;
-        U[4] = v[1] / n;
-        U[7] = v[2] / n;
-        have[1] = true;
+    if (!h1) {  // any unit vector orthogonal to u0: drop the smallest component
+        const double a0 = U[0], a1 = U[3], a2 = U[6];
+        double e0 = 0, e1 = 0, e2 = 0, d;
+        if (fabs(a0) <= fabs(a1) && fabs(a0) <= fabs(a2)) {
+            e0 = 1;
+            d = a0;
+        } else if (fabs(a1) <= fabs(a2)) {
+            e1 = 1;
+            d = a1;
+        } else {
+            e2 = 1;
+            d = a2;
+        }
+        const double v0 = e0 - d * a0, v1 = e1 - d * a1, v2 = e2 - d * a2;
+        const double n = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
+        U[1] = v0 / n;
+        U[4] = v1 / n;
+        U[7] = v2 / n;
     }
-    if (!have[2]) {
-        double a[3] = {U[0], U[3], U[6]}, b[3] = {U[1], U[4], U[7]};
-        U[2] = a[1] * b[2] - a[2] * b[1];
-        U[5] = a[2] * b[0] - a[0] * b[2];
-        U[8] = a[0] * b[1] - a[1] * b[0];
+    if (!h2) {
+        const double a0 = U[0], a1 = U[3], a2 = U[6], b0 = U[1], b1 = U[4], b2 = U[7];
+        U[2] = a1 * b2 - a2 * b1;
+        U[5] = a2 * b0 - a0 * b2;
+        U[8] = a0 * b1 - a1 * b0;
     }
+}
+
+// Cholesky solve of a symmetric positive definite system (compile-time indices).
+// returns false when A is not positive definite.
+template <int N>
+WM_HD bool chol_solve(const double *A, const double *b, double *x) {
+    double L[N * N];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (j > i) continue;
+            double s = A[i * N + j];
+#pragma unroll
+            for (int k = 0; k < N; ++k)
+                if (k < j) s -= L[i * N + k] * L[j * N + k];
+            if (i == j) {
+                if (!(s > 0.0)) {
+                    ok = false;
+                    s = 1.0;
+                }
+                L[i * N + i] = sqrt(s);
+            } else {
+                L[i * N + j] = s / L[j * N + j];
+            }
+        }
+    }
+    double y[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if (k < i) s -= L[i * N + k] * y[k];
+        y[i] = s / L[i * N + i];
+    }
+#pragma unroll
+    for (int ii = 0; ii < N; ++ii) {
+        const int i = N - 1 - ii;
+        double s = y[i];
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if (k > i) s -= L[k * N + i] * x[k];
+        x[i] = s / L[i * N + i];
+    }
+    return ok;
 }
 
 // Gauss-Jordan inverse with partial pivoting, N <= 6.  returns false if singular.
@@ -172,12 +245,16 @@ WM_HD bool inverse(const double *A, double *Ainv) {
 template <int N>
 WM_HD void mat_mul(const double *A, const double *B, double *C) {
     double t[N * N];
+#pragma unroll
     for (int i = 0; i < N; ++i)
+#pragma unroll
         for (int j = 0; j < N; ++j) {
             double s = 0;
+#pragma unroll
             for (int k = 0; k < N; ++k) s += A[i * N + k] * B[k * N + j];
             t[i * N + j] = s;
         }
+#pragma unroll
     for (int i = 0; i < N * N; ++i) C[i] = t[i];
 }
 
@@ -194,6 +271,7 @@ WM_HD void rodrigues(const double *w, double *R) {
     const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
     double K2[9];
     mat_mul<3>(K, K, K2);
+#pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * K[i] + b * K2[i];
 }
 
@@ -204,22 +282,31 @@ WM_HD void rodrigues(const double *w, double *R) {
 WM_HD void umeyama_from_stats(const double *st, double *T) {
     const double n = st[kSvdN];
     double pm[3], qm[3], sigma[9], U[9], S[3], V[9], R[9];
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
         pm[i] = st[kSvdSp + i] / n;
         qm[i] = st[kSvdSq + i] / n;
     }
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = 0; j < 3; ++j) sigma[i * 3 + j] = st[kSvdSqp + i * 3 + j] / n - qm[i] * pm[j];
     svd3(sigma, U, S, V);
     const double s2 = (det3(U) * det3(V) < 0) ? -1.0 : 1.0;
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = 0; j < 3; ++j) {
             double s = 0;
+#pragma unroll
             for (int k = 0; k < 3; ++k) s += U[i * 3 + k] * (k == 2 ? s2 : 1.0) * V[j * 3 + k];
             R[i * 3 + j] = s;
         }
+#pragma unroll
     for (int i = 0; i < 16; ++i) T[i] = 0;
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
+#pragma unroll
         for (int j = 0; j < 3; ++j) T[i * 4 + j] = R[i * 3 + j];
         T[i * 4 + 3] = qm[i] - (R[i * 3 + 0] * pm[0] + R[i * 3 + 1] * pm[1] + R[i * 3 + 2] * pm[2]);
     }
@@ -228,23 +315,27 @@ WM_HD void umeyama_from_stats(const double *st, double *T) {
 
 // Gauss-Newton step: (J^T J) delta = -J^T r, T_k = [exp(dw) | dt].
 WM_HD bool gn6_from_stats(const double *st, double *T) {
-    double H[36], Hinv[36], delta[6], R[9];
-    int k = 0;
-    for (int i = 0; i < 6; ++i)
-        for (int j = i; j < 6; ++j) {
-            H[i * 6 + j] = st[kGnH + k];
-            H[j * 6 + i] = st[kGnH + k];
-            ++k;
-        }
-    bool ok = inverse<6>(H, Hinv);
-    for (int i = 0; i < 6; ++i) {
-        double s = 0;
-        for (int j = 0; j < 6; ++j) s += Hinv[i * 6 + j] * st[kGnG + j];
-        delta[i] = -s;
+    double H[36], delta[6], rhs[6], R[9];
+    {
+        int k = 0;  // upper triangle, row-major
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (j >= i) {
+                    H[i * 6 + j] = st[kGnH + k];
+                    H[j * 6 + i] = st[kGnH + k];
+                    ++k;
+                }
     }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rhs[i] = -st[kGnG + i];
+    const bool ok = chol_solve<6>(H, rhs, delta);
     rodrigues(delta + 3, R);
     mat4_identity(T);
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
+#pragma unroll
         for (int j = 0; j < 3; ++j) T[i * 4 + j] = R[i * 3 + j];
         T[i * 4 + 3] = delta[i];
     }

@@ -255,7 +255,7 @@ float threshold_d2(double max_corr) {
     return f;
 }
 
-int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1) {
+int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2) {
     const unsigned n = (unsigned) ctx->n_src;
     if (n == 0) return WM_OK;
     const IcpDevState *st = ctx->d_state.as<IcpDevState>();
@@ -276,6 +276,7 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1) {
                            ctx->levels[l].d, ctx->src_sorted.as<float4>(), st, thr_d2, keys, qin,
                            qcount + l, qout, qcount + l + 1, l == L - 1 ? 1 : 0);
     }
+    if (ev2) WM_HIP(ctx, hipEventRecord(ev2, ctx->stream));
     WM_HIP(ctx, hipGetLastError());
     return WM_OK;
 }

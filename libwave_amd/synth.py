@@ -28,7 +28,8 @@ def make_T(t=(0.2, -0.1, 0.05), rpy=(0.01, -0.02, 0.03)):
 T_GT = make_T()
 
 
-def scene(n, seed=42):
+def scene(n, seed=42, layout_seed=20240):
+    """n points sampled (seed) on a fixed scene geometry (layout_seed)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     n_ground = int(0.4 * n)
     n_wall = int(0.3 * n)
@@ -43,8 +44,9 @@ def scene(n, seed=42):
     w[:, 2] = rng.uniform(0, 8, n_wall)
     w[:, 0] = np.where(side == 0, -50, np.where(side == 1, 50, -50 + 100 * u))
     w[:, 1] = np.where(side == 2, -30, np.where(side == 3, 30, -30 + 60 * u))
-    # 200 boxes; a fixed sub-generator so the box layout depends on the seed only
-    brng = np.random.Generator(np.random.PCG64(seed * 7919 + 1))
+    # 200 boxes; the layout is part of the scene geometry, NOT of the sampling seed,
+    # so S(n, seed) and S(n, seed + 1) are two samplings of the same surfaces
+    brng = np.random.Generator(np.random.PCG64(layout_seed))
     nb = 200
     centre = np.stack([brng.uniform(-45, 45, nb), brng.uniform(-25, 25, nb)], axis=1)
     size = np.stack([brng.uniform(0.5, 4, nb), brng.uniform(0.5, 2, nb), brng.uniform(0.5, 2, nb)], axis=1)

@@ -15,11 +15,11 @@ for h in cells:
     ctx.set_grid_cell(h)
     t0 = time.time(); ctx.set_source(ref); t1 = time.time(); ctx.set_target(tgt); t2 = time.time()
     for rep in range(3):
-        r = ctx.icp_align(max_corr=3.0, force_iterations=iters, nn_method=capi.WM_NN_GRID, profile=1)
+        r = ctx.icp_align(max_corr=3.0, force_iterations=iters, nn_method=capi.WM_NN_GRID, profile=2)
     r2 = ctx.icp_align(max_corr=3.0, force_iterations=iters, nn_method=capi.WM_NN_GRID, profile=0)
     print("cell=%.3f (used %.3f) levels=%d set_source %.1f ms set_target %.1f ms" % (h, r["grid_cell"], r["nn_levels"], (t1-t0)*1e3, (t2-t1)*1e3))
-    print("  profile: align %.2f ms nn %.2f stats %.2f solve %.2f ms; per-iter nn %.1f us; deferred %d" % (
-        r["align_ms"], r["nn_ms"], r["stats_ms"], r["solve_ms"], r["nn_ms"]/max(r["nn_launches"],1)*1e3, r["deferred"]))
+    print("  profile: align %.2f ms nn %.2f coarse %.2f stats %.2f solve %.2f ms; per-iter nn %.1f us; deferred %d" % (
+        r["align_ms"], r["nn_ms"], r["coarse_ms"], r["stats_ms"], r["solve_ms"], r["nn_ms"]/max(r["nn_launches"],1)*1e3, r["deferred"]))
     print("  noprofile: align %.2f ms -> %.1f us/iter; err vs gt %s" % (r2["align_ms"], r2["align_ms"]/iters*1e3,
           np.abs(r2["T"]-T_gt).max()))
     for k in range(3):

@@ -5,7 +5,8 @@ def pose_error(T_a, T_b):
     """(translation distance [m], rotation angle [rad]) between two 4x4 transforms."""
     dt = float(np.linalg.norm(T_a[:3, 3] - T_b[:3, 3]))
     R = T_a[:3, :3].T @ T_b[:3, :3]
-    ang = float(np.arccos(np.clip((np.trace(R) - 1.0) / 2.0, -1.0, 1.0)))
+    # |R - I|_F = 2 sqrt(2) |sin(theta / 2)|: well conditioned near theta = 0 (arccos is not)
+    ang = float(2.0 * np.arcsin(min(1.0, np.linalg.norm(R - np.eye(3)) / (2.0 * np.sqrt(2.0)))))
     return dt, ang
 
 

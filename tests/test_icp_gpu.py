@@ -132,8 +132,8 @@ def test_icp_forced_iterations_match_oracle(wm, ctx, oracle, n, method):
     assert dt <= 1e-7 and ang <= 1e-8, (dt, ang)
     dt, ang = pose_error(got["T"], pcl["T"])
     assert dt <= TOL_T and ang <= TOL_R, (dt, ang)
-    dt, ang = pose_error(got["T"], T_gt)
-    assert dt < 5e-3 and ang < 1e-3
+    dt, ang = pose_error(got["T"], T_gt)   # two different samplings of the scene: cm-level
+    assert dt < 2e-2 and ang < 2e-3
 
 
 def test_icp_gn6_reaches_the_same_fixed_point(wm, ctx, oracle):
