@@ -131,6 +131,10 @@ void wm_icp_default_params(wm_icp_params *p);
  * otherwise (T_out then untouched, as ICPMatcher leaves `result`). */
 int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_stats *stats);
 
+/* Per-iteration device time (ms) of the correspondence kernel in the last
+ * wm_icp_align call that ran with profile >= 1; returns the number written. */
+int wm_get_iteration_times(wm_ctx *ctx, float *nn_ms, int cap);
+
 /* PCL's icp.correspondences_ after align (read by estimateLUM / estimateCensi,
  * icp_pcl_functions.cpp:191, icp.cpp:213): per source point (caller's order)
  * the matched target index (caller's order; -1 = none) and squared distance. */

@@ -71,6 +71,7 @@ def lib():
         L.wm_icp_default_params.argtypes = [C.POINTER(IcpParams)]
         L.wm_icp_default_params.restype = None
         L.wm_icp_align.argtypes = [C.c_void_p, C.POINTER(IcpParams), _dp, C.POINTER(IcpStats)]
+        L.wm_get_iteration_times.argtypes = [C.c_void_p, _fp, C.c_int]
         L.wm_get_correspondences.argtypes = [C.c_void_p, _ip, _fp, C.c_size_t]
         L.wm_nn_search.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int, _ip, _fp, C.c_size_t, _fp]
         L.wm_icp_stats_for.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
@@ -177,6 +178,11 @@ class Context:
                     nn_ms=s.nn_ms, coarse_ms=s.coarse_ms, stats_ms=s.stats_ms, solve_ms=s.solve_ms,
                     nn_launches=s.nn_launches, nn_levels=s.nn_levels, deferred=s.deferred,
                     grid_cell=s.grid_cell)
+
+    def iteration_times(self, cap=1024):
+        buf = np.zeros(cap, np.float32)
+        n = lib().wm_get_iteration_times(self._h, buf.ctypes.data_as(_fp), cap)
+        return buf[:n].copy()
 
     def correspondences(self):
         idx = np.empty(self.n_src, np.int32)

@@ -79,7 +79,26 @@ __global__ void __launch_bounds__(kBlock) k_bbox(const float4 *pts, size_t n, un
         }
         cnt += __shfl_down(cnt, off);
     }
-    if ((threadIdx.x & 63) == 0) {
+    // one set of atomics per workgroup (contended same-address atomics are ~11 ns each)
+    __shared__ float s_lo[kBlock / 64][3], s_hi[kBlock / 64][3];
+    __shared__ unsigned s_cnt[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        for (int d = 0; d < 3; ++d) {
+            s_lo[wave][d] = lo[d];
+            s_hi[wave][d] = hi[d];
+        }
+        s_cnt[wave] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) {
+            for (int d = 0; d < 3; ++d) {
+                lo[d] = fminf(lo[d], s_lo[w][d]);
+                hi[d] = fmaxf(hi[d], s_hi[w][d]);
+            }
+            cnt += s_cnt[w];
+        }
         for (int d = 0; d < 3; ++d) {
             atomicMin(&out[d], f2ord(lo[d]));
             atomicMax(&out[3 + d], f2ord(hi[d]));
@@ -95,7 +114,7 @@ int compute_bbox(wm_ctx *ctx, const float4 *pts, size_t n, Bbox *out, size_t *n_
                                ctx->stream));
     if (n > 0) {
         unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
-        if (blocks > 2048) blocks = 2048;
+        if (blocks > 512) blocks = 512;
         hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, n,
                            ctx->bbox_buf.as<unsigned>());
         WM_HIP(ctx, hipGetLastError());
@@ -463,18 +482,24 @@ int ensure_levels(wm_ctx *ctx, double max_corr) {
     const float4 *pts = ctx->tgt_orig.as<float4>();
     double h = ctx->levels[0].d.h;
     int L = 1;
-    // one ring at the last level must cover max_corr (plus the float margin)
-    while (h * (1.0 - 2.0 * ctx->levels[L - 1].d.slack) < max_corr && L < kMaxLevels) {
-        const double need = max_corr * 1.02 / (1.0 - 2.0 * ctx->levels[L - 1].d.slack);
-        double nh = h * 4.0;
-        if (nh > need || L == kMaxLevels - 1) nh = fmax(need, h * 1.5);
-        WM_TRY(build_grid_level(ctx, pts, ctx->n_tgt_input, ctx->tgt_bbox, (float) nh,
+    // cell size x2 per level until a level's cells reach max_corr / 2: the search scans
+    // boxes of cells, so the last level need not cover max_corr in one ring
+    while (2.0 * h < max_corr && L < kMaxLevels) {
+        h *= 2.0;
+        WM_TRY(build_grid_level(ctx, pts, ctx->n_tgt_input, ctx->tgt_bbox, (float) h,
                                 &ctx->levels[L], nullptr));
-        h = nh;
         ++L;
     }
     ctx->n_levels = L;
     ctx->levels_max_corr = max_corr;
+    // publish the ladder for the search kernel
+    LevelsDev host{};
+    for (int l = 0; l < L; ++l) host.g[l] = ctx->levels[l].d;
+    host.n = L;
+    WM_HIP(ctx, ctx->d_levels.reserve(sizeof(LevelsDev)));
+    WM_HIP(ctx, hipMemcpyAsync(ctx->d_levels.p, &host, sizeof(host), hipMemcpyHostToDevice,
+                               ctx->stream));
+    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `host` is a stack object
     return WM_OK;
 }
 

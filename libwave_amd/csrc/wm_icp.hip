@@ -227,6 +227,7 @@ __global__ void __launch_bounds__(kBlock)
     for (int k = 0; k < 12; ++k) st->Tf[k] = (float) Tn[k];
     const int iter = st->iter + 1;
     st->iter = iter;
+    st->have_prev = 1;
     const int max_iter = st->max_iter;
 
     // pcl::registration::DefaultConvergenceCriteria::hasConverged()
@@ -307,8 +308,6 @@ static int launch_stats(wm_ctx *ctx, int mode) {
 static int prepare_work(wm_ctx *ctx) {
     const size_t n = ctx->n_src > 0 ? ctx->n_src : 1;
     WM_HIP(ctx, ctx->keys.reserve(n * sizeof(unsigned long long)));
-    WM_HIP(ctx, ctx->queue_a.reserve(n * sizeof(unsigned)));
-    WM_HIP(ctx, ctx->queue_b.reserve(n * sizeof(unsigned)));
     WM_HIP(ctx, ctx->partials.reserve((size_t) kMaxStatBlocks * kAcc * sizeof(double)));
     WM_HIP(ctx, ctx->d_state.reserve(sizeof(IcpDevState)));
     if (!ctx->h_state)
@@ -409,7 +408,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
     (void) hipSetDevice(ctx->device);
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->src_sorted, &ctx->tgt_orig, &ctx->staging, &ctx->cell_of, &ctx->counts,
-                      &ctx->block_sums, &ctx->bbox_buf, &ctx->keys, &ctx->queue_a, &ctx->queue_b,
+                      &ctx->block_sums, &ctx->bbox_buf, &ctx->keys, &ctx->d_levels,
                       &ctx->partials, &ctx->corr_tmp_idx, &ctx->corr_tmp_d2, &ctx->d_state};
     for (DevBuf *b : bufs) b->release();
     for (auto &l : ctx->levels) {
@@ -520,6 +519,7 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
 
     const int max_it = p->force_iterations > 0 ? p->force_iterations : p->max_iter;
     const int nb = stat_blocks(ctx->n_src);
+    ctx->iter_nn_ms.clear();
     IcpDevState *dst = ctx->d_state.as<IcpDevState>();
     WM_HIP(ctx, hipEventRecord(ctx->ev_a, ctx->stream));
     int launched = 0;
@@ -586,6 +586,7 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
                     (void) hipEventElapsedTime(&b, e[2], e[3]);
                     (void) hipEventElapsedTime(&c, e[3], e[4]);
                 }
+                ctx->iter_nn_ms.push_back(a);
                 stats->nn_ms += a;
                 stats->coarse_ms += a2;
                 stats->stats_ms += b;
@@ -625,6 +626,14 @@ static int unpack_correspondences(wm_ctx *ctx, int32_t *match_idx, float *d2, si
                                    hipMemcpyDeviceToHost, ctx->stream));
     WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return WM_OK;
+}
+
+int wm_get_iteration_times(wm_ctx *ctx, float *nn_ms, int cap) {
+    if (!ctx || !nn_ms || cap < 0) return 0;
+    int n = (int) ctx->iter_nn_ms.size();
+    if (n > cap) n = cap;
+    for (int i = 0; i < n; ++i) nn_ms[i] = ctx->iter_nn_ms[i];
+    return n;
 }
 
 int wm_get_correspondences(wm_ctx *ctx, int32_t *match_idx, float *d2, size_t cap) {

@@ -72,6 +72,11 @@ struct GridDev {
     const uint32_t *cell_start; // nx*ny*nz + 1
 };
 
+struct LevelsDev {  // the level ladder as the search kernel reads it (lives in HBM)
+    GridDev g[kMaxLevels];
+    int n;
+};
+
 struct GridLevel {
     GridDev d{};
     DevBuf pts, cell_start;
@@ -89,6 +94,7 @@ struct IcpDevState {
     double stats[kStatsLen];
     double mse, prev_mse;
     int iter, done, converged, state, n_corr, max_iter, forced, mode;
+    int have_prev;  // keys[] hold the previous iteration's result (level prediction)
     double rot_thr, trans_thr, fit_eps;
     unsigned queue_count[kMaxLevels + 1];
     unsigned long long deferred_total;
@@ -121,7 +127,7 @@ struct wm_ctx {
 
     // scratch
     wm::DevBuf staging, cell_of, counts, block_sums, bbox_buf;
-    wm::DevBuf keys, queue_a, queue_b, partials, corr_tmp_idx, corr_tmp_d2;
+    wm::DevBuf keys, partials, corr_tmp_idx, corr_tmp_d2, d_levels;
     wm::DevBuf d_state;
     wm::IcpDevState *h_state = nullptr;  // pinned
     bool have_corr = false;
@@ -133,6 +139,7 @@ struct wm_ctx {
     // events for profile mode
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    std::vector<float> iter_nn_ms;
 };
 
 namespace wm {

@@ -13,14 +13,14 @@
 // floats order like unsigned ints, so "min over keys" is the exact arg-min with
 // the tie rule built in, and "no match" is the initial key (threshold, ~0).
 //
-// Three kernels:
-//   k_nn_grid_thread  level 0, one lane per query: probes the 3x3x3 cell block as
-//                     9 contiguous x-rows of the cell-sorted target, nearest rows
-//                     first, pruning rows by their AABB distance.
-//   k_nn_grid_wave    levels >= 1, one wavefront per query still unresolved by the
-//                     finer level (its ring did not certify the minimum): lanes
-//                     stride the candidate rows with coalesced float4 loads.
-//   k_nn_brute        LDS-tiled all-pairs search (small clouds / cross-check).
+// Two kernels:
+//   k_nn_grid   one lane per query over a ladder of uniform grids (cell size x4 per
+//               level).  Lane phase: the 3x3x3 (then 5x5x5) cell block of the fine level
+//               as contiguous x-rows of the cell-sorted target, nearest rows first, rows
+//               pruned by their AABB distance.  Cooperative phase: queries the fine
+//               level could not certify are scanned by the whole wavefront on the level
+//               that covers their current bound.
+//   k_nn_brute  LDS-tiled all-pairs search (small clouds / cross-check).
 #include "wm_internal.hpp"
 
 namespace wm {
@@ -74,76 +74,105 @@ __device__ __forceinline__ Cell locate(const GridDev &g, float x, float y, float
     return c;
 }
 
-// distance (cell units) from the query to the faces of its 3x3x3 block: every
-// point NOT in the block is at least this far away.
-__device__ __forceinline__ float block_margin(const Cell &c) {
-    float mx = fminf(c.fx - (float) (c.cx - 1), (float) (c.cx + 2) - c.fx);
-    float my = fminf(c.fy - (float) (c.cy - 1), (float) (c.cy + 2) - c.fy);
-    float mz = fminf(c.fz - (float) (c.cz - 1), (float) (c.cz + 2) - c.fz);
+// distance (cell units) from the query to the faces of its (2R+1)^3 cell block:
+// every point NOT in the block is at least this far away.
+__device__ __forceinline__ float block_margin(const Cell &c, int R = 1) {
+    float mx = fminf(c.fx - (float) (c.cx - R), (float) (c.cx + R + 1) - c.fx);
+    float my = fminf(c.fy - (float) (c.cy - R), (float) (c.cy + R + 1) - c.fy);
+    float mz = fminf(c.fz - (float) (c.cz - R), (float) (c.cz + R + 1) - c.fz);
     return fminf(mx, fminf(my, mz));
 }
 
 // lower bound (cell units) of the distance from the query to row (cy+dy, cz+dz)
 __device__ __forceinline__ float row_bound(const Cell &c, int dy, int dz) {
-    float ry = dy == 0 ? 0.f : (dy < 0 ? c.fy - (float) c.cy : (float) (c.cy + 1) - c.fy);
-    float rz = dz == 0 ? 0.f : (dz < 0 ? c.fz - (float) c.cz : (float) (c.cz + 1) - c.fz);
+    float ry = dy == 0 ? 0.f : (dy < 0 ? c.fy - (float) (c.cy + dy + 1) : (float) (c.cy + dy) - c.fy);
+    float rz = dz == 0 ? 0.f : (dz < 0 ? c.fz - (float) (c.cz + dz + 1) : (float) (c.cz + dz) - c.fz);
     return sqrtf(ry * ry + rz * rz);
 }
 
 __device__ __forceinline__ bool certified(const GridDev &g, const Cell &c, float best_d2,
-                                          float thr_d2) {
+                                          float thr_d2, int R = 1) {
     // resolved when the block provably contains the minimum, or when it covers
     // the whole acceptance radius (nothing outside can be <= threshold)
-    const float m = (block_margin(c) - g.slack) * g.h;
+    const float m = (block_margin(c, R) - g.slack) * g.h;
     if (m <= 0.f) return false;
     const float m2 = m * m;
     return best_d2 <= m2 || thr_d2 <= m2;
 }
 
-// --------------------------------------------------------------- level 0
-__global__ void __launch_bounds__(kBlock)
-    k_nn_grid_thread(GridDev g, const float4 *__restrict__ src, unsigned n,
-                     const IcpDevState *__restrict__ st, float thr_d2,
-                     unsigned long long *__restrict__ keys, unsigned *__restrict__ queue,
-                     unsigned *__restrict__ queue_count, int last_level) {
-    if (st->done) return;
-    const unsigned i = xcd_remap(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = src[i];
-    float qx, qy, qz;
-    xform(st->Tf, p, qx, qy, qz);
-    const Cell c = locate(g, qx, qy, qz);
-    unsigned long long best = make_key(thr_d2, kNoIdx);
-    const int x0 = max(c.cx - 1, 0), x1 = min(c.cx + 1, g.nx - 1);
-    if (x0 <= x1) {
-#pragma unroll 1
-        for (int r = 0; r < 9; ++r) {
-            const int dy = kRowDy[r], dz = kRowDz[r];
-            const int yy = c.cy + dy, zz = c.cz + dz;
-            if (yy < 0 || yy >= g.ny || zz < 0 || zz >= g.nz) continue;
-            if (r > 0) {
-                const float lb = (row_bound(c, dy, dz) - g.slack) * g.h;
-                if (lb > 0.f && lb * lb > __uint_as_float((unsigned) (best >> 32))) continue;
-            }
-            const size_t base = ((size_t) zz * g.ny + yy) * g.nx;
-            const unsigned s = g.cell_start[base + x0];
-            const unsigned e = g.cell_start[base + x1 + 1];
-            for (unsigned j = s; j < e; ++j) {
-                const float4 t = g.pts[j];
-                const unsigned long long k = make_key(canon_d2(qx, qy, qz, t), __float_as_uint(t.w));
-                best = k < best ? k : best;
-            }
-        }
+// ------------------------------------------------------------- grid search
+// scan the contiguous run [s, e) of cell-sorted target points, four loads in flight
+__device__ __forceinline__ unsigned long long scan_run(const float4 *__restrict__ pts, unsigned s,
+                                                       unsigned e, float qx, float qy, float qz,
+                                                       unsigned long long best) {
+    for (unsigned j = s; j < e; j += 4) {
+        // clamped re-reads of the last point are harmless: min() is idempotent
+        const unsigned last = e - 1;
+        const float4 t0 = pts[j];
+        const float4 t1 = pts[min(j + 1, last)];
+        const float4 t2 = pts[min(j + 2, last)];
+        const float4 t3 = pts[min(j + 3, last)];
+        const unsigned long long k0 = make_key(canon_d2(qx, qy, qz, t0), __float_as_uint(t0.w));
+        const unsigned long long k1 = make_key(canon_d2(qx, qy, qz, t1), __float_as_uint(t1.w));
+        const unsigned long long k2 = make_key(canon_d2(qx, qy, qz, t2), __float_as_uint(t2.w));
+        const unsigned long long k3 = make_key(canon_d2(qx, qy, qz, t3), __float_as_uint(t3.w));
+        const unsigned long long a = k0 < k1 ? k0 : k1, b = k2 < k3 ? k2 : k3;
+        const unsigned long long m = a < b ? a : b;
+        best = m < best ? m : best;
     }
-    keys[i] = best;
-    if (!last_level &&
-        !certified(g, c, __uint_as_float((unsigned) (best >> 32)), thr_d2)) {
-        const unsigned slot = atomicAdd(queue_count, 1u);
-        queue[slot] = i;
-    }
+    return best;
 }
 
-// ------------------------------------------------------------- levels >= 1
+// Scan every target point in the box of cells covering [q - r, q + r]^3 on level g
+// (one contiguous run per (y,z) row of the box, centre row first, rows pruned by
+// their AABB distance to the query) and report the distance `margin` from the query
+// to the faces of that box: every point NOT scanned is farther than `margin`.
+__device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float qx, float qy,
+                                                       float qz, float r, unsigned long long best,
+                                                       float *margin) {
+    const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
+    const float rc = r * g.inv_h + g.slack;
+    // clamp in float first so far-away queries cannot overflow the int conversion
+    const float big = 4.0e6f;
+    const int x0 = (int) floorf(fminf(fmaxf(fx - rc, -big), big));
+    const int x1 = (int) floorf(fminf(fmaxf(fx + rc, -big), big));
+    const int y0 = (int) floorf(fminf(fmaxf(fy - rc, -big), big));
+    const int y1 = (int) floorf(fminf(fmaxf(fy + rc, -big), big));
+    const int z0 = (int) floorf(fminf(fmaxf(fz - rc, -big), big));
+    const int z1 = (int) floorf(fminf(fmaxf(fz + rc, -big), big));
+    const float mx = fminf(fx - (float) x0, (float) (x1 + 1) - fx);
+    const float my = fminf(fy - (float) y0, (float) (y1 + 1) - fy);
+    const float mz = fminf(fz - (float) z0, (float) (z1 + 1) - fz);
+    *margin = (fminf(mx, fminf(my, mz)) - g.slack) * g.h;
+    const int xa = max(x0, 0), xb = min(x1, g.nx - 1);
+    const int ya = max(y0, 0), yb = min(y1, g.ny - 1);
+    const int za = max(z0, 0), zb = min(z1, g.nz - 1);
+    if (xa > xb || ya > yb || za > zb) return best;
+    const int cy = (int) floorf(fminf(fmaxf(fy, -big), big));
+    const int cz = (int) floorf(fminf(fmaxf(fz, -big), big));
+    // centre row first: it almost always holds the neighbour and arms the pruning
+    if (cy >= ya && cy <= yb && cz >= za && cz <= zb) {
+        const size_t base = ((size_t) cz * g.ny + cy) * g.nx;
+        best = scan_run(g.pts, g.cell_start[base + xa], g.cell_start[base + xb + 1], qx, qy, qz,
+                        best);
+    }
+#pragma unroll 1
+    for (int zz = za; zz <= zb; ++zz) {
+        const float rz = zz > cz ? (float) zz - fz : (zz < cz ? fz - (float) (zz + 1) : 0.f);
+#pragma unroll 1
+        for (int yy = ya; yy <= yb; ++yy) {
+            if (yy == cy && zz == cz) continue;
+            const float ry = yy > cy ? (float) yy - fy : (yy < cy ? fy - (float) (yy + 1) : 0.f);
+            const float lb = (sqrtf(ry * ry + rz * rz) - g.slack) * g.h;
+            if (lb > 0.f && lb * lb > __uint_as_float((unsigned) (best >> 32))) continue;
+            const size_t base = ((size_t) zz * g.ny + yy) * g.nx;
+            best = scan_run(g.pts, g.cell_start[base + xa], g.cell_start[base + xb + 1], qx, qy,
+                            qz, best);
+        }
+    }
+    return best;
+}
+
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -153,55 +182,155 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return v;
 }
 
-__global__ void __launch_bounds__(kBlock)
-    k_nn_grid_wave(GridDev g, const float4 *__restrict__ src, const IcpDevState *__restrict__ st,
-                   float thr_d2, unsigned long long *__restrict__ keys,
-                   const unsigned *__restrict__ qin, const unsigned *__restrict__ qin_count,
-                   unsigned *__restrict__ qout, unsigned *__restrict__ qout_count,
-                   int last_level) {
-    if (st->done) return;
-    const unsigned lane = threadIdx.x & 63u;
-    const unsigned wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const unsigned nwaves = (gridDim.x * kBlock) >> 6;
-    const unsigned cnt = *qin_count;
-    for (unsigned w = wave; w < cnt; w += nwaves) {
-        const unsigned i = qin[w];
-        const float4 p = src[i];
-        float qx, qy, qz;
-        xform(st->Tf, p, qx, qy, qz);
-        const Cell c = locate(g, qx, qy, qz);
-        unsigned long long best = keys[i];  // upper bound from the finer level
-        const int x0 = max(c.cx - 1, 0), x1 = min(c.cx + 1, g.nx - 1);
-        if (x0 <= x1) {
-#pragma unroll 1
-            for (int r = 0; r < 9; ++r) {
-                const int dy = kRowDy[r], dz = kRowDz[r];
-                const int yy = c.cy + dy, zz = c.cz + dz;
-                if (yy < 0 || yy >= g.ny || zz < 0 || zz >= g.nz) continue;
-                best = wave_min_u64(best);  // wave-uniform bound for the prune
-                const float lb = (row_bound(c, dy, dz) - g.slack) * g.h;
-                if (lb > 0.f && lb * lb > __uint_as_float((unsigned) (best >> 32))) continue;
+__device__ __forceinline__ float rl_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ unsigned rl_u(unsigned v, int lane) {
+    return (unsigned) __builtin_amdgcn_readlane((int) v, lane);
+}
+
+// Wave-cooperative version of scan_box for ONE query (q, r, best are wave-uniform):
+// the (y,z) rows of the box are first resolved to point ranges by up to 64 lanes in
+// parallel (one memory round trip), then every row is streamed by all 64 lanes with
+// coalesced float4 loads.  Used for queries far from their neighbour, whose scans
+// would otherwise serialise thousands of dependent loads in one lane.
+__device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, float qx, float qy,
+                                                            float qz, float r,
+                                                            unsigned long long best, unsigned lane,
+                                                            float *margin) {
+    const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
+    const float rc = r * g.inv_h + g.slack;
+    const float big = 4.0e6f;
+    const int x0 = (int) floorf(fminf(fmaxf(fx - rc, -big), big));
+    const int x1 = (int) floorf(fminf(fmaxf(fx + rc, -big), big));
+    const int y0 = (int) floorf(fminf(fmaxf(fy - rc, -big), big));
+    const int y1 = (int) floorf(fminf(fmaxf(fy + rc, -big), big));
+    const int z0 = (int) floorf(fminf(fmaxf(fz - rc, -big), big));
+    const int z1 = (int) floorf(fminf(fmaxf(fz + rc, -big), big));
+    const float mx = fminf(fx - (float) x0, (float) (x1 + 1) - fx);
+    const float my = fminf(fy - (float) y0, (float) (y1 + 1) - fy);
+    const float mz = fminf(fz - (float) z0, (float) (z1 + 1) - fz);
+    *margin = (fminf(mx, fminf(my, mz)) - g.slack) * g.h;
+    const int xa = max(x0, 0), xb = min(x1, g.nx - 1);
+    const int ya = max(y0, 0), yb = min(y1, g.ny - 1);
+    const int za = max(z0, 0), zb = min(z1, g.nz - 1);
+    if (xa > xb || ya > yb || za > zb) return best;
+    const int cy = (int) floorf(fminf(fmaxf(fy, -big), big));
+    const int cz = (int) floorf(fminf(fmaxf(fz, -big), big));
+    const int wy = yb - ya + 1;
+    const int nrows = wy * (zb - za + 1);
+    const float bd2 = __uint_as_float((unsigned) (best >> 32));
+    unsigned long long mine = best;
+    for (int k0 = 0; k0 < nrows; k0 += 64) {
+        // lanes resolve up to 64 rows at once
+        const int k = k0 + (int) lane;
+        unsigned s = 0, e = 0;
+        if (k < nrows) {
+            const int yy = ya + k % wy, zz = za + k / wy;
+            const float ry = yy > cy ? (float) yy - fy : (yy < cy ? fy - (float) (yy + 1) : 0.f);
+            const float rz = zz > cz ? (float) zz - fz : (zz < cz ? fz - (float) (zz + 1) : 0.f);
+            const float lb = (sqrtf(ry * ry + rz * rz) - g.slack) * g.h;
+            if (!(lb > 0.f && lb * lb > bd2)) {
                 const size_t base = ((size_t) zz * g.ny + yy) * g.nx;
-                const unsigned s = g.cell_start[base + x0];
-                const unsigned e = g.cell_start[base + x1 + 1];
-                for (unsigned j = s + lane; j < e; j += 64u) {
-                    const float4 t = g.pts[j];
-                    const unsigned long long k =
-                        make_key(canon_d2(qx, qy, qz, t), __float_as_uint(t.w));
-                    best = k < best ? k : best;
-                }
+                s = g.cell_start[base + xa];
+                e = g.cell_start[base + xb + 1];
             }
         }
-        best = wave_min_u64(best);
-        if (lane == 0) {
-            keys[i] = best;
-            if (!last_level &&
-                !certified(g, c, __uint_as_float((unsigned) (best >> 32)), thr_d2)) {
-                const unsigned slot = atomicAdd(qout_count, 1u);
-                qout[slot] = i;
+        unsigned long long rows = __ballot(e > s);
+        while (rows) {
+            const int rl = __ffsll((long long) rows) - 1;
+            rows &= rows - 1;
+            const unsigned rs = rl_u(s, rl), re = rl_u(e, rl);
+            for (unsigned j = rs + lane; j < re; j += 128u) {
+                const float4 t0 = g.pts[j];
+                const unsigned j1 = j + 64u < re ? j + 64u : j;
+                const float4 t1 = g.pts[j1];
+                const unsigned long long a = make_key(canon_d2(qx, qy, qz, t0), __float_as_uint(t0.w));
+                const unsigned long long b = make_key(canon_d2(qx, qy, qz, t1), __float_as_uint(t1.w));
+                const unsigned long long m = a < b ? a : b;
+                mine = m < mine ? m : mine;
             }
         }
     }
+    return wave_min_u64(mine);
+}
+
+// One lane per query: a certified radius search over a ladder of uniform grids
+// (cell size x2 per level).
+//   r <- the distance this query found in the previous iteration (x1.25), or half a
+//        fine cell on the first pass;
+//   repeat: scan the box of cells covering ball(q, r) on the finest level whose cell
+//           size is >= r; certified when best <= margin(box) or the box already
+//           covers max_corr; otherwise r <- best (if something was found: the next
+//           scan is then certain to certify) or 2r.
+// Light scans (r within ~a fine cell: every query once the clouds are roughly aligned)
+// run in the query's own lane.  Heavy scans are handed to the whole wavefront, one
+// query at a time (coop_scan_box), seeded with the radius its Morton neighbour needed.
+// The radius and level choices change the work, never the result.
+__global__ void __launch_bounds__(kBlock)
+    k_nn_grid(const LevelsDev *__restrict__ lv, const float4 *__restrict__ src, unsigned n,
+              IcpDevState *__restrict__ st, float thr_d2, unsigned long long *__restrict__ keys) {
+    if (st->done) return;
+    const unsigned i = xcd_remap(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63u;
+    const bool active = i < n;
+    const int L = lv->n;
+    const float h0 = lv->g[0].h;
+    const float rmax = sqrtf(thr_d2) * 1.0001f + 1e-6f;
+    const float r_light = 1.25f * h0;  // lane-serial scans stay within ~3^3 fine cells
+    float qx = 0.f, qy = 0.f, qz = 0.f, r = 0.f;
+    unsigned long long best = make_key(thr_d2, kNoIdx);
+    bool heavy = false;
+    if (active) {
+        const float4 p = src[i];
+        xform(st->Tf, p, qx, qy, qz);
+        r = 0.5f * h0;
+        if (st->have_prev) {
+            const float d2p = __uint_as_float((unsigned) (keys[i] >> 32));  // thr when unmatched
+            r = fmaxf(1.25f * sqrtf(d2p), 0.1f * h0);
+        }
+        r = fminf(r, rmax);
+        heavy = r > r_light;
+        while (!heavy) {
+            const GridDev g = lv->g[0];
+            float margin;
+            best = scan_box(g, qx, qy, qz, r, best, &margin);
+            const float bd2 = __uint_as_float((unsigned) (best >> 32));
+            if (margin > 0.f && (bd2 <= margin * margin || thr_d2 <= margin * margin)) break;
+            r = ((unsigned) best != kNoIdx) ? sqrtf(bd2) * 1.0001f + 1e-6f : 2.0f * r;
+            r = fminf(r, rmax);
+            heavy = r > r_light;
+        }
+    }
+    // ---- cooperative phase: the wave takes its heavy queries one at a time
+    unsigned long long todo = __ballot(heavy);
+    const unsigned n_heavy = __popcll(todo);
+    float seed = 0.f;  // radius the previous heavy query of this wave ended with
+    while (todo) {
+        const int sl = __ffsll((long long) todo) - 1;
+        todo &= todo - 1;
+        const float ux = rl_f(qx, sl), uy = rl_f(qy, sl), uz = rl_f(qz, sl);
+        float ur = rl_f(r, sl);
+        unsigned long long ub = ((unsigned long long) rl_u((unsigned) (best >> 32), sl) << 32) |
+                                rl_u((unsigned) best, sl);
+        if ((unsigned) ub == kNoIdx && seed > ur) ur = fminf(seed, rmax);  // neighbour's radius
+        for (;;) {
+            int l = 0;
+            while (l < L - 1 && lv->g[l].h < ur) ++l;
+            const GridDev g = lv->g[l];
+            float margin;
+            ub = coop_scan_box(g, ux, uy, uz, ur, ub, lane, &margin);
+            const float bd2 = __uint_as_float((unsigned) (ub >> 32));
+            if (margin > 0.f && (bd2 <= margin * margin || thr_d2 <= margin * margin)) break;
+            if (ur >= rmax) break;
+            ur = ((unsigned) ub != kNoIdx) ? sqrtf(bd2) * 1.0001f + 1e-6f : 2.0f * ur;
+            ur = fminf(ur, rmax);
+        }
+        seed = ((unsigned) ub != kNoIdx) ? 1.25f * sqrtf(__uint_as_float((unsigned) (ub >> 32))) : ur;
+        if ((int) lane == sl) best = ub;
+    }
+    if (active) keys[i] = best;
+    if (lane == 0 && n_heavy) atomicAdd(&st->queue_count[1], n_heavy);  // stats only
 }
 
 // ----------------------------------------------------------- brute force
@@ -258,24 +387,15 @@ float threshold_d2(double max_corr) {
 int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2) {
     const unsigned n = (unsigned) ctx->n_src;
     if (n == 0) return WM_OK;
-    const IcpDevState *st = ctx->d_state.as<IcpDevState>();
+    IcpDevState *st = ctx->d_state.as<IcpDevState>();
     unsigned long long *keys = ctx->keys.as<unsigned long long>();
-    unsigned *qcount = const_cast<unsigned *>(st->queue_count);
-    unsigned *qa = ctx->queue_a.as<unsigned>(), *qb = ctx->queue_b.as<unsigned>();
-    const int L = ctx->n_levels;
     unsigned blocks = (n + kBlock - 1) / kBlock;
     blocks = (blocks + 7u) & ~7u;  // xcd_remap needs a multiple of 8
     if (ev0) WM_HIP(ctx, hipEventRecord(ev0, ctx->stream));
-    hipLaunchKernelGGL(k_nn_grid_thread, dim3(blocks), dim3(kBlock), 0, ctx->stream,
-                       ctx->levels[0].d, ctx->src_sorted.as<float4>(), n, st, thr_d2, keys, qa,
-                       qcount + 1, L == 1 ? 1 : 0);
+    hipLaunchKernelGGL(k_nn_grid, dim3(blocks), dim3(kBlock), 0, ctx->stream,
+                       ctx->d_levels.as<LevelsDev>(), ctx->src_sorted.as<float4>(), n, st, thr_d2,
+                       keys);
     if (ev1) WM_HIP(ctx, hipEventRecord(ev1, ctx->stream));
-    for (int l = 1; l < L; ++l) {
-        unsigned *qin = (l & 1) ? qa : qb, *qout = (l & 1) ? qb : qa;
-        hipLaunchKernelGGL(k_nn_grid_wave, dim3(2048), dim3(kBlock), 0, ctx->stream,
-                           ctx->levels[l].d, ctx->src_sorted.as<float4>(), st, thr_d2, keys, qin,
-                           qcount + l, qout, qcount + l + 1, l == L - 1 ? 1 : 0);
-    }
     if (ev2) WM_HIP(ctx, hipEventRecord(ev2, ctx->stream));
     WM_HIP(ctx, hipGetLastError());
     return WM_OK;

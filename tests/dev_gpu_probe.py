@@ -16,6 +16,7 @@ for h in cells:
     t0 = time.time(); ctx.set_source(ref); t1 = time.time(); ctx.set_target(tgt); t2 = time.time()
     for rep in range(3):
         r = ctx.icp_align(max_corr=3.0, force_iterations=iters, nn_method=capi.WM_NN_GRID, profile=2)
+    print("  per-iter nn us:", " ".join("%.0f" % (x*1e3) for x in ctx.iteration_times()))
     r2 = ctx.icp_align(max_corr=3.0, force_iterations=iters, nn_method=capi.WM_NN_GRID, profile=0)
     print("cell=%.3f (used %.3f) levels=%d set_source %.1f ms set_target %.1f ms" % (h, r["grid_cell"], r["nn_levels"], (t1-t0)*1e3, (t2-t1)*1e3))
     print("  profile: align %.2f ms nn %.2f coarse %.2f stats %.2f solve %.2f ms; per-iter nn %.1f us; deferred %d" % (
