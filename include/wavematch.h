@@ -131,6 +131,30 @@ void wm_icp_default_params(wm_icp_params *p);
  * otherwise (T_out then untouched, as ICPMatcher leaves `result`). */
 int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_stats *stats);
 
+/* ICPMatcher::match() in one call (wave_matching/src/icp.cpp:75-133): with both
+ * caller clouds as inputs, runs the reference's three branches entirely on device
+ *   res > 0 && multiscale_steps > 0 : for i = steps..0: leaf = 2^i * res, VoxelGrid
+ *        both clouds, pre-transform the filtered ref by the running transform,
+ *        max_corr = 2^i * p->max_corr, align, running = T_i * running  (icp.cpp:77-104)
+ *   res > 0 && multiscale_steps == 0: VoxelGrid both clouds, align    (icp.cpp:105-122)
+ *   res <= 0                         : align on the full clouds       (icp.cpp:123-131)
+ * Returns WM_OK and writes T_out only when every align converged (as match() does). */
+int wm_icp_match(wm_ctx *ctx, const void *ref, size_t n_ref, const void *target, size_t n_target,
+                 size_t stride_bytes, int mem, const wm_icp_params *p, float res,
+                 int multiscale_steps, double T_out[16], wm_icp_stats *stats);
+
+/* pcl::VoxelGrid<PointXYZ>::filter on device (icp.cpp:81-90,106-113; gicp.cpp:39-40,
+ * 49-50): float centroid per occupied leaf, ascending leaf index; `out` must hold
+ * `cap` points of `out_stride` bytes. */
+int wm_voxel_downsample(wm_ctx *ctx, const void *pts, size_t n, size_t stride_bytes, int mem,
+                        float leaf, void *out, size_t out_stride, int out_mem, size_t cap,
+                        size_t *n_out);
+
+/* pcl::transformPointCloud(in, out, Eigen::Affine3d) on device (icp.cpp:84-86; every
+ * reference test fixture, tests/icp_tests.cpp:31): double arithmetic, float store. */
+int wm_transform_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride_bytes, int mem,
+                       const double T[16], void *out, size_t out_stride, int out_mem);
+
 /* Per-iteration device time (ms) of the correspondence kernel in the last
  * wm_icp_align call that ran with profile >= 1; returns the number written. */
 int wm_get_iteration_times(wm_ctx *ctx, float *nn_ms, int cap);

@@ -71,6 +71,14 @@ def lib():
         L.wm_icp_default_params.argtypes = [C.POINTER(IcpParams)]
         L.wm_icp_default_params.restype = None
         L.wm_icp_align.argtypes = [C.c_void_p, C.POINTER(IcpParams), _dp, C.POINTER(IcpStats)]
+        L.wm_icp_match.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                   C.c_size_t, C.c_int, C.POINTER(IcpParams), C.c_float, C.c_int,
+                                   _dp, C.POINTER(IcpStats)]
+        L.wm_voxel_downsample.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
+                                          C.c_float, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t,
+                                          C.POINTER(C.c_size_t)]
+        L.wm_transform_cloud.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
+                                         _dp, C.c_void_p, C.c_size_t, C.c_int]
         L.wm_get_iteration_times.argtypes = [C.c_void_p, _fp, C.c_int]
         L.wm_get_correspondences.argtypes = [C.c_void_p, _ip, _fp, C.c_size_t]
         L.wm_nn_search.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int, _ip, _fp, C.c_size_t, _fp]
@@ -178,6 +186,48 @@ class Context:
                     nn_ms=s.nn_ms, coarse_ms=s.coarse_ms, stats_ms=s.stats_ms, solve_ms=s.solve_ms,
                     nn_launches=s.nn_launches, nn_levels=s.nn_levels, deferred=s.deferred,
                     grid_cell=s.grid_cell)
+
+    @staticmethod
+    def _stats_dict(rc, T, s):
+        return dict(rc=rc, T=T if rc == WM_OK else None, converged=bool(s.converged),
+                    iterations=s.iterations, state=CONV_NAMES.get(s.state, s.state),
+                    n_corr=s.n_corr, mse=s.mse, prev_mse=s.prev_mse, align_ms=s.align_ms,
+                    nn_ms=s.nn_ms, coarse_ms=s.coarse_ms, stats_ms=s.stats_ms,
+                    solve_ms=s.solve_ms, nn_launches=s.nn_launches, nn_levels=s.nn_levels,
+                    deferred=s.deferred, grid_cell=s.grid_cell)
+
+    def icp_match(self, ref, target, res=-1.0, multiscale_steps=0, params=None, **kw):
+        """ICPMatcher::match() (icp.cpp:75-133) in one C-ABI call."""
+        p = params or icp_params(**kw)
+        pr, nr, sr, mr, k1 = _cloud_arg(ref)
+        pt, nt, stt, mt, k2 = _cloud_arg(target)
+        assert sr == stt and mr == mt
+        T = np.zeros((4, 4), np.float64)
+        s = IcpStats()
+        rc = self._check(lib().wm_icp_match(self._h, C.c_void_p(pr), nr, C.c_void_p(pt), nt, sr, mr,
+                                            C.byref(p), C.c_float(res), int(multiscale_steps),
+                                            T.ctypes.data_as(_dp), C.byref(s)), "wm_icp_match")
+        self.n_src, self.n_tgt = self.sizes()
+        return self._stats_dict(rc, T, s)
+
+    def voxel_downsample(self, cloud, leaf):
+        ptr, n, stride, mem, keep = _cloud_arg(cloud)
+        out = np.empty((max(n, 1), 3), np.float32)
+        m = C.c_size_t(0)
+        self._check(lib().wm_voxel_downsample(self._h, C.c_void_p(ptr), n, stride, mem,
+                                              C.c_float(leaf), C.c_void_p(out.ctypes.data), 12,
+                                              WM_MEM_HOST, len(out), C.byref(m)),
+                    "wm_voxel_downsample")
+        return out[:m.value].copy()
+
+    def transform_cloud(self, cloud, T):
+        ptr, n, stride, mem, keep = _cloud_arg(cloud)
+        T = np.ascontiguousarray(T, np.float64)
+        out = np.empty((n, 3), np.float32)
+        self._check(lib().wm_transform_cloud(self._h, C.c_void_p(ptr), n, stride, mem,
+                                             T.ctypes.data_as(_dp), C.c_void_p(out.ctypes.data), 12,
+                                             WM_MEM_HOST), "wm_transform_cloud")
+        return out
 
     def iteration_times(self, cap=1024):
         buf = np.zeros(cap, np.float32)

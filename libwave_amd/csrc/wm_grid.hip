@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(kBlock) k_scan_add(unsigned *out, size_t n,
 }
 
 // out must hold n+1 entries
-static int exclusive_scan(wm_ctx *ctx, const unsigned *in, size_t n, unsigned *out) {
+int exclusive_scan(wm_ctx *ctx, const unsigned *in, size_t n, unsigned *out) {
     size_t ntiles = (n + kScanTile - 1) / kScanTile;
     WM_HIP(ctx, ctx->block_sums.reserve((ntiles + 2) * sizeof(unsigned)));
     unsigned *sums = ctx->block_sums.as<unsigned>();

@@ -408,7 +408,9 @@ void wm_ctx_destroy(wm_ctx *ctx) {
     (void) hipSetDevice(ctx->device);
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->src_sorted, &ctx->tgt_orig, &ctx->staging, &ctx->cell_of, &ctx->counts,
-                      &ctx->block_sums, &ctx->bbox_buf, &ctx->keys, &ctx->d_levels,
+                      &ctx->block_sums, &ctx->bbox_buf, &ctx->keys, &ctx->d_levels, &ctx->vg_idx, &ctx->vg_idx2, &ctx->vg_perm,
+                      &ctx->vg_perm2, &ctx->vg_tmp, &ctx->vg_seg, &ctx->io_a, &ctx->io_b, &ctx->ds_ref,
+                      &ctx->ds_tgt, &ctx->match_ref, &ctx->match_tgt,
                       &ctx->partials, &ctx->corr_tmp_idx, &ctx->corr_tmp_d2, &ctx->d_state};
     for (DevBuf *b : bufs) b->release();
     for (auto &l : ctx->levels) {
@@ -625,6 +627,65 @@ static int unpack_correspondences(wm_ctx *ctx, int32_t *match_idx, float *d2, si
         WM_HIP(ctx, hipMemcpyAsync(d2, ctx->corr_tmp_d2.p, n_in * sizeof(float),
                                    hipMemcpyDeviceToHost, ctx->stream));
     WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WM_OK;
+}
+
+int wm_icp_match(wm_ctx *ctx, const void *ref, size_t n_ref, const void *target, size_t n_target,
+                 size_t stride, int mem, const wm_icp_params *p, float res, int multiscale_steps,
+                 double T_out[16], wm_icp_stats *stats) {
+    if (!ctx || !p || !T_out || (n_ref > 0 && !ref) || (n_target > 0 && !target) || stride < 12 ||
+        (stride & 3) || n_ref > 0x7FFFFFF0u || n_target > 0x7FFFFFF0u)
+        return WM_ERR_ARG;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!(res > 0)) {  // icp.cpp:123-131
+        WM_TRY(wm_set_source(ctx, ref, n_ref, stride, mem));
+        WM_TRY(wm_set_target(ctx, target, n_target, stride, mem));
+        return wm_icp_align(ctx, p, T_out, stats);
+    }
+    const size_t cap_r = n_ref > 0 ? n_ref : 1, cap_t = n_target > 0 ? n_target : 1;
+    WM_HIP(ctx, ctx->match_ref.reserve(cap_r * sizeof(float4)));
+    WM_HIP(ctx, ctx->match_tgt.reserve(cap_t * sizeof(float4)));
+    WM_HIP(ctx, ctx->ds_ref.reserve(cap_r * sizeof(float4)));
+    WM_HIP(ctx, ctx->ds_tgt.reserve(cap_t * sizeof(float4)));
+    float4 *d_ref = ctx->match_ref.as<float4>(), *d_tgt = ctx->match_tgt.as<float4>();
+    float4 *ds_ref = ctx->ds_ref.as<float4>(), *ds_tgt = ctx->ds_tgt.as<float4>();
+    WM_TRY(pack_cloud(ctx, ref, n_ref, stride, mem, d_ref));
+    WM_TRY(pack_cloud(ctx, target, n_target, stride, mem, d_tgt));
+    wm_icp_params prm = *p;
+    wm_icp_stats last, total;
+    memset(&total, 0, sizeof(total));
+    double running[16];
+    mat4_identity(running);
+    const int steps = multiscale_steps > 0 ? multiscale_steps : 0;
+    for (int i = steps; i >= 0; --i) {
+        const float leaf = (float) (pow(2, i) * res);  // icp.cpp:80
+        size_t nr = 0, nt = 0;
+        WM_TRY(voxel_downsample_dev(ctx, d_ref, n_ref, leaf, ds_ref, &nr));
+        WM_TRY(voxel_downsample_dev(ctx, d_tgt, n_target, leaf, ds_tgt, &nt));
+        if (steps > 0) {
+            WM_TRY(transform_cloud_dev(ctx, ds_ref, nr, running, ds_ref));  // icp.cpp:84-86
+            prm.max_corr = pow(2, i) * p->max_corr;                          // icp.cpp:93-94
+        }
+        WM_TRY(wm_set_source(ctx, ds_ref, nr, sizeof(float4), WM_MEM_DEVICE));
+        WM_TRY(wm_set_target(ctx, ds_tgt, nt, sizeof(float4), WM_MEM_DEVICE));
+        double Ti[16];
+        const int rc = wm_icp_align(ctx, &prm, Ti, &last);
+        total.align_ms += last.align_ms;
+        total.nn_ms += last.nn_ms;
+        total.nn_launches += last.nn_launches;
+        if (stats) {
+            const float a = total.align_ms, b = total.nn_ms;
+            const int c = total.nn_launches;
+            *stats = last;
+            stats->align_ms = a;
+            stats->nn_ms = b;
+            stats->nn_launches = c;
+        }
+        if (rc != WM_OK) return rc;  // icp.cpp:96-98: fail fast, result untouched
+        mat4_mul(Ti, running, running);  // icp.cpp:99-101
+    }
+    memcpy(T_out, running, sizeof(running));
     return WM_OK;
 }
 

@@ -128,6 +128,7 @@ struct wm_ctx {
     // scratch
     wm::DevBuf staging, cell_of, counts, block_sums, bbox_buf;
     wm::DevBuf keys, partials, corr_tmp_idx, corr_tmp_d2, d_levels;
+    wm::DevBuf vg_idx, vg_idx2, vg_perm, vg_perm2, vg_tmp, vg_seg, io_a, io_b, ds_ref, ds_tgt, match_ref, match_tgt;
     wm::DevBuf d_state;
     wm::IcpDevState *h_state = nullptr;  // pinned
     bool have_corr = false;
@@ -152,6 +153,14 @@ int build_grid_level(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, f
 int morton_sort(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, float4 *out,
                 size_t *n_valid);
 int ensure_levels(wm_ctx *ctx, double max_corr);
+int exclusive_scan(wm_ctx *ctx, const unsigned *in, size_t n, unsigned *out);
+
+// ---- wm_voxel.hip
+// pcl::VoxelGrid on device: `in` is a packed float4 cloud (w = index, NaN = invalid);
+// writes centroids (float4, w = output index) to `out` (capacity >= n), count to *n_out
+int voxel_downsample_dev(wm_ctx *ctx, const float4 *in, size_t n, float leaf, float4 *out,
+                         size_t *n_out);
+int transform_cloud_dev(wm_ctx *ctx, const float4 *in, size_t n, const double T[16], float4 *out);
 
 // ---- wm_nn.hip
 int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2);

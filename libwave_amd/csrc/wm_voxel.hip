@@ -1,0 +1,238 @@
+// wm_voxel.hip -- pcl::VoxelGrid<PointXYZ>::filter and pcl::transformPointCloud on
+// device, as libwave's matchers use them before every align:
+//   wave_matching/src/icp.cpp:81-90,106-113   (filter both clouds, per scale)
+//   wave_matching/src/icp.cpp:84-86           (pre-transform the filtered ref)
+//   wave_matching/src/gicp.cpp:39-40,49-50
+// Semantics follow PCL 1.8 filters/impl/voxel_grid.hpp: leaf index
+// ijk = floor(p * (1/leaf)) - floor(min * (1/leaf)) in float, linear index
+// i + j*dx + k*dx*dy, one float centroid (sequential float sum, ascending point
+// index) per occupied leaf, output in ascending leaf-index order; non-finite points
+// are skipped; if dx*dy*dz overflows int32 the input is returned unfiltered.
+// The sort by leaf index is rocPRIM's stable radix sort (a plain library sort);
+// everything else is hand-written.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "wm_internal.hpp"
+
+namespace wm {
+
+__global__ void __launch_bounds__(kBlock)
+    k_vg_index(const float4 *__restrict__ in, unsigned n, float inv, int mbx, int mby, int mbz,
+               int dx, int dxy, unsigned *__restrict__ idx, unsigned *__restrict__ perm) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = in[i];
+    unsigned key = 0xFFFFFFFFu;  // invalid points sort to the end
+    if (p.x == p.x) {
+        const int i0 = (int) (floorf(__fmul_rn(p.x, inv)) - (float) mbx);
+        const int i1 = (int) (floorf(__fmul_rn(p.y, inv)) - (float) mby);
+        const int i2 = (int) (floorf(__fmul_rn(p.z, inv)) - (float) mbz);
+        key = (unsigned) (i0 + i1 * dx + i2 * dxy);
+    }
+    idx[i] = key;
+    perm[i] = i;
+}
+
+// head flag per sorted position (1 where a new leaf starts); invalid tail gets 0
+__global__ void __launch_bounds__(kBlock)
+    k_vg_flags(const unsigned *__restrict__ idx_sorted, unsigned n, unsigned *__restrict__ flags) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const unsigned k = idx_sorted[i];
+    flags[i] = (k != 0xFFFFFFFFu && (i == 0 || idx_sorted[i - 1] != k)) ? 1u : 0u;
+}
+
+// one lane per leaf: sequential float sum over its points in ascending point index
+__global__ void __launch_bounds__(kBlock)
+    k_vg_centroid(const float4 *__restrict__ in, const unsigned *__restrict__ idx_sorted,
+                  const unsigned *__restrict__ perm_sorted, const unsigned *__restrict__ seg,
+                  unsigned n, float4 *__restrict__ out) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const unsigned k = idx_sorted[i];
+    if (k == 0xFFFFFFFFu || (i > 0 && idx_sorted[i - 1] == k)) return;  // not a leaf head
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    unsigned j = i;
+    for (; j < n && idx_sorted[j] == k; ++j) {
+        const float4 p = in[perm_sorted[j]];
+        sx = __fadd_rn(sx, p.x);
+        sy = __fadd_rn(sy, p.y);
+        sz = __fadd_rn(sz, p.z);
+    }
+    const float cnt = (float) (j - i);
+    const unsigned o = seg[i];  // exclusive scan of the head flags = output slot
+    out[o] = make_float4(__fdiv_rn(sx, cnt), __fdiv_rn(sy, cnt), __fdiv_rn(sz, cnt),
+                         __uint_as_float(o));
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_copy_valid(const float4 *__restrict__ in, unsigned n, float4 *__restrict__ out) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) {
+        float4 p = in[i];
+        p.w = __uint_as_float(i);
+        out[i] = p;
+    }
+}
+
+int voxel_downsample_dev(wm_ctx *ctx, const float4 *in, size_t n, float leaf, float4 *out,
+                         size_t *n_out) {
+    *n_out = 0;
+    if (n == 0) return WM_OK;
+    if (!(leaf > 0)) return WM_ERR_ARG;
+    Bbox bb;
+    size_t valid = 0;
+    WM_TRY(compute_bbox(ctx, in, n, &bb, &valid));
+    if (valid == 0) return WM_OK;
+    const float inv = 1.0f / leaf;
+    const int64_t ex = (int64_t) ((bb.hi[0] - bb.lo[0]) * inv) + 1;
+    const int64_t ey = (int64_t) ((bb.hi[1] - bb.lo[1]) * inv) + 1;
+    const int64_t ez = (int64_t) ((bb.hi[2] - bb.lo[2]) * inv) + 1;
+    const unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
+    if (ex * ey * ez > (int64_t) INT32_MAX) {
+        // PCL: "Leaf size is too small for the input dataset" -> output = input
+        hipLaunchKernelGGL(k_copy_valid, dim3(blocks), dim3(kBlock), 0, ctx->stream, in,
+                           (unsigned) n, out);
+        WM_HIP(ctx, hipGetLastError());
+        *n_out = n;
+        return WM_OK;
+    }
+    int mb[3], db[3];
+    for (int d = 0; d < 3; ++d) {
+        mb[d] = (int) floorf(bb.lo[d] * inv);
+        db[d] = (int) floorf(bb.hi[d] * inv) - mb[d] + 1;
+    }
+    WM_HIP(ctx, ctx->vg_idx.reserve(n * 4));
+    WM_HIP(ctx, ctx->vg_idx2.reserve(n * 4));
+    WM_HIP(ctx, ctx->vg_perm.reserve(n * 4));
+    WM_HIP(ctx, ctx->vg_perm2.reserve(n * 4));
+    WM_HIP(ctx, ctx->vg_seg.reserve((n + 1) * 4));
+    unsigned *idx = ctx->vg_idx.as<unsigned>(), *idx2 = ctx->vg_idx2.as<unsigned>();
+    unsigned *perm = ctx->vg_perm.as<unsigned>(), *perm2 = ctx->vg_perm2.as<unsigned>();
+    unsigned *seg = ctx->vg_seg.as<unsigned>();
+    hipLaunchKernelGGL(k_vg_index, dim3(blocks), dim3(kBlock), 0, ctx->stream, in, (unsigned) n,
+                       inv, mb[0], mb[1], mb[2], db[0], db[0] * db[1], idx, perm);
+    size_t tmp_bytes = 0;
+    WM_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, idx, idx2, perm, perm2, n, 0, 32,
+                                          ctx->stream));
+    WM_HIP(ctx, ctx->vg_tmp.reserve(tmp_bytes));
+    WM_HIP(ctx, rocprim::radix_sort_pairs(ctx->vg_tmp.p, tmp_bytes, idx, idx2, perm, perm2, n, 0,
+                                          32, ctx->stream));
+    // head flags -> exclusive scan -> output slot per leaf; total = number of leaves
+    hipLaunchKernelGGL(k_vg_flags, dim3(blocks), dim3(kBlock), 0, ctx->stream, idx2, (unsigned) n,
+                       idx /* reuse as flags */);
+    WM_TRY(exclusive_scan(ctx, idx, n, seg));
+    hipLaunchKernelGGL(k_vg_centroid, dim3(blocks), dim3(kBlock), 0, ctx->stream, in, idx2, perm2,
+                       seg, (unsigned) n, out);
+    WM_HIP(ctx, hipGetLastError());
+    unsigned total = 0;
+    WM_HIP(ctx, hipMemcpyAsync(&total, seg + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = total;
+    return WM_OK;
+}
+
+// pcl::transformPointCloud(in, out, Eigen::Affine3d): double arithmetic
+// ((T00*x + T01*y) + T02*z) + T03, float store; non-finite points stay non-finite
+struct Mat34d {
+    double m[12];
+};
+
+__global__ void __launch_bounds__(kBlock)
+    k_transform_d(const float4 *__restrict__ in, unsigned n, Mat34d T, float4 *__restrict__ out) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = in[i];
+    const double x = p.x, y = p.y, z = p.z;
+    float4 o;
+    o.x = (float) __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(T.m[0], x), __dmul_rn(T.m[1], y)),
+                                      __dmul_rn(T.m[2], z)), T.m[3]);
+    o.y = (float) __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(T.m[4], x), __dmul_rn(T.m[5], y)),
+                                      __dmul_rn(T.m[6], z)), T.m[7]);
+    o.z = (float) __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(T.m[8], x), __dmul_rn(T.m[9], y)),
+                                      __dmul_rn(T.m[10], z)), T.m[11]);
+    o.w = p.w;
+    out[i] = o;
+}
+
+int transform_cloud_dev(wm_ctx *ctx, const float4 *in, size_t n, const double T[16], float4 *out) {
+    if (n == 0) return WM_OK;
+    Mat34d m;
+    for (int k = 0; k < 12; ++k) m.m[k] = T[k];
+    hipLaunchKernelGGL(k_transform_d, dim3((unsigned) ((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       ctx->stream, in, (unsigned) n, m, out);
+    WM_HIP(ctx, hipGetLastError());
+    return WM_OK;
+}
+
+// float4 (device) -> caller layout (stride >= 12), host or device destination
+__global__ void __launch_bounds__(kBlock)
+    k_unpack(const float4 *__restrict__ in, unsigned n, size_t stride, unsigned char *out) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = in[i];
+    float *o = reinterpret_cast<float *>(out + (size_t) i * stride);
+    o[0] = p.x;
+    o[1] = p.y;
+    o[2] = p.z;
+    if (stride >= 16) o[3] = 1.0f;  // pcl::PointXYZ's padding member (data[3] = 1)
+}
+
+static int export_cloud(wm_ctx *ctx, const float4 *dev, size_t n, void *out, size_t stride, int mem) {
+    if (n == 0) return WM_OK;
+    unsigned char *dst = static_cast<unsigned char *>(out);
+    if (mem == WM_MEM_HOST) {
+        WM_HIP(ctx, ctx->staging.reserve(n * stride));
+        dst = ctx->staging.as<unsigned char>();
+        if (stride > 16) WM_HIP(ctx, hipMemsetAsync(dst, 0, n * stride, ctx->stream));
+    }
+    hipLaunchKernelGGL(k_unpack, dim3((unsigned) ((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       ctx->stream, dev, (unsigned) n, stride, dst);
+    WM_HIP(ctx, hipGetLastError());
+    if (mem == WM_MEM_HOST)
+        WM_HIP(ctx, hipMemcpyAsync(out, dst, n * stride, hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WM_OK;
+}
+
+}  // namespace wm
+
+using namespace wm;
+
+extern "C" {
+
+int wm_voxel_downsample(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, float leaf,
+                        void *out, size_t out_stride, int out_mem, size_t cap, size_t *n_out) {
+    if (!ctx || !n_out || (n > 0 && (!pts || !out)) || stride < 12 || (stride & 3) ||
+        out_stride < 12 || (out_stride & 3) || !(leaf > 0) || n > 0x7FFFFFF0u)
+        return WM_ERR_ARG;
+    *n_out = 0;
+    if (n == 0) return WM_OK;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_HIP(ctx, ctx->io_a.reserve(n * sizeof(float4)));
+    WM_HIP(ctx, ctx->io_b.reserve(n * sizeof(float4)));
+    WM_TRY(pack_cloud(ctx, pts, n, stride, mem, ctx->io_a.as<float4>()));
+    size_t m = 0;
+    WM_TRY(voxel_downsample_dev(ctx, ctx->io_a.as<float4>(), n, leaf, ctx->io_b.as<float4>(), &m));
+    if (m > cap) return WM_ERR_ARG;
+    *n_out = m;
+    return export_cloud(ctx, ctx->io_b.as<float4>(), m, out, out_stride, out_mem);
+}
+
+int wm_transform_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem,
+                       const double T[16], void *out, size_t out_stride, int out_mem) {
+    if (!ctx || !T || (n > 0 && (!pts || !out)) || stride < 12 || (stride & 3) || out_stride < 12 ||
+        (out_stride & 3) || n > 0x7FFFFFF0u)
+        return WM_ERR_ARG;
+    if (n == 0) return WM_OK;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_HIP(ctx, ctx->io_a.reserve(n * sizeof(float4)));
+    WM_HIP(ctx, ctx->io_b.reserve(n * sizeof(float4)));
+    WM_TRY(pack_cloud(ctx, pts, n, stride, mem, ctx->io_a.as<float4>()));
+    WM_TRY(transform_cloud_dev(ctx, ctx->io_a.as<float4>(), n, T, ctx->io_b.as<float4>()));
+    return export_cloud(ctx, ctx->io_b.as<float4>(), n, out, out_stride, out_mem);
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+"""GPU parity: VoxelGrid, transformPointCloud and the whole ICPMatcher::match()
+(wave_matching/src/icp.cpp:75-133, all three branches) through the C ABI vs the oracle,
+on the reference's own fixture and test perturbations (tests/icp_tests.cpp)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import TOL_R, TOL_T, pose_error
+from libwave_amd import synth
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("leaf", [0.05, 0.1, 0.4, 0.8])
+def test_voxel_grid_bit_exact(ctx, oracle, testscan, leaf):
+    got = ctx.voxel_downsample(testscan, leaf)
+    want = oracle.voxel_grid(testscan, leaf)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)   # float centroids, same order: bit-identical
+
+
+def test_voxel_grid_synthetic_and_edge_cases(ctx, oracle):
+    pts = synth.scene(200000, seed=3)
+    assert np.array_equal(ctx.voxel_downsample(pts, 0.25), oracle.voxel_grid(pts, 0.25))
+    bad = pts[:5000].copy()
+    bad[::50, 0] = np.nan
+    assert np.array_equal(ctx.voxel_downsample(bad, 0.5), oracle.voxel_grid(bad, 0.5))
+    assert len(ctx.voxel_downsample(pts[:0], 0.1)) == 0
+    one = ctx.voxel_downsample(pts[:1], 0.1)
+    assert np.array_equal(one, pts[:1])
+    # index space overflows int32 -> PCL returns the input unfiltered
+    huge = np.array([[0, 0, 0], [3000, 3000, 3000]], np.float32)
+    assert np.array_equal(ctx.voxel_downsample(huge, 0.001), huge)
+
+
+def test_transform_cloud_bit_exact(ctx, oracle, testscan):
+    T = synth.make_T((0.2, -3.0, 1.5), (0.3, -0.2, 1.1))
+    assert np.array_equal(ctx.transform_cloud(testscan, T), oracle.transform_cloud_d(testscan, T))
+
+
+CASES = {  # name: (res, multiscale_steps, tx) -- wave_matching/tests/icp_tests.cpp
+    "fullResNullMatch": (-1.0, 0, 0.0),
+    "nullDisplacement": (0.05, 0, 0.0),
+    "smallDisplacement": (0.05, 0, 0.2),
+    "multiscale": (0.1, 3, 0.2),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_reference_icp_match_cases(wm, ctx, oracle, testscan, case):
+    res, steps, tx = CASES[case]
+    with open(os.path.join(HERE, "golden", "icp_golden.json")) as f:
+        gold = json.load(f)["cases"][case]
+    perturb = np.eye(4)
+    perturb[0, 3] = tx
+    target = oracle.transform_cloud_d(testscan, perturb)
+    got = ctx.icp_match(testscan, target, res=res, multiscale_steps=steps)
+    assert got["rc"] == 0 and got["converged"]
+    # the reference test's assertion (threshold, icp_tests.cpp:37)
+    assert np.linalg.norm(got["T"] - perturb) < 0.1
+    # parity with the oracle / the independent golden
+    want = oracle.IcpMatch(testscan, target, res=res, multiscale_steps=steps, incremental_float=0)
+    assert want.ok
+    assert got["iterations"] == want.r.iterations
+    dt, ang = pose_error(got["T"], want.T)
+    assert dt <= 1e-6 and ang <= 1e-7, (dt, ang)
+    dt, ang = pose_error(got["T"], np.array(gold["T"]))
+    assert dt <= 1e-6 and ang <= 1e-7
+    lit = oracle.IcpMatch(testscan, target, res=res, multiscale_steps=steps, incremental_float=1,
+                          float_sums=1)
+    dt, ang = pose_error(got["T"], lit.T)
+    assert dt <= TOL_T and ang <= TOL_R
+
+
+def test_match_on_synthetic_multiscale(wm, ctx, oracle):
+    ref, tgt, T_gt = synth.pair(60000, seed=5, mode="resample")
+    got = ctx.icp_match(ref, tgt, res=0.1, multiscale_steps=2, max_corr=3.0)
+    want = oracle.IcpMatch(ref, tgt, res=0.1, multiscale_steps=2, incremental_float=0)
+    assert got["rc"] == 0 and want.ok
+    dt, ang = pose_error(got["T"], want.T)
+    assert dt <= 1e-6 and ang <= 1e-7, (dt, ang)
+
+
+def test_match_failure_leaves_result_untouched(wm, ctx):
+    a = synth.scene(2000, seed=1)
+    got = ctx.icp_match(a, a + np.float32(100.0), res=0.5, multiscale_steps=1)
+    assert got["rc"] == wm.WM_TOO_FEW and got["T"] is None
