@@ -155,6 +155,22 @@ int wm_voxel_downsample(wm_ctx *ctx, const void *pts, size_t n, size_t stride_by
 int wm_transform_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride_bytes, int mem,
                        const double T[16], void *out, size_t out_stride, int out_mem);
 
+/* ICPMatcher's information-matrix estimators on the correspondences of the last
+ * align (wave_matching/src/icp.cpp:135-142):
+ *   WM_INFO_LUM     estimateLUM     icp_pcl_functions.cpp:182-289
+ *   WM_INFO_CENSI   estimateCensi   icp.cpp:167-397   (T_result = Matcher::result,
+ *                   lin/ang_covar = ICPMatcherParams::lidar_{lin,ang}_covar)
+ *   WM_INFO_LUMOLD  estimateLUMold  icp_pcl_functions.cpp:51-179  (fresh exact NN of
+ *                   the aligned cloud, d2 < max_corr^2)
+ * info is the 6x6 row-major result.  *degenerate (may be NULL) is set when the LUM
+ * residual s^2 underflows: LUM then yields identity, LUMold divides by it anyway
+ * (both as the reference does).  LUM / Censi return WM_NOT_CONVERGED and leave info
+ * untouched when the last align did not converge (the reference's hasConverged()
+ * guard). */
+enum { WM_INFO_LUM = 0, WM_INFO_CENSI = 1, WM_INFO_LUMOLD = 2 };
+int wm_icp_info(wm_ctx *ctx, int method, const double T_result[16], double lin_covar,
+                double ang_covar, double max_corr, double info[36], int *degenerate);
+
 /* Per-iteration device time (ms) of the correspondence kernel in the last
  * wm_icp_align call that ran with profile >= 1; returns the number written. */
 int wm_get_iteration_times(wm_ctx *ctx, float *nn_ms, int cap);

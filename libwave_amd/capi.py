@@ -17,6 +17,7 @@ WM_OK, WM_NOT_CONVERGED, WM_TOO_FEW = 0, 1, 2
 WM_MEM_HOST, WM_MEM_DEVICE = 0, 1
 WM_ICP_SVD, WM_ICP_GN6 = 0, 1
 WM_NN_AUTO, WM_NN_GRID, WM_NN_BRUTE = 0, 1, 2
+WM_INFO_LUM, WM_INFO_CENSI, WM_INFO_LUMOLD = 0, 1, 2
 WM_STATS_LEN = 32
 CONV_NAMES = {0: "NOT_CONVERGED", 1: "ITERATIONS", 2: "TRANSFORM", 3: "ABS_MSE", 4: "REL_MSE",
               5: "NO_CORRESPONDENCES", 6: "FORCED"}
@@ -79,6 +80,8 @@ def lib():
                                           C.POINTER(C.c_size_t)]
         L.wm_transform_cloud.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
                                          _dp, C.c_void_p, C.c_size_t, C.c_int]
+        L.wm_icp_info.argtypes = [C.c_void_p, C.c_int, _dp, C.c_double, C.c_double, C.c_double, _dp,
+                                  C.POINTER(C.c_int)]
         L.wm_get_iteration_times.argtypes = [C.c_void_p, _fp, C.c_int]
         L.wm_get_correspondences.argtypes = [C.c_void_p, _ip, _fp, C.c_size_t]
         L.wm_nn_search.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int, _ip, _fp, C.c_size_t, _fp]
@@ -228,6 +231,17 @@ class Context:
                                              T.ctypes.data_as(_dp), C.c_void_p(out.ctypes.data), 12,
                                              WM_MEM_HOST), "wm_transform_cloud")
         return out
+
+    def icp_info(self, method, T_result=None, lin_covar=2.5e-4, ang_covar=7.78e-9, max_corr=3.0):
+        """estimateLUM / estimateCensi / estimateLUMold on the last align's correspondences."""
+        info = np.zeros((6, 6), np.float64)
+        deg = C.c_int(0)
+        T = None if T_result is None else np.ascontiguousarray(T_result, np.float64)
+        rc = self._check(lib().wm_icp_info(self._h, int(method),
+                                           T.ctypes.data_as(_dp) if T is not None else None,
+                                           float(lin_covar), float(ang_covar), float(max_corr),
+                                           info.ctypes.data_as(_dp), C.byref(deg)), "wm_icp_info")
+        return rc, info, bool(deg.value)
 
     def iteration_times(self, cap=1024):
         buf = np.zeros(cap, np.float32)

@@ -360,6 +360,21 @@ static hipEvent_t get_event(wm_ctx *ctx, size_t k) {
     return ctx->ev_pool[k];
 }
 
+int nn_pass(wm_ctx *ctx, const double T[16], float thr_d2, double max_corr, bool predict) {
+    WM_TRY(prepare_work(ctx));
+    const bool brute = use_brute(ctx, WM_NN_AUTO) || ctx->n_tgt == 0;
+    if (!brute) WM_TRY(ensure_levels(ctx, max_corr));
+    init_state(ctx->h_state, T, nullptr, DBL_MAX);
+    ctx->h_state->have_prev = predict ? 1 : 0;
+    WM_TRY(upload_state(ctx));
+    if (brute)
+        WM_TRY(launch_nn_brute(ctx, thr_d2, nullptr, nullptr));
+    else
+        WM_TRY(launch_nn_grid(ctx, thr_d2, nullptr, nullptr, nullptr));
+    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WM_OK;
+}
+
 }  // namespace wm
 
 using namespace wm;
@@ -408,7 +423,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
     (void) hipSetDevice(ctx->device);
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->src_sorted, &ctx->tgt_orig, &ctx->staging, &ctx->cell_of, &ctx->counts,
-                      &ctx->block_sums, &ctx->bbox_buf, &ctx->keys, &ctx->d_levels, &ctx->vg_idx, &ctx->vg_idx2, &ctx->vg_perm,
+                      &ctx->block_sums, &ctx->bbox_buf, &ctx->keys, &ctx->keys_bak, &ctx->d_levels, &ctx->vg_idx, &ctx->vg_idx2, &ctx->vg_perm,
                       &ctx->vg_perm2, &ctx->vg_tmp, &ctx->vg_seg, &ctx->io_a, &ctx->io_b, &ctx->ds_ref,
                       &ctx->ds_tgt, &ctx->match_ref, &ctx->match_tgt,
                       &ctx->partials, &ctx->corr_tmp_idx, &ctx->corr_tmp_d2, &ctx->d_state};
@@ -564,6 +579,8 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
     const IcpDevState &s = *ctx->h_state;
     ctx->prev_mse = s.prev_mse;
     ctx->have_corr = true;
+    ctx->last_align_valid = true;
+    ctx->last_align_converged = s.converged != 0;
     memcpy(ctx->corr_T, s.T, sizeof(s.T));
     if (stats) {
         stats->converged = s.converged;
@@ -723,6 +740,7 @@ int wm_nn_search(wm_ctx *ctx, const double T[16], double max_corr, int nn_method
     WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (kernel_ms) (void) hipEventElapsedTime(kernel_ms, ctx->ev_a, ctx->ev_b);
     ctx->have_corr = true;
+    ctx->last_align_valid = false;
     memcpy(ctx->corr_T, T, sizeof(double) * 16);
     if (match_idx || d2) return unpack_correspondences(ctx, match_idx, d2, cap);
     return WM_OK;

@@ -131,7 +131,8 @@ struct wm_ctx {
     wm::DevBuf vg_idx, vg_idx2, vg_perm, vg_perm2, vg_tmp, vg_seg, io_a, io_b, ds_ref, ds_tgt, match_ref, match_tgt;
     wm::DevBuf d_state;
     wm::IcpDevState *h_state = nullptr;  // pinned
-    bool have_corr = false;
+    bool have_corr = false, last_align_valid = false, last_align_converged = false;
+    wm::DevBuf keys_bak;
     double corr_T[16];
 
     // carried PCL object state
@@ -166,5 +167,11 @@ int transform_cloud_dev(wm_ctx *ctx, const float4 *in, size_t n, const double T[
 int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2);
 int launch_nn_brute(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1);
 float threshold_d2(double max_corr);
+float threshold_d2_strict(double max_corr);
+
+// ---- wm_icp.hip
+// one correspondence pass with transform T; `predict` lets the search start from the
+// radii in the current keys
+int nn_pass(wm_ctx *ctx, const double T[16], float thr_d2, double max_corr, bool predict);
 
 }  // namespace wm

@@ -384,6 +384,15 @@ float threshold_d2(double max_corr) {
     return f;
 }
 
+// strict variant: accepted iff (double) d2 < max_corr^2 (estimateLUMold's gate)
+float threshold_d2_strict(double max_corr) {
+    const double m2 = max_corr * max_corr;
+    if (!(m2 < 3.0e38)) return 3.0e38f;
+    float f = (float) m2;
+    if ((double) f >= m2) f = nextafterf(f, 0.0f);
+    return f;
+}
+
 int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2) {
     const unsigned n = (unsigned) ctx->n_src;
     if (n == 0) return WM_OK;
