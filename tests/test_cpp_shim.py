@@ -1,0 +1,42 @@
+"""The reference's own gtest cases (wave_matching/tests/icp_tests.cpp,
+multi_matcher_tests.cpp), re-expressed in C++ against the drop-in wave:: API
+(tests/cpp/*.cpp), built by libwave_amd/host/Makefile and run as a binary."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "wave_matching_tests")
+
+
+def _run(filt=None, timeout=600):
+    import __graft_entry__ as g
+    g.build()
+    env = dict(os.environ, WAVE_TEST_ROOT=ROOT)
+    cmd = [BIN] + ([filt] if filt else [])
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_cpp_shim_builds_and_links():
+    import __graft_entry__ as g
+    g.build()
+    assert os.path.exists(BIN)
+    out = subprocess.run(["nm", "-D", "--defined-only",
+                          os.path.join(ROOT, "libwave_amd", "libwave_matching.so")],
+                         capture_output=True, text=True).stdout
+    for sym in ("ICPMatcher5matchEv", "ICPMatcher12estimateInfoEv", "ICPMatcherParamsC1ERKNSt"):
+        assert sym in out, sym
+
+
+def test_cpp_yaml_params_on_cpu():
+    r = _run("paramsFromYaml")
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_reference_gtest_cases_pass_on_gpu():
+    r = _run()
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 failed" in r.stdout
