@@ -57,6 +57,12 @@ const char *wm_last_error(const wm_ctx *ctx);
 /* library / build identification, e.g. "wavematch-hip 0.1 gfx950" */
 const char *wm_version(void);
 
+/* external != 0: adopt the caller's HIP stream (e.g. torch's current stream, so that
+ * collectives issued by the caller order correctly against this context's kernels);
+ * a NULL handle then means the default stream.  external == 0: back to the context's
+ * own stream.  The external stream is not owned. */
+int wm_ctx_set_stream(wm_ctx *ctx, void *hip_stream, int external);
+
 /* ---------------------------------------------------------------- clouds */
 /* wave `ref` == PCL source (the cloud that is moved / queried):
  *   icp.setInputSource  wave_matching/src/icp.cpp:87,110,125
@@ -201,6 +207,36 @@ int wm_icp_stats_for(wm_ctx *ctx, const double T[16], int mode, double stats[WM_
  * TransformationEstimationSVD / pcl::umeyama [PCL transformation_estimation_svd.hpp]. */
 int wm_umeyama_from_stats(const double stats[WM_STATS_LEN], double Tk_out[16]);
 int wm_gn6_from_stats(const double stats[WM_STATS_LEN], double Tk_out[16]);
+
+/* ---------------------------------------------- sharded registration (multi-GPU)
+ * One registration spread over the GPUs of a node, one process (rank) per GPU:
+ * every rank holds the full source cloud and the target points of one x-slab
+ * [x_lo - max_corr, x_hi + max_corr] (wm_set_target of that subset), handles the
+ * source points whose TRANSFORMED x falls into [x_lo, x_hi) (so each source point
+ * is handled by exactly one rank and its true neighbour within max_corr is in that
+ * rank's subset), and the WM_STATS_LEN-double statistics block is summed over ranks
+ * (RCCL all-reduce over xGMI) once per iteration; every rank then applies the same
+ * solve, so the transform never needs broadcasting.
+ *   wm_icp_shard_begin        reset the iteration state (like the start of align())
+ *   wm_icp_shard_local_stats  enqueue search + reduction; writes this rank's partial
+ *                             statistics to stats_dev (WM_STATS_LEN doubles in HBM)
+ *   <caller all-reduces stats_dev (sum) on a stream ordered after the ctx stream>
+ *   wm_icp_shard_apply        enqueue the solve + stopping rules from stats_dev
+ *   wm_icp_shard_poll         sync; report done / transform / statistics
+ * All enqueue calls are asynchronous on the context's stream (wm_ctx_set_stream). */
+int wm_icp_shard_begin(wm_ctx *ctx, const wm_icp_params *p, double x_lo, double x_hi);
+int wm_icp_shard_local_stats(wm_ctx *ctx, void *stats_dev);
+int wm_icp_shard_apply(wm_ctx *ctx, const void *stats_dev);
+int wm_icp_shard_poll(wm_ctx *ctx, int *done, double T_out[16], wm_icp_stats *stats);
+
+/* Host-only twin of the per-iteration solve + PCL stopping rules (no GPU touched):
+ * the very function the device runs after the all-reduce, callable on the CPU so
+ * that the sharded control flow can be exercised without a GPU. */
+typedef struct wm_host_icp wm_host_icp;
+int wm_host_icp_create(wm_host_icp **out, const wm_icp_params *p);
+void wm_host_icp_destroy(wm_host_icp *h);
+int wm_host_icp_apply(wm_host_icp *h, const double stats[WM_STATS_LEN]);
+int wm_host_icp_get(const wm_host_icp *h, int *done, double T_out[16], wm_icp_stats *stats);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,16 @@ def lib():
                                          _dp, C.c_void_p, C.c_size_t, C.c_int]
         L.wm_icp_info.argtypes = [C.c_void_p, C.c_int, _dp, C.c_double, C.c_double, C.c_double, _dp,
                                   C.POINTER(C.c_int)]
+        L.wm_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.wm_icp_shard_begin.argtypes = [C.c_void_p, C.POINTER(IcpParams), C.c_double, C.c_double]
+        L.wm_icp_shard_local_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.wm_icp_shard_apply.argtypes = [C.c_void_p, C.c_void_p]
+        L.wm_icp_shard_poll.argtypes = [C.c_void_p, C.POINTER(C.c_int), _dp, C.POINTER(IcpStats)]
+        L.wm_host_icp_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(IcpParams)]
+        L.wm_host_icp_destroy.argtypes = [C.c_void_p]
+        L.wm_host_icp_destroy.restype = None
+        L.wm_host_icp_apply.argtypes = [C.c_void_p, _dp]
+        L.wm_host_icp_get.argtypes = [C.c_void_p, C.POINTER(C.c_int), _dp, C.POINTER(IcpStats)]
         L.wm_get_iteration_times.argtypes = [C.c_void_p, _fp, C.c_int]
         L.wm_get_correspondences.argtypes = [C.c_void_p, _ip, _fp, C.c_size_t]
         L.wm_nn_search.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int, _ip, _fp, C.c_size_t, _fp]
@@ -243,6 +253,33 @@ class Context:
                                            info.ctypes.data_as(_dp), C.byref(deg)), "wm_icp_info")
         return rc, info, bool(deg.value)
 
+    # ---- sharded (multi-GPU) stepping
+    def set_stream(self, stream_ptr, external=True):
+        self._check(lib().wm_ctx_set_stream(self._h, C.c_void_p(stream_ptr), int(external)),
+                    "wm_ctx_set_stream")
+
+    def shard_begin(self, params, x_lo, x_hi):
+        self._check(lib().wm_icp_shard_begin(self._h, C.byref(params), float(x_lo), float(x_hi)),
+                    "wm_icp_shard_begin")
+
+    def shard_local_stats(self, dev_ptr):
+        self._check(lib().wm_icp_shard_local_stats(self._h, C.c_void_p(dev_ptr)),
+                    "wm_icp_shard_local_stats")
+
+    def shard_apply(self, dev_ptr):
+        self._check(lib().wm_icp_shard_apply(self._h, C.c_void_p(dev_ptr)), "wm_icp_shard_apply")
+
+    def shard_poll(self):
+        done = C.c_int(0)
+        T = np.zeros((4, 4), np.float64)
+        s = IcpStats()
+        rc = self._check(lib().wm_icp_shard_poll(self._h, C.byref(done), T.ctypes.data_as(_dp),
+                                                 C.byref(s)), "wm_icp_shard_poll")
+        d = self._stats_dict(rc, T, s)
+        d["T"] = T
+        d["done"] = bool(done.value)
+        return d
+
     def iteration_times(self, cap=1024):
         buf = np.zeros(cap, np.float32)
         n = lib().wm_get_iteration_times(self._h, buf.ctypes.data_as(_fp), cap)
@@ -273,6 +310,37 @@ class Context:
         self._check(lib().wm_icp_stats_for(self._h, T.ctypes.data_as(_dp), int(mode),
                                            st.ctypes.data_as(_dp)), "wm_icp_stats_for")
         return st
+
+
+class HostIcp:
+    """The per-iteration solve + PCL stopping rules on the host (wm_host_icp_*): the same
+    function the device runs after the all-reduce."""
+
+    def __init__(self, params):
+        self._h = C.c_void_p()
+        rc = lib().wm_host_icp_create(C.byref(self._h), C.byref(params))
+        if rc != WM_OK:
+            raise WmError("wm_host_icp_create failed")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().wm_host_icp_destroy(self._h)
+            self._h = None
+
+    def apply(self, stats):
+        st = np.ascontiguousarray(stats, np.float64)
+        assert st.size == WM_STATS_LEN
+        lib().wm_host_icp_apply(self._h, st.ctypes.data_as(_dp))
+
+    def get(self):
+        done = C.c_int(0)
+        T = np.zeros((4, 4), np.float64)
+        s = IcpStats()
+        lib().wm_host_icp_get(self._h, C.byref(done), T.ctypes.data_as(_dp), C.byref(s))
+        return dict(done=bool(done.value), T=T, converged=bool(s.converged),
+                    iterations=s.iterations, state=CONV_NAMES.get(s.state, s.state),
+                    n_corr=s.n_corr, mse=s.mse, rc=0 if s.converged or not done.value else
+                    (WM_TOO_FEW if s.state == 5 else WM_NOT_CONVERGED))
 
 
 def umeyama_from_stats(stats):

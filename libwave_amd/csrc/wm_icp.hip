@@ -148,52 +148,15 @@ __device__ __host__ inline void expand_stats(int mode, const double *a, double *
     }
 }
 
-// PHASE 1: sum partials -> st->stats.   PHASE 2: solve + criteria from st->stats.
-// Single GPU launches <1|2>; the sharded path launches <1>, all-reduces
-// st->stats over RCCL, then launches <2>.
-template <int PHASES>
-__global__ void __launch_bounds__(kBlock)
-    k_reduce_solve(const double *__restrict__ partials, int nblocks, IcpDevState *st) {
-    if (st->done) return;
-    constexpr int kRows = 15;  // 15 row-lanes x 17 components = 255 active threads
-    __shared__ double lds[kRows][kAcc];
-    if (PHASES & 1) {
-        const int c = threadIdx.x % kAcc, r = threadIdx.x / kAcc;
-        if (r < kRows) {
-            // 8 independent accumulators: keeps 8 loads in flight instead of one
-            // dependent load->add chain per partial (which costs a memory latency each)
-            double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            int b = r;
-            for (; b + 7 * kRows < nblocks; b += 8 * kRows) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) s[u] += partials[(size_t) (b + u * kRows) * kAcc + c];
-            }
-            for (int u = 0; b < nblocks; b += kRows, ++u) s[u] += partials[(size_t) b * kAcc + c];
-            lds[r][c] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double a[kAcc];
-#pragma unroll
-            for (int k = 0; k < kAcc; ++k) {
-                double t = 0;
-#pragma unroll
-                for (int sl = 0; sl < kRows; ++sl) t += lds[sl][k];
-                a[k] = t;
-            }
-            double ex[kStatsLen];
-            expand_stats(st->mode, a, ex);
-#pragma unroll
-            for (int k = 0; k < kStatsLen; ++k) st->stats[k] = ex[k];
-        }
-    }
-    if (!(PHASES & 2)) return;
-    if (threadIdx.x != 0) return;
+// The solve + stopping rules of one ICP iteration, from the (all-reduced) statistics.
+// Runs as lane 0 of k_reduce_solve on the GPU and as plain host code in
+// wm_host_icp_apply (the sharded path's CPU tests drive exactly this function).
+__host__ __device__ inline void icp_apply_stats(IcpDevState *st, const double *stats_in) {
 
     // work on a register copy: every st-> access is a global round trip
     double stats[kStatsLen];
 #pragma unroll
-    for (int k = 0; k < kStatsLen; ++k) stats[k] = st->stats[k];
+    for (int k = 0; k < kStatsLen; ++k) stats[k] = stats_in[k];
     const int mode = st->mode;
     const double n = stats[0];
     const double sd2 = mode == WM_ICP_SVD ? stats[kSvdSd2] : stats[kGnSd2];
@@ -263,6 +226,56 @@ __global__ void __launch_bounds__(kBlock)
         return;
     }
     st->prev_mse = mse;
+}
+
+// PHASE 1: sum partials -> st->stats.   PHASE 2: solve + criteria from st->stats.
+// Single GPU launches <1|2>; the sharded path launches <1>, all-reduces
+// st->stats over RCCL, then launches <2>.
+template <int PHASES>
+__global__ void __launch_bounds__(kBlock)
+    k_reduce_solve(const double *__restrict__ partials, int nblocks, IcpDevState *st,
+                   double *stats_io) {
+    if (st->done) return;
+    constexpr int kRows = 15;  // 15 row-lanes x 17 components = 255 active threads
+    __shared__ double lds[kRows][kAcc];
+    if (PHASES & 1) {
+        const int c = threadIdx.x % kAcc, r = threadIdx.x / kAcc;
+        if (r < kRows) {
+            // 8 independent accumulators: keeps 8 loads in flight instead of one
+            // dependent load->add chain per partial (which costs a memory latency each)
+            double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int b = r;
+            for (; b + 7 * kRows < nblocks; b += 8 * kRows) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s[u] += partials[(size_t) (b + u * kRows) * kAcc + c];
+            }
+            for (int u = 0; b < nblocks; b += kRows, ++u) s[u] += partials[(size_t) b * kAcc + c];
+            lds[r][c] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a[kAcc];
+#pragma unroll
+            for (int k = 0; k < kAcc; ++k) {
+                double t = 0;
+#pragma unroll
+                for (int sl = 0; sl < kRows; ++sl) t += lds[sl][k];
+                a[k] = t;
+            }
+            double ex[kStatsLen];
+            expand_stats(st->mode, a, ex);
+            double *dst = (PHASES == 1 && stats_io) ? stats_io : st->stats;
+#pragma unroll
+            for (int k = 0; k < kStatsLen; ++k) dst[k] = ex[k];
+        }
+    }
+    if (!(PHASES & 2)) return;
+    if (threadIdx.x != 0) return;
+    icp_apply_stats(st, (PHASES & 1) ? st->stats : (stats_io ? stats_io : st->stats));
+    if (!(PHASES & 1) && stats_io) {
+#pragma unroll
+        for (int k = 0; k < kStatsLen; ++k) st->stats[k] = stats_io[k];
+    }
 }
 
 // keys (source-sorted order) -> caller-order (match index, d2)
@@ -409,12 +422,23 @@ int wm_ctx_create(wm_ctx **out, int device) {
     if (!ctx) return WM_ERR_NOMEM;
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev_a) != hipSuccess || hipEventCreate(&ctx->ev_b) != hipSuccess) {
         delete ctx;
         return WM_ERR_HIP;
     }
+    ctx->stream = ctx->own_stream;
     *out = ctx;
+    return WM_OK;
+}
+
+int wm_ctx_set_stream(wm_ctx *ctx, void *hip_stream, int external) {
+    if (!ctx) return WM_ERR_ARG;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // NB: a NULL handle with external != 0 is the (legacy) default stream -- which is
+    // what torch.cuda.current_stream().cuda_stream returns unless a side stream is active
+    ctx->stream = external ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
     return WM_OK;
 }
 
@@ -436,7 +460,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
     for (hipEvent_t e : ctx->ev_pool) (void) hipEventDestroy(e);
     if (ctx->ev_a) (void) hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) (void) hipEventDestroy(ctx->ev_b);
-    if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream) (void) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
@@ -566,7 +590,7 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
             WM_TRY(launch_stats(ctx, p->mode));
             if (e2) WM_HIP(ctx, hipEventRecord(e2, ctx->stream));
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<3>), dim3(1), dim3(kBlock), 0,
-                               ctx->stream, ctx->partials.as<double>(), nb, dst);
+                               ctx->stream, ctx->partials.as<double>(), nb, dst, (double *) nullptr);
             if (e3) WM_HIP(ctx, hipEventRecord(e3, ctx->stream));
         }
         WM_HIP(ctx, hipGetLastError());
@@ -706,6 +730,148 @@ int wm_icp_match(wm_ctx *ctx, const void *ref, size_t n_ref, const void *target,
     return WM_OK;
 }
 
+// ------------------------------------------------ sharded (multi-GPU) stepping
+int wm_icp_shard_begin(wm_ctx *ctx, const wm_icp_params *p, double x_lo, double x_hi) {
+    if (!ctx || !p || !(p->max_corr > 0) || !(x_lo < x_hi)) return WM_ERR_ARG;
+    if (ctx->n_src_input == 0) return WM_ERR_STATE;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_TRY(prepare_work(ctx));
+    ctx->shard_brute = use_brute(ctx, p->nn_method) || ctx->n_tgt == 0;
+    if (!ctx->shard_brute) WM_TRY(ensure_levels(ctx, p->max_corr));
+    ctx->shard_thr = threshold_d2(p->max_corr);
+    ctx->shard_params = *p;
+    double I[16];
+    mat4_identity(I);
+    init_state(ctx->h_state, I, p, DBL_MAX);
+    ctx->h_state->slab_on = 1;
+    ctx->h_state->slab_lo = x_lo < -3.0e38 ? -INFINITY : (float) x_lo;
+    ctx->h_state->slab_hi = x_hi > 3.0e38 ? INFINITY : (float) x_hi;
+    WM_TRY(upload_state(ctx));
+    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->iter_nn_ms.clear();
+    ctx->shard_active = true;
+    return WM_OK;
+}
+
+int wm_icp_shard_local_stats(wm_ctx *ctx, void *stats_dev) {
+    if (!ctx || !stats_dev) return WM_ERR_ARG;
+    if (!ctx->shard_active) return WM_ERR_STATE;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->shard_params.profile) {
+        const size_t k = ctx->iter_nn_ms.size();
+        e0 = get_event(ctx, 2 * k);
+        e1 = get_event(ctx, 2 * k + 1);
+        ctx->iter_nn_ms.push_back(-1.f);
+    }
+    if (ctx->n_src > 0) {
+        if (ctx->shard_brute)
+            WM_TRY(launch_nn_brute(ctx, ctx->shard_thr, e0, e1));
+        else
+            WM_TRY(launch_nn_grid(ctx, ctx->shard_thr, e0, e1, nullptr));
+        WM_TRY(launch_stats(ctx, ctx->shard_params.mode));
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<1>), dim3(1), dim3(kBlock), 0, ctx->stream,
+                       ctx->partials.as<double>(), ctx->n_src > 0 ? stat_blocks(ctx->n_src) : 0,
+                       ctx->d_state.as<IcpDevState>(), static_cast<double *>(stats_dev));
+    WM_HIP(ctx, hipGetLastError());
+    return WM_OK;
+}
+
+int wm_icp_shard_apply(wm_ctx *ctx, const void *stats_dev) {
+    if (!ctx || !stats_dev) return WM_ERR_ARG;
+    if (!ctx->shard_active) return WM_ERR_STATE;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<2>), dim3(1), dim3(kBlock), 0, ctx->stream,
+                       (const double *) nullptr, 0, ctx->d_state.as<IcpDevState>(),
+                       const_cast<double *>(static_cast<const double *>(stats_dev)));
+    WM_HIP(ctx, hipGetLastError());
+    return WM_OK;
+}
+
+int wm_icp_shard_poll(wm_ctx *ctx, int *done, double T_out[16], wm_icp_stats *stats) {
+    if (!ctx) return WM_ERR_ARG;
+    if (!ctx->shard_active) return WM_ERR_STATE;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_TRY(download_state(ctx));
+    const IcpDevState &s = *ctx->h_state;
+    if (done) *done = s.done;
+    if (T_out) memcpy(T_out, s.T, sizeof(s.T));
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->converged = s.converged;
+        stats->iterations = s.iter;
+        stats->state = s.state;
+        stats->n_corr = s.n_corr;
+        stats->mse = s.mse;
+        stats->prev_mse = s.prev_mse;
+        stats->deferred = s.deferred_total;
+        stats->nn_levels = ctx->shard_brute ? 0 : ctx->n_levels;
+        stats->grid_cell = ctx->shard_brute ? 0.f : ctx->levels[0].d.h;
+        if (ctx->shard_params.profile) {
+            for (size_t k = 0; k < ctx->iter_nn_ms.size(); ++k) {
+                float ms = 0;
+                if (ctx->n_src > 0 &&
+                    hipEventElapsedTime(&ms, ctx->ev_pool[2 * k], ctx->ev_pool[2 * k + 1]) == hipSuccess) {
+                    ctx->iter_nn_ms[k] = ms;
+                    stats->nn_ms += ms;
+                    stats->nn_launches += 1;
+                }
+            }
+        }
+    }
+    if (s.done) {
+        ctx->have_corr = true;
+        ctx->last_align_valid = true;
+        ctx->last_align_converged = s.converged != 0;
+        memcpy(ctx->corr_T, s.T, sizeof(s.T));
+    }
+    if (s.state == WM_CONV_NO_CORRESPONDENCES) return WM_TOO_FEW_CORRESPONDENCES;
+    if (s.done && !s.converged) return WM_NOT_CONVERGED;
+    return WM_OK;
+}
+
+// ------------------------------------------------ host-only ICP state machine
+struct wm_host_icp {
+    IcpDevState st;
+};
+
+int wm_host_icp_create(wm_host_icp **out, const wm_icp_params *p) {
+    if (!out || !p) return WM_ERR_ARG;
+    wm_host_icp *h = new (std::nothrow) wm_host_icp();
+    if (!h) return WM_ERR_NOMEM;
+    double I[16];
+    mat4_identity(I);
+    init_state(&h->st, I, p, DBL_MAX);
+    *out = h;
+    return WM_OK;
+}
+
+void wm_host_icp_destroy(wm_host_icp *h) { delete h; }
+
+int wm_host_icp_apply(wm_host_icp *h, const double stats[WM_STATS_LEN]) {
+    if (!h || !stats) return WM_ERR_ARG;
+    if (h->st.done) return WM_OK;
+    icp_apply_stats(&h->st, stats);
+    return WM_OK;
+}
+
+int wm_host_icp_get(const wm_host_icp *h, int *done, double T_out[16], wm_icp_stats *stats) {
+    if (!h) return WM_ERR_ARG;
+    if (done) *done = h->st.done;
+    if (T_out) memcpy(T_out, h->st.T, sizeof(h->st.T));
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->converged = h->st.converged;
+        stats->iterations = h->st.iter;
+        stats->state = h->st.state;
+        stats->n_corr = h->st.n_corr;
+        stats->mse = h->st.mse;
+        stats->prev_mse = h->st.prev_mse;
+    }
+    return WM_OK;
+}
+
 int wm_get_iteration_times(wm_ctx *ctx, float *nn_ms, int cap) {
     if (!ctx || !nn_ms || cap < 0) return 0;
     int n = (int) ctx->iter_nn_ms.size();
@@ -759,7 +925,7 @@ int wm_icp_stats_for(wm_ctx *ctx, const double T[16], int mode, double stats[WM_
     WM_TRY(launch_stats(ctx, mode));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<1>), dim3(1), dim3(kBlock), 0, ctx->stream,
                        ctx->partials.as<double>(), stat_blocks(ctx->n_src),
-                       ctx->d_state.as<IcpDevState>());
+                       ctx->d_state.as<IcpDevState>(), (double *) nullptr);
     WM_HIP(ctx, hipGetLastError());
     WM_TRY(download_state(ctx));
     memcpy(stats, ctx->h_state->stats, sizeof(double) * WM_STATS_LEN);

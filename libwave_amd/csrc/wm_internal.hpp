@@ -95,6 +95,10 @@ struct IcpDevState {
     double mse, prev_mse;
     int iter, done, converged, state, n_corr, max_iter, forced, mode;
     int have_prev;  // keys[] hold the previous iteration's result (level prediction)
+    // sharded registration: this rank handles the source points whose transformed x
+    // lies in [slab_lo, slab_hi)
+    int slab_on;
+    float slab_lo, slab_hi;
     double rot_thr, trans_thr, fit_eps;
     unsigned queue_count[kMaxLevels + 1];
     unsigned long long deferred_total;
@@ -109,7 +113,7 @@ struct Bbox {
 // The opaque C handle.
 struct wm_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, own_stream = nullptr;
     std::string last_error;
 
     // source (wave `ref`): Morton-ordered float4, .w = caller's index
@@ -142,6 +146,12 @@ struct wm_ctx {
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     std::vector<float> iter_nn_ms;
+
+    // sharded (multi-GPU) stepping
+    bool shard_active = false;
+    wm_icp_params shard_params{};
+    float shard_thr = 0;
+    bool shard_brute = false;
 };
 
 namespace wm {

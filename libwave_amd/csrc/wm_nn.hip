@@ -281,13 +281,22 @@ __global__ void __launch_bounds__(kBlock)
     float qx = 0.f, qy = 0.f, qz = 0.f, r = 0.f;
     unsigned long long best = make_key(thr_d2, kNoIdx);
     bool heavy = false;
+    bool mine = active;
     if (active) {
         const float4 p = src[i];
         xform(st->Tf, p, qx, qy, qz);
+        // sharded registration: only the rank owning this x-slab handles the point
+        if (st->slab_on && !(qx >= st->slab_lo && qx < st->slab_hi)) mine = false;
+    }
+    if (active && !mine) best = ~0ull;  // "not mine": no match, and no radius prediction
+    if (mine) {
         r = 0.5f * h0;
         if (st->have_prev) {
-            const float d2p = __uint_as_float((unsigned) (keys[i] >> 32));  // thr when unmatched
-            r = fmaxf(1.25f * sqrtf(d2p), 0.1f * h0);
+            const unsigned long long prev = keys[i];
+            if (prev != ~0ull) {
+                const float d2p = __uint_as_float((unsigned) (prev >> 32));  // thr if unmatched
+                r = fmaxf(1.25f * sqrtf(d2p), 0.1f * h0);
+            }
         }
         r = fminf(r, rmax);
         heavy = r > r_light;
@@ -357,6 +366,7 @@ __global__ void __launch_bounds__(kBlock)
     const unsigned m0 = blockIdx.y * per, m1 = min(m0 + per, m);
     float qx = 0, qy = 0, qz = 0;
     if (i < n) xform(st->Tf, src[i], qx, qy, qz);
+    const bool mine = !(st->slab_on && !(qx >= st->slab_lo && qx < st->slab_hi));
     unsigned long long best = make_key(thr_d2, kNoIdx);
     for (unsigned t0 = m0; t0 < m1; t0 += kBruteTile) {
         const unsigned cnt = min((unsigned) kBruteTile, m1 - t0);
@@ -371,7 +381,7 @@ __global__ void __launch_bounds__(kBlock)
             best = key < best ? key : best;
         }
     }
-    if (i < n && best < make_key(thr_d2, kNoIdx)) atomicMin(&keys[i], best);
+    if (i < n && mine && best < make_key(thr_d2, kNoIdx)) atomicMin(&keys[i], best);
 }
 
 // largest float whose value, compared as PCL does ((double) d2 > max_corr^2 ->

@@ -1,0 +1,107 @@
+"""Sharding one registration over the GPUs of a node (host-side logic).
+
+north_star: "partition the target cloud across the 8 GPUs of one node with RCCL all-reduce
+over xGMI of the normal equations only".  Rank r indexes the target points of one x-slab
+plus a max_corr halo, handles the source points whose TRANSFORMED x falls in its slab (so
+every source point is handled by exactly one rank and its true neighbour within max_corr is
+in that rank's subset: exact, no per-point exchange), and the 32-double statistics block is
+summed over ranks once per iteration; every rank then applies the identical solve.
+
+The iteration driver (ShardedIcp) is engine-agnostic: bench.py runs it with GpuShardEngine
+(HIP kernels through the C ABI, torch.distributed/RCCL for the all-reduce); the CPU tests run
+the SAME driver with an oracle-backed engine over gloo.
+"""
+import numpy as np
+
+from . import capi
+
+
+def plan_slabs(target_xyz, world, axis=0):
+    """Equal-count slab edges along `axis`: [(lo, hi)] * world with lo[0] = -inf,
+    hi[-1] = +inf and hi[r] == lo[r+1] exactly (as float32, the type the device compares)."""
+    x = np.asarray(target_xyz)[:, axis]
+    x = x[np.isfinite(x)]
+    if world == 1 or len(x) == 0:
+        return [(-np.inf, np.inf)] * world if world == 1 else \
+            [(-np.inf, np.inf)] + [(np.inf, np.inf)] * (world - 1)
+    qs = np.quantile(x.astype(np.float64), np.arange(1, world) / world)
+    edges = [float(np.float32(q)) for q in qs]
+    for i in range(1, len(edges)):  # strictly increasing, still float32-representable
+        if edges[i] <= edges[i - 1]:
+            edges[i] = float(np.nextafter(np.float32(edges[i - 1]), np.float32(np.inf)))
+    lo = [-np.inf] + edges
+    hi = edges + [np.inf]
+    return list(zip(lo, hi))
+
+
+def slab_target_mask(target_xyz, lo, hi, halo, axis=0):
+    """Target points a rank must index: x in [lo - halo, hi + halo]."""
+    x = np.asarray(target_xyz)[:, axis].astype(np.float64)
+    return (x >= lo - halo) & (x <= hi + halo)
+
+
+class GpuShardEngine:
+    """One rank's share of a sharded registration on one MI355X."""
+
+    def __init__(self, device, ref, target, rank, world, max_corr, use_torch_stream=True):
+        import torch
+        self.torch = torch
+        self.dev = torch.device("cuda", device)
+        self.rank, self.world = rank, world
+        self.lo, self.hi = plan_slabs(target, world)[rank]
+        # a float32-safe halo: max_corr plus a hair for the float rounding of x
+        self.halo = float(max_corr) * (1.0 + 1e-6) + 1e-4
+        mask = slab_target_mask(target, self.lo, self.hi, self.halo)
+        self.n_target_local = int(mask.sum())
+        self.d_ref = torch.from_numpy(np.ascontiguousarray(ref, np.float32)).to(self.dev)
+        self.d_tgt = torch.from_numpy(np.ascontiguousarray(target[mask], np.float32)).to(self.dev)
+        self.ctx = capi.Context(device)
+        if use_torch_stream:
+            self.ctx.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        self.stats = torch.zeros(capi.WM_STATS_LEN, dtype=torch.float64, device=self.dev)
+        self.rebuild()
+
+    def rebuild(self):
+        """index build, part of every timed registration"""
+        self.ctx.set_source(self.d_ref)
+        self.ctx.set_target(self.d_tgt)
+
+    def begin(self, params):
+        self.ctx.shard_begin(params, self.lo, self.hi)
+
+    def local_stats(self):
+        self.ctx.shard_local_stats(self.stats.data_ptr())
+        return self.stats
+
+    def apply(self, stats):
+        self.ctx.shard_apply(stats.data_ptr())
+
+    def poll(self):
+        return self.ctx.shard_poll()
+
+
+class ShardedIcp:
+    """ICP iteration loop with one all-reduce of the statistics block per iteration."""
+
+    def __init__(self, engine, dist=None, device=None, batch=8):
+        self.eng, self.dist, self.batch = engine, dist, batch
+
+    def align(self, params=None, **kw):
+        p = params or capi.icp_params(**kw)
+        forced = p.force_iterations > 0
+        max_it = p.force_iterations if forced else p.max_iter
+        self.eng.begin(p)
+        it = 0
+        out = None
+        while it < max_it:
+            nb = max_it if forced else min(self.batch, max_it - it)
+            for _ in range(nb):
+                t = self.eng.local_stats()
+                if self.dist is not None:
+                    self.dist.all_reduce(t)       # SUM over ranks (RCCL on GPU, gloo in tests)
+                self.eng.apply(t)
+            it += nb
+            out = self.eng.poll()
+            if out["done"]:
+                break
+        return out

@@ -1,0 +1,140 @@
+"""CPU tests of the multi-GPU path's host logic: slab planning, the exactly-one-owner /
+halo-exactness properties, and the sharded iteration driver over gloo with world_size 2
+(the same ShardedIcp loop bench.py runs over RCCL, with an oracle-backed engine standing
+in for the HIP kernels; the solve + stopping rules are the product's own host function)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import pose_error, svd_stats_numpy
+from libwave_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_plan_slabs_properties():
+    from libwave_amd import sharding
+    tgt = synth.scene(50000, seed=3)
+    for world in (1, 2, 4, 8):
+        slabs = sharding.plan_slabs(tgt, world)
+        assert len(slabs) == world and slabs[0][0] == -np.inf and slabs[-1][1] == np.inf
+        for (l0, h0), (l1, h1) in zip(slabs[:-1], slabs[1:]):
+            assert h0 == l1 and l0 < h0
+            assert np.float32(h0) == h0          # representable in the device's compare type
+        x = tgt[:, 0]
+        owner = np.zeros(len(x), int)
+        for lo, hi in slabs:
+            owner += ((x >= lo) & (x < hi)).astype(int)
+        assert (owner == 1).all()                # every point has exactly one owner
+        counts = [int(((x >= lo) & (x < hi)).sum()) for lo, hi in slabs]
+        assert max(counts) - min(counts) <= 0.02 * len(x) + 2
+
+
+def test_halo_makes_sharded_nn_exact(oracle):
+    from libwave_amd import sharding
+    ref, tgt, _ = synth.pair(20000, seed=5)
+    max_corr = 1.5
+    full_idx, full_d2 = oracle.KdTree(tgt).nn(ref)
+    keep = full_d2.astype(np.float64) <= max_corr ** 2
+    got = np.full(len(ref), -1)
+    for lo, hi in sharding.plan_slabs(tgt, 4):
+        mask = sharding.slab_target_mask(tgt, lo, hi, max_corr * (1 + 1e-6) + 1e-4)
+        gidx = np.nonzero(mask)[0]
+        mine = (ref[:, 0] >= lo) & (ref[:, 0] < hi)
+        li, ld2 = oracle.KdTree(tgt[mask]).nn(ref[mine])
+        ok = ld2.astype(np.float64) <= max_corr ** 2
+        got[np.nonzero(mine)[0][ok]] = gidx[li[ok]]
+    assert np.array_equal(got, np.where(keep, full_idx, -1))
+
+
+class OracleShardEngine:
+    """Same interface as sharding.GpuShardEngine, kernels replaced by the CPU oracle."""
+
+    def __init__(self, ref, tgt, rank, world, max_corr, oracle, capi):
+        import torch
+        from libwave_amd import sharding
+        self.torch, self.O, self.capi = torch, oracle, capi
+        self.ref = ref
+        self.lo, self.hi = sharding.plan_slabs(tgt, world)[rank]
+        mask = sharding.slab_target_mask(tgt, self.lo, self.hi, max_corr * (1 + 1e-6) + 1e-4)
+        self.tgt = tgt[mask]
+        self.tree = oracle.KdTree(self.tgt)
+        self.max_corr = max_corr
+
+    def begin(self, params):
+        self.host = self.capi.HostIcp(params)
+
+    def local_stats(self):
+        T = self.host.get()["T"]
+        moved = self.O.transform_cloud_f(self.ref, T.astype(np.float32))
+        mine = (moved[:, 0] >= np.float32(self.lo)) & (moved[:, 0] < np.float32(self.hi))
+        st = np.zeros(32)
+        if mine.any() and len(self.tgt):
+            idx, d2 = self.tree.nn(moved[mine])
+            ok = d2.astype(np.float64) <= self.max_corr ** 2
+            st = svd_stats_numpy(moved[mine][ok], self.tgt[idx[ok]], d2[ok])
+        return self.torch.from_numpy(st)
+
+    def apply(self, t):
+        self.host.apply(t.numpy())
+
+    def poll(self):
+        return self.host.get()
+
+
+def _worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from libwave_amd import capi, sharding
+    from oracle import oracle_py as O
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ref, tgt, _ = synth.pair(n, seed=42)
+        eng = OracleShardEngine(ref, tgt, rank, world, 3.0, O, capi)
+        out = {}
+        for name, kw in (("forced", dict(force_iterations=6)), ("free", dict(max_iter=40))):
+            r = sharding.ShardedIcp(eng, dist).align(max_corr=3.0, **kw)
+            out[name] = (r["T"].tolist(), r["iterations"], r["state"], r["n_corr"])
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_icp_over_gloo_matches_unsharded_oracle(oracle, wm):
+    import multiprocessing as mp
+    n, world, port = 6000, 2, 29731
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref, tgt, _ = synth.pair(n, seed=42)
+    for name, kw in (("forced", dict(force_iterations=6)), ("free", dict(max_iter=40))):
+        want = oracle.icp_align(ref, tgt, max_corr=3.0, incremental_float=0, **kw)
+        T0, it0, st0, nc0 = res[0][name]
+        T1, it1, st1, nc1 = res[1][name]
+        assert np.array_equal(np.array(T0), np.array(T1))      # every rank solves identically
+        assert (it0, st0, nc0) == (it1, st1, nc1) == (want["iterations"], want["state"],
+                                                        want["n_corr"])
+        dt, ang = pose_error(np.array(T0), want["T"])
+        assert dt <= 1e-9 and ang <= 1e-9, (dt, ang)
+
+
+def test_host_icp_state_machine_matches_oracle_single_rank(oracle, wm):
+    from libwave_amd import sharding
+    ref, tgt, _ = synth.pair(4000, seed=9)
+    eng = OracleShardEngine(ref, tgt, 0, 1, 3.0, oracle, wm)
+    got = sharding.ShardedIcp(eng, None).align(max_corr=3.0, max_iter=50)
+    want = oracle.icp_align(ref, tgt, max_corr=3.0, max_iter=50, incremental_float=0)
+    assert (got["iterations"], got["state"]) == (want["iterations"], want["state"])
+    dt, ang = pose_error(got["T"], want["T"])
+    assert dt <= 1e-9 and ang <= 1e-9
