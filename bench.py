@@ -95,7 +95,8 @@ def main():
     ref, tgt, T_gt = synth.pair(n_total, seed=42, mode="resample")
     dev = torch.device("cuda", local_rank)
 
-    if world == 1:
+    force_sharded = os.environ.get("WM_BENCH_FORCE_SHARDED") == "1"  # plumbing check at N=1
+    if world == 1 and not force_sharded:
         d_ref = torch.from_numpy(ref).to(dev)
         d_tgt = torch.from_numpy(tgt).to(dev)
         ctx = capi.Context(local_rank)

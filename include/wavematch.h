@@ -208,6 +208,34 @@ int wm_icp_stats_for(wm_ctx *ctx, const double T[16], int mode, double stats[WM_
 int wm_umeyama_from_stats(const double stats[WM_STATS_LEN], double Tk_out[16]);
 int wm_gn6_from_stats(const double stats[WM_STATS_LEN], double Tk_out[16]);
 
+/* ------------------------------------------------------------------- NDT */
+typedef struct {
+    double res;           /* NDTMatcherParams::res,       ndt.hpp:40 -> ndt.cpp:32 setResolution */
+    double step_size;     /* NDTMatcherParams::step_size, ndt.hpp:37 -> ndt.cpp:31 setStepSize  */
+    double t_eps;         /* NDTMatcherParams::t_eps,     ndt.hpp:39 -> ndt.cpp:30              */
+    int max_iter;         /* NDTMatcherParams::max_iter,  ndt.hpp:38 -> ndt.cpp:33              */
+    double outlier_ratio; /* PCL default 0.55 (not set by libwave) */
+    int skip_line_search; /* 1: PCL 1.8.x behaviour (More-Thuente loop never runs) */
+    int pcl_d1_sign;      /* 1: PCL's h_ang_d1[2] = +sy; 0: the true derivative -sy */
+    int force_iterations; /* >0: exactly this many Newton iterations (bench) */
+} wm_ndt_params;
+
+typedef struct {
+    int converged, iterations, n_voxels, evaluations;
+    double score;          /* trans_probability_: score / number of source points */
+    float deriv_kernel_ms; /* summed device time of the derivative kernel */
+} wm_ndt_stats;
+
+void wm_ndt_default_params(wm_ndt_params *p);
+/* pcl::NormalDistributionsTransform::align + hasConverged + getFinalTransformation
+ * (wave_matching/src/ndt.cpp:59-61) on the clouds given by wm_set_source /
+ * wm_set_target; the voxel statistics of setInputTarget (ndt.cpp:55) are (re)built on
+ * device when the target or `res` changed. */
+int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *p, double T_out[16], wm_ndt_stats *stats);
+/* computeDerivatives at pose (tx,ty,tz,rx,ry,rz): score, gradient(6), Hessian(36) */
+int wm_ndt_derivatives(wm_ctx *ctx, const wm_ndt_params *p, const double pose[6], double *score,
+                       double grad[6], double hess[36], int *n_voxels);
+
 /* ---------------------------------------------- sharded registration (multi-GPU)
  * One registration spread over the GPUs of a node, one process (rank) per GPU:
  * every rank holds the full source cloud and the target points of one x-slab

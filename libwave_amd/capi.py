@@ -43,6 +43,18 @@ class IcpStats(C.Structure):
                 ("deferred", C.c_uint64), ("grid_cell", C.c_float)]
 
 
+class NdtParams(C.Structure):
+    _fields_ = [("res", C.c_double), ("step_size", C.c_double), ("t_eps", C.c_double),
+                ("max_iter", C.c_int), ("outlier_ratio", C.c_double),
+                ("skip_line_search", C.c_int), ("pcl_d1_sign", C.c_int),
+                ("force_iterations", C.c_int)]
+
+
+class NdtStats(C.Structure):
+    _fields_ = [("converged", C.c_int), ("iterations", C.c_int), ("n_voxels", C.c_int),
+                ("evaluations", C.c_int), ("score", C.c_double), ("deriv_kernel_ms", C.c_float)]
+
+
 _dp = C.POINTER(C.c_double)
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
@@ -92,6 +104,11 @@ def lib():
         L.wm_host_icp_destroy.restype = None
         L.wm_host_icp_apply.argtypes = [C.c_void_p, _dp]
         L.wm_host_icp_get.argtypes = [C.c_void_p, C.POINTER(C.c_int), _dp, C.POINTER(IcpStats)]
+        L.wm_ndt_default_params.argtypes = [C.POINTER(NdtParams)]
+        L.wm_ndt_default_params.restype = None
+        L.wm_ndt_align.argtypes = [C.c_void_p, C.POINTER(NdtParams), _dp, C.POINTER(NdtStats)]
+        L.wm_ndt_derivatives.argtypes = [C.c_void_p, C.POINTER(NdtParams), _dp, _dp, _dp, _dp,
+                                         C.POINTER(C.c_int)]
         L.wm_get_iteration_times.argtypes = [C.c_void_p, _fp, C.c_int]
         L.wm_get_correspondences.argtypes = [C.c_void_p, _ip, _fp, C.c_size_t]
         L.wm_nn_search.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int, _ip, _fp, C.c_size_t, _fp]
@@ -114,6 +131,16 @@ def declared_symbols(header=None):
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         names += re.findall(r"\b(wm_[a-z0-9_]+)\s*\(", txt)
     return sorted(set(names))
+
+
+def ndt_params(**kw):
+    p = NdtParams()
+    lib().wm_ndt_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
 
 
 def icp_params(**kw):
@@ -252,6 +279,29 @@ class Context:
                                            float(lin_covar), float(ang_covar), float(max_corr),
                                            info.ctypes.data_as(_dp), C.byref(deg)), "wm_icp_info")
         return rc, info, bool(deg.value)
+
+    # ---- NDT
+    def ndt_align(self, params=None, **kw):
+        p = params or ndt_params(**kw)
+        T = np.zeros((4, 4), np.float64)
+        s = NdtStats()
+        rc = self._check(lib().wm_ndt_align(self._h, C.byref(p), T.ctypes.data_as(_dp),
+                                            C.byref(s)), "wm_ndt_align")
+        return dict(rc=rc, T=T if rc == WM_OK else None, converged=bool(s.converged),
+                    iterations=s.iterations, n_voxels=s.n_voxels, evaluations=s.evaluations,
+                    score=s.score, deriv_kernel_ms=s.deriv_kernel_ms)
+
+    def ndt_derivatives(self, pose, params=None, **kw):
+        p = params or ndt_params(**kw)
+        pose = np.ascontiguousarray(pose, np.float64)
+        score = C.c_double(0)
+        g, H = np.zeros(6), np.zeros((6, 6))
+        nv = C.c_int(0)
+        self._check(lib().wm_ndt_derivatives(self._h, C.byref(p), pose.ctypes.data_as(_dp),
+                                             C.byref(score), g.ctypes.data_as(_dp),
+                                             H.ctypes.data_as(_dp), C.byref(nv)),
+                    "wm_ndt_derivatives")
+        return score.value, g, H, nv.value
 
     # ---- sharded (multi-GPU) stepping
     def set_stream(self, stream_ptr, external=True):

@@ -447,7 +447,8 @@ void wm_ctx_destroy(wm_ctx *ctx) {
     (void) hipSetDevice(ctx->device);
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->src_sorted, &ctx->tgt_orig, &ctx->staging, &ctx->cell_of, &ctx->counts,
-                      &ctx->block_sums, &ctx->bbox_buf, &ctx->keys, &ctx->keys_bak, &ctx->d_levels, &ctx->vg_idx, &ctx->vg_idx2, &ctx->vg_perm,
+                      &ctx->block_sums, &ctx->bbox_buf, &ctx->keys, &ctx->keys_bak, &ctx->d_levels, &ctx->ndt_keys, &ctx->ndt_keys2,
+                      &ctx->ndt_vox, &ctx->ndt_vkey, &ctx->ndt_hkeys, &ctx->ndt_hvals, &ctx->vg_idx, &ctx->vg_idx2, &ctx->vg_perm,
                       &ctx->vg_perm2, &ctx->vg_tmp, &ctx->vg_seg, &ctx->io_a, &ctx->io_b, &ctx->ds_ref,
                       &ctx->ds_tgt, &ctx->match_ref, &ctx->match_tgt,
                       &ctx->partials, &ctx->corr_tmp_idx, &ctx->corr_tmp_d2, &ctx->d_state};
@@ -505,6 +506,7 @@ int wm_set_target(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem
     if (!ctx || (n > 0 && !pts) || stride < 12 || (stride & 3) || n > 0x7FFFFFF0u) return WM_ERR_ARG;
     WM_HIP(ctx, hipSetDevice(ctx->device));
     ctx->have_corr = false;
+    ctx->ndt_built = false;
     ctx->n_tgt_input = n;
     ctx->n_tgt = 0;
     for (auto &l : ctx->levels) l.built = false;

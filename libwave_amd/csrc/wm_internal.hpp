@@ -147,6 +147,12 @@ struct wm_ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     std::vector<float> iter_nn_ms;
 
+    // NDT voxel model of the target
+    wm::DevBuf ndt_keys, ndt_keys2, ndt_vox, ndt_vkey, ndt_hkeys, ndt_hvals;
+    bool ndt_built = false;
+    double ndt_res = -1;
+    unsigned ndt_nvox = 0, ndt_nvalid = 0, ndt_hmask = 0;
+
     // sharded (multi-GPU) stepping
     bool shard_active = false;
     wm_icp_params shard_params{};

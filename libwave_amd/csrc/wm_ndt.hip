@@ -1,0 +1,831 @@
+// wm_ndt.hip -- pcl::NormalDistributionsTransform on device, as libwave's NDTMatcher
+// drives it (wave_matching/src/ndt.cpp:18-34 setters, :48-65 setInput*/align):
+//   k_ndt_key / rocPRIM sort / k_ndt_voxel_stats / k_ndt_hash_insert
+//        = pcl::VoxelGridCovariance::filter (setInputTarget, ndt.cpp:55): per-voxel
+//          n, sum p, sum p p^T (double, ascending point order), mean, covariance,
+//          eigenvalue inflation (>= 0.01 lambda_max), inverse; voxels with < 6 points
+//          dropped; an open-addressing hash (voxel ijk -> record) replaces PCL's kd-tree
+//          over the voxel means (a mean within `res` of a point lies in one of the 27
+//          voxels around it).
+//   k_ndt_derivs  = computeDerivatives / updateDerivatives / computeHessian: one lane per
+//          source point, score + 6 gradient + 36 Hessian sums in double, fixed-order
+//          workgroup reduction.  These 43 doubles are the only thing the host sees.
+//   host: Newton step (JacobiSVD solve) + More-Thuente line search
+//          (computeStepLengthMT / trialValueSelectionMT / updateIntervalMT).
+// [PCL registration/impl/ndt.hpp, filters/impl/voxel_grid_covariance.hpp; Magnusson 2009]
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "wm_internal.hpp"
+
+#include <float.h>
+#include <math.h>
+
+namespace wm {
+
+constexpr int kNdtAcc = 43;
+constexpr int kNdtBlocks = 1024;
+constexpr unsigned long long kEmptyKey = ~0ull;
+
+struct NdtVoxel {
+    double mean[3];
+    double icov[9];
+};
+
+__host__ __device__ inline unsigned long long ndt_key(int i, int j, int k) {
+    return ((unsigned long long) (unsigned) (i + (1 << 20)) << 42) |
+           ((unsigned long long) (unsigned) (j + (1 << 20)) << 21) |
+           (unsigned long long) (unsigned) (k + (1 << 20));
+}
+
+__device__ __forceinline__ unsigned ndt_hash(unsigned long long x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return (unsigned) x;
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_ndt_key(const float4 *__restrict__ pts, unsigned n, float inv, unsigned long long *keys,
+              unsigned *perm) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    unsigned long long key = kEmptyKey;  // non-finite points sort last
+    if (p.x == p.x) {
+        const int a = (int) floorf(__fmul_rn(p.x, inv));
+        const int b = (int) floorf(__fmul_rn(p.y, inv));
+        const int c = (int) floorf(__fmul_rn(p.z, inv));
+        // sort order (k, j, i): k in the top bits
+        key = ndt_key(c, b, a);
+    }
+    keys[i] = key;
+    perm[i] = i;
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_ndt_flags(const unsigned long long *__restrict__ keys, unsigned n, unsigned *flags) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = keys[i];
+    flags[i] = (k != kEmptyKey && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+}
+
+// symmetric 3x3 eigen-decomposition (cyclic Jacobi), eigenvalues ascending
+__device__ inline void sym_eig3(const double *Ain, double *evals, double *V) {
+    double A[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        A[i] = Ain[i];
+        V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+        const double diag = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
+        if (off <= 1e-32 * diag || off == 0.0) break;
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) {
+            const int p = pr == 2 ? 1 : 0, q = pr == 0 ? 1 : 2;
+            const double apq = A[p * 3 + q];
+            if (fabs(apq) < 1e-300) continue;
+            const double theta = (A[q * 3 + q] - A[p * 3 + p]) / (2.0 * apq);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double akp = A[k * 3 + p], akq = A[k * 3 + q];
+                A[k * 3 + p] = c * akp - s * akq;
+                A[k * 3 + q] = s * akp + c * akq;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double apk = A[p * 3 + k], aqk = A[q * 3 + k];
+                A[p * 3 + k] = c * apk - s * aqk;
+                A[q * 3 + k] = s * apk + c * aqk;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double vkp = V[k * 3 + p], vkq = V[k * 3 + q];
+                V[k * 3 + p] = c * vkp - s * vkq;
+                V[k * 3 + q] = s * vkp + c * vkq;
+            }
+        }
+    }
+    evals[0] = A[0];
+    evals[1] = A[4];
+    evals[2] = A[8];
+    // ascending sort with column swaps (static indices)
+#define SWAPCOL(a, b)                                  \
+    if (evals[b] < evals[a]) {                         \
+        double t = evals[a];                           \
+        evals[a] = evals[b];                           \
+        evals[b] = t;                                  \
+        _Pragma("unroll") for (int k = 0; k < 3; ++k) { \
+            t = V[k * 3 + a];                          \
+            V[k * 3 + a] = V[k * 3 + b];               \
+            V[k * 3 + b] = t;                          \
+        }                                              \
+    }
+    SWAPCOL(0, 1)
+    SWAPCOL(0, 2)
+    SWAPCOL(1, 2)
+#undef SWAPCOL
+}
+
+__device__ inline bool inverse3(const double *m, double *o) {
+    const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8],
+                 c02 = m[3] * m[7] - m[4] * m[6];
+    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    const double id = 1.0 / det;
+    o[0] = c00 * id;
+    o[1] = (m[2] * m[7] - m[1] * m[8]) * id;
+    o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c01 * id;
+    o[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+    o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c02 * id;
+    o[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+    o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ok = ok && isfinite(o[k]);
+    return ok;
+}
+
+// one lane per voxel head: statistics in ascending point order, then the PCL
+// covariance conditioning.  seg[i] (exclusive scan of head flags) = voxel slot.
+__global__ void __launch_bounds__(kBlock)
+    k_ndt_voxel_stats(const float4 *__restrict__ pts, const unsigned long long *__restrict__ keys,
+                      const unsigned *__restrict__ perm, const unsigned *__restrict__ seg,
+                      unsigned n, NdtVoxel *__restrict__ vox, unsigned long long *__restrict__ vkey,
+                      unsigned *__restrict__ n_valid) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = keys[i];
+    if (key == kEmptyKey || (i > 0 && keys[i - 1] == key)) return;
+    double s[3] = {0, 0, 0}, pp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned j = i;
+    for (; j < n && keys[j] == key; ++j) {
+        const float4 p = pts[perm[j]];
+        const double d[3] = {(double) p.x, (double) p.y, (double) p.z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            s[a] += d[a];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) pp[a * 3 + b] += d[a] * d[b];
+        }
+    }
+    const unsigned slot = seg[i];
+    const double nn = (double) (j - i);
+    NdtVoxel v;
+    bool valid = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) v.mean[a] = s[a] / nn;
+    if (j - i >= 6) {  // min_points_per_voxel_
+        double cov[9], evals[3], evecs[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                cov[a * 3 + b] = ((pp[a * 3 + b] - 2.0 * (s[a] * v.mean[b])) / nn + v.mean[a] * v.mean[b]) *
+                                 ((nn - 1.0) / nn);
+        sym_eig3(cov, evals, evecs);
+        if (!(evals[0] < 0 || evals[1] < 0 || evals[2] <= 0)) {
+            const double minv = 0.01 * evals[2];
+            if (evals[0] < minv) {
+                evals[0] = minv;
+                if (evals[1] < minv) evals[1] = minv;
+                double einv[9], t[9];
+                inverse3(evecs, einv);
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) t[a * 3 + b] = evecs[a * 3 + b] * evals[b];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        double acc = 0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) acc += t[a * 3 + k] * einv[k * 3 + b];
+                        cov[a * 3 + b] = acc;
+                    }
+            }
+            valid = inverse3(cov, v.icov);
+        }
+    }
+    vox[slot] = v;
+    vkey[slot] = valid ? key : kEmptyKey;
+    if (valid) atomicAdd(n_valid, 1u);
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_ndt_hash_insert(const unsigned long long *__restrict__ vkey, unsigned nvox,
+                      unsigned long long *__restrict__ hkeys, unsigned *__restrict__ hvals,
+                      unsigned mask) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nvox) return;
+    const unsigned long long key = vkey[i];
+    if (key == kEmptyKey) return;
+    unsigned h = ndt_hash(key) & mask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS(&hkeys[h], kEmptyKey, key);
+        if (prev == kEmptyKey) {
+            hvals[h] = i;
+            return;
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+struct NdtArgs {
+    float Tf[12];
+    float inv_res;
+    double res2, d1, d2;
+    // computeAngleDerivatives: 8 Jacobian and 15 Hessian 3-vectors
+    double j[8][3];
+    double h[15][3];
+};
+
+__device__ __forceinline__ double dot3d(const double *a, const double *b) {
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+
+// a[0] = score, a[1..6] = gradient, a[7..42] = Hessian (row-major 6x6)
+template <bool GRAD, bool HESS>
+__global__ void __launch_bounds__(kBlock)
+    k_ndt_derivs(const float4 *__restrict__ src, unsigned n, const NdtVoxel *__restrict__ vox,
+                 const unsigned long long *__restrict__ hkeys, const unsigned *__restrict__ hvals,
+                 unsigned mask, NdtArgs A, double *__restrict__ partials) {
+    double acc[kNdtAcc];
+#pragma unroll
+    for (int k = 0; k < kNdtAcc; ++k) acc[k] = 0.0;
+    for (unsigned idx = blockIdx.x * kBlock + threadIdx.x; idx < n; idx += gridDim.x * kBlock) {
+        const float4 sp = src[idx];
+        const float xt0 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.Tf[0], sp.x), __fmul_rn(A.Tf[1], sp.y)),
+                                              __fmul_rn(A.Tf[2], sp.z)), A.Tf[3]);
+        const float xt1 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.Tf[4], sp.x), __fmul_rn(A.Tf[5], sp.y)),
+                                              __fmul_rn(A.Tf[6], sp.z)), A.Tf[7]);
+        const float xt2 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.Tf[8], sp.x), __fmul_rn(A.Tf[9], sp.y)),
+                                              __fmul_rn(A.Tf[10], sp.z)), A.Tf[11]);
+        const int ci = (int) floorf(__fmul_rn(xt0, A.inv_res));
+        const int cj = (int) floorf(__fmul_rn(xt1, A.inv_res));
+        const int ck = (int) floorf(__fmul_rn(xt2, A.inv_res));
+        const double x[3] = {(double) sp.x, (double) sp.y, (double) sp.z};
+        // point Jacobian (3x6) and second derivatives, computePointDerivatives
+        double J[18];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) J[k] = 0.0;
+        J[0] = J[7] = J[14] = 1.0;
+        J[1 * 6 + 3] = dot3d(x, A.j[0]);
+        J[2 * 6 + 3] = dot3d(x, A.j[1]);
+        J[0 * 6 + 4] = dot3d(x, A.j[2]);
+        J[1 * 6 + 4] = dot3d(x, A.j[3]);
+        J[2 * 6 + 4] = dot3d(x, A.j[4]);
+        J[0 * 6 + 5] = dot3d(x, A.j[5]);
+        J[1 * 6 + 5] = dot3d(x, A.j[6]);
+        J[2 * 6 + 5] = dot3d(x, A.j[7]);
+        double PH[6][3];  // a, b, c, d, e, f
+        if (HESS) {
+            PH[0][0] = 0.0;
+            PH[0][1] = dot3d(x, A.h[0]);
+            PH[0][2] = dot3d(x, A.h[1]);
+            PH[1][0] = 0.0;
+            PH[1][1] = dot3d(x, A.h[2]);
+            PH[1][2] = dot3d(x, A.h[3]);
+            PH[2][0] = 0.0;
+            PH[2][1] = dot3d(x, A.h[4]);
+            PH[2][2] = dot3d(x, A.h[5]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                PH[3][r] = dot3d(x, A.h[6 + r]);
+                PH[4][r] = dot3d(x, A.h[9 + r]);
+                PH[5][r] = dot3d(x, A.h[12 + r]);
+            }
+        }
+#pragma unroll 1
+        for (int nb = 0; nb < 27; ++nb) {
+            const int di = nb % 3 - 1, dj = (nb / 3) % 3 - 1, dk = nb / 9 - 1;
+            const unsigned long long key = ndt_key(ck + dk, cj + dj, ci + di);
+            unsigned hpos = ndt_hash(key) & mask;
+            unsigned vi = 0xFFFFFFFFu;
+            for (;;) {
+                const unsigned long long hk = hkeys[hpos];
+                if (hk == key) {
+                    vi = hvals[hpos];
+                    break;
+                }
+                if (hk == kEmptyKey) break;
+                hpos = (hpos + 1) & mask;
+            }
+            if (vi == 0xFFFFFFFFu) continue;
+            const NdtVoxel v = vox[vi];
+            {  // kd-tree radius test in float on the float-stored means
+                const float fx = __fsub_rn(xt0, (float) v.mean[0]), fy = __fsub_rn(xt1, (float) v.mean[1]),
+                            fz = __fsub_rn(xt2, (float) v.mean[2]);
+                const float dd = __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz));
+                if (!((double) dd < A.res2)) continue;
+            }
+            const double xx[3] = {(double) xt0 - v.mean[0], (double) xt1 - v.mean[1], (double) xt2 - v.mean[2]};
+            double cx[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) cx[a] = v.icov[a * 3] * xx[0] + v.icov[a * 3 + 1] * xx[1] + v.icov[a * 3 + 2] * xx[2];
+            const double q = dot3d(xx, cx);
+            const double e = exp(-A.d2 * q / 2.0);
+            double w = A.d2 * e;
+            if (w > 1 || w < 0 || w != w) continue;
+            acc[0] += -A.d1 * e;
+            w *= A.d1;
+            if (GRAD || HESS) {
+                double cJ[6][3], xcJ[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+                        cJ[i][a] = v.icov[a * 3] * J[0 * 6 + i] + v.icov[a * 3 + 1] * J[1 * 6 + i] +
+                                   v.icov[a * 3 + 2] * J[2 * 6 + i];
+                    xcJ[i] = dot3d(xx, cJ[i]);
+                    if (GRAD) acc[1 + i] += xcJ[i] * w;
+                }
+                if (HESS) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {
+                            double t2 = 0.0, t3 = 0.0;
+                            if (i >= 3 && j >= 3) {
+                                // block (i, j) of point_hessian_: a b c / b d e / c e f
+                                const int hi = i - 3, hj = j - 3;
+                                const int sel = (hi == 0 && hj == 0) ? 0 : ((hi + hj == 1) ? 1 : ((hi + hj == 2 && hi != hj) ? 2 : ((hi == 1 && hj == 1) ? 3 : ((hi + hj == 3) ? 4 : 5))));
+                                const double *hv = PH[sel];
+                                double ch[3];
+#pragma unroll
+                                for (int a = 0; a < 3; ++a)
+                                    ch[a] = v.icov[a * 3] * hv[0] + v.icov[a * 3 + 1] * hv[1] + v.icov[a * 3 + 2] * hv[2];
+                                t2 = dot3d(xx, ch);
+                            }
+#pragma unroll
+                            for (int b = 0; b < 3; ++b) t3 += J[b * 6 + j] * cJ[i][b];
+                            acc[7 + i * 6 + j] += w * (-A.d2 * xcJ[i] * xcJ[j] + t2 + t3);
+                        }
+                }
+            }
+        }
+    }
+    // fixed-order reduction: wave xor-tree, then the 4 waves through LDS
+#pragma unroll
+    for (int k = 0; k < kNdtAcc; ++k)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off);
+    __shared__ double lds[kBlock / 64][kNdtAcc];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < kNdtAcc; ++k) lds[wave][k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < kNdtAcc) {
+        double s = 0;
+        for (int w = 0; w < kBlock / 64; ++w) s += lds[w][threadIdx.x];
+        partials[(size_t) blockIdx.x * kNdtAcc + threadIdx.x] = s;
+    }
+}
+
+// ----------------------------------------------------------------- host
+struct NdtModel {
+    double res = -1;
+    size_t n_target = 0;
+    unsigned nvox = 0, nvalid = 0, hmask = 0;
+};
+
+static int ndt_build(wm_ctx *ctx, double res) {
+    const size_t n = ctx->n_tgt_input;
+    const float4 *pts = ctx->tgt_orig.as<float4>();
+    const unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
+    WM_HIP(ctx, ctx->ndt_keys.reserve(n * 8));
+    WM_HIP(ctx, ctx->ndt_keys2.reserve(n * 8));
+    WM_HIP(ctx, ctx->vg_perm.reserve(n * 4));
+    WM_HIP(ctx, ctx->vg_perm2.reserve(n * 4));
+    WM_HIP(ctx, ctx->vg_idx.reserve(n * 4));
+    WM_HIP(ctx, ctx->vg_seg.reserve((n + 1) * 4));
+    unsigned long long *k1 = ctx->ndt_keys.as<unsigned long long>(), *k2 = ctx->ndt_keys2.as<unsigned long long>();
+    unsigned *p1 = ctx->vg_perm.as<unsigned>(), *p2 = ctx->vg_perm2.as<unsigned>();
+    unsigned *flags = ctx->vg_idx.as<unsigned>(), *seg = ctx->vg_seg.as<unsigned>();
+    hipLaunchKernelGGL(k_ndt_key, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, (unsigned) n,
+                       1.0f / (float) res, k1, p1);
+    size_t tmp = 0;
+    WM_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp, k1, k2, p1, p2, n, 0, 64, ctx->stream));
+    WM_HIP(ctx, ctx->vg_tmp.reserve(tmp));
+    WM_HIP(ctx, rocprim::radix_sort_pairs(ctx->vg_tmp.p, tmp, k1, k2, p1, p2, n, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(k_ndt_flags, dim3(blocks), dim3(kBlock), 0, ctx->stream, k2, (unsigned) n, flags);
+    WM_TRY(exclusive_scan(ctx, flags, n, seg));
+    unsigned nvox = 0;
+    WM_HIP(ctx, hipMemcpyAsync(&nvox, seg + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->ndt_nvox = nvox;
+    ctx->ndt_nvalid = 0;
+    unsigned cap = 16;
+    while (cap < 2 * nvox + 2) cap <<= 1;
+    ctx->ndt_hmask = cap - 1;
+    WM_HIP(ctx, ctx->ndt_vox.reserve((size_t) (nvox > 0 ? nvox : 1) * sizeof(NdtVoxel)));
+    WM_HIP(ctx, ctx->ndt_vkey.reserve((size_t) (nvox > 0 ? nvox : 1) * 8 + 8));
+    WM_HIP(ctx, ctx->ndt_hkeys.reserve((size_t) cap * 8));
+    WM_HIP(ctx, ctx->ndt_hvals.reserve((size_t) cap * 4));
+    WM_HIP(ctx, hipMemsetAsync(ctx->ndt_hkeys.p, 0xFF, (size_t) cap * 8, ctx->stream));
+    unsigned *d_nvalid = ctx->bbox_buf.as<unsigned>();
+    WM_HIP(ctx, ctx->bbox_buf.reserve(64));
+    d_nvalid = ctx->bbox_buf.as<unsigned>();
+    WM_HIP(ctx, hipMemsetAsync(d_nvalid, 0, 4, ctx->stream));
+    if (nvox > 0) {
+        hipLaunchKernelGGL(k_ndt_voxel_stats, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, k2, p2,
+                           seg, (unsigned) n, ctx->ndt_vox.as<NdtVoxel>(),
+                           ctx->ndt_vkey.as<unsigned long long>(), d_nvalid);
+        hipLaunchKernelGGL(k_ndt_hash_insert, dim3((nvox + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                           ctx->stream, ctx->ndt_vkey.as<unsigned long long>(), nvox,
+                           ctx->ndt_hkeys.as<unsigned long long>(), ctx->ndt_hvals.as<unsigned>(),
+                           ctx->ndt_hmask);
+        WM_HIP(ctx, hipGetLastError());
+    }
+    unsigned nvalid = 0;
+    WM_HIP(ctx, hipMemcpyAsync(&nvalid, d_nvalid, 4, hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->ndt_nvalid = nvalid;
+    ctx->ndt_res = res;
+    ctx->ndt_built = true;
+    return WM_OK;
+}
+
+static void pose_to_matrix_f(const double p[6], float T[16]) {
+    const float cx = cosf((float) p[3]), sx = sinf((float) p[3]);
+    const float cy = cosf((float) p[4]), sy = sinf((float) p[4]);
+    const float cz = cosf((float) p[5]), sz = sinf((float) p[5]);
+    T[0] = cy * cz;
+    T[1] = -cy * sz;
+    T[2] = sy;
+    T[4] = cx * sz + sx * sy * cz;
+    T[5] = cx * cz - sx * sy * sz;
+    T[6] = -sx * cy;
+    T[8] = sx * sz - cx * sy * cz;
+    T[9] = sx * cz + cx * sy * sz;
+    T[10] = cx * cy;
+    T[3] = (float) p[0];
+    T[7] = (float) p[1];
+    T[11] = (float) p[2];
+    T[12] = T[13] = T[14] = 0;
+    T[15] = 1;
+}
+
+static void angle_derivatives(const double p[6], int pcl_d1_sign, NdtArgs *A) {
+    double cx, cy, cz, sx, sy, sz;
+    if (fabs(p[3]) < 10e-5) { cx = 1.0; sx = 0.0; } else { cx = cos(p[3]); sx = sin(p[3]); }
+    if (fabs(p[4]) < 10e-5) { cy = 1.0; sy = 0.0; } else { cy = cos(p[4]); sy = sin(p[4]); }
+    if (fabs(p[5]) < 10e-5) { cz = 1.0; sz = 0.0; } else { cz = cos(p[5]); sz = sin(p[5]); }
+    const double j[8][3] = {
+        {-sx * sz + cx * sy * cz, -sx * cz - cx * sy * sz, -cx * cy},  // a
+        {cx * sz + sx * sy * cz, cx * cz - sx * sy * sz, -sx * cy},    // b
+        {-sy * cz, sy * sz, cy},                                       // c
+        {sx * cy * cz, -sx * cy * sz, sx * sy},                        // d
+        {-cx * cy * cz, cx * cy * sz, -cx * sy},                       // e
+        {-cy * sz, -cy * cz, 0},                                       // f
+        {cx * cz - sx * sy * sz, -cx * sz - sx * sy * cz, 0},          // g
+        {sx * cz + cx * sy * sz, cx * sy * cz - sx * sz, 0}};          // h
+    const double h[15][3] = {
+        {-cx * sz - sx * sy * cz, -cx * cz + sx * sy * sz, sx * cy},   // a2
+        {-sx * sz + cx * sy * cz, -cx * sy * sz - sx * cz, -cx * cy},  // a3
+        {cx * cy * cz, -cx * cy * sz, cx * sy},                        // b2
+        {sx * cy * cz, -sx * cy * sz, sx * sy},                        // b3
+        {-sx * cz - cx * sy * sz, sx * sz - cx * sy * cz, 0},          // c2
+        {cx * cz - sx * sy * sz, -sx * sy * cz - cx * sz, 0},          // c3
+        {-cy * cz, cy * sz, pcl_d1_sign ? sy : -sy},                   // d1
+        {-sx * sy * cz, sx * sy * sz, sx * cy},                        // d2
+        {cx * sy * cz, -cx * sy * sz, -cx * cy},                       // d3
+        {sy * sz, sy * cz, 0},                                         // e1
+        {-sx * cy * sz, -sx * cy * cz, 0},                             // e2
+        {cx * cy * sz, cx * cy * cz, 0},                               // e3
+        {-cy * cz, cy * sz, 0},                                        // f1
+        {-cx * sz - sx * sy * cz, -cx * cz + sx * sy * sz, 0},         // f2
+        {-sx * sz + cx * sy * cz, -cx * sy * sz - sx * cz, 0}};        // f3
+    memcpy(A->j, j, sizeof(j));
+    memcpy(A->h, h, sizeof(h));
+}
+
+struct NdtEval {
+    wm_ctx *ctx;
+    const wm_ndt_params *prm;
+    double d1, d2;
+    int evals = 0;
+    float kernel_ms = 0;
+};
+
+// score (+ gradient, + Hessian) at pose p; returns <0 on HIP error via *rc
+static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess, int *rc) {
+    wm_ctx *ctx = E.ctx;
+    NdtArgs A;
+    float Tf[16];
+    pose_to_matrix_f(p, Tf);
+    for (int k = 0; k < 12; ++k) A.Tf[k] = Tf[k];
+    A.inv_res = 1.0f / (float) E.prm->res;
+    A.res2 = E.prm->res * E.prm->res;
+    A.d1 = E.d1;
+    A.d2 = E.d2;
+    angle_derivatives(p, E.prm->pcl_d1_sign, &A);
+    const unsigned n = (unsigned) ctx->n_src;
+    int nb = (int) ((n + kBlock - 1) / kBlock);
+    if (nb > kNdtBlocks) nb = kNdtBlocks;
+    if (nb < 1) nb = 1;
+    double *partials = ctx->partials.as<double>();
+    const NdtVoxel *vox = ctx->ndt_vox.as<NdtVoxel>();
+    const unsigned long long *hk = ctx->ndt_hkeys.as<unsigned long long>();
+    const unsigned *hv = ctx->ndt_hvals.as<unsigned>();
+    const float4 *src = ctx->src_sorted.as<float4>();
+    (void) hipEventRecord(ctx->ev_a, ctx->stream);
+    if (hess && grad)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<true, true>), dim3(nb), dim3(kBlock), 0,
+                           ctx->stream, src, n, vox, hk, hv, ctx->ndt_hmask, A, partials);
+    else if (grad)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<true, false>), dim3(nb), dim3(kBlock), 0,
+                           ctx->stream, src, n, vox, hk, hv, ctx->ndt_hmask, A, partials);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<false, true>), dim3(nb), dim3(kBlock), 0,
+                           ctx->stream, src, n, vox, hk, hv, ctx->ndt_hmask, A, partials);
+    (void) hipEventRecord(ctx->ev_b, ctx->stream);
+    std::vector<double> h((size_t) nb * kNdtAcc);
+    if (hipMemcpyAsync(h.data(), partials, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        ctx->last_error = "ndt_eval: HIP error";
+        *rc = WM_ERR_HIP;
+        return 0;
+    }
+    float ms = 0;
+    (void) hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b);
+    E.kernel_ms += ms;
+    E.evals += 1;
+    double a[kNdtAcc];
+    for (int k = 0; k < kNdtAcc; ++k) {
+        double s = 0;
+        for (int b = 0; b < nb; ++b) s += h[(size_t) b * kNdtAcc + k];
+        a[k] = s;
+    }
+    if (grad)
+        for (int k = 0; k < 6; ++k) grad[k] = a[1 + k];
+    if (hess)
+        for (int k = 0; k < 36; ++k) hess[k] = a[7 + k];
+    return a[0];
+}
+
+// One-sided Jacobi SVD solve x = V S^+ U^T b for a 6x6 system (Eigen JacobiSVD::solve)
+static void svd_solve6(const double *A, const double *b, double *x) {
+    constexpr int N = 6;
+    double W[N * N], V[N * N];
+    memcpy(W, A, sizeof(W));
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) V[i * N + j] = (i == j);
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int i = 0; i < N - 1; ++i)
+            for (int j = i + 1; j < N; ++j) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int k = 0; k < N; ++k) {
+                    alpha += W[k * N + i] * W[k * N + i];
+                    beta += W[k * N + j] * W[k * N + j];
+                    gamma += W[k * N + i] * W[k * N + j];
+                }
+                if (fabs(gamma) <= 1e-300 || fabs(gamma) <= 2.3e-16 * sqrt(alpha * beta)) continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int k = 0; k < N; ++k) {
+                    const double wi = W[k * N + i], wj = W[k * N + j];
+                    W[k * N + i] = c * wi - s * wj;
+                    W[k * N + j] = s * wi + c * wj;
+                    const double vi = V[k * N + i], vj = V[k * N + j];
+                    V[k * N + i] = c * vi - s * vj;
+                    V[k * N + j] = s * vi + c * vj;
+                }
+            }
+        if (!rotated) break;
+    }
+    double sv[N], smax = 0;
+    for (int j = 0; j < N; ++j) {
+        double s2 = 0;
+        for (int k = 0; k < N; ++k) s2 += W[k * N + j] * W[k * N + j];
+        sv[j] = sqrt(s2);
+        if (sv[j] > smax) smax = sv[j];
+    }
+    const double thr = smax * N * 2.220446049250313e-16;
+    double y[N];
+    for (int j = 0; j < N; ++j) {
+        double s = 0;
+        for (int k = 0; k < N; ++k) s += W[k * N + j] * b[k];  // (U S)_j . b
+        y[j] = (sv[j] > thr) ? s / (sv[j] * sv[j]) : 0.0;      // U_j . b / S_j
+    }
+    for (int i = 0; i < N; ++i) {
+        double s = 0;
+        for (int j = 0; j < N; ++j) s += V[i * N + j] * y[j];
+        x[i] = s;
+    }
+}
+
+static double psi_mt(double a, double f_a, double f_0, double g_0, double mu) { return f_a - f_0 - mu * g_0 * a; }
+static double dpsi_mt(double g_a, double g_0, double mu) { return g_a - mu * g_0; }
+
+static bool update_interval_mt(double &a_l, double &f_l, double &g_l, double &a_u, double &f_u,
+                               double &g_u, double a_t, double f_t, double g_t) {
+    if (f_t > f_l) {
+        a_u = a_t; f_u = f_t; g_u = g_t;
+        return false;
+    } else if (g_t * (a_l - a_t) > 0) {
+        a_l = a_t; f_l = f_t; g_l = g_t;
+        return false;
+    } else if (g_t * (a_l - a_t) < 0) {
+        a_u = a_l; f_u = f_l; g_u = g_l;
+        a_l = a_t; f_l = f_t; g_l = g_t;
+        return false;
+    }
+    return true;
+}
+
+static double trial_value_mt(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u,
+                             double a_t, double f_t, double g_t) {
+    if (f_t > f_l) {
+        const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = sqrt(z * z - g_t * g_l);
+        const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+        const double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
+        return fabs(a_c - a_l) < fabs(a_q - a_l) ? a_c : 0.5 * (a_q + a_c);
+    } else if (g_t * g_l < 0) {
+        const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = sqrt(z * z - g_t * g_l);
+        const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+        const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+        return fabs(a_c - a_t) >= fabs(a_s - a_t) ? a_c : a_s;
+    } else if (fabs(g_t) <= fabs(g_l)) {
+        const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = sqrt(z * z - g_t * g_l);
+        const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+        const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+        const double a_n = fabs(a_c - a_t) < fabs(a_s - a_t) ? a_c : a_s;
+        return a_t > a_l ? fmin(a_t + 0.66 * (a_u - a_t), a_n) : fmax(a_t + 0.66 * (a_u - a_t), a_n);
+    }
+    const double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u, w = sqrt(z * z - g_t * g_u);
+    return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
+}
+
+static double step_length_mt(NdtEval &E, const double x[6], double dir[6], double step_init,
+                             double step_max, double step_min, double *score, double grad[6],
+                             double hess[36], int *rc) {
+    const double phi_0 = -(*score), mu = 1.e-4, nu = 0.9;
+    double d_phi_0 = 0, x_t[6];
+    for (int a = 0; a < 6; ++a) d_phi_0 -= grad[a] * dir[a];
+    if (d_phi_0 >= 0) {
+        if (d_phi_0 == 0) return 0;
+        d_phi_0 *= -1;
+        for (int a = 0; a < 6; ++a) dir[a] *= -1;
+    }
+    const int max_step_iterations = 10;
+    int step_iterations = 0;
+    double a_l = 0, a_u = 0;
+    double f_l = psi_mt(a_l, phi_0, phi_0, d_phi_0, mu), g_l = dpsi_mt(d_phi_0, d_phi_0, mu);
+    double f_u = psi_mt(a_u, phi_0, phi_0, d_phi_0, mu), g_u = dpsi_mt(d_phi_0, d_phi_0, mu);
+    bool interval_converged = E.prm->skip_line_search ? ((step_max - step_min) > 0) : ((step_max - step_min) < 0);
+    bool open_interval = true;
+    double a_t = fmax(fmin(step_init, step_max), step_min);
+    for (int a = 0; a < 6; ++a) x_t[a] = x[a] + dir[a] * a_t;
+    *score = ndt_eval(E, x_t, grad, hess, rc);
+    if (*rc != WM_OK) return 0;
+    double phi_t = -(*score), d_phi_t = 0;
+    for (int a = 0; a < 6; ++a) d_phi_t -= grad[a] * dir[a];
+    double psi_t = psi_mt(a_t, phi_t, phi_0, d_phi_0, mu), d_psi_t = dpsi_mt(d_phi_t, d_phi_0, mu);
+    while (!interval_converged && step_iterations < max_step_iterations &&
+           !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
+        a_t = open_interval ? trial_value_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t)
+                            : trial_value_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
+        a_t = fmax(fmin(a_t, step_max), step_min);
+        for (int a = 0; a < 6; ++a) x_t[a] = x[a] + dir[a] * a_t;
+        *score = ndt_eval(E, x_t, grad, nullptr, rc);
+        if (*rc != WM_OK) return 0;
+        phi_t = -(*score);
+        d_phi_t = 0;
+        for (int a = 0; a < 6; ++a) d_phi_t -= grad[a] * dir[a];
+        psi_t = psi_mt(a_t, phi_t, phi_0, d_phi_0, mu);
+        d_psi_t = dpsi_mt(d_phi_t, d_phi_0, mu);
+        if (open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
+            open_interval = false;
+            f_l = f_l + phi_0 - mu * d_phi_0 * a_l;
+            g_l = g_l + mu * d_phi_0;
+            f_u = f_u + phi_0 - mu * d_phi_0 * a_u;
+            g_u = g_u + mu * d_phi_0;
+        }
+        interval_converged = open_interval
+                                 ? update_interval_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t)
+                                 : update_interval_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
+        ++step_iterations;
+    }
+    if (step_iterations) {  // computeHessian at the accepted point
+        (void) ndt_eval(E, x_t, nullptr, hess, rc);
+    }
+    return a_t;
+}
+
+}  // namespace wm
+
+using namespace wm;
+
+extern "C" {
+
+void wm_ndt_default_params(wm_ndt_params *p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->res = 5;         // ndt.hpp:40
+    p->step_size = 3;   // ndt.hpp:37 (an int in the reference)
+    p->t_eps = 1e-8;    // ndt.hpp:39
+    p->max_iter = 100;  // ndt.hpp:38
+    p->outlier_ratio = 0.55;
+    p->skip_line_search = 0;
+    p->pcl_d1_sign = 1;
+}
+
+int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *prm, double T_out[16], wm_ndt_stats *stats) {
+    if (!ctx || !prm || !T_out || !(prm->res > 0) || !(prm->step_size > 0)) return WM_ERR_ARG;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (ctx->n_src_input == 0 || ctx->n_tgt_input == 0) return WM_ERR_STATE;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_HIP(ctx, ctx->partials.reserve((size_t) kNdtBlocks * kNdtAcc * sizeof(double)));
+    if (!ctx->ndt_built || ctx->ndt_res != prm->res) WM_TRY(ndt_build(ctx, prm->res));
+    NdtEval E;
+    E.ctx = ctx;
+    E.prm = prm;
+    {
+        const double c1 = 10.0 * (1.0 - prm->outlier_ratio), c2 = prm->outlier_ratio / pow(prm->res, 3);
+        const double d3 = -log(c2);
+        E.d1 = -log(c1 + c2) - d3;
+        E.d2 = -2.0 * log((-log(c1 * exp(-0.5) + c2) - d3) / E.d1);
+    }
+    double p[6] = {0, 0, 0, 0, 0, 0}, grad[6], hess[36], delta[6];
+    int rc = WM_OK, iter = 0;
+    bool converged = false;
+    const int max_it = prm->force_iterations > 0 ? prm->force_iterations : prm->max_iter;
+    double score = ndt_eval(E, p, grad, hess, &rc);
+    if (rc != WM_OK) return rc;
+    while (!converged) {
+        double neg[6], norm = 0;
+        for (int a = 0; a < 6; ++a) neg[a] = -grad[a];
+        svd_solve6(hess, neg, delta);
+        for (int a = 0; a < 6; ++a) norm += delta[a] * delta[a];
+        norm = sqrt(norm);
+        if (norm == 0 || norm != norm) {
+            converged = (norm == norm);
+            break;
+        }
+        for (int a = 0; a < 6; ++a) delta[a] /= norm;
+        const double alpha = step_length_mt(E, p, delta, norm, prm->step_size, prm->t_eps / 2, &score,
+                                            grad, hess, &rc);
+        if (rc != WM_OK) return rc;
+        for (int a = 0; a < 6; ++a) p[a] += delta[a] * alpha;
+        if (prm->force_iterations > 0) {
+            if (iter + 1 >= max_it) converged = true;
+        } else if (iter > max_it || (iter && fabs(alpha) < prm->t_eps)) {
+            converged = true;
+        }
+        ++iter;
+    }
+    if (stats) {
+        stats->converged = converged;
+        stats->iterations = iter;
+        stats->n_voxels = (int) ctx->ndt_nvalid;
+        stats->evaluations = E.evals;
+        stats->score = ctx->n_src > 0 ? score / (double) ctx->n_src_input : 0;
+        stats->deriv_kernel_ms = E.kernel_ms;
+    }
+    if (!converged) return WM_NOT_CONVERGED;
+    float Tf[16];
+    pose_to_matrix_f(p, Tf);
+    for (int k = 0; k < 16; ++k) T_out[k] = (double) Tf[k];
+    return WM_OK;
+}
+
+// score / gradient / Hessian at a given pose (kernel-level parity)
+int wm_ndt_derivatives(wm_ctx *ctx, const wm_ndt_params *prm, const double pose[6], double *score,
+                       double grad[6], double hess[36], int *n_voxels) {
+    if (!ctx || !prm || !pose || !score || !(prm->res > 0)) return WM_ERR_ARG;
+    if (ctx->n_src_input == 0 || ctx->n_tgt_input == 0) return WM_ERR_STATE;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_HIP(ctx, ctx->partials.reserve((size_t) kNdtBlocks * kNdtAcc * sizeof(double)));
+    if (!ctx->ndt_built || ctx->ndt_res != prm->res) WM_TRY(ndt_build(ctx, prm->res));
+    NdtEval E;
+    E.ctx = ctx;
+    E.prm = prm;
+    const double c1 = 10.0 * (1.0 - prm->outlier_ratio), c2 = prm->outlier_ratio / pow(prm->res, 3);
+    const double d3 = -log(c2);
+    E.d1 = -log(c1 + c2) - d3;
+    E.d2 = -2.0 * log((-log(c1 * exp(-0.5) + c2) - d3) / E.d1);
+    int rc = WM_OK;
+    double g[6], h[36];
+    *score = ndt_eval(E, pose, g, h, &rc);
+    if (grad) memcpy(grad, g, sizeof(g));
+    if (hess) memcpy(hess, h, sizeof(h));
+    if (n_voxels) *n_voxels = (int) ctx->ndt_nvalid;
+    return rc;
+}
+
+}  // extern "C"

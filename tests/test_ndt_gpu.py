@@ -1,0 +1,74 @@
+"""GPU parity of the NDT path (voxel statistics, score/gradient/Hessian kernel, Newton +
+More-Thuente driver) vs the oracle, on the reference's own test cases
+(wave_matching/tests/ndt_tests.cpp:45-102: res 0.05 / 0.1 identity, res 0.3 +0.2 m)."""
+import numpy as np
+import pytest
+
+from helpers import TOL_R, TOL_T, pose_error
+from libwave_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("res", [0.3, 1.0])
+def test_ndt_derivatives_match_oracle(wm, ctx, oracle, testscan, res):
+    P = np.eye(4)
+    P[0, 3] = 0.2
+    target = oracle.transform_cloud_d(testscan, P)
+    ctx.set_source(testscan)
+    ctx.set_target(target)
+    grid = oracle.NdtGrid(target, res)
+    for d1 in (1, 0):
+        oprm = oracle.ndt_params(res=res, pcl_d1_sign=d1)
+        for pose in (np.zeros(6), np.array([0.05, -0.02, 0.01, 0.004, -0.003, 0.006])):
+            s, g, H, nv = ctx.ndt_derivatives(pose, res=res, pcl_d1_sign=d1)
+            os_, og, oH = grid.derivatives(testscan, pose, oprm)
+            assert nv == grid.size()
+            assert abs(s - os_) <= 1e-9 * abs(os_)
+            np.testing.assert_allclose(g, og, rtol=1e-8, atol=1e-8 * np.abs(og).max())
+            np.testing.assert_allclose(H, oH, rtol=1e-8, atol=1e-8 * np.abs(oH).max())
+
+
+CASES = [("fullResNullMatch", 0.05, 0.0), ("nullDisplacement", 0.1, 0.0),
+         ("smallDisplacement", 0.3, 0.2)]
+
+
+@pytest.mark.parametrize("name,res,tx", CASES)
+def test_reference_ndt_cases(wm, ctx, oracle, testscan, name, res, tx):
+    P = np.eye(4)
+    P[0, 3] = tx
+    target = oracle.transform_cloud_d(testscan, P)
+    ctx.set_source(testscan)
+    ctx.set_target(target)
+    got = ctx.ndt_align(res=res, step_size=3, max_iter=100, t_eps=1e-8)  # tests/config/ndt.yaml
+    want = oracle.ndt_align(testscan, target, res=res, step_size=3, max_iter=100, t_eps=1e-8)
+    assert got["rc"] == 0 and got["converged"] and want["converged"]
+    assert np.linalg.norm(got["T"] - P) < 0.12          # ndt_tests.cpp:37 threshold
+    assert got["n_voxels"] == want["n_voxels"]
+    assert got["iterations"] == want["iterations"]
+    dt, ang = pose_error(got["T"], want["T"])
+    assert dt <= TOL_T and ang <= TOL_R, (dt, ang)
+
+
+def test_ndt_synthetic_and_skip_line_search(wm, ctx, oracle):
+    ref, tgt, T_gt = synth.pair(60000, seed=11)
+    ctx.set_source(ref)
+    ctx.set_target(tgt)
+    for kw in (dict(step_size=0.1), dict(step_size=0.1, skip_line_search=1, max_iter=30)):
+        got = ctx.ndt_align(res=1.0, t_eps=1e-6, **kw)
+        want = oracle.ndt_align(ref, tgt, res=1.0, t_eps=1e-6, **kw)
+        assert got["rc"] == 0
+        assert got["iterations"] == want["iterations"]
+        dt, ang = pose_error(got["T"], want["T"])
+        assert dt <= TOL_T and ang <= TOL_R, (dt, ang)
+
+
+def test_ndt_rebuilds_model_when_target_or_res_changes(wm, ctx, oracle, testscan):
+    ctx.set_source(testscan)
+    ctx.set_target(testscan)
+    a = ctx.ndt_derivatives(np.zeros(6), res=0.5)[3]
+    b = ctx.ndt_derivatives(np.zeros(6), res=1.0)[3]
+    assert a == oracle.NdtGrid(testscan, 0.5).size() and b == oracle.NdtGrid(testscan, 1.0).size()
+    ctx.set_target(testscan[:20000])
+    c = ctx.ndt_derivatives(np.zeros(6), res=1.0)[3]
+    assert c == oracle.NdtGrid(testscan[:20000], 1.0).size()
