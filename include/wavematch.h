@@ -208,6 +208,43 @@ int wm_icp_stats_for(wm_ctx *ctx, const double T[16], int mode, double stats[WM_
 int wm_umeyama_from_stats(const double stats[WM_STATS_LEN], double Tk_out[16]);
 int wm_gn6_from_stats(const double stats[WM_STATS_LEN], double Tk_out[16]);
 
+/* ------------------------------------------------------------------ GICP */
+typedef struct {
+    int corr_rand;        /* GICPMatcherParams::corr_rand, gicp.hpp:34 -> gicp.cpp:31 */
+    int max_iter;         /* GICPMatcherParams::max_iter,  gicp.hpp:35 -> gicp.cpp:32 */
+    double r_eps;         /* GICPMatcherParams::r_eps,     gicp.hpp:36 -> gicp.cpp:33 */
+    double t_eps;         /* PCL default 5e-4 (libwave never sets it) */
+    double max_corr;      /* PCL-GICP default 5 m (libwave never sets it) */
+    double gicp_epsilon;  /* PCL default 1e-3 */
+    int max_inner;        /* PCL default 20 BFGS iterations per outer iteration */
+    int force_iterations; /* >0: exactly this many outer iterations (bench) */
+} wm_gicp_params;
+
+typedef struct {
+    int converged, iterations, n_corr, inner_total, evaluations;
+    double f_final;
+    float fdf_kernel_ms; /* summed device time of the objective/gradient kernel */
+} wm_gicp_stats;
+
+void wm_gicp_default_params(wm_gicp_params *p);
+/* pcl::GeneralizedIterativeClosestPoint::align + hasConverged + getFinalTransformation
+ * (wave_matching/src/gicp.cpp:58-60) on the clouds given by wm_set_source/wm_set_target.
+ * Per-point covariances (computeCovariances, k = corr_rand) are computed on device and
+ * cached per cloud. */
+int wm_gicp_align(wm_ctx *ctx, const wm_gicp_params *p, double T_out[16], wm_gicp_stats *stats);
+/* GICPMatcher::setRef + setTarget + match in one call (gicp.cpp:37-64): both clouds are
+ * voxel-filtered on device when res > 0. */
+int wm_gicp_match(wm_ctx *ctx, const void *ref, size_t n_ref, const void *target, size_t n_target,
+                  size_t stride_bytes, int mem, const wm_gicp_params *p, float res, double T_out[16],
+                  wm_gicp_stats *stats);
+/* OptimizationFunctorWithIndices::fdf once: pairs + Mahalanobis matrices formed with
+ * T_pair as one outer iteration does, then f and gradient at x = (t, roll, pitch, yaw). */
+int wm_gicp_eval(wm_ctx *ctx, const wm_gicp_params *p, const double T_pair[16], const double x[6],
+                 double *f, double g[6], int *n_pairs);
+/* computeCovariances of both clouds (9 doubles per point, caller order); either output
+ * may be NULL (kernel-level parity). */
+int wm_gicp_covariances(wm_ctx *ctx, int k, double eps, double *cov_source, double *cov_target);
+
 /* ------------------------------------------------------------------- NDT */
 typedef struct {
     double res;           /* NDTMatcherParams::res,       ndt.hpp:40 -> ndt.cpp:32 setResolution */

@@ -43,6 +43,18 @@ class IcpStats(C.Structure):
                 ("deferred", C.c_uint64), ("grid_cell", C.c_float)]
 
 
+class GicpParams(C.Structure):
+    _fields_ = [("corr_rand", C.c_int), ("max_iter", C.c_int), ("r_eps", C.c_double),
+                ("t_eps", C.c_double), ("max_corr", C.c_double), ("gicp_epsilon", C.c_double),
+                ("max_inner", C.c_int), ("force_iterations", C.c_int)]
+
+
+class GicpStats(C.Structure):
+    _fields_ = [("converged", C.c_int), ("iterations", C.c_int), ("n_corr", C.c_int),
+                ("inner_total", C.c_int), ("evaluations", C.c_int), ("f_final", C.c_double),
+                ("fdf_kernel_ms", C.c_float)]
+
+
 class NdtParams(C.Structure):
     _fields_ = [("res", C.c_double), ("step_size", C.c_double), ("t_eps", C.c_double),
                 ("max_iter", C.c_int), ("outlier_ratio", C.c_double),
@@ -104,6 +116,15 @@ def lib():
         L.wm_host_icp_destroy.restype = None
         L.wm_host_icp_apply.argtypes = [C.c_void_p, _dp]
         L.wm_host_icp_get.argtypes = [C.c_void_p, C.POINTER(C.c_int), _dp, C.POINTER(IcpStats)]
+        L.wm_gicp_default_params.argtypes = [C.POINTER(GicpParams)]
+        L.wm_gicp_default_params.restype = None
+        L.wm_gicp_align.argtypes = [C.c_void_p, C.POINTER(GicpParams), _dp, C.POINTER(GicpStats)]
+        L.wm_gicp_match.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                    C.c_size_t, C.c_int, C.POINTER(GicpParams), C.c_float, _dp,
+                                    C.POINTER(GicpStats)]
+        L.wm_gicp_eval.argtypes = [C.c_void_p, C.POINTER(GicpParams), _dp, _dp, _dp, _dp,
+                                   C.POINTER(C.c_int)]
+        L.wm_gicp_covariances.argtypes = [C.c_void_p, C.c_int, C.c_double, _dp, _dp]
         L.wm_ndt_default_params.argtypes = [C.POINTER(NdtParams)]
         L.wm_ndt_default_params.restype = None
         L.wm_ndt_align.argtypes = [C.c_void_p, C.POINTER(NdtParams), _dp, C.POINTER(NdtStats)]
@@ -131,6 +152,16 @@ def declared_symbols(header=None):
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         names += re.findall(r"\b(wm_[a-z0-9_]+)\s*\(", txt)
     return sorted(set(names))
+
+
+def gicp_params(**kw):
+    p = GicpParams()
+    lib().wm_gicp_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
 
 
 def ndt_params(**kw):
@@ -279,6 +310,53 @@ class Context:
                                            float(lin_covar), float(ang_covar), float(max_corr),
                                            info.ctypes.data_as(_dp), C.byref(deg)), "wm_icp_info")
         return rc, info, bool(deg.value)
+
+    # ---- GICP
+    @staticmethod
+    def _gicp_dict(rc, T, s):
+        return dict(rc=rc, T=T if rc == WM_OK else None, converged=bool(s.converged),
+                    iterations=s.iterations, n_corr=s.n_corr, inner_total=s.inner_total,
+                    evaluations=s.evaluations, f=s.f_final, fdf_kernel_ms=s.fdf_kernel_ms)
+
+    def gicp_align(self, params=None, **kw):
+        p = params or gicp_params(**kw)
+        T = np.zeros((4, 4), np.float64)
+        s = GicpStats()
+        rc = self._check(lib().wm_gicp_align(self._h, C.byref(p), T.ctypes.data_as(_dp),
+                                             C.byref(s)), "wm_gicp_align")
+        return self._gicp_dict(rc, T, s)
+
+    def gicp_match(self, ref, target, res=-1.0, params=None, **kw):
+        p = params or gicp_params(**kw)
+        pr, nr, sr, mr, k1 = _cloud_arg(ref)
+        pt, nt, stt, mt, k2 = _cloud_arg(target)
+        assert sr == stt and mr == mt
+        T = np.zeros((4, 4), np.float64)
+        s = GicpStats()
+        rc = self._check(lib().wm_gicp_match(self._h, C.c_void_p(pr), nr, C.c_void_p(pt), nt, sr, mr,
+                                             C.byref(p), C.c_float(res), T.ctypes.data_as(_dp),
+                                             C.byref(s)), "wm_gicp_match")
+        self.n_src, self.n_tgt = self.sizes()
+        return self._gicp_dict(rc, T, s)
+
+    def gicp_eval(self, T_pair, x, params=None, **kw):
+        p = params or gicp_params(**kw)
+        T = np.ascontiguousarray(T_pair, np.float64)
+        x = np.ascontiguousarray(x, np.float64)
+        f = C.c_double(0)
+        g = np.zeros(6)
+        m = C.c_int(0)
+        self._check(lib().wm_gicp_eval(self._h, C.byref(p), T.ctypes.data_as(_dp),
+                                       x.ctypes.data_as(_dp), C.byref(f), g.ctypes.data_as(_dp),
+                                       C.byref(m)), "wm_gicp_eval")
+        return f.value, g, m.value
+
+    def gicp_covariances(self, k=10, eps=1e-3):
+        cs = np.zeros((self.n_src, 3, 3), np.float64)
+        ct = np.zeros((self.n_tgt, 3, 3), np.float64)
+        self._check(lib().wm_gicp_covariances(self._h, int(k), float(eps), cs.ctypes.data_as(_dp),
+                                              ct.ctypes.data_as(_dp)), "wm_gicp_covariances")
+        return cs, ct
 
     # ---- NDT
     def ndt_align(self, params=None, **kw):

@@ -1,0 +1,869 @@
+// wm_gicp.hip -- pcl::GeneralizedIterativeClosestPoint on device, as libwave's
+// GICPMatcher drives it (wave_matching/src/gicp.cpp:31-34 setters, :37-64
+// setInput*/align):
+//   k_gicp_cov    computeCovariances: exact k-NN of every point in its own cloud
+//                 (certified box search on that cloud's grid, (d2, index) order), float
+//                 products into double sums, 3x3 SVD, spectrum replaced by (1, 1, eps)
+//   k_nn_grid     (wm_nn.hip) the per-iteration 1-NN with the strict d2 < 25 gate
+//   k_gicp_mahal  M_i = (C2_j + R C1_i R^T)^-1 for every matched pair
+//   k_gicp_fdf    OptimizationFunctorWithIndices::fdf: f, sum M r (3), sum p (M r)^T (9)
+//                 -> 13 doubles per evaluation; the only thing the optimiser sees
+//   host          estimateRigidTransformationBFGS: pcl::BFGS (GSL vector_bfgs2 with
+//                 Fletcher's line search), applyState, the outer delta test
+// [PCL registration/impl/gicp.hpp, registration/bfgs.h]
+#include "wm_internal.hpp"
+
+#include <float.h>
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+namespace wm {
+
+constexpr int kGicpAcc = 13;
+constexpr int kGicpBlocks = 1024;
+
+__device__ __forceinline__ unsigned long long g_make_key(float d2, unsigned idx) {
+    return ((unsigned long long) __float_as_uint(d2) << 32) | idx;
+}
+__device__ __forceinline__ float g_d2(float qx, float qy, float qz, const float4 &t) {
+    const float dx = qx - t.x, dy = qy - t.y, dz = qz - t.z;
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// sorted insertion into an ascending register-resident list (drops the largest)
+template <int K>
+__device__ __forceinline__ void knn_insert(unsigned long long (&best)[K], unsigned long long key) {
+    if (key >= best[K - 1]) return;
+    unsigned long long cur = key;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const bool sw = cur < best[j];
+        const unsigned long long t = best[j];
+        best[j] = sw ? cur : t;
+        cur = sw ? t : cur;
+    }
+}
+
+// k nearest neighbours of q among the cell-sorted points of grid g: scan the box of cells
+// covering ball(q, r); certified once the k-th distance is within the box margin.
+template <int K>
+__device__ void knn_search(const GridDev &g, float qx, float qy, float qz, int k,
+                           unsigned long long (&best)[K]) {
+    const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
+    float r = 1.5f * g.h;
+    const float rmax = (float) (g.nx + g.ny + g.nz + 3) * g.h;  // covers the whole grid
+    for (;;) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) best[j] = ~0ull;
+        const float rc = r * g.inv_h + g.slack;
+        const int x0 = (int) floorf(fx - rc), x1 = (int) floorf(fx + rc);
+        const int y0 = (int) floorf(fy - rc), y1 = (int) floorf(fy + rc);
+        const int z0 = (int) floorf(fz - rc), z1 = (int) floorf(fz + rc);
+        const float mx = fminf(fx - (float) x0, (float) (x1 + 1) - fx);
+        const float my = fminf(fy - (float) y0, (float) (y1 + 1) - fy);
+        const float mz = fminf(fz - (float) z0, (float) (z1 + 1) - fz);
+        const float margin = (fminf(mx, fminf(my, mz)) - g.slack) * g.h;
+        const int xa = max(x0, 0), xb = min(x1, g.nx - 1);
+        const int ya = max(y0, 0), yb = min(y1, g.ny - 1);
+        const int za = max(z0, 0), zb = min(z1, g.nz - 1);
+        for (int zz = za; zz <= zb; ++zz)
+            for (int yy = ya; yy <= yb; ++yy) {
+                const size_t base = ((size_t) zz * g.ny + yy) * g.nx;
+                const unsigned s = g.cell_start[base + xa], e = g.cell_start[base + xb + 1];
+                for (unsigned j = s; j < e; ++j) {
+                    const float4 t = g.pts[j];
+                    knn_insert<K>(best, g_make_key(g_d2(qx, qy, qz, t), __float_as_uint(t.w)));
+                }
+            }
+        unsigned long long kth = ~0ull;
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (j == k - 1) kth = best[j];
+        const bool covers_all = x0 <= 0 && y0 <= 0 && z0 <= 0 && x1 >= g.nx - 1 && y1 >= g.ny - 1 &&
+                                z1 >= g.nz - 1;
+        if (covers_all) return;
+        if (kth != ~0ull && margin > 0.f) {
+            const float kd2 = __uint_as_float((unsigned) (kth >> 32));
+            if (kd2 <= margin * margin) return;
+            r = fmaxf(sqrtf(kd2) * 1.0001f + 1e-6f, 1.5f * r);  // one more pass certifies
+        } else {
+            r *= 2.0f;
+        }
+        r = fminf(r, rmax);
+    }
+}
+
+// computeCovariances for every point of `qpts` (any order); neighbours come from grid g
+// (built over the same cloud), coordinates are gathered from `orig` by caller index.
+template <int K>
+__global__ void __launch_bounds__(kBlock)
+    k_gicp_cov(GridDev g, const float4 *__restrict__ qpts, unsigned n,
+               const float4 *__restrict__ orig, int k, double eps, double *__restrict__ cov_out,
+               int by_w) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 q = qpts[i];
+    const unsigned slot = by_w ? __float_as_uint(q.w) : i;
+    double *out = cov_out + (size_t) slot * 9;
+    if (!(q.x == q.x)) {  // non-finite point: never matched; keep a defined value
+#pragma unroll
+        for (int a = 0; a < 9; ++a) out[a] = (a % 4 == 0) ? 1.0 : 0.0;
+        return;
+    }
+    unsigned long long best[K];
+    knn_search<K>(g, q.x, q.y, q.z, k, best);
+    double mean[3] = {0, 0, 0}, c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        if (j < k && best[j] != ~0ull) {
+            const float4 p = orig[(unsigned) best[j]];
+            mean[0] += p.x;
+            mean[1] += p.y;
+            mean[2] += p.z;
+            c[0] += __fmul_rn(p.x, p.x);  // float products, as `cov(0,0) += pt.x*pt.x`
+            c[3] += __fmul_rn(p.y, p.x);
+            c[4] += __fmul_rn(p.y, p.y);
+            c[6] += __fmul_rn(p.z, p.x);
+            c[7] += __fmul_rn(p.z, p.y);
+            c[8] += __fmul_rn(p.z, p.z);
+        }
+    }
+    const double kk = (double) k;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) mean[a] /= kk;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            if (b <= a) {
+                c[a * 3 + b] /= kk;
+                c[a * 3 + b] -= mean[a] * mean[b];
+                c[b * 3 + a] = c[a * 3 + b];
+            }
+    double U[9], S[3], V[9];
+    svd3(c, U, S, V);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            double s = 0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) s += (j == 2 ? eps : 1.0) * U[a * 3 + j] * U[b * 3 + j];
+            out[a * 3 + b] = s;
+        }
+}
+
+struct Mat3d {
+    double m[9];
+};
+
+__device__ inline void inv3(const double *m, double *o) {
+    const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8],
+                 c02 = m[3] * m[7] - m[4] * m[6];
+    const double id = 1.0 / (m[0] * c00 + m[1] * c01 + m[2] * c02);
+    o[0] = c00 * id;
+    o[1] = (m[2] * m[7] - m[1] * m[8]) * id;
+    o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c01 * id;
+    o[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+    o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c02 * id;
+    o[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+    o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+// mahalanobis_[i] = (R C1_i R^T + C2_j)^-1 for matched i (sorted-source order)
+__global__ void __launch_bounds__(kBlock)
+    k_gicp_mahal(unsigned n, const unsigned long long *__restrict__ keys,
+                 const double *__restrict__ C1, const double *__restrict__ C2, Mat3d R,
+                 double *__restrict__ mahal) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const unsigned j = (unsigned) keys[i];
+    if (j == kNoIdx) return;
+    const double *c1 = C1 + (size_t) i * 9, *c2 = C2 + (size_t) j * 9;
+    double M[9], t[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            double s = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) s += R.m[a * 3 + c] * c1[c * 3 + b];
+            M[a * 3 + b] = s;
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            double s = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) s += M[a * 3 + c] * R.m[b * 3 + c];
+            t[a * 3 + b] = s + c2[a * 3 + b];
+        }
+    double o[9];
+    inv3(t, o);
+    double *dst = mahal + (size_t) i * 9;
+#pragma unroll
+    for (int a = 0; a < 9; ++a) dst[a] = o[a];
+}
+
+struct FdfArgs {
+    float T[12];  // T(x) = applyState(base, x), float
+    float B[12];  // base_transformation_
+};
+
+// a[0] = sum r^T M r, a[1..3] = sum M r, a[4..12] = sum p_base (M r)^T; count separately
+__global__ void __launch_bounds__(kBlock)
+    k_gicp_fdf(const float4 *__restrict__ src, unsigned n,
+               const unsigned long long *__restrict__ keys, const float4 *__restrict__ tgt,
+               const double *__restrict__ mahal, FdfArgs A, double *__restrict__ partials) {
+    double a[kGicpAcc];
+#pragma unroll
+    for (int k = 0; k < kGicpAcc; ++k) a[k] = 0.0;
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const unsigned j = (unsigned) keys[i];
+        if (j == kNoIdx) continue;
+        const float4 p = src[i], q = tgt[j];
+        const float ppx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.T[0], p.x), __fmul_rn(A.T[1], p.y)), __fmul_rn(A.T[2], p.z)), A.T[3]);
+        const float ppy = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.T[4], p.x), __fmul_rn(A.T[5], p.y)), __fmul_rn(A.T[6], p.z)), A.T[7]);
+        const float ppz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.T[8], p.x), __fmul_rn(A.T[9], p.y)), __fmul_rn(A.T[10], p.z)), A.T[11]);
+        const double res[3] = {(double) __fsub_rn(ppx, q.x), (double) __fsub_rn(ppy, q.y),
+                               (double) __fsub_rn(ppz, q.z)};
+        const double *M = mahal + (size_t) i * 9;
+        double temp[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) temp[r] = M[r * 3] * res[0] + M[r * 3 + 1] * res[1] + M[r * 3 + 2] * res[2];
+        a[0] += res[0] * temp[0] + res[1] * temp[1] + res[2] * temp[2];
+        const float pbx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.B[0], p.x), __fmul_rn(A.B[1], p.y)), __fmul_rn(A.B[2], p.z)), A.B[3]);
+        const float pby = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.B[4], p.x), __fmul_rn(A.B[5], p.y)), __fmul_rn(A.B[6], p.z)), A.B[7]);
+        const float pbz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.B[8], p.x), __fmul_rn(A.B[9], p.y)), __fmul_rn(A.B[10], p.z)), A.B[11]);
+        const double pb[3] = {(double) pbx, (double) pby, (double) pbz};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            a[1 + r] += temp[r];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a[4 + r * 3 + c] += pb[r] * temp[c];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kGicpAcc; ++k)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a[k] += __shfl_down(a[k], off);
+    __shared__ double lds[kBlock / 64][kGicpAcc];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < kGicpAcc; ++k) lds[wave][k] = a[k];
+    __syncthreads();
+    if (threadIdx.x < kGicpAcc) {
+        double s = 0;
+        for (int w = 0; w < kBlock / 64; ++w) s += lds[w][threadIdx.x];
+        partials[(size_t) blockIdx.x * kGicpAcc + threadIdx.x] = s;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_count_matched(const unsigned long long *__restrict__ keys, unsigned n, unsigned *out) {
+    unsigned c = 0;
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        c += ((unsigned) keys[i] != kNoIdx);
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+// ------------------------------------------------------------------ host
+static void state_to_matrix_f(const double base[16], const double x[6], float T[16]) {
+    const float cphi = cosf((float) x[3]), sphi = sinf((float) x[3]);
+    const float cth = cosf((float) x[4]), sth = sinf((float) x[4]);
+    const float cpsi = cosf((float) x[5]), spsi = sinf((float) x[5]);
+    float R[9], B[16], o[16];
+    R[0] = cpsi * cth;
+    R[1] = cpsi * sth * sphi - spsi * cphi;
+    R[2] = cpsi * sth * cphi + spsi * sphi;
+    R[3] = spsi * cth;
+    R[4] = spsi * sth * sphi + cpsi * cphi;
+    R[5] = spsi * sth * cphi - cpsi * sphi;
+    R[6] = -sth;
+    R[7] = cth * sphi;
+    R[8] = cth * cphi;
+    for (int i = 0; i < 16; ++i) B[i] = (float) base[i];
+    memcpy(o, B, sizeof(o));
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float s = 0;
+            for (int k = 0; k < 3; ++k) s += R[i * 3 + k] * B[k * 4 + j];
+            o[i * 4 + j] = s;
+        }
+    o[3] = B[3] + (float) x[0];
+    o[7] = B[7] + (float) x[1];
+    o[11] = B[11] + (float) x[2];
+    memcpy(T, o, sizeof(o));
+}
+
+static void r_derivative(const double x[6], const double Racc[9], double g[6]) {
+    const double phi = x[3], theta = x[4], psi = x[5];
+    const double cphi = cos(phi), sphi = sin(phi), ctheta = cos(theta), stheta = sin(theta),
+                 cpsi = cos(psi), spsi = sin(psi);
+    const double dPhi[9] = {0, sphi * spsi + cphi * cpsi * stheta, cphi * spsi - cpsi * sphi * stheta,
+                            0, -cpsi * sphi + cphi * spsi * stheta, -cphi * cpsi - sphi * spsi * stheta,
+                            0, cphi * ctheta, -ctheta * sphi};
+    const double dTheta[9] = {-cpsi * stheta, cpsi * ctheta * sphi, cphi * cpsi * ctheta,
+                              -spsi * stheta, ctheta * sphi * spsi, cphi * ctheta * spsi,
+                              -ctheta, -sphi * stheta, -cphi * stheta};
+    const double dPsi[9] = {-ctheta * spsi, -cphi * cpsi - sphi * spsi * stheta, cpsi * sphi - cphi * spsi * stheta,
+                            cpsi * ctheta, -cphi * spsi + cpsi * sphi * stheta, sphi * spsi + cphi * cpsi * stheta,
+                            0, 0, 0};
+    g[3] = g[4] = g[5] = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {  // matricesInnerProd: sum mat1(j,i) * mat2(i,j)
+            g[3] += dPhi[j * 3 + i] * Racc[i * 3 + j];
+            g[4] += dTheta[j * 3 + i] * Racc[i * 3 + j];
+            g[5] += dPsi[j * 3 + i] * Racc[i * 3 + j];
+        }
+}
+
+struct GicpFn {
+    wm_ctx *ctx;
+    const double *base;
+    int m = 0;  // matched pairs
+    int evals = 0;
+    float kernel_ms = 0;
+    int rc = WM_OK;
+};
+
+static double gicp_fdf(GicpFn &F, const double x[6], double g[6]) {
+    wm_ctx *ctx = F.ctx;
+    FdfArgs A;
+    float T[16];
+    state_to_matrix_f(F.base, x, T);
+    for (int k = 0; k < 12; ++k) {
+        A.T[k] = T[k];
+        A.B[k] = (float) F.base[k];
+    }
+    const unsigned n = (unsigned) ctx->n_src;
+    int nb = (int) ((n + kBlock - 1) / kBlock);
+    if (nb > kGicpBlocks) nb = kGicpBlocks;
+    if (nb < 1) nb = 1;
+    (void) hipEventRecord(ctx->ev_a, ctx->stream);
+    hipLaunchKernelGGL(k_gicp_fdf, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->src_sorted.as<float4>(),
+                       n, ctx->keys.as<unsigned long long>(), ctx->tgt_orig.as<float4>(),
+                       ctx->gicp_mahal.as<double>(), A, ctx->partials.as<double>());
+    (void) hipEventRecord(ctx->ev_b, ctx->stream);
+    std::vector<double> h((size_t) nb * kGicpAcc);
+    if (hipMemcpyAsync(h.data(), ctx->partials.p, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        F.rc = WM_ERR_HIP;
+        ctx->last_error = "gicp_fdf: HIP error";
+        return 0;
+    }
+    float ms = 0;
+    (void) hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b);
+    F.kernel_ms += ms;
+    F.evals++;
+    double a[kGicpAcc];
+    for (int k = 0; k < kGicpAcc; ++k) {
+        double s = 0;
+        for (int b = 0; b < nb; ++b) s += h[(size_t) b * kGicpAcc + k];
+        a[k] = s;
+    }
+    const double m = (double) F.m;
+    if (g) {
+        double Racc[9];
+        for (int k = 0; k < 3; ++k) g[k] = a[1 + k] * 2.0 / m;
+        for (int k = 0; k < 9; ++k) Racc[k] = a[4 + k] * 2.0 / m;
+        r_derivative(x, Racc, g);
+    }
+    return a[0] / m;
+}
+
+// ---- pcl::BFGS (GSL vector_bfgs2 + Fletcher line search)
+struct LineFn {
+    GicpFn *F;
+    double x0[6], p[6], f0, df0;
+    double x_a[6], g_a[6], alpha_c, f_c, df_c;
+    bool have_c = false;
+    void eval(double alpha) {
+        if (have_c && alpha == alpha_c) return;
+        for (int i = 0; i < 6; ++i) x_a[i] = x0[i] + alpha * p[i];
+        f_c = gicp_fdf(*F, x_a, g_a);
+        df_c = 0;
+        for (int i = 0; i < 6; ++i) df_c += g_a[i] * p[i];
+        alpha_c = alpha;
+        have_c = true;
+    }
+};
+
+static double cubic(double c0, double c1, double c2, double c3, double z) { return c0 + z * (c1 + z * (c2 + z * c3)); }
+static void check_extremum(double c0, double c1, double c2, double c3, double z, double *zmin, double *fmin) {
+    const double y = cubic(c0, c1, c2, c3, z);
+    if (y < *fmin) {
+        *zmin = z;
+        *fmin = y;
+    }
+}
+static int solve_quadratic(double a, double b, double c, double *x0, double *x1) {
+    if (a == 0) {
+        if (b == 0) return 0;
+        *x0 = -c / b;
+        return 1;
+    }
+    const double disc = b * b - 4 * a * c;
+    if (disc > 0) {
+        if (b == 0) {
+            const double r = sqrt(-c / a);
+            *x0 = -r;
+            *x1 = r;
+        } else {
+            const double sgnb = (b > 0 ? 1 : -1);
+            const double temp = -0.5 * (b + sgnb * sqrt(disc));
+            const double r1 = temp / a, r2 = c / temp;
+            *x0 = r1 < r2 ? r1 : r2;
+            *x1 = r1 < r2 ? r2 : r1;
+        }
+        return 2;
+    } else if (disc == 0) {
+        *x0 = *x1 = -0.5 * b / a;
+        return 2;
+    }
+    return 0;
+}
+static double interp_quad(double f0, double fp0, double f1, double zl, double zh) {
+    const double fl = f0 + zl * (fp0 + zl * (f1 - f0 - fp0));
+    const double fh = f0 + zh * (fp0 + zh * (f1 - f0 - fp0));
+    const double c = 2 * (f1 - f0 - fp0);
+    double zmin = zl, fmin = fl;
+    if (fh < fmin) {
+        zmin = zh;
+        fmin = fh;
+    }
+    if (c > 0) {
+        const double z = -fp0 / c;
+        if (z > zl && z < zh) {
+            const double f = f0 + z * (fp0 + z * (f1 - f0 - fp0));
+            if (f < fmin) {
+                zmin = z;
+                fmin = f;
+            }
+        }
+    }
+    return zmin;
+}
+static double interp_cubic(double f0, double fp0, double f1, double fp1, double zl, double zh) {
+    const double eta = 3 * (f1 - f0) - 2 * fp0 - fp1, xi = fp0 + fp1 - 2 * (f1 - f0);
+    const double c0 = f0, c1 = fp0, c2 = eta, c3 = xi;
+    double zmin = zl, fmin = cubic(c0, c1, c2, c3, zl), z0, z1;
+    check_extremum(c0, c1, c2, c3, zh, &zmin, &fmin);
+    const int n = solve_quadratic(3 * c3, 2 * c2, c1, &z0, &z1);
+    if (n == 2) {
+        if (z0 > zl && z0 < zh) check_extremum(c0, c1, c2, c3, z0, &zmin, &fmin);
+        if (z1 > zl && z1 < zh) check_extremum(c0, c1, c2, c3, z1, &zmin, &fmin);
+    } else if (n == 1) {
+        if (z0 > zl && z0 < zh) check_extremum(c0, c1, c2, c3, z0, &zmin, &fmin);
+    }
+    return zmin;
+}
+static double interpolate(double a, double fa, double fpa, double b, double fb, double fpb, double xmin,
+                          double xmax, int order) {
+    double ymin = (xmin - a) / (b - a), ymax = (xmax - a) / (b - a);
+    if (ymin > ymax) {
+        const double t = ymin;
+        ymin = ymax;
+        ymax = t;
+    }
+    const double y = (order > 2 && fpb == fpb) ? interp_cubic(fa, fpa * (b - a), fb, fpb * (b - a), ymin, ymax)
+                                               : interp_quad(fa, fpa * (b - a), fb, ymin, ymax);
+    return a + y * (b - a);
+}
+
+static bool line_search(LineFn &L, double rho, double sigma, double tau1, double tau2, double tau3,
+                        int order, double alpha1, double *alpha_new) {
+    const double f0 = L.f0, fp0 = L.df0;
+    double falpha, falpha_prev = f0, fpalpha, fpalpha_prev = fp0, delta, alpha_next;
+    double alpha = alpha1, alpha_prev = 0.0;
+    double a = 0.0, b = alpha, fa = f0, fb = 0.0, fpa = fp0, fpb = 0.0;
+    int i = 0;
+    while (i++ < 100) {
+        L.eval(alpha);
+        falpha = L.f_c;
+        if (falpha > f0 + alpha * rho * fp0 || falpha >= falpha_prev) {
+            a = alpha_prev; fa = falpha_prev; fpa = fpalpha_prev;
+            b = alpha; fb = falpha; fpb = NAN;
+            break;
+        }
+        fpalpha = L.df_c;
+        if (fabs(fpalpha) <= -sigma * fp0) {
+            *alpha_new = alpha;
+            return true;
+        }
+        if (fpalpha >= 0) {
+            a = alpha; fa = falpha; fpa = fpalpha;
+            b = alpha_prev; fb = falpha_prev; fpb = fpalpha_prev;
+            break;
+        }
+        delta = alpha - alpha_prev;
+        alpha_next = interpolate(alpha_prev, falpha_prev, fpalpha_prev, alpha, falpha, fpalpha,
+                                 alpha + delta, alpha + tau1 * delta, order);
+        alpha_prev = alpha; falpha_prev = falpha; fpalpha_prev = fpalpha;
+        alpha = alpha_next;
+    }
+    while (i++ < 100) {
+        delta = b - a;
+        alpha = interpolate(a, fa, fpa, b, fb, fpb, a + tau2 * delta, b - tau3 * delta, order);
+        L.eval(alpha);
+        falpha = L.f_c;
+        if ((a - alpha) * fpa <= DBL_EPSILON) return false;  // roundoff prevents progress
+        if (falpha > f0 + rho * alpha * fp0 || falpha >= fa) {
+            b = alpha; fb = falpha; fpb = NAN;
+        } else {
+            fpalpha = L.df_c;
+            if (fabs(fpalpha) <= -sigma * fp0) {
+                *alpha_new = alpha;
+                return true;
+            }
+            if (((b - a) >= 0 && fpalpha >= 0) || ((b - a) <= 0 && fpalpha <= 0)) {
+                b = a; fb = fa; fpb = fpa;
+                a = alpha; fa = falpha; fpa = fpalpha;
+            } else {
+                a = alpha; fa = falpha; fpa = fpalpha;
+            }
+        }
+    }
+    *alpha_new = alpha;
+    return true;
+}
+
+static double norm6(const double *v) {
+    double s = 0;
+    for (int i = 0; i < 6; ++i) s += v[i] * v[i];
+    return sqrt(s);
+}
+
+// estimateRigidTransformationBFGS; returns inner iterations, -1 if < 4 pairs
+static int bfgs_minimize(GicpFn &F, double x[6], int max_inner, double *f_out) {
+    const double rho = 0.01, sigma = 0.01, tau1 = 9, tau2 = 0.05, tau3 = 0.5, gradient_tol = 1e-2;
+    if (F.m < 4) return -1;
+    double g[6], x0[6], g0[6], p[6], dx0[6], dg0[6];
+    double f = gicp_fdf(F, x, g);
+    memcpy(x0, x, sizeof(x0));
+    memcpy(g0, g, sizeof(g0));
+    double g0norm = norm6(g0);
+    for (int i = 0; i < 6; ++i) p[i] = -g0[i] / g0norm;
+    double pnorm = norm6(p), fp0 = -g0norm, delta_f = 0;
+    int inner = 0;
+    do {
+        ++inner;
+        if (F.rc != WM_OK) break;
+        if (pnorm == 0.0 || g0norm == 0.0 || fp0 == 0 || pnorm != pnorm || g0norm != g0norm) break;
+        const double f_prev = f;
+        double alpha = 0, alpha1;
+        if (delta_f < 0) {
+            const double del = fmax(-delta_f, 10 * DBL_EPSILON * fabs(f_prev));
+            alpha1 = fmin(1.0, 2.0 * del / (-fp0));
+        } else {
+            alpha1 = 1.0;  // parameters.step_size
+        }
+        LineFn L;
+        L.F = &F;
+        memcpy(L.x0, x0, sizeof(x0));
+        memcpy(L.p, p, sizeof(p));
+        L.f0 = f_prev;
+        L.df0 = fp0;
+        if (!line_search(L, rho, sigma, tau1, tau2, tau3, 3, alpha1, &alpha)) break;
+        L.eval(alpha);
+        memcpy(x, L.x_a, sizeof(L.x_a));
+        memcpy(g, L.g_a, sizeof(L.g_a));
+        f = L.f_c;
+        delta_f = f - f_prev;
+        double dxg = 0, dgg = 0, dxdg = 0, A, B, pg = 0;
+        for (int i = 0; i < 6; ++i) {
+            dx0[i] = x[i] - x0[i];
+            dg0[i] = g[i] - g0[i];
+        }
+        for (int i = 0; i < 6; ++i) {
+            dxg += dx0[i] * g[i];
+            dgg += dg0[i] * g[i];
+            dxdg += dx0[i] * dg0[i];
+        }
+        const double dgnorm = norm6(dg0);
+        if (dxdg != 0) {
+            B = dxg / dxdg;
+            A = -(1.0 + dgnorm * dgnorm / dxdg) * B + dgg / dxdg;
+        } else {
+            B = 0;
+            A = 0;
+        }
+        for (int i = 0; i < 6; ++i) p[i] = g[i] - A * dx0[i] - B * dg0[i];
+        memcpy(g0, g, sizeof(g0));
+        memcpy(x0, x, sizeof(x0));
+        g0norm = norm6(g0);
+        pnorm = norm6(p);
+        for (int i = 0; i < 6; ++i) pg += p[i] * g0[i];
+        const double dir = (pg >= 0) ? -1.0 : +1.0;
+        for (int i = 0; i < 6; ++i) p[i] *= dir / pnorm;
+        pnorm = norm6(p);
+        fp0 = 0;
+        for (int i = 0; i < 6; ++i) fp0 += p[i] * g0[i];
+        if (norm6(g) < gradient_tol) break;
+    } while (inner < max_inner);
+    if (f_out) *f_out = f;
+    return inner;
+}
+
+static float choose_cell(const Bbox &bb, size_t n) {
+    double vol = 1;
+    for (int d = 0; d < 3; ++d) vol *= fmax((double) bb.hi[d] - bb.lo[d], 1e-3);
+    return (float) fmax(cbrt(vol / fmax((double) n, 1.0)) * 1.5, 1e-4);
+}
+
+template <int K>
+static int launch_cov(wm_ctx *ctx, const GridDev &g, const float4 *q, size_t n, const float4 *orig,
+                      int k, double eps, double *out, int by_w) {
+    if (n == 0) return WM_OK;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gicp_cov<K>), dim3((unsigned) ((n + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, ctx->stream, g, q, (unsigned) n, orig, k, eps, out, by_w);
+    WM_HIP(ctx, hipGetLastError());
+    return WM_OK;
+}
+
+static int compute_covariances(wm_ctx *ctx, int k, double eps) {
+    if (k > 32) return WM_ERR_ARG;
+    const bool same = ctx->gicp_cov_k == k && ctx->gicp_cov_eps == eps;
+    if (!(ctx->gicp_cov_tgt_valid && same)) {
+        // target: neighbours from the level-0 grid (built by wm_set_target)
+        WM_HIP(ctx, ctx->gicp_c2.reserve((ctx->n_tgt_input > 0 ? ctx->n_tgt_input : 1) * 9 * sizeof(double)));
+        const GridDev &g = ctx->levels[0].d;
+        const float4 *q = ctx->tgt_orig.as<float4>();
+        if (k <= 16)
+            WM_TRY(launch_cov<16>(ctx, g, q, ctx->n_tgt_input, q, k, eps, ctx->gicp_c2.as<double>(), 0));
+        else
+            WM_TRY(launch_cov<32>(ctx, g, q, ctx->n_tgt_input, q, k, eps, ctx->gicp_c2.as<double>(), 0));
+        ctx->gicp_cov_tgt_valid = true;
+    }
+    if (!(ctx->gicp_cov_src_valid && same)) {
+        // source: its own grid; covariances stored in Morton (src_sorted) order
+        WM_HIP(ctx, ctx->gicp_c1.reserve((ctx->n_src > 0 ? ctx->n_src : 1) * 9 * sizeof(double)));
+        double occ = 0;
+        float h = choose_cell(ctx->src_bbox, ctx->n_src);
+        WM_TRY(build_grid_level(ctx, ctx->src_orig.as<float4>(), ctx->n_src_input, ctx->src_bbox, h,
+                                &ctx->src_grid, &occ));
+        if (occ > 6.0 || (occ > 0 && occ < 1.5)) {
+            h = (float) (h * sqrt(3.0 / occ));
+            WM_TRY(build_grid_level(ctx, ctx->src_orig.as<float4>(), ctx->n_src_input, ctx->src_bbox, h,
+                                    &ctx->src_grid, nullptr));
+        }
+        const float4 *q = ctx->src_sorted.as<float4>();
+        if (k <= 16)
+            WM_TRY(launch_cov<16>(ctx, ctx->src_grid.d, q, ctx->n_src, ctx->src_orig.as<float4>(), k, eps,
+                                  ctx->gicp_c1.as<double>(), 0));
+        else
+            WM_TRY(launch_cov<32>(ctx, ctx->src_grid.d, q, ctx->n_src, ctx->src_orig.as<float4>(), k, eps,
+                                  ctx->gicp_c1.as<double>(), 0));
+        ctx->gicp_cov_src_valid = true;
+    }
+    ctx->gicp_cov_k = k;
+    ctx->gicp_cov_eps = eps;
+    return WM_OK;
+}
+
+}  // namespace wm
+
+using namespace wm;
+
+extern "C" {
+
+void wm_gicp_default_params(wm_gicp_params *p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->corr_rand = 10;       // gicp.hpp:34
+    p->max_iter = 100;       // gicp.hpp:35
+    p->r_eps = 1e-8;         // gicp.hpp:36
+    p->t_eps = 5e-4;         // PCL GICP transformation_epsilon_ (libwave never sets it)
+    p->max_corr = 5.0;       // PCL GICP corr_dist_threshold_  (libwave never sets it)
+    p->gicp_epsilon = 1e-3;  // PCL GICP gicp_epsilon_
+    p->max_inner = 20;       // max_inner_iterations_
+}
+
+int wm_gicp_covariances(wm_ctx *ctx, int k, double eps, double *cov_source, double *cov_target) {
+    if (!ctx || k < 1 || k > 32) return WM_ERR_ARG;
+    if (ctx->n_src_input == 0 || ctx->n_tgt_input == 0) return WM_ERR_STATE;
+    if ((size_t) k > ctx->n_src || (size_t) k > ctx->n_tgt) return WM_NOT_CONVERGED;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_TRY(compute_covariances(ctx, k, eps));
+    if (cov_target)
+        WM_HIP(ctx, hipMemcpyAsync(cov_target, ctx->gicp_c2.p, ctx->n_tgt_input * 9 * sizeof(double),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (cov_source) {
+        // un-permute from Morton order to caller order
+        std::vector<double> tmp(ctx->n_src * 9);
+        std::vector<float> pts(ctx->n_src * 4);
+        WM_HIP(ctx, hipMemcpy(tmp.data(), ctx->gicp_c1.p, tmp.size() * 8, hipMemcpyDeviceToHost));
+        WM_HIP(ctx, hipMemcpy(pts.data(), ctx->src_sorted.p, pts.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ctx->n_src; ++i) {
+            unsigned o;
+            memcpy(&o, &pts[i * 4 + 3], 4);
+            memcpy(cov_source + (size_t) o * 9, &tmp[i * 9], 9 * sizeof(double));
+        }
+    }
+    return WM_OK;
+}
+
+int wm_gicp_align(wm_ctx *ctx, const wm_gicp_params *prm, double T_out[16], wm_gicp_stats *stats) {
+    if (!ctx || !prm || !T_out || prm->corr_rand < 1 || prm->corr_rand > 32 || !(prm->max_corr > 0))
+        return WM_ERR_ARG;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (ctx->n_src_input == 0 || ctx->n_tgt_input == 0) return WM_ERR_STATE;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    // PCL: "Number of points in cloud is less than k_correspondences_" -> no alignment
+    if ((size_t) prm->corr_rand > ctx->n_src || (size_t) prm->corr_rand > ctx->n_tgt) return WM_NOT_CONVERGED;
+    WM_TRY(compute_covariances(ctx, prm->corr_rand, prm->gicp_epsilon));
+    const size_t n = ctx->n_src;
+    WM_HIP(ctx, ctx->gicp_mahal.reserve(n * 9 * sizeof(double)));
+    WM_HIP(ctx, ctx->partials.reserve((size_t) kGicpBlocks * kGicpAcc * sizeof(double) + 64));
+    const float thr = threshold_d2_strict(prm->max_corr);
+    double base[16];
+    mat4_identity(base);
+    float T[16], prevT[16];
+    for (int i = 0; i < 16; ++i) T[i] = prevT[i] = (i % 5 == 0) ? 1.f : 0.f;
+    GicpFn F;
+    F.ctx = ctx;
+    F.base = base;
+    const int max_it = prm->force_iterations > 0 ? prm->force_iterations : prm->max_iter;
+    int iter = 0, inner_total = 0;
+    bool converged = false;
+    double f_last = 0;
+    unsigned cnt = 0;
+    const unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
+    while (!converged) {
+        double Td[16];
+        for (int i = 0; i < 16; ++i) Td[i] = (double) T[i];
+        // 1-NN of every transformed source point, d2 < max_corr^2 (strict)
+        WM_TRY(nn_pass(ctx, Td, thr, prm->max_corr, iter > 0));
+        Mat3d R;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) R.m[a * 3 + b] = (double) T[a * 4 + b];
+        unsigned *d_cnt = ctx->bbox_buf.as<unsigned>();
+        WM_HIP(ctx, hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(k_gicp_mahal, dim3(blocks), dim3(kBlock), 0, ctx->stream, (unsigned) n,
+                           ctx->keys.as<unsigned long long>(), ctx->gicp_c1.as<double>(),
+                           ctx->gicp_c2.as<double>(), R, ctx->gicp_mahal.as<double>());
+        hipLaunchKernelGGL(k_count_matched, dim3(blocks > 1024 ? 1024 : blocks), dim3(kBlock), 0,
+                           ctx->stream, ctx->keys.as<unsigned long long>(), (unsigned) n, d_cnt);
+        WM_HIP(ctx, hipGetLastError());
+        WM_HIP(ctx, hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+        WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(prevT, T, sizeof(T));
+        double x[6] = {T[3], T[7], T[11], atan2(T[9], T[10]), asin(-T[8]), atan2(T[4], T[0])};
+        F.m = (int) cnt;
+        const int inner = bfgs_minimize(F, x, prm->max_inner, &f_last);
+        if (F.rc != WM_OK) return F.rc;
+        if (inner < 0) break;  // NotEnoughPointsException: loop breaks, converged_ stays false
+        inner_total += inner;
+        state_to_matrix_f(base, x, T);
+        double delta = 0;
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) {
+                const double ratio = (a < 3 && b < 3) ? 1.0 / prm->r_eps : 1.0 / prm->t_eps;
+                const double cd = ratio * fabs((double) prevT[a * 4 + b] - (double) T[a * 4 + b]);
+                if (cd > delta) delta = cd;
+            }
+        ++iter;
+        if (prm->force_iterations > 0 ? (iter >= max_it) : (iter >= max_it || delta < 1)) {
+            converged = true;
+            memcpy(prevT, T, sizeof(T));
+        }
+    }
+    ctx->have_corr = true;
+    ctx->last_align_valid = false;
+    if (stats) {
+        stats->converged = converged;
+        stats->iterations = iter;
+        stats->n_corr = (int) cnt;
+        stats->inner_total = inner_total;
+        stats->evaluations = F.evals;
+        stats->f_final = f_last;
+        stats->fdf_kernel_ms = F.kernel_ms;
+    }
+    if (!converged) return cnt < 4 ? WM_TOO_FEW_CORRESPONDENCES : WM_NOT_CONVERGED;
+    for (int i = 0; i < 16; ++i) T_out[i] = (double) prevT[i];
+    return WM_OK;
+}
+
+// One evaluation of the GICP objective and gradient (kernel-level parity): pairs and
+// Mahalanobis matrices are formed with T_pair exactly as one outer iteration does, then
+// f and its gradient are evaluated at state x on top of the identity base.
+int wm_gicp_eval(wm_ctx *ctx, const wm_gicp_params *prm, const double T_pair[16], const double x[6],
+                 double *f, double g[6], int *n_pairs) {
+    if (!ctx || !prm || !T_pair || !x || !f) return WM_ERR_ARG;
+    if (ctx->n_src_input == 0 || ctx->n_tgt_input == 0) return WM_ERR_STATE;
+    if ((size_t) prm->corr_rand > ctx->n_src || (size_t) prm->corr_rand > ctx->n_tgt) return WM_NOT_CONVERGED;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_TRY(compute_covariances(ctx, prm->corr_rand, prm->gicp_epsilon));
+    const size_t n = ctx->n_src;
+    WM_HIP(ctx, ctx->gicp_mahal.reserve(n * 9 * sizeof(double)));
+    WM_HIP(ctx, ctx->partials.reserve((size_t) kGicpBlocks * kGicpAcc * sizeof(double) + 64));
+    double Td[16];
+    Mat3d R;
+    for (int i = 0; i < 16; ++i) Td[i] = (double) (float) T_pair[i];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) R.m[a * 3 + b] = Td[a * 4 + b];
+    WM_TRY(nn_pass(ctx, Td, threshold_d2_strict(prm->max_corr), prm->max_corr, false));
+    const unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
+    unsigned *d_cnt = ctx->bbox_buf.as<unsigned>(), cnt = 0;
+    WM_HIP(ctx, hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_gicp_mahal, dim3(blocks), dim3(kBlock), 0, ctx->stream, (unsigned) n,
+                       ctx->keys.as<unsigned long long>(), ctx->gicp_c1.as<double>(),
+                       ctx->gicp_c2.as<double>(), R, ctx->gicp_mahal.as<double>());
+    hipLaunchKernelGGL(k_count_matched, dim3(blocks > 1024 ? 1024 : blocks), dim3(kBlock), 0,
+                       ctx->stream, ctx->keys.as<unsigned long long>(), (unsigned) n, d_cnt);
+    WM_HIP(ctx, hipGetLastError());
+    WM_HIP(ctx, hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_corr = true;
+    ctx->last_align_valid = false;
+    if (n_pairs) *n_pairs = (int) cnt;
+    if (cnt == 0) return WM_TOO_FEW_CORRESPONDENCES;
+    double base[16];
+    mat4_identity(base);
+    GicpFn F;
+    F.ctx = ctx;
+    F.base = base;
+    F.m = (int) cnt;
+    double gg[6];
+    *f = gicp_fdf(F, x, gg);
+    if (g) memcpy(g, gg, sizeof(gg));
+    return F.rc;
+}
+
+// GICPMatcher: setRef / setTarget (voxel filter when res > 0, gicp.cpp:37-55) + match
+int wm_gicp_match(wm_ctx *ctx, const void *ref, size_t n_ref, const void *target, size_t n_target,
+                  size_t stride, int mem, const wm_gicp_params *p, float res, double T_out[16],
+                  wm_gicp_stats *stats) {
+    if (!ctx || !p || !T_out || (n_ref > 0 && !ref) || (n_target > 0 && !target) || stride < 12 ||
+        (stride & 3) || n_ref > 0x7FFFFFF0u || n_target > 0x7FFFFFF0u)
+        return WM_ERR_ARG;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    if (!(res > 0)) {
+        WM_TRY(wm_set_source(ctx, ref, n_ref, stride, mem));
+        WM_TRY(wm_set_target(ctx, target, n_target, stride, mem));
+        return wm_gicp_align(ctx, p, T_out, stats);
+    }
+    const size_t cap_r = n_ref > 0 ? n_ref : 1, cap_t = n_target > 0 ? n_target : 1;
+    WM_HIP(ctx, ctx->match_ref.reserve(cap_r * sizeof(float4)));
+    WM_HIP(ctx, ctx->match_tgt.reserve(cap_t * sizeof(float4)));
+    WM_HIP(ctx, ctx->ds_ref.reserve(cap_r * sizeof(float4)));
+    WM_HIP(ctx, ctx->ds_tgt.reserve(cap_t * sizeof(float4)));
+    WM_TRY(pack_cloud(ctx, ref, n_ref, stride, mem, ctx->match_ref.as<float4>()));
+    WM_TRY(pack_cloud(ctx, target, n_target, stride, mem, ctx->match_tgt.as<float4>()));
+    size_t nr = 0, nt = 0;
+    WM_TRY(voxel_downsample_dev(ctx, ctx->match_ref.as<float4>(), n_ref, res, ctx->ds_ref.as<float4>(), &nr));
+    WM_TRY(voxel_downsample_dev(ctx, ctx->match_tgt.as<float4>(), n_target, res, ctx->ds_tgt.as<float4>(), &nt));
+    WM_TRY(wm_set_source(ctx, ctx->ds_ref.p, nr, sizeof(float4), WM_MEM_DEVICE));
+    WM_TRY(wm_set_target(ctx, ctx->ds_tgt.p, nt, sizeof(float4), WM_MEM_DEVICE));
+    return wm_gicp_align(ctx, p, T_out, stats);
+}
+
+}  // extern "C"

@@ -448,7 +448,9 @@ void wm_ctx_destroy(wm_ctx *ctx) {
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->src_sorted, &ctx->tgt_orig, &ctx->staging, &ctx->cell_of, &ctx->counts,
                       &ctx->block_sums, &ctx->bbox_buf, &ctx->keys, &ctx->keys_bak, &ctx->d_levels, &ctx->ndt_keys, &ctx->ndt_keys2,
-                      &ctx->ndt_vox, &ctx->ndt_vkey, &ctx->ndt_hkeys, &ctx->ndt_hvals, &ctx->vg_idx, &ctx->vg_idx2, &ctx->vg_perm,
+                      &ctx->ndt_vox, &ctx->ndt_vkey, &ctx->ndt_hkeys, &ctx->ndt_hvals, &ctx->src_orig,
+                      &ctx->gicp_c1, &ctx->gicp_c2, &ctx->gicp_mahal, &ctx->src_grid.pts,
+                      &ctx->src_grid.cell_start, &ctx->vg_idx, &ctx->vg_idx2, &ctx->vg_perm,
                       &ctx->vg_perm2, &ctx->vg_tmp, &ctx->vg_seg, &ctx->io_a, &ctx->io_b, &ctx->ds_ref,
                       &ctx->ds_tgt, &ctx->match_ref, &ctx->match_tgt,
                       &ctx->partials, &ctx->corr_tmp_idx, &ctx->corr_tmp_d2, &ctx->d_state};
@@ -488,12 +490,13 @@ int wm_set_source(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem
     ctx->n_src_input = n;
     ctx->n_src = 0;
     if (n == 0) return WM_OK;
-    // pack into scratch, then Morton-order into src_sorted
-    DevBuf &tmp = ctx->corr_tmp_d2;
+    // pack (caller order, kept for GICP's k-NN covariances), then Morton-order
+    ctx->gicp_cov_src_valid = false;
+    DevBuf &tmp = ctx->src_orig;
     WM_HIP(ctx, tmp.reserve(n * sizeof(float4)));
     WM_HIP(ctx, ctx->src_sorted.reserve(n * sizeof(float4)));
     WM_TRY(pack_cloud(ctx, pts, n, stride, mem, tmp.as<float4>()));
-    Bbox bb;
+    Bbox &bb = ctx->src_bbox;
     size_t valid = 0;
     WM_TRY(compute_bbox(ctx, tmp.as<float4>(), n, &bb, &valid));
     size_t sorted = 0;
@@ -507,6 +510,7 @@ int wm_set_target(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem
     WM_HIP(ctx, hipSetDevice(ctx->device));
     ctx->have_corr = false;
     ctx->ndt_built = false;
+    ctx->gicp_cov_tgt_valid = false;
     ctx->n_tgt_input = n;
     ctx->n_tgt = 0;
     for (auto &l : ctx->levels) l.built = false;

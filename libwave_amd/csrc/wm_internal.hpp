@@ -147,6 +147,14 @@ struct wm_ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     std::vector<float> iter_nn_ms;
 
+    // GICP: caller-order source, its own search grid, per-point covariances
+    wm::DevBuf src_orig, gicp_c1, gicp_c2, gicp_mahal;
+    wm::Bbox src_bbox{};
+    wm::GridLevel src_grid;
+    bool gicp_cov_src_valid = false, gicp_cov_tgt_valid = false;
+    int gicp_cov_k = 0;
+    double gicp_cov_eps = 0;
+
     // NDT voxel model of the target
     wm::DevBuf ndt_keys, ndt_keys2, ndt_vox, ndt_vkey, ndt_hkeys, ndt_hvals;
     bool ndt_built = false;

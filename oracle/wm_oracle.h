@@ -155,7 +155,8 @@ int wmo_gicp_covariances(const float *xyz, int n, int k, double eps, double *cov
 int wmo_gicp_align(const float *src, int n, const float *tgt, int m,
                    const wmo_gicp_params *p, double T_out[16], wmo_gicp_result *res);
 /* f and gradient of the GICP objective for given pairs (kernel-level parity):
- * x = (tx,ty,tz,roll,pitch,yaw); base = 4x4 applied first.  M = n_pairs x 9 */
+ * x = (tx,ty,tz,roll,pitch,yaw); base = 4x4 applied first.  mahal = n_src x 9, indexed by
+ * source index like PCL's mahalanobis_ vector */
 double wmo_gicp_fdf(const float *src, const float *tgt, const int *src_idx,
                     const int *tgt_idx, const double *mahal, int n_pairs,
                     const double base[16], const double x[6], double g[6]);

@@ -1,0 +1,107 @@
+"""GPU parity of the GICP path (k-NN covariances, Mahalanobis matrices, objective /
+gradient reduction, BFGS driver) vs the oracle, on the reference's own test cases
+(wave_matching/tests/gicp_tests.cpp:43-100)."""
+import numpy as np
+import pytest
+
+from helpers import TOL_R, TOL_T, pose_error
+from libwave_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k", [10, 20])
+def test_gicp_covariances_match_oracle(wm, ctx, oracle, k):
+    ref, tgt, _ = synth.pair(20000, seed=4)
+    ctx.set_source(ref)
+    ctx.set_target(tgt)
+    cs, ct = ctx.gicp_covariances(k=k, eps=1e-3)
+    ocs = oracle.gicp_covariances(ref, k=k, eps=1e-3)
+    oct_ = oracle.gicp_covariances(tgt, k=k, eps=1e-3)
+    # same neighbours (exact k-NN, (d2, index) order) and same SVD => same matrices;
+    # degenerate neighbourhoods (repeated singular values) have a non-unique basis
+    for got, want in ((cs, ocs), (ct, oct_)):
+        err = np.abs(got - want).reshape(len(got), -1).max(1)
+        assert (err > 1e-9).mean() < 2e-3, (err > 1e-9).mean()
+        ev = np.linalg.eigvalsh(got[:200])
+        np.testing.assert_allclose(ev, np.tile([1e-3, 1, 1], (200, 1)), atol=1e-9)
+
+
+CASES = [("fullResNullMatch", -1.0, 0.0), ("nullDisplacement", 0.05, 0.0),
+         ("smallDisplacement", 0.05, 0.2)]
+
+
+@pytest.mark.parametrize("name,res,tx", CASES)
+def test_reference_gicp_cases(wm, ctx, oracle, testscan, name, res, tx):
+    P = np.eye(4)
+    P[0, 3] = tx
+    target = oracle.transform_cloud_d(testscan, P)
+    got = ctx.gicp_match(testscan, target, res=res)     # GICPMatcherParams defaults
+    a = testscan if res < 0 else oracle.voxel_grid(testscan, res)
+    b = target if res < 0 else oracle.voxel_grid(target, res)
+    want = oracle.gicp_align(a, b)
+    assert got["rc"] == 0 and got["converged"] and want["converged"]
+    assert np.linalg.norm(got["T"] - P) < 0.1            # gicp_tests.cpp:36 threshold
+    assert got["n_corr"] == want["n_corr"]
+    # PCL's outer stop test (r_eps = 1e-8 on the float-stored rotation) fires only when the
+    # rotation block is bit-stable, so a last-bit difference in the reduction order can move
+    # the stopping iteration by one; the transform itself is what parity is judged on
+    assert abs(got["iterations"] - want["iterations"]) <= 1
+    dt, ang = pose_error(got["T"], want["T"])
+    assert dt <= TOL_T and ang <= TOL_R, (dt, ang)
+
+
+def test_gicp_objective_and_gradient_match_oracle(wm, ctx, oracle):
+    """One fdf evaluation: same pairs, same Mahalanobis matrices, f and gradient to 1e-9."""
+    ref, tgt, _ = synth.pair(30000, seed=21)
+    ctx.set_source(ref)
+    ctx.set_target(tgt)
+    T_pair = synth.make_T((0.1, -0.05, 0.02), (0.004, -0.01, 0.015)).astype(np.float32).astype(np.float64)
+    x = np.array([0.12, -0.06, 0.03, 0.005, -0.012, 0.017])
+    f, g, m = ctx.gicp_eval(T_pair, x)
+    gi, gd = ctx.correspondences()
+    moved = oracle.transform_cloud_f(ref, T_pair.astype(np.float32))
+    oi, od = oracle.KdTree(tgt).nn(moved)
+    keep = od.astype(np.float64) < 25.0
+    assert m == keep.sum() and np.array_equal(gi, np.where(keep, oi, -1))
+    C1 = oracle.gicp_covariances(ref)
+    C2 = oracle.gicp_covariances(tgt)
+    R = T_pair[:3, :3]
+    M = np.zeros((len(ref), 3, 3))
+    si = np.nonzero(keep)[0].astype(np.int32)
+    M[si] = np.linalg.inv(C2[oi[si]] + R @ C1[si] @ R.T)
+    of, og = oracle.gicp_fdf(ref, tgt, si, oi[si], M, np.eye(4), x)
+    assert abs(f - of) <= 1e-9 * abs(of)
+    np.testing.assert_allclose(g, og, rtol=1e-8, atol=1e-8 * np.abs(og).max())
+
+
+def test_gicp_on_noisy_synthetic_pair(wm, ctx, oracle):
+    """BASELINE config 3 shape (resample pair with noise), small enough for the oracle.
+    On noisy data PCL's inner optimiser (BFGS, gradient tolerance 1e-2, objective evaluated
+    through a float-quantised transform) stops wherever its line search lands: last-bit
+    differences in the reduction order change the path, so two faithful implementations
+    agree only to ~1e-3 m in the weakly constrained (sliding) directions.  Bit-level parity
+    is asserted on the pieces (covariances, pairs, f, gradient: tests above); here the
+    outcome is checked against the oracle at that sensitivity and against ground truth."""
+    ref, tgt, T_gt = synth.pair(30000, seed=21)
+    ctx.set_source(ref)
+    ctx.set_target(tgt)
+    one = ctx.gicp_align(force_iterations=1)
+    one_o = oracle.gicp_align(ref, tgt, force_iterations=1)
+    dt, ang = pose_error(one["T"], one_o["T"])   # first outer iteration: identical path
+    assert one["n_corr"] == one_o["n_corr"] and dt <= 1e-6 and ang <= 1e-6, (dt, ang)
+    got = ctx.gicp_align()
+    want = oracle.gicp_align(ref, tgt)
+    assert got["rc"] == 0 and got["converged"]
+    dt, ang = pose_error(got["T"], want["T"])
+    assert dt <= 3e-3 and ang <= 3e-4, (dt, ang)
+    dt, ang = pose_error(got["T"], T_gt)
+    assert dt < 5e-3 and ang < 1e-3
+
+
+def test_gicp_too_few_points(wm, ctx):
+    pts = synth.scene(1000, seed=1)
+    ctx.set_source(pts[:5])           # fewer points than corr_rand = 10
+    ctx.set_target(pts)
+    r = ctx.gicp_align()
+    assert r["rc"] == wm.WM_NOT_CONVERGED and r["T"] is None
