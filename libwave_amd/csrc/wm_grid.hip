@@ -427,6 +427,97 @@ int morton_sort(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, float4
     return WM_OK;
 }
 
+// ---- coarser levels derived from the next finer one (cell size exactly x2, same origin):
+// a coarse cell is the union of 2x2x2 fine cells, i.e. of 4 contiguous runs of the fine
+// cell-sorted array (the two x-children of a row are adjacent).  Counting is a handful of
+// cell_start reads per coarse cell and the copy moves whole runs: no atomics, no keys.
+__device__ __forceinline__ void child_run(const unsigned *fs, int fnx, int fny, int fnz, int X,
+                                          int Y, int Z, int r, unsigned *s, unsigned *e) {
+    const int y = 2 * Y + (r & 1), z = 2 * Z + (r >> 1);
+    *s = *e = 0;
+    if (y >= fny || z >= fnz) return;
+    const size_t base = ((size_t) z * fny + y) * fnx;
+    const int xa = 2 * X, xb = min(2 * X + 2, fnx);
+    *s = fs[base + xa];
+    *e = fs[base + xb];
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_coarse_count(const unsigned *__restrict__ fs, int fnx, int fny, int fnz, int cnx, int cny,
+                   size_t ncells, unsigned *__restrict__ counts) {
+    const size_t c = (size_t) blockIdx.x * kBlock + threadIdx.x;
+    if (c >= ncells) return;
+    const int X = (int) (c % cnx), Y = (int) ((c / cnx) % cny), Z = (int) (c / ((size_t) cnx * cny));
+    unsigned total = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        unsigned s, e;
+        child_run(fs, fnx, fny, fnz, X, Y, Z, r, &s, &e);
+        total += e - s;
+    }
+    counts[c] = total;
+}
+
+// LANES = 1: one lane per coarse cell (many small cells); LANES = 64: one wave per cell
+template <int LANES>
+__global__ void __launch_bounds__(kBlock)
+    k_coarse_copy(const unsigned *__restrict__ fs, const float4 *__restrict__ fpts, int fnx, int fny,
+                  int fnz, int cnx, int cny, size_t ncells, const unsigned *__restrict__ cs,
+                  float4 *__restrict__ out) {
+    const size_t t = (size_t) blockIdx.x * kBlock + threadIdx.x;
+    const size_t c = t / LANES;
+    const unsigned lane = (unsigned) (t % LANES);
+    if (c >= ncells) return;
+    unsigned dst = cs[c];
+    if (cs[c + 1] == dst) return;
+    const int X = (int) (c % cnx), Y = (int) ((c / cnx) % cny), Z = (int) (c / ((size_t) cnx * cny));
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+        unsigned s, e;
+        child_run(fs, fnx, fny, fnz, X, Y, Z, r, &s, &e);
+        for (unsigned j = s + lane; j < e; j += LANES) out[dst + (j - s)] = fpts[j];
+        dst += e - s;
+    }
+}
+
+static int derive_grid_level(wm_ctx *ctx, const GridLevel &fine, GridLevel *lvl, size_t n) {
+    const GridDev &f = fine.d;
+    const int nx = (f.nx + 1) / 2, ny = (f.ny + 1) / 2, nz = (f.nz + 1) / 2;
+    const uint64_t ncells = (uint64_t) nx * ny * nz;
+    lvl->ncells = ncells;
+    WM_HIP(ctx, lvl->pts.reserve((n > 0 ? n : 1) * sizeof(float4)));
+    WM_HIP(ctx, lvl->cell_start.reserve((ncells + 1) * sizeof(unsigned)));
+    WM_HIP(ctx, ctx->counts.reserve(ncells * sizeof(unsigned)));
+    unsigned *counts = ctx->counts.as<unsigned>();
+    const unsigned blocks = (unsigned) ((ncells + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_coarse_count, dim3(blocks), dim3(kBlock), 0, ctx->stream, f.cell_start, f.nx,
+                       f.ny, f.nz, nx, ny, (size_t) ncells, counts);
+    WM_TRY(exclusive_scan(ctx, counts, ncells, lvl->cell_start.as<unsigned>()));
+    if ((double) n / (double) ncells < 8.0) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coarse_copy<1>), dim3(blocks), dim3(kBlock), 0, ctx->stream,
+                           f.cell_start, f.pts, f.nx, f.ny, f.nz, nx, ny, (size_t) ncells,
+                           lvl->cell_start.as<unsigned>(), lvl->pts.as<float4>());
+    } else {
+        const unsigned wblocks = (unsigned) ((ncells * 64 + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coarse_copy<64>), dim3(wblocks), dim3(kBlock), 0,
+                           ctx->stream, f.cell_start, f.pts, f.nx, f.ny, f.nz, nx, ny, (size_t) ncells,
+                           lvl->cell_start.as<unsigned>(), lvl->pts.as<float4>());
+    }
+    WM_HIP(ctx, hipGetLastError());
+    lvl->d = f;
+    lvl->d.h = 2.0f * f.h;  // exact in float
+    lvl->d.inv_h = 1.0f / lvl->d.h;
+    lvl->d.nx = nx;
+    lvl->d.ny = ny;
+    lvl->d.nz = nz;
+    lvl->d.pts = lvl->pts.as<float4>();
+    lvl->d.cell_start = lvl->cell_start.as<unsigned>();
+    // a point sits in coarse cell (fine cell >> 1): the fine level's geometric margin
+    // (slack_f * h_f) is slack_f / 2 coarse cells; keep the fine value (conservative)
+    lvl->built = true;
+    return WM_OK;
+}
+
 // Level 0: cell size from the measured density (a few points per occupied cell).
 // Levels >= 1: cell size x4 per level until one ring of cells covers max_corr.
 static int build_level0(wm_ctx *ctx) {
@@ -453,8 +544,15 @@ static int build_level0(wm_ctx *ctx) {
         return build_grid_level(ctx, pts, n, bb, (float) h, &ctx->levels[0], nullptr);
     }
     const double target_occ = 3.0;
-    // first guess assumes points spread over surfaces: occupancy ~ h^2
+    // first guess assumes points spread over surfaces: occupancy ~ h^2 ...
     h = clamp_h(fmax(cbrt(vol / fmax((double) ctx->n_tgt, 1.0)) * 1.5, 1e-4));
+    // ... unless the previous target looked alike (consecutive scans of one sensor do):
+    // then its tuned cell size is the first guess and usually passes the check at once
+    if (ctx->tuned_h > 0 && ctx->tuned_n > 0) {
+        const double rn = (double) ctx->n_tgt / (double) ctx->tuned_n;
+        const double rv = vol / ctx->tuned_vol;
+        if (rn > 0.8 && rn < 1.25 && rv > 0.6 && rv < 1.6) h = clamp_h(ctx->tuned_h);
+    }
     double occ = 0;
     for (int it = 0; it < 3; ++it) {
         WM_TRY(build_grid_level(ctx, pts, n, bb, (float) h, &ctx->levels[0], &occ));
@@ -469,6 +567,9 @@ static int build_level0(wm_ctx *ctx) {
     }
     if (!ctx->levels[0].built || ctx->levels[0].d.h != (float) h)
         WM_TRY(build_grid_level(ctx, pts, n, bb, (float) h, &ctx->levels[0], nullptr));
+    ctx->tuned_h = h;
+    ctx->tuned_n = ctx->n_tgt;
+    ctx->tuned_vol = vol;
     return WM_OK;
 }
 
@@ -486,10 +587,10 @@ int ensure_levels(wm_ctx *ctx, double max_corr) {
     // boxes of cells, so the last level need not cover max_corr in one ring
     while (2.0 * h < max_corr && L < kMaxLevels) {
         h *= 2.0;
-        WM_TRY(build_grid_level(ctx, pts, ctx->n_tgt_input, ctx->tgt_bbox, (float) h,
-                                &ctx->levels[L], nullptr));
+        WM_TRY(derive_grid_level(ctx, ctx->levels[L - 1], &ctx->levels[L], ctx->n_tgt_input));
         ++L;
     }
+    (void) pts;
     ctx->n_levels = L;
     ctx->levels_max_corr = max_corr;
     // publish the ladder for the search kernel

@@ -23,7 +23,7 @@
 namespace wm {
 
 constexpr int kAcc = 17;
-constexpr int kMaxStatBlocks = 1024;
+constexpr int kMaxStatBlocks = 256;
 
 __device__ __forceinline__ void xform_pt(const float *T, const float4 &p, float &x, float &y,
                                          float &z) {

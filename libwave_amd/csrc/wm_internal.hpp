@@ -128,6 +128,8 @@ struct wm_ctx {
     int n_levels = 0;
     double levels_max_corr = -1;
     float grid_cell_override = 0;
+    double tuned_h = 0, tuned_vol = 0;  // last auto-tuned level-0 cell size and its cloud
+    size_t tuned_n = 0;
 
     // scratch
     wm::DevBuf staging, cell_of, counts, block_sums, bbox_buf;
