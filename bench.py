@@ -66,6 +66,21 @@ def cpu_baseline(ref, tgt, iters_full, max_corr, cpu_iters):
     }
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the correspondence kernel from the committed PMC summary
+    (profiles/pmc_latest.json, written by scripts/gpu_pmc.sh + scripts/pmc_to_json.py from
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same bench command).
+    FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B for wide
+    coalesced 16-B/lane reads); WRITE_SIZE is taken as reported.  None if not available."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)["k_nn_grid"]
+        return (2.0 * d["FETCH_SIZE_kb_per_dispatch"] + d["WRITE_SIZE_kb_per_dispatch"]) * 1024.0
+    except Exception:
+        return None
+
+
 def main():
     a = parse()
     import torch
@@ -155,13 +170,14 @@ def main():
             "value": value, "unit": "registrations/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 points / f64 reductions", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": "ICPMatcher %d<->%d synthetic XYZ clouds (BASELINE configs[%d]), "
                             "%d forced iterations, max_corr=%g, res=-1; step = set_source + "
                             "set_target (index build) + align" % (n_total, n_total,
                                                                  1 if world == 1 else 4,
                                                                  a.iters, a.max_corr),
+                "arithmetic": "f32 points and distances, f64 reductions and solve",
                 "points_per_cloud_total": n_total, "points_per_gpu": a.points,
                 "iterations": a.iters, "parallelism": parallelism,
                 "registrations_per_s_raw": regs_per_s_raw,
@@ -170,11 +186,15 @@ def main():
                 "deferred_queries_per_registration": r.get("deferred"),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "wm::k_nn_grid_thread (level-0 correspondence search)",
+                "bound": "hbm", "kernel": "wm::k_nn_grid (correspondence search)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": pmc_traffic_bytes() if world == 1 else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_us": nn_us, "launches_timed": nn_launches,
+                "note": "both clouds (32 MB) stay resident in L2 / Infinity Cache across the 50 "
+                        "iterations; the kernel is a latency-bound gather (PMC: SQ_WAIT_ANY ~50-68 % "
+                        "of wave cycles), not an HBM stream",
             },
         }
         if world == 1 and not a.no_cpu_baseline:

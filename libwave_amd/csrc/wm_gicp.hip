@@ -54,7 +54,7 @@ __device__ void knn_search(const GridDev &g, float qx, float qy, float qz, int k
     const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
     float r = 1.5f * g.h;
     const float rmax = (float) (g.nx + g.ny + g.nz + 3) * g.h;  // covers the whole grid
-    for (;;) {
+    for (int pass = 0; pass < 64; ++pass) {  // r at least x1.5 per pass: rmax is reached long before
 #pragma unroll
         for (int j = 0; j < K; ++j) best[j] = ~0ull;
         const float rc = r * g.inv_h + g.slack;
@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(kBlock)
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const unsigned j = (unsigned) keys[i];
         if (j == kNoIdx) continue;
-        const float4 p = src[i], q = tgt[j];
+        const float4 p = src[i], q = tgt[i];  // tgt = match coordinates per source point
         const float ppx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.T[0], p.x), __fmul_rn(A.T[1], p.y)), __fmul_rn(A.T[2], p.z)), A.T[3]);
         const float ppy = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.T[4], p.x), __fmul_rn(A.T[5], p.y)), __fmul_rn(A.T[6], p.z)), A.T[7]);
         const float ppz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.T[8], p.x), __fmul_rn(A.T[9], p.y)), __fmul_rn(A.T[10], p.z)), A.T[11]);
@@ -349,7 +349,7 @@ static double gicp_fdf(GicpFn &F, const double x[6], double g[6]) {
     if (nb < 1) nb = 1;
     (void) hipEventRecord(ctx->ev_a, ctx->stream);
     hipLaunchKernelGGL(k_gicp_fdf, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->src_sorted.as<float4>(),
-                       n, ctx->keys.as<unsigned long long>(), ctx->tgt_orig.as<float4>(),
+                       n, ctx->keys.as<unsigned long long>(), ctx->match_pt.as<float4>(),
                        ctx->gicp_mahal.as<double>(), A, ctx->partials.as<double>());
     (void) hipEventRecord(ctx->ev_b, ctx->stream);
     std::vector<double> h((size_t) nb * kGicpAcc);

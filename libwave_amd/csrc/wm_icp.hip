@@ -18,6 +18,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include <new>
 
 namespace wm {
@@ -52,7 +54,7 @@ __global__ void __launch_bounds__(kBlock)
         const float4 p4 = src[i];
         float fx, fy, fz;
         xform_pt(st->Tf, p4, fx, fy, fz);
-        const float4 q4 = tgt[idx];
+        const float4 q4 = tgt[i];  // match coordinates, written by the search (coalesced)
         const double px = fx, py = fy, pz = fz, qx = q4.x, qy = q4.y, qz = q4.z;
         const double d2 = (double) __uint_as_float((unsigned) (key >> 32));
         a[0] += 1.0;
@@ -307,12 +309,12 @@ static int launch_stats(wm_ctx *ctx, int mode) {
     if (mode == WM_ICP_SVD)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_stats<WM_ICP_SVD>), dim3(nb), dim3(kBlock), 0,
                            ctx->stream, ctx->src_sorted.as<float4>(), n,
-                           ctx->keys.as<unsigned long long>(), ctx->tgt_orig.as<float4>(), st,
+                           ctx->keys.as<unsigned long long>(), ctx->match_pt.as<float4>(), st,
                            ctx->partials.as<double>());
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_stats<WM_ICP_GN6>), dim3(nb), dim3(kBlock), 0,
                            ctx->stream, ctx->src_sorted.as<float4>(), n,
-                           ctx->keys.as<unsigned long long>(), ctx->tgt_orig.as<float4>(), st,
+                           ctx->keys.as<unsigned long long>(), ctx->match_pt.as<float4>(), st,
                            ctx->partials.as<double>());
     WM_HIP(ctx, hipGetLastError());
     return WM_OK;
@@ -321,6 +323,7 @@ static int launch_stats(wm_ctx *ctx, int mode) {
 static int prepare_work(wm_ctx *ctx) {
     const size_t n = ctx->n_src > 0 ? ctx->n_src : 1;
     WM_HIP(ctx, ctx->keys.reserve(n * sizeof(unsigned long long)));
+    WM_HIP(ctx, ctx->match_pt.reserve(n * sizeof(float4)));
     WM_HIP(ctx, ctx->partials.reserve((size_t) kMaxStatBlocks * kAcc * sizeof(double)));
     WM_HIP(ctx, ctx->d_state.reserve(sizeof(IcpDevState)));
     if (!ctx->h_state)
@@ -428,6 +431,10 @@ int wm_ctx_create(wm_ctx **out, int device) {
         return WM_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    if (const char *e = getenv("WM_TUNE_R_LIGHT")) {  // developer tuning knob
+        const float v = (float) atof(e);
+        if (v > 0) ctx->tune_r_light = v;
+    }
     *out = ctx;
     return WM_OK;
 }
@@ -447,7 +454,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
     (void) hipSetDevice(ctx->device);
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->src_sorted, &ctx->tgt_orig, &ctx->staging, &ctx->cell_of, &ctx->counts,
-                      &ctx->block_sums, &ctx->bbox_buf, &ctx->keys, &ctx->keys_bak, &ctx->d_levels, &ctx->ndt_keys, &ctx->ndt_keys2,
+                      &ctx->block_sums, &ctx->bbox_buf, &ctx->keys, &ctx->keys_bak, &ctx->match_pt, &ctx->match_pt_bak, &ctx->d_levels, &ctx->ndt_keys, &ctx->ndt_keys2,
                       &ctx->ndt_vox, &ctx->ndt_vkey, &ctx->ndt_hkeys, &ctx->ndt_hvals, &ctx->src_orig,
                       &ctx->gicp_c1, &ctx->gicp_c2, &ctx->gicp_mahal, &ctx->src_grid.pts,
                       &ctx->src_grid.cell_start, &ctx->vg_idx, &ctx->vg_idx2, &ctx->vg_perm,

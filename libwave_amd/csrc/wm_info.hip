@@ -440,9 +440,15 @@ int wm_icp_info(wm_ctx *ctx, int method, const double T_result[16], double lin_c
         WM_HIP(ctx, ctx->keys_bak.reserve(kb > 0 ? kb : 8));
         WM_HIP(ctx, hipMemcpyAsync(ctx->keys_bak.p, ctx->keys.p, kb, hipMemcpyDeviceToDevice,
                                    ctx->stream));
+        const size_t mb = ctx->n_src * sizeof(float4);
+        WM_HIP(ctx, ctx->match_pt_bak.reserve(mb > 0 ? mb : 16));
+        WM_HIP(ctx, hipMemcpyAsync(ctx->match_pt_bak.p, ctx->match_pt.p, mb, hipMemcpyDeviceToDevice,
+                                   ctx->stream));
         int rc = nn_pass(ctx, ctx->corr_T, threshold_d2_strict(max_corr), max_corr, true);
         if (rc == WM_OK) rc = lum_from_current_keys(ctx, args, info, true);
         WM_HIP(ctx, hipMemcpyAsync(ctx->keys.p, ctx->keys_bak.p, kb, hipMemcpyDeviceToDevice,
+                                   ctx->stream));
+        WM_HIP(ctx, hipMemcpyAsync(ctx->match_pt.p, ctx->match_pt_bak.p, mb, hipMemcpyDeviceToDevice,
                                    ctx->stream));
         WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (rc < 0) return rc;

@@ -128,11 +128,13 @@ struct wm_ctx {
     int n_levels = 0;
     double levels_max_corr = -1;
     float grid_cell_override = 0;
+    float tune_r_light = 3.0f;   // lane-serial vs cooperative scan threshold, in level-0 cells
     double tuned_h = 0, tuned_vol = 0;  // last auto-tuned level-0 cell size and its cloud
     size_t tuned_n = 0;
 
     // scratch
     wm::DevBuf staging, cell_of, counts, block_sums, bbox_buf;
+    wm::DevBuf match_pt, match_pt_bak;  // float4 per (sorted) source point: its match's xyz
     wm::DevBuf keys, partials, corr_tmp_idx, corr_tmp_d2, d_levels;
     wm::DevBuf vg_idx, vg_idx2, vg_perm, vg_perm2, vg_tmp, vg_seg, io_a, io_b, ds_ref, ds_tgt, match_ref, match_tgt;
     wm::DevBuf d_state;

@@ -102,23 +102,29 @@ __device__ __forceinline__ bool certified(const GridDev &g, const Cell &c, float
 
 // ------------------------------------------------------------- grid search
 // scan the contiguous run [s, e) of cell-sorted target points, four loads in flight
+// (bpos follows the winner: its position in `pts`, so the caller can fetch its coordinates)
 __device__ __forceinline__ unsigned long long scan_run(const float4 *__restrict__ pts, unsigned s,
                                                        unsigned e, float qx, float qy, float qz,
-                                                       unsigned long long best) {
+                                                       unsigned long long best, unsigned &bpos) {
     for (unsigned j = s; j < e; j += 4) {
         // clamped re-reads of the last point are harmless: min() is idempotent
         const unsigned last = e - 1;
+        const unsigned j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
         const float4 t0 = pts[j];
-        const float4 t1 = pts[min(j + 1, last)];
-        const float4 t2 = pts[min(j + 2, last)];
-        const float4 t3 = pts[min(j + 3, last)];
+        const float4 t1 = pts[j1];
+        const float4 t2 = pts[j2];
+        const float4 t3 = pts[j3];
         const unsigned long long k0 = make_key(canon_d2(qx, qy, qz, t0), __float_as_uint(t0.w));
         const unsigned long long k1 = make_key(canon_d2(qx, qy, qz, t1), __float_as_uint(t1.w));
         const unsigned long long k2 = make_key(canon_d2(qx, qy, qz, t2), __float_as_uint(t2.w));
         const unsigned long long k3 = make_key(canon_d2(qx, qy, qz, t3), __float_as_uint(t3.w));
         const unsigned long long a = k0 < k1 ? k0 : k1, b = k2 < k3 ? k2 : k3;
+        const unsigned pa = k0 < k1 ? j : j1, pb = k2 < k3 ? j2 : j3;
         const unsigned long long m = a < b ? a : b;
-        best = m < best ? m : best;
+        const unsigned pm = a < b ? pa : pb;
+        const bool up = m < best;
+        best = up ? m : best;
+        bpos = up ? pm : bpos;
     }
     return best;
 }
@@ -129,7 +135,7 @@ __device__ __forceinline__ unsigned long long scan_run(const float4 *__restrict_
 // to the faces of that box: every point NOT scanned is farther than `margin`.
 __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float qx, float qy,
                                                        float qz, float r, unsigned long long best,
-                                                       float *margin) {
+                                                       unsigned &bpos, float *margin) {
     const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
     const float rc = r * g.inv_h + g.slack;
     // clamp in float first so far-away queries cannot overflow the int conversion
@@ -154,7 +160,7 @@ __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float q
     if (cy >= ya && cy <= yb && cz >= za && cz <= zb) {
         const size_t base = ((size_t) cz * g.ny + cy) * g.nx;
         best = scan_run(g.pts, g.cell_start[base + xa], g.cell_start[base + xb + 1], qx, qy, qz,
-                        best);
+                        best, bpos);
     }
 #pragma unroll 1
     for (int zz = za; zz <= zb; ++zz) {
@@ -167,7 +173,7 @@ __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float q
             if (lb > 0.f && lb * lb > __uint_as_float((unsigned) (best >> 32))) continue;
             const size_t base = ((size_t) zz * g.ny + yy) * g.nx;
             best = scan_run(g.pts, g.cell_start[base + xa], g.cell_start[base + xb + 1], qx, qy,
-                            qz, best);
+                            qz, best, bpos);
         }
     }
     return best;
@@ -197,7 +203,7 @@ __device__ __forceinline__ unsigned rl_u(unsigned v, int lane) {
 __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, float qx, float qy,
                                                             float qz, float r,
                                                             unsigned long long best, unsigned lane,
-                                                            float *margin) {
+                                                            float *margin, float4 *win) {
     const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
     const float rc = r * g.inv_h + g.slack;
     const float big = 4.0e6f;
@@ -221,6 +227,7 @@ __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, fl
     const int nrows = wy * (zb - za + 1);
     const float bd2 = __uint_as_float((unsigned) (best >> 32));
     unsigned long long mine = best;
+    unsigned mpos = 0;
     for (int k0 = 0; k0 < nrows; k0 += 64) {
         // lanes resolve up to 64 rows at once
         const int k = k0 + (int) lane;
@@ -248,11 +255,24 @@ __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, fl
                 const unsigned long long a = make_key(canon_d2(qx, qy, qz, t0), __float_as_uint(t0.w));
                 const unsigned long long b = make_key(canon_d2(qx, qy, qz, t1), __float_as_uint(t1.w));
                 const unsigned long long m = a < b ? a : b;
-                mine = m < mine ? m : mine;
+                const unsigned pm = a < b ? j : j1;
+                const bool up = m < mine;
+                mine = up ? m : mine;
+                mpos = up ? pm : mpos;
             }
         }
     }
-    return wave_min_u64(mine);
+    const unsigned long long res = wave_min_u64(mine);
+    if (res < best) {  // improved: fetch the winner's coordinates on its lane, broadcast them
+        const unsigned long long who = __ballot(mine == res);
+        const int wl = __ffsll((long long) who) - 1;
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((int) lane == wl) c = g.pts[mpos];
+        win->x = rl_f(c.x, wl);
+        win->y = rl_f(c.y, wl);
+        win->z = rl_f(c.z, wl);
+    }
+    return res;
 }
 
 // One lane per query: a certified radius search over a ladder of uniform grids
@@ -269,7 +289,8 @@ __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, fl
 // The radius and level choices change the work, never the result.
 __global__ void __launch_bounds__(kBlock)
     k_nn_grid(const LevelsDev *__restrict__ lv, const float4 *__restrict__ src, unsigned n,
-              IcpDevState *__restrict__ st, float thr_d2, unsigned long long *__restrict__ keys) {
+              IcpDevState *__restrict__ st, float thr_d2, unsigned long long *__restrict__ keys,
+              float4 *__restrict__ match_pt, float r_light_cells) {
     if (st->done) return;
     const unsigned i = xcd_remap(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
@@ -277,8 +298,9 @@ __global__ void __launch_bounds__(kBlock)
     const int L = lv->n;
     const float h0 = lv->g[0].h;
     const float rmax = sqrtf(thr_d2) * 1.0001f + 1e-6f;
-    const float r_light = 1.25f * h0;  // lane-serial scans stay within ~3^3 fine cells
+    const float r_light = r_light_cells * h0;  // larger radii go to the cooperative path
     float qx = 0.f, qy = 0.f, qz = 0.f, r = 0.f;
+    float bqx = 0.f, bqy = 0.f, bqz = 0.f;  // coordinates of the current best match
     unsigned long long best = make_key(thr_d2, kNoIdx);
     bool heavy = false;
     bool mine = active;
@@ -294,20 +316,49 @@ __global__ void __launch_bounds__(kBlock)
         if (st->have_prev) {
             const unsigned long long prev = keys[i];
             if (prev != ~0ull) {
-                const float d2p = __uint_as_float((unsigned) (prev >> 32));  // thr if unmatched
-                r = fmaxf(1.25f * sqrtf(d2p), 0.1f * h0);
+                const unsigned pidx = (unsigned) prev;
+                if (pidx != kNoIdx) {
+                    // the point matched in the previous iteration is a real candidate: its
+                    // distance under the NEW pose is an upper bound of the new NN distance,
+                    // so one scan of ball(q, that distance) is certain to certify
+                    const float4 tp = match_pt[i];  // its coordinates, stored last iteration
+                    const float d2b = canon_d2(qx, qy, qz, tp);
+                    if (d2b <= thr_d2) {
+                        best = make_key(d2b, pidx);
+                        bqx = tp.x;
+                        bqy = tp.y;
+                        bqz = tp.z;
+                        r = fmaxf(sqrtf(d2b) * 1.0001f + 1e-6f, 0.05f * h0);
+                    } else {
+                        r = rmax;
+                    }
+                } else {
+                    r = rmax;  // nothing within max_corr last time
+                }
             }
         }
         r = fminf(r, rmax);
         heavy = r > r_light;
-        while (!heavy) {
-            const GridDev g = lv->g[0];
+        for (int pass = 0; !heavy && pass < 32; ++pass) {
+            int l = 0;
+            while (l < L - 1 && lv->g[l].h < r) ++l;  // finest level whose cells cover r
+            const GridDev g = lv->g[l];
             float margin;
-            best = scan_box(g, qx, qy, qz, r, best, &margin);
+            unsigned bpos = 0;
+            const unsigned long long before = best;
+            best = scan_box(g, qx, qy, qz, r, best, bpos, &margin);
+            if (best != before) {
+                const float4 c = g.pts[bpos];
+                bqx = c.x;
+                bqy = c.y;
+                bqz = c.z;
+            }
             const float bd2 = __uint_as_float((unsigned) (best >> 32));
             if (margin > 0.f && (bd2 <= margin * margin || thr_d2 <= margin * margin)) break;
-            r = ((unsigned) best != kNoIdx) ? sqrtf(bd2) * 1.0001f + 1e-6f : 2.0f * r;
-            r = fminf(r, rmax);
+            // not certified: the radius must GROW (a query sitting on a cell face can have a
+            // non-positive margin however small its neighbour distance is)
+            const float rn = ((unsigned) best != kNoIdx) ? sqrtf(bd2) * 1.0001f + 1e-6f : 2.0f * r;
+            r = fminf(fmaxf(rn, 1.25f * r), rmax);
             heavy = r > r_light;
         }
     }
@@ -322,23 +373,32 @@ __global__ void __launch_bounds__(kBlock)
         float ur = rl_f(r, sl);
         unsigned long long ub = ((unsigned long long) rl_u((unsigned) (best >> 32), sl) << 32) |
                                 rl_u((unsigned) best, sl);
+        float4 uwin = make_float4(rl_f(bqx, sl), rl_f(bqy, sl), rl_f(bqz, sl), 0.f);
         if ((unsigned) ub == kNoIdx && seed > ur) ur = fminf(seed, rmax);  // neighbour's radius
-        for (;;) {
+        for (int pass = 0; pass < 64; ++pass) {
             int l = 0;
             while (l < L - 1 && lv->g[l].h < ur) ++l;
             const GridDev g = lv->g[l];
             float margin;
-            ub = coop_scan_box(g, ux, uy, uz, ur, ub, lane, &margin);
+            ub = coop_scan_box(g, ux, uy, uz, ur, ub, lane, &margin, &uwin);
             const float bd2 = __uint_as_float((unsigned) (ub >> 32));
             if (margin > 0.f && (bd2 <= margin * margin || thr_d2 <= margin * margin)) break;
             if (ur >= rmax) break;
-            ur = ((unsigned) ub != kNoIdx) ? sqrtf(bd2) * 1.0001f + 1e-6f : 2.0f * ur;
-            ur = fminf(ur, rmax);
+            const float rn = ((unsigned) ub != kNoIdx) ? sqrtf(bd2) * 1.0001f + 1e-6f : 2.0f * ur;
+            ur = fminf(fmaxf(rn, 1.25f * ur), rmax);
         }
         seed = ((unsigned) ub != kNoIdx) ? 1.25f * sqrtf(__uint_as_float((unsigned) (ub >> 32))) : ur;
-        if ((int) lane == sl) best = ub;
+        if ((int) lane == sl) {
+            best = ub;
+            bqx = uwin.x;
+            bqy = uwin.y;
+            bqz = uwin.z;
+        }
     }
-    if (active) keys[i] = best;
+    if (active) {
+        keys[i] = best;
+        match_pt[i] = make_float4(bqx, bqy, bqz, 0.f);
+    }
     if (lane == 0 && n_heavy) atomicAdd(&st->queue_count[1], n_heavy);  // stats only
 }
 
@@ -384,6 +444,18 @@ __global__ void __launch_bounds__(kBlock)
     if (i < n && mine && best < make_key(thr_d2, kNoIdx)) atomicMin(&keys[i], best);
 }
 
+// after the all-pairs search: coordinates of every match (the grid search tracks them itself)
+__global__ void __launch_bounds__(kBlock)
+    k_fill_match(const unsigned long long *__restrict__ keys, unsigned n,
+                 const float4 *__restrict__ tgt, const IcpDevState *__restrict__ st,
+                 float4 *__restrict__ match_pt) {
+    if (st->done) return;
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const unsigned idx = (unsigned) keys[i];
+    match_pt[i] = idx == kNoIdx ? make_float4(0.f, 0.f, 0.f, 0.f) : tgt[idx];
+}
+
 // largest float whose value, compared as PCL does ((double) d2 > max_corr^2 ->
 // reject), is still accepted
 float threshold_d2(double max_corr) {
@@ -413,7 +485,7 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
     if (ev0) WM_HIP(ctx, hipEventRecord(ev0, ctx->stream));
     hipLaunchKernelGGL(k_nn_grid, dim3(blocks), dim3(kBlock), 0, ctx->stream,
                        ctx->d_levels.as<LevelsDev>(), ctx->src_sorted.as<float4>(), n, st, thr_d2,
-                       keys);
+                       keys, ctx->match_pt.as<float4>(), ctx->tune_r_light);
     if (ev1) WM_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     if (ev2) WM_HIP(ctx, hipEventRecord(ev2, ctx->stream));
     WM_HIP(ctx, hipGetLastError());
@@ -440,6 +512,8 @@ int launch_nn_brute(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1) {
         hipLaunchKernelGGL(k_nn_brute, dim3(bx, splits), dim3(kBlock), 0, ctx->stream,
                            ctx->tgt_orig.as<float4>(), m, ctx->src_sorted.as<float4>(), n, st,
                            thr_d2, keys);
+    hipLaunchKernelGGL(k_fill_match, dim3(bx), dim3(kBlock), 0, ctx->stream, keys, n,
+                       ctx->tgt_orig.as<float4>(), st, ctx->match_pt.as<float4>());
     if (ev1) WM_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     WM_HIP(ctx, hipGetLastError());
     return WM_OK;
