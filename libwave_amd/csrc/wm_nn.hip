@@ -14,12 +14,9 @@
 // the tie rule built in, and "no match" is the initial key (threshold, ~0).
 //
 // Two kernels:
-//   k_nn_grid   one lane per query over a ladder of uniform grids (cell size x4 per
-//               level).  Lane phase: the 3x3x3 (then 5x5x5) cell block of the fine level
-//               as contiguous x-rows of the cell-sorted target, nearest rows first, rows
-//               pruned by their AABB distance.  Cooperative phase: queries the fine
-//               level could not certify are scanned by the whole wavefront on the level
-//               that covers their current bound.
+//   k_nn_grid   one lane per query: a certified radius search over a ladder of uniform
+//               grids (cell size x2 per level); small radii are scanned by the query's own
+//               lane, large ones by the whole wavefront (see the kernel's comment).
 //   k_nn_brute  LDS-tiled all-pairs search (small clouds / cross-check).
 #include "wm_internal.hpp"
 
@@ -51,53 +48,6 @@ __device__ __forceinline__ void xform(const float *T, const float4 &p, float &x,
 __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblocks) {
     const unsigned per = (nblocks + 7u) / 8u;
     return (b & 7u) * per + (b >> 3);
-}
-
-// (dy, dz) of the 9 x-rows of a 3x3x3 block, nearest first
-__device__ __constant__ signed char kRowDy[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
-__device__ __constant__ signed char kRowDz[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
-
-struct Cell {
-    float fx, fy, fz;  // query position in cell units
-    int cx, cy, cz;
-};
-
-__device__ __forceinline__ Cell locate(const GridDev &g, float x, float y, float z) {
-    Cell c;
-    c.fx = (x - g.ox) * g.inv_h;
-    c.fy = (y - g.oy) * g.inv_h;
-    c.fz = (z - g.oz) * g.inv_h;
-    // clamp before the int conversion so far-away queries cannot overflow
-    c.cx = (int) floorf(fminf(fmaxf(c.fx, -4.0f), (float) g.nx + 4.0f));
-    c.cy = (int) floorf(fminf(fmaxf(c.fy, -4.0f), (float) g.ny + 4.0f));
-    c.cz = (int) floorf(fminf(fmaxf(c.fz, -4.0f), (float) g.nz + 4.0f));
-    return c;
-}
-
-// distance (cell units) from the query to the faces of its (2R+1)^3 cell block:
-// every point NOT in the block is at least this far away.
-__device__ __forceinline__ float block_margin(const Cell &c, int R = 1) {
-    float mx = fminf(c.fx - (float) (c.cx - R), (float) (c.cx + R + 1) - c.fx);
-    float my = fminf(c.fy - (float) (c.cy - R), (float) (c.cy + R + 1) - c.fy);
-    float mz = fminf(c.fz - (float) (c.cz - R), (float) (c.cz + R + 1) - c.fz);
-    return fminf(mx, fminf(my, mz));
-}
-
-// lower bound (cell units) of the distance from the query to row (cy+dy, cz+dz)
-__device__ __forceinline__ float row_bound(const Cell &c, int dy, int dz) {
-    float ry = dy == 0 ? 0.f : (dy < 0 ? c.fy - (float) (c.cy + dy + 1) : (float) (c.cy + dy) - c.fy);
-    float rz = dz == 0 ? 0.f : (dz < 0 ? c.fz - (float) (c.cz + dz + 1) : (float) (c.cz + dz) - c.fz);
-    return sqrtf(ry * ry + rz * rz);
-}
-
-__device__ __forceinline__ bool certified(const GridDev &g, const Cell &c, float best_d2,
-                                          float thr_d2, int R = 1) {
-    // resolved when the block provably contains the minimum, or when it covers
-    // the whole acceptance radius (nothing outside can be <= threshold)
-    const float m = (block_margin(c, R) - g.slack) * g.h;
-    if (m <= 0.f) return false;
-    const float m2 = m * m;
-    return best_d2 <= m2 || thr_d2 <= m2;
 }
 
 // ------------------------------------------------------------- grid search
