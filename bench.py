@@ -107,7 +107,9 @@ def main():
     from libwave_amd import capi, synth
 
     n_total = a.points * world
-    ref, tgt, T_gt = synth.pair(n_total, seed=42, mode="resample")
+    # weak scaling: `world` tiles of the base scene side by side (same density, longer map);
+    # world == 1 is the plain 1M<->1M pair of BASELINE configs[1]
+    ref, tgt, T_gt = synth.pair_tiled(a.points, world, seed=42)
     dev = torch.device("cuda", local_rank)
 
     force_sharded = os.environ.get("WM_BENCH_FORCE_SHARDED") == "1"  # plumbing check at N=1
@@ -178,6 +180,7 @@ def main():
                                                                  1 if world == 1 else 4,
                                                                  a.iters, a.max_corr),
                 "arithmetic": "f32 points and distances, f64 reductions and solve",
+                "scene": "base scene x%d tiled along x at constant density; T_gt rotation / %d" % (world, world),
                 "points_per_cloud_total": n_total, "points_per_gpu": a.points,
                 "iterations": a.iters, "parallelism": parallelism,
                 "registrations_per_s_raw": regs_per_s_raw,

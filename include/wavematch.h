@@ -127,6 +127,8 @@ typedef struct {
     int nn_levels;       /* grid levels used */
     uint64_t deferred;   /* queries that needed a coarser grid level (profile=1) */
     float grid_cell;     /* level-0 cell size used */
+    int owned_violations; /* sharded path: iterations in which the ranks together did not
+                             handle every source point (see wm_icp_shard_begin) */
 } wm_icp_stats;
 
 void wm_icp_default_params(wm_icp_params *p);
@@ -197,7 +199,8 @@ int wm_nn_search(wm_ctx *ctx, const double T[16], double max_corr, int nn_method
 /* The sufficient statistics one ICP iteration reduces to (what crosses xGMI in
  * the multi-GPU path).  SVD mode: stats[0]=n, [1..3]=sum p, [4..6]=sum q,
  * [7..15]=sum q p^T (row-major), [16]=sum d2.  GN6 mode: [0]=n, [1]=sum d2,
- * [2..22]=upper triangle of J^T J (row-major), [23..28]=J^T r.  Uses the
+ * [2..22]=upper triangle of J^T J (row-major), [23..28]=J^T r.  Both: [31] = number of
+ * source points this context handled (== cloud size unless sharded).  Uses the
  * correspondences of the last wm_nn_search / align iteration. */
 #define WM_STATS_LEN 32
 int wm_icp_stats_for(wm_ctx *ctx, const double T[16], int mode, double stats[WM_STATS_LEN]);
@@ -288,8 +291,16 @@ int wm_ndt_derivatives(wm_ctx *ctx, const wm_ndt_params *p, const double pose[6]
  *   <caller all-reduces stats_dev (sum) on a stream ordered after the ctx stream>
  *   wm_icp_shard_apply        enqueue the solve + stopping rules from stats_dev
  *   wm_icp_shard_poll         sync; report done / transform / statistics
- * All enqueue calls are asynchronous on the context's stream (wm_ctx_set_stream). */
-int wm_icp_shard_begin(wm_ctx *ctx, const wm_icp_params *p, double x_lo, double x_hi);
+ * All enqueue calls are asynchronous on the context's stream (wm_ctx_set_stream).
+ * A rank need not hold the full source cloud: any superset of the points that can fall
+ * into its slab will do (e.g. those within a band around the slab).  To keep that exact,
+ * pass expect_owned_total = the number of (finite) source points of the whole cloud:
+ * stats[WM_STATS_LEN-1] carries the number of points each rank handled, and every
+ * iteration in which the all-reduced count differs is tallied in
+ * wm_icp_stats.owned_violations -- the caller then redoes the registration with wider
+ * bands / full clouds.  0 disables the check. */
+int wm_icp_shard_begin(wm_ctx *ctx, const wm_icp_params *p, double x_lo, double x_hi,
+                       size_t expect_owned_total);
 int wm_icp_shard_local_stats(wm_ctx *ctx, void *stats_dev);
 int wm_icp_shard_apply(wm_ctx *ctx, const void *stats_dev);
 int wm_icp_shard_poll(wm_ctx *ctx, int *done, double T_out[16], wm_icp_stats *stats);
@@ -298,7 +309,7 @@ int wm_icp_shard_poll(wm_ctx *ctx, int *done, double T_out[16], wm_icp_stats *st
  * the very function the device runs after the all-reduce, callable on the CPU so
  * that the sharded control flow can be exercised without a GPU. */
 typedef struct wm_host_icp wm_host_icp;
-int wm_host_icp_create(wm_host_icp **out, const wm_icp_params *p);
+int wm_host_icp_create(wm_host_icp **out, const wm_icp_params *p, size_t expect_owned_total);
 void wm_host_icp_destroy(wm_host_icp *h);
 int wm_host_icp_apply(wm_host_icp *h, const double stats[WM_STATS_LEN]);
 int wm_host_icp_get(const wm_host_icp *h, int *done, double T_out[16], wm_icp_stats *stats);

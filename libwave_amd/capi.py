@@ -40,7 +40,8 @@ class IcpStats(C.Structure):
                 ("align_ms", C.c_float), ("nn_ms", C.c_float), ("coarse_ms", C.c_float),
                 ("stats_ms", C.c_float),
                 ("solve_ms", C.c_float), ("nn_launches", C.c_int), ("nn_levels", C.c_int),
-                ("deferred", C.c_uint64), ("grid_cell", C.c_float)]
+                ("deferred", C.c_uint64), ("grid_cell", C.c_float),
+                ("owned_violations", C.c_int)]
 
 
 class GicpParams(C.Structure):
@@ -107,11 +108,12 @@ def lib():
         L.wm_icp_info.argtypes = [C.c_void_p, C.c_int, _dp, C.c_double, C.c_double, C.c_double, _dp,
                                   C.POINTER(C.c_int)]
         L.wm_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-        L.wm_icp_shard_begin.argtypes = [C.c_void_p, C.POINTER(IcpParams), C.c_double, C.c_double]
+        L.wm_icp_shard_begin.argtypes = [C.c_void_p, C.POINTER(IcpParams), C.c_double, C.c_double,
+                                         C.c_size_t]
         L.wm_icp_shard_local_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.wm_icp_shard_apply.argtypes = [C.c_void_p, C.c_void_p]
         L.wm_icp_shard_poll.argtypes = [C.c_void_p, C.POINTER(C.c_int), _dp, C.POINTER(IcpStats)]
-        L.wm_host_icp_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(IcpParams)]
+        L.wm_host_icp_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(IcpParams), C.c_size_t]
         L.wm_host_icp_destroy.argtypes = [C.c_void_p]
         L.wm_host_icp_destroy.restype = None
         L.wm_host_icp_apply.argtypes = [C.c_void_p, _dp]
@@ -251,12 +253,7 @@ class Context:
         s = IcpStats()
         rc = self._check(lib().wm_icp_align(self._h, C.byref(p), T.ctypes.data_as(_dp),
                                             C.byref(s)), "wm_icp_align")
-        return dict(rc=rc, T=T if rc == WM_OK else None, converged=bool(s.converged),
-                    iterations=s.iterations, state=CONV_NAMES.get(s.state, s.state),
-                    n_corr=s.n_corr, mse=s.mse, prev_mse=s.prev_mse, align_ms=s.align_ms,
-                    nn_ms=s.nn_ms, coarse_ms=s.coarse_ms, stats_ms=s.stats_ms, solve_ms=s.solve_ms,
-                    nn_launches=s.nn_launches, nn_levels=s.nn_levels, deferred=s.deferred,
-                    grid_cell=s.grid_cell)
+        return self._stats_dict(rc, T, s)
 
     @staticmethod
     def _stats_dict(rc, T, s):
@@ -265,7 +262,8 @@ class Context:
                     n_corr=s.n_corr, mse=s.mse, prev_mse=s.prev_mse, align_ms=s.align_ms,
                     nn_ms=s.nn_ms, coarse_ms=s.coarse_ms, stats_ms=s.stats_ms,
                     solve_ms=s.solve_ms, nn_launches=s.nn_launches, nn_levels=s.nn_levels,
-                    deferred=s.deferred, grid_cell=s.grid_cell)
+                    deferred=s.deferred, grid_cell=s.grid_cell,
+                    owned_violations=s.owned_violations)
 
     def icp_match(self, ref, target, res=-1.0, multiscale_steps=0, params=None, **kw):
         """ICPMatcher::match() (icp.cpp:75-133) in one C-ABI call."""
@@ -386,9 +384,9 @@ class Context:
         self._check(lib().wm_ctx_set_stream(self._h, C.c_void_p(stream_ptr), int(external)),
                     "wm_ctx_set_stream")
 
-    def shard_begin(self, params, x_lo, x_hi):
-        self._check(lib().wm_icp_shard_begin(self._h, C.byref(params), float(x_lo), float(x_hi)),
-                    "wm_icp_shard_begin")
+    def shard_begin(self, params, x_lo, x_hi, expect_owned_total=0):
+        self._check(lib().wm_icp_shard_begin(self._h, C.byref(params), float(x_lo), float(x_hi),
+                                             int(expect_owned_total)), "wm_icp_shard_begin")
 
     def shard_local_stats(self, dev_ptr):
         self._check(lib().wm_icp_shard_local_stats(self._h, C.c_void_p(dev_ptr)),
@@ -444,9 +442,9 @@ class HostIcp:
     """The per-iteration solve + PCL stopping rules on the host (wm_host_icp_*): the same
     function the device runs after the all-reduce."""
 
-    def __init__(self, params):
+    def __init__(self, params, expect_owned_total=0):
         self._h = C.c_void_p()
-        rc = lib().wm_host_icp_create(C.byref(self._h), C.byref(params))
+        rc = lib().wm_host_icp_create(C.byref(self._h), C.byref(params), int(expect_owned_total))
         if rc != WM_OK:
             raise WmError("wm_host_icp_create failed")
 
@@ -467,7 +465,8 @@ class HostIcp:
         lib().wm_host_icp_get(self._h, C.byref(done), T.ctypes.data_as(_dp), C.byref(s))
         return dict(done=bool(done.value), T=T, converged=bool(s.converged),
                     iterations=s.iterations, state=CONV_NAMES.get(s.state, s.state),
-                    n_corr=s.n_corr, mse=s.mse, rc=0 if s.converged or not done.value else
+                    n_corr=s.n_corr, mse=s.mse, owned_violations=s.owned_violations,
+                    rc=0 if s.converged or not done.value else
                     (WM_TOO_FEW if s.state == 5 else WM_NOT_CONVERGED))
 
 

@@ -24,7 +24,7 @@
 
 namespace wm {
 
-constexpr int kAcc = 17;
+constexpr int kAcc = 18;  // 17 statistics + the number of source points this rank handled
 constexpr int kMaxStatBlocks = 256;
 
 __device__ __forceinline__ void xform_pt(const float *T, const float4 &p, float &x, float &y,
@@ -47,13 +47,18 @@ __global__ void __launch_bounds__(kBlock)
     double a[kAcc];
 #pragma unroll
     for (int k = 0; k < kAcc; ++k) a[k] = 0.0;
+    const bool slab_on = st->slab_on != 0;
+    const float slab_lo = st->slab_lo, slab_hi = st->slab_hi;
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const unsigned long long key = keys[i];
-        const unsigned idx = (unsigned) key;
-        if (idx == kNoIdx) continue;
         const float4 p4 = src[i];
         float fx, fy, fz;
         xform_pt(st->Tf, p4, fx, fy, fz);
+        // sharded registration: the same ownership test as the search kernel
+        if (slab_on && !(fx >= slab_lo && fx < slab_hi)) continue;
+        a[17] += 1.0;
+        const unsigned long long key = keys[i];
+        const unsigned idx = (unsigned) key;
+        if (idx == kNoIdx) continue;
         const float4 q4 = tgt[i];  // match coordinates, written by the search (coalesced)
         const double px = fx, py = fy, pz = fz, qx = q4.x, qy = q4.y, qz = q4.z;
         const double d2 = (double) __uint_as_float((unsigned) (key >> 32));
@@ -113,6 +118,7 @@ __global__ void __launch_bounds__(kBlock)
 __device__ __host__ inline void expand_stats(int mode, const double *a, double *st) {
 #pragma unroll
     for (int k = 0; k < kStatsLen; ++k) st[k] = 0.0;
+    st[kStatsLen - 1] = a[17];  // source points handled (ownership check of the sharded path)
     if (mode == WM_ICP_SVD) {
         st[kSvdN] = a[0];
         for (int k = 0; k < 3; ++k) st[kSvdSp + k] = a[1 + k];
@@ -165,6 +171,7 @@ __host__ __device__ inline void icp_apply_stats(IcpDevState *st, const double *s
     const double mse = n > 0 ? sd2 / n : 0.0;
     st->n_corr = (int) n;
     st->mse = mse;
+    if (st->expect_owned > 0 && stats[kStatsLen - 1] != st->expect_owned) st->owned_violations += 1;
     // bookkeeping for the next iteration's queues
     st->deferred_total += st->queue_count[1];
 #pragma unroll
@@ -238,7 +245,7 @@ __global__ void __launch_bounds__(kBlock)
     k_reduce_solve(const double *__restrict__ partials, int nblocks, IcpDevState *st,
                    double *stats_io) {
     if (st->done) return;
-    constexpr int kRows = 15;  // 15 row-lanes x 17 components = 255 active threads
+    constexpr int kRows = kBlock / kAcc;  // row-lanes x kAcc components <= 256 threads
     __shared__ double lds[kRows][kAcc];
     if (PHASES & 1) {
         const int c = threadIdx.x % kAcc, r = threadIdx.x / kAcc;
@@ -744,7 +751,8 @@ int wm_icp_match(wm_ctx *ctx, const void *ref, size_t n_ref, const void *target,
 }
 
 // ------------------------------------------------ sharded (multi-GPU) stepping
-int wm_icp_shard_begin(wm_ctx *ctx, const wm_icp_params *p, double x_lo, double x_hi) {
+int wm_icp_shard_begin(wm_ctx *ctx, const wm_icp_params *p, double x_lo, double x_hi,
+                       size_t expect_owned_total) {
     if (!ctx || !p || !(p->max_corr > 0) || !(x_lo < x_hi)) return WM_ERR_ARG;
     if (ctx->n_src_input == 0) return WM_ERR_STATE;
     WM_HIP(ctx, hipSetDevice(ctx->device));
@@ -759,6 +767,10 @@ int wm_icp_shard_begin(wm_ctx *ctx, const wm_icp_params *p, double x_lo, double 
     ctx->h_state->slab_on = 1;
     ctx->h_state->slab_lo = x_lo < -3.0e38 ? -INFINITY : (float) x_lo;
     ctx->h_state->slab_hi = x_hi > 3.0e38 ? INFINITY : (float) x_hi;
+    ctx->h_state->expect_owned = (double) expect_owned_total;
+    // keys double as next iteration's candidates: start from "nothing known"
+    WM_HIP(ctx, hipMemsetAsync(ctx->keys.p, 0xFF, (ctx->n_src > 0 ? ctx->n_src : 1) * sizeof(unsigned long long),
+                               ctx->stream));
     WM_TRY(upload_state(ctx));
     WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->iter_nn_ms.clear();
@@ -819,6 +831,7 @@ int wm_icp_shard_poll(wm_ctx *ctx, int *done, double T_out[16], wm_icp_stats *st
         stats->mse = s.mse;
         stats->prev_mse = s.prev_mse;
         stats->deferred = s.deferred_total;
+        stats->owned_violations = s.owned_violations;
         stats->nn_levels = ctx->shard_brute ? 0 : ctx->n_levels;
         stats->grid_cell = ctx->shard_brute ? 0.f : ctx->levels[0].d.h;
         if (ctx->shard_params.profile) {
@@ -849,13 +862,14 @@ struct wm_host_icp {
     IcpDevState st;
 };
 
-int wm_host_icp_create(wm_host_icp **out, const wm_icp_params *p) {
+int wm_host_icp_create(wm_host_icp **out, const wm_icp_params *p, size_t expect_owned_total) {
     if (!out || !p) return WM_ERR_ARG;
     wm_host_icp *h = new (std::nothrow) wm_host_icp();
     if (!h) return WM_ERR_NOMEM;
     double I[16];
     mat4_identity(I);
     init_state(&h->st, I, p, DBL_MAX);
+    h->st.expect_owned = (double) expect_owned_total;
     *out = h;
     return WM_OK;
 }
@@ -881,6 +895,7 @@ int wm_host_icp_get(const wm_host_icp *h, int *done, double T_out[16], wm_icp_st
         stats->n_corr = h->st.n_corr;
         stats->mse = h->st.mse;
         stats->prev_mse = h->st.prev_mse;
+        stats->owned_violations = h->st.owned_violations;
     }
     return WM_OK;
 }

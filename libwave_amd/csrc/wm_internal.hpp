@@ -99,6 +99,11 @@ struct IcpDevState {
     // lies in [slab_lo, slab_hi)
     int slab_on;
     float slab_lo, slab_hi;
+    // every rank holds only the source points near its slab; the all-reduced count of
+    // handled points must equal the cloud size in EVERY iteration, else a point fell
+    // outside all bands and the registration has to be redone with full source clouds
+    double expect_owned;
+    int owned_violations;
     double rot_thr, trans_thr, fit_eps;
     unsigned queue_count[kMaxLevels + 1];
     unsigned long long deferred_total;

@@ -260,7 +260,8 @@ __global__ void __launch_bounds__(kBlock)
         // sharded registration: only the rank owning this x-slab handles the point
         if (st->slab_on && !(qx >= st->slab_lo && qx < st->slab_hi)) mine = false;
     }
-    if (active && !mine) best = ~0ull;  // "not mine": no match, and no radius prediction
+    // a point of another rank's slab is left untouched: its key / match keep whatever this
+    // rank last found for it (still a valid candidate if it ever comes back)
     if (mine) {
         r = 0.5f * h0;
         if (st->have_prev) {
@@ -345,7 +346,7 @@ __global__ void __launch_bounds__(kBlock)
             bqz = uwin.z;
         }
     }
-    if (active) {
+    if (mine) {
         keys[i] = best;
         match_pt[i] = make_float4(bqx, bqy, bqz, 0.f);
     }

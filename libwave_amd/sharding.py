@@ -40,25 +40,55 @@ def slab_target_mask(target_xyz, lo, hi, halo, axis=0):
     return (x >= lo - halo) & (x <= hi + halo)
 
 
+def slab_source_mask(source_xyz, lo, hi, pad, axis=0):
+    """Source points a rank needs: those whose INITIAL x lies within `pad` of its slab.  A
+    point can be missed only if the registration moves it by more than `pad` along x into
+    the slab; the ownership count carried in the statistics block detects that (every
+    iteration), and the driver then redoes the registration with full source clouds."""
+    x = np.asarray(source_xyz)[:, axis].astype(np.float64)
+    return np.isfinite(x) & (x >= lo - pad) & (x <= hi + pad)
+
+
 class GpuShardEngine:
     """One rank's share of a sharded registration on one MI355X."""
 
-    def __init__(self, device, ref, target, rank, world, max_corr, use_torch_stream=True):
+    def __init__(self, device, ref, target, rank, world, max_corr, use_torch_stream=True,
+                 source_pad=None):
         import torch
         self.torch = torch
         self.dev = torch.device("cuda", device)
         self.rank, self.world = rank, world
         self.lo, self.hi = plan_slabs(target, world)[rank]
+        # source band: default pad = max_corr (a registration that moves points farther than
+        # its own correspondence gate is already outside ICP's basin); None/inf = full cloud
+        self.source_pad = float(max_corr) if source_pad is None else float(source_pad)
+        ref = np.ascontiguousarray(ref, np.float32)
+        self.n_source_total = int(np.isfinite(ref).all(1).sum())
+        self._ref_full = ref
+        self._full_source = world == 1 or not np.isfinite(self.source_pad)
         # a float32-safe halo: max_corr plus a hair for the float rounding of x
         self.halo = float(max_corr) * (1.0 + 1e-6) + 1e-4
         mask = slab_target_mask(target, self.lo, self.hi, self.halo)
         self.n_target_local = int(mask.sum())
-        self.d_ref = torch.from_numpy(np.ascontiguousarray(ref, np.float32)).to(self.dev)
+        self._upload_source()
         self.d_tgt = torch.from_numpy(np.ascontiguousarray(target[mask], np.float32)).to(self.dev)
         self.ctx = capi.Context(device)
         if use_torch_stream:
             self.ctx.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
         self.stats = torch.zeros(capi.WM_STATS_LEN, dtype=torch.float64, device=self.dev)
+        self.rebuild()
+
+    def _upload_source(self):
+        ref = self._ref_full
+        if not self._full_source:
+            ref = ref[slab_source_mask(ref, self.lo, self.hi, self.source_pad)]
+        self.n_source_local = len(ref)
+        self.d_ref = self.torch.from_numpy(np.ascontiguousarray(ref)).to(self.dev)
+
+    def use_full_source(self):
+        """safe mode after an ownership violation: every rank holds the whole source cloud"""
+        self._full_source = True
+        self._upload_source()
         self.rebuild()
 
     def rebuild(self):
@@ -67,7 +97,7 @@ class GpuShardEngine:
         self.ctx.set_target(self.d_tgt)
 
     def begin(self, params):
-        self.ctx.shard_begin(params, self.lo, self.hi)
+        self.ctx.shard_begin(params, self.lo, self.hi, self.n_source_total)
 
     def local_stats(self):
         self.ctx.shard_local_stats(self.stats.data_ptr())
@@ -86,7 +116,7 @@ class ShardedIcp:
     def __init__(self, engine, dist=None, device=None, batch=8):
         self.eng, self.dist, self.batch = engine, dist, batch
 
-    def align(self, params=None, **kw):
+    def align(self, params=None, _retry=False, **kw):
         p = params or capi.icp_params(**kw)
         forced = p.force_iterations > 0
         max_it = p.force_iterations if forced else p.max_iter
@@ -104,4 +134,10 @@ class ShardedIcp:
             out = self.eng.poll()
             if out["done"]:
                 break
+        if out is not None and out.get("owned_violations", 0) > 0 and not _retry:
+            # some source point left every rank's band: identical on all ranks (it is computed
+            # from the all-reduced block), so all ranks take this branch together
+            self.eng.use_full_source()
+            out = self.align(params=p, _retry=True)
+            out["redone_with_full_source"] = True
         return out

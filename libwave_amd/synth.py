@@ -84,3 +84,29 @@ def pair(n, seed=42, mode="resample", T=None, noise=0.01):
     else:
         raise ValueError(mode)
     return ref, tgt, T
+
+
+TILE_X = 100.0  # the base scene spans x in [-50, 50]
+
+
+def pair_tiled(n_per_tile, tiles, seed=42, noise=0.01):
+    """Weak-scaling workload: `tiles` copies of the base scene side by side along x (each its
+    own sampling), i.e. a map `tiles` times longer at the SAME point density, so that the work
+    per point -- which for a radius-bounded search grows with density -- is the same at every
+    size.  The ground-truth rotation is divided by `tiles` so that the initial misalignment
+    field (<= ~1.7 m at the far ends) is the same too; the translation is unchanged.
+    tiles == 1 is exactly pair(n_per_tile, seed, 'resample')."""
+    if tiles == 1:
+        return pair(n_per_tile, seed=seed, mode="resample", noise=noise)
+    T = make_T((0.2, -0.1, 0.05), tuple(a / tiles for a in (0.01, -0.02, 0.03)))
+    refs, tgts = [], []
+    for k in range(tiles):
+        off = np.array([(k - (tiles - 1) / 2.0) * TILE_X, 0.0, 0.0])
+        s = seed + 7 * k
+        refs.append((scene(n_per_tile, s).astype(np.float64) + off).astype(np.float32))
+        other = scene(n_per_tile, s + 1).astype(np.float64) + off
+        rng = np.random.Generator(np.random.PCG64(s + 1000003))
+        tgts.append((other + rng.normal(0, noise, other.shape)).astype(np.float32))
+    ref = np.ascontiguousarray(np.concatenate(refs))
+    tgt = transform_points(np.concatenate(tgts), T)
+    return ref, tgt, T

@@ -52,19 +52,25 @@ def test_halo_makes_sharded_nn_exact(oracle):
 class OracleShardEngine:
     """Same interface as sharding.GpuShardEngine, kernels replaced by the CPU oracle."""
 
-    def __init__(self, ref, tgt, rank, world, max_corr, oracle, capi):
+    def __init__(self, ref, tgt, rank, world, max_corr, oracle, capi, source_pad=None):
         import torch
         from libwave_amd import sharding
         self.torch, self.O, self.capi = torch, oracle, capi
-        self.ref = ref
         self.lo, self.hi = sharding.plan_slabs(tgt, world)[rank]
+        self.ref_full = ref
+        self.n_total = len(ref)
+        pad = max_corr if source_pad is None else source_pad
+        self.ref = ref if world == 1 else ref[sharding.slab_source_mask(ref, self.lo, self.hi, pad)]
         mask = sharding.slab_target_mask(tgt, self.lo, self.hi, max_corr * (1 + 1e-6) + 1e-4)
         self.tgt = tgt[mask]
         self.tree = oracle.KdTree(self.tgt)
         self.max_corr = max_corr
 
+    def use_full_source(self):
+        self.ref = self.ref_full
+
     def begin(self, params):
-        self.host = self.capi.HostIcp(params)
+        self.host = self.capi.HostIcp(params, self.n_total)
 
     def local_stats(self):
         T = self.host.get()["T"]
@@ -75,6 +81,7 @@ class OracleShardEngine:
             idx, d2 = self.tree.nn(moved[mine])
             ok = d2.astype(np.float64) <= self.max_corr ** 2
             st = svd_stats_numpy(moved[mine][ok], self.tgt[idx[ok]], d2[ok])
+        st[31] = mine.sum()          # source points this rank handled (ownership check)
         return self.torch.from_numpy(st)
 
     def apply(self, t):
@@ -84,7 +91,7 @@ class OracleShardEngine:
         return self.host.get()
 
 
-def _worker(rank, world, port, n, q):
+def _worker(rank, world, port, n, q, source_pad=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -94,23 +101,29 @@ def _worker(rank, world, port, n, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ref, tgt, _ = synth.pair(n, seed=42)
-        eng = OracleShardEngine(ref, tgt, rank, world, 3.0, O, capi)
-        out = {}
+        eng = OracleShardEngine(ref, tgt, rank, world, 3.0, O, capi, source_pad)
+        out = {"n_local": len(eng.ref)}
         for name, kw in (("forced", dict(force_iterations=6)), ("free", dict(max_iter=40))):
             r = sharding.ShardedIcp(eng, dist).align(max_corr=3.0, **kw)
             out[name] = (r["T"].tolist(), r["iterations"], r["state"], r["n_corr"])
+            out[name + "_redone"] = bool(r.get("redone_with_full_source"))
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_sharded_icp_over_gloo_matches_unsharded_oracle(oracle, wm):
+@pytest.mark.parametrize("source_pad,port", [(None, 29731), (0.01, 29741)])
+def test_sharded_icp_over_gloo_matches_unsharded_oracle(oracle, wm, source_pad, port):
+    """source_pad=None: each rank holds the source points within max_corr of its slab.
+    source_pad=0.01: a band far too narrow -> the ownership count exposes the lost points and
+    the driver redoes the registration with full source clouds; the result must not change."""
     import multiprocessing as mp
-    n, world, port = 6000, 2, 29731
+    n, world = 6000, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q, source_pad))
+             for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=240) for _ in range(world))
@@ -118,6 +131,11 @@ def test_sharded_icp_over_gloo_matches_unsharded_oracle(oracle, wm):
         p.join(timeout=60)
         assert p.exitcode == 0
     ref, tgt, _ = synth.pair(n, seed=42)
+    assert res[0]["n_local"] < n and res[1]["n_local"] < n     # bands, not the full cloud
+    if source_pad is not None:
+        assert res[0]["forced_redone"] and res[1]["forced_redone"]
+    else:
+        assert not res[0]["forced_redone"] and not res[0]["free_redone"]
     for name, kw in (("forced", dict(force_iterations=6)), ("free", dict(max_iter=40))):
         want = oracle.icp_align(ref, tgt, max_corr=3.0, incremental_float=0, **kw)
         T0, it0, st0, nc0 = res[0][name]

@@ -15,8 +15,9 @@ pytestmark = pytest.mark.gpu
 class TwoRanksOneGpu:
     """Drives `world` GpuShardEngines on one device; sum of their stats = the all-reduce."""
 
-    def __init__(self, ref, tgt, world, max_corr):
-        self.engs = [sharding.GpuShardEngine(0, ref, tgt, r, world, max_corr) for r in range(world)]
+    def __init__(self, ref, tgt, world, max_corr, source_pad=None):
+        self.engs = [sharding.GpuShardEngine(0, ref, tgt, r, world, max_corr, source_pad=source_pad)
+                     for r in range(world)]
 
     def begin(self, p):
         for e in self.engs:
@@ -33,6 +34,10 @@ class TwoRanksOneGpu:
         for e in self.engs:
             e.stats.copy_(t)
             e.apply(e.stats)
+
+    def use_full_source(self):
+        for e in self.engs:
+            e.use_full_source()
 
     def poll(self):
         outs = [e.poll() for e in self.engs]
@@ -69,6 +74,25 @@ def test_sharded_free_running_and_ownership(wm, ctx):
     ctx.nn_search(np.eye(4), 2.0, wm.WM_NN_GRID, want=False)
     n_full = ctx.icp_stats_for(np.eye(4))[0]
     assert all(n > 0 for n in n_local) and sum(n_local) == n_full
+
+
+def test_narrow_source_band_is_detected_and_redone(wm, ctx):
+    ref, tgt, _ = synth.pair(30000, seed=42)
+    ctx.set_source(ref)
+    ctx.set_target(tgt)
+    want = ctx.icp_align(max_corr=3.0, force_iterations=10)
+    two = TwoRanksOneGpu(ref, tgt, 2, 3.0, source_pad=0.01)   # far too narrow
+    assert all(e.n_source_local < len(ref) for e in two.engs)
+    got = sharding.ShardedIcp(two, None).align(max_corr=3.0, force_iterations=10)
+    assert got.get("redone_with_full_source") and got["owned_violations"] == 0
+    dt, ang = pose_error(got["T"], want["T"])
+    assert dt <= 1e-9 and ang <= 1e-9
+    ok = TwoRanksOneGpu(ref, tgt, 2, 3.0)                      # default band = max_corr
+    got = sharding.ShardedIcp(ok, None).align(max_corr=3.0, force_iterations=10)
+    assert not got.get("redone_with_full_source") and got["owned_violations"] == 0
+    assert all(e.n_source_local < len(ref) for e in ok.engs)
+    dt, ang = pose_error(got["T"], want["T"])
+    assert dt <= 1e-9 and ang <= 1e-9
 
 
 def test_sharded_driver_with_external_stream_world1(wm):
