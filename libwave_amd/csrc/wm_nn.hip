@@ -50,6 +50,18 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblocks) {
     return (b & 7u) * per + (b >> 3);
 }
 
+// The grid tables are reached through pointers read from memory, so the compiler only knows
+// them as generic (flat) addresses; they always point into HBM -- say so, and get global_load
+// instead of flat_load (no LDS-aperture check, no lgkmcnt coupling).
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) f4v *gp_f4;
+typedef const __attribute__((address_space(1))) unsigned *gp_u32;
+__device__ __forceinline__ float4 ldp(const float4 *p, size_t j) {
+    const f4v v = ((gp_f4) p)[j];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ unsigned ldc(const unsigned *p, size_t j) { return ((gp_u32) p)[j]; }
+
 // ------------------------------------------------------------- grid search
 // scan the contiguous run [s, e) of cell-sorted target points, four loads in flight
 // (bpos follows the winner: its position in `pts`, so the caller can fetch its coordinates)
@@ -60,10 +72,10 @@ __device__ __forceinline__ unsigned long long scan_run(const float4 *__restrict_
         // clamped re-reads of the last point are harmless: min() is idempotent
         const unsigned last = e - 1;
         const unsigned j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
-        const float4 t0 = pts[j];
-        const float4 t1 = pts[j1];
-        const float4 t2 = pts[j2];
-        const float4 t3 = pts[j3];
+        const float4 t0 = ldp(pts, j);
+        const float4 t1 = ldp(pts, j1);
+        const float4 t2 = ldp(pts, j2);
+        const float4 t3 = ldp(pts, j3);
         const unsigned long long k0 = make_key(canon_d2(qx, qy, qz, t0), __float_as_uint(t0.w));
         const unsigned long long k1 = make_key(canon_d2(qx, qy, qz, t1), __float_as_uint(t1.w));
         const unsigned long long k2 = make_key(canon_d2(qx, qy, qz, t2), __float_as_uint(t2.w));
@@ -75,6 +87,52 @@ __device__ __forceinline__ unsigned long long scan_run(const float4 *__restrict_
         const bool up = m < best;
         best = up ? m : best;
         bpos = up ? pm : bpos;
+    }
+    return best;
+}
+
+// The common case of scan_box -- the box spans at most 3 x 3 (y, z) rows, which is what the
+// level choice (cell size >= r) guarantees: all (up to 18) cell_start loads are issued up
+// front as independent loads (one memory round trip instead of one per row), then the rows
+// are scanned in raster order, pruned by their AABB distance against the running best (the
+// previous iteration's match usually makes that bound tight before the first row).
+__device__ __forceinline__ unsigned long long scan_rows9(const GridDev &g, float qx, float qy,
+                                                         float qz, float fy, float fz, int xa,
+                                                         int xb, int ya, int yb, int za, int zb,
+                                                         unsigned long long best, unsigned &bpos) {
+    const int cy = (int) floorf(fy), cz = (int) floorf(fz);
+    // A row whose (y,z) distance to the query exceeds the best distance so far cannot hold
+    // the neighbour.  Compared in cell units against rb = sqrt(best) / h + slack, inflated by
+    // 1e-5 so that the (approximate) hardware square root can only make the test more
+    // conservative: pruning changes the work, never the result.
+    unsigned rs[9], re[9];
+    {
+        const float rb =
+            (__builtin_amdgcn_sqrtf(__uint_as_float((unsigned) (best >> 32))) * g.inv_h + g.slack) *
+            1.00001f;
+        const float rb2 = rb * rb;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int yy = ya + k % 3, zz = za + k / 3;
+            const float ry = yy > cy ? (float) yy - fy : (yy < cy ? fy - (float) (yy + 1) : 0.f);
+            const float rz = zz > cz ? (float) zz - fz : (zz < cz ? fz - (float) (zz + 1) : 0.f);
+            const bool ok = yy <= yb && zz <= zb && !(ry * ry + rz * rz > rb2);
+            const unsigned base = ok ? ((unsigned) zz * g.ny + yy) * g.nx : 0u;
+            rs[k] = ok ? ldc(g.cell_start, base + xa) : 0u;
+            re[k] = ok ? ldc(g.cell_start, base + xb + 1) : 0u;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        if (re[k] <= rs[k]) continue;
+        const int yy = ya + k % 3, zz = za + k / 3;
+        const float ry = yy > cy ? (float) yy - fy : (yy < cy ? fy - (float) (yy + 1) : 0.f);
+        const float rz = zz > cz ? (float) zz - fz : (zz < cz ? fz - (float) (zz + 1) : 0.f);
+        const float rb =
+            (__builtin_amdgcn_sqrtf(__uint_as_float((unsigned) (best >> 32))) * g.inv_h + g.slack) *
+            1.00001f;
+        if (ry * ry + rz * rz > rb * rb) continue;
+        best = scan_run(g.pts, rs[k], re[k], qx, qy, qz, best, bpos);
     }
     return best;
 }
@@ -104,12 +162,15 @@ __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float q
     const int ya = max(y0, 0), yb = min(y1, g.ny - 1);
     const int za = max(z0, 0), zb = min(z1, g.nz - 1);
     if (xa > xb || ya > yb || za > zb) return best;
+    if (yb - ya < 3 && zb - za < 3)  // wave-divergent, but nearly always taken
+        return scan_rows9(g, qx, qy, qz, fminf(fmaxf(fy, -big), big), fminf(fmaxf(fz, -big), big), xa,
+                          xb, ya, yb, za, zb, best, bpos);
     const int cy = (int) floorf(fminf(fmaxf(fy, -big), big));
     const int cz = (int) floorf(fminf(fmaxf(fz, -big), big));
     // centre row first: it almost always holds the neighbour and arms the pruning
     if (cy >= ya && cy <= yb && cz >= za && cz <= zb) {
         const size_t base = ((size_t) cz * g.ny + cy) * g.nx;
-        best = scan_run(g.pts, g.cell_start[base + xa], g.cell_start[base + xb + 1], qx, qy, qz,
+        best = scan_run(g.pts, ldc(g.cell_start, base + xa), ldc(g.cell_start, base + xb + 1), qx, qy, qz,
                         best, bpos);
     }
 #pragma unroll 1
@@ -122,7 +183,7 @@ __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float q
             const float lb = (sqrtf(ry * ry + rz * rz) - g.slack) * g.h;
             if (lb > 0.f && lb * lb > __uint_as_float((unsigned) (best >> 32))) continue;
             const size_t base = ((size_t) zz * g.ny + yy) * g.nx;
-            best = scan_run(g.pts, g.cell_start[base + xa], g.cell_start[base + xb + 1], qx, qy,
+            best = scan_run(g.pts, ldc(g.cell_start, base + xa), ldc(g.cell_start, base + xb + 1), qx, qy,
                             qz, best, bpos);
         }
     }
@@ -189,8 +250,8 @@ __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, fl
             const float lb = (sqrtf(ry * ry + rz * rz) - g.slack) * g.h;
             if (!(lb > 0.f && lb * lb > bd2)) {
                 const size_t base = ((size_t) zz * g.ny + yy) * g.nx;
-                s = g.cell_start[base + xa];
-                e = g.cell_start[base + xb + 1];
+                s = ldc(g.cell_start, base + xa);
+                e = ldc(g.cell_start, base + xb + 1);
             }
         }
         unsigned long long rows = __ballot(e > s);
@@ -199,9 +260,9 @@ __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, fl
             rows &= rows - 1;
             const unsigned rs = rl_u(s, rl), re = rl_u(e, rl);
             for (unsigned j = rs + lane; j < re; j += 128u) {
-                const float4 t0 = g.pts[j];
+                const float4 t0 = ldp(g.pts, j);
                 const unsigned j1 = j + 64u < re ? j + 64u : j;
-                const float4 t1 = g.pts[j1];
+                const float4 t1 = ldp(g.pts, j1);
                 const unsigned long long a = make_key(canon_d2(qx, qy, qz, t0), __float_as_uint(t0.w));
                 const unsigned long long b = make_key(canon_d2(qx, qy, qz, t1), __float_as_uint(t1.w));
                 const unsigned long long m = a < b ? a : b;
@@ -217,7 +278,7 @@ __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, fl
         const unsigned long long who = __ballot(mine == res);
         const int wl = __ffsll((long long) who) - 1;
         float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((int) lane == wl) c = g.pts[mpos];
+        if ((int) lane == wl) c = ldp(g.pts, mpos);
         win->x = rl_f(c.x, wl);
         win->y = rl_f(c.y, wl);
         win->z = rl_f(c.z, wl);
@@ -237,12 +298,13 @@ __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, fl
 // run in the query's own lane.  Heavy scans are handed to the whole wavefront, one
 // query at a time (coop_scan_box), seeded with the radius its Morton neighbour needed.
 // The radius and level choices change the work, never the result.
-__global__ void __launch_bounds__(kBlock)
+constexpr int kNnBlock = 64;  // one wave per block: finest dispatch granularity, smallest tail
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5)))
     k_nn_grid(const LevelsDev *__restrict__ lv, const float4 *__restrict__ src, unsigned n,
               IcpDevState *__restrict__ st, float thr_d2, unsigned long long *__restrict__ keys,
-              float4 *__restrict__ match_pt, float r_light_cells) {
+              float4 *__restrict__ match_pt, float r_light_cells, float coop_lf) {
     if (st->done) return;
-    const unsigned i = xcd_remap(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+    const unsigned i = xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
     const bool active = i < n;
     const int L = lv->n;
@@ -299,7 +361,7 @@ __global__ void __launch_bounds__(kBlock)
             const unsigned long long before = best;
             best = scan_box(g, qx, qy, qz, r, best, bpos, &margin);
             if (best != before) {
-                const float4 c = g.pts[bpos];
+                const float4 c = ldp(g.pts, bpos);
                 bqx = c.x;
                 bqy = c.y;
                 bqz = c.z;
@@ -328,7 +390,7 @@ __global__ void __launch_bounds__(kBlock)
         if ((unsigned) ub == kNoIdx && seed > ur) ur = fminf(seed, rmax);  // neighbour's radius
         for (int pass = 0; pass < 64; ++pass) {
             int l = 0;
-            while (l < L - 1 && lv->g[l].h < ur) ++l;
+            while (l < L - 1 && lv->g[l].h < coop_lf * ur) ++l;
             const GridDev g = lv->g[l];
             float margin;
             ub = coop_scan_box(g, ux, uy, uz, ur, ub, lane, &margin, &uwin);
@@ -431,12 +493,13 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
     if (n == 0) return WM_OK;
     IcpDevState *st = ctx->d_state.as<IcpDevState>();
     unsigned long long *keys = ctx->keys.as<unsigned long long>();
-    unsigned blocks = (n + kBlock - 1) / kBlock;
+    const unsigned nb = ctx->tune_nn_block > 0 ? (unsigned) ctx->tune_nn_block : (unsigned) kNnBlock;
+    unsigned blocks = (n + nb - 1) / nb;
     blocks = (blocks + 7u) & ~7u;  // xcd_remap needs a multiple of 8
     if (ev0) WM_HIP(ctx, hipEventRecord(ev0, ctx->stream));
-    hipLaunchKernelGGL(k_nn_grid, dim3(blocks), dim3(kBlock), 0, ctx->stream,
+    hipLaunchKernelGGL(k_nn_grid, dim3(blocks), dim3(nb), 0, ctx->stream,
                        ctx->d_levels.as<LevelsDev>(), ctx->src_sorted.as<float4>(), n, st, thr_d2,
-                       keys, ctx->match_pt.as<float4>(), ctx->tune_r_light);
+                       keys, ctx->match_pt.as<float4>(), ctx->tune_r_light, ctx->tune_coop_lf);
     if (ev1) WM_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     if (ev2) WM_HIP(ctx, hipEventRecord(ev2, ctx->stream));
     WM_HIP(ctx, hipGetLastError());
