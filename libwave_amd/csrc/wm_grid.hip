@@ -6,6 +6,10 @@
 // Target levels are sorted x-fastest so that x-adjacent cells are contiguous in
 // memory; the source cloud is counting-sorted by a Morton cell code so that a
 // wavefront's 64 consecutive queries stay spatially compact under any rigid T.
+#include <cstring>  // before rocprim (its headers use memcpy unqualified)
+
+#include <rocprim/rocprim.hpp>
+
 #include "wm_internal.hpp"
 
 #include <math.h>
@@ -44,32 +48,31 @@ int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, f
 }
 
 // ------------------------------------------------------------------ bbox
-__device__ inline unsigned f2ord(float f) {  // order-preserving float -> uint
-    unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-inline float ord2f(unsigned u) {
-    unsigned v = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
-    float f;
-    memcpy(&f, &v, 4);
-    return f;
-}
-
-// out[0..2] = min (ordered uint), out[3..5] = max, out[6] = valid count
-__global__ void __launch_bounds__(kBlock) k_bbox(const float4 *pts, size_t n, unsigned *out) {
+// One partial per workgroup: out[8 b + 0..2] = min, [3..5] = max (as floats), [6] = valid count.
+// The host reduces the partials (it waits for the result anyway); no same-address atomics.
+constexpr int kBboxBlocks = 512;
+__global__ void __launch_bounds__(kBlock) k_bbox(const float4 *pts, size_t n, float *out) {
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     unsigned cnt = 0;
-    for (size_t i = (size_t) blockIdx.x * kBlock + threadIdx.x; i < n;
-         i += (size_t) gridDim.x * kBlock) {
-        float4 p = pts[i];
-        if (p.x == p.x) {  // not NaN
-            lo[0] = fminf(lo[0], p.x);
-            lo[1] = fminf(lo[1], p.y);
-            lo[2] = fminf(lo[2], p.z);
-            hi[0] = fmaxf(hi[0], p.x);
-            hi[1] = fmaxf(hi[1], p.y);
-            hi[2] = fmaxf(hi[2], p.z);
-            ++cnt;
+    const size_t stride = (size_t) gridDim.x * kBlock;
+    for (size_t i0 = (size_t) blockIdx.x * kBlock + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // four loads in flight
+            const size_t i = i0 + u * stride;
+            p[u] = i < n ? pts[i] : make_float4(NAN, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (p[u].x == p[u].x) {  // not NaN
+                lo[0] = fminf(lo[0], p[u].x);
+                lo[1] = fminf(lo[1], p[u].y);
+                lo[2] = fminf(lo[2], p[u].z);
+                hi[0] = fmaxf(hi[0], p[u].x);
+                hi[1] = fmaxf(hi[1], p[u].y);
+                hi[2] = fmaxf(hi[2], p[u].z);
+                ++cnt;
+            }
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -79,7 +82,6 @@ __global__ void __launch_bounds__(kBlock) k_bbox(const float4 *pts, size_t n, un
         }
         cnt += __shfl_down(cnt, off);
     }
-    // one set of atomics per workgroup (contended same-address atomics are ~11 ns each)
     __shared__ float s_lo[kBlock / 64][3], s_hi[kBlock / 64][3];
     __shared__ unsigned s_cnt[kBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -99,37 +101,47 @@ __global__ void __launch_bounds__(kBlock) k_bbox(const float4 *pts, size_t n, un
             }
             cnt += s_cnt[w];
         }
+        float *o = out + 8 * (size_t) blockIdx.x;
         for (int d = 0; d < 3; ++d) {
-            atomicMin(&out[d], f2ord(lo[d]));
-            atomicMax(&out[3 + d], f2ord(hi[d]));
+            o[d] = lo[d];
+            o[3 + d] = hi[d];
         }
-        atomicAdd(&out[6], cnt);
+        o[6] = __uint_as_float(cnt);
     }
 }
 
 int compute_bbox(wm_ctx *ctx, const float4 *pts, size_t n, Bbox *out, size_t *n_valid) {
-    unsigned init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0, 0};
-    WM_HIP(ctx, ctx->bbox_buf.reserve(sizeof(init)));
-    WM_HIP(ctx, hipMemcpyAsync(ctx->bbox_buf.p, init, sizeof(init), hipMemcpyHostToDevice,
-                               ctx->stream));
-    if (n > 0) {
-        unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
-        if (blocks > 512) blocks = 512;
-        hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, n,
-                           ctx->bbox_buf.as<unsigned>());
-        WM_HIP(ctx, hipGetLastError());
-    }
-    unsigned res[8];
-    WM_HIP(ctx, hipMemcpyAsync(res, ctx->bbox_buf.p, sizeof(res), hipMemcpyDeviceToHost,
-                               ctx->stream));
+    for (int d = 0; d < 3; ++d) out->lo[d] = out->hi[d] = 0.f;
+    *n_valid = 0;
+    if (n == 0) return WM_OK;
+    unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
+    if (blocks > (unsigned) kBboxBlocks) blocks = kBboxBlocks;
+    WM_HIP(ctx, ctx->bbox_buf.reserve(8 * sizeof(float) * kBboxBlocks));
+    hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, n,
+                       ctx->bbox_buf.as<float>());
+    WM_HIP(ctx, hipGetLastError());
+    static thread_local float res[8 * kBboxBlocks];
+    WM_HIP(ctx, hipMemcpyAsync(res, ctx->bbox_buf.p, 8 * sizeof(float) * blocks,
+                               hipMemcpyDeviceToHost, ctx->stream));
     WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int d = 0; d < 3; ++d) {
-        out->lo[d] = ord2f(res[d]);
-        out->hi[d] = ord2f(res[3 + d]);
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    size_t cnt = 0;
+    for (unsigned b = 0; b < blocks; ++b) {
+        const float *o = res + 8 * b;
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = fminf(lo[d], o[d]);
+            hi[d] = fmaxf(hi[d], o[3 + d]);
+        }
+        unsigned c;
+        memcpy(&c, &o[6], 4);
+        cnt += c;
     }
-    *n_valid = res[6];
-    if (res[6] == 0)
-        for (int d = 0; d < 3; ++d) out->lo[d] = out->hi[d] = 0.f;
+    *n_valid = cnt;
+    if (cnt > 0)
+        for (int d = 0; d < 3; ++d) {
+            out->lo[d] = lo[d];
+            out->hi[d] = hi[d];
+        }
     return WM_OK;
 }
 
@@ -193,26 +205,6 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const float4 *pts, size_t n,
     if (c == kNoIdx) return;
     unsigned pos = cell_start[c] + atomicAdd(&fill[c], 1u);
     out[pos] = pts[i];
-}
-
-// Within a cell the scatter order depends on atomic arrival; restore ascending
-// original index so that every downstream sum runs in a reproducible order.
-__global__ void __launch_bounds__(kBlock) k_sort_cells(const unsigned *cell_start, size_t ncells,
-                                                        float4 *pts) {
-    size_t c = (size_t) blockIdx.x * kBlock + threadIdx.x;
-    if (c >= ncells) return;
-    unsigned s = cell_start[c], e = cell_start[c + 1];
-    if (e - s < 2 || e - s > 128) return;  // huge cells: keep arrival order (rounding only)
-    for (unsigned i = s + 1; i < e; ++i) {  // insertion sort; cells hold a handful of points
-        float4 v = pts[i];
-        unsigned vi = __float_as_uint(v.w);
-        unsigned j = i;
-        while (j > s && __float_as_uint(pts[j - 1].w) > vi) {
-            pts[j] = pts[j - 1];
-            --j;
-        }
-        pts[j] = v;
-    }
 }
 
 // ------------------------------------------------------- exclusive scan
@@ -311,7 +303,7 @@ int exclusive_scan(wm_ctx *ctx, const unsigned *in, size_t n, unsigned *out) {
 
 template <class KeyFn>
 static int counting_sort(wm_ctx *ctx, const float4 *pts, size_t n, KeyFn key, size_t ncells,
-                         unsigned *cell_start /* ncells+1 */, float4 *out, bool sort_cells) {
+                         unsigned *cell_start /* ncells+1 */, float4 *out) {
     WM_HIP(ctx, ctx->cell_of.reserve(n * sizeof(unsigned)));
     WM_HIP(ctx, ctx->counts.reserve(ncells * sizeof(unsigned)));
     unsigned *counts = ctx->counts.as<unsigned>();
@@ -326,16 +318,12 @@ static int counting_sort(wm_ctx *ctx, const float4 *pts, size_t n, KeyFn key, si
     hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, n, cell_of,
                        cell_start, counts, out);
     WM_HIP(ctx, hipGetLastError());
-    if (sort_cells) {
-        unsigned cblocks = (unsigned) ((ncells + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(k_sort_cells, dim3(cblocks), dim3(kBlock), 0, ctx->stream, cell_start,
-                           ncells, out);
-        WM_HIP(ctx, hipGetLastError());
-    }
     return WM_OK;
 }
 
-// occupied-cell count (for choosing the level-0 cell size)
+// occupied-cell count (for choosing the level-0 cell size): one partial per workgroup,
+// summed by the host
+constexpr int kOccBlocks = 1024;
 __global__ void __launch_bounds__(kBlock) k_count_occupied(const unsigned *cell_start,
                                                             size_t ncells, unsigned *out) {
     unsigned c = 0;
@@ -343,7 +331,13 @@ __global__ void __launch_bounds__(kBlock) k_count_occupied(const unsigned *cell_
          i += (size_t) gridDim.x * kBlock)
         c += (cell_start[i + 1] != cell_start[i]);
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+    __shared__ unsigned s_c[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) c += s_c[w];
+        out[blockIdx.x] = c;
+    }
 }
 
 static void grid_dims(const Bbox &bb, float h, int *nx, int *ny, int *nz) {
@@ -363,7 +357,7 @@ int build_grid_level(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, f
     LinearKey key{bb.lo[0], bb.lo[1], bb.lo[2], 1.0f / h, nx, ny, nz};
     if (n > 0) {
         WM_TRY(counting_sort(ctx, pts, n, key, ncells, lvl->cell_start.as<unsigned>(),
-                             lvl->pts.as<float4>(), false));
+                             lvl->pts.as<float4>()));
     } else {
         WM_HIP(ctx, hipMemsetAsync(lvl->cell_start.p, 0, (ncells + 1) * sizeof(unsigned),
                                    ctx->stream));
@@ -387,43 +381,73 @@ int build_grid_level(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, f
     lvl->d.cell_start = lvl->cell_start.as<unsigned>();
     lvl->built = true;
     if (avg_occupancy) {
-        unsigned zero = 0, occ = 0;
-        unsigned *d_occ = ctx->bbox_buf.as<unsigned>() + 7;
-        WM_HIP(ctx, hipMemcpyAsync(d_occ, &zero, 4, hipMemcpyHostToDevice, ctx->stream));
         unsigned blocks = (unsigned) ((ncells + kBlock - 1) / kBlock);
-        if (blocks > 4096) blocks = 4096;
+        if (blocks > (unsigned) kOccBlocks) blocks = kOccBlocks;
+        WM_HIP(ctx, ctx->bbox_buf.reserve(sizeof(unsigned) * kOccBlocks));
+        unsigned *d_occ = ctx->bbox_buf.as<unsigned>();
         hipLaunchKernelGGL(k_count_occupied, dim3(blocks), dim3(kBlock), 0, ctx->stream,
                            lvl->cell_start.as<unsigned>(), (size_t) ncells, d_occ);
-        WM_HIP(ctx, hipMemcpyAsync(&occ, d_occ, 4, hipMemcpyDeviceToHost, ctx->stream));
+        static thread_local unsigned part[kOccBlocks];
+        WM_HIP(ctx, hipMemcpyAsync(part, d_occ, sizeof(unsigned) * blocks, hipMemcpyDeviceToHost,
+                                   ctx->stream));
         WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        uint64_t occ = 0;
+        for (unsigned b = 0; b < blocks; ++b) occ += part[b];
         *avg_occupancy = occ ? (double) n / occ : 0.0;
     }
     return WM_OK;
 }
 
-int morton_sort(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, float4 *out,
-                size_t *n_valid) {
-    if (n == 0) {
-        *n_valid = 0;
-        return WM_OK;
-    }
+// Source ordering: stable radix sort of (Morton cell code, original index) pairs, then a
+// gather.  Stable => points of one Morton cell keep ascending original index, so every
+// downstream sum over the source runs in a reproducible order.  Non-finite points get the
+// key past the last cell and fall off the end (n_valid comes from the bbox pass).
+__global__ void __launch_bounds__(kBlock) k_morton_keys(const float4 *pts, unsigned n, MortonKey key,
+                                                         unsigned invalid, unsigned *keys,
+                                                         unsigned *vals) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    keys[i] = p.x == p.x ? key(p) : invalid;
+    vals[i] = i;
+}
+
+__global__ void __launch_bounds__(kBlock) k_gather(const float4 *pts, const unsigned *vals,
+                                                    unsigned n, float4 *out) {
+    const unsigned j = blockIdx.x * kBlock + threadIdx.x;
+    if (j < n) out[j] = pts[vals[j]];
+}
+
+int morton_sort(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, size_t n_valid,
+                float4 *out) {
+    if (n == 0 || n_valid == 0) return WM_OK;
     int bits = (int) ceil(log2(cbrt((double) n)));
     if (bits < 3) bits = 3;
     if (bits > 8) bits = 8;
-    int cells = 1 << bits;
-    size_t ncells = (size_t) 1 << (3 * bits);
+    const int cells = 1 << bits;
     float ext[3];
     for (int d = 0; d < 3; ++d) ext[d] = fmaxf(bb.hi[d] - bb.lo[d], 1e-6f);
     MortonKey key{bb.lo[0], bb.lo[1], bb.lo[2], cells / ext[0], cells / ext[1], cells / ext[2],
                   cells};
-    DevBuf &cs = ctx->corr_tmp_idx;  // scratch for the transient cell_start
-    WM_HIP(ctx, cs.reserve((ncells + 1) * sizeof(unsigned)));
-    WM_TRY(counting_sort(ctx, pts, n, key, ncells, cs.as<unsigned>(), out, true));
-    unsigned total = 0;
-    WM_HIP(ctx, hipMemcpyAsync(&total, cs.as<unsigned>() + ncells, 4, hipMemcpyDeviceToHost,
-                               ctx->stream));
-    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *n_valid = total;
+    WM_HIP(ctx, ctx->vg_idx.reserve(n * 4));
+    WM_HIP(ctx, ctx->vg_idx2.reserve(n * 4));
+    WM_HIP(ctx, ctx->vg_perm.reserve(n * 4));
+    WM_HIP(ctx, ctx->vg_perm2.reserve(n * 4));
+    unsigned *k1 = ctx->vg_idx.as<unsigned>(), *k2 = ctx->vg_idx2.as<unsigned>();
+    unsigned *v1 = ctx->vg_perm.as<unsigned>(), *v2 = ctx->vg_perm2.as<unsigned>();
+    const unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_morton_keys, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, (unsigned) n,
+                       key, 1u << (3 * bits), k1, v1);
+    size_t tmp_bytes = 0;
+    WM_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, k1, k2, v1, v2, n, 0, 3 * bits + 1,
+                                          ctx->stream));
+    WM_HIP(ctx, ctx->vg_tmp.reserve(tmp_bytes));
+    WM_HIP(ctx, rocprim::radix_sort_pairs(ctx->vg_tmp.p, tmp_bytes, k1, k2, v1, v2, n, 0,
+                                          3 * bits + 1, ctx->stream));
+    const unsigned gblocks = (unsigned) ((n_valid + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_gather, dim3(gblocks), dim3(kBlock), 0, ctx->stream, pts, v2,
+                       (unsigned) n_valid, out);
+    WM_HIP(ctx, hipGetLastError());
     return WM_OK;
 }
 

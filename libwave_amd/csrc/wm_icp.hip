@@ -518,9 +518,8 @@ int wm_set_source(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem
     Bbox &bb = ctx->src_bbox;
     size_t valid = 0;
     WM_TRY(compute_bbox(ctx, tmp.as<float4>(), n, &bb, &valid));
-    size_t sorted = 0;
-    WM_TRY(morton_sort(ctx, tmp.as<float4>(), n, bb, ctx->src_sorted.as<float4>(), &sorted));
-    ctx->n_src = sorted;
+    WM_TRY(morton_sort(ctx, tmp.as<float4>(), n, bb, valid, ctx->src_sorted.as<float4>()));
+    ctx->n_src = valid;
     return WM_OK;
 }
 

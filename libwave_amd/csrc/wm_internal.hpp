@@ -134,7 +134,7 @@ struct wm_ctx {
     double levels_max_corr = -1;
     float grid_cell_override = 0;
     int tune_nn_block = 0;       // 0 = default block size of the correspondence kernel
-    float tune_coop_lf = 1.0f;   // cooperative scan: finest level with cell size >= this x radius
+    float tune_coop_lf = 0.5f;   // cooperative scan: finest level with cell size >= this x radius
     float tune_r_light = 3.0f;   // lane-serial vs cooperative scan threshold, in level-0 cells
     double tuned_h = 0, tuned_vol = 0;  // last auto-tuned level-0 cell size and its cloud
     size_t tuned_n = 0;
@@ -186,8 +186,8 @@ int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, f
 int compute_bbox(wm_ctx *ctx, const float4 *pts, size_t n, Bbox *out, size_t *n_valid);
 int build_grid_level(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, float h,
                      GridLevel *lvl, double *avg_occupancy);
-int morton_sort(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, float4 *out,
-                size_t *n_valid);
+int morton_sort(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, size_t n_valid,
+                float4 *out);
 int ensure_levels(wm_ctx *ctx, double max_corr);
 int exclusive_scan(wm_ctx *ctx, const unsigned *in, size_t n, unsigned *out);
 

@@ -237,6 +237,7 @@ __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, fl
     const int wy = yb - ya + 1;
     const int nrows = wy * (zb - za + 1);
     const float bd2 = __uint_as_float((unsigned) (best >> 32));
+    const float Rb = __builtin_amdgcn_sqrtf(bd2) * g.inv_h * 1.00001f;  // best distance, in cells
     unsigned long long mine = best;
     unsigned mpos = 0;
     for (int k0 = 0; k0 < nrows; k0 += 64) {
@@ -247,11 +248,22 @@ __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, fl
             const int yy = ya + k % wy, zz = za + k / wy;
             const float ry = yy > cy ? (float) yy - fy : (yy < cy ? fy - (float) (yy + 1) : 0.f);
             const float rz = zz > cz ? (float) zz - fz : (zz < cz ? fz - (float) (zz + 1) : 0.f);
-            const float lb = (sqrtf(ry * ry + rz * rz) - g.slack) * g.h;
-            if (!(lb > 0.f && lb * lb > bd2)) {
-                const size_t base = ((size_t) zz * g.ny + yy) * g.nx;
-                s = ldc(g.cell_start, base + xa);
-                e = ldc(g.cell_start, base + xb + 1);
+            // Only the part of the row inside ball(q, sqrt(best)) can hold a closer point: with
+            // rho the (y,z) distance of the row, a point of the row closer than Rb has
+            // |x - qx| <= sqrt(Rb^2 - (rho - slack)^2) <= sqrt(Rb^2 - rho^2 + 2 slack (Rb + slack))
+            // (cell units; Rb inflated by 1e-5 against the approximate square roots).
+            const float rho2 = ry * ry + rz * rz;
+            const float lim = Rb + g.slack;
+            if (!(rho2 > lim * lim)) {
+                const float hx2 = fmaxf(Rb * Rb - rho2 + 2.f * g.slack * lim, 0.f);
+                const float hx = __builtin_amdgcn_sqrtf(hx2) * 1.00001f + g.slack;
+                const int xl = max(xa, (int) floorf(fminf(fmaxf(fx - hx, -big), big)));
+                const int xh = min(xb, (int) floorf(fminf(fmaxf(fx + hx, -big), big)));
+                if (xl <= xh) {
+                    const size_t base = ((size_t) zz * g.ny + yy) * g.nx;
+                    s = ldc(g.cell_start, base + xl);
+                    e = ldc(g.cell_start, base + xh + 1);
+                }
             }
         }
         unsigned long long rows = __ballot(e > s);
