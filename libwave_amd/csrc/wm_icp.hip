@@ -438,6 +438,10 @@ int wm_ctx_create(wm_ctx **out, int device) {
         return WM_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    if (const char *e = getenv("WM_TUNE_LANE_LF")) {
+        const float v = (float) atof(e);
+        if (v > 0) ctx->tune_lane_lf = v;
+    }
     if (const char *e = getenv("WM_TUNE_NN_BLOCK")) ctx->tune_nn_block = atoi(e);
     if (const char *e = getenv("WM_TUNE_COOP_LF")) {
         const float v = (float) atof(e);

@@ -91,69 +91,31 @@ __device__ __forceinline__ unsigned long long scan_run(const float4 *__restrict_
     return best;
 }
 
-// The common case of scan_box -- the box spans at most 3 x 3 (y, z) rows, which is what the
-// level choice (cell size >= r) guarantees: all (up to 18) cell_start loads are issued up
-// front as independent loads (one memory round trip instead of one per row), then the rows
-// are scanned in raster order, pruned by their AABB distance against the running best (the
-// previous iteration's match usually makes that bound tight before the first row).
-__device__ __forceinline__ unsigned long long scan_rows9(const GridDev &g, float qx, float qy,
-                                                         float qz, float fy, float fz, int xa,
-                                                         int xb, int ya, int yb, int za, int zb,
-                                                         unsigned long long best, unsigned &bpos) {
-    const int cy = (int) floorf(fy), cz = (int) floorf(fz);
-    // A row whose (y,z) distance to the query exceeds the best distance so far cannot hold
-    // the neighbour.  Compared in cell units against rb = sqrt(best) / h + slack, inflated by
-    // 1e-5 so that the (approximate) hardware square root can only make the test more
-    // conservative: pruning changes the work, never the result.
-    unsigned rs[9], re[9];
-    {
-        const float rb =
-            (__builtin_amdgcn_sqrtf(__uint_as_float((unsigned) (best >> 32))) * g.inv_h + g.slack) *
-            1.00001f;
-        const float rb2 = rb * rb;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int yy = ya + k % 3, zz = za + k / 3;
-            const float ry = yy > cy ? (float) yy - fy : (yy < cy ? fy - (float) (yy + 1) : 0.f);
-            const float rz = zz > cz ? (float) zz - fz : (zz < cz ? fz - (float) (zz + 1) : 0.f);
-            const bool ok = yy <= yb && zz <= zb && !(ry * ry + rz * rz > rb2);
-            const unsigned base = ok ? ((unsigned) zz * g.ny + yy) * g.nx : 0u;
-            rs[k] = ok ? ldc(g.cell_start, base + xa) : 0u;
-            re[k] = ok ? ldc(g.cell_start, base + xb + 1) : 0u;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        if (re[k] <= rs[k]) continue;
-        const int yy = ya + k % 3, zz = za + k / 3;
-        const float ry = yy > cy ? (float) yy - fy : (yy < cy ? fy - (float) (yy + 1) : 0.f);
-        const float rz = zz > cz ? (float) zz - fz : (zz < cz ? fz - (float) (zz + 1) : 0.f);
-        const float rb =
-            (__builtin_amdgcn_sqrtf(__uint_as_float((unsigned) (best >> 32))) * g.inv_h + g.slack) *
-            1.00001f;
-        if (ry * ry + rz * rz > rb * rb) continue;
-        best = scan_run(g.pts, rs[k], re[k], qx, qy, qz, best, bpos);
-    }
-    return best;
-}
-
-// Scan every target point in the box of cells covering [q - r, q + r]^3 on level g
-// (one contiguous run per (y,z) row of the box, centre row first, rows pruned by
-// their AABB distance to the query) and report the distance `margin` from the query
-// to the faces of that box: every point NOT scanned is farther than `margin`.
+// Scan the target points that can lie inside ball(q, min(r, sqrt(best))) on level g and report
+// the distance `margin` from the query to the faces of the box of cells covering
+// [q - r, q + r]^3: every point NOT scanned is either farther than `margin` or farther than
+// the best distance at the time it was skipped.
+//   * the box is walked row by row ((y,z) rows; cells are x-fastest, so a row is one
+//     contiguous run of the cell-sorted array), kRowChunk rows at a time: the chunk's
+//     cell_start look-ups are issued together (one memory round trip per chunk, not per row);
+//   * a row is cut down to the chord of ball(q, sqrt(best)) -- with rho the (y,z) distance of
+//     the row, a point of the row closer than Rb has
+//         |x - qx| <= sqrt(Rb^2 - (rho - slack)^2) <= sqrt(Rb^2 - rho^2 + 2 slack (Rb + slack))
+//     (cell units; Rb inflated by 1e-5 against the approximate hardware square roots): rows
+//     outside the ball cost nothing, rows near its rim a cell or two.
+// Pruning changes the work, never the result.
+constexpr int kRowChunk = 4;
 __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float qx, float qy,
                                                        float qz, float r, unsigned long long best,
                                                        unsigned &bpos, float *margin) {
-    const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
+    const float big = 4.0e6f;  // clamp in float so far-away queries cannot overflow the int cast
+    const float fx = fminf(fmaxf((qx - g.ox) * g.inv_h, -big), big);
+    const float fy = fminf(fmaxf((qy - g.oy) * g.inv_h, -big), big);
+    const float fz = fminf(fmaxf((qz - g.oz) * g.inv_h, -big), big);
     const float rc = r * g.inv_h + g.slack;
-    // clamp in float first so far-away queries cannot overflow the int conversion
-    const float big = 4.0e6f;
-    const int x0 = (int) floorf(fminf(fmaxf(fx - rc, -big), big));
-    const int x1 = (int) floorf(fminf(fmaxf(fx + rc, -big), big));
-    const int y0 = (int) floorf(fminf(fmaxf(fy - rc, -big), big));
-    const int y1 = (int) floorf(fminf(fmaxf(fy + rc, -big), big));
-    const int z0 = (int) floorf(fminf(fmaxf(fz - rc, -big), big));
-    const int z1 = (int) floorf(fminf(fmaxf(fz + rc, -big), big));
+    const int x0 = (int) floorf(fx - rc), x1 = (int) floorf(fx + rc);
+    const int y0 = (int) floorf(fy - rc), y1 = (int) floorf(fy + rc);
+    const int z0 = (int) floorf(fz - rc), z1 = (int) floorf(fz + rc);
     const float mx = fminf(fx - (float) x0, (float) (x1 + 1) - fx);
     const float my = fminf(fy - (float) y0, (float) (y1 + 1) - fy);
     const float mz = fminf(fz - (float) z0, (float) (z1 + 1) - fz);
@@ -162,30 +124,32 @@ __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float q
     const int ya = max(y0, 0), yb = min(y1, g.ny - 1);
     const int za = max(z0, 0), zb = min(z1, g.nz - 1);
     if (xa > xb || ya > yb || za > zb) return best;
-    if (yb - ya < 3 && zb - za < 3)  // wave-divergent, but nearly always taken
-        return scan_rows9(g, qx, qy, qz, fminf(fmaxf(fy, -big), big), fminf(fmaxf(fz, -big), big), xa,
-                          xb, ya, yb, za, zb, best, bpos);
-    const int cy = (int) floorf(fminf(fmaxf(fy, -big), big));
-    const int cz = (int) floorf(fminf(fmaxf(fz, -big), big));
-    // centre row first: it almost always holds the neighbour and arms the pruning
-    if (cy >= ya && cy <= yb && cz >= za && cz <= zb) {
-        const size_t base = ((size_t) cz * g.ny + cy) * g.nx;
-        best = scan_run(g.pts, ldc(g.cell_start, base + xa), ldc(g.cell_start, base + xb + 1), qx, qy, qz,
-                        best, bpos);
-    }
-#pragma unroll 1
-    for (int zz = za; zz <= zb; ++zz) {
-        const float rz = zz > cz ? (float) zz - fz : (zz < cz ? fz - (float) (zz + 1) : 0.f);
-#pragma unroll 1
-        for (int yy = ya; yy <= yb; ++yy) {
-            if (yy == cy && zz == cz) continue;
+    const int cy = (int) floorf(fy), cz = (int) floorf(fz);
+    int yy = ya, zz = za;  // row cursor
+    while (zz <= zb) {
+        const float Rb =
+            __builtin_amdgcn_sqrtf(__uint_as_float((unsigned) (best >> 32))) * g.inv_h * 1.00001f;
+        const float lim = Rb + g.slack;
+        const float lim2 = lim * lim, c0 = Rb * Rb + 2.f * g.slack * lim;
+        unsigned rs[kRowChunk], re[kRowChunk];
+#pragma unroll
+        for (int u = 0; u < kRowChunk; ++u) {
             const float ry = yy > cy ? (float) yy - fy : (yy < cy ? fy - (float) (yy + 1) : 0.f);
-            const float lb = (sqrtf(ry * ry + rz * rz) - g.slack) * g.h;
-            if (lb > 0.f && lb * lb > __uint_as_float((unsigned) (best >> 32))) continue;
-            const size_t base = ((size_t) zz * g.ny + yy) * g.nx;
-            best = scan_run(g.pts, ldc(g.cell_start, base + xa), ldc(g.cell_start, base + xb + 1), qx, qy,
-                            qz, best, bpos);
+            const float rz = zz > cz ? (float) zz - fz : (zz < cz ? fz - (float) (zz + 1) : 0.f);
+            const float rho2 = ry * ry + rz * rz;
+            const float hx = __builtin_amdgcn_sqrtf(fmaxf(c0 - rho2, 0.f)) * 1.00001f + g.slack;
+            const int xl = max(xa, (int) floorf(fx - hx)), xh = min(xb, (int) floorf(fx + hx));
+            const bool ok = zz <= zb && !(rho2 > lim2) && xl <= xh;
+            const unsigned base = ok ? ((unsigned) zz * g.ny + yy) * g.nx : 0u;
+            rs[u] = ok ? ldc(g.cell_start, base + xl) : 0u;
+            re[u] = ok ? ldc(g.cell_start, base + xh + 1) : 0u;
+            const bool wrap = yy >= yb;
+            yy = wrap ? ya : yy + 1;
+            zz += wrap;
         }
+#pragma unroll
+        for (int u = 0; u < kRowChunk; ++u)
+            if (re[u] > rs[u]) best = scan_run(g.pts, rs[u], re[u], qx, qy, qz, best, bpos);
     }
     return best;
 }
@@ -314,7 +278,7 @@ constexpr int kNnBlock = 64;  // one wave per block: finest dispatch granularity
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5)))
     k_nn_grid(const LevelsDev *__restrict__ lv, const float4 *__restrict__ src, unsigned n,
               IcpDevState *__restrict__ st, float thr_d2, unsigned long long *__restrict__ keys,
-              float4 *__restrict__ match_pt, float r_light_cells, float coop_lf) {
+              float4 *__restrict__ match_pt, float r_light_cells, float lane_lf, float coop_lf) {
     if (st->done) return;
     const unsigned i = xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
@@ -366,7 +330,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 
         heavy = r > r_light;
         for (int pass = 0; !heavy && pass < 32; ++pass) {
             int l = 0;
-            while (l < L - 1 && lv->g[l].h < r) ++l;  // finest level whose cells cover r
+            while (l < L - 1 && lv->g[l].h < lane_lf * r) ++l;
             const GridDev g = lv->g[l];
             float margin;
             unsigned bpos = 0;
@@ -511,7 +475,7 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
     if (ev0) WM_HIP(ctx, hipEventRecord(ev0, ctx->stream));
     hipLaunchKernelGGL(k_nn_grid, dim3(blocks), dim3(nb), 0, ctx->stream,
                        ctx->d_levels.as<LevelsDev>(), ctx->src_sorted.as<float4>(), n, st, thr_d2,
-                       keys, ctx->match_pt.as<float4>(), ctx->tune_r_light, ctx->tune_coop_lf);
+                       keys, ctx->match_pt.as<float4>(), ctx->tune_r_light, ctx->tune_lane_lf, ctx->tune_coop_lf);
     if (ev1) WM_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     if (ev2) WM_HIP(ctx, hipEventRecord(ev2, ctx->stream));
     WM_HIP(ctx, hipGetLastError());
