@@ -340,6 +340,14 @@ __global__ void __launch_bounds__(kBlock) k_count_occupied(const unsigned *cell_
     }
 }
 
+// Four NaN entries after the last point of a level's cell-sorted array: the search reads
+// groups of four entries and may run past the end of the last run.
+__global__ void k_pad_tail(const unsigned *cell_start, size_t ncells, float4 *pts) {
+    const unsigned end = cell_start[ncells];
+    const float nanv = __builtin_nanf("");
+    if (threadIdx.x < 4) pts[end + threadIdx.x] = make_float4(nanv, nanv, nanv, __uint_as_float(kNoIdx));
+}
+
 static void grid_dims(const Bbox &bb, float h, int *nx, int *ny, int *nz) {
     *nx = (int) floor((bb.hi[0] - bb.lo[0]) / h) + 1;
     *ny = (int) floor((bb.hi[1] - bb.lo[1]) / h) + 1;
@@ -352,7 +360,7 @@ int build_grid_level(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, f
     grid_dims(bb, h, &nx, &ny, &nz);
     uint64_t ncells = (uint64_t) nx * ny * nz;
     lvl->ncells = ncells;
-    WM_HIP(ctx, lvl->pts.reserve((n > 0 ? n : 1) * sizeof(float4)));
+    WM_HIP(ctx, lvl->pts.reserve((n + 4) * sizeof(float4)));
     WM_HIP(ctx, lvl->cell_start.reserve((ncells + 1) * sizeof(unsigned)));
     LinearKey key{bb.lo[0], bb.lo[1], bb.lo[2], 1.0f / h, nx, ny, nz};
     if (n > 0) {
@@ -362,6 +370,8 @@ int build_grid_level(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, f
         WM_HIP(ctx, hipMemsetAsync(lvl->cell_start.p, 0, (ncells + 1) * sizeof(unsigned),
                                    ctx->stream));
     }
+    hipLaunchKernelGGL(k_pad_tail, dim3(1), dim3(64), 0, ctx->stream, lvl->cell_start.as<unsigned>(),
+                       (size_t) ncells, lvl->pts.as<float4>());
     // float cell assignment can be off by the rounding of (p - origin) * inv_h:
     // keep a cell-unit margin in every geometric bound that relies on it.
     float extent = fmaxf(fmaxf(bb.hi[0] - bb.lo[0], bb.hi[1] - bb.lo[1]), bb.hi[2] - bb.lo[2]);
@@ -509,7 +519,7 @@ static int derive_grid_level(wm_ctx *ctx, const GridLevel &fine, GridLevel *lvl,
     const int nx = (f.nx + 1) / 2, ny = (f.ny + 1) / 2, nz = (f.nz + 1) / 2;
     const uint64_t ncells = (uint64_t) nx * ny * nz;
     lvl->ncells = ncells;
-    WM_HIP(ctx, lvl->pts.reserve((n > 0 ? n : 1) * sizeof(float4)));
+    WM_HIP(ctx, lvl->pts.reserve((n + 4) * sizeof(float4)));
     WM_HIP(ctx, lvl->cell_start.reserve((ncells + 1) * sizeof(unsigned)));
     WM_HIP(ctx, ctx->counts.reserve(ncells * sizeof(unsigned)));
     unsigned *counts = ctx->counts.as<unsigned>();
@@ -527,6 +537,8 @@ static int derive_grid_level(wm_ctx *ctx, const GridLevel &fine, GridLevel *lvl,
                            ctx->stream, f.cell_start, f.pts, f.nx, f.ny, f.nz, nx, ny, (size_t) ncells,
                            lvl->cell_start.as<unsigned>(), lvl->pts.as<float4>());
     }
+    hipLaunchKernelGGL(k_pad_tail, dim3(1), dim3(64), 0, ctx->stream, lvl->cell_start.as<unsigned>(),
+                       (size_t) ncells, lvl->pts.as<float4>());
     WM_HIP(ctx, hipGetLastError());
     lvl->d = f;
     lvl->d.h = 2.0f * f.h;  // exact in float

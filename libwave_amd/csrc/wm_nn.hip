@@ -61,32 +61,29 @@ __device__ __forceinline__ float4 ldp(const float4 *p, size_t j) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ unsigned ldc(const unsigned *p, size_t j) { return ((gp_u32) p)[j]; }
+__device__ __forceinline__ float canon_d2v(float qx, float qy, float qz, const f4v &t) {
+    return canon_d2(qx, qy, qz, make_float4(t.x, t.y, t.z, t.w));
+}
 
 // ------------------------------------------------------------- grid search
-// scan the contiguous run [s, e) of cell-sorted target points, four loads in flight
-// (bpos follows the winner: its position in `pts`, so the caller can fetch its coordinates)
+// scan the contiguous run [s, e) of cell-sorted target points, four loads in flight.
+// The last group may read up to three entries past e: they are the next cells' points (real
+// target points -- a closer one among them is a legitimate find) or the NaN padding at the end
+// of the array (a NaN distance has the largest key and never wins), so no clamping is needed
+// and the four loads share one address.
 __device__ __forceinline__ unsigned long long scan_run(const float4 *__restrict__ pts, unsigned s,
                                                        unsigned e, float qx, float qy, float qz,
-                                                       unsigned long long best, unsigned &bpos) {
+                                                       unsigned long long best) {
     for (unsigned j = s; j < e; j += 4) {
-        // clamped re-reads of the last point are harmless: min() is idempotent
-        const unsigned last = e - 1;
-        const unsigned j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
-        const float4 t0 = ldp(pts, j);
-        const float4 t1 = ldp(pts, j1);
-        const float4 t2 = ldp(pts, j2);
-        const float4 t3 = ldp(pts, j3);
-        const unsigned long long k0 = make_key(canon_d2(qx, qy, qz, t0), __float_as_uint(t0.w));
-        const unsigned long long k1 = make_key(canon_d2(qx, qy, qz, t1), __float_as_uint(t1.w));
-        const unsigned long long k2 = make_key(canon_d2(qx, qy, qz, t2), __float_as_uint(t2.w));
-        const unsigned long long k3 = make_key(canon_d2(qx, qy, qz, t3), __float_as_uint(t3.w));
+        const gp_f4 p = (gp_f4) pts + j;
+        const f4v t0 = p[0], t1 = p[1], t2 = p[2], t3 = p[3];
+        const unsigned long long k0 = make_key(canon_d2v(qx, qy, qz, t0), __float_as_uint(t0.w));
+        const unsigned long long k1 = make_key(canon_d2v(qx, qy, qz, t1), __float_as_uint(t1.w));
+        const unsigned long long k2 = make_key(canon_d2v(qx, qy, qz, t2), __float_as_uint(t2.w));
+        const unsigned long long k3 = make_key(canon_d2v(qx, qy, qz, t3), __float_as_uint(t3.w));
         const unsigned long long a = k0 < k1 ? k0 : k1, b = k2 < k3 ? k2 : k3;
-        const unsigned pa = k0 < k1 ? j : j1, pb = k2 < k3 ? j2 : j3;
         const unsigned long long m = a < b ? a : b;
-        const unsigned pm = a < b ? pa : pb;
-        const bool up = m < best;
-        best = up ? m : best;
-        bpos = up ? pm : bpos;
+        best = m < best ? m : best;
     }
     return best;
 }
@@ -107,7 +104,7 @@ __device__ __forceinline__ unsigned long long scan_run(const float4 *__restrict_
 constexpr int kRowChunk = 4;
 __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float qx, float qy,
                                                        float qz, float r, unsigned long long best,
-                                                       unsigned &bpos, float *margin) {
+                                                       float *margin) {
     const float big = 4.0e6f;  // clamp in float so far-away queries cannot overflow the int cast
     const float fx = fminf(fmaxf((qx - g.ox) * g.inv_h, -big), big);
     const float fy = fminf(fmaxf((qy - g.oy) * g.inv_h, -big), big);
@@ -149,7 +146,7 @@ __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float q
         }
 #pragma unroll
         for (int u = 0; u < kRowChunk; ++u)
-            if (re[u] > rs[u]) best = scan_run(g.pts, rs[u], re[u], qx, qy, qz, best, bpos);
+            if (re[u] > rs[u]) best = scan_run(g.pts, rs[u], re[u], qx, qy, qz, best);
     }
     return best;
 }
@@ -178,7 +175,7 @@ __device__ __forceinline__ unsigned rl_u(unsigned v, int lane) {
 __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, float qx, float qy,
                                                             float qz, float r,
                                                             unsigned long long best, unsigned lane,
-                                                            float *margin, float4 *win) {
+                                                            float *margin) {
     const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
     const float rc = r * g.inv_h + g.slack;
     const float big = 4.0e6f;
@@ -203,7 +200,6 @@ __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, fl
     const float bd2 = __uint_as_float((unsigned) (best >> 32));
     const float Rb = __builtin_amdgcn_sqrtf(bd2) * g.inv_h * 1.00001f;  // best distance, in cells
     unsigned long long mine = best;
-    unsigned mpos = 0;
     for (int k0 = 0; k0 < nrows; k0 += 64) {
         // lanes resolve up to 64 rows at once
         const int k = k0 + (int) lane;
@@ -237,29 +233,15 @@ __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, fl
             const unsigned rs = rl_u(s, rl), re = rl_u(e, rl);
             for (unsigned j = rs + lane; j < re; j += 128u) {
                 const float4 t0 = ldp(g.pts, j);
-                const unsigned j1 = j + 64u < re ? j + 64u : j;
-                const float4 t1 = ldp(g.pts, j1);
+                const float4 t1 = ldp(g.pts, j + 64u < re ? j + 64u : j);
                 const unsigned long long a = make_key(canon_d2(qx, qy, qz, t0), __float_as_uint(t0.w));
                 const unsigned long long b = make_key(canon_d2(qx, qy, qz, t1), __float_as_uint(t1.w));
                 const unsigned long long m = a < b ? a : b;
-                const unsigned pm = a < b ? j : j1;
-                const bool up = m < mine;
-                mine = up ? m : mine;
-                mpos = up ? pm : mpos;
+                mine = m < mine ? m : mine;
             }
         }
     }
-    const unsigned long long res = wave_min_u64(mine);
-    if (res < best) {  // improved: fetch the winner's coordinates on its lane, broadcast them
-        const unsigned long long who = __ballot(mine == res);
-        const int wl = __ffsll((long long) who) - 1;
-        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((int) lane == wl) c = ldp(g.pts, mpos);
-        win->x = rl_f(c.x, wl);
-        win->y = rl_f(c.y, wl);
-        win->z = rl_f(c.z, wl);
-    }
-    return res;
+    return wave_min_u64(mine);
 }
 
 // One lane per query: a certified radius search over a ladder of uniform grids
@@ -278,7 +260,8 @@ constexpr int kNnBlock = 64;  // one wave per block: finest dispatch granularity
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5)))
     k_nn_grid(const LevelsDev *__restrict__ lv, const float4 *__restrict__ src, unsigned n,
               IcpDevState *__restrict__ st, float thr_d2, unsigned long long *__restrict__ keys,
-              float4 *__restrict__ match_pt, float r_light_cells, float lane_lf, float coop_lf) {
+              float4 *__restrict__ match_pt, const float4 *__restrict__ tgt_orig,
+              float r_light_cells, float lane_lf, float coop_lf) {
     if (st->done) return;
     const unsigned i = xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
@@ -288,8 +271,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 
     const float rmax = sqrtf(thr_d2) * 1.0001f + 1e-6f;
     const float r_light = r_light_cells * h0;  // larger radii go to the cooperative path
     float qx = 0.f, qy = 0.f, qz = 0.f, r = 0.f;
-    float bqx = 0.f, bqy = 0.f, bqz = 0.f;  // coordinates of the current best match
+    float bqx = 0.f, bqy = 0.f, bqz = 0.f;  // coordinates of the previous iteration's match
     unsigned long long best = make_key(thr_d2, kNoIdx);
+    unsigned long long seeded = best;  // the key the search started from
     bool heavy = false;
     bool mine = active;
     if (active) {
@@ -313,7 +297,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 
                     const float4 tp = match_pt[i];  // its coordinates, stored last iteration
                     const float d2b = canon_d2(qx, qy, qz, tp);
                     if (d2b <= thr_d2) {
-                        best = make_key(d2b, pidx);
+                        best = seeded = make_key(d2b, pidx);
                         bqx = tp.x;
                         bqy = tp.y;
                         bqz = tp.z;
@@ -333,15 +317,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 
             while (l < L - 1 && lv->g[l].h < lane_lf * r) ++l;
             const GridDev g = lv->g[l];
             float margin;
-            unsigned bpos = 0;
-            const unsigned long long before = best;
-            best = scan_box(g, qx, qy, qz, r, best, bpos, &margin);
-            if (best != before) {
-                const float4 c = ldp(g.pts, bpos);
-                bqx = c.x;
-                bqy = c.y;
-                bqz = c.z;
-            }
+            best = scan_box(g, qx, qy, qz, r, best, &margin);
             const float bd2 = __uint_as_float((unsigned) (best >> 32));
             if (margin > 0.f && (bd2 <= margin * margin || thr_d2 <= margin * margin)) break;
             // not certified: the radius must GROW (a query sitting on a cell face can have a
@@ -362,14 +338,13 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 
         float ur = rl_f(r, sl);
         unsigned long long ub = ((unsigned long long) rl_u((unsigned) (best >> 32), sl) << 32) |
                                 rl_u((unsigned) best, sl);
-        float4 uwin = make_float4(rl_f(bqx, sl), rl_f(bqy, sl), rl_f(bqz, sl), 0.f);
         if ((unsigned) ub == kNoIdx && seed > ur) ur = fminf(seed, rmax);  // neighbour's radius
         for (int pass = 0; pass < 64; ++pass) {
             int l = 0;
             while (l < L - 1 && lv->g[l].h < coop_lf * ur) ++l;
             const GridDev g = lv->g[l];
             float margin;
-            ub = coop_scan_box(g, ux, uy, uz, ur, ub, lane, &margin, &uwin);
+            ub = coop_scan_box(g, ux, uy, uz, ur, ub, lane, &margin);
             const float bd2 = __uint_as_float((unsigned) (ub >> 32));
             if (margin > 0.f && (bd2 <= margin * margin || thr_d2 <= margin * margin)) break;
             if (ur >= rmax) break;
@@ -377,15 +352,19 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 
             ur = fminf(fmaxf(rn, 1.25f * ur), rmax);
         }
         seed = ((unsigned) ub != kNoIdx) ? 1.25f * sqrtf(__uint_as_float((unsigned) (ub >> 32))) : ur;
-        if ((int) lane == sl) {
-            best = ub;
-            bqx = uwin.x;
-            bqy = uwin.y;
-            bqz = uwin.z;
-        }
+        if ((int) lane == sl) best = ub;
     }
     if (mine) {
         keys[i] = best;
+        // the match's coordinates ride along for the statistics kernel and for the next
+        // iteration's seed; a new winner's are read from the caller-ordered target copy
+        // (its key carries the original index)
+        if (best != seeded && (unsigned) best != kNoIdx) {
+            const f4v c = ((gp_f4) tgt_orig)[(unsigned) best];
+            bqx = c.x;
+            bqy = c.y;
+            bqz = c.z;
+        }
         match_pt[i] = make_float4(bqx, bqy, bqz, 0.f);
     }
     if (lane == 0 && n_heavy) atomicAdd(&st->queue_count[1], n_heavy);  // stats only
@@ -475,7 +454,7 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
     if (ev0) WM_HIP(ctx, hipEventRecord(ev0, ctx->stream));
     hipLaunchKernelGGL(k_nn_grid, dim3(blocks), dim3(nb), 0, ctx->stream,
                        ctx->d_levels.as<LevelsDev>(), ctx->src_sorted.as<float4>(), n, st, thr_d2,
-                       keys, ctx->match_pt.as<float4>(), ctx->tune_r_light, ctx->tune_lane_lf, ctx->tune_coop_lf);
+                       keys, ctx->match_pt.as<float4>(), ctx->tgt_orig.as<float4>(), ctx->tune_r_light, ctx->tune_lane_lf, ctx->tune_coop_lf);
     if (ev1) WM_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     if (ev2) WM_HIP(ctx, hipEventRecord(ev2, ctx->stream));
     WM_HIP(ctx, hipGetLastError());
