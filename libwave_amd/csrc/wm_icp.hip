@@ -49,52 +49,68 @@ __global__ void __launch_bounds__(kBlock)
     for (int k = 0; k < kAcc; ++k) a[k] = 0.0;
     const bool slab_on = st->slab_on != 0;
     const float slab_lo = st->slab_lo, slab_hi = st->slab_hi;
-    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const float4 p4 = src[i];
-        float fx, fy, fz;
-        xform_pt(st->Tf, p4, fx, fy, fz);
-        // sharded registration: the same ownership test as the search kernel
-        if (slab_on && !(fx >= slab_lo && fx < slab_hi)) continue;
-        a[17] += 1.0;
-        const unsigned long long key = keys[i];
-        const unsigned idx = (unsigned) key;
-        if (idx == kNoIdx) continue;
-        const float4 q4 = tgt[i];  // match coordinates, written by the search (coalesced)
-        const double px = fx, py = fy, pz = fz, qx = q4.x, qy = q4.y, qz = q4.z;
-        const double d2 = (double) __uint_as_float((unsigned) (key >> 32));
-        a[0] += 1.0;
-        a[1] += px;
-        a[2] += py;
-        a[3] += pz;
-        if (MODE == WM_ICP_SVD) {
-            a[4] += qx;
-            a[5] += qy;
-            a[6] += qz;
-            a[7] += qx * px;
-            a[8] += qx * py;
-            a[9] += qx * pz;
-            a[10] += qy * px;
-            a[11] += qy * py;
-            a[12] += qy * pz;
-            a[13] += qz * px;
-            a[14] += qz * py;
-            a[15] += qz * pz;
-        } else {
-            const double rx = px - qx, ry = py - qy, rz = pz - qz;
-            a[4] += py * py + pz * pz;  // (A^T A)(0,0)
-            a[5] += -px * py;           // (0,1)
-            a[6] += -px * pz;           // (0,2)
-            a[7] += px * px + pz * pz;  // (1,1)
-            a[8] += -py * pz;           // (1,2)
-            a[9] += px * px + py * py;  // (2,2)
-            a[10] += rx;
-            a[11] += ry;
-            a[12] += rz;
-            a[13] += py * rz - pz * ry;  // p x r
-            a[14] += pz * rx - px * rz;
-            a[15] += px * ry - py * rx;
+    // four points per trip: all twelve loads are issued before the first use, so a wave keeps
+    // ~10 KB in flight (the kernel is a pure HBM/L2 stream); accumulation order is unchanged
+    const unsigned stride = gridDim.x * kBlock;
+    for (unsigned i0 = blockIdx.x * kBlock + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        float4 p4v[4], q4v[4];
+        unsigned long long keyv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned i = i0 + u * stride;
+            const unsigned ic = i < n ? i : i0;
+            p4v[u] = src[ic];
+            keyv[u] = keys[ic];
+            q4v[u] = tgt[ic];  // match coordinates, written by the search (coalesced)
         }
-        a[16] += d2;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * stride >= n) break;
+            float fx, fy, fz;
+            xform_pt(st->Tf, p4v[u], fx, fy, fz);
+            // sharded registration: the same ownership test as the search kernel
+            if (slab_on && !(fx >= slab_lo && fx < slab_hi)) continue;
+            a[17] += 1.0;
+            const unsigned long long key = keyv[u];
+            const unsigned idx = (unsigned) key;
+            if (idx == kNoIdx) continue;
+            const float4 q4 = q4v[u];
+            const double px = fx, py = fy, pz = fz, qx = q4.x, qy = q4.y, qz = q4.z;
+            const double d2 = (double) __uint_as_float((unsigned) (key >> 32));
+            a[0] += 1.0;
+            a[1] += px;
+            a[2] += py;
+            a[3] += pz;
+            if (MODE == WM_ICP_SVD) {
+                a[4] += qx;
+                a[5] += qy;
+                a[6] += qz;
+                a[7] += qx * px;
+                a[8] += qx * py;
+                a[9] += qx * pz;
+                a[10] += qy * px;
+                a[11] += qy * py;
+                a[12] += qy * pz;
+                a[13] += qz * px;
+                a[14] += qz * py;
+                a[15] += qz * pz;
+            } else {
+                const double rx = px - qx, ry = py - qy, rz = pz - qz;
+                a[4] += py * py + pz * pz;  // (A^T A)(0,0)
+                a[5] += -px * py;           // (0,1)
+                a[6] += -px * pz;           // (0,2)
+                a[7] += px * px + pz * pz;  // (1,1)
+                a[8] += -py * pz;           // (1,2)
+                a[9] += px * px + py * py;  // (2,2)
+                a[10] += rx;
+                a[11] += ry;
+                a[12] += rz;
+                a[13] += py * rz - pz * ry;  // p x r
+                a[14] += pz * rx - px * rz;
+                a[15] += px * ry - py * rx;
+            }
+            a[16] += d2;
+    }
     }
     // wave reduction (fixed xor-tree order), then across the 4 waves through LDS
 #pragma unroll
