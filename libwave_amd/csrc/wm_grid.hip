@@ -492,29 +492,35 @@ __global__ void __launch_bounds__(kBlock)
     counts[c] = total;
 }
 
-// LANES = 1: one lane per coarse cell (many small cells); LANES = 64: one wave per cell
-template <int LANES>
+// One lane per POINT of the fine array: its level-0 cell (recomputed from its coordinates,
+// exactly as the level-0 sort did) shifted right gives its fine and coarse cells; its slot in
+// the coarse array is the coarse cell's start + the lengths of the child runs before its own
+// + its offset in its run.  Reads and writes are coalesced (a run moves as a block) and the
+// order inside a coarse cell is fixed: child runs in (y, z) order, fine order inside a run.
 __global__ void __launch_bounds__(kBlock)
-    k_coarse_copy(const unsigned *__restrict__ fs, const float4 *__restrict__ fpts, int fnx, int fny,
-                  int fnz, int cnx, int cny, size_t ncells, const unsigned *__restrict__ cs,
-                  float4 *__restrict__ out) {
-    const size_t t = (size_t) blockIdx.x * kBlock + threadIdx.x;
-    const size_t c = t / LANES;
-    const unsigned lane = (unsigned) (t % LANES);
-    if (c >= ncells) return;
-    unsigned dst = cs[c];
-    if (cs[c + 1] == dst) return;
-    const int X = (int) (c % cnx), Y = (int) ((c / cnx) % cny), Z = (int) (c / ((size_t) cnx * cny));
-#pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
+    k_coarse_move(const unsigned *__restrict__ fs, const float4 *__restrict__ fpts, size_t fncells,
+                  LinearKey key0, int shift, int fnx, int fny, int fnz, int cnx, int cny,
+                  const unsigned *__restrict__ cs, float4 *__restrict__ out) {
+    const unsigned j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= fs[fncells]) return;
+    const float4 p = fpts[j];
+    int x = min(max((int) floorf((p.x - key0.ox) * key0.inv_h), 0), key0.nx - 1) >> shift;
+    int y = min(max((int) floorf((p.y - key0.oy) * key0.inv_h), 0), key0.ny - 1) >> shift;
+    int z = min(max((int) floorf((p.z - key0.oz) * key0.inv_h), 0), key0.nz - 1) >> shift;
+    const int X = x >> 1, Y = y >> 1, Z = z >> 1, r = (y & 1) + 2 * (z & 1);
+    unsigned dst = cs[((size_t) Z * cny + Y) * cnx + X];
+    for (int q = 0; q < r; ++q) {
         unsigned s, e;
-        child_run(fs, fnx, fny, fnz, X, Y, Z, r, &s, &e);
-        for (unsigned j = s + lane; j < e; j += LANES) out[dst + (j - s)] = fpts[j];
+        child_run(fs, fnx, fny, fnz, X, Y, Z, q, &s, &e);
         dst += e - s;
     }
+    unsigned s, e;
+    child_run(fs, fnx, fny, fnz, X, Y, Z, r, &s, &e);
+    out[dst + (j - s)] = p;
 }
 
-static int derive_grid_level(wm_ctx *ctx, const GridLevel &fine, GridLevel *lvl, size_t n) {
+static int derive_grid_level(wm_ctx *ctx, const GridLevel &fine, int fine_index, GridLevel *lvl,
+                             size_t n) {
     const GridDev &f = fine.d;
     const int nx = (f.nx + 1) / 2, ny = (f.ny + 1) / 2, nz = (f.nz + 1) / 2;
     const uint64_t ncells = (uint64_t) nx * ny * nz;
@@ -527,14 +533,12 @@ static int derive_grid_level(wm_ctx *ctx, const GridLevel &fine, GridLevel *lvl,
     hipLaunchKernelGGL(k_coarse_count, dim3(blocks), dim3(kBlock), 0, ctx->stream, f.cell_start, f.nx,
                        f.ny, f.nz, nx, ny, (size_t) ncells, counts);
     WM_TRY(exclusive_scan(ctx, counts, ncells, lvl->cell_start.as<unsigned>()));
-    if ((double) n / (double) ncells < 8.0) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coarse_copy<1>), dim3(blocks), dim3(kBlock), 0, ctx->stream,
-                           f.cell_start, f.pts, f.nx, f.ny, f.nz, nx, ny, (size_t) ncells,
-                           lvl->cell_start.as<unsigned>(), lvl->pts.as<float4>());
-    } else {
-        const unsigned wblocks = (unsigned) ((ncells * 64 + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coarse_copy<64>), dim3(wblocks), dim3(kBlock), 0,
-                           ctx->stream, f.cell_start, f.pts, f.nx, f.ny, f.nz, nx, ny, (size_t) ncells,
+    {
+        const GridDev &g0 = ctx->levels[0].d;
+        const LinearKey key0{g0.ox, g0.oy, g0.oz, g0.inv_h, g0.nx, g0.ny, g0.nz};
+        const unsigned pblocks = (unsigned) ((n + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_coarse_move, dim3(pblocks), dim3(kBlock), 0, ctx->stream, f.cell_start,
+                           f.pts, (size_t) fine.ncells, key0, fine_index, f.nx, f.ny, f.nz, nx, ny,
                            lvl->cell_start.as<unsigned>(), lvl->pts.as<float4>());
     }
     hipLaunchKernelGGL(k_pad_tail, dim3(1), dim3(64), 0, ctx->stream, lvl->cell_start.as<unsigned>(),
@@ -619,11 +623,13 @@ int ensure_levels(wm_ctx *ctx, double max_corr) {
     const float4 *pts = ctx->tgt_orig.as<float4>();
     double h = ctx->levels[0].d.h;
     int L = 1;
-    // cell size x2 per level until a level's cells reach max_corr / 2: the search scans
-    // boxes of cells, so the last level need not cover max_corr in one ring
-    while (2.0 * h < max_corr && L < kMaxLevels) {
+    // cell size x2 per level until a level's cells reach max_corr / 5: the search picks the
+    // finest level whose cells are >= 0.2 r (lane scan) or 0.5 r (cooperative scan) and walks
+    // boxes of cells, so coarser levels than that would never be chosen by the former and save
+    // the latter (rare far-out queries) only a few row look-ups
+    while (h < 0.2 * max_corr && L < kMaxLevels) {
         h *= 2.0;
-        WM_TRY(derive_grid_level(ctx, ctx->levels[L - 1], &ctx->levels[L], ctx->n_tgt_input));
+        WM_TRY(derive_grid_level(ctx, ctx->levels[L - 1], L - 1, &ctx->levels[L], ctx->n_tgt_input));
         ++L;
     }
     (void) pts;
