@@ -84,7 +84,10 @@ int wm_cloud_sizes(const wm_ctx *ctx, size_t *n_source, size_t *n_target);
 
 /* ------------------------------------------------------------------- ICP */
 enum { WM_ICP_SVD = 0, WM_ICP_GN6 = 1 };
-enum { WM_NN_AUTO = 0, WM_NN_GRID = 1, WM_NN_BRUTE = 2 };
+enum { WM_NN_AUTO = 0, WM_NN_GRID = 1, WM_NN_BRUTE = 2,
+       /* wm_nn_search only, OR-ed in: seed every query with the point it matched in the previous
+        * search of the same clouds (what consecutive ICP iterations do); same result, less work */
+       WM_NN_WARM = 0x100 };
 enum { /* pcl::registration::DefaultConvergenceCriteria::ConvergenceState */
        WM_CONV_NOT_CONVERGED = 0,
        WM_CONV_ITERATIONS = 1,

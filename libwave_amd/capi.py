@@ -17,6 +17,7 @@ WM_OK, WM_NOT_CONVERGED, WM_TOO_FEW = 0, 1, 2
 WM_MEM_HOST, WM_MEM_DEVICE = 0, 1
 WM_ICP_SVD, WM_ICP_GN6 = 0, 1
 WM_NN_AUTO, WM_NN_GRID, WM_NN_BRUTE = 0, 1, 2
+WM_NN_WARM = 0x100
 WM_INFO_LUM, WM_INFO_CENSI, WM_INFO_LUMOLD = 0, 1, 2
 WM_STATS_LEN = 32
 CONV_NAMES = {0: "NOT_CONVERGED", 1: "ITERATIONS", 2: "TRANSFORM", 3: "ABS_MSE", 4: "REL_MSE",

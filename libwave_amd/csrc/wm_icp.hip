@@ -945,9 +945,12 @@ int wm_nn_search(wm_ctx *ctx, const double T[16], double max_corr, int nn_method
     if (ctx->n_src_input == 0 || ctx->n_tgt_input == 0) return WM_ERR_STATE;
     WM_HIP(ctx, hipSetDevice(ctx->device));
     WM_TRY(prepare_work(ctx));
+    const bool warm = (nn_method & WM_NN_WARM) && ctx->have_corr;
+    nn_method &= ~WM_NN_WARM;
     const bool brute = use_brute(ctx, nn_method) || ctx->n_tgt == 0;
     if (!brute) WM_TRY(ensure_levels(ctx, max_corr));
     init_state(ctx->h_state, T, nullptr, DBL_MAX);
+    ctx->h_state->have_prev = warm ? 1 : 0;
     WM_TRY(upload_state(ctx));
     const float thr = threshold_d2(max_corr);
     hipEvent_t e0 = kernel_ms ? ctx->ev_a : nullptr, e1 = kernel_ms ? ctx->ev_b : nullptr;
