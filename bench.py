@@ -200,9 +200,11 @@ def main():
                 "traffic": pmc_traffic_bytes() if world == 1 else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_us": nn_us, "launches_timed": nn_launches,
-                "note": "both clouds (32 MB) stay resident in L2 / Infinity Cache across the 50 "
-                        "iterations; the kernel is a latency-bound gather (PMC: SQ_WAIT_ANY ~50-68 % "
-                        "of wave cycles), not an HBM stream",
+                "note": "the kernel streams 64 B/point (source, previous key + match in; key + match "
+                        "out) and gathers its candidates out of L1/L2 (hit rate ~89 %); per-iteration "
+                        "PMC (profiles/r01c_pmc_k_nn_grid_per_iteration.csv): VALU ~50 % and texture "
+                        "addresser ~58 % busy, ~44 % of lanes active -- a dependent chain of small "
+                        "gathers, not an HBM stream",
             },
         }
         if world == 1 and not a.no_cpu_baseline:
