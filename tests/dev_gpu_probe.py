@@ -19,8 +19,8 @@ for h in cells:
     print("  per-iter nn us:", " ".join("%.0f" % (x*1e3) for x in ctx.iteration_times()))
     r2 = ctx.icp_align(max_corr=3.0, force_iterations=iters, nn_method=capi.WM_NN_GRID, profile=0)
     print("cell=%.3f (used %.3f) levels=%d set_source %.1f ms set_target %.1f ms" % (h, r["grid_cell"], r["nn_levels"], (t1-t0)*1e3, (t2-t1)*1e3))
-    print("  profile: align %.2f ms nn %.2f coarse %.2f stats %.2f solve %.2f ms; per-iter nn %.1f us; deferred %d" % (
-        r["align_ms"], r["nn_ms"], r["coarse_ms"], r["stats_ms"], r["solve_ms"], r["nn_ms"]/max(r["nn_launches"],1)*1e3, r["deferred"]))
+    print("  profile: align %.2f ms nn %.2f coarse %.2f stats %.2f solve %.2f ms; per-iter nn %.1f us; deferred %d settled %d" % (
+        r["align_ms"], r["nn_ms"], r["coarse_ms"], r["stats_ms"], r["solve_ms"], r["nn_ms"]/max(r["nn_launches"],1)*1e3, r["deferred"], r.get("settled", -1)))
     print("  noprofile: align %.2f ms -> %.1f us/iter; err vs gt %s" % (r2["align_ms"], r2["align_ms"]/iters*1e3,
           np.abs(r2["T"]-T_gt).max()))
     for k in range(3):

@@ -124,3 +124,42 @@ def test_warm_search_after_brute_force(wm, ctx, oracle):
     gi, gd = ctx.nn_search(T, 3.0, wm.WM_NN_GRID | wm.WM_NN_WARM)
     wi, wd, keep = _expect(oracle, ref, tgt, T, 3.0)
     assert np.array_equal(gi, wi) and np.array_equal(gd[keep], wd[keep])
+
+
+def _tiny_steps(rng, n):
+    """A converging pose sequence: steps shrink from centimetres to micrometres (what the
+    warm searches of a converging ICP see: seeds that are almost always still the answer)."""
+    T = synth.make_T((0.05, -0.03, 0.02), (0.004, -0.002, 0.006))
+    out = [T]
+    for k in range(n):
+        s = 0.5 ** k
+        dT = synth.make_T(tuple(rng.normal(0, 0.01 * s, 3)), tuple(rng.normal(0, 0.002 * s, 3)))
+        T = dT @ T
+        out.append(T)
+    return out + [out[-1], out[-1]]
+
+
+def test_converging_warm_sequence_stays_exact(wm, ctx, oracle):
+    rng = np.random.default_rng(31)
+    ref, tgt, _ = synth.pair(40000, seed=29, mode="resample")
+    _run(wm, ctx, oracle, ref, tgt, _tiny_steps(rng, 18), 3.0)
+
+
+def test_warm_searches_keep_resolving_ties_to_the_lowest_index(wm, ctx, oracle):
+    """Target = a regular lattice, queries at (and a hair off) cell centres and face centres:
+    2-, 4- and 8-way exact ties in float distance must keep resolving to the lowest index while
+    the pose creeps by micrometres."""
+    g = np.arange(-8, 9, dtype=np.float32) * np.float32(0.5)
+    tgt = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    rng = np.random.default_rng(37)
+    tgt = tgt[rng.permutation(len(tgt))]                     # indices unrelated to position
+    c = np.stack(np.meshgrid(g[:-1], g[:-1], g[:-1], indexing="ij"), -1).reshape(-1, 3)
+    ref = np.r_[c + np.float32(0.25),                        # cell centres: 8-way ties
+                c + np.array([0.25, 0.25, 0.0], np.float32),  # face centres: 4-way
+                c + np.array([0.25, 0.0, 0.0], np.float32),   # edge centres: 2-way
+                c + rng.normal(0, 1e-4, c.shape).astype(np.float32) + np.float32(0.25)]
+    poses = [np.eye(4), np.eye(4)]
+    for k in range(6):
+        poses.append(synth.make_T((1e-6 * (k + 1), -2e-6 * k, 1e-6), (0, 0, 1e-7 * k)))
+    poses += [np.eye(4), np.eye(4)]
+    _run(wm, ctx, oracle, ref, tgt, poses, 1.0)
