@@ -347,21 +347,30 @@ static double gicp_fdf(GicpFn &F, const double x[6], double g[6]) {
     int nb = (int) ((n + kBlock - 1) / kBlock);
     if (nb > kGicpBlocks) nb = kGicpBlocks;
     if (nb < 1) nb = 1;
-    (void) hipEventRecord(ctx->ev_a, ctx->stream);
-    hipLaunchKernelGGL(k_gicp_fdf, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->src_sorted.as<float4>(),
-                       n, ctx->keys.as<unsigned long long>(), ctx->match_pt.as<float4>(),
-                       ctx->gicp_mahal.as<double>(), A, ctx->partials.as<double>());
-    (void) hipEventRecord(ctx->ev_b, ctx->stream);
-    std::vector<double> h((size_t) nb * kGicpAcc);
-    if (hipMemcpyAsync(h.data(), ctx->partials.p, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    // The partial sums are written straight into pinned, device-visible host memory: no copy
+    // kernel, no staging -- this loop runs ~270 times per registration and is latency-bound.
+    if (!ctx->h_gicp &&
+        hipHostMalloc((void **) &ctx->h_gicp, sizeof(double) * kGicpBlocks * kGicpAcc,
+                      hipHostMallocDefault) != hipSuccess) {
         F.rc = WM_ERR_HIP;
-        ctx->last_error = "gicp_fdf: HIP error";
+        ctx->last_error = "gicp_fdf: hipHostMalloc failed";
         return 0;
     }
-    float ms = 0;
-    (void) hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b);
-    F.kernel_ms += ms;
+    if (ctx->gicp_profile) (void) hipEventRecord(ctx->ev_a, ctx->stream);
+    hipLaunchKernelGGL(k_gicp_fdf, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->src_sorted.as<float4>(),
+                       n, ctx->keys.as<unsigned long long>(), ctx->match_pt.as<float4>(),
+                       ctx->gicp_mahal.as<double>(), A, ctx->h_gicp);
+    if (ctx->gicp_profile) (void) hipEventRecord(ctx->ev_b, ctx->stream);
+    if (fast_stream_wait(ctx) != WM_OK) {
+        F.rc = WM_ERR_HIP;
+        return 0;
+    }
+    const double *h = ctx->h_gicp;
+    if (ctx->gicp_profile) {
+        float ms = 0;
+        (void) hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b);
+        F.kernel_ms += ms;
+    }
     F.evals++;
     double a[kGicpAcc];
     for (int k = 0; k < kGicpAcc; ++k) {
@@ -745,6 +754,7 @@ int wm_gicp_align(wm_ctx *ctx, const wm_gicp_params *prm, double T_out[16], wm_g
         Mat3d R;
         for (int a = 0; a < 3; ++a)
             for (int b = 0; b < 3; ++b) R.m[a * 3 + b] = (double) T[a * 4 + b];
+        WM_HIP(ctx, ctx->bbox_buf.reserve(64));
         unsigned *d_cnt = ctx->bbox_buf.as<unsigned>();
         WM_HIP(ctx, hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
         hipLaunchKernelGGL(k_gicp_mahal, dim3(blocks), dim3(kBlock), 0, ctx->stream, (unsigned) n,
@@ -812,6 +822,7 @@ int wm_gicp_eval(wm_ctx *ctx, const wm_gicp_params *prm, const double T_pair[16]
         for (int b = 0; b < 3; ++b) R.m[a * 3 + b] = Td[a * 4 + b];
     WM_TRY(nn_pass(ctx, Td, threshold_d2_strict(prm->max_corr), prm->max_corr, false));
     const unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
+    WM_HIP(ctx, ctx->bbox_buf.reserve(64));
     unsigned *d_cnt = ctx->bbox_buf.as<unsigned>(), cnt = 0;
     WM_HIP(ctx, hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
     hipLaunchKernelGGL(k_gicp_mahal, dim3(blocks), dim3(kBlock), 0, ctx->stream, (unsigned) n,

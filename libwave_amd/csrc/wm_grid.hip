@@ -116,14 +116,12 @@ int compute_bbox(wm_ctx *ctx, const float4 *pts, size_t n, Bbox *out, size_t *n_
     if (n == 0) return WM_OK;
     unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
     if (blocks > (unsigned) kBboxBlocks) blocks = kBboxBlocks;
-    WM_HIP(ctx, ctx->bbox_buf.reserve(8 * sizeof(float) * kBboxBlocks));
-    hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, n,
-                       ctx->bbox_buf.as<float>());
+    // the partials go straight into pinned host memory: no copy, and a polled wait
+    float *res = (float *) pinned_scratch(ctx, 8 * sizeof(float) * kBboxBlocks);
+    if (!res) return WM_ERR_HIP;
+    hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, n, res);
     WM_HIP(ctx, hipGetLastError());
-    static thread_local float res[8 * kBboxBlocks];
-    WM_HIP(ctx, hipMemcpyAsync(res, ctx->bbox_buf.p, 8 * sizeof(float) * blocks,
-                               hipMemcpyDeviceToHost, ctx->stream));
-    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    WM_TRY(fast_stream_wait(ctx));
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     size_t cnt = 0;
     for (unsigned b = 0; b < blocks; ++b) {
@@ -393,14 +391,11 @@ int build_grid_level(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, f
     if (avg_occupancy) {
         unsigned blocks = (unsigned) ((ncells + kBlock - 1) / kBlock);
         if (blocks > (unsigned) kOccBlocks) blocks = kOccBlocks;
-        WM_HIP(ctx, ctx->bbox_buf.reserve(sizeof(unsigned) * kOccBlocks));
-        unsigned *d_occ = ctx->bbox_buf.as<unsigned>();
+        unsigned *part = (unsigned *) pinned_scratch(ctx, sizeof(unsigned) * kOccBlocks);
+        if (!part) return WM_ERR_HIP;
         hipLaunchKernelGGL(k_count_occupied, dim3(blocks), dim3(kBlock), 0, ctx->stream,
-                           lvl->cell_start.as<unsigned>(), (size_t) ncells, d_occ);
-        static thread_local unsigned part[kOccBlocks];
-        WM_HIP(ctx, hipMemcpyAsync(part, d_occ, sizeof(unsigned) * blocks, hipMemcpyDeviceToHost,
-                                   ctx->stream));
-        WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                           lvl->cell_start.as<unsigned>(), (size_t) ncells, part);
+        WM_TRY(fast_stream_wait(ctx));
         uint64_t occ = 0;
         for (unsigned b = 0; b < blocks; ++b) occ += part[b];
         *avg_occupancy = occ ? (double) n / occ : 0.0;
@@ -640,9 +635,13 @@ int ensure_levels(wm_ctx *ctx, double max_corr) {
     for (int l = 0; l < L; ++l) host.g[l] = ctx->levels[l].d;
     host.n = L;
     WM_HIP(ctx, ctx->d_levels.reserve(sizeof(LevelsDev)));
-    WM_HIP(ctx, hipMemcpyAsync(ctx->d_levels.p, &host, sizeof(host), hipMemcpyHostToDevice,
+    // staged in pinned memory the ctx owns: the copy is asynchronous and needs no wait (the
+    // next user of the scratch waits on the stream before touching it)
+    LevelsDev *stage = (LevelsDev *) ((char *) pinned_scratch(ctx, 0) + (32u << 10));
+    if (!ctx->h_scratch) return WM_ERR_HIP;
+    *stage = host;
+    WM_HIP(ctx, hipMemcpyAsync(ctx->d_levels.p, stage, sizeof(host), hipMemcpyHostToDevice,
                                ctx->stream));
-    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `host` is a stack object
     return WM_OK;
 }
 

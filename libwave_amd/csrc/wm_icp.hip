@@ -14,6 +14,8 @@
 //      the RCCL all-reduce carries between (2) and (3).
 #include "wm_internal.hpp"
 
+#include <chrono>
+
 #include <float.h>
 #include <math.h>
 #include <string.h>
@@ -379,8 +381,47 @@ static int upload_state(wm_ctx *ctx) {
 static int download_state(wm_ctx *ctx) {
     WM_HIP(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state.p, sizeof(IcpDevState),
                                hipMemcpyDeviceToHost, ctx->stream));
-    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return fast_stream_wait(ctx);
+}
+
+__global__ void k_signal(unsigned *flag, unsigned seq) { *flag = seq; }
+
+int fast_stream_wait(wm_ctx *ctx) {
+    if (!ctx->h_sig) {
+        WM_HIP(ctx, hipHostMalloc((void **) &ctx->h_sig, 64, hipHostMallocDefault));
+        *ctx->h_sig = 0;
+    }
+    const unsigned seq = ++ctx->sig_seq;
+    hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, ctx->stream, ctx->h_sig, seq);
+    WM_HIP(ctx, hipGetLastError());
+    // spin briefly (the waits this is for are tens of microseconds), then let the runtime block:
+    // many worker threads spinning for long would starve each other and the runtime's helpers
+    volatile unsigned *flag = ctx->h_sig;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 1; *flag != seq; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 63u) == 0 &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(80)) {
+            WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            break;
+        }
+    }
     return WM_OK;
+}
+
+void *pinned_scratch(wm_ctx *ctx, size_t bytes) {
+    if (bytes < (64u << 10)) bytes = 64u << 10;
+    if (ctx->h_scratch_bytes < bytes) {
+        if (ctx->h_scratch) {
+            (void) hipStreamSynchronize(ctx->stream);
+            (void) hipHostFree(ctx->h_scratch);
+        }
+        ctx->h_scratch = nullptr;
+        ctx->h_scratch_bytes = 0;
+        if (hipHostMalloc(&ctx->h_scratch, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+        ctx->h_scratch_bytes = bytes;
+    }
+    return ctx->h_scratch;
 }
 
 static bool use_brute(const wm_ctx *ctx, int nn_method) {
@@ -458,6 +499,7 @@ int wm_ctx_create(wm_ctx **out, int device) {
         const float v = (float) atof(e);
         if (v > 0) ctx->tune_lane_lf = v;
     }
+    if (const char *e = getenv("WM_GICP_PROFILE")) ctx->gicp_profile = atoi(e) != 0;
     if (const char *e = getenv("WM_TUNE_NN_BLOCK")) ctx->tune_nn_block = atoi(e);
     if (const char *e = getenv("WM_TUNE_COOP_LF")) {
         const float v = (float) atof(e);
@@ -499,6 +541,9 @@ void wm_ctx_destroy(wm_ctx *ctx) {
         l.cell_start.release();
     }
     if (ctx->h_state) (void) hipHostFree(ctx->h_state);
+    if (ctx->h_gicp) (void) hipHostFree(ctx->h_gicp);
+    if (ctx->h_sig) (void) hipHostFree(ctx->h_sig);
+    if (ctx->h_scratch) (void) hipHostFree(ctx->h_scratch);
     for (hipEvent_t e : ctx->ev_pool) (void) hipEventDestroy(e);
     if (ctx->ev_a) (void) hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) (void) hipEventDestroy(ctx->ev_b);

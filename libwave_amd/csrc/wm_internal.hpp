@@ -147,6 +147,12 @@ struct wm_ctx {
     wm::DevBuf vg_idx, vg_idx2, vg_perm, vg_perm2, vg_tmp, vg_seg, io_a, io_b, ds_ref, ds_tgt, match_ref, match_tgt;
     wm::DevBuf d_state;
     wm::IcpDevState *h_state = nullptr;  // pinned
+    void *h_scratch = nullptr;           // pinned, device-visible scratch (reduction partials, level table)
+    size_t h_scratch_bytes = 0;
+    unsigned *h_sig = nullptr;           // pinned: completion flag polled by fast_stream_wait
+    unsigned sig_seq = 0;
+    double *h_gicp = nullptr;            // pinned, device-visible: the GICP objective's partial sums land here
+    bool gicp_profile = false;           // HIP events around every objective evaluation (fdf_kernel_ms)
     bool have_corr = false, last_align_valid = false, last_align_converged = false;
     wm::DevBuf keys_bak;
     double corr_T[16];
@@ -190,6 +196,12 @@ int build_grid_level(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, f
 int morton_sort(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, size_t n_valid,
                 float4 *out);
 int ensure_levels(wm_ctx *ctx, double max_corr);
+// wait for everything queued on the ctx stream, polling a pinned flag (a few microseconds
+// instead of hipStreamSynchronize's wake-up latency); for host loops that sync hundreds of times
+int fast_stream_wait(wm_ctx *ctx);
+// pinned, device-visible host scratch of at least `bytes` (kernels write small results into it
+// directly; the host reads them after fast_stream_wait)
+void *pinned_scratch(wm_ctx *ctx, size_t bytes);
 int exclusive_scan(wm_ctx *ctx, const unsigned *in, size_t n, unsigned *out);
 
 // ---- wm_voxel.hip
