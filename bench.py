@@ -95,7 +95,10 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_sharded = os.environ.get("WM_BENCH_FORCE_SHARDED") == "1"  # plumbing check at N=1
+    if world > 1 or (force_sharded and "RANK" in os.environ):
+        # (a one-rank group under torch.distributed.run still sends every iteration's block
+        # through RCCL: the whole N > 1 code path on a single GPU)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -112,7 +115,6 @@ def main():
     ref, tgt, T_gt = synth.pair_tiled(a.points, world, seed=42)
     dev = torch.device("cuda", local_rank)
 
-    force_sharded = os.environ.get("WM_BENCH_FORCE_SHARDED") == "1"  # plumbing check at N=1
     if world == 1 and not force_sharded:
         d_ref = torch.from_numpy(ref).to(dev)
         d_tgt = torch.from_numpy(tgt).to(dev)
