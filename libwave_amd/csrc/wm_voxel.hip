@@ -20,11 +20,12 @@ namespace wm {
 
 __global__ void __launch_bounds__(kBlock)
     k_vg_index(const float4 *__restrict__ in, unsigned n, float inv, int mbx, int mby, int mbz,
-               int dx, int dxy, unsigned *__restrict__ idx, unsigned *__restrict__ perm) {
+               int dx, int dxy, unsigned invalid, unsigned *__restrict__ idx,
+               unsigned *__restrict__ perm) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float4 p = in[i];
-    unsigned key = 0xFFFFFFFFu;  // invalid points sort to the end
+    unsigned key = invalid;  // one past the last leaf: invalid points sort to the end
     if (p.x == p.x) {
         const int i0 = (int) (floorf(__fmul_rn(p.x, inv)) - (float) mbx);
         const int i1 = (int) (floorf(__fmul_rn(p.y, inv)) - (float) mby);
@@ -37,29 +38,46 @@ __global__ void __launch_bounds__(kBlock)
 
 // head flag per sorted position (1 where a new leaf starts); invalid tail gets 0
 __global__ void __launch_bounds__(kBlock)
-    k_vg_flags(const unsigned *__restrict__ idx_sorted, unsigned n, unsigned *__restrict__ flags) {
+    k_vg_flags(const unsigned *__restrict__ idx_sorted, unsigned n, unsigned invalid,
+               unsigned *__restrict__ flags) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const unsigned k = idx_sorted[i];
-    flags[i] = (k != 0xFFFFFFFFu && (i == 0 || idx_sorted[i - 1] != k)) ? 1u : 0u;
+    flags[i] = (k != invalid && (i == 0 || idx_sorted[i - 1] != k)) ? 1u : 0u;
 }
 
-// one lane per leaf: sequential float sum over its points in ascending point index
+// one lane per leaf: sequential float sum over its points in ascending point index (the order
+// is part of the result: float addition does not associate).  Four points per trip: the
+// leaf-index / permutation / point loads of a trip are issued together, the adds stay in order.
 __global__ void __launch_bounds__(kBlock)
     k_vg_centroid(const float4 *__restrict__ in, const unsigned *__restrict__ idx_sorted,
                   const unsigned *__restrict__ perm_sorted, const unsigned *__restrict__ seg,
-                  unsigned n, float4 *__restrict__ out) {
+                  unsigned n, unsigned invalid, float4 *__restrict__ out) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const unsigned k = idx_sorted[i];
-    if (k == 0xFFFFFFFFu || (i > 0 && idx_sorted[i - 1] == k)) return;  // not a leaf head
+    if (k == invalid || (i > 0 && idx_sorted[i - 1] == k)) return;  // not a leaf head
     float sx = 0.f, sy = 0.f, sz = 0.f;
     unsigned j = i;
-    for (; j < n && idx_sorted[j] == k; ++j) {
-        const float4 p = in[perm_sorted[j]];
-        sx = __fadd_rn(sx, p.x);
-        sy = __fadd_rn(sy, p.y);
-        sz = __fadd_rn(sz, p.z);
+    for (bool more = true; more;) {
+        unsigned kk[4];
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned ju = j + u < n ? j + u : n - 1;
+            kk[u] = j + u < n ? idx_sorted[ju] : invalid;
+            p[u] = in[perm_sorted[ju]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            more = more && kk[u] == k;
+            if (more) {
+                sx = __fadd_rn(sx, p[u].x);
+                sy = __fadd_rn(sy, p[u].y);
+                sz = __fadd_rn(sz, p[u].z);
+                ++j;
+            }
+        }
     }
     const float cnt = (float) (j - i);
     const unsigned o = seg[i];  // exclusive scan of the head flags = output slot
@@ -112,24 +130,31 @@ int voxel_downsample_dev(wm_ctx *ctx, const float4 *in, size_t n, float leaf, fl
     unsigned *idx = ctx->vg_idx.as<unsigned>(), *idx2 = ctx->vg_idx2.as<unsigned>();
     unsigned *perm = ctx->vg_perm.as<unsigned>(), *perm2 = ctx->vg_perm2.as<unsigned>();
     unsigned *seg = ctx->vg_seg.as<unsigned>();
+    // leaf indices run 0 .. total-1; `total` itself marks dropped points, so the sort only
+    // needs the bits of `total` (coarse leaves: 2-3 radix passes instead of 4)
+    const unsigned invalid = (unsigned) ((int64_t) db[0] * db[1] * db[2]);
+    int bits = 1;
+    while (bits < 32 && (invalid >> bits) != 0u) ++bits;
     hipLaunchKernelGGL(k_vg_index, dim3(blocks), dim3(kBlock), 0, ctx->stream, in, (unsigned) n,
-                       inv, mb[0], mb[1], mb[2], db[0], db[0] * db[1], idx, perm);
+                       inv, mb[0], mb[1], mb[2], db[0], db[0] * db[1], invalid, idx, perm);
     size_t tmp_bytes = 0;
-    WM_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, idx, idx2, perm, perm2, n, 0, 32,
+    WM_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, idx, idx2, perm, perm2, n, 0, bits,
                                           ctx->stream));
     WM_HIP(ctx, ctx->vg_tmp.reserve(tmp_bytes));
     WM_HIP(ctx, rocprim::radix_sort_pairs(ctx->vg_tmp.p, tmp_bytes, idx, idx2, perm, perm2, n, 0,
-                                          32, ctx->stream));
+                                          bits, ctx->stream));
     // head flags -> exclusive scan -> output slot per leaf; total = number of leaves
     hipLaunchKernelGGL(k_vg_flags, dim3(blocks), dim3(kBlock), 0, ctx->stream, idx2, (unsigned) n,
-                       idx /* reuse as flags */);
+                       invalid, idx /* reuse as flags */);
     WM_TRY(exclusive_scan(ctx, idx, n, seg));
     hipLaunchKernelGGL(k_vg_centroid, dim3(blocks), dim3(kBlock), 0, ctx->stream, in, idx2, perm2,
-                       seg, (unsigned) n, out);
+                       seg, (unsigned) n, invalid, out);
     WM_HIP(ctx, hipGetLastError());
-    unsigned total = 0;
-    WM_HIP(ctx, hipMemcpyAsync(&total, seg + n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned *h_total = (unsigned *) pinned_scratch(ctx, 0);
+    if (!h_total) return WM_ERR_HIP;
+    WM_HIP(ctx, hipMemcpyAsync(h_total, seg + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    WM_TRY(fast_stream_wait(ctx));
+    const unsigned total = *h_total;
     *n_out = total;
     return WM_OK;
 }
