@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--iters", type=int, default=50, help="forced ICP iterations per registration")
     ap.add_argument("--max-corr", type=float, default=3.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=6, help="oracle iterations timed for the baseline")
+    ap.add_argument("--cpu-iters", type=int, default=20, help="oracle iterations timed for the baseline")
     return ap.parse_args()
 
 
