@@ -1,7 +1,15 @@
-// wave::GICPMatcher -- drop-in for the reference's
-// wave_matching/include/wave/matching/gicp.hpp:30-70.  Same parameter struct and class
-// surface; the pcl::GeneralizedIterativeClosestPoint / pcl::VoxelGrid members
-// (gicp.hpp:61-62) are replaced by a wm_ctx.
+// wave::GICPMatcher on the MI355X back end.
+//
+// match() is wm_gicp_match (include/wavematch.h): voxel filter of both clouds, k-nearest-
+// neighbour covariances with the (1, 1, epsilon) spectrum, then PCL-GICP's outer loop --
+// correspondences, per-pair Mahalanobis matrices, a BFGS minimisation whose objective and
+// gradient are device reductions -- until the rotation / translation deltas fall under the
+// thresholds.  PCL-GICP defaults libwave never overrides stay as they are (max correspondence
+// distance 5, transformation epsilon 5e-4, gicp_epsilon 1e-3, 20 inner iterations).
+//
+// Kept from the reference (wave_matching/include/wave/matching/gicp.hpp:30-70, src/gicp.cpp):
+// the parameter struct, the class surface, and the YAML constructor's quirk of parsing the file
+// but keeping the defaults (gicp.cpp:8-13).
 #ifndef WAVE_MATCHING_GICP_HPP
 #define WAVE_MATCHING_GICP_HPP
 
@@ -15,28 +23,25 @@ struct wm_ctx;
 namespace wave {
 
 struct GICPMatcherParams {
-    GICPMatcherParams(const std::string &config_path);
     GICPMatcherParams() {}
+    GICPMatcherParams(const std::string &config_path);
 
-    int corr_rand = 10;
-    int max_iter = 100;
-    double r_eps = 1e-8;
-    double fit_eps = 1e-2;
-    float res = 0.1;
+    int corr_rand = 10;     // neighbours per covariance estimate
+    int max_iter = 100;     // outer iterations
+    double r_eps = 1e-8;    // rotation epsilon
+    double fit_eps = 1e-2;  // euclidean fitness epsilon
+    float res = 0.1;        // voxel edge (<= 0: none)
 };
 
 class GICPMatcher : public Matcher<PCLPointCloudPtr> {
  public:
     explicit GICPMatcher(GICPMatcherParams params1);
-    GICPMatcher(const GICPMatcher &other);
+    GICPMatcher(const GICPMatcher &other);  // for MultiMatcher; the copy gets its own context
     ~GICPMatcher();
 
-    /** sets the reference pointcloud (voxel-filtered at match() when res > 0; gicp.cpp:37-45) */
     void setRef(const PCLPointCloudPtr &ref);
-    /** sets the target pointcloud (gicp.cpp:47-55) */
     void setTarget(const PCLPointCloudPtr &target);
-    /** runs GICP matcher. Blocks until finished. true if successful (gicp.cpp:57-64) */
-    bool match();
+    bool match();  // blocks until the registration is done; true when it converged
 
  private:
     wm_ctx *ctx;

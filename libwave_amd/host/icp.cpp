@@ -1,184 +1,134 @@
-// wave::ICPMatcher over the C ABI of libwavematch_hip.so.  Function-by-function mirror
-// of the reference's wave_matching/src/icp.cpp (constructor / YAML params :6-51,
-// setRef/setTarget :67-73, match :75-133, estimateInfo :135-142) with the PCL calls
-// replaced by wm_* calls; no registration arithmetic happens on the host.
+// wave::ICPMatcher: parameters in, one wm_icp_match out, wm_icp_info for the information
+// matrix.  No registration arithmetic happens on the host.  Reference behaviour followed:
+// wave_matching/src/icp.cpp (parameters :6-51, handles :67-73, match :75-133, estimator
+// dispatch :135-142) and src/icp_pcl_functions.cpp (LUM / LUMold).
 #include "wave/matching/icp.hpp"
 
-#include <cstdlib>
-#include <stdexcept>
-
-#include "wavematch.h"
+#include "shim.hpp"
 
 namespace wave {
 
-namespace {
-int g_default_device = -1;
-int default_device() {
-    if (g_default_device >= 0) return g_default_device;
-    const char *e = std::getenv("WAVE_MATCHING_DEVICE");
-    return e ? std::atoi(e) : 0;
-}
-void to_affine(const double T[16], Affine3 *out) {
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) out->matrix()(i, j) = T[i * 4 + j];
-}
-void from_affine(const Affine3 &a, double T[16]) {
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) T[i * 4 + j] = a.matrix()(i, j);
-}
-}  // namespace
-
-void ICPMatcher::setDefaultDevice(int device) {
-    g_default_device = device;
-}
+void ICPMatcher::setDefaultDevice(int device) { shim::setDefaultDevice(device); }
 
 ICPMatcherParams::ICPMatcherParams(const std::string &config_path) {
-    ConfigParser parser;
-    int covar_est_temp;
-    parser.addParam("max_corr", &(this->max_corr));
-    parser.addParam("max_iter", &(this->max_iter));
-    parser.addParam("t_eps", &(this->t_eps));
-    parser.addParam("lidar_ang_covar", &(this->lidar_ang_covar));
-    parser.addParam("lidar_lin_covar", &(this->lidar_lin_covar));
-    parser.addParam("covar_estimator", &covar_est_temp);
-    parser.addParam("res", &(this->res));
-    parser.addParam("multiscale_steps", &(this->multiscale_steps));
-    // NB: like the reference (icp.cpp:9-16) `fit_eps` is NOT read from the file.
-
-    if (parser.load(config_path) != ConfigStatus::OK) {
-        throw std::runtime_error{"Failed to Load Matcher Config"};
-    }
-
-    if ((covar_est_temp >= ICPMatcherParams::covar_method::LUM) &&
-        (covar_est_temp <= ICPMatcherParams::covar_method::LUMold)) {
-        this->covar_estimator = static_cast<ICPMatcherParams::covar_method>(covar_est_temp);
-    } else {
+    int estimator = 0;
+    // `fit_eps` is deliberately absent: the reference's loader never reads it (icp.cpp:9-16)
+    shim::loadYaml(config_path, {{"max_corr", &max_corr},
+                                 {"max_iter", &max_iter},
+                                 {"t_eps", &t_eps},
+                                 {"lidar_ang_covar", &lidar_ang_covar},
+                                 {"lidar_lin_covar", &lidar_lin_covar},
+                                 {"covar_estimator", &estimator},
+                                 {"res", &res},
+                                 {"multiscale_steps", &multiscale_steps}});
+    if (estimator < covar_method::LUM || estimator > covar_method::LUMold) {
         LOG_ERROR("Invalid covariance estimate method, using LUM");
-        this->covar_estimator = ICPMatcherParams::covar_method::LUM;
+        estimator = covar_method::LUM;
     }
+    covar_estimator = static_cast<covar_method>(estimator);
 }
 
 ICPMatcher::ICPMatcher(ICPMatcherParams params1)
-    : params(params1), ctx(nullptr), device(default_device()), converged(false) {
-    this->ref = boost::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
-    this->target = boost::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
-    this->resolution = this->params.res;
+    : params(params1), ctx(nullptr), device(shim::defaultDevice()), converged(false),
+      ref(shim::emptyCloud()), target(shim::emptyCloud()) {
+    resolution = params.res;
 }
 
-// A copy is a fresh matcher with the same parameters and cloud handles: device
-// state (like the PCL members of the reference) is per object.
+// Copies share parameters and cloud handles, never device state: like the PCL members of the
+// reference class, a context belongs to one object (and is created by the thread that uses it).
 ICPMatcher::ICPMatcher(const ICPMatcher &o)
-    : Matcher<PCLPointCloudPtr>(o), params(o.params), ctx(nullptr), device(o.device),
-      converged(false), ref(o.ref), target(o.target) {}
+    : Matcher<PCLPointCloudPtr>(o), params(o.params), ctx(nullptr), device(o.device), converged(false),
+      ref(o.ref), target(o.target) {}
 
 ICPMatcher &ICPMatcher::operator=(const ICPMatcher &o) {
-    if (this != &o) {
-        if (this->ctx) wm_ctx_destroy(this->ctx);
-        this->ctx = nullptr;
-        Matcher<PCLPointCloudPtr>::operator=(o);
-        this->params = o.params;
-        this->device = o.device;
-        this->converged = false;
-        this->ref = o.ref;
-        this->target = o.target;
-    }
+    if (this == &o) return *this;
+    shim::release(ctx);
+    Matcher<PCLPointCloudPtr>::operator=(o);
+    params = o.params;
+    device = o.device;
+    converged = false;
+    ref = o.ref;
+    target = o.target;
     return *this;
 }
 
-ICPMatcher::~ICPMatcher() {
-    if (this->ctx) wm_ctx_destroy(this->ctx);
-}
+ICPMatcher::~ICPMatcher() { shim::release(ctx); }
 
-bool ICPMatcher::ensureContext() {
-    if (this->ctx) return true;
-    int rc = wm_ctx_create(&this->ctx, this->device);
-    if (rc != WM_OK) {
-        LOG_ERROR("wm_ctx_create(device %d) failed: %s", this->device, wm_strerror(rc));
-        this->ctx = nullptr;
-        return false;
-    }
-    return true;
-}
+bool ICPMatcher::ensureContext() { return shim::acquire(ctx, device); }
 
-void ICPMatcher::setRef(const PCLPointCloudPtr &ref) {
-    this->ref = ref;
-}
+void ICPMatcher::setRef(const PCLPointCloudPtr &cloud) { ref = cloud; }
 
-void ICPMatcher::setTarget(const PCLPointCloudPtr &target) {
-    this->target = target;
-}
+void ICPMatcher::setTarget(const PCLPointCloudPtr &cloud) { target = cloud; }
 
 bool ICPMatcher::match() {
-    this->converged = false;
-    if (!this->ensureContext()) return false;
+    converged = false;
+    if (!ensureContext()) return false;
     wm_icp_params p;
     wm_icp_default_params(&p);
-    p.max_corr = this->params.max_corr;   // icp.cpp:47
-    p.max_iter = this->params.max_iter;   // icp.cpp:48
-    p.t_eps = this->params.t_eps;         // icp.cpp:49
-    p.fit_eps = this->params.fit_eps;     // icp.cpp:50
-    p.carry_state = 1;                    // one PCL object per matcher: criteria state persists
+    p.max_corr = params.max_corr;  // setMaxCorrespondenceDistance,  icp.cpp:47
+    p.max_iter = params.max_iter;  // setMaximumIterations,          icp.cpp:48
+    p.t_eps = params.t_eps;        // setTransformationEpsilon,      icp.cpp:49
+    p.fit_eps = params.fit_eps;    // setEuclideanFitnessEpsilon,    icp.cpp:50
+    p.carry_state = 1;             // one PCL object per matcher: its criteria remember the last MSE
     double T[16];
-    wm_icp_stats st;
-    static_assert(sizeof(pcl::PointXYZ) == 16, "PointXYZ stride");
-    const int rc = wm_icp_match(this->ctx, this->ref->points.data(), this->ref->points.size(),
-                                this->target->points.data(), this->target->points.size(),
-                                sizeof(pcl::PointXYZ), WM_MEM_HOST, &p, this->params.res,
-                                this->params.multiscale_steps, T, &st);
-    if (rc < 0) {
-        LOG_ERROR("wm_icp_match failed: %s [%s]", wm_strerror(rc), wm_last_error(this->ctx));
-        return false;
-    }
-    if (rc != WM_OK) return false;  // not converged: `result` left untouched (icp.cpp:132)
-    to_affine(T, &this->result);
-    this->converged = true;
+    wm_icp_stats stats;
+    const int rc = wm_icp_match(ctx, cloudData(ref), cloudSize(ref), cloudData(target), cloudSize(target),
+                                kCloudStride, WM_MEM_HOST, &p, params.res, params.multiscale_steps, T,
+                                &stats);
+    // anything but WM_OK leaves `result` as it was (icp.cpp:132)
+    if (!shim::succeeded(rc, "wm_icp_match", ctx)) return false;
+    shim::toAffine(T, result);
+    converged = true;
     return true;
 }
 
+// ---- information matrix
+// The reference's dispatch (icp.cpp:136-141) is a switch without `break`: LUM runs all three
+// estimators, CENSI the last two, and whatever was asked for, LUMold writes `information` last.
+// Kept, because results depend on it.
 void ICPMatcher::estimateInfo() {
-    // The reference's switch has no `break`s (icp.cpp:136-141): LUM runs LUM, Censi and
-    // LUMold; CENSI runs Censi and LUMold; the final `information` is always LUMold's.
-    switch (this->params.covar_estimator) {
-        case ICPMatcherParams::covar_method::LUM: this->estimateLUM();       // fall through
-        case ICPMatcherParams::covar_method::CENSI: this->estimateCensi();   // fall through
-        case ICPMatcherParams::covar_method::LUMold: this->estimateLUMold();
-        default: return;
-    }
+    const int first = params.covar_estimator;
+    if (first <= ICPMatcherParams::LUM) estimateLUM();
+    if (first <= ICPMatcherParams::CENSI) estimateCensi();
+    if (first <= ICPMatcherParams::LUMold) estimateLUMold();
 }
 
-static void store_info(const double info[36], Mat6 *out) {
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) (*out)(i, j) = info[i * 6 + j];
+namespace {
+void storeInfo(const double in[36], Mat6 &out) {
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) out(r, c) = in[6 * r + c];
 }
+void warnIfDegenerate(int degenerate) {
+    if (degenerate) LOG_ERROR("Covariance matrix calculation was unsuccessful");
+}
+}  // namespace
 
 void ICPMatcher::estimateLUM() {
-    if (!this->ctx || !this->converged) return;  // hasConverged() guard, icp_pcl_functions.cpp:190
+    if (!ctx || !converged) return;  // hasConverged() guard of icp_pcl_functions.cpp:190
     double info[36];
     int degenerate = 0;
-    if (wm_icp_info(this->ctx, WM_INFO_LUM, nullptr, 0, 0, 0, info, &degenerate) != WM_OK) return;
-    if (degenerate) LOG_ERROR("Covariance matrix calculation was unsuccessful");
-    store_info(info, &this->information);
+    if (wm_icp_info(ctx, WM_INFO_LUM, nullptr, 0, 0, 0, info, &degenerate) != WM_OK) return;
+    warnIfDegenerate(degenerate);
+    storeInfo(info, information);
 }
 
 void ICPMatcher::estimateLUMold() {
-    if (!this->ctx) return;
+    if (!ctx) return;
     double info[36];
     int degenerate = 0;
-    if (wm_icp_info(this->ctx, WM_INFO_LUMOLD, nullptr, 0, 0, this->params.max_corr, info,
-                    &degenerate) != WM_OK)
-        return;
-    if (degenerate) LOG_ERROR("Covariance matrix calculation was unsuccessful");
-    store_info(info, &this->information);
+    if (wm_icp_info(ctx, WM_INFO_LUMOLD, nullptr, 0, 0, params.max_corr, info, &degenerate) != WM_OK) return;
+    warnIfDegenerate(degenerate);
+    storeInfo(info, information);
 }
 
 void ICPMatcher::estimateCensi() {
-    if (!this->ctx || !this->converged) return;  // icp.cpp:174
+    if (!ctx || !converged) return;  // icp.cpp:174
     double info[36], T[16];
-    from_affine(this->result, T);
-    if (wm_icp_info(this->ctx, WM_INFO_CENSI, T, this->params.lidar_lin_covar,
-                    this->params.lidar_ang_covar, 0, info, nullptr) != WM_OK)
+    shim::fromAffine(result, T);
+    if (wm_icp_info(ctx, WM_INFO_CENSI, T, params.lidar_lin_covar, params.lidar_ang_covar, 0, info, nullptr) !=
+        WM_OK)
         return;
-    store_info(info, &this->information);
+    storeInfo(info, information);
 }
 
 }  // namespace wave

@@ -1,6 +1,6 @@
-"""The reference's own gtest cases (wave_matching/tests/icp_tests.cpp,
-multi_matcher_tests.cpp), re-expressed in C++ against the drop-in wave:: API
-(tests/cpp/*.cpp), built by libwave_amd/host/Makefile and run as a binary."""
+"""The cases of the reference's gtest suites (wave_matching/tests/{icp,gicp,ndt,multi_matcher}
+_tests.cpp) run in C++ against the drop-in wave:: API: tests/cpp/matcher_cases.cpp (a table of
+registrations + a few construction / estimator / pool cases), built by libwave_amd/host/Makefile."""
 import os
 import subprocess
 
