@@ -1,6 +1,6 @@
 """Developer probe (not a test): quick timing of the ICP path on the GPU box."""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import __graft_entry__ as g
 g.build()

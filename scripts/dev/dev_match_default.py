@@ -2,7 +2,7 @@
 multiscale_steps = 3, max_corr = 3, max_iter = 100, t_eps = 1e-8, fit_eps = 1e-2) on 1M-point
 clouds -- the path a libwave user gets without touching the config."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from libwave_amd import capi, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000

@@ -1,7 +1,7 @@
 """Developer probe: per-rank cost of the sharded path at world=W emulated on ONE GPU
 (no all-reduce: the pose update uses this rank's partial statistics, so only timing is meaningful)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from libwave_amd import capi, sharding, synth
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 8

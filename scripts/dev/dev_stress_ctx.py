@@ -1,7 +1,7 @@
 """Developer stress: many short-lived contexts, first-call paths (allocations, pinned scratch,
 flag waits) exercised over and over."""
 import sys, os, gc
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from libwave_amd import capi, synth
 mode = sys.argv[1] if len(sys.argv) > 1 else "match"
