@@ -144,9 +144,40 @@ __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float q
             yy = wrap ? ya : yy + 1;
             zz += wrap;
         }
+        // Walk the chunk's runs with a lane-private cursor: a lane moves on to its next
+        // non-empty run as soon as its current one is done, so the wave makes
+        // max-over-lanes(sum of a lane's trips) trips, not sum-over-runs(max-over-lanes).
+        // With sparse rows (far queries: most rows of the ball are empty) that is several
+        // times fewer.  Four points per trip, one address (reads past a run's end are
+        // harmless, see scan_run).
+        unsigned j = rs[0], e = re[0];
+        int u = 0;
 #pragma unroll
-        for (int u = 0; u < kRowChunk; ++u)
-            if (re[u] > rs[u]) best = scan_run(g.pts, rs[u], re[u], qx, qy, qz, best);
+        for (int k = 1; k < kRowChunk; ++k) {
+            const bool take = j >= e;
+            j = take ? rs[k] : j;
+            e = take ? re[k] : e;
+            u = take ? k : u;
+        }
+        while (j < e) {
+            const gp_f4 p = (gp_f4) g.pts + j;
+            const f4v t0 = p[0], t1 = p[1], t2 = p[2], t3 = p[3];
+            const unsigned long long k0 = make_key(canon_d2v(qx, qy, qz, t0), __float_as_uint(t0.w));
+            const unsigned long long k1 = make_key(canon_d2v(qx, qy, qz, t1), __float_as_uint(t1.w));
+            const unsigned long long k2 = make_key(canon_d2v(qx, qy, qz, t2), __float_as_uint(t2.w));
+            const unsigned long long k3 = make_key(canon_d2v(qx, qy, qz, t3), __float_as_uint(t3.w));
+            const unsigned long long a = k0 < k1 ? k0 : k1, b = k2 < k3 ? k2 : k3;
+            const unsigned long long m = a < b ? a : b;
+            best = m < best ? m : best;
+            j += 4;
+#pragma unroll
+            for (int k = 1; k < kRowChunk; ++k) {
+                const bool take = k > u && j >= e;
+                j = take ? rs[k] : j;
+                e = take ? re[k] : e;
+                u = take ? k : u;
+            }
+        }
     }
     return best;
 }
