@@ -101,7 +101,7 @@ __device__ __forceinline__ unsigned long long scan_run(const float4 *__restrict_
 //     (cell units; Rb inflated by 1e-5 against the approximate hardware square roots): rows
 //     outside the ball cost nothing, rows near its rim a cell or two.
 // Pruning changes the work, never the result.
-constexpr int kRowChunk = 4;
+constexpr int kRowChunk = 6;
 __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float qx, float qy,
                                                        float qz, float r, unsigned long long best,
                                                        float *margin) {
