@@ -500,7 +500,6 @@ int wm_ctx_create(wm_ctx **out, int device) {
         if (v > 0) ctx->tune_lane_lf = v;
     }
     if (const char *e = getenv("WM_GICP_PROFILE")) ctx->gicp_profile = atoi(e) != 0;
-    if (const char *e = getenv("WM_TUNE_NN_BLOCK")) ctx->tune_nn_block = atoi(e);
     if (const char *e = getenv("WM_TUNE_COOP_LF")) {
         const float v = (float) atof(e);
         if (v > 0) ctx->tune_coop_lf = v;

@@ -134,7 +134,6 @@ struct wm_ctx {
     double levels_max_corr = -1;
     float grid_cell_override = 0;
     float tune_lane_lf = 0.2f;   // lane-serial scan: finest level with cell size >= this x radius
-    int tune_nn_block = 0;       // 0 = default block size of the correspondence kernel
     float tune_coop_lf = 0.5f;   // cooperative scan: finest level with cell size >= this x radius
     float tune_r_light = 12.0f;  // lane-serial vs cooperative scan threshold, in level-0 cells
     double tuned_h = 0, tuned_vol = 0;  // last auto-tuned level-0 cell size and its cloud

@@ -104,7 +104,7 @@ __device__ __forceinline__ unsigned long long scan_run(const float4 *__restrict_
 constexpr int kRowChunk = 6;
 __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float qx, float qy,
                                                        float qz, float r, unsigned long long best,
-                                                       float *margin) {
+                                                       float *margin, uint2 *runs, unsigned lane) {
     const float big = 4.0e6f;  // clamp in float so far-away queries cannot overflow the int cast
     const float fx = fminf(fmaxf((qx - g.ox) * g.inv_h, -big), big);
     const float fy = fminf(fmaxf((qy - g.oy) * g.inv_h, -big), big);
@@ -144,20 +144,24 @@ __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float q
             yy = wrap ? ya : yy + 1;
             zz += wrap;
         }
-        // Walk the chunk's runs with a lane-private cursor: a lane moves on to its next
-        // non-empty run as soon as its current one is done, so the wave makes
-        // max-over-lanes(sum of a lane's trips) trips, not sum-over-runs(max-over-lanes).
-        // With sparse rows (far queries: most rows of the ball are empty) that is several
-        // times fewer.  Four points per trip, one address (reads past a run's end are
-        // harmless, see scan_run).
-        unsigned j = rs[0], e = re[0];
-        int u = 0;
+        // The chunk's non-empty runs go into this lane's column of an LDS list, and the lane
+        // walks its own list: it moves on to its next run as soon as the current one is done,
+        // so the wave makes max-over-lanes(sum of a lane's trips) trips, not
+        // sum-over-runs(max-over-lanes).  With sparse rows (far queries: most rows of the ball
+        // are empty) that is several times fewer.  Four points per trip, one address (reads
+        // past a run's end are harmless, see scan_run).  No barrier: a lane only reads back
+        // what it wrote itself, and LDS operations of one wave execute in order.
+        unsigned cnt = 0;
 #pragma unroll
-        for (int k = 1; k < kRowChunk; ++k) {
-            const bool take = j >= e;
-            j = take ? rs[k] : j;
-            e = take ? re[k] : e;
-            u = take ? k : u;
+        for (int u = 0; u < kRowChunk; ++u)
+            if (re[u] > rs[u]) runs[cnt++ * 64u + lane] = make_uint2(rs[u], re[u]);
+        // ONE flat loop (a nested per-run loop would make the lanes wait for each other at
+        // every run boundary again)
+        unsigned idx = 0, j = 0, e = 0;
+        if (cnt) {
+            const uint2 run = runs[lane];
+            j = run.x;
+            e = run.y;
         }
         while (j < e) {
             const gp_f4 p = (gp_f4) g.pts + j;
@@ -170,12 +174,10 @@ __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float q
             const unsigned long long m = a < b ? a : b;
             best = m < best ? m : best;
             j += 4;
-#pragma unroll
-            for (int k = 1; k < kRowChunk; ++k) {
-                const bool take = k > u && j >= e;
-                j = take ? rs[k] : j;
-                e = take ? re[k] : e;
-                u = take ? k : u;
+            if (j >= e && ++idx < cnt) {
+                const uint2 run = runs[idx * 64u + lane];
+                j = run.x;
+                e = run.y;
             }
         }
     }
@@ -294,6 +296,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 
               float4 *__restrict__ match_pt, const float4 *__restrict__ tgt_orig,
               float r_light_cells, float lane_lf, float coop_lf) {
     if (st->done) return;
+    __shared__ uint2 s_runs[kRowChunk * kNnBlock];  // [run][lane]: each lane's pending runs
     const unsigned i = xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
     const bool active = i < n;
@@ -348,7 +351,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 
             while (l < L - 1 && lv->g[l].h < lane_lf * r) ++l;
             const GridDev g = lv->g[l];
             float margin;
-            best = scan_box(g, qx, qy, qz, r, best, &margin);
+            best = scan_box(g, qx, qy, qz, r, best, &margin, s_runs, lane);
             const float bd2 = __uint_as_float((unsigned) (best >> 32));
             if (margin > 0.f && (bd2 <= margin * margin || thr_d2 <= margin * margin)) break;
             // not certified: the radius must GROW (a query sitting on a cell face can have a
@@ -479,7 +482,7 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
     if (n == 0) return WM_OK;
     IcpDevState *st = ctx->d_state.as<IcpDevState>();
     unsigned long long *keys = ctx->keys.as<unsigned long long>();
-    const unsigned nb = ctx->tune_nn_block > 0 ? (unsigned) ctx->tune_nn_block : (unsigned) kNnBlock;
+    const unsigned nb = (unsigned) kNnBlock;  // one wave per workgroup (its LDS run list is sized for that)
     unsigned blocks = (n + nb - 1) / nb;
     blocks = (blocks + 7u) & ~7u;  // xcd_remap needs a multiple of 8
     if (ev0) WM_HIP(ctx, hipEventRecord(ev0, ctx->stream));
