@@ -296,6 +296,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 
               float4 *__restrict__ match_pt, const float4 *__restrict__ tgt_orig,
               float r_light_cells, float lane_lf, float coop_lf) {
     if (st->done) return;
+    static_assert(kNnBlock == 64, "the run list is indexed by lane: one wavefront per workgroup");
     __shared__ uint2 s_runs[kRowChunk * kNnBlock];  // [run][lane]: each lane's pending runs
     const unsigned i = xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
