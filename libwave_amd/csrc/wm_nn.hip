@@ -121,28 +121,39 @@ __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float q
     const int ya = max(y0, 0), yb = min(y1, g.ny - 1);
     const int za = max(z0, 0), zb = min(z1, g.nz - 1);
     if (xa > xb || ya > yb || za > zb) return best;
-    const int cy = (int) floorf(fy), cz = (int) floorf(fz);
     int yy = ya, zz = za;  // row cursor
     while (zz <= zb) {
         const float Rb =
             __builtin_amdgcn_sqrtf(__uint_as_float((unsigned) (best >> 32))) * g.inv_h * 1.00001f;
         const float lim = Rb + g.slack;
         const float lim2 = lim * lim, c0 = Rb * Rb + 2.f * g.slack * lim;
-        unsigned rs[kRowChunk], re[kRowChunk];
+        // addresses first, then all look-ups back to back and unconditional (a row outside the
+        // ball reads cell_start[0] twice: an empty run) -- with predicated loads the compiler
+        // interleaves address arithmetic, branches and waits, and the twelve look-ups of a
+        // chunk no longer overlap
+        unsigned a0[kRowChunk], a1[kRowChunk];
 #pragma unroll
         for (int u = 0; u < kRowChunk; ++u) {
-            const float ry = yy > cy ? (float) yy - fy : (yy < cy ? fy - (float) (yy + 1) : 0.f);
-            const float rz = zz > cz ? (float) zz - fz : (zz < cz ? fz - (float) (zz + 1) : 0.f);
+            // distance from the query to row (yy, zz) along y and z, in cells: positive on the
+            // far side, 0 inside the query's own row (branch-free form of the three cases)
+            const float ry = fmaxf(fmaxf((float) yy - fy, fy - (float) (yy + 1)), 0.f);
+            const float rz = fmaxf(fmaxf((float) zz - fz, fz - (float) (zz + 1)), 0.f);
             const float rho2 = ry * ry + rz * rz;
             const float hx = __builtin_amdgcn_sqrtf(fmaxf(c0 - rho2, 0.f)) * 1.00001f + g.slack;
             const int xl = max(xa, (int) floorf(fx - hx)), xh = min(xb, (int) floorf(fx + hx));
             const bool ok = zz <= zb && !(rho2 > lim2) && xl <= xh;
-            const unsigned base = ok ? ((unsigned) zz * g.ny + yy) * g.nx : 0u;
-            rs[u] = ok ? ldc(g.cell_start, base + xl) : 0u;
-            re[u] = ok ? ldc(g.cell_start, base + xh + 1) : 0u;
+            const unsigned base = ((unsigned) zz * g.ny + yy) * g.nx;
+            a0[u] = ok ? base + xl : 0u;
+            a1[u] = ok ? base + xh + 1 : 0u;
             const bool wrap = yy >= yb;
             yy = wrap ? ya : yy + 1;
             zz += wrap;
+        }
+        unsigned rs[kRowChunk], re[kRowChunk];
+#pragma unroll
+        for (int u = 0; u < kRowChunk; ++u) {
+            rs[u] = ldc(g.cell_start, a0[u]);
+            re[u] = ldc(g.cell_start, a1[u]);
         }
         // The chunk's non-empty runs go into this lane's column of an LDS list, and the lane
         // walks its own list: it moves on to its next run as soon as the current one is done,
