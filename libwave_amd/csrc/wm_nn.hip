@@ -322,8 +322,18 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 
     unsigned long long seeded = best;  // the key the search started from
     bool heavy = false;
     bool mine = active;
+    // the query and its seed (previous key + previous match coordinates) are three
+    // independent streams: all three loads are issued before the first use -- one memory round
+    // trip, not three dependent ones
+    const bool have_prev = st->have_prev != 0;  // wave-uniform
+    unsigned long long prev = ~0ull;
+    float4 tp = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) {
         const float4 p = src[i];
+        if (have_prev) {
+            prev = keys[i];
+            tp = match_pt[i];
+        }
         xform(st->Tf, p, qx, qy, qz);
         // sharded registration: only the rank owning this x-slab handles the point
         if (st->slab_on && !(qx >= st->slab_lo && qx < st->slab_hi)) mine = false;
@@ -332,27 +342,20 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 
     // rank last found for it (still a valid candidate if it ever comes back)
     if (mine) {
         r = 0.5f * h0;
-        if (st->have_prev) {
-            const unsigned long long prev = keys[i];
-            if (prev != ~0ull) {
-                const unsigned pidx = (unsigned) prev;
-                if (pidx != kNoIdx) {
-                    // the point matched in the previous iteration is a real candidate: its
-                    // distance under the NEW pose is an upper bound of the new NN distance,
-                    // so one scan of ball(q, that distance) is certain to certify
-                    const float4 tp = match_pt[i];  // its coordinates, stored last iteration
-                    const float d2b = canon_d2(qx, qy, qz, tp);
-                    if (d2b <= thr_d2) {
-                        best = seeded = make_key(d2b, pidx);
-                        bqx = tp.x;
-                        bqy = tp.y;
-                        bqz = tp.z;
-                        r = fmaxf(sqrtf(d2b) * 1.0001f + 1e-6f, 0.05f * h0);
-                    } else {
-                        r = rmax;
-                    }
-                } else {
-                    r = rmax;  // nothing within max_corr last time
+        if (prev != ~0ull) {
+            const unsigned pidx = (unsigned) prev;
+            r = rmax;  // nothing (close enough) to start from: the full radius
+            if (pidx != kNoIdx) {
+                // the point matched in the previous iteration is a real candidate: its
+                // distance under the NEW pose is an upper bound of the new NN distance, so
+                // one scan of ball(q, that distance) is certain to certify
+                const float d2b = canon_d2(qx, qy, qz, tp);
+                if (d2b <= thr_d2) {
+                    best = seeded = make_key(d2b, pidx);
+                    bqx = tp.x;
+                    bqy = tp.y;
+                    bqz = tp.z;
+                    r = fmaxf(sqrtf(d2b) * 1.0001f + 1e-6f, 0.05f * h0);
                 }
             }
         }
