@@ -205,7 +205,7 @@ def main():
                 "note": "the kernel streams 64 B/point (source, previous key + match in; key + match "
                         "out) and gathers its candidates out of L1/L2 (hit rate ~89 %); per-iteration "
                         "PMC (profiles/r01d_pmc_k_nn_grid_per_iteration.csv): VALU ~50 % and texture "
-                        "addresser ~54 % busy, ~62 % of lanes active -- a dependent chain of small "
+                        "addresser ~59 % busy, ~66 % of lanes active -- a dependent chain of small "
                         "gathers, not an HBM stream",
             },
         }
