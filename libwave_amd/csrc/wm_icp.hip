@@ -495,6 +495,7 @@ int wm_ctx_create(wm_ctx **out, int device) {
         return WM_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    if (const char *e = getenv("WM_TUNE_NDT_DENSE")) ctx->tune_ndt_dense = atoi(e);
     if (const char *e = getenv("WM_TUNE_LANE_LF")) {
         const float v = (float) atof(e);
         if (v > 0) ctx->tune_lane_lf = v;
@@ -528,7 +529,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->src_sorted, &ctx->tgt_orig, &ctx->staging, &ctx->cell_of, &ctx->counts,
                       &ctx->block_sums, &ctx->bbox_buf, &ctx->keys, &ctx->keys_bak, &ctx->match_pt, &ctx->match_pt_bak, &ctx->d_levels, &ctx->ndt_keys, &ctx->ndt_keys2,
-                      &ctx->ndt_vox, &ctx->ndt_vkey, &ctx->ndt_hkeys, &ctx->ndt_hvals, &ctx->src_orig,
+                      &ctx->ndt_vox, &ctx->ndt_vkey, &ctx->ndt_hkeys, &ctx->ndt_hvals, &ctx->ndt_dense, &ctx->src_orig,
                       &ctx->gicp_c1, &ctx->gicp_c2, &ctx->gicp_mahal, &ctx->src_grid.pts,
                       &ctx->src_grid.cell_start, &ctx->vg_idx, &ctx->vg_idx2, &ctx->vg_perm,
                       &ctx->vg_perm2, &ctx->vg_tmp, &ctx->vg_seg, &ctx->io_a, &ctx->io_b, &ctx->ds_ref,

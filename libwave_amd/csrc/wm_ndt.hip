@@ -241,6 +241,30 @@ __global__ void __launch_bounds__(kBlock)
     }
 }
 
+// Dense alternative to the hash grid when the voxel lattice over the target's bounding box is
+// small (a few million cells): cell (i, j, k) -> voxel slot, -1 = empty / invalid.  A neighbour
+// look-up is then ONE 4-byte load instead of a hash and a probe sequence.
+struct NdtDense {
+    const int *table;  // nullptr: use the hash grid
+    int i0, j0, k0;    // lattice origin (cell indices)
+    int nx, ny, nz;
+};
+
+__global__ void __launch_bounds__(kBlock)
+    k_ndt_dense_fill(const unsigned long long *__restrict__ vkey, unsigned nvox, NdtDense d, int *table) {
+    const unsigned s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= nvox) return;
+    const unsigned long long key = vkey[s];
+    if (key == kEmptyKey) return;
+    // ndt_key(k, j, i): k in the top bits, 21 bits each, biased by 2^20
+    const int k = (int) ((key >> 42) & 0x1FFFFFu) - (1 << 20);
+    const int j = (int) ((key >> 21) & 0x1FFFFFu) - (1 << 20);
+    const int i = (int) (key & 0x1FFFFFu) - (1 << 20);
+    const int a = i - d.i0, b = j - d.j0, c = k - d.k0;
+    if (a < 0 || b < 0 || c < 0 || a >= d.nx || b >= d.ny || c >= d.nz) return;
+    table[((size_t) c * d.ny + b) * d.nx + a] = (int) s;
+}
+
 struct NdtArgs {
     float Tf[12];
     float inv_res;
@@ -259,7 +283,7 @@ template <bool GRAD, bool HESS>
 __global__ void __launch_bounds__(kBlock)
     k_ndt_derivs(const float4 *__restrict__ src, unsigned n, const NdtVoxel *__restrict__ vox,
                  const unsigned long long *__restrict__ hkeys, const unsigned *__restrict__ hvals,
-                 unsigned mask, NdtArgs A, double *__restrict__ partials) {
+                 unsigned mask, NdtDense dense, NdtArgs A, double *__restrict__ partials) {
     double acc[kNdtAcc];
 #pragma unroll
     for (int k = 0; k < kNdtAcc; ++k) acc[k] = 0.0;
@@ -309,26 +333,39 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll 1
         for (int nb = 0; nb < 27; ++nb) {
             const int di = nb % 3 - 1, dj = (nb / 3) % 3 - 1, dk = nb / 9 - 1;
-            const unsigned long long key = ndt_key(ck + dk, cj + dj, ci + di);
-            unsigned hpos = ndt_hash(key) & mask;
             unsigned vi = 0xFFFFFFFFu;
-            for (;;) {
-                const unsigned long long hk = hkeys[hpos];
-                if (hk == key) {
-                    vi = hvals[hpos];
-                    break;
+            if (dense.table) {  // uniform: one load
+                const int a = ci + di - dense.i0, b = cj + dj - dense.j0, c = ck + dk - dense.k0;
+                if (a >= 0 && b >= 0 && c >= 0 && a < dense.nx && b < dense.ny && c < dense.nz)
+                    vi = (unsigned) dense.table[((size_t) c * dense.ny + b) * dense.nx + a];
+            } else {
+                const unsigned long long key = ndt_key(ck + dk, cj + dj, ci + di);
+                unsigned hpos = ndt_hash(key) & mask;
+                for (;;) {
+                    const unsigned long long hk = hkeys[hpos];
+                    if (hk == key) {
+                        vi = hvals[hpos];
+                        break;
+                    }
+                    if (hk == kEmptyKey) break;
+                    hpos = (hpos + 1) & mask;
                 }
-                if (hk == kEmptyKey) break;
-                hpos = (hpos + 1) & mask;
             }
             if (vi == 0xFFFFFFFFu) continue;
-            const NdtVoxel v = vox[vi];
+            // mean first (24 B): most neighbouring voxels fail the radius test, and only the
+            // ones that pass need their inverse covariance (72 B)
+            NdtVoxel v;
+            v.mean[0] = vox[vi].mean[0];
+            v.mean[1] = vox[vi].mean[1];
+            v.mean[2] = vox[vi].mean[2];
             {  // kd-tree radius test in float on the float-stored means
                 const float fx = __fsub_rn(xt0, (float) v.mean[0]), fy = __fsub_rn(xt1, (float) v.mean[1]),
                             fz = __fsub_rn(xt2, (float) v.mean[2]);
                 const float dd = __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz));
                 if (!((double) dd < A.res2)) continue;
             }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) v.icov[k] = vox[vi].icov[k];
             const double xx[3] = {(double) xt0 - v.mean[0], (double) xt1 - v.mean[1], (double) xt2 - v.mean[2]};
             double cx[3];
 #pragma unroll
@@ -448,6 +485,33 @@ static int ndt_build(wm_ctx *ctx, double res) {
                            ctx->ndt_hmask);
         WM_HIP(ctx, hipGetLastError());
     }
+    // dense cell -> slot table over the target's bounding box, when that lattice is small
+    ctx->ndt_dense_on = false;
+    if (nvox > 0) {
+        const float inv = 1.0f / (float) res;
+        const Bbox &bb = ctx->tgt_bbox;
+        int lo[3], dim[3];
+        int64_t cells = 1;
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = (int) floorf(bb.lo[d] * inv);  // the same float product as k_ndt_key
+            dim[d] = (int) floorf(bb.hi[d] * inv) - lo[d] + 1;
+            cells *= dim[d] > 0 ? dim[d] : 1;
+        }
+        if (cells <= (int64_t) 32 << 20) {
+            WM_HIP(ctx, ctx->ndt_dense.reserve((size_t) cells * 4));
+            WM_HIP(ctx, hipMemsetAsync(ctx->ndt_dense.p, 0xFF, (size_t) cells * 4, ctx->stream));
+            const NdtDense d{ctx->ndt_dense.as<int>(), lo[0], lo[1], lo[2], dim[0], dim[1], dim[2]};
+            hipLaunchKernelGGL(k_ndt_dense_fill, dim3((nvox + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                               ctx->stream, ctx->ndt_vkey.as<unsigned long long>(), nvox, d,
+                               ctx->ndt_dense.as<int>());
+            WM_HIP(ctx, hipGetLastError());
+            for (int k = 0; k < 3; ++k) {
+                ctx->ndt_dense_lo[k] = lo[k];
+                ctx->ndt_dense_dim[k] = dim[k];
+            }
+            ctx->ndt_dense_on = true;
+        }
+    }
     unsigned nvalid = 0;
     WM_HIP(ctx, hipMemcpyAsync(&nvalid, d_nvalid, 4, hipMemcpyDeviceToHost, ctx->stream));
     WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -540,16 +604,21 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
     const unsigned long long *hk = ctx->ndt_hkeys.as<unsigned long long>();
     const unsigned *hv = ctx->ndt_hvals.as<unsigned>();
     const float4 *src = ctx->src_sorted.as<float4>();
+    NdtDense dense{nullptr, 0, 0, 0, 0, 0, 0};
+    if (ctx->ndt_dense_on && ctx->tune_ndt_dense)
+        dense = NdtDense{ctx->ndt_dense.as<int>(), ctx->ndt_dense_lo[0], ctx->ndt_dense_lo[1],
+                         ctx->ndt_dense_lo[2], ctx->ndt_dense_dim[0], ctx->ndt_dense_dim[1],
+                         ctx->ndt_dense_dim[2]};
     (void) hipEventRecord(ctx->ev_a, ctx->stream);
     if (hess && grad)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<true, true>), dim3(nb), dim3(kBlock), 0,
-                           ctx->stream, src, n, vox, hk, hv, ctx->ndt_hmask, A, partials);
+                           ctx->stream, src, n, vox, hk, hv, ctx->ndt_hmask, dense, A, partials);
     else if (grad)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<true, false>), dim3(nb), dim3(kBlock), 0,
-                           ctx->stream, src, n, vox, hk, hv, ctx->ndt_hmask, A, partials);
+                           ctx->stream, src, n, vox, hk, hv, ctx->ndt_hmask, dense, A, partials);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<false, true>), dim3(nb), dim3(kBlock), 0,
-                           ctx->stream, src, n, vox, hk, hv, ctx->ndt_hmask, A, partials);
+                           ctx->stream, src, n, vox, hk, hv, ctx->ndt_hmask, dense, A, partials);
     (void) hipEventRecord(ctx->ev_b, ctx->stream);
     std::vector<double> h((size_t) nb * kNdtAcc);
     if (hipMemcpyAsync(h.data(), partials, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
