@@ -279,8 +279,10 @@ __device__ __forceinline__ double dot3d(const double *a, const double *b) {
 }
 
 // a[0] = score, a[1..6] = gradient, a[7..42] = Hessian (row-major 6x6)
+// (at least two waves per SIMD: the Hessian variants sit a couple of registers above the
+// 256-register line that would leave a single wave with nothing to hide its loads behind)
 template <bool GRAD, bool HESS>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2)))
     k_ndt_derivs(const float4 *__restrict__ src, unsigned n, const NdtVoxel *__restrict__ vox,
                  const unsigned long long *__restrict__ hkeys, const unsigned *__restrict__ hvals,
                  unsigned mask, NdtDense dense, NdtArgs A, double *__restrict__ partials) {
