@@ -637,6 +637,20 @@ static int launch_cov(wm_ctx *ctx, const GridDev &g, const float4 *q, size_t n, 
     return WM_OK;
 }
 
+// the neighbour list lives in registers, so its length is a template parameter: the smallest
+// instantiated size >= k keeps both the insertion cost (K compare-swaps per accepted candidate,
+// executed by the whole wave) and the register footprint down
+static int launch_cov_k(wm_ctx *ctx, const GridDev &g, const float4 *q, size_t n, const float4 *orig,
+                        int k, double eps, double *out) {
+    if (k <= 8) return launch_cov<8>(ctx, g, q, n, orig, k, eps, out, 0);
+    if (k <= 10) return launch_cov<10>(ctx, g, q, n, orig, k, eps, out, 0);
+    if (k <= 12) return launch_cov<12>(ctx, g, q, n, orig, k, eps, out, 0);
+    if (k <= 16) return launch_cov<16>(ctx, g, q, n, orig, k, eps, out, 0);
+    if (k <= 20) return launch_cov<20>(ctx, g, q, n, orig, k, eps, out, 0);
+    if (k <= 24) return launch_cov<24>(ctx, g, q, n, orig, k, eps, out, 0);
+    return launch_cov<32>(ctx, g, q, n, orig, k, eps, out, 0);
+}
+
 static int compute_covariances(wm_ctx *ctx, int k, double eps) {
     if (k > 32) return WM_ERR_ARG;
     const bool same = ctx->gicp_cov_k == k && ctx->gicp_cov_eps == eps;
@@ -645,10 +659,7 @@ static int compute_covariances(wm_ctx *ctx, int k, double eps) {
         WM_HIP(ctx, ctx->gicp_c2.reserve((ctx->n_tgt_input > 0 ? ctx->n_tgt_input : 1) * 9 * sizeof(double)));
         const GridDev &g = ctx->levels[0].d;
         const float4 *q = ctx->tgt_orig.as<float4>();
-        if (k <= 16)
-            WM_TRY(launch_cov<16>(ctx, g, q, ctx->n_tgt_input, q, k, eps, ctx->gicp_c2.as<double>(), 0));
-        else
-            WM_TRY(launch_cov<32>(ctx, g, q, ctx->n_tgt_input, q, k, eps, ctx->gicp_c2.as<double>(), 0));
+        WM_TRY(launch_cov_k(ctx, g, q, ctx->n_tgt_input, q, k, eps, ctx->gicp_c2.as<double>()));
         ctx->gicp_cov_tgt_valid = true;
     }
     if (!(ctx->gicp_cov_src_valid && same)) {
@@ -664,12 +675,8 @@ static int compute_covariances(wm_ctx *ctx, int k, double eps) {
                                     &ctx->src_grid, nullptr));
         }
         const float4 *q = ctx->src_sorted.as<float4>();
-        if (k <= 16)
-            WM_TRY(launch_cov<16>(ctx, ctx->src_grid.d, q, ctx->n_src, ctx->src_orig.as<float4>(), k, eps,
-                                  ctx->gicp_c1.as<double>(), 0));
-        else
-            WM_TRY(launch_cov<32>(ctx, ctx->src_grid.d, q, ctx->n_src, ctx->src_orig.as<float4>(), k, eps,
-                                  ctx->gicp_c1.as<double>(), 0));
+        WM_TRY(launch_cov_k(ctx, ctx->src_grid.d, q, ctx->n_src, ctx->src_orig.as<float4>(), k, eps,
+                            ctx->gicp_c1.as<double>()));
         ctx->gicp_cov_src_valid = true;
     }
     ctx->gicp_cov_k = k;
