@@ -10,9 +10,10 @@ from libwave_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("k", [10, 20])
+# one value per neighbour-list instantiation of k_gicp_cov (8, 10, 12, 16, 20, 24, 32) + edges
+@pytest.mark.parametrize("k", [3, 8, 10, 11, 16, 20, 23, 32])
 def test_gicp_covariances_match_oracle(wm, ctx, oracle, k):
-    ref, tgt, _ = synth.pair(20000, seed=4)
+    ref, tgt, _ = synth.pair(8000 if k > 20 else 20000, seed=4)
     ctx.set_source(ref)
     ctx.set_target(tgt)
     cs, ct = ctx.gicp_covariances(k=k, eps=1e-3)
