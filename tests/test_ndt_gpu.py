@@ -72,3 +72,30 @@ def test_ndt_rebuilds_model_when_target_or_res_changes(wm, ctx, oracle, testscan
     ctx.set_target(testscan[:20000])
     c = ctx.ndt_derivatives(np.zeros(6), res=1.0)[3]
     assert c == oracle.NdtGrid(testscan[:20000], 1.0).size()
+
+
+def test_ndt_hash_grid_and_dense_table_agree_bit_for_bit(wm, testscan, oracle):
+    """The dense cell -> voxel table (small lattices) and the open-addressing hash (the fallback
+    for lattices over 32 M cells) are two look-ups of the same voxels in the same neighbour order,
+    so every accumulated double must be identical; the hash path has no other coverage."""
+    import os
+    P = np.eye(4)
+    P[0, 3] = 0.2
+    target = oracle.transform_cloud_d(testscan, P)
+    pose = np.array([0.05, -0.02, 0.01, 0.004, -0.003, 0.006])
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["WM_TUNE_NDT_DENSE"] = mode
+        try:
+            c = wm.Context(0)   # the knob is read when a context is created
+        finally:
+            del os.environ["WM_TUNE_NDT_DENSE"]
+        c.set_source(testscan)
+        c.set_target(target)
+        out[mode] = (c.ndt_derivatives(pose, res=0.5), c.ndt_align(res=0.5))
+    (s1, g1, H1, n1), a1 = out["1"]
+    (s0, g0, H0, n0), a0 = out["0"]
+    assert n1 == n0 and s1 == s0
+    assert np.array_equal(g1, g0) and np.array_equal(H1, H0)
+    assert a1["rc"] == a0["rc"] == 0 and np.array_equal(a1["T"], a0["T"])
+    assert a1["iterations"] == a0["iterations"]
