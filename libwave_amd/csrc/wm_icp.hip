@@ -262,7 +262,14 @@ template <int PHASES>
 __global__ void __launch_bounds__(kBlock)
     k_reduce_solve(const double *__restrict__ partials, int nblocks, IcpDevState *st,
                    double *stats_io) {
-    if (st->done) return;
+    // The solve runs in ONE lane and touches two dozen fields of the state: read from HBM one
+    // dependent access at a time that is most of this kernel's ~10 us.  So the whole state is
+    // staged in LDS by all threads (one round trip), worked on there, and written back whole.
+    __shared__ IcpDevState s_st;
+    static_assert(sizeof(IcpDevState) % 4 == 0, "word-wise staging");
+    constexpr unsigned kWords = sizeof(IcpDevState) / 4;
+    for (unsigned w = threadIdx.x; w < kWords; w += kBlock)
+        reinterpret_cast<unsigned *>(&s_st)[w] = reinterpret_cast<const unsigned *>(st)[w];
     constexpr int kRows = kBlock / kAcc;  // row-lanes x kAcc components <= 256 threads
     __shared__ double lds[kRows][kAcc];
     if (PHASES & 1) {
@@ -279,8 +286,11 @@ __global__ void __launch_bounds__(kBlock)
             for (int u = 0; b < nblocks; b += kRows, ++u) s[u] += partials[(size_t) b * kAcc + c];
             lds[r][c] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
+    }
+    __syncthreads();
+    if (s_st.done) return;  // (uniform: every thread reads the staged copy)
+    if (threadIdx.x == 0) {
+        if (PHASES & 1) {
             double a[kAcc];
 #pragma unroll
             for (int k = 0; k < kAcc; ++k) {
@@ -290,19 +300,27 @@ __global__ void __launch_bounds__(kBlock)
                 a[k] = t;
             }
             double ex[kStatsLen];
-            expand_stats(st->mode, a, ex);
-            double *dst = (PHASES == 1 && stats_io) ? stats_io : st->stats;
+            expand_stats(s_st.mode, a, ex);
 #pragma unroll
-            for (int k = 0; k < kStatsLen; ++k) dst[k] = ex[k];
+            for (int k = 0; k < kStatsLen; ++k) s_st.stats[k] = ex[k];
+            if (PHASES == 1 && stats_io) {  // the block the all-reduce works on
+#pragma unroll
+                for (int k = 0; k < kStatsLen; ++k) stats_io[k] = ex[k];
+            }
+        } else if (stats_io) {  // PHASES == 2: the all-reduced block comes in
+#pragma unroll
+            for (int k = 0; k < kStatsLen; ++k) s_st.stats[k] = stats_io[k];
+        }
+        if (PHASES & 2) {
+            double stats[kStatsLen];
+#pragma unroll
+            for (int k = 0; k < kStatsLen; ++k) stats[k] = s_st.stats[k];
+            icp_apply_stats(&s_st, stats);
         }
     }
-    if (!(PHASES & 2)) return;
-    if (threadIdx.x != 0) return;
-    icp_apply_stats(st, (PHASES & 1) ? st->stats : (stats_io ? stats_io : st->stats));
-    if (!(PHASES & 1) && stats_io) {
-#pragma unroll
-        for (int k = 0; k < kStatsLen; ++k) st->stats[k] = stats_io[k];
-    }
+    __syncthreads();
+    for (unsigned w = threadIdx.x; w < kWords; w += kBlock)
+        reinterpret_cast<unsigned *>(st)[w] = reinterpret_cast<const unsigned *>(&s_st)[w];
 }
 
 // keys (source-sorted order) -> caller-order (match index, d2)

@@ -59,9 +59,14 @@ WM_HD bool jacobi_pair(double *W, double *V) {
         beta += W[k * 3 + J] * W[k * 3 + J];
         gamma += W[k * 3 + I] * W[k * 3 + J];
     }
-    if (fabs(gamma) <= 1e-300 || fabs(gamma) <= 2.3e-16 * sqrt(alpha * beta)) return false;
-    const double zeta = (beta - alpha) / (2.0 * gamma);
-    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    // columns already orthogonal to working precision?  (squared form: no square root)
+    if (fabs(gamma) <= 1e-300 || gamma * gamma <= (2.3e-16 * 2.3e-16) * (alpha * beta)) return false;
+    // tan of the rotation angle, smaller root: with zeta = (beta - alpha) / (2 gamma),
+    //   t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) = sign(d g) |g| / (|d| + sqrt(d^2 + g^2)),
+    // d = beta - alpha, g = 2 gamma -- one square root and one division instead of two and two
+    // (this runs in a single GPU lane: every f64 division / root is a few hundred cycles)
+    const double d = beta - alpha, g = 2.0 * gamma;
+    const double t = ((d >= 0) == (g >= 0) ? fabs(g) : -fabs(g)) / (fabs(d) + sqrt(d * d + g * g));
     const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
