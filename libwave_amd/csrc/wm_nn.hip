@@ -290,16 +290,18 @@ __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, fl
 
 // One lane per query: a certified radius search over a ladder of uniform grids
 // (cell size x2 per level).
-//   r <- the distance this query found in the previous iteration (x1.25), or half a
-//        fine cell on the first pass;
-//   repeat: scan the box of cells covering ball(q, r) on the finest level whose cell
-//           size is >= r; certified when best <= margin(box) or the box already
-//           covers max_corr; otherwise r <- best (if something was found: the next
-//           scan is then certain to certify) or 2r.
-// Light scans (r within ~a fine cell: every query once the clouds are roughly aligned)
-// run in the query's own lane.  Heavy scans are handed to the whole wavefront, one
-// query at a time (coop_scan_box), seeded with the radius its Morton neighbour needed.
-// The radius and level choices change the work, never the result.
+//   r <- the distance, under the NEW pose, to the point this query matched in the previous
+//        iteration (a real candidate, so an upper bound of the answer); half a fine cell when
+//        there is none;
+//   repeat: scan ball(q, min(r, sqrt(best))) inside the box of cells covering [q - r, q + r]^3,
+//           on the finest level whose cell is >= lane_lf * r (0.2 r: many short rows, each cut
+//           to the ball's chord); certified when best <= margin(box) or the box already covers
+//           max_corr; otherwise r <- best (something was found: the next scan is certain to
+//           certify) or 2 r.
+// Scans up to r_light (12 fine cells: all but ~1e-3 of the queries of a typical pair) run in the
+// query's own lane (scan_box).  Longer ones are handed to the whole wavefront, one query at a
+// time (coop_scan_box), seeded with the radius its Morton neighbour needed.
+// The radius, level and pruning choices change the work, never the result.
 constexpr int kNnBlock = 64;  // one wave per block: finest dispatch granularity, smallest tail
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5)))
     k_nn_grid(const LevelsDev *__restrict__ lv, const float4 *__restrict__ src, unsigned n,
