@@ -28,6 +28,7 @@ namespace wm {
 
 constexpr int kAcc = 18;  // 17 statistics + the number of source points this rank handled
 constexpr int kMaxStatBlocks = 256;
+constexpr int kStatUnroll = 4;  // points per thread per trip of the statistics kernel
 
 __device__ __forceinline__ void xform_pt(const float *T, const float4 &p, float &x, float &y,
                                          float &z) {
@@ -51,14 +52,14 @@ __global__ void __launch_bounds__(kBlock)
     for (int k = 0; k < kAcc; ++k) a[k] = 0.0;
     const bool slab_on = st->slab_on != 0;
     const float slab_lo = st->slab_lo, slab_hi = st->slab_hi;
-    // four points per trip: all twelve loads are issued before the first use, so a wave keeps
+    // kStatUnroll points per trip: all their loads are issued before the first use, so a wave keeps
     // ~10 KB in flight (the kernel is a pure HBM/L2 stream); accumulation order is unchanged
     const unsigned stride = gridDim.x * kBlock;
-    for (unsigned i0 = blockIdx.x * kBlock + threadIdx.x; i0 < n; i0 += 4 * stride) {
-        float4 p4v[4], q4v[4];
-        unsigned long long keyv[4];
+    for (unsigned i0 = blockIdx.x * kBlock + threadIdx.x; i0 < n; i0 += kStatUnroll * stride) {
+        float4 p4v[kStatUnroll], q4v[kStatUnroll];
+        unsigned long long keyv[kStatUnroll];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kStatUnroll; ++u) {
             const unsigned i = i0 + u * stride;
             const unsigned ic = i < n ? i : i0;
             p4v[u] = src[ic];
@@ -66,7 +67,7 @@ __global__ void __launch_bounds__(kBlock)
             q4v[u] = tgt[ic];  // match coordinates, written by the search (coalesced)
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kStatUnroll; ++u) {
             if (i0 + u * stride >= n) break;
             float fx, fy, fz;
             xform_pt(st->Tf, p4v[u], fx, fy, fz);
