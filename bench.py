@@ -66,6 +66,27 @@ def cpu_baseline(ref, tgt, iters_full, max_corr, cpu_iters):
     }
 
 
+def measured_copy_bandwidth(torch, dev):
+    """Device-to-device copy rate of this very box (GB/s, read + write bytes): the practical HBM
+    ceiling to hold next to the 8 TB/s specification (SURVEY 8(d) asks for it in the same run)."""
+    n = 1 << 28  # 1 GiB of f32 in, 1 GiB out
+    a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 10
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del a, b
+    return 2.0 * n * 4 / (ms * 1e-3) / 1e9
+
+
 def pmc_traffic_bytes():
     """HBM bytes per launch of the correspondence kernel from the committed PMC summary
     (profiles/pmc_latest.json, written by scripts/gpu_pmc.sh + scripts/pmc_to_json.py from
@@ -200,6 +221,7 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic_bytes() if world == 1 else None,
+                "peak_measured_copy": measured_copy_bandwidth(torch, dev) if world == 1 else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_us": nn_us, "launches_timed": nn_launches,
                 "note": "the kernel streams 64 B/point (source, previous key + match in; key + match "
