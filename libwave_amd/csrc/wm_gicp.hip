@@ -714,8 +714,7 @@ int wm_gicp_covariances(wm_ctx *ctx, int k, double eps, double *cov_source, doub
     WM_HIP(ctx, hipSetDevice(ctx->device));
     WM_TRY(compute_covariances(ctx, k, eps));
     if (cov_target)
-        WM_HIP(ctx, hipMemcpyAsync(cov_target, ctx->gicp_c2.p, ctx->n_tgt_input * 9 * sizeof(double),
-                                   hipMemcpyDeviceToHost, ctx->stream));
+        WM_TRY(copy_to_caller(ctx, cov_target, ctx->gicp_c2.p, ctx->n_tgt_input * 9 * sizeof(double)));
     WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (cov_source) {
         // un-permute from Morton order to caller order

@@ -34,9 +34,13 @@ int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, f
     if (n == 0) return WM_OK;
     const unsigned char *dptr = nullptr;
     if (mem == WM_MEM_HOST) {
+        // Caller memory is pageable.  A BLOCKING copy, after the stream has drained: the staging
+        // buffer may still feed the previous cloud's k_pack, and an asynchronous copy from
+        // pageable memory leaves the runtime pinning / unpinning the caller's pages behind our
+        // back (rare GPU faults on host addresses were seen with two 16 MB clouds back to back).
+        WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         WM_HIP(ctx, ctx->staging.reserve(n * stride));
-        WM_HIP(ctx, hipMemcpyAsync(ctx->staging.p, pts, n * stride, hipMemcpyHostToDevice,
-                                   ctx->stream));
+        WM_HIP(ctx, hipMemcpy(ctx->staging.p, pts, n * stride, hipMemcpyHostToDevice));
         dptr = ctx->staging.as<unsigned char>();
     } else {
         dptr = static_cast<const unsigned char *>(pts);

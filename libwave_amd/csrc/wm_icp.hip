@@ -397,22 +397,58 @@ static int upload_state(wm_ctx *ctx) {
     return WM_OK;
 }
 
-static int download_state(wm_ctx *ctx) {
-    WM_HIP(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state.p, sizeof(IcpDevState),
-                               hipMemcpyDeviceToHost, ctx->stream));
-    return fast_stream_wait(ctx);
+__global__ void k_signal(unsigned *flag, unsigned seq) { *flag = seq; }
+
+// One workgroup copies `words` 32-bit words from device memory into pinned host memory and
+// then raises the completion flag: data and flag are written by the SAME kernel, in that order
+// (barrier, then a system-scope fence by the signalling thread).  An asynchronous D2H copy
+// followed by a signalling kernel is NOT safe to poll on: the copy may be done by a DMA engine
+// whose writes are not ordered against the shader's flag write on the way to host memory
+// (seen as a stale point count / state on some machines, a few times in a hundred runs).
+__global__ void __launch_bounds__(kBlock)
+    k_fetch_signal(unsigned *dst, const unsigned *src, unsigned words, unsigned *flag, unsigned seq) {
+    for (unsigned w = threadIdx.x; w < words; w += kBlock) dst[w] = src[w];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        *(volatile unsigned *) flag = seq;
+    }
 }
 
-__global__ void k_signal(unsigned *flag, unsigned seq) { *flag = seq; }
+static int wait_flag(wm_ctx *ctx, unsigned seq);
+
+int fast_fetch(wm_ctx *ctx, void *dst_pinned, const void *src_dev, size_t bytes) {
+    if (bytes & 3) return WM_ERR_ARG;
+    if (!ctx->h_sig) {
+        WM_HIP(ctx, hipHostMalloc((void **) &ctx->h_sig, 64, hipHostMallocDefault));
+        *ctx->h_sig = 0;
+    }
+    const unsigned seq = ++ctx->sig_seq;
+    hipLaunchKernelGGL(k_fetch_signal, dim3(1), dim3(kBlock), 0, ctx->stream, (unsigned *) dst_pinned,
+                       (const unsigned *) src_dev, (unsigned) (bytes / 4), ctx->h_sig, seq);
+    WM_HIP(ctx, hipGetLastError());
+    return wait_flag(ctx, seq);
+}
+
+static int download_state(wm_ctx *ctx) {
+    return fast_fetch(ctx, ctx->h_state, ctx->d_state.p, sizeof(IcpDevState));
+}
 
 int fast_stream_wait(wm_ctx *ctx) {
     if (!ctx->h_sig) {
         WM_HIP(ctx, hipHostMalloc((void **) &ctx->h_sig, 64, hipHostMallocDefault));
         *ctx->h_sig = 0;
     }
+    // ONLY after kernels that wrote their results into pinned memory themselves (kernel ->
+    // kernel order in one stream is also the order of their host writes); see fast_fetch for
+    // results that still sit in device memory
     const unsigned seq = ++ctx->sig_seq;
     hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, ctx->stream, ctx->h_sig, seq);
     WM_HIP(ctx, hipGetLastError());
+    return wait_flag(ctx, seq);
+}
+
+static int wait_flag(wm_ctx *ctx, unsigned seq) {
     // spin briefly (the waits this is for are tens of microseconds), then let the runtime block:
     // many worker threads spinning for long would starve each other and the runtime's helpers
     volatile unsigned *flag = ctx->h_sig;
@@ -425,6 +461,12 @@ int fast_stream_wait(wm_ctx *ctx) {
             break;
         }
     }
+    return WM_OK;
+}
+
+int copy_to_caller(wm_ctx *ctx, void *dst, const void *src_dev, size_t bytes) {
+    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bytes) WM_HIP(ctx, hipMemcpy(dst, src_dev, bytes, hipMemcpyDeviceToHost));
     return WM_OK;
 }
 
@@ -515,6 +557,7 @@ int wm_ctx_create(wm_ctx **out, int device) {
     }
     ctx->stream = ctx->own_stream;
     if (const char *e = getenv("WM_TUNE_NDT_DENSE")) ctx->tune_ndt_dense = atoi(e);
+    if (const char *e = getenv("WM_TRACE")) ctx->trace = atoi(e) != 0;
     if (const char *e = getenv("WM_TUNE_LANE_LF")) {
         const float v = (float) atof(e);
         if (v > 0) ctx->tune_lane_lf = v;
@@ -769,12 +812,8 @@ static int unpack_correspondences(wm_ctx *ctx, int32_t *match_idx, float *d2, si
                            ctx->corr_tmp_d2.as<float>());
         WM_HIP(ctx, hipGetLastError());
     }
-    if (match_idx)
-        WM_HIP(ctx, hipMemcpyAsync(match_idx, ctx->corr_tmp_idx.p, n_in * sizeof(int),
-                                   hipMemcpyDeviceToHost, ctx->stream));
-    if (d2)
-        WM_HIP(ctx, hipMemcpyAsync(d2, ctx->corr_tmp_d2.p, n_in * sizeof(float),
-                                   hipMemcpyDeviceToHost, ctx->stream));
+    if (match_idx) WM_TRY(copy_to_caller(ctx, match_idx, ctx->corr_tmp_idx.p, n_in * sizeof(int)));
+    if (d2) WM_TRY(copy_to_caller(ctx, d2, ctx->corr_tmp_d2.p, n_in * sizeof(float)));
     WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return WM_OK;
 }
@@ -799,8 +838,11 @@ int wm_icp_match(wm_ctx *ctx, const void *ref, size_t n_ref, const void *target,
     WM_HIP(ctx, ctx->ds_tgt.reserve(cap_t * sizeof(float4)));
     float4 *d_ref = ctx->match_ref.as<float4>(), *d_tgt = ctx->match_tgt.as<float4>();
     float4 *ds_ref = ctx->ds_ref.as<float4>(), *ds_tgt = ctx->ds_tgt.as<float4>();
+    WM_TRACE(ctx, "match: begin");
     WM_TRY(pack_cloud(ctx, ref, n_ref, stride, mem, d_ref));
+    WM_TRACE(ctx, "match: packed ref");
     WM_TRY(pack_cloud(ctx, target, n_target, stride, mem, d_tgt));
+    WM_TRACE(ctx, "match: packed target");
     wm_icp_params prm = *p;
     wm_icp_stats last, total;
     memset(&total, 0, sizeof(total));
@@ -811,15 +853,20 @@ int wm_icp_match(wm_ctx *ctx, const void *ref, size_t n_ref, const void *target,
         const float leaf = (float) (pow(2, i) * res);  // icp.cpp:80
         size_t nr = 0, nt = 0;
         WM_TRY(voxel_downsample_dev(ctx, d_ref, n_ref, leaf, ds_ref, &nr));
+        WM_TRACE(ctx, "match: voxel ref");
         WM_TRY(voxel_downsample_dev(ctx, d_tgt, n_target, leaf, ds_tgt, &nt));
+        WM_TRACE(ctx, "match: voxel target");
         if (steps > 0) {
             WM_TRY(transform_cloud_dev(ctx, ds_ref, nr, running, ds_ref));  // icp.cpp:84-86
             prm.max_corr = pow(2, i) * p->max_corr;                          // icp.cpp:93-94
         }
         WM_TRY(wm_set_source(ctx, ds_ref, nr, sizeof(float4), WM_MEM_DEVICE));
+        WM_TRACE(ctx, "match: set_source");
         WM_TRY(wm_set_target(ctx, ds_tgt, nt, sizeof(float4), WM_MEM_DEVICE));
+        WM_TRACE(ctx, "match: set_target");
         double Ti[16];
         const int rc = wm_icp_align(ctx, &prm, Ti, &last);
+        WM_TRACE(ctx, "match: align");
         total.align_ms += last.align_ms;
         total.nn_ms += last.nn_ms;
         total.nn_launches += last.nn_launches;

@@ -311,9 +311,7 @@ __global__ void __launch_bounds__(kBlock)
 
 static int reduce_partials(wm_ctx *ctx, int nblocks, int nacc, double *out) {
     std::vector<double> h((size_t) nblocks * kInfoAcc);
-    WM_HIP(ctx, hipMemcpyAsync(h.data(), ctx->partials.p, h.size() * sizeof(double),
-                               hipMemcpyDeviceToHost, ctx->stream));
-    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    WM_TRY(copy_to_caller(ctx, h.data(), ctx->partials.p, h.size() * sizeof(double)));
     for (int k = 0; k < nacc; ++k) {
         double s = 0;
         for (int b = 0; b < nblocks; ++b) s += h[(size_t) b * kInfoAcc + k];  // fixed order

@@ -1,6 +1,7 @@
 // wm_internal.hpp -- context, device-side structs and helpers shared by the
 // HIP translation units of libwavematch_hip.so (gfx950 only).
 #pragma once
+#include <stdio.h>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -133,6 +134,7 @@ struct wm_ctx {
     int n_levels = 0;
     double levels_max_corr = -1;
     float grid_cell_override = 0;
+    bool trace = false;
     float tune_lane_lf = 0.2f;   // lane-serial scan: finest level with cell size >= this x radius
     float tune_coop_lf = 0.5f;   // cooperative scan: finest level with cell size >= this x radius
     float tune_r_light = 12.0f;  // lane-serial vs cooperative scan threshold, in level-0 cells
@@ -201,9 +203,26 @@ int ensure_levels(wm_ctx *ctx, double max_corr);
 // wait for everything queued on the ctx stream, polling a pinned flag (a few microseconds
 // instead of hipStreamSynchronize's wake-up latency); for host loops that sync hundreds of times
 int fast_stream_wait(wm_ctx *ctx);
+// fetch a few words from device memory into pinned host memory and wait for them (copy and
+// completion flag written by one kernel, in order)
+int fast_fetch(wm_ctx *ctx, void *dst_pinned, const void *src_dev, size_t bytes);
+// developer tracing (env WM_TRACE=1): drain the stream and print a marker, so that a GPU fault can
+// be pinned to the stage that was running
+#define WM_TRACE(ctx, what)                                                     \
+    do {                                                                        \
+        if ((ctx)->trace) {                                                     \
+            (void) hipStreamSynchronize((ctx)->stream);                         \
+            fprintf(stderr, "[wm] %s\n", what);                                 \
+            fflush(stderr);                                                     \
+        }                                                                       \
+    } while (0)
 // pinned, device-visible host scratch of at least `bytes` (kernels write small results into it
 // directly; the host reads them after fast_stream_wait)
 void *pinned_scratch(wm_ctx *ctx, size_t bytes);
+// device -> caller (pageable) memory: drain the stream, then a BLOCKING copy.  Asynchronous copies
+// to / from pageable memory leave the runtime pinning and unpinning the caller's pages on its own
+// schedule; rare GPU faults on host addresses were traced to that path (see pack_cloud).
+int copy_to_caller(wm_ctx *ctx, void *dst, const void *src_dev, size_t bytes);
 int exclusive_scan(wm_ctx *ctx, const unsigned *in, size_t n, unsigned *out);
 
 // ---- wm_voxel.hip

@@ -623,8 +623,7 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
                            ctx->stream, src, n, vox, hk, hv, ctx->ndt_hmask, dense, A, partials);
     (void) hipEventRecord(ctx->ev_b, ctx->stream);
     std::vector<double> h((size_t) nb * kNdtAcc);
-    if (hipMemcpyAsync(h.data(), partials, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    if (copy_to_caller(ctx, h.data(), partials, h.size() * 8) != WM_OK) {
         ctx->last_error = "ndt_eval: HIP error";
         *rc = WM_ERR_HIP;
         return 0;

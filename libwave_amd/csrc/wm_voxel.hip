@@ -152,8 +152,7 @@ int voxel_downsample_dev(wm_ctx *ctx, const float4 *in, size_t n, float leaf, fl
     WM_HIP(ctx, hipGetLastError());
     unsigned *h_total = (unsigned *) pinned_scratch(ctx, 0);
     if (!h_total) return WM_ERR_HIP;
-    WM_HIP(ctx, hipMemcpyAsync(h_total, seg + n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    WM_TRY(fast_stream_wait(ctx));
+    WM_TRY(fast_fetch(ctx, h_total, seg + n, 4));
     const unsigned total = *h_total;
     *n_out = total;
     return WM_OK;
@@ -216,8 +215,7 @@ static int export_cloud(wm_ctx *ctx, const float4 *dev, size_t n, void *out, siz
     hipLaunchKernelGGL(k_unpack, dim3((unsigned) ((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                        ctx->stream, dev, (unsigned) n, stride, dst);
     WM_HIP(ctx, hipGetLastError());
-    if (mem == WM_MEM_HOST)
-        WM_HIP(ctx, hipMemcpyAsync(out, dst, n * stride, hipMemcpyDeviceToHost, ctx->stream));
+    if (mem == WM_MEM_HOST) WM_TRY(copy_to_caller(ctx, out, dst, n * stride));
     WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return WM_OK;
 }
