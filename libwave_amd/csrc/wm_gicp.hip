@@ -22,7 +22,7 @@
 namespace wm {
 
 constexpr int kGicpAcc = 13;
-constexpr int kGicpBlocks = 1024;
+constexpr int kGicpBlocks = 512;  // partial rows per objective evaluation (fetched by one wave)
 
 __device__ __forceinline__ unsigned long long g_make_key(float d2, unsigned idx) {
     return ((unsigned long long) __float_as_uint(d2) << 32) | idx;
@@ -352,8 +352,9 @@ static double gicp_fdf(GicpFn &F, const double x[6], double g[6]) {
     int nb = (int) ((n + kBlock - 1) / kBlock);
     if (nb > kGicpBlocks) nb = kGicpBlocks;
     if (nb < 1) nb = 1;
-    // The partial sums are written straight into pinned, device-visible host memory: no copy
-    // kernel, no staging -- this loop runs ~270 times per registration and is latency-bound.
+    // The partial sums land in device memory and are fetched into pinned memory by one
+    // wavefront (fast_fetch): no copy engine, no pageable staging -- this loop runs ~270 times
+    // per registration and is latency-bound.
     if (!ctx->h_gicp &&
         hipHostMalloc((void **) &ctx->h_gicp, sizeof(double) * kGicpBlocks * kGicpAcc,
                       hipHostMallocDefault) != hipSuccess) {
@@ -364,9 +365,9 @@ static double gicp_fdf(GicpFn &F, const double x[6], double g[6]) {
     if (ctx->gicp_profile) (void) hipEventRecord(ctx->ev_a, ctx->stream);
     hipLaunchKernelGGL(k_gicp_fdf, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->src_sorted.as<float4>(),
                        n, ctx->keys.as<unsigned long long>(), ctx->match_pt.as<float4>(),
-                       ctx->gicp_mahal.as<double>(), A, ctx->h_gicp);
+                       ctx->gicp_mahal.as<double>(), A, ctx->partials.as<double>());
     if (ctx->gicp_profile) (void) hipEventRecord(ctx->ev_b, ctx->stream);
-    if (fast_stream_wait(ctx) != WM_OK) {
+    if (fast_fetch(ctx, ctx->h_gicp, ctx->partials.p, sizeof(double) * (size_t) nb * kGicpAcc) != WM_OK) {
         F.rc = WM_ERR_HIP;
         return 0;
     }

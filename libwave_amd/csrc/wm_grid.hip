@@ -34,10 +34,8 @@ int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, f
     if (n == 0) return WM_OK;
     const unsigned char *dptr = nullptr;
     if (mem == WM_MEM_HOST) {
-        // Caller memory is pageable.  A BLOCKING copy, after the stream has drained: the staging
-        // buffer may still feed the previous cloud's k_pack, and an asynchronous copy from
-        // pageable memory leaves the runtime pinning / unpinning the caller's pages behind our
-        // back (rare GPU faults on host addresses were seen with two 16 MB clouds back to back).
+        // Caller memory is pageable: a blocking copy, after the stream has drained (the staging
+        // buffer may still feed the previous cloud's k_pack)
         WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         WM_HIP(ctx, ctx->staging.reserve(n * stride));
         WM_HIP(ctx, hipMemcpy(ctx->staging.p, pts, n * stride, hipMemcpyHostToDevice));
@@ -120,12 +118,14 @@ int compute_bbox(wm_ctx *ctx, const float4 *pts, size_t n, Bbox *out, size_t *n_
     if (n == 0) return WM_OK;
     unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
     if (blocks > (unsigned) kBboxBlocks) blocks = kBboxBlocks;
-    // the partials go straight into pinned host memory: no copy, and a polled wait
+    // partials in device memory, fetched into pinned memory by one wavefront (fast_fetch)
     float *res = (float *) pinned_scratch(ctx, 8 * sizeof(float) * kBboxBlocks);
     if (!res) return WM_ERR_HIP;
-    hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, n, res);
+    WM_HIP(ctx, ctx->bbox_buf.reserve(8 * sizeof(float) * kBboxBlocks));
+    hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, n,
+                       ctx->bbox_buf.as<float>());
     WM_HIP(ctx, hipGetLastError());
-    WM_TRY(fast_stream_wait(ctx));
+    WM_TRY(fast_fetch(ctx, res, ctx->bbox_buf.p, 8 * sizeof(float) * blocks));
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     size_t cnt = 0;
     for (unsigned b = 0; b < blocks; ++b) {
@@ -397,9 +397,10 @@ int build_grid_level(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, f
         if (blocks > (unsigned) kOccBlocks) blocks = kOccBlocks;
         unsigned *part = (unsigned *) pinned_scratch(ctx, sizeof(unsigned) * kOccBlocks);
         if (!part) return WM_ERR_HIP;
+        WM_HIP(ctx, ctx->bbox_buf.reserve(sizeof(unsigned) * kOccBlocks));
         hipLaunchKernelGGL(k_count_occupied, dim3(blocks), dim3(kBlock), 0, ctx->stream,
-                           lvl->cell_start.as<unsigned>(), (size_t) ncells, part);
-        WM_TRY(fast_stream_wait(ctx));
+                           lvl->cell_start.as<unsigned>(), (size_t) ncells, ctx->bbox_buf.as<unsigned>());
+        WM_TRY(fast_fetch(ctx, part, ctx->bbox_buf.p, sizeof(unsigned) * blocks));
         uint64_t occ = 0;
         for (unsigned b = 0; b < blocks; ++b) occ += part[b];
         *avg_occupancy = occ ? (double) n / occ : 0.0;

@@ -397,25 +397,27 @@ static int upload_state(wm_ctx *ctx) {
     return WM_OK;
 }
 
-__global__ void k_signal(unsigned *flag, unsigned seq) { *flag = seq; }
-
-// One workgroup copies `words` 32-bit words from device memory into pinned host memory and
-// then raises the completion flag: data and flag are written by the SAME kernel, in that order
-// (barrier, then a system-scope fence by the signalling thread).  An asynchronous D2H copy
-// followed by a signalling kernel is NOT safe to poll on: the copy may be done by a DMA engine
-// whose writes are not ordered against the shader's flag write on the way to host memory
-// (seen as a stale point count / state on some machines, a few times in a hundred runs).
-__global__ void __launch_bounds__(kBlock)
+// Small results the host has to wait for (bounding-box / occupancy partials, the iteration
+// state, a voxel count, the GICP objective's sums) are produced in DEVICE memory and then
+// fetched by ONE wavefront that copies them into pinned host memory, executes a system-scope
+// fence in every lane, and only then raises the completion flag the host polls.  Anything
+// weaker was seen to fail a few times in a hundred runs on some machines: a flag written by a
+// later kernel (or a DMA copy followed by a signalling kernel) can reach host memory BEFORE
+// data written by other compute units / engines, which travel other routes through the fabric
+// -- the host then reads stale partials (a bounding-box count larger than the cloud, a stale
+// voxel count) and the next kernel walks off the end of a buffer.
+__global__ void __launch_bounds__(64)
     k_fetch_signal(unsigned *dst, const unsigned *src, unsigned words, unsigned *flag, unsigned seq) {
-    for (unsigned w = threadIdx.x; w < words; w += kBlock) dst[w] = src[w];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence_system();
-        *(volatile unsigned *) flag = seq;
+    if ((words & 3u) == 0 && (((size_t) dst | (size_t) src) & 15u) == 0) {
+        const uint4 *s4 = (const uint4 *) src;
+        uint4 *d4 = (uint4 *) dst;
+        for (unsigned w = threadIdx.x; w < words / 4; w += 64u) d4[w] = s4[w];
+    } else {
+        for (unsigned w = threadIdx.x; w < words; w += 64u) dst[w] = src[w];
     }
+    __threadfence_system();  // every lane: all of this wave's stores are performed system-wide
+    if (threadIdx.x == 0) *(volatile unsigned *) flag = seq;
 }
-
-static int wait_flag(wm_ctx *ctx, unsigned seq);
 
 int fast_fetch(wm_ctx *ctx, void *dst_pinned, const void *src_dev, size_t bytes) {
     if (bytes & 3) return WM_ERR_ARG;
@@ -424,31 +426,9 @@ int fast_fetch(wm_ctx *ctx, void *dst_pinned, const void *src_dev, size_t bytes)
         *ctx->h_sig = 0;
     }
     const unsigned seq = ++ctx->sig_seq;
-    hipLaunchKernelGGL(k_fetch_signal, dim3(1), dim3(kBlock), 0, ctx->stream, (unsigned *) dst_pinned,
+    hipLaunchKernelGGL(k_fetch_signal, dim3(1), dim3(64), 0, ctx->stream, (unsigned *) dst_pinned,
                        (const unsigned *) src_dev, (unsigned) (bytes / 4), ctx->h_sig, seq);
     WM_HIP(ctx, hipGetLastError());
-    return wait_flag(ctx, seq);
-}
-
-static int download_state(wm_ctx *ctx) {
-    return fast_fetch(ctx, ctx->h_state, ctx->d_state.p, sizeof(IcpDevState));
-}
-
-int fast_stream_wait(wm_ctx *ctx) {
-    if (!ctx->h_sig) {
-        WM_HIP(ctx, hipHostMalloc((void **) &ctx->h_sig, 64, hipHostMallocDefault));
-        *ctx->h_sig = 0;
-    }
-    // ONLY after kernels that wrote their results into pinned memory themselves (kernel ->
-    // kernel order in one stream is also the order of their host writes); see fast_fetch for
-    // results that still sit in device memory
-    const unsigned seq = ++ctx->sig_seq;
-    hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, ctx->stream, ctx->h_sig, seq);
-    WM_HIP(ctx, hipGetLastError());
-    return wait_flag(ctx, seq);
-}
-
-static int wait_flag(wm_ctx *ctx, unsigned seq) {
     // spin briefly (the waits this is for are tens of microseconds), then let the runtime block:
     // many worker threads spinning for long would starve each other and the runtime's helpers
     volatile unsigned *flag = ctx->h_sig;
@@ -462,6 +442,10 @@ static int wait_flag(wm_ctx *ctx, unsigned seq) {
         }
     }
     return WM_OK;
+}
+
+static int download_state(wm_ctx *ctx) {
+    return fast_fetch(ctx, ctx->h_state, ctx->d_state.p, sizeof(IcpDevState));
 }
 
 int copy_to_caller(wm_ctx *ctx, void *dst, const void *src_dev, size_t bytes) {
@@ -641,11 +625,15 @@ int wm_set_source(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem
     DevBuf &tmp = ctx->src_orig;
     WM_HIP(ctx, tmp.reserve(n * sizeof(float4)));
     WM_HIP(ctx, ctx->src_sorted.reserve(n * sizeof(float4)));
+    if (ctx->trace) fprintf(stderr, "[wm] set_source: n=%zu stride=%zu mem=%d ptr=%p\n", n, stride, mem, pts);
     WM_TRY(pack_cloud(ctx, pts, n, stride, mem, tmp.as<float4>()));
+    WM_TRACE(ctx, "set_source: packed");
     Bbox &bb = ctx->src_bbox;
     size_t valid = 0;
     WM_TRY(compute_bbox(ctx, tmp.as<float4>(), n, &bb, &valid));
+    if (ctx->trace) fprintf(stderr, "[wm] set_source: bbox valid=%zu lo=(%g %g %g) hi=(%g %g %g)\n", valid, bb.lo[0], bb.lo[1], bb.lo[2], bb.hi[0], bb.hi[1], bb.hi[2]);
     WM_TRY(morton_sort(ctx, tmp.as<float4>(), n, bb, valid, ctx->src_sorted.as<float4>()));
+    WM_TRACE(ctx, "set_source: sorted");
     ctx->n_src = valid;
     return WM_OK;
 }
@@ -856,8 +844,10 @@ int wm_icp_match(wm_ctx *ctx, const void *ref, size_t n_ref, const void *target,
         WM_TRACE(ctx, "match: voxel ref");
         WM_TRY(voxel_downsample_dev(ctx, d_tgt, n_target, leaf, ds_tgt, &nt));
         WM_TRACE(ctx, "match: voxel target");
+        if (ctx->trace) fprintf(stderr, "[wm] match: leaf=%g nr=%zu nt=%zu\n", leaf, nr, nt);
         if (steps > 0) {
             WM_TRY(transform_cloud_dev(ctx, ds_ref, nr, running, ds_ref));  // icp.cpp:84-86
+            WM_TRACE(ctx, "match: transformed");
             prm.max_corr = pow(2, i) * p->max_corr;                          // icp.cpp:93-94
         }
         WM_TRY(wm_set_source(ctx, ds_ref, nr, sizeof(float4), WM_MEM_DEVICE));

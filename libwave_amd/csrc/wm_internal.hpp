@@ -150,7 +150,7 @@ struct wm_ctx {
     wm::IcpDevState *h_state = nullptr;  // pinned
     void *h_scratch = nullptr;           // pinned, device-visible scratch (reduction partials, level table)
     size_t h_scratch_bytes = 0;
-    unsigned *h_sig = nullptr;           // pinned: completion flag polled by fast_stream_wait
+    unsigned *h_sig = nullptr;           // pinned: completion flag polled by fast_fetch
     unsigned sig_seq = 0;
     double *h_gicp = nullptr;            // pinned, device-visible: the GICP objective's partial sums land here
     bool gicp_profile = false;           // HIP events around every objective evaluation (fdf_kernel_ms)
@@ -200,11 +200,8 @@ int build_grid_level(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, f
 int morton_sort(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, size_t n_valid,
                 float4 *out);
 int ensure_levels(wm_ctx *ctx, double max_corr);
-// wait for everything queued on the ctx stream, polling a pinned flag (a few microseconds
-// instead of hipStreamSynchronize's wake-up latency); for host loops that sync hundreds of times
-int fast_stream_wait(wm_ctx *ctx);
-// fetch a few words from device memory into pinned host memory and wait for them (copy and
-// completion flag written by one kernel, in order)
+// fetch a small result from device memory into pinned host memory and wait for it (copy, fence
+// and completion flag by one wavefront; see k_fetch_signal)
 int fast_fetch(wm_ctx *ctx, void *dst_pinned, const void *src_dev, size_t bytes);
 // developer tracing (env WM_TRACE=1): drain the stream and print a marker, so that a GPU fault can
 // be pinned to the stage that was running
@@ -217,11 +214,10 @@ int fast_fetch(wm_ctx *ctx, void *dst_pinned, const void *src_dev, size_t bytes)
         }                                                                       \
     } while (0)
 // pinned, device-visible host scratch of at least `bytes` (kernels write small results into it
-// directly; the host reads them after fast_stream_wait)
+// through fast_fetch; the host reads them once its flag has arrived)
 void *pinned_scratch(wm_ctx *ctx, size_t bytes);
-// device -> caller (pageable) memory: drain the stream, then a BLOCKING copy.  Asynchronous copies
-// to / from pageable memory leave the runtime pinning and unpinning the caller's pages on its own
-// schedule; rare GPU faults on host addresses were traced to that path (see pack_cloud).
+// device -> caller (pageable) memory: drain the stream, then a blocking copy (the caller's pages
+// are pinned and unpinned by the runtime inside that one call)
 int copy_to_caller(wm_ctx *ctx, void *dst, const void *src_dev, size_t bytes);
 int exclusive_scan(wm_ctx *ctx, const unsigned *in, size_t n, unsigned *out);
 
