@@ -140,7 +140,7 @@ __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float q
             const float rz = fmaxf(fmaxf((float) zz - fz, fz - (float) (zz + 1)), 0.f);
             const float rho2 = ry * ry + rz * rz;
             const float hx = __builtin_amdgcn_sqrtf(fmaxf(c0 - rho2, 0.f)) * 1.00001f + g.slack;
-            const int xl = max(xa, (int) floorf(fx - hx)), xh = min(xb, (int) floorf(fx + hx));
+            const int xl = max(xa, __float2int_rd(fx - hx)), xh = min(xb, __float2int_rd(fx + hx));
             const bool ok = zz <= zb && !(rho2 > lim2) && xl <= xh;
             const unsigned base = ((unsigned) zz * g.ny + yy) * g.nx;
             a0[u] = ok ? base + xl : 0u;
