@@ -34,6 +34,14 @@ def test_cpp_yaml_params_on_cpu():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_cpp_construction_cases_on_cpu():
+    """Matcher / MultiMatcher construction and teardown need no device (contexts are created at
+    the first match): the four *.initialization cases, incl. the worker pool's start and join."""
+    r = _run("initialization")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "4 tests ran, 0 failed" in r.stdout
+
+
 @pytest.mark.gpu
 def test_reference_gtest_cases_pass_on_gpu():
     r = _run()
