@@ -102,9 +102,11 @@ __device__ __forceinline__ unsigned long long scan_run(const float4 *__restrict_
 //     outside the ball cost nothing, rows near its rim a cell or two.
 // Pruning changes the work, never the result.
 constexpr int kRowChunk = 6;
+constexpr int kLayeredRows = 18;  // boxes with more (y,z) rows than this are walked layer by layer
 __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float qx, float qy,
                                                        float qz, float r, unsigned long long best,
-                                                       float *margin, uint2 *runs, unsigned lane) {
+                                                       float *margin, uint2 *runs, unsigned lane,
+                                                       bool allow_layered) {
     const float big = 4.0e6f;  // clamp in float so far-away queries cannot overflow the int cast
     const float fx = fminf(fmaxf((qx - g.ox) * g.inv_h, -big), big);
     const float fy = fminf(fmaxf((qy - g.oy) * g.inv_h, -big), big);
@@ -121,34 +123,8 @@ __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float q
     const int ya = max(y0, 0), yb = min(y1, g.ny - 1);
     const int za = max(z0, 0), zb = min(z1, g.nz - 1);
     if (xa > xb || ya > yb || za > zb) return best;
-    int yy = ya, zz = za;  // row cursor
-    while (zz <= zb) {
-        const float Rb =
-            __builtin_amdgcn_sqrtf(__uint_as_float((unsigned) (best >> 32))) * g.inv_h * 1.00001f;
-        const float lim = Rb + g.slack;
-        const float lim2 = lim * lim, c0 = Rb * Rb + 2.f * g.slack * lim;
-        // addresses first, then all look-ups back to back and unconditional (a row outside the
-        // ball reads cell_start[0] twice: an empty run) -- with predicated loads the compiler
-        // interleaves address arithmetic, branches and waits, and the twelve look-ups of a
-        // chunk no longer overlap
-        unsigned a0[kRowChunk], a1[kRowChunk];
-#pragma unroll
-        for (int u = 0; u < kRowChunk; ++u) {
-            // distance from the query to row (yy, zz) along y and z, in cells: positive on the
-            // far side, 0 inside the query's own row (branch-free form of the three cases)
-            const float ry = fmaxf(fmaxf((float) yy - fy, fy - (float) (yy + 1)), 0.f);
-            const float rz = fmaxf(fmaxf((float) zz - fz, fz - (float) (zz + 1)), 0.f);
-            const float rho2 = ry * ry + rz * rz;
-            const float hx = __builtin_amdgcn_sqrtf(fmaxf(c0 - rho2, 0.f)) * 1.00001f + g.slack;
-            const int xl = max(xa, __float2int_rd(fx - hx)), xh = min(xb, __float2int_rd(fx + hx));
-            const bool ok = zz <= zb && !(rho2 > lim2) && xl <= xh;
-            const unsigned base = ((unsigned) zz * g.ny + yy) * g.nx;
-            a0[u] = ok ? base + xl : 0u;
-            a1[u] = ok ? base + xh + 1 : 0u;
-            const bool wrap = yy >= yb;
-            yy = wrap ? ya : yy + 1;
-            zz += wrap;
-        }
+    // look-ups of one chunk of rows (addresses a0/a1), then the walk over its non-empty runs
+    auto lookup_and_walk = [&](const unsigned (&a0)[kRowChunk], const unsigned (&a1)[kRowChunk]) {
         unsigned rs[kRowChunk], re[kRowChunk];
 #pragma unroll
         for (int u = 0; u < kRowChunk; ++u) {
@@ -191,6 +167,79 @@ __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float q
                 e = run.y;
             }
         }
+    };
+    // Big boxes (queries still far from their neighbour: dozens of rows, most of them empty
+    // space) are walked layer by layer, the z-layers in lock-step across the wave: what depends
+    // on the layer only (its z distance, the y chord of the ball in it, its base address) is
+    // computed once per layer, and only the rows inside the y chord are enumerated at all.
+    const bool layered =
+        allow_layered && __popcll(__ballot((yb - ya + 1) * (zb - za + 1) > kLayeredRows)) >= 8;
+    if (layered) {
+        for (int kz = 0;; ++kz) {
+            const int zz = za + kz;
+            const bool zact = zz <= zb;
+            if (__ballot(zact) == 0ull) break;
+            const float Rb =
+                __builtin_amdgcn_sqrtf(__uint_as_float((unsigned) (best >> 32))) * g.inv_h * 1.00001f;
+            const float lim = Rb + g.slack;
+            const float lim2 = lim * lim, c0 = Rb * Rb + 2.f * g.slack * lim;
+            const float rz = fmaxf(fmaxf((float) zz - fz, fz - (float) (zz + 1)), 0.f);
+            const float rz2 = rz * rz;
+            // rows of this layer that can touch the ball: their y distance is <= sqrt(lim^2 - rz^2)
+            const float hy = __builtin_amdgcn_sqrtf(fmaxf(lim2 - rz2, 0.f)) * 1.00001f;
+            const bool zin = zact && !(rz2 > lim2);
+            const int yl = zin ? max(ya, __float2int_rd(fy - hy)) : 1;
+            const int yh = zin ? min(yb, __float2int_rd(fy + hy)) : 0;
+            const unsigned basez = (unsigned) zz * g.ny * g.nx;
+            for (int y0 = yl; __ballot(y0 <= yh) != 0ull; y0 += kRowChunk) {
+                unsigned a0[kRowChunk], a1[kRowChunk];
+#pragma unroll
+                for (int u = 0; u < kRowChunk; ++u) {
+                    const int yy = y0 + u;
+                    const float yf = (float) yy;
+                    const float ry = fmaxf(fmaxf(yf - fy, fy - (yf + 1.f)), 0.f);
+                    const float rho2 = ry * ry + rz2;
+                    const float hx = __builtin_amdgcn_sqrtf(fmaxf(c0 - rho2, 0.f)) * 1.00001f + g.slack;
+                    const int xl = max(xa, __float2int_rd(fx - hx)), xh = min(xb, __float2int_rd(fx + hx));
+                    const bool ok = yy <= yh && !(rho2 > lim2) && xl <= xh;
+                    const unsigned base = basez + (unsigned) yy * g.nx;
+                    a0[u] = ok ? base + xl : 0u;
+                    a1[u] = ok ? base + xh + 1 : 0u;
+                }
+                lookup_and_walk(a0, a1);
+            }
+        }
+        return best;
+    }
+    int yy = ya, zz = za;  // row cursor
+    while (zz <= zb) {
+        const float Rb =
+            __builtin_amdgcn_sqrtf(__uint_as_float((unsigned) (best >> 32))) * g.inv_h * 1.00001f;
+        const float lim = Rb + g.slack;
+        const float lim2 = lim * lim, c0 = Rb * Rb + 2.f * g.slack * lim;
+        // addresses first, then all look-ups back to back and unconditional (a row outside the
+        // ball reads cell_start[0] twice: an empty run) -- with predicated loads the compiler
+        // interleaves address arithmetic, branches and waits, and the twelve look-ups of a
+        // chunk no longer overlap
+        unsigned a0[kRowChunk], a1[kRowChunk];
+#pragma unroll
+        for (int u = 0; u < kRowChunk; ++u) {
+            // distance from the query to row (yy, zz) along y and z, in cells: positive on the
+            // far side, 0 inside the query's own row (branch-free form of the three cases)
+            const float ry = fmaxf(fmaxf((float) yy - fy, fy - (float) (yy + 1)), 0.f);
+            const float rz = fmaxf(fmaxf((float) zz - fz, fz - (float) (zz + 1)), 0.f);
+            const float rho2 = ry * ry + rz * rz;
+            const float hx = __builtin_amdgcn_sqrtf(fmaxf(c0 - rho2, 0.f)) * 1.00001f + g.slack;
+            const int xl = max(xa, __float2int_rd(fx - hx)), xh = min(xb, __float2int_rd(fx + hx));
+            const bool ok = zz <= zb && !(rho2 > lim2) && xl <= xh;
+            const unsigned base = ((unsigned) zz * g.ny + yy) * g.nx;
+            a0[u] = ok ? base + xl : 0u;
+            a1[u] = ok ? base + xh + 1 : 0u;
+            const bool wrap = yy >= yb;
+            yy = wrap ? ya : yy + 1;
+            zz += wrap;
+        }
+        lookup_and_walk(a0, a1);
     }
     return best;
 }
@@ -368,7 +417,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 
             while (l < L - 1 && lv->g[l].h < lane_lf * r) ++l;
             const GridDev g = lv->g[l];
             float margin;
-            best = scan_box(g, qx, qy, qz, r, best, &margin, s_runs, lane);
+            best = scan_box(g, qx, qy, qz, r, best, &margin, s_runs, lane, have_prev);
             const float bd2 = __uint_as_float((unsigned) (best >> 32));
             if (margin > 0.f && (bd2 <= margin * margin || thr_d2 <= margin * margin)) break;
             // not certified: the radius must GROW (a query sitting on a cell face can have a
