@@ -286,6 +286,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))
     k_ndt_derivs(const float4 *__restrict__ src, unsigned n, const NdtVoxel *__restrict__ vox,
                  const unsigned long long *__restrict__ hkeys, const unsigned *__restrict__ hvals,
                  unsigned mask, NdtDense dense, NdtArgs A, double *__restrict__ partials) {
+    __shared__ unsigned s_near[27 * kBlock];  // per-lane lists, pass 1 -> pass 2 (lane-private)
     double acc[kNdtAcc];
 #pragma unroll
     for (int k = 0; k < kNdtAcc; ++k) acc[k] = 0.0;
@@ -302,18 +303,17 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))
         const int ck = (int) floorf(__fmul_rn(xt2, A.inv_res));
         const double x[3] = {(double) sp.x, (double) sp.y, (double) sp.z};
         // point Jacobian (3x6) and second derivatives, computePointDerivatives
-        double J[18];
-#pragma unroll
-        for (int k = 0; k < 18; ++k) J[k] = 0.0;
-        J[0] = J[7] = J[14] = 1.0;
-        J[1 * 6 + 3] = dot3d(x, A.j[0]);
-        J[2 * 6 + 3] = dot3d(x, A.j[1]);
-        J[0 * 6 + 4] = dot3d(x, A.j[2]);
-        J[1 * 6 + 4] = dot3d(x, A.j[3]);
-        J[2 * 6 + 4] = dot3d(x, A.j[4]);
-        J[0 * 6 + 5] = dot3d(x, A.j[5]);
-        J[1 * 6 + 5] = dot3d(x, A.j[6]);
-        J[2 * 6 + 5] = dot3d(x, A.j[7]);
+        // Jc[c][b] = J(b, 3 + c); J(0, 3) = 0 and columns 0..2 are the identity
+        double Jc[3][3];
+        Jc[0][0] = 0.0;
+        Jc[0][1] = dot3d(x, A.j[0]);
+        Jc[0][2] = dot3d(x, A.j[1]);
+        Jc[1][0] = dot3d(x, A.j[2]);
+        Jc[1][1] = dot3d(x, A.j[3]);
+        Jc[1][2] = dot3d(x, A.j[4]);
+        Jc[2][0] = dot3d(x, A.j[5]);
+        Jc[2][1] = dot3d(x, A.j[6]);
+        Jc[2][2] = dot3d(x, A.j[7]);
         double PH[6][3];  // a, b, c, d, e, f
         if (HESS) {
             PH[0][0] = 0.0;
@@ -332,7 +332,14 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))
                 PH[5][r] = dot3d(x, A.h[12 + r]);
             }
         }
-#pragma unroll 1
+        // Pass 1: the 27 neighbouring cells -> this lane's own list of voxels within `res`
+        // (slot numbers in LDS, column = lane).  Only about one neighbour in five passes, and
+        // WHICH ones differs from lane to lane; evaluating inside the 27-trip loop would run the
+        // f64 body with most lanes masked off.  Pass 2 walks the compacted list, so a wave pays
+        // max-over-lanes(list length) bodies instead of one per cell any lane needs.  The list
+        // keeps cell order, so every lane still adds its voxels in the same order as before.
+        int n_near = 0;
+#pragma unroll 3
         for (int nb = 0; nb < 27; ++nb) {
             const int di = nb % 3 - 1, dj = (nb / 3) % 3 - 1, dk = nb / 9 - 1;
             unsigned vi = 0xFFFFFFFFu;
@@ -354,18 +361,21 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))
                 }
             }
             if (vi == 0xFFFFFFFFu) continue;
-            // mean first (24 B): most neighbouring voxels fail the radius test, and only the
-            // ones that pass need their inverse covariance (72 B)
+            // kd-tree radius test in float on the float-stored means (24 B of the 96 B record)
+            const float fx = __fsub_rn(xt0, (float) vox[vi].mean[0]), fy = __fsub_rn(xt1, (float) vox[vi].mean[1]),
+                        fz = __fsub_rn(xt2, (float) vox[vi].mean[2]);
+            const float dd = __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz));
+            if (!((double) dd < A.res2)) continue;
+            s_near[n_near * kBlock + threadIdx.x] = vi;
+            ++n_near;
+        }
+#pragma unroll 1
+        for (int t = 0; t < n_near; ++t) {
+            const unsigned vi = s_near[t * kBlock + threadIdx.x];
             NdtVoxel v;
             v.mean[0] = vox[vi].mean[0];
             v.mean[1] = vox[vi].mean[1];
             v.mean[2] = vox[vi].mean[2];
-            {  // kd-tree radius test in float on the float-stored means
-                const float fx = __fsub_rn(xt0, (float) v.mean[0]), fy = __fsub_rn(xt1, (float) v.mean[1]),
-                            fz = __fsub_rn(xt2, (float) v.mean[2]);
-                const float dd = __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz));
-                if (!((double) dd < A.res2)) continue;
-            }
 #pragma unroll
             for (int k = 0; k < 9; ++k) v.icov[k] = vox[vi].icov[k];
             const double xx[3] = {(double) xt0 - v.mean[0], (double) xt1 - v.mean[1], (double) xt2 - v.mean[2]};
@@ -379,13 +389,22 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))
             acc[0] += -A.d1 * e;
             w *= A.d1;
             if (GRAD || HESS) {
+                // icov * J, column by column.  Columns 0..2 of the point Jacobian are the
+                // identity and J(0,3) is zero (computePointDerivatives), so those products are
+                // read off icov instead of being multiplied out against constants.
                 double cJ[6][3], xcJ[6];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
 #pragma unroll
-                    for (int a = 0; a < 3; ++a)
-                        cJ[i][a] = v.icov[a * 3] * J[0 * 6 + i] + v.icov[a * 3 + 1] * J[1 * 6 + i] +
-                                   v.icov[a * 3 + 2] * J[2 * 6 + i];
+                    for (int a = 0; a < 3; ++a) {
+                        if (i < 3) {
+                            cJ[i][a] = v.icov[a * 3 + i];
+                        } else {
+                            double c = v.icov[a * 3 + 1] * Jc[i - 3][1] + v.icov[a * 3 + 2] * Jc[i - 3][2];
+                            if (i > 3) c += v.icov[a * 3] * Jc[i - 3][0];
+                            cJ[i][a] = c;
+                        }
+                    }
                     xcJ[i] = dot3d(xx, cJ[i]);
                     if (GRAD) acc[1 + i] += xcJ[i] * w;
                 }
@@ -394,7 +413,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))
                     for (int i = 0; i < 6; ++i)
 #pragma unroll
                         for (int j = i; j < 6; ++j) {  // upper triangle; the host mirrors it
-                            double t2 = 0.0, t3 = 0.0;
+                            double t2 = 0.0, t3;
                             if (i >= 3 && j >= 3) {
                                 // block (i, j) of point_hessian_: a b c / b d e / c e f
                                 const int hi = i - 3, hj = j - 3;
@@ -402,12 +421,19 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))
                                 const double *hv = PH[sel];
                                 double ch[3];
 #pragma unroll
-                                for (int a = 0; a < 3; ++a)
-                                    ch[a] = v.icov[a * 3] * hv[0] + v.icov[a * 3 + 1] * hv[1] + v.icov[a * 3 + 2] * hv[2];
+                                for (int a = 0; a < 3; ++a) {
+                                    ch[a] = v.icov[a * 3 + 1] * hv[1] + v.icov[a * 3 + 2] * hv[2];
+                                    if (sel >= 3) ch[a] += v.icov[a * 3] * hv[0];  // a, b, c have x = 0
+                                }
                                 t2 = dot3d(xx, ch);
                             }
-#pragma unroll
-                            for (int b = 0; b < 3; ++b) t3 += J[b * 6 + j] * cJ[i][b];
+                            // column j of J against row i of icov * J
+                            if (j < 3) {
+                                t3 = cJ[i][j];
+                            } else {
+                                t3 = Jc[j - 3][1] * cJ[i][1] + Jc[j - 3][2] * cJ[i][2];
+                                if (j > 3) t3 += Jc[j - 3][0] * cJ[i][0];
+                            }
                             acc[7 + i * 6 + j] += w * (-A.d2 * xcJ[i] * xcJ[j] + t2 + t3);
                         }
                 }
