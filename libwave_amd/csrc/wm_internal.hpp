@@ -175,7 +175,7 @@ struct wm_ctx {
     double gicp_cov_eps = 0;
 
     // NDT voxel model of the target
-    wm::DevBuf ndt_keys, ndt_keys2, ndt_vox, ndt_vkey, ndt_hkeys, ndt_hvals, ndt_dense;
+    wm::DevBuf ndt_keys, ndt_keys2, ndt_vox, ndt_vkey, ndt_hkeys, ndt_hvals, ndt_dense, ndt_meanf;
     bool ndt_dense_on = false;  // dense cell -> voxel-slot table built (small lattices)
     int ndt_dense_lo[3] = {0, 0, 0}, ndt_dense_dim[3] = {0, 0, 0};
     int tune_ndt_dense = 1;

@@ -160,8 +160,8 @@ __device__ inline bool inverse3(const double *m, double *o) {
 __global__ void __launch_bounds__(kBlock)
     k_ndt_voxel_stats(const float4 *__restrict__ pts, const unsigned long long *__restrict__ keys,
                       const unsigned *__restrict__ perm, const unsigned *__restrict__ seg,
-                      unsigned n, NdtVoxel *__restrict__ vox, unsigned long long *__restrict__ vkey,
-                      unsigned *__restrict__ n_valid) {
+                      unsigned n, NdtVoxel *__restrict__ vox, float4 *__restrict__ meanf,
+                      unsigned long long *__restrict__ vkey, unsigned *__restrict__ n_valid) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const unsigned long long key = keys[i];
@@ -218,6 +218,8 @@ __global__ void __launch_bounds__(kBlock)
         }
     }
     vox[slot] = v;
+    // the radius test of the derivative passes runs on float means (PCL's kd-tree of centroids)
+    meanf[slot] = make_float4((float) v.mean[0], (float) v.mean[1], (float) v.mean[2], 0.0f);
     vkey[slot] = valid ? key : kEmptyKey;
     if (valid) atomicAdd(n_valid, 1u);
 }
@@ -265,6 +267,10 @@ __global__ void __launch_bounds__(kBlock)
     table[((size_t) c * d.ny + b) * d.nx + a] = (int) s;
 }
 
+struct __attribute__((packed, aligned(4))) Int3 {  // three adjacent table cells, one 12-byte load
+    int a, b, c;
+};
+
 struct NdtArgs {
     float Tf[12];
     float inv_res;
@@ -284,7 +290,7 @@ __device__ __forceinline__ double dot3d(const double *a, const double *b) {
 template <bool GRAD, bool HESS>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2)))
     k_ndt_derivs(const float4 *__restrict__ src, unsigned n, const NdtVoxel *__restrict__ vox,
-                 const unsigned long long *__restrict__ hkeys, const unsigned *__restrict__ hvals,
+                 const float4 *__restrict__ meanf, const unsigned long long *__restrict__ hkeys, const unsigned *__restrict__ hvals,
                  unsigned mask, NdtDense dense, NdtArgs A, double *__restrict__ partials) {
     __shared__ unsigned s_near[27 * kBlock];  // per-lane lists, pass 1 -> pass 2 (lane-private)
     double acc[kNdtAcc];
@@ -339,35 +345,51 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))
         // max-over-lanes(list length) bodies instead of one per cell any lane needs.  The list
         // keeps cell order, so every lane still adds its voxels in the same order as before.
         int n_near = 0;
+        // dense lattice: the block's centre in table coordinates; the table carries two empty
+        // cells of margin, so a centre in [1, n-2] reads in bounds and any other has no neighbours
+        const int ta = ci - dense.i0, tb = cj - dense.j0, tc = ck - dense.k0;
+        const bool in_table = dense.table && ta >= 1 && tb >= 1 && tc >= 1 && ta <= dense.nx - 2 &&
+                              tb <= dense.ny - 2 && tc <= dense.nz - 2;
 #pragma unroll 3
-        for (int nb = 0; nb < 27; ++nb) {
-            const int di = nb % 3 - 1, dj = (nb / 3) % 3 - 1, dk = nb / 9 - 1;
-            unsigned vi = 0xFFFFFFFFu;
-            if (dense.table) {  // uniform: one load
-                const int a = ci + di - dense.i0, b = cj + dj - dense.j0, c = ck + dk - dense.k0;
-                if (a >= 0 && b >= 0 && c >= 0 && a < dense.nx && b < dense.ny && c < dense.nz)
-                    vi = (unsigned) dense.table[((size_t) c * dense.ny + b) * dense.nx + a];
+        for (int row = 0; row < 9; ++row) {  // (dk, dj); the three di cells are adjacent in x
+            const int dj = row % 3 - 1, dk = row / 3 - 1;
+            unsigned v3[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            if (dense.table) {  // uniform
+                if (in_table) {
+                    const Int3 r = *(const Int3 *) (dense.table +
+                                                    (((size_t) (tc + dk) * dense.ny + (tb + dj)) * dense.nx + (ta - 1)));
+                    v3[0] = (unsigned) r.a;
+                    v3[1] = (unsigned) r.b;
+                    v3[2] = (unsigned) r.c;
+                }
             } else {
-                const unsigned long long key = ndt_key(ck + dk, cj + dj, ci + di);
-                unsigned hpos = ndt_hash(key) & mask;
-                for (;;) {
-                    const unsigned long long hk = hkeys[hpos];
-                    if (hk == key) {
-                        vi = hvals[hpos];
-                        break;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const unsigned long long key = ndt_key(ck + dk, cj + dj, ci + d - 1);
+                    unsigned hpos = ndt_hash(key) & mask;
+                    for (;;) {
+                        const unsigned long long hk = hkeys[hpos];
+                        if (hk == key) {
+                            v3[d] = hvals[hpos];
+                            break;
+                        }
+                        if (hk == kEmptyKey) break;
+                        hpos = (hpos + 1) & mask;
                     }
-                    if (hk == kEmptyKey) break;
-                    hpos = (hpos + 1) & mask;
                 }
             }
-            if (vi == 0xFFFFFFFFu) continue;
-            // kd-tree radius test in float on the float-stored means (24 B of the 96 B record)
-            const float fx = __fsub_rn(xt0, (float) vox[vi].mean[0]), fy = __fsub_rn(xt1, (float) vox[vi].mean[1]),
-                        fz = __fsub_rn(xt2, (float) vox[vi].mean[2]);
-            const float dd = __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz));
-            if (!((double) dd < A.res2)) continue;
-            s_near[n_near * kBlock + threadIdx.x] = vi;
-            ++n_near;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const unsigned vi = v3[d];
+                if (vi == 0xFFFFFFFFu) continue;
+                // kd-tree radius test in float on the float means (one 16-byte load)
+                const float4 m = meanf[vi];
+                const float fx = __fsub_rn(xt0, m.x), fy = __fsub_rn(xt1, m.y), fz = __fsub_rn(xt2, m.z);
+                const float dd = __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz));
+                if (!((double) dd < A.res2)) continue;
+                s_near[n_near * kBlock + threadIdx.x] = vi;
+                ++n_near;
+            }
         }
 #pragma unroll 1
         for (int t = 0; t < n_near; ++t) {
@@ -496,6 +518,7 @@ static int ndt_build(wm_ctx *ctx, double res) {
     ctx->ndt_hmask = cap - 1;
     WM_HIP(ctx, ctx->ndt_vox.reserve((size_t) (nvox > 0 ? nvox : 1) * sizeof(NdtVoxel)));
     WM_HIP(ctx, ctx->ndt_vkey.reserve((size_t) (nvox > 0 ? nvox : 1) * 8 + 8));
+    WM_HIP(ctx, ctx->ndt_meanf.reserve((size_t) (nvox > 0 ? nvox : 1) * sizeof(float4)));
     WM_HIP(ctx, ctx->ndt_hkeys.reserve((size_t) cap * 8));
     WM_HIP(ctx, ctx->ndt_hvals.reserve((size_t) cap * 4));
     WM_HIP(ctx, hipMemsetAsync(ctx->ndt_hkeys.p, 0xFF, (size_t) cap * 8, ctx->stream));
@@ -505,7 +528,7 @@ static int ndt_build(wm_ctx *ctx, double res) {
     WM_HIP(ctx, hipMemsetAsync(d_nvalid, 0, 4, ctx->stream));
     if (nvox > 0) {
         hipLaunchKernelGGL(k_ndt_voxel_stats, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, k2, p2,
-                           seg, (unsigned) n, ctx->ndt_vox.as<NdtVoxel>(),
+                           seg, (unsigned) n, ctx->ndt_vox.as<NdtVoxel>(), ctx->ndt_meanf.as<float4>(),
                            ctx->ndt_vkey.as<unsigned long long>(), d_nvalid);
         hipLaunchKernelGGL(k_ndt_hash_insert, dim3((nvox + kBlock - 1) / kBlock), dim3(kBlock), 0,
                            ctx->stream, ctx->ndt_vkey.as<unsigned long long>(), nvox,
@@ -521,8 +544,11 @@ static int ndt_build(wm_ctx *ctx, double res) {
         int lo[3], dim[3];
         int64_t cells = 1;
         for (int d = 0; d < 3; ++d) {
-            lo[d] = (int) floorf(bb.lo[d] * inv);  // the same float product as k_ndt_key
-            dim[d] = (int) floorf(bb.hi[d] * inv) - lo[d] + 1;
+            // two empty cells of margin on every side: a query whose own cell lies within one
+            // cell of the occupied box reads its 3x3x3 block without a bounds test, and one
+            // further out has no neighbours at all
+            lo[d] = (int) floorf(bb.lo[d] * inv) - 2;  // the same float product as k_ndt_key
+            dim[d] = (int) floorf(bb.hi[d] * inv) - lo[d] + 3;
             cells *= dim[d] > 0 ? dim[d] : 1;
         }
         if (cells <= (int64_t) 32 << 20) {
@@ -640,13 +666,16 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
     (void) hipEventRecord(ctx->ev_a, ctx->stream);
     if (hess && grad)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<true, true>), dim3(nb), dim3(kBlock), 0,
-                           ctx->stream, src, n, vox, hk, hv, ctx->ndt_hmask, dense, A, partials);
+                           ctx->stream, src, n, vox, ctx->ndt_meanf.as<float4>(), hk, hv, ctx->ndt_hmask, dense, A,
+                           partials);
     else if (grad)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<true, false>), dim3(nb), dim3(kBlock), 0,
-                           ctx->stream, src, n, vox, hk, hv, ctx->ndt_hmask, dense, A, partials);
+                           ctx->stream, src, n, vox, ctx->ndt_meanf.as<float4>(), hk, hv, ctx->ndt_hmask, dense, A,
+                           partials);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<false, true>), dim3(nb), dim3(kBlock), 0,
-                           ctx->stream, src, n, vox, hk, hv, ctx->ndt_hmask, dense, A, partials);
+                           ctx->stream, src, n, vox, ctx->ndt_meanf.as<float4>(), hk, hv, ctx->ndt_hmask, dense, A,
+                           partials);
     (void) hipEventRecord(ctx->ev_b, ctx->stream);
     std::vector<double> h((size_t) nb * kNdtAcc);
     if (copy_to_caller(ctx, h.data(), partials, h.size() * 8) != WM_OK) {
