@@ -266,7 +266,7 @@ typedef struct {
 typedef struct {
     int converged, iterations, n_voxels, evaluations;
     double score;          /* trans_probability_: score / number of source points */
-    float deriv_kernel_ms; /* summed device time of the derivative kernel */
+    float deriv_kernel_ms; /* summed device time of the derivative kernel; 0 unless WM_NDT_PROFILE=1 */
 } wm_ndt_stats;
 
 void wm_ndt_default_params(wm_ndt_params *p);

@@ -406,16 +406,20 @@ static int upload_state(wm_ctx *ctx) {
 // data written by other compute units / engines, which travel other routes through the fabric
 // -- the host then reads stale partials (a bounding-box count larger than the cloud, a stale
 // voxel count) and the next kernel walks off the end of a buffer.
-__global__ void __launch_bounds__(64)
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
     k_fetch_signal(unsigned *dst, const unsigned *src, unsigned words, unsigned *flag, unsigned seq) {
     if ((words & 3u) == 0 && (((size_t) dst | (size_t) src) & 15u) == 0) {
         const uint4 *s4 = (const uint4 *) src;
         uint4 *d4 = (uint4 *) dst;
-        for (unsigned w = threadIdx.x; w < words / 4; w += 64u) d4[w] = s4[w];
+        for (unsigned w = threadIdx.x; w < words / 4; w += THREADS) d4[w] = s4[w];
     } else {
-        for (unsigned w = threadIdx.x; w < words; w += 64u) dst[w] = src[w];
+        for (unsigned w = threadIdx.x; w < words; w += THREADS) dst[w] = src[w];
     }
     __threadfence_system();  // every lane: all of this wave's stores are performed system-wide
+    // more than one wave (large fetches): each has fenced its own stores before it arrives here,
+    // and the flag is written after all of them have
+    if (THREADS > 64) __syncthreads();
     if (threadIdx.x == 0) *(volatile unsigned *) flag = seq;
 }
 
@@ -426,8 +430,12 @@ int fast_fetch(wm_ctx *ctx, void *dst_pinned, const void *src_dev, size_t bytes)
         *ctx->h_sig = 0;
     }
     const unsigned seq = ++ctx->sig_seq;
-    hipLaunchKernelGGL(k_fetch_signal, dim3(1), dim3(64), 0, ctx->stream, (unsigned *) dst_pinned,
-                       (const unsigned *) src_dev, (unsigned) (bytes / 4), ctx->h_sig, seq);
+    if (bytes <= 4096)  // one wave: nothing to wait for but its own stores
+        hipLaunchKernelGGL(k_fetch_signal<64>, dim3(1), dim3(64), 0, ctx->stream, (unsigned *) dst_pinned,
+                           (const unsigned *) src_dev, (unsigned) (bytes / 4), ctx->h_sig, seq);
+    else
+        hipLaunchKernelGGL(k_fetch_signal<1024>, dim3(1), dim3(1024), 0, ctx->stream, (unsigned *) dst_pinned,
+                           (const unsigned *) src_dev, (unsigned) (bytes / 4), ctx->h_sig, seq);
     WM_HIP(ctx, hipGetLastError());
     // spin briefly (the waits this is for are tens of microseconds), then let the runtime block:
     // many worker threads spinning for long would starve each other and the runtime's helpers
@@ -547,6 +555,7 @@ int wm_ctx_create(wm_ctx **out, int device) {
         if (v > 0) ctx->tune_lane_lf = v;
     }
     if (const char *e = getenv("WM_GICP_PROFILE")) ctx->gicp_profile = atoi(e) != 0;
+    if (const char *e = getenv("WM_NDT_PROFILE")) ctx->ndt_profile = atoi(e) != 0;
     if (const char *e = getenv("WM_TUNE_COOP_LF")) {
         const float v = (float) atof(e);
         if (v > 0) ctx->tune_coop_lf = v;
@@ -588,6 +597,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
     }
     if (ctx->h_state) (void) hipHostFree(ctx->h_state);
     if (ctx->h_gicp) (void) hipHostFree(ctx->h_gicp);
+    if (ctx->h_ndt) (void) hipHostFree(ctx->h_ndt);
     if (ctx->h_sig) (void) hipHostFree(ctx->h_sig);
     if (ctx->h_scratch) (void) hipHostFree(ctx->h_scratch);
     for (hipEvent_t e : ctx->ev_pool) (void) hipEventDestroy(e);

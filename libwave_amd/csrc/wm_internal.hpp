@@ -153,6 +153,8 @@ struct wm_ctx {
     unsigned *h_sig = nullptr;           // pinned: completion flag polled by fast_fetch
     unsigned sig_seq = 0;
     double *h_gicp = nullptr;            // pinned, device-visible: the GICP objective's partial sums land here
+    double *h_ndt = nullptr;             // pinned: the NDT derivative passes' block partials
+    bool ndt_profile = false;            // HIP events around every derivative pass (kernel_ms)
     bool gicp_profile = false;           // HIP events around every objective evaluation (fdf_kernel_ms)
     bool have_corr = false, last_align_valid = false, last_align_converged = false;
     wm::DevBuf keys_bak;

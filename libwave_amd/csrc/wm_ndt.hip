@@ -24,7 +24,10 @@
 
 namespace wm {
 
-constexpr int kNdtAcc = 43;
+constexpr int kNdtAcc = 28;  // score, 6 gradient entries, the 21 of the Hessian's upper triangle
+__host__ __device__ constexpr int ndt_tri(int i, int j) {  // (i <= j) -> accumulator slot
+    return 7 + i * 6 - i * (i - 1) / 2 + (j - i);
+}
 constexpr int kNdtBlocks = 1024;
 constexpr unsigned long long kEmptyKey = ~0ull;
 
@@ -284,7 +287,7 @@ __device__ __forceinline__ double dot3d(const double *a, const double *b) {
     return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
 }
 
-// a[0] = score, a[1..6] = gradient, a[7..42] = Hessian (row-major 6x6)
+// a[0] = score, a[1..6] = gradient, a[7..27] = upper triangle of the Hessian, row by row
 // (at least two waves per SIMD: the Hessian variants sit a couple of registers above the
 // 256-register line that would leave a single wave with nothing to hide its loads behind)
 template <bool GRAD, bool HESS>
@@ -456,7 +459,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))
                                 t3 = Jc[j - 3][1] * cJ[i][1] + Jc[j - 3][2] * cJ[i][2];
                                 if (j > 3) t3 += Jc[j - 3][0] * cJ[i][0];
                             }
-                            acc[7 + i * 6 + j] += w * (-A.d2 * xcJ[i] * xcJ[j] + t2 + t3);
+                            acc[ndt_tri(i, j)] += w * (-A.d2 * xcJ[i] * xcJ[j] + t2 + t3);
                         }
                 }
             }
@@ -663,7 +666,7 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
         dense = NdtDense{ctx->ndt_dense.as<int>(), ctx->ndt_dense_lo[0], ctx->ndt_dense_lo[1],
                          ctx->ndt_dense_lo[2], ctx->ndt_dense_dim[0], ctx->ndt_dense_dim[1],
                          ctx->ndt_dense_dim[2]};
-    (void) hipEventRecord(ctx->ev_a, ctx->stream);
+    if (ctx->ndt_profile) (void) hipEventRecord(ctx->ev_a, ctx->stream);
     if (hess && grad)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<true, true>), dim3(nb), dim3(kBlock), 0,
                            ctx->stream, src, n, vox, ctx->ndt_meanf.as<float4>(), hk, hv, ctx->ndt_hmask, dense, A,
@@ -676,33 +679,41 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<false, true>), dim3(nb), dim3(kBlock), 0,
                            ctx->stream, src, n, vox, ctx->ndt_meanf.as<float4>(), hk, hv, ctx->ndt_hmask, dense, A,
                            partials);
-    (void) hipEventRecord(ctx->ev_b, ctx->stream);
-    std::vector<double> h((size_t) nb * kNdtAcc);
-    if (copy_to_caller(ctx, h.data(), partials, h.size() * 8) != WM_OK) {
+    if (ctx->ndt_profile) (void) hipEventRecord(ctx->ev_b, ctx->stream);
+    const size_t hbytes = (size_t) nb * kNdtAcc * sizeof(double);
+    if (!ctx->h_ndt && hipHostMalloc((void **) &ctx->h_ndt, (size_t) kNdtBlocks * kNdtAcc * sizeof(double),
+                                     hipHostMallocDefault) != hipSuccess) {
+        ctx->last_error = "ndt_eval: pinned allocation failed";
+        *rc = WM_ERR_HIP;
+        return 0;
+    }
+    const double *h = ctx->h_ndt;
+    if (fast_fetch(ctx, ctx->h_ndt, partials, hbytes) != WM_OK) {
         ctx->last_error = "ndt_eval: HIP error";
         *rc = WM_ERR_HIP;
         return 0;
     }
     float ms = 0;
-    (void) hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b);
+    if (ctx->ndt_profile) {  // event timing needs the stream drained; off unless asked for
+        (void) hipStreamSynchronize(ctx->stream);
+        (void) hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b);
+    }
     E.kernel_ms += ms;
     E.evals += 1;
+    // block partials in block order, every accumulator with its own running sum
     double a[kNdtAcc];
-    for (int k = 0; k < kNdtAcc; ++k) {
-        double s = 0;
-        for (int b = 0; b < nb; ++b) s += h[(size_t) b * kNdtAcc + k];
-        a[k] = s;
-    }
+    for (int k = 0; k < kNdtAcc; ++k) a[k] = 0.0;
+    for (int b = 0; b < nb; ++b)
+        for (int k = 0; k < kNdtAcc; ++k) a[k] += h[(size_t) b * kNdtAcc + k];
     if (grad)
         for (int k = 0; k < 6; ++k) grad[k] = a[1 + k];
     if (hess) {
-        for (int k = 0; k < 36; ++k) hess[k] = a[7 + k];
         // PCL fills all 36 entries; H(j,i) differs from H(i,j) only in the rounding of two
         // commuted products (~1e-16 relative).  The kernel accumulates the upper triangle -- 21
         // instead of 36 f64 accumulators and 40 % less arithmetic in its dominant loop -- and
         // the lower one is its mirror.
         for (int i = 0; i < 6; ++i)
-            for (int j = 0; j < i; ++j) hess[i * 6 + j] = hess[j * 6 + i];
+            for (int j = i; j < 6; ++j) hess[i * 6 + j] = hess[j * 6 + i] = a[ndt_tri(i, j)];
     }
     return a[0];
 }
