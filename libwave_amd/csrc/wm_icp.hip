@@ -15,6 +15,7 @@
 #include "wm_internal.hpp"
 
 #include <chrono>
+#include <thread>
 
 #include <float.h>
 #include <math.h>
@@ -437,16 +438,27 @@ int fast_fetch(wm_ctx *ctx, void *dst_pinned, const void *src_dev, size_t bytes)
         hipLaunchKernelGGL(k_fetch_signal<1024>, dim3(1), dim3(1024), 0, ctx->stream, (unsigned *) dst_pinned,
                            (const unsigned *) src_dev, (unsigned) (bytes / 4), ctx->h_sig, seq);
     WM_HIP(ctx, hipGetLastError());
-    // spin briefly (the waits this is for are tens of microseconds), then let the runtime block:
-    // many worker threads spinning for long would starve each other and the runtime's helpers
+    // Three stages.  Spin (most waits are tens of microseconds); then poll with a yield between
+    // looks, so that worker threads sharing a core take turns instead of starving each other
+    // (kernels of a few hundred microseconds: the NDT passes at 2M points); only then let the
+    // runtime block -- its wake-up costs 0.1-0.2 ms on some hosts, which a registration that
+    // waits a hundred times cannot afford, but it is the right thing for a wait of milliseconds
+    // and it is what reports a failed kernel.
     volatile unsigned *flag = ctx->h_sig;
     const auto t0 = std::chrono::steady_clock::now();
+    bool yielding = false;
     for (unsigned spins = 1; *flag != seq; ++spins) {
-        __builtin_ia32_pause();
-        if ((spins & 63u) == 0 &&
-            std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(80)) {
-            WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            break;
+        if (yielding)
+            std::this_thread::yield();
+        else
+            __builtin_ia32_pause();
+        if ((spins & 63u) == 0 || yielding) {
+            const auto waited = std::chrono::steady_clock::now() - t0;
+            if (waited > std::chrono::milliseconds(4)) {
+                WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                break;
+            }
+            yielding = waited > std::chrono::microseconds(80);
         }
     }
     return WM_OK;

@@ -430,7 +430,13 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))
                             cJ[i][a] = c;
                         }
                     }
-                    xcJ[i] = dot3d(xx, cJ[i]);
+                    // xx^T icov J_i through cx = icov xx (icov is symmetric up to rounding)
+                    if (i < 3) {
+                        xcJ[i] = cx[i];
+                    } else {
+                        xcJ[i] = cx[1] * Jc[i - 3][1] + cx[2] * Jc[i - 3][2];
+                        if (i > 3) xcJ[i] += cx[0] * Jc[i - 3][0];
+                    }
                     if (GRAD) acc[1 + i] += xcJ[i] * w;
                 }
                 if (HESS) {
@@ -444,13 +450,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))
                                 const int hi = i - 3, hj = j - 3;
                                 const int sel = (hi == 0 && hj == 0) ? 0 : ((hi + hj == 1) ? 1 : ((hi + hj == 2 && hi != hj) ? 2 : ((hi == 1 && hj == 1) ? 3 : ((hi + hj == 3) ? 4 : 5))));
                                 const double *hv = PH[sel];
-                                double ch[3];
-#pragma unroll
-                                for (int a = 0; a < 3; ++a) {
-                                    ch[a] = v.icov[a * 3 + 1] * hv[1] + v.icov[a * 3 + 2] * hv[2];
-                                    if (sel >= 3) ch[a] += v.icov[a * 3] * hv[0];  // a, b, c have x = 0
-                                }
-                                t2 = dot3d(xx, ch);
+                                // xx^T icov h = cx . h; the a, b, c blocks have h.x = 0
+                                t2 = cx[1] * hv[1] + cx[2] * hv[2];
+                                if (sel >= 3) t2 += cx[0] * hv[0];
                             }
                             // column j of J against row i of icov * J
                             if (j < 3) {
