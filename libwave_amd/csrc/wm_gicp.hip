@@ -352,9 +352,9 @@ static double gicp_fdf(GicpFn &F, const double x[6], double g[6]) {
     int nb = (int) ((n + kBlock - 1) / kBlock);
     if (nb > kGicpBlocks) nb = kGicpBlocks;
     if (nb < 1) nb = 1;
-    // The partial sums land in device memory and are fetched into pinned memory by one
-    // wavefront (fast_fetch): no copy engine, no pageable staging -- this loop runs ~270 times
-    // per registration and is latency-bound.
+    // The block partials stay in device memory; one workgroup adds them up and writes the
+    // kGicpAcc sums into pinned memory (fast_fetch_sum): no copy engine, no pageable staging,
+    // 104 bytes over PCIe -- this loop runs ~180 times per registration and is latency-bound.
     if (!ctx->h_gicp &&
         hipHostMalloc((void **) &ctx->h_gicp, sizeof(double) * kGicpBlocks * kGicpAcc,
                       hipHostMallocDefault) != hipSuccess) {
@@ -367,23 +367,17 @@ static double gicp_fdf(GicpFn &F, const double x[6], double g[6]) {
                        n, ctx->keys.as<unsigned long long>(), ctx->match_pt.as<float4>(),
                        ctx->gicp_mahal.as<double>(), A, ctx->partials.as<double>());
     if (ctx->gicp_profile) (void) hipEventRecord(ctx->ev_b, ctx->stream);
-    if (fast_fetch(ctx, ctx->h_gicp, ctx->partials.p, sizeof(double) * (size_t) nb * kGicpAcc) != WM_OK) {
+    if (fast_fetch_sum(ctx, ctx->h_gicp, ctx->partials.as<double>(), (unsigned) nb, kGicpAcc) != WM_OK) {
         F.rc = WM_ERR_HIP;
         return 0;
     }
-    const double *h = ctx->h_gicp;
     if (ctx->gicp_profile) {
         float ms = 0;
         (void) hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b);
         F.kernel_ms += ms;
     }
     F.evals++;
-    double a[kGicpAcc];
-    for (int k = 0; k < kGicpAcc; ++k) {
-        double s = 0;
-        for (int b = 0; b < nb; ++b) s += h[(size_t) b * kGicpAcc + k];
-        a[k] = s;
-    }
+    const double *a = ctx->h_gicp;  // the kGicpAcc sums over blocks
     const double m = (double) F.m;
     if (g) {
         double Racc[9];

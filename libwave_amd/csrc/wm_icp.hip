@@ -424,20 +424,7 @@ __global__ void __launch_bounds__(THREADS)
     if (threadIdx.x == 0) *(volatile unsigned *) flag = seq;
 }
 
-int fast_fetch(wm_ctx *ctx, void *dst_pinned, const void *src_dev, size_t bytes) {
-    if (bytes & 3) return WM_ERR_ARG;
-    if (!ctx->h_sig) {
-        WM_HIP(ctx, hipHostMalloc((void **) &ctx->h_sig, 64, hipHostMallocDefault));
-        *ctx->h_sig = 0;
-    }
-    const unsigned seq = ++ctx->sig_seq;
-    if (bytes <= 4096)  // one wave: nothing to wait for but its own stores
-        hipLaunchKernelGGL(k_fetch_signal<64>, dim3(1), dim3(64), 0, ctx->stream, (unsigned *) dst_pinned,
-                           (const unsigned *) src_dev, (unsigned) (bytes / 4), ctx->h_sig, seq);
-    else
-        hipLaunchKernelGGL(k_fetch_signal<1024>, dim3(1), dim3(1024), 0, ctx->stream, (unsigned *) dst_pinned,
-                           (const unsigned *) src_dev, (unsigned) (bytes / 4), ctx->h_sig, seq);
-    WM_HIP(ctx, hipGetLastError());
+static int wait_flag(wm_ctx *ctx, unsigned seq) {
     // Three stages.  Spin (most waits are tens of microseconds); then poll with a yield between
     // looks, so that worker threads sharing a core take turns instead of starving each other
     // (kernels of a few hundred microseconds: the NDT passes at 2M points); only then let the
@@ -462,6 +449,84 @@ int fast_fetch(wm_ctx *ctx, void *dst_pinned, const void *src_dev, size_t bytes)
         }
     }
     return WM_OK;
+}
+
+int fast_fetch(wm_ctx *ctx, void *dst_pinned, const void *src_dev, size_t bytes) {
+    if (bytes & 3) return WM_ERR_ARG;
+    if (!ctx->h_sig) {
+        WM_HIP(ctx, hipHostMalloc((void **) &ctx->h_sig, 64, hipHostMallocDefault));
+        *ctx->h_sig = 0;
+    }
+    const unsigned seq = ++ctx->sig_seq;
+    if (bytes <= 4096)  // one wave: nothing to wait for but its own stores
+        hipLaunchKernelGGL(k_fetch_signal<64>, dim3(1), dim3(64), 0, ctx->stream, (unsigned *) dst_pinned,
+                           (const unsigned *) src_dev, (unsigned) (bytes / 4), ctx->h_sig, seq);
+    else
+        hipLaunchKernelGGL(k_fetch_signal<1024>, dim3(1), dim3(1024), 0, ctx->stream, (unsigned *) dst_pinned,
+                           (const unsigned *) src_dev, (unsigned) (bytes / 4), ctx->h_sig, seq);
+    WM_HIP(ctx, hipGetLastError());
+    return wait_flag(ctx, seq);
+}
+
+// Column sums of a [rows][k] block of f64 partials (k <= 32), reduced ON THE DEVICE by one
+// workgroup and delivered as k doubles: what the host needs from a GICP objective or an NDT
+// derivative pass is the sum over blocks, and shipping every block's partials over PCIe to add
+// them on the host cost more than the pass's own launch.  Fixed order, no atomics: thread t
+// adds elements t, t + S, t + 2S, ... (S = the largest multiple of k <= 1024, so a thread stays
+// in one column and a wave reads consecutive doubles), eight threads per column then add those
+// partial sums group by group, one thread per column adds the eight.  The k results are written
+// and fenced by lanes of wave 0, which also writes the flag (k_fetch_signal's rule).
+__global__ void __launch_bounds__(1024)
+    k_sum_fetch(double *dst, const double *__restrict__ src, unsigned rows, unsigned k, unsigned *flag,
+                unsigned seq) {
+    __shared__ double s1[1024];
+    __shared__ double s2[8][32];
+    const unsigned t = threadIdx.x;
+    const unsigned groups = 1024u / k, stride = groups * k, total = rows * k;
+    double a = 0.0;
+    if (t < stride) {
+        unsigned e = t;
+        for (; e + 3 * stride < total; e += 4 * stride) {  // four loads in flight, added in order
+            const double v0 = src[e], v1 = src[e + stride], v2 = src[e + 2 * stride], v3 = src[e + 3 * stride];
+            a += v0;
+            a += v1;
+            a += v2;
+            a += v3;
+        }
+        for (; e < total; e += stride) a += src[e];
+    }
+    s1[t] = a;
+    __syncthreads();
+    if (t < 8 * k) {
+        const unsigned c = t % k, g = t / k;
+        double b = 0.0;
+        for (unsigned gg = g; gg < groups; gg += 8) b += s1[gg * k + c];
+        s2[g][c] = b;
+    }
+    __syncthreads();
+    if (t < k) {
+        double r = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) r += s2[g][t];
+        dst[t] = r;
+    }
+    if (t < 64) {
+        __threadfence_system();
+        if (t == 0) *(volatile unsigned *) flag = seq;
+    }
+}
+
+int fast_fetch_sum(wm_ctx *ctx, double *dst_pinned, const double *src_dev, unsigned rows, unsigned k) {
+    if (k < 1 || k > 32 || rows < 1) return WM_ERR_ARG;
+    if (!ctx->h_sig) {
+        WM_HIP(ctx, hipHostMalloc((void **) &ctx->h_sig, 64, hipHostMallocDefault));
+        *ctx->h_sig = 0;
+    }
+    const unsigned seq = ++ctx->sig_seq;
+    hipLaunchKernelGGL(k_sum_fetch, dim3(1), dim3(1024), 0, ctx->stream, dst_pinned, src_dev, rows, k,
+                       ctx->h_sig, seq);
+    WM_HIP(ctx, hipGetLastError());
+    return wait_flag(ctx, seq);
 }
 
 static int download_state(wm_ctx *ctx) {

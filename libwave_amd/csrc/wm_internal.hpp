@@ -205,6 +205,8 @@ int ensure_levels(wm_ctx *ctx, double max_corr);
 // fetch a small result from device memory into pinned host memory and wait for it (copy, fence
 // and completion flag by one wavefront; see k_fetch_signal)
 int fast_fetch(wm_ctx *ctx, void *dst_pinned, const void *src_dev, size_t bytes);
+// column sums of a [rows][k] f64 block (k <= 32), reduced on the device, k doubles delivered
+int fast_fetch_sum(wm_ctx *ctx, double *dst_pinned, const double *src_dev, unsigned rows, unsigned k);
 // developer tracing (env WM_TRACE=1): drain the stream and print a marker, so that a GPU fault can
 // be pinned to the stage that was running
 #define WM_TRACE(ctx, what)                                                     \

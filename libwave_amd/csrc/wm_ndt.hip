@@ -682,15 +682,13 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
                            ctx->stream, src, n, vox, ctx->ndt_meanf.as<float4>(), hk, hv, ctx->ndt_hmask, dense, A,
                            partials);
     if (ctx->ndt_profile) (void) hipEventRecord(ctx->ev_b, ctx->stream);
-    const size_t hbytes = (size_t) nb * kNdtAcc * sizeof(double);
-    if (!ctx->h_ndt && hipHostMalloc((void **) &ctx->h_ndt, (size_t) kNdtBlocks * kNdtAcc * sizeof(double),
-                                     hipHostMallocDefault) != hipSuccess) {
+    if (!ctx->h_ndt && hipHostMalloc((void **) &ctx->h_ndt, 64 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
         ctx->last_error = "ndt_eval: pinned allocation failed";
         *rc = WM_ERR_HIP;
         return 0;
     }
-    const double *h = ctx->h_ndt;
-    if (fast_fetch(ctx, ctx->h_ndt, partials, hbytes) != WM_OK) {
+    // sums over blocks, formed on the device (fixed order); 224 bytes come back
+    if (fast_fetch_sum(ctx, ctx->h_ndt, partials, (unsigned) nb, kNdtAcc) != WM_OK) {
         ctx->last_error = "ndt_eval: HIP error";
         *rc = WM_ERR_HIP;
         return 0;
@@ -702,11 +700,7 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
     }
     E.kernel_ms += ms;
     E.evals += 1;
-    // block partials in block order, every accumulator with its own running sum
-    double a[kNdtAcc];
-    for (int k = 0; k < kNdtAcc; ++k) a[k] = 0.0;
-    for (int b = 0; b < nb; ++b)
-        for (int k = 0; k < kNdtAcc; ++k) a[k] += h[(size_t) b * kNdtAcc + k];
+    const double *a = ctx->h_ndt;
     if (grad)
         for (int k = 0; k < 6; ++k) grad[k] = a[1 + k];
     if (hess) {
