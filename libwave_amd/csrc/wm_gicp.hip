@@ -22,7 +22,7 @@
 namespace wm {
 
 constexpr int kGicpAcc = 13;
-constexpr int kGicpBlocks = 512;  // partial rows per objective evaluation (fetched by one wave)
+constexpr int kGicpBlocksMax = 4096;  // partial rows per objective evaluation (ctx->tune_gicp_blocks)
 
 __device__ __forceinline__ unsigned long long g_make_key(float d2, unsigned idx) {
     return ((unsigned long long) __float_as_uint(d2) << 32) | idx;
@@ -350,13 +350,13 @@ static double gicp_fdf(GicpFn &F, const double x[6], double g[6]) {
     }
     const unsigned n = (unsigned) ctx->n_src;
     int nb = (int) ((n + kBlock - 1) / kBlock);
-    if (nb > kGicpBlocks) nb = kGicpBlocks;
+    if (nb > ctx->tune_gicp_blocks) nb = ctx->tune_gicp_blocks;
     if (nb < 1) nb = 1;
     // The block partials stay in device memory; one workgroup adds them up and writes the
     // kGicpAcc sums into pinned memory (fast_fetch_sum): no copy engine, no pageable staging,
     // 104 bytes over PCIe -- this loop runs ~180 times per registration and is latency-bound.
     if (!ctx->h_gicp &&
-        hipHostMalloc((void **) &ctx->h_gicp, sizeof(double) * kGicpBlocks * kGicpAcc,
+        hipHostMalloc((void **) &ctx->h_gicp, sizeof(double) * 64,
                       hipHostMallocDefault) != hipSuccess) {
         F.rc = WM_ERR_HIP;
         ctx->last_error = "gicp_fdf: hipHostMalloc failed";
@@ -737,7 +737,7 @@ int wm_gicp_align(wm_ctx *ctx, const wm_gicp_params *prm, double T_out[16], wm_g
     WM_TRY(compute_covariances(ctx, prm->corr_rand, prm->gicp_epsilon));
     const size_t n = ctx->n_src;
     WM_HIP(ctx, ctx->gicp_mahal.reserve(n * 9 * sizeof(double)));
-    WM_HIP(ctx, ctx->partials.reserve((size_t) kGicpBlocks * kGicpAcc * sizeof(double) + 64));
+    WM_HIP(ctx, ctx->partials.reserve((size_t) kGicpBlocksMax * kGicpAcc * sizeof(double) + 64));
     const float thr = threshold_d2_strict(prm->max_corr);
     double base[16];
     mat4_identity(base);
@@ -820,7 +820,7 @@ int wm_gicp_eval(wm_ctx *ctx, const wm_gicp_params *prm, const double T_pair[16]
     WM_TRY(compute_covariances(ctx, prm->corr_rand, prm->gicp_epsilon));
     const size_t n = ctx->n_src;
     WM_HIP(ctx, ctx->gicp_mahal.reserve(n * 9 * sizeof(double)));
-    WM_HIP(ctx, ctx->partials.reserve((size_t) kGicpBlocks * kGicpAcc * sizeof(double) + 64));
+    WM_HIP(ctx, ctx->partials.reserve((size_t) kGicpBlocksMax * kGicpAcc * sizeof(double) + 64));
     double Td[16];
     Mat3d R;
     for (int i = 0; i < 16; ++i) Td[i] = (double) (float) T_pair[i];

@@ -626,6 +626,10 @@ int wm_ctx_create(wm_ctx **out, int device) {
     }
     ctx->stream = ctx->own_stream;
     if (const char *e = getenv("WM_TUNE_NDT_DENSE")) ctx->tune_ndt_dense = atoi(e);
+    if (const char *e = getenv("WM_TUNE_GICP_BLOCKS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 4096) ctx->tune_gicp_blocks = v;
+    }
     if (const char *e = getenv("WM_TRACE")) ctx->trace = atoi(e) != 0;
     if (const char *e = getenv("WM_TUNE_LANE_LF")) {
         const float v = (float) atof(e);

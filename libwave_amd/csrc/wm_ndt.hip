@@ -158,21 +158,33 @@ __device__ inline bool inverse3(const double *m, double *o) {
     return ok;
 }
 
-// one lane per voxel head: statistics in ascending point order, then the PCL
-// covariance conditioning.  seg[i] (exclusive scan of head flags) = voxel slot.
+// heads[slot] = first sorted position of voxel `slot`; heads[n_voxels] = one past the last
+// finite point (seg[n] = n_voxels, the scan's total)
 __global__ void __launch_bounds__(kBlock)
-    k_ndt_voxel_stats(const float4 *__restrict__ pts, const unsigned long long *__restrict__ keys,
-                      const unsigned *__restrict__ perm, const unsigned *__restrict__ seg,
-                      unsigned n, NdtVoxel *__restrict__ vox, float4 *__restrict__ meanf,
-                      unsigned long long *__restrict__ vkey, unsigned *__restrict__ n_valid) {
+    k_ndt_heads(const unsigned long long *__restrict__ keys, const unsigned *__restrict__ flags,
+                const unsigned *__restrict__ seg, unsigned n, unsigned *__restrict__ heads) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
+    if (flags[i]) heads[seg[i]] = i;
+    if (keys[i] != kEmptyKey && (i + 1 == n || keys[i + 1] == kEmptyKey)) heads[seg[n]] = i + 1;
+}
+
+// one lane per voxel (compacted: every lane of a wave has a voxel, and the waves spread over
+// the whole device): statistics in ascending point order, then the PCL covariance conditioning.
+constexpr int kVoxStatBlock = 64;
+__global__ void __launch_bounds__(kVoxStatBlock)
+    k_ndt_voxel_stats(const float4 *__restrict__ pts, const unsigned long long *__restrict__ keys,
+                      const unsigned *__restrict__ perm, const unsigned *__restrict__ heads,
+                      unsigned nvox, NdtVoxel *__restrict__ vox, float4 *__restrict__ meanf,
+                      unsigned long long *__restrict__ vkey, unsigned *__restrict__ n_valid) {
+    const unsigned slot = blockIdx.x * kVoxStatBlock + threadIdx.x;
+    if (slot >= nvox) return;
+    const unsigned i = heads[slot], j = heads[slot + 1];
     const unsigned long long key = keys[i];
-    if (key == kEmptyKey || (i > 0 && keys[i - 1] == key)) return;
     double s[3] = {0, 0, 0}, pp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned j = i;
-    for (; j < n && keys[j] == key; ++j) {
-        const float4 p = pts[perm[j]];
+#pragma unroll 4
+    for (unsigned t = i; t < j; ++t) {
+        const float4 p = pts[perm[t]];
         const double d[3] = {(double) p.x, (double) p.y, (double) p.z};
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -181,7 +193,6 @@ __global__ void __launch_bounds__(kBlock)
             for (int b = 0; b < 3; ++b) pp[a * 3 + b] += d[a] * d[b];
         }
     }
-    const unsigned slot = seg[i];
     const double nn = (double) (j - i);
     NdtVoxel v;
     bool valid = false;
@@ -394,15 +405,27 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))
                 ++n_near;
             }
         }
+        // the next voxel's record (mean + inverse covariance, 96 B) is requested before the
+        // current one is evaluated: with two waves per SIMD a pass-2 trip would otherwise start
+        // with a full memory round trip that nothing hides
+        NdtVoxel vn;
+        {
+            const unsigned v0 = n_near > 0 ? s_near[threadIdx.x] : 0u;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) vn.mean[k] = vox[v0].mean[k];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) vn.icov[k] = vox[v0].icov[k];
+        }
 #pragma unroll 1
         for (int t = 0; t < n_near; ++t) {
-            const unsigned vi = s_near[t * kBlock + threadIdx.x];
-            NdtVoxel v;
-            v.mean[0] = vox[vi].mean[0];
-            v.mean[1] = vox[vi].mean[1];
-            v.mean[2] = vox[vi].mean[2];
+            const NdtVoxel v = vn;
+            {
+                const unsigned v1 = t + 1 < n_near ? s_near[(t + 1) * kBlock + threadIdx.x] : 0u;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) v.icov[k] = vox[vi].icov[k];
+                for (int k = 0; k < 3; ++k) vn.mean[k] = vox[v1].mean[k];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) vn.icov[k] = vox[v1].icov[k];
+            }
             const double xx[3] = {(double) xt0 - v.mean[0], (double) xt1 - v.mean[1], (double) xt2 - v.mean[2]};
             double cx[3];
 #pragma unroll
@@ -498,7 +521,7 @@ static int ndt_build(wm_ctx *ctx, double res) {
     const unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
     WM_HIP(ctx, ctx->ndt_keys.reserve(n * 8));
     WM_HIP(ctx, ctx->ndt_keys2.reserve(n * 8));
-    WM_HIP(ctx, ctx->vg_perm.reserve(n * 4));
+    WM_HIP(ctx, ctx->vg_perm.reserve((n + 1) * 4));  // later: the voxels' head positions (+ end)
     WM_HIP(ctx, ctx->vg_perm2.reserve(n * 4));
     WM_HIP(ctx, ctx->vg_idx.reserve(n * 4));
     WM_HIP(ctx, ctx->vg_seg.reserve((n + 1) * 4));
@@ -532,8 +555,12 @@ static int ndt_build(wm_ctx *ctx, double res) {
     d_nvalid = ctx->bbox_buf.as<unsigned>();
     WM_HIP(ctx, hipMemsetAsync(d_nvalid, 0, 4, ctx->stream));
     if (nvox > 0) {
-        hipLaunchKernelGGL(k_ndt_voxel_stats, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, k2, p2,
-                           seg, (unsigned) n, ctx->ndt_vox.as<NdtVoxel>(), ctx->ndt_meanf.as<float4>(),
+        unsigned *heads = p1;  // the sort's input permutation is dead by now
+        hipLaunchKernelGGL(k_ndt_heads, dim3(blocks), dim3(kBlock), 0, ctx->stream, k2, flags, seg, (unsigned) n,
+                           heads);
+        hipLaunchKernelGGL(k_ndt_voxel_stats, dim3((nvox + kVoxStatBlock - 1) / kVoxStatBlock),
+                           dim3(kVoxStatBlock), 0, ctx->stream, pts, k2, p2, heads, nvox,
+                           ctx->ndt_vox.as<NdtVoxel>(), ctx->ndt_meanf.as<float4>(),
                            ctx->ndt_vkey.as<unsigned long long>(), d_nvalid);
         hipLaunchKernelGGL(k_ndt_hash_insert, dim3((nvox + kBlock - 1) / kBlock), dim3(kBlock), 0,
                            ctx->stream, ctx->ndt_vkey.as<unsigned long long>(), nvox,

@@ -23,7 +23,8 @@ def main():
     from libwave_amd import capi, synth
     dev = torch.device("cuda", 0)
     ctx = capi.Context(0)
-    reps = 5
+    reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 5
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None  # gicp | ndt
 
     def timed(fn):
         fn()
@@ -34,6 +35,13 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps * 1e3, r
 
+    if only in (None, "gicp"):
+        run_gicp(ctx, dev, timed, synth, torch)
+    if only in (None, "ndt"):
+        run_ndt(ctx, dev, timed, synth, torch)
+
+
+def run_gicp(ctx, dev, timed, synth, torch):
     ref, tgt, T_gt = synth.pair(500_000, seed=42)
     d_ref, d_tgt = torch.from_numpy(ref).to(dev), torch.from_numpy(tgt).to(dev)
 
@@ -48,6 +56,9 @@ def main():
                       "outer_iterations": r.get("iterations"), "translation_error_m": err,
                       "detail": {k: v for k, v in r.items() if k not in ("T",) and np.isscalar(v)}}))
 
+
+
+def run_ndt(ctx, dev, timed, synth, torch):
     ref, tgt, T_gt = synth.pair(2_000_000, seed=42)
     d_ref, d_tgt = torch.from_numpy(ref).to(dev), torch.from_numpy(tgt).to(dev)
 
