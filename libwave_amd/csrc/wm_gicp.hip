@@ -49,10 +49,10 @@ __device__ __forceinline__ void knn_insert(unsigned long long (&best)[K], unsign
 // k nearest neighbours of q among the cell-sorted points of grid g: scan the box of cells
 // covering ball(q, r); certified once the k-th distance is within the box margin.
 template <int K>
-__device__ void knn_search(const GridDev &g, float qx, float qy, float qz, int k,
+__device__ void knn_search(const GridDev &g, float qx, float qy, float qz, int k, float r0_cells,
                            unsigned long long (&best)[K]) {
     const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
-    float r = 1.5f * g.h;
+    float r = r0_cells * g.h;
     const float rmax = (float) (g.nx + g.ny + g.nz + 3) * g.h;  // covers the whole grid
     for (int pass = 0; pass < 64; ++pass) {  // r at least x1.5 per pass: rmax is reached long before
 #pragma unroll
@@ -101,7 +101,7 @@ template <int K>
 __global__ void __launch_bounds__(kBlock)
     k_gicp_cov(GridDev g, const float4 *__restrict__ qpts, unsigned n,
                const float4 *__restrict__ orig, int k, double eps, double *__restrict__ cov_out,
-               int by_w) {
+               int by_w, float r0_cells) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float4 q = qpts[i];
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(kBlock)
         return;
     }
     unsigned long long best[K];
-    knn_search<K>(g, q.x, q.y, q.z, k, best);
+    knn_search<K>(g, q.x, q.y, q.z, k, r0_cells, best);
     double mean[3] = {0, 0, 0}, c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < K; ++j) {
@@ -632,7 +632,8 @@ static int launch_cov(wm_ctx *ctx, const GridDev &g, const float4 *q, size_t n, 
                       int k, double eps, double *out, int by_w) {
     if (n == 0) return WM_OK;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gicp_cov<K>), dim3((unsigned) ((n + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, ctx->stream, g, q, (unsigned) n, orig, k, eps, out, by_w);
+                       dim3(kBlock), 0, ctx->stream, g, q, (unsigned) n, orig, k, eps, out, by_w,
+                       ctx->tune_knn_r0 > 0 ? ctx->tune_knn_r0 : (k <= 12 ? 1.0f : 1.5f));
     WM_HIP(ctx, hipGetLastError());
     return WM_OK;
 }
@@ -641,14 +642,14 @@ static int launch_cov(wm_ctx *ctx, const GridDev &g, const float4 *q, size_t n, 
 // instantiated size >= k keeps both the insertion cost (K compare-swaps per accepted candidate,
 // executed by the whole wave) and the register footprint down
 static int launch_cov_k(wm_ctx *ctx, const GridDev &g, const float4 *q, size_t n, const float4 *orig,
-                        int k, double eps, double *out) {
-    if (k <= 8) return launch_cov<8>(ctx, g, q, n, orig, k, eps, out, 0);
-    if (k <= 10) return launch_cov<10>(ctx, g, q, n, orig, k, eps, out, 0);
-    if (k <= 12) return launch_cov<12>(ctx, g, q, n, orig, k, eps, out, 0);
-    if (k <= 16) return launch_cov<16>(ctx, g, q, n, orig, k, eps, out, 0);
-    if (k <= 20) return launch_cov<20>(ctx, g, q, n, orig, k, eps, out, 0);
-    if (k <= 24) return launch_cov<24>(ctx, g, q, n, orig, k, eps, out, 0);
-    return launch_cov<32>(ctx, g, q, n, orig, k, eps, out, 0);
+                        int k, double eps, double *out, int by_w) {
+    if (k <= 8) return launch_cov<8>(ctx, g, q, n, orig, k, eps, out, by_w);
+    if (k <= 10) return launch_cov<10>(ctx, g, q, n, orig, k, eps, out, by_w);
+    if (k <= 12) return launch_cov<12>(ctx, g, q, n, orig, k, eps, out, by_w);
+    if (k <= 16) return launch_cov<16>(ctx, g, q, n, orig, k, eps, out, by_w);
+    if (k <= 20) return launch_cov<20>(ctx, g, q, n, orig, k, eps, out, by_w);
+    if (k <= 24) return launch_cov<24>(ctx, g, q, n, orig, k, eps, out, by_w);
+    return launch_cov<32>(ctx, g, q, n, orig, k, eps, out, by_w);
 }
 
 static int compute_covariances(wm_ctx *ctx, int k, double eps) {
@@ -658,8 +659,15 @@ static int compute_covariances(wm_ctx *ctx, int k, double eps) {
         // target: neighbours from the level-0 grid (built by wm_set_target)
         WM_HIP(ctx, ctx->gicp_c2.reserve((ctx->n_tgt_input > 0 ? ctx->n_tgt_input : 1) * 9 * sizeof(double)));
         const GridDev &g = ctx->levels[0].d;
-        const float4 *q = ctx->tgt_orig.as<float4>();
-        WM_TRY(launch_cov_k(ctx, g, q, ctx->n_tgt_input, q, k, eps, ctx->gicp_c2.as<double>()));
+        const float4 *orig = ctx->tgt_orig.as<float4>();
+        // queries in the grid's own (cell-sorted) order -- a wave's 64 queries then scan the same
+        // few rows of cells -- with the result stored under each point's caller index (.w).
+        // Only finite points are in the grid; a cloud with non-finite ones takes caller order,
+        // which also writes their (never read) placeholder covariances.
+        if (ctx->n_tgt == ctx->n_tgt_input)
+            WM_TRY(launch_cov_k(ctx, g, g.pts, ctx->n_tgt, orig, k, eps, ctx->gicp_c2.as<double>(), 1));
+        else
+            WM_TRY(launch_cov_k(ctx, g, orig, ctx->n_tgt_input, orig, k, eps, ctx->gicp_c2.as<double>(), 0));
         ctx->gicp_cov_tgt_valid = true;
     }
     if (!(ctx->gicp_cov_src_valid && same)) {
@@ -676,7 +684,7 @@ static int compute_covariances(wm_ctx *ctx, int k, double eps) {
         }
         const float4 *q = ctx->src_sorted.as<float4>();
         WM_TRY(launch_cov_k(ctx, ctx->src_grid.d, q, ctx->n_src, ctx->src_orig.as<float4>(), k, eps,
-                            ctx->gicp_c1.as<double>()));
+                            ctx->gicp_c1.as<double>(), 0));
         ctx->gicp_cov_src_valid = true;
     }
     ctx->gicp_cov_k = k;

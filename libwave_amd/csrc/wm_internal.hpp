@@ -181,6 +181,7 @@ struct wm_ctx {
     bool ndt_dense_on = false;  // dense cell -> voxel-slot table built (small lattices)
     int ndt_dense_lo[3] = {0, 0, 0}, ndt_dense_dim[3] = {0, 0, 0};
     int tune_ndt_dense = 1;
+    float tune_knn_r0 = 0.f;     // first radius of the k-NN (covariance) scan in cells; 0 = by k (1.0 up to k = 12, else 1.5)
     int tune_gicp_blocks = 512;  // workgroups (= partial rows) of one GICP objective evaluation
     bool ndt_built = false;
     double ndt_res = -1;
