@@ -358,51 +358,70 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))
         // f64 body with most lanes masked off.  Pass 2 walks the compacted list, so a wave pays
         // max-over-lanes(list length) bodies instead of one per cell any lane needs.  The list
         // keeps cell order, so every lane still adds its voxels in the same order as before.
-        int n_near = 0;
-        // dense lattice: the block's centre in table coordinates; the table carries two empty
-        // cells of margin, so a centre in [1, n-2] reads in bounds and any other has no neighbours
-        const int ta = ci - dense.i0, tb = cj - dense.j0, tc = ck - dense.k0;
-        const bool in_table = dense.table && ta >= 1 && tb >= 1 && tc >= 1 && ta <= dense.nx - 2 &&
-                              tb <= dense.ny - 2 && tc <= dense.nz - 2;
-#pragma unroll 3
-        for (int row = 0; row < 9; ++row) {  // (dk, dj); the three di cells are adjacent in x
-            const int dj = row % 3 - 1, dk = row / 3 - 1;
-            unsigned v3[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-            if (dense.table) {  // uniform
-                if (in_table) {
-                    const Int3 r = *(const Int3 *) (dense.table +
-                                                    (((size_t) (tc + dk) * dense.ny + (tb + dj)) * dense.nx + (ta - 1)));
-                    v3[0] = (unsigned) r.a;
-                    v3[1] = (unsigned) r.b;
-                    v3[2] = (unsigned) r.c;
-                }
-            } else {
+        // 1a: the occupied cells of the 3x3x3 block -> candidate list.  dense lattice: the block's
+        // centre in table coordinates; the table carries two empty cells of margin, so a centre in
+        // [1, n-2] reads in bounds and any other has no neighbours.  All nine row loads (three
+        // adjacent cells each) are issued together.
+        int n_cand = 0;
+        if (dense.table) {  // uniform
+            const int ta = ci - dense.i0, tb = cj - dense.j0, tc = ck - dense.k0;
+            if (ta >= 1 && tb >= 1 && tc >= 1 && ta <= dense.nx - 2 && tb <= dense.ny - 2 && tc <= dense.nz - 2) {
+                Int3 rows[9];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const unsigned long long key = ndt_key(ck + dk, cj + dj, ci + d - 1);
-                    unsigned hpos = ndt_hash(key) & mask;
-                    for (;;) {
-                        const unsigned long long hk = hkeys[hpos];
-                        if (hk == key) {
-                            v3[d] = hvals[hpos];
-                            break;
+                for (int row = 0; row < 9; ++row) {  // (dk, dj); the three di cells are adjacent in x
+                    const int dj = row % 3 - 1, dk = row / 3 - 1;
+                    rows[row] = *(const Int3 *) (dense.table +
+                                                 (((size_t) (tc + dk) * dense.ny + (tb + dj)) * dense.nx + (ta - 1)));
+                }
+#pragma unroll
+                for (int row = 0; row < 9; ++row) {
+                    const int v3[3] = {rows[row].a, rows[row].b, rows[row].c};
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+                        if (v3[d] != -1) {
+                            s_near[n_cand * kBlock + threadIdx.x] = (unsigned) v3[d];
+                            ++n_cand;
                         }
-                        if (hk == kEmptyKey) break;
-                        hpos = (hpos + 1) & mask;
-                    }
                 }
             }
+        } else {
+#pragma unroll 1
+            for (int nb = 0; nb < 27; ++nb) {
+                const int di = nb % 3 - 1, dj = (nb / 3) % 3 - 1, dk = nb / 9 - 1;
+                const unsigned long long key = ndt_key(ck + dk, cj + dj, ci + di);
+                unsigned hpos = ndt_hash(key) & mask;
+                for (;;) {
+                    const unsigned long long hk = hkeys[hpos];
+                    if (hk == key) {
+                        s_near[n_cand * kBlock + threadIdx.x] = hvals[hpos];
+                        ++n_cand;
+                        break;
+                    }
+                    if (hk == kEmptyKey) break;
+                    hpos = (hpos + 1) & mask;
+                }
+            }
+        }
+        // 1b: kd-tree radius test in float on the float means (one 16-byte load each), four
+        // candidates per trip so that four loads are in flight; survivors are compacted in place
+        // (the write index never passes the read index), still in cell order
+        int n_near = 0;
+#pragma unroll 1
+        for (int r = 0; r < n_cand; r += 4) {
+            unsigned cv[4];
+            float4 cm[4];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const unsigned vi = v3[d];
-                if (vi == 0xFFFFFFFFu) continue;
-                // kd-tree radius test in float on the float means (one 16-byte load)
-                const float4 m = meanf[vi];
-                const float fx = __fsub_rn(xt0, m.x), fy = __fsub_rn(xt1, m.y), fz = __fsub_rn(xt2, m.z);
+            for (int u = 0; u < 4; ++u) cv[u] = s_near[min(r + u, n_cand - 1) * kBlock + threadIdx.x];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cm[u] = meanf[cv[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float fx = __fsub_rn(xt0, cm[u].x), fy = __fsub_rn(xt1, cm[u].y), fz = __fsub_rn(xt2, cm[u].z);
                 const float dd = __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz));
-                if (!((double) dd < A.res2)) continue;
-                s_near[n_near * kBlock + threadIdx.x] = vi;
-                ++n_near;
+                if (r + u < n_cand && (double) dd < A.res2) {
+                    s_near[n_near * kBlock + threadIdx.x] = cv[u];
+                    ++n_near;
+                }
             }
         }
         // the next voxel's record (mean + inverse covariance, 96 B) is requested before the
