@@ -445,7 +445,7 @@ static int wait_flag(wm_ctx *ctx, unsigned seq) {
                 WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 break;
             }
-            yielding = waited > std::chrono::microseconds(80);
+            yielding = waited > std::chrono::microseconds(ctx->tune_spin_us);
         }
     }
     return WM_OK;
@@ -629,6 +629,11 @@ int wm_ctx_create(wm_ctx **out, int device) {
     if (const char *e = getenv("WM_TUNE_KNN_R0")) {
         const float v = (float) atof(e);
         if (v >= 0.25f && v <= 8.f) ctx->tune_knn_r0 = v;
+    }
+    if (const char *e = getenv("WM_TUNE_SPIN_US")) ctx->tune_spin_us = atoi(e);
+    if (const char *e = getenv("WM_TUNE_NDT_BLOCKS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 4096) ctx->tune_ndt_blocks = v;
     }
     if (const char *e = getenv("WM_TUNE_GICP_BLOCKS")) {
         const int v = atoi(e);

@@ -19,6 +19,7 @@
 
 #include "wm_internal.hpp"
 
+#include <chrono>
 #include <float.h>
 #include <math.h>
 
@@ -28,7 +29,7 @@ constexpr int kNdtAcc = 28;  // score, 6 gradient entries, the 21 of the Hessian
 __host__ __device__ constexpr int ndt_tri(int i, int j) {  // (i <= j) -> accumulator slot
     return 7 + i * 6 - i * (i - 1) / 2 + (j - i);
 }
-constexpr int kNdtBlocks = 1024;
+constexpr int kNdtBlocks = 4096;  // upper bound; ctx->tune_ndt_blocks workgroups per pass
 constexpr unsigned long long kEmptyKey = ~0ull;
 
 struct NdtVoxel {
@@ -686,6 +687,7 @@ struct NdtEval {
     double d1, d2;
     int evals = 0;
     float kernel_ms = 0;
+    double host_launch_us = 0, host_wait_us = 0;  // WM_NDT_PROFILE=2: wall time inside the launch calls / the wait
 };
 
 // score (+ gradient, + Hessian) at pose p; returns <0 on HIP error via *rc
@@ -702,7 +704,7 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
     angle_derivatives(p, E.prm->pcl_d1_sign, &A);
     const unsigned n = (unsigned) ctx->n_src;
     int nb = (int) ((n + kBlock - 1) / kBlock);
-    if (nb > kNdtBlocks) nb = kNdtBlocks;
+    if (nb > ctx->tune_ndt_blocks) nb = ctx->tune_ndt_blocks;
     if (nb < 1) nb = 1;
     double *partials = ctx->partials.as<double>();
     const NdtVoxel *vox = ctx->ndt_vox.as<NdtVoxel>();
@@ -714,6 +716,7 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
         dense = NdtDense{ctx->ndt_dense.as<int>(), ctx->ndt_dense_lo[0], ctx->ndt_dense_lo[1],
                          ctx->ndt_dense_lo[2], ctx->ndt_dense_dim[0], ctx->ndt_dense_dim[1],
                          ctx->ndt_dense_dim[2]};
+    const auto t_launch0 = std::chrono::steady_clock::now();
     if (ctx->ndt_profile) (void) hipEventRecord(ctx->ev_a, ctx->stream);
     if (hess && grad)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<true, true>), dim3(nb), dim3(kBlock), 0,
@@ -733,12 +736,16 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
         *rc = WM_ERR_HIP;
         return 0;
     }
+    const auto t_launch1 = std::chrono::steady_clock::now();
     // sums over blocks, formed on the device (fixed order); 224 bytes come back
     if (fast_fetch_sum(ctx, ctx->h_ndt, partials, (unsigned) nb, kNdtAcc) != WM_OK) {
         ctx->last_error = "ndt_eval: HIP error";
         *rc = WM_ERR_HIP;
         return 0;
     }
+    const auto t_wait1 = std::chrono::steady_clock::now();
+    E.host_launch_us += std::chrono::duration<double, std::micro>(t_launch1 - t_launch0).count();
+    E.host_wait_us += std::chrono::duration<double, std::micro>(t_wait1 - t_launch1).count();
     float ms = 0;
     if (ctx->ndt_profile) {  // event timing needs the stream drained; off unless asked for
         (void) hipStreamSynchronize(ctx->stream);
@@ -981,6 +988,9 @@ int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *prm, double T_out[16], wm_ndt
         stats->evaluations = E.evals;
         stats->score = ctx->n_src > 0 ? score / (double) ctx->n_src_input : 0;
         stats->deriv_kernel_ms = E.kernel_ms;
+        if (ctx->trace)
+            fprintf(stderr, "[wm] ndt: %d passes, host time in launches %.0f us, in waits %.0f us, kernels %.3f ms\n",
+                    E.evals, E.host_launch_us, E.host_wait_us, E.kernel_ms);
     }
     if (!converged) return WM_NOT_CONVERGED;
     float Tf[16];

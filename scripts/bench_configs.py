@@ -27,13 +27,21 @@ def main():
     only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None  # gicp | ndt
 
     def timed(fn):
+        """median over `reps` individually timed registrations (ms) after one warm-up call.
+        The median, not the mean: on this pool a process sees ONE stall of 60-90 ms at a random
+        moment in its first few hundred milliseconds of GPU load (it lands in whichever call is
+        running -- set_source, set_target or an align -- and never recurs); a mean over five
+        registrations would report that as a 2x slower NDT."""
         fn()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        times = []
         for _ in range(reps):
+            t0 = time.perf_counter()
             r = fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps * 1e3, r
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) * 1e3)
+        timed.last = [round(t, 3) for t in times]
+        return float(np.median(times)), r
 
     if only in (None, "gicp"):
         run_gicp(ctx, dev, timed, synth, torch)
@@ -54,6 +62,7 @@ def run_gicp(ctx, dev, timed, synth, torch):
     print(json.dumps({"config": "GICPMatcher 500k<->500k (BASELINE configs[2])", "ms_per_registration": ms,
                       "registrations_per_s": 1e3 / ms, "rc": r["rc"],
                       "outer_iterations": r.get("iterations"), "translation_error_m": err,
+                      "ms_each": timed.last,
                       "detail": {k: v for k, v in r.items() if k not in ("T",) and np.isscalar(v)}}))
 
 
@@ -62,16 +71,27 @@ def run_ndt(ctx, dev, timed, synth, torch):
     ref, tgt, T_gt = synth.pair(2_000_000, seed=42)
     d_ref, d_tgt = torch.from_numpy(ref).to(dev), torch.from_numpy(tgt).to(dev)
 
+    calls = []  # per-call wall time of every C-ABI call (ms), to spot a one-off slow call
+
     def ndt():
+        t0 = time.perf_counter()
         ctx.set_source(d_ref)
+        t1 = time.perf_counter()
         ctx.set_target(d_tgt)
-        return ctx.ndt_align(res=0.5)
+        t2 = time.perf_counter()
+        r = ctx.ndt_align(res=0.5)
+        t3 = time.perf_counter()
+        calls.append([round((t1 - t0) * 1e3, 2), round((t2 - t1) * 1e3, 2), round((t3 - t2) * 1e3, 2)])
+        return r
     ms, r = timed(ndt)
     err = float(np.linalg.norm(r["T"][:3, 3] - T_gt[:3, 3])) if r["T"] is not None else None
     print(json.dumps({"config": "NDTMatcher 2M<->2M, 0.5 m voxels (BASELINE configs[3])",
                       "ms_per_registration": ms, "registrations_per_s": 1e3 / ms, "rc": r["rc"],
                       "iterations": r["iterations"], "n_voxels": r["n_voxels"],
-                      "derivative_passes": r["evaluations"], "translation_error_m": err}))
+                      "derivative_passes": r["evaluations"], "translation_error_m": err,
+                      "deriv_kernel_ms": r.get("deriv_kernel_ms"),
+                      "ms_each": timed.last,
+                      "set_source_set_target_align_ms_per_call": calls}))
 
 
 if __name__ == "__main__":
