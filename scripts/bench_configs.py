@@ -28,10 +28,11 @@ def main():
 
     def timed(fn):
         """median over `reps` individually timed registrations (ms) after one warm-up call.
-        The median, not the mean: on this pool a process sees ONE stall of 60-90 ms at a random
-        moment in its first few hundred milliseconds of GPU load (it lands in whichever call is
-        running -- set_source, set_target or an align -- and never recurs); a mean over five
-        registrations would report that as a 2x slower NDT."""
+        The median, not the mean: on this pool the device stalls ONCE per process for 70-80 ms
+        somewhere in the first one or two NDT registrations (the time shows up in the waits for
+        the f64 derivative kernels, whose own event-timed durations are unchanged; the ICP and
+        GICP kernels never trigger it) and never again; a mean over five registrations would
+        report that as a 2x slower NDT.  `ms_each` lists every registration."""
         fn()
         torch.cuda.synchronize()
         times = []
