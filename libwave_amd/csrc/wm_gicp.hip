@@ -656,7 +656,8 @@ static int compute_covariances(wm_ctx *ctx, int k, double eps) {
     if (k > 32) return WM_ERR_ARG;
     const bool same = ctx->gicp_cov_k == k && ctx->gicp_cov_eps == eps;
     if (!(ctx->gicp_cov_tgt_valid && same)) {
-        // target: neighbours from the level-0 grid (built by wm_set_target)
+        // target: neighbours from the level-0 search grid
+        if (!ctx->levels[0].built) WM_TRY(ensure_levels(ctx, -1.0));
         WM_HIP(ctx, ctx->gicp_c2.reserve((ctx->n_tgt_input > 0 ? ctx->n_tgt_input : 1) * 9 * sizeof(double)));
         const GridDev &g = ctx->levels[0].d;
         const float4 *orig = ctx->tgt_orig.as<float4>();

@@ -755,7 +755,8 @@ int wm_set_target(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem
     size_t valid = 0;
     WM_TRY(compute_bbox(ctx, ctx->tgt_orig.as<float4>(), n, &ctx->tgt_bbox, &valid));
     ctx->n_tgt = valid;
-    if (valid > 0) WM_TRY(ensure_levels(ctx, -1.0));  // level 0 now; coarser levels at align
+    // the search grid is built by the first caller that searches (ensure_levels in the ICP / GICP /
+    // search entry points): an NDT registration never needs it
     return WM_OK;
 }
 
