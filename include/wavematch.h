@@ -308,6 +308,20 @@ int wm_icp_shard_local_stats(wm_ctx *ctx, void *stats_dev);
 int wm_icp_shard_apply(wm_ctx *ctx, const void *stats_dev);
 int wm_icp_shard_poll(wm_ctx *ctx, int *done, double T_out[16], wm_icp_stats *stats);
 
+/* Sharded NDT ("replicate the target, shard ref by index range"; no reference
+ * counterpart -- PCL's NDT is single-threaded).  Every rank sets the SAME two clouds and builds
+ * the same voxel model (cheap: < 0.5 ms at 2M points); the Morton-ordered source is dealt out
+ * to the ranks in chunks of 4096 points, round-robin (every rank works on the whole scene at
+ * 1/world density: equal work), rank r evaluates its chunks in every derivative pass, and the 28
+ * sums of that pass (score, gradient, upper triangle of the Hessian) are summed over the ranks by
+ * `reduce` before the Newton / More-Thuente logic sees them.  `reduce` must leave bit-identical
+ * values on every rank (an RCCL / gloo all-reduce does): all ranks then take the same decisions
+ * and return the same transform, with no broadcast.  It is called on the thread that called
+ * wm_ndt_align, with a host array; return 0 on success (anything else aborts the registration
+ * with WM_ERR_STATE).  world = 1 or reduce = NULL restores the single-GPU behaviour. */
+typedef int (*wm_allreduce_fn)(double *vals, int n, void *user);
+int wm_ndt_set_shard(wm_ctx *ctx, int rank, int world, wm_allreduce_fn reduce, void *user);
+
 /* Host-only twin of the per-iteration solve + PCL stopping rules (no GPU touched):
  * the very function the device runs after the all-reduce, callable on the CPU so
  * that the sharded control flow can be exercised without a GPU. */

@@ -72,6 +72,8 @@ class NdtStats(C.Structure):
 _dp = C.POINTER(C.c_double)
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
+# int reduce(double *vals, int n, void *user): in-place sum over the ranks (include/wavematch.h)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, _dp, C.c_int, C.c_void_p)
 _LIB = None
 
 
@@ -133,6 +135,7 @@ def lib():
         L.wm_ndt_align.argtypes = [C.c_void_p, C.POINTER(NdtParams), _dp, C.POINTER(NdtStats)]
         L.wm_ndt_derivatives.argtypes = [C.c_void_p, C.POINTER(NdtParams), _dp, _dp, _dp, _dp,
                                          C.POINTER(C.c_int)]
+        L.wm_ndt_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]
         L.wm_get_iteration_times.argtypes = [C.c_void_p, _fp, C.c_int]
         L.wm_get_correspondences.argtypes = [C.c_void_p, _ip, _fp, C.c_size_t]
         L.wm_nn_search.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int, _ip, _fp, C.c_size_t, _fp]
@@ -379,6 +382,14 @@ class Context:
                                              H.ctypes.data_as(_dp), C.byref(nv)),
                     "wm_ndt_derivatives")
         return score.value, g, H, nv.value
+
+    def ndt_set_shard(self, rank, world, reduce=None):
+        """This context evaluates slice `rank` of `world` of the source in every NDT derivative
+        pass; `reduce` = an ALLREDUCE_FN (see sharding.make_allreduce) that sums the 28 pass totals
+        over the ranks.  The context keeps the callback alive."""
+        self._ndt_reduce = reduce if reduce is not None else ALLREDUCE_FN(0)
+        self._check(lib().wm_ndt_set_shard(self._h, int(rank), int(world), self._ndt_reduce, None),
+                    "wm_ndt_set_shard")
 
     # ---- sharded (multi-GPU) stepping
     def set_stream(self, stream_ptr, external=True):

@@ -153,6 +153,9 @@ struct wm_ctx {
     unsigned *h_sig = nullptr;           // pinned: completion flag polled by fast_fetch
     unsigned sig_seq = 0;
     double *h_gicp = nullptr;            // pinned, device-visible: the GICP objective's partial sums land here
+    int ndt_rank = 0, ndt_world = 1;     // wm_ndt_set_shard: this context's slice of the source
+    int (*ndt_reduce)(double *, int, void *) = nullptr;
+    void *ndt_reduce_user = nullptr;
     double *h_ndt = nullptr;             // pinned: the NDT derivative passes' block partials
     bool ndt_profile = false;            // HIP events around every derivative pass (kernel_ms)
     bool gicp_profile = false;           // HIP events around every objective evaluation (fdf_kernel_ms)

@@ -25,6 +25,7 @@
 
 namespace wm {
 
+constexpr unsigned kNdtChunkLog2 = 12;  // sharded NDT: ranks take turns in chunks of 4096 source points
 constexpr int kNdtAcc = 28;  // score, 6 gradient entries, the 21 of the Hessian's upper triangle
 __host__ __device__ constexpr int ndt_tri(int i, int j) {  // (i <= j) -> accumulator slot
     return 7 + i * 6 - i * (i - 1) / 2 + (j - i);
@@ -304,14 +305,22 @@ __device__ __forceinline__ double dot3d(const double *a, const double *b) {
 // 256-register line that would leave a single wave with nothing to hide its loads behind)
 template <bool GRAD, bool HESS>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2)))
-    k_ndt_derivs(const float4 *__restrict__ src, unsigned n, const NdtVoxel *__restrict__ vox,
+    k_ndt_derivs(const float4 *__restrict__ src, unsigned n, unsigned n_total, unsigned shard_rank,
+                 unsigned shard_world, const NdtVoxel *__restrict__ vox,
                  const float4 *__restrict__ meanf, const unsigned long long *__restrict__ hkeys, const unsigned *__restrict__ hvals,
                  unsigned mask, NdtDense dense, NdtArgs A, double *__restrict__ partials) {
     __shared__ unsigned s_near[27 * kBlock];  // per-lane lists, pass 1 -> pass 2 (lane-private)
     double acc[kNdtAcc];
 #pragma unroll
     for (int k = 0; k < kNdtAcc; ++k) acc[k] = 0.0;
-    for (unsigned idx = blockIdx.x * kBlock + threadIdx.x; idx < n; idx += gridDim.x * kBlock) {
+    // n = local count (a multiple of the chunk when sharded); the global index interleaves the
+    // ranks chunk by chunk, so every rank works on a uniform sample of the Morton-ordered cloud
+    for (unsigned loc = blockIdx.x * kBlock + threadIdx.x; loc < n; loc += gridDim.x * kBlock) {
+        const unsigned idx = shard_world > 1
+                                 ? (((loc >> kNdtChunkLog2) * shard_world + shard_rank) << kNdtChunkLog2) |
+                                       (loc & ((1u << kNdtChunkLog2) - 1u))
+                                 : loc;
+        if (idx >= n_total) continue;
         const float4 sp = src[idx];
         const float xt0 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.Tf[0], sp.x), __fmul_rn(A.Tf[1], sp.y)),
                                               __fmul_rn(A.Tf[2], sp.z)), A.Tf[3]);
@@ -702,7 +711,18 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
     A.d1 = E.d1;
     A.d2 = E.d2;
     angle_derivatives(p, E.prm->pcl_d1_sign, &A);
-    const unsigned n = (unsigned) ctx->n_src;
+    // this rank's share of the Morton-ordered source (all of it unless wm_ndt_set_shard): chunks
+    // of 4096 points dealt out round-robin, so every rank sees the whole scene at 1/world density
+    // (contiguous slices would give the ranks different neighbour counts, i.e. different times)
+    const bool sharded = ctx->ndt_world > 1 && ctx->ndt_reduce;
+    const unsigned n_total = (unsigned) ctx->n_src;
+    const unsigned s_rank = sharded ? (unsigned) ctx->ndt_rank : 0u, s_world = sharded ? (unsigned) ctx->ndt_world : 1u;
+    unsigned n = n_total;
+    if (sharded) {
+        const unsigned chunks = (n_total + (1u << kNdtChunkLog2) - 1u) >> kNdtChunkLog2;
+        const unsigned mine = chunks > s_rank ? (chunks - s_rank + s_world - 1u) / s_world : 0u;
+        n = mine << kNdtChunkLog2;
+    }
     int nb = (int) ((n + kBlock - 1) / kBlock);
     if (nb > ctx->tune_ndt_blocks) nb = ctx->tune_ndt_blocks;
     if (nb < 1) nb = 1;
@@ -720,15 +740,18 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
     if (ctx->ndt_profile) (void) hipEventRecord(ctx->ev_a, ctx->stream);
     if (hess && grad)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<true, true>), dim3(nb), dim3(kBlock), 0,
-                           ctx->stream, src, n, vox, ctx->ndt_meanf.as<float4>(), hk, hv, ctx->ndt_hmask, dense, A,
+                           ctx->stream, src, n, n_total, s_rank, s_world, vox, ctx->ndt_meanf.as<float4>(), hk,
+                           hv, ctx->ndt_hmask, dense, A,
                            partials);
     else if (grad)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<true, false>), dim3(nb), dim3(kBlock), 0,
-                           ctx->stream, src, n, vox, ctx->ndt_meanf.as<float4>(), hk, hv, ctx->ndt_hmask, dense, A,
+                           ctx->stream, src, n, n_total, s_rank, s_world, vox, ctx->ndt_meanf.as<float4>(), hk,
+                           hv, ctx->ndt_hmask, dense, A,
                            partials);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<false, true>), dim3(nb), dim3(kBlock), 0,
-                           ctx->stream, src, n, vox, ctx->ndt_meanf.as<float4>(), hk, hv, ctx->ndt_hmask, dense, A,
+                           ctx->stream, src, n, n_total, s_rank, s_world, vox, ctx->ndt_meanf.as<float4>(), hk,
+                           hv, ctx->ndt_hmask, dense, A,
                            partials);
     if (ctx->ndt_profile) (void) hipEventRecord(ctx->ev_b, ctx->stream);
     if (!ctx->h_ndt && hipHostMalloc((void **) &ctx->h_ndt, 64 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
@@ -753,7 +776,13 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
     }
     E.kernel_ms += ms;
     E.evals += 1;
-    const double *a = ctx->h_ndt;
+    double a[kNdtAcc];
+    for (int k = 0; k < kNdtAcc; ++k) a[k] = ctx->h_ndt[k];
+    if (sharded && ctx->ndt_reduce(a, kNdtAcc, ctx->ndt_reduce_user) != 0) {
+        ctx->last_error = "ndt_eval: the all-reduce callback failed";
+        *rc = WM_ERR_STATE;
+        return 0;
+    }
     if (grad)
         for (int k = 0; k < 6; ++k) grad[k] = a[1 + k];
     if (hess) {
@@ -935,6 +964,15 @@ void wm_ndt_default_params(wm_ndt_params *p) {
     p->outlier_ratio = 0.55;
     p->skip_line_search = 0;
     p->pcl_d1_sign = 1;
+}
+
+int wm_ndt_set_shard(wm_ctx *ctx, int rank, int world, wm_allreduce_fn reduce, void *user) {
+    if (!ctx || world < 1 || rank < 0 || rank >= world) return WM_ERR_ARG;
+    ctx->ndt_rank = rank;
+    ctx->ndt_world = world;
+    ctx->ndt_reduce = reduce;
+    ctx->ndt_reduce_user = user;
+    return WM_OK;
 }
 
 int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *prm, double T_out[16], wm_ndt_stats *stats) {

@@ -141,3 +141,62 @@ class ShardedIcp:
             out = self.align(params=p, _retry=True)
             out["redone_with_full_source"] = True
         return out
+
+
+def make_allreduce(dist, device=None):
+    """The `reduce` callback of wm_ndt_set_shard over a torch.distributed group: sums the n
+    doubles of one NDT derivative pass over the ranks, in place.  `device` = the rank's GPU for
+    the nccl (RCCL) backend -- the values make one round trip through a device tensor -- or None
+    for a host backend (gloo).  Every rank receives bit-identical sums (ring / tree all-reduce
+    forms each element once and distributes it), which is what keeps the ranks' Newton and
+    line-search decisions identical."""
+    import torch
+
+    def reduce(vals, n, _user):
+        try:
+            a = np.ctypeslib.as_array(vals, shape=(n,))
+            t = torch.from_numpy(a.copy())
+            if device is not None:
+                t = t.to(device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            a[:] = t.cpu().numpy()
+            return 0
+        except Exception:  # never unwind through the C caller
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    return capi.ALLREDUCE_FN(reduce)
+
+
+class ThreadGroupReduce:
+    """In-process stand-in for the all-reduce: `world` threads (one context each, e.g. several
+    contexts on ONE GPU) meet at a barrier, the values are added in rank order, and every thread
+    gets the same sums.  Used by the GPU tests; shows what `reduce` has to guarantee."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self._barrier = threading.Barrier(world)
+        self._slots = [None] * world
+        self._sum = None
+
+    def callback(self, rank):
+        def reduce(vals, n, _user):
+            try:
+                a = np.ctypeslib.as_array(vals, shape=(n,))
+                self._slots[rank] = a.copy()
+                if self._barrier.wait() == 0:
+                    tot = np.zeros(n)
+                    for r in range(self.world):
+                        tot += self._slots[r]
+                    self._sum = tot
+                self._barrier.wait()
+                a[:] = self._sum
+                self._barrier.wait()  # nobody overwrites _sum before everyone has read it
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        return capi.ALLREDUCE_FN(reduce)

@@ -99,3 +99,49 @@ def test_ndt_hash_grid_and_dense_table_agree_bit_for_bit(wm, testscan, oracle):
     assert np.array_equal(g1, g0) and np.array_equal(H1, H0)
     assert a1["rc"] == a0["rc"] == 0 and np.array_equal(a1["T"], a0["T"])
     assert a1["iterations"] == a0["iterations"]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_ndt_equals_unsharded(wm, world):
+    """wm_ndt_set_shard: `world` contexts on one GPU (one thread each) evaluate their slices of the
+    source; the 28 pass totals are summed in rank order by a barrier-based callback standing in for
+    the RCCL all-reduce.  All ranks must return the SAME transform (bit for bit: identical sums ->
+    identical Newton / line-search decisions) and it must equal the unsharded registration up to
+    the summation order of the partial sums."""
+    import threading
+    from libwave_amd import sharding
+    ref, tgt, _ = synth.pair(60000, seed=11)
+    single = wm.Context(0)
+    single.set_source(ref)
+    single.set_target(tgt)
+    want = single.ndt_align(res=1.0)
+    assert want["rc"] == wm.WM_OK
+    group = sharding.ThreadGroupReduce(world)
+    ctxs = [wm.Context(0) for _ in range(world)]
+    got = [None] * world
+
+    def run(r):
+        c = ctxs[r]
+        c.ndt_set_shard(r, world, group.callback(r))
+        c.set_source(ref)
+        c.set_target(tgt)
+        got[r] = c.ndt_align(res=1.0)
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    for r in range(world):
+        assert got[r] is not None and got[r]["rc"] == wm.WM_OK
+        assert np.array_equal(got[r]["T"], got[0]["T"])
+        assert got[r]["iterations"] == want["iterations"]
+        assert got[r]["evaluations"] == want["evaluations"]
+    # the transform is returned through PCL's float matrix: one float ulp of a rotation entry is
+    # ~1e-7 rad, which is what a different summation order of the f64 partial sums can flip
+    dt, ang = pose_error(got[0]["T"], want["T"])
+    assert dt <= 5e-7 and ang <= 5e-7, (dt, ang)
+    assert abs(got[0]["score"] - want["score"]) <= 1e-9 * abs(want["score"])
+    # back to the whole cloud on a context that was a rank
+    ctxs[0].ndt_set_shard(0, 1)
+    again = ctxs[0].ndt_align(res=1.0)
+    assert np.array_equal(again["T"], want["T"])

@@ -156,3 +156,66 @@ def test_host_icp_state_machine_matches_oracle_single_rank(oracle, wm):
     assert (got["iterations"], got["state"]) == (want["iterations"], want["state"])
     dt, ang = pose_error(got["T"], want["T"])
     assert dt <= 1e-9 and ang <= 1e-9
+
+
+def _reduce_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import torch.distributed as dist
+    from libwave_amd import sharding
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cb = sharding.make_allreduce(dist)          # the callback wm_ndt_set_shard is given
+        out = []
+        for call in range(3):                        # as many calls as derivative passes
+            vals = (C.c_double * 28)(*[(rank + 1) * 0.1 * (k + 1) + call for k in range(28)])
+            rc = cb(vals, 28, None)
+            out.append((rc, list(vals)))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_ndt_allreduce_callback_over_gloo_world2():
+    """The reduce callback of the sharded NDT (wm_ndt_set_shard): called through its C signature
+    on two gloo ranks, it must leave the same sums -- bit for bit -- on both."""
+    import multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_reduce_worker, args=(r, world, 29761, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=100) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for call in range(3):
+        rc0, v0 = res[0][call]
+        rc1, v1 = res[1][call]
+        assert rc0 == 0 and rc1 == 0 and v0 == v1
+        want = [(0.1 * (k + 1) + call) + (0.2 * (k + 1) + call) for k in range(28)]
+        assert np.allclose(v0, want, rtol=1e-15, atol=0)
+
+
+def test_thread_group_reduce_sums_in_rank_order():
+    import ctypes as C
+    import threading
+    from libwave_amd import sharding
+    g = sharding.ThreadGroupReduce(3)
+    out = [None] * 3
+
+    def run(r):
+        cb = g.callback(r)
+        for call in range(4):
+            a = (C.c_double * 5)(*[10.0 ** r + k + call for k in range(5)])
+            assert cb(a, 5, None) == 0
+            out[r] = list(a)
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(30)
+    assert out[0] == out[1] == out[2] == [111.0 + 3 * (k + 3) for k in range(5)]
