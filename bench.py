@@ -18,6 +18,13 @@ objects: "roofline" (correspondence kernel vs the HBM roof) and "cpu_baseline"
 import argparse
 import json
 import os
+
+# One process per GPU: keep numpy / torch CPU thread pools small.  Their default is one thread per
+# logical CPU (256 here); the pools' spinning workers burn the container's CPU quota during set-up
+# and the whole process is then throttled for tens of milliseconds somewhere in the timed region
+# (cgroup cpu.stat: nr_throttled) -- seen as one 50-90 ms registration per run.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "4")
 import sys
 import time
 
@@ -166,12 +173,15 @@ def main():
     t0 = time.perf_counter()
     nn_ms = 0.0
     nn_launches = 0
+    step_ms = []
     for k in range(a.steps):
         # HIP events around every launch of the correspondence kernel cost a barrier packet
         # each, so they bracket the launches of ONE timed step in three (at least the last);
         # the others run exactly as a caller's registration would
         timed = (k % 3 == 2) or k == a.steps - 1
+        t_step = time.perf_counter()
         r = step(1 if timed else 0)
+        step_ms.append((time.perf_counter() - t_step) * 1e3)  # (align blocks: host time = step time)
         if timed:
             nn_ms += r["nn_ms"]
             nn_launches += r["nn_launches"]
@@ -215,6 +225,7 @@ def main():
                 "icp_iterations_per_s": regs_per_s_raw * a.iters,
                 "final_translation_error_m": err_t, "grid_cell_m": r.get("grid_cell"),
                 "deferred_queries_per_registration": r.get("deferred"),
+                "ms_each_step_rank0": [round(t, 3) for t in step_ms],
             },
             "roofline": {
                 "bound": "hbm", "kernel": "wm::k_nn_grid (correspondence search)",

@@ -7,6 +7,13 @@ Each is one full C-ABI registration with both clouds already resident in HBM
 Prints one JSON line per config; `python bench.py` stays the headline (configs[1])."""
 import json
 import os
+
+# One process per GPU: keep numpy / torch CPU thread pools small.  Their default is one thread per
+# logical CPU (256 here); the pools' spinning workers burn the container's CPU quota during set-up
+# and the whole process is then throttled for tens of milliseconds somewhere in the timed region
+# (cgroup cpu.stat: nr_throttled) -- seen as one 50-90 ms registration per run.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "4")
 import sys
 import time
 
@@ -28,11 +35,11 @@ def main():
 
     def timed(fn):
         """median over `reps` individually timed registrations (ms) after one warm-up call.
-        The median, not the mean: on this pool the device stalls ONCE per process for 70-80 ms
-        somewhere in the first one or two NDT registrations (the time shows up in the waits for
-        the f64 derivative kernels, whose own event-timed durations are unchanged; the ICP and
-        GICP kernels never trigger it) and never again; a mean over five registrations would
-        report that as a 2x slower NDT.  `ms_each` lists every registration."""
+        The median, and every registration listed in `ms_each`: a 50-90 ms outlier once per
+        process turned out to be the container's CPU quota (cgroup cpu.max = 16 CPUs): numpy's
+        and torch's thread pools (one thread per logical CPU, 256) burn it during set-up and the
+        whole process is throttled somewhere in the next periods -- inside whichever call is
+        waiting for the GPU.  The thread-pool limits at the top of this file remove it."""
         fn()
         torch.cuda.synchronize()
         times = []

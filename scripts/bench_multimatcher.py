@@ -6,6 +6,13 @@ n_threads matchers).  Reports registrations/s for small clouds, where one regist
 fill the GPU and concurrency is what buys throughput.  ctypes releases the GIL during the calls."""
 import json
 import os
+
+# One process per GPU: keep numpy / torch CPU thread pools small.  Their default is one thread per
+# logical CPU (256 here); the pools' spinning workers burn the container's CPU quota during set-up
+# and the whole process is then throttled for tens of milliseconds somewhere in the timed region
+# (cgroup cpu.stat: nr_throttled) -- seen as one 50-90 ms registration per run.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "4")
 import sys
 import threading
 import time

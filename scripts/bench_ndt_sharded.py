@@ -12,6 +12,13 @@ dealt out round-robin, i.e. the whole scene at 1/N density) in each derivative p
 registrations, max over ranks)."""
 import json
 import os
+
+# One process per GPU: keep numpy / torch CPU thread pools small.  Their default is one thread per
+# logical CPU (256 here); the pools' spinning workers burn the container's CPU quota during set-up
+# and the whole process is then throttled for tens of milliseconds somewhere in the timed region
+# (cgroup cpu.stat: nr_throttled) -- seen as one 50-90 ms registration per run.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "4")
 import sys
 import time
 
