@@ -101,6 +101,50 @@ def test_ndt_hash_grid_and_dense_table_agree_bit_for_bit(wm, testscan, oracle):
     assert a1["iterations"] == a0["iterations"]
 
 
+def test_ndt_queries_around_and_outside_the_voxel_lattice(wm, oracle):
+    """The dense cell table carries a two-cell empty margin and queries outside it skip the
+    look-up altogether: source points placed 0, 1, 2, 3 and 50 cells outside every face of the
+    target's bounding box (and a few non-finite ones) must contribute exactly what the oracle's
+    kd-tree radius search gives them, and the hash path must agree bit for bit."""
+    import os
+    rng = np.random.default_rng(3)
+    res = 0.5
+    target = (rng.random((40000, 3)) * [6.0, 4.0, 2.0] + [1.0, -2.0, 0.25]).astype(np.float32)
+    lo, hi = target.min(0), target.max(0)
+    pts = [target[::40] + rng.normal(0, 0.05, (1000, 3)).astype(np.float32)]
+    for cells in (0.0, 0.999, 1.0, 1.999, 2.0, 2.5, 3.0, 50.0):
+        for axis in range(3):
+            for side in (-1, 1):
+                p = (rng.random((40, 3)) * (hi - lo) + lo).astype(np.float32)
+                p[:, axis] = (hi[axis] + cells * res) if side > 0 else (lo[axis] - cells * res)
+                pts.append(p)
+    src = np.concatenate(pts).astype(np.float32)
+    src[5] = [np.nan, 0, 0]
+    src[77] = [0, np.inf, 0]
+    grid = oracle.NdtGrid(target, res)
+    oprm = oracle.ndt_params(res=res)
+    finite = np.isfinite(src).all(1)
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["WM_TUNE_NDT_DENSE"] = mode
+        try:
+            c = wm.Context(0)
+        finally:
+            del os.environ["WM_TUNE_NDT_DENSE"]
+        c.set_source(src)
+        c.set_target(target)
+        for pose in (np.zeros(6), np.array([0.3, -0.2, 0.1, 0.01, -0.02, 0.015])):
+            s, g, H, nv = c.ndt_derivatives(pose, res=res)
+            os_, og, oH = grid.derivatives(src[finite], pose, oprm)
+            assert nv == grid.size()
+            assert abs(s - os_) <= 1e-9 * abs(os_)
+            np.testing.assert_allclose(g, og, rtol=1e-8, atol=1e-8 * np.abs(og).max())
+            np.testing.assert_allclose(H, oH, rtol=1e-8, atol=1e-8 * np.abs(oH).max())
+            out.setdefault(mode, []).append((s, g, H))
+    for (s1, g1, H1), (s0, g0, H0) in zip(out["1"], out["0"]):
+        assert s1 == s0 and np.array_equal(g1, g0) and np.array_equal(H1, H0)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_ndt_equals_unsharded(wm, world):
     """wm_ndt_set_shard: `world` contexts on one GPU (one thread each) evaluate their slices of the
