@@ -28,6 +28,28 @@ def test_gicp_covariances_match_oracle(wm, ctx, oracle, k):
         np.testing.assert_allclose(ev, np.tile([1e-3, 1, 1], (200, 1)), atol=1e-9)
 
 
+def test_gicp_covariances_with_nonfinite_target_points(wm, ctx, oracle):
+    """Target covariances are computed in the search grid's own order when every target point is
+    finite and in caller order otherwise (non-finite points are not in the grid): both routes must
+    give the finite points the oracle's matrices, addressed by CALLER index."""
+    ref, tgt, _ = synth.pair(12000, seed=9)
+    bad = np.array([0, 17, 4000, 11999])
+    tgt_nan = tgt.copy()
+    tgt_nan[bad] = np.nan
+    keep = np.ones(len(tgt), bool)
+    keep[bad] = False
+    want = oracle.gicp_covariances(tgt[keep], k=10, eps=1e-3)
+    ctx.set_source(ref)
+    ctx.set_target(tgt_nan)
+    _, ct = ctx.gicp_covariances(k=10, eps=1e-3)
+    err = np.abs(ct[keep] - want).reshape(keep.sum(), -1).max(1)
+    assert (err > 1e-9).mean() < 2e-3
+    # and the all-finite route (grid order) on the same finite points
+    ctx.set_target(tgt[keep])
+    _, ct2 = ctx.gicp_covariances(k=10, eps=1e-3)
+    assert np.array_equal(ct2, ct[keep])
+
+
 CASES = [("fullResNullMatch", -1.0, 0.0), ("nullDisplacement", 0.05, 0.0),
          ("smallDisplacement", 0.05, 0.2)]
 
