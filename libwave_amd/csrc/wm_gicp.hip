@@ -48,9 +48,18 @@ __device__ __forceinline__ void knn_insert(unsigned long long (&best)[K], unsign
 
 // k nearest neighbours of q among the cell-sorted points of grid g: scan the box of cells
 // covering ball(q, r); certified once the k-th distance is within the box margin.
+//
+// A pass resolves the box's rows (runs of x-adjacent cells = contiguous points) kKnnRows at a
+// time -- their cell_start look-ups are issued together, unconditionally (a row outside the box
+// reads row 0 and is given an empty run) -- pushes the non-empty runs into the lane's own column
+// of `runs` (LDS) and then walks them in ONE flat loop, a candidate per trip: a lane moves on to its
+// next run the moment its current one ends, so the wave makes max-over-lanes(candidates of a lane)
+// trips rather than sum-over-rows(max-over-lanes(row length)).  (Same structure, and for the same
+// reason, as the correspondence search's lane scan.)
+constexpr int kKnnRows = 8;
 template <int K>
 __device__ void knn_search(const GridDev &g, float qx, float qy, float qz, int k, float r0_cells,
-                           unsigned long long (&best)[K]) {
+                           unsigned long long (&best)[K], uint2 *runs, unsigned lane_col, unsigned col_stride) {
     const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
     float r = r0_cells * g.h;
     const float rmax = (float) (g.nx + g.ny + g.nz + 3) * g.h;  // covers the whole grid
@@ -68,15 +77,48 @@ __device__ void knn_search(const GridDev &g, float qx, float qy, float qz, int k
         const int xa = max(x0, 0), xb = min(x1, g.nx - 1);
         const int ya = max(y0, 0), yb = min(y1, g.ny - 1);
         const int za = max(z0, 0), zb = min(z1, g.nz - 1);
-        for (int zz = za; zz <= zb; ++zz)
-            for (int yy = ya; yy <= yb; ++yy) {
-                const size_t base = ((size_t) zz * g.ny + yy) * g.nx;
-                const unsigned s = g.cell_start[base + xa], e = g.cell_start[base + xb + 1];
-                for (unsigned j = s; j < e; ++j) {
-                    const float4 t = g.pts[j];
-                    knn_insert<K>(best, g_make_key(g_d2(qx, qy, qz, t), __float_as_uint(t.w)));
+        const bool any = xa <= xb && ya <= yb && za <= zb;
+        int yy = ya, zz = any ? za : zb + 1;  // row cursor; zz > zb = past the last row
+        while (zz <= zb) {
+            unsigned rs[kKnnRows], re[kKnnRows];
+#pragma unroll
+            for (int u = 0; u < kKnnRows; ++u) {
+                const bool live = zz <= zb;
+                const size_t base = ((size_t) (live ? zz : za) * g.ny + (live ? yy : ya)) * g.nx;
+                rs[u] = g.cell_start[base + xa];
+                re[u] = live ? g.cell_start[base + xb + 1] : 0u;  // dead row: e <= s
+                if (++yy > yb) {
+                    yy = ya;
+                    ++zz;
                 }
             }
+            int n_runs = 0;
+#pragma unroll
+            for (int u = 0; u < kKnnRows; ++u)
+                if (re[u] > rs[u]) {
+                    runs[n_runs * col_stride + lane_col] = make_uint2(rs[u], re[u]);
+                    ++n_runs;
+                }
+            int ri = 0;
+            unsigned j = 0, e = 0;
+            if (n_runs > 0) {
+                const uint2 r0 = runs[lane_col];
+                j = r0.x;
+                e = r0.y;
+            }
+            while (ri < n_runs) {
+                const float4 t = g.pts[j];
+                knn_insert<K>(best, g_make_key(g_d2(qx, qy, qz, t), __float_as_uint(t.w)));
+                if (++j == e) {
+                    ++ri;
+                    if (ri < n_runs) {
+                        const uint2 rn = runs[ri * col_stride + lane_col];
+                        j = rn.x;
+                        e = rn.y;
+                    }
+                }
+            }
+        }
         unsigned long long kth = ~0ull;
 #pragma unroll
         for (int j = 0; j < K; ++j)
@@ -102,6 +144,7 @@ __global__ void __launch_bounds__(kBlock)
     k_gicp_cov(GridDev g, const float4 *__restrict__ qpts, unsigned n,
                const float4 *__restrict__ orig, int k, double eps, double *__restrict__ cov_out,
                int by_w, float r0_cells) {
+    __shared__ uint2 s_runs[kKnnRows * kBlock];  // per-lane run lists of knn_search (lane-private)
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float4 q = qpts[i];
@@ -113,7 +156,7 @@ __global__ void __launch_bounds__(kBlock)
         return;
     }
     unsigned long long best[K];
-    knn_search<K>(g, q.x, q.y, q.z, k, r0_cells, best);
+    knn_search<K>(g, q.x, q.y, q.z, k, r0_cells, best, s_runs, threadIdx.x, kBlock);
     double mean[3] = {0, 0, 0}, c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < K; ++j) {
