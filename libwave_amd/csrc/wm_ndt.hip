@@ -1,15 +1,17 @@
 // wm_ndt.hip -- pcl::NormalDistributionsTransform on device, as libwave's NDTMatcher
 // drives it (wave_matching/src/ndt.cpp:18-34 setters, :48-65 setInput*/align):
-//   k_ndt_key / rocPRIM sort / k_ndt_voxel_stats / k_ndt_hash_insert
+//   k_ndt_key / rocPRIM sort / k_ndt_heads / k_ndt_voxel_stats / k_ndt_hash_insert, k_ndt_dense_fill
 //        = pcl::VoxelGridCovariance::filter (setInputTarget, ndt.cpp:55): per-voxel
 //          n, sum p, sum p p^T (double, ascending point order), mean, covariance,
 //          eigenvalue inflation (>= 0.01 lambda_max), inverse; voxels with < 6 points
-//          dropped; an open-addressing hash (voxel ijk -> record) replaces PCL's kd-tree
-//          over the voxel means (a mean within `res` of a point lies in one of the 27
-//          voxels around it).
+//          dropped; a dense cell -> record table over the target's bounding box (or, for
+//          huge lattices, an open-addressing hash) replaces PCL's kd-tree over the voxel
+//          means (a mean within `res` of a point lies in one of the 27 voxels around it).
 //   k_ndt_derivs  = computeDerivatives / updateDerivatives / computeHessian: one lane per
-//          source point, score + 6 gradient + 36 Hessian sums in double, fixed-order
-//          workgroup reduction.  These 43 doubles are the only thing the host sees.
+//          source point; pass 1 lists the point's voxels within `res`, pass 2 adds their
+//          terms: score + 6 gradient + the 21 upper-triangle Hessian sums in double,
+//          fixed-order workgroup reduction.  k_sum_fetch (wm_icp.hip) adds the workgroups'
+//          partials; those 28 doubles are the only thing the host sees.
 //   host: Newton step (JacobiSVD solve) + More-Thuente line search
 //          (computeStepLengthMT / trialValueSelectionMT / updateIntervalMT).
 // [PCL registration/impl/ndt.hpp, filters/impl/voxel_grid_covariance.hpp; Magnusson 2009]
