@@ -319,7 +319,34 @@ __global__ void __launch_bounds__(kBlock)
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
         c += ((unsigned) keys[i] != kNoIdx);
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+    // one atomic per WORKGROUP, and few workgroups: same-address atomics retire one at a time
+    // (~11 ns each); one per wave of a 1024-block grid made this count take 49 us
+    __shared__ unsigned s_c[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+        for (int w = 0; w < kBlock / 64; ++w) t += s_c[w];
+        if (t) atomicAdd(out, t);
+    }
+}
+
+// number of matched source points -> host (pinned fetch: no pageable staging, no stream sync)
+static int count_matched(wm_ctx *ctx, size_t n, unsigned *cnt) {
+    WM_HIP(ctx, ctx->bbox_buf.reserve(64));
+    unsigned *d_cnt = ctx->bbox_buf.as<unsigned>();
+    WM_HIP(ctx, hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
+    unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
+    if (blocks > 128) blocks = 128;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_count_matched, dim3(blocks), dim3(kBlock), 0, ctx->stream,
+                       ctx->keys.as<unsigned long long>(), (unsigned) n, d_cnt);
+    WM_HIP(ctx, hipGetLastError());
+    unsigned *h = (unsigned *) pinned_scratch(ctx, 0);
+    if (!h) return WM_ERR_HIP;
+    WM_TRY(fast_fetch(ctx, h, d_cnt, 4));
+    *cnt = *h;
+    return WM_OK;
 }
 
 // ------------------------------------------------------------------ host
@@ -812,17 +839,10 @@ int wm_gicp_align(wm_ctx *ctx, const wm_gicp_params *prm, double T_out[16], wm_g
         Mat3d R;
         for (int a = 0; a < 3; ++a)
             for (int b = 0; b < 3; ++b) R.m[a * 3 + b] = (double) T[a * 4 + b];
-        WM_HIP(ctx, ctx->bbox_buf.reserve(64));
-        unsigned *d_cnt = ctx->bbox_buf.as<unsigned>();
-        WM_HIP(ctx, hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
         hipLaunchKernelGGL(k_gicp_mahal, dim3(blocks), dim3(kBlock), 0, ctx->stream, (unsigned) n,
                            ctx->keys.as<unsigned long long>(), ctx->gicp_c1.as<double>(),
                            ctx->gicp_c2.as<double>(), R, ctx->gicp_mahal.as<double>());
-        hipLaunchKernelGGL(k_count_matched, dim3(blocks > 1024 ? 1024 : blocks), dim3(kBlock), 0,
-                           ctx->stream, ctx->keys.as<unsigned long long>(), (unsigned) n, d_cnt);
-        WM_HIP(ctx, hipGetLastError());
-        WM_HIP(ctx, hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
-        WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        WM_TRY(count_matched(ctx, n, &cnt));
         memcpy(prevT, T, sizeof(T));
         double x[6] = {T[3], T[7], T[11], atan2(T[9], T[10]), asin(-T[8]), atan2(T[4], T[0])};
         F.m = (int) cnt;
@@ -880,17 +900,11 @@ int wm_gicp_eval(wm_ctx *ctx, const wm_gicp_params *prm, const double T_pair[16]
         for (int b = 0; b < 3; ++b) R.m[a * 3 + b] = Td[a * 4 + b];
     WM_TRY(nn_pass(ctx, Td, threshold_d2_strict(prm->max_corr), prm->max_corr, false));
     const unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
-    WM_HIP(ctx, ctx->bbox_buf.reserve(64));
-    unsigned *d_cnt = ctx->bbox_buf.as<unsigned>(), cnt = 0;
-    WM_HIP(ctx, hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
+    unsigned cnt = 0;
     hipLaunchKernelGGL(k_gicp_mahal, dim3(blocks), dim3(kBlock), 0, ctx->stream, (unsigned) n,
                        ctx->keys.as<unsigned long long>(), ctx->gicp_c1.as<double>(),
                        ctx->gicp_c2.as<double>(), R, ctx->gicp_mahal.as<double>());
-    hipLaunchKernelGGL(k_count_matched, dim3(blocks > 1024 ? 1024 : blocks), dim3(kBlock), 0,
-                       ctx->stream, ctx->keys.as<unsigned long long>(), (unsigned) n, d_cnt);
-    WM_HIP(ctx, hipGetLastError());
-    WM_HIP(ctx, hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
-    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    WM_TRY(count_matched(ctx, n, &cnt));
     ctx->have_corr = true;
     ctx->last_align_valid = false;
     if (n_pairs) *n_pairs = (int) cnt;
