@@ -567,9 +567,10 @@ static int ndt_build(wm_ctx *ctx, double res) {
     WM_HIP(ctx, rocprim::radix_sort_pairs(ctx->vg_tmp.p, tmp, k1, k2, p1, p2, n, 0, 64, ctx->stream));
     hipLaunchKernelGGL(k_ndt_flags, dim3(blocks), dim3(kBlock), 0, ctx->stream, k2, (unsigned) n, flags);
     WM_TRY(exclusive_scan(ctx, flags, n, seg));
-    unsigned nvox = 0;
-    WM_HIP(ctx, hipMemcpyAsync(&nvox, seg + n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned *h_word = (unsigned *) pinned_scratch(ctx, 0);
+    if (!h_word) return WM_ERR_HIP;
+    WM_TRY(fast_fetch(ctx, h_word, seg + n, 4));  // the scan's total = number of voxels
+    const unsigned nvox = *h_word;
     ctx->ndt_nvox = nvox;
     ctx->ndt_nvalid = 0;
     unsigned cap = 16;
@@ -629,10 +630,8 @@ static int ndt_build(wm_ctx *ctx, double res) {
             ctx->ndt_dense_on = true;
         }
     }
-    unsigned nvalid = 0;
-    WM_HIP(ctx, hipMemcpyAsync(&nvalid, d_nvalid, 4, hipMemcpyDeviceToHost, ctx->stream));
-    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->ndt_nvalid = nvalid;
+    WM_TRY(fast_fetch(ctx, h_word, d_nvalid, 4));
+    ctx->ndt_nvalid = *h_word;
     ctx->ndt_res = res;
     ctx->ndt_built = true;
     return WM_OK;
