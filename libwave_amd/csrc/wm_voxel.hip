@@ -46,43 +46,47 @@ __global__ void __launch_bounds__(kBlock)
     flags[i] = (k != invalid && (i == 0 || idx_sorted[i - 1] != k)) ? 1u : 0u;
 }
 
-// one lane per leaf: sequential float sum over its points in ascending point index (the order
-// is part of the result: float addition does not associate).  Four points per trip: the
-// leaf-index / permutation / point loads of a trip are issued together, the adds stay in order.
+// heads[slot] = first sorted position of leaf `slot`; heads[n_leaves] = one past the last valid
+// point (seg[n] = n_leaves, the scan's total)
 __global__ void __launch_bounds__(kBlock)
-    k_vg_centroid(const float4 *__restrict__ in, const unsigned *__restrict__ idx_sorted,
-                  const unsigned *__restrict__ perm_sorted, const unsigned *__restrict__ seg,
-                  unsigned n, unsigned invalid, float4 *__restrict__ out) {
+    k_vg_heads(const unsigned *__restrict__ idx_sorted, const unsigned *__restrict__ flags,
+               const unsigned *__restrict__ seg, unsigned n, unsigned invalid,
+               unsigned *__restrict__ heads) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const unsigned k = idx_sorted[i];
-    if (k == invalid || (i > 0 && idx_sorted[i - 1] == k)) return;  // not a leaf head
+    if (flags[i]) heads[seg[i]] = i;
+    if (idx_sorted[i] != invalid && (i + 1 == n || idx_sorted[i + 1] == invalid)) heads[seg[n]] = i + 1;
+}
+
+// one lane per leaf (compacted: every lane of a wave has a leaf -- with one lane per POINT and
+// only the leaf heads working, a wave of a coarse grid ran a few lanes out of 64): sequential
+// float sum over the leaf's points in ascending point index (the order is part of the result:
+// float addition does not associate).  Four points per trip: their permutation / point loads are
+// issued together, the adds stay in order.  The grid is sized for n leaves; lanes beyond the
+// scan's total (read from the device) leave at once, so no host round trip precedes the launch.
+__global__ void __launch_bounds__(kBlock)
+    k_vg_centroid(const float4 *__restrict__ in, const unsigned *__restrict__ perm_sorted,
+                  const unsigned *__restrict__ heads, const unsigned *__restrict__ n_leaves,
+                  float4 *__restrict__ out) {
+    const unsigned slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= *n_leaves) return;
+    const unsigned i = heads[slot], j = heads[slot + 1];
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    unsigned j = i;
-    for (bool more = true; more;) {
-        unsigned kk[4];
+    for (unsigned t = i; t < j; t += 4) {
         float4 p[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const unsigned ju = j + u < n ? j + u : n - 1;
-            kk[u] = j + u < n ? idx_sorted[ju] : invalid;
-            p[u] = in[perm_sorted[ju]];
-        }
+        for (int u = 0; u < 4; ++u) p[u] = in[perm_sorted[t + u < j ? t + u : j - 1]];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            more = more && kk[u] == k;
-            if (more) {
+        for (int u = 0; u < 4; ++u)
+            if (t + u < j) {
                 sx = __fadd_rn(sx, p[u].x);
                 sy = __fadd_rn(sy, p[u].y);
                 sz = __fadd_rn(sz, p[u].z);
-                ++j;
             }
-        }
     }
     const float cnt = (float) (j - i);
-    const unsigned o = seg[i];  // exclusive scan of the head flags = output slot
-    out[o] = make_float4(__fdiv_rn(sx, cnt), __fdiv_rn(sy, cnt), __fdiv_rn(sz, cnt),
-                         __uint_as_float(o));
+    out[slot] = make_float4(__fdiv_rn(sx, cnt), __fdiv_rn(sy, cnt), __fdiv_rn(sz, cnt),
+                            __uint_as_float(slot));
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -124,7 +128,7 @@ int voxel_downsample_dev(wm_ctx *ctx, const float4 *in, size_t n, float leaf, fl
     }
     WM_HIP(ctx, ctx->vg_idx.reserve(n * 4));
     WM_HIP(ctx, ctx->vg_idx2.reserve(n * 4));
-    WM_HIP(ctx, ctx->vg_perm.reserve(n * 4));
+    WM_HIP(ctx, ctx->vg_perm.reserve((n + 1) * 4));  // after the sort: the leaves' head positions (+ end)
     WM_HIP(ctx, ctx->vg_perm2.reserve(n * 4));
     WM_HIP(ctx, ctx->vg_seg.reserve((n + 1) * 4));
     unsigned *idx = ctx->vg_idx.as<unsigned>(), *idx2 = ctx->vg_idx2.as<unsigned>();
@@ -147,8 +151,11 @@ int voxel_downsample_dev(wm_ctx *ctx, const float4 *in, size_t n, float leaf, fl
     hipLaunchKernelGGL(k_vg_flags, dim3(blocks), dim3(kBlock), 0, ctx->stream, idx2, (unsigned) n,
                        invalid, idx /* reuse as flags */);
     WM_TRY(exclusive_scan(ctx, idx, n, seg));
-    hipLaunchKernelGGL(k_vg_centroid, dim3(blocks), dim3(kBlock), 0, ctx->stream, in, idx2, perm2,
-                       seg, (unsigned) n, invalid, out);
+    unsigned *heads = perm;  // the sort's input permutation is dead by now
+    hipLaunchKernelGGL(k_vg_heads, dim3(blocks), dim3(kBlock), 0, ctx->stream, idx2, idx, seg,
+                       (unsigned) n, invalid, heads);
+    hipLaunchKernelGGL(k_vg_centroid, dim3(blocks), dim3(kBlock), 0, ctx->stream, in, perm2, heads,
+                       seg + n, out);
     WM_HIP(ctx, hipGetLastError());
     unsigned *h_total = (unsigned *) pinned_scratch(ctx, 0);
     if (!h_total) return WM_ERR_HIP;
