@@ -939,12 +939,18 @@ int wm_icp_match(wm_ctx *ctx, const void *ref, size_t n_ref, const void *target,
     double running[16];
     mat4_identity(running);
     const int steps = multiscale_steps > 0 ? multiscale_steps : 0;
+    // both clouds are filtered once per scale: their bounding boxes are found once
+    VgKnown kr{}, kt{};
+    if (steps > 0) {
+        if (n_ref > 0) WM_TRY(compute_bbox(ctx, d_ref, n_ref, &kr.bb, &kr.valid));
+        if (n_target > 0) WM_TRY(compute_bbox(ctx, d_tgt, n_target, &kt.bb, &kt.valid));
+    }
     for (int i = steps; i >= 0; --i) {
         const float leaf = (float) (pow(2, i) * res);  // icp.cpp:80
         size_t nr = 0, nt = 0;
-        WM_TRY(voxel_downsample_dev(ctx, d_ref, n_ref, leaf, ds_ref, &nr));
+        WM_TRY(voxel_downsample_dev(ctx, d_ref, n_ref, leaf, ds_ref, &nr, steps > 0 && n_ref > 0 ? &kr : nullptr));
         WM_TRACE(ctx, "match: voxel ref");
-        WM_TRY(voxel_downsample_dev(ctx, d_tgt, n_target, leaf, ds_tgt, &nt));
+        WM_TRY(voxel_downsample_dev(ctx, d_tgt, n_target, leaf, ds_tgt, &nt, steps > 0 && n_target > 0 ? &kt : nullptr));
         WM_TRACE(ctx, "match: voxel target");
         if (ctx->trace) fprintf(stderr, "[wm] match: leaf=%g nr=%zu nt=%zu\n", leaf, nr, nt);
         if (steps > 0) {

@@ -236,8 +236,14 @@ int exclusive_scan(wm_ctx *ctx, const unsigned *in, size_t n, unsigned *out);
 // ---- wm_voxel.hip
 // pcl::VoxelGrid on device: `in` is a packed float4 cloud (w = index, NaN = invalid);
 // writes centroids (float4, w = output index) to `out` (capacity >= n), count to *n_out
+// `known`: the cloud's bounding box and finite-point count if the caller already has them (the
+// multiscale match filters the same cloud at four leaf sizes); nullptr = computed here
+struct VgKnown {
+    Bbox bb;
+    size_t valid;
+};
 int voxel_downsample_dev(wm_ctx *ctx, const float4 *in, size_t n, float leaf, float4 *out,
-                         size_t *n_out);
+                         size_t *n_out, const VgKnown *known = nullptr);
 int transform_cloud_dev(wm_ctx *ctx, const float4 *in, size_t n, const double T[16], float4 *out);
 
 // ---- wm_nn.hip

@@ -101,13 +101,18 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 int voxel_downsample_dev(wm_ctx *ctx, const float4 *in, size_t n, float leaf, float4 *out,
-                         size_t *n_out) {
+                         size_t *n_out, const VgKnown *known) {
     *n_out = 0;
     if (n == 0) return WM_OK;
     if (!(leaf > 0)) return WM_ERR_ARG;
     Bbox bb;
     size_t valid = 0;
-    WM_TRY(compute_bbox(ctx, in, n, &bb, &valid));
+    if (known) {
+        bb = known->bb;
+        valid = known->valid;
+    } else {
+        WM_TRY(compute_bbox(ctx, in, n, &bb, &valid));
+    }
     if (valid == 0) return WM_OK;
     const float inv = 1.0f / leaf;
     const int64_t ex = (int64_t) ((bb.hi[0] - bb.lo[0]) * inv) + 1;
