@@ -62,9 +62,10 @@ __global__ void __launch_bounds__(kBlock)
 // one lane per leaf (compacted: every lane of a wave has a leaf -- with one lane per POINT and
 // only the leaf heads working, a wave of a coarse grid ran a few lanes out of 64): sequential
 // float sum over the leaf's points in ascending point index (the order is part of the result:
-// float addition does not associate).  Four points per trip: their permutation / point loads are
+// float addition does not associate).  kVgTrip points per trip: their permutation / point loads are
 // issued together, the adds stay in order.  The grid is sized for n leaves; lanes beyond the
 // scan's total (read from the device) leave at once, so no host round trip precedes the launch.
+constexpr int kVgTrip = 8;
 __global__ void __launch_bounds__(kBlock)
     k_vg_centroid(const float4 *__restrict__ in, const unsigned *__restrict__ perm_sorted,
                   const unsigned *__restrict__ heads, const unsigned *__restrict__ n_leaves,
@@ -73,12 +74,12 @@ __global__ void __launch_bounds__(kBlock)
     if (slot >= *n_leaves) return;
     const unsigned i = heads[slot], j = heads[slot + 1];
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (unsigned t = i; t < j; t += 4) {
-        float4 p[4];
+    for (unsigned t = i; t < j; t += kVgTrip) {
+        float4 p[kVgTrip];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) p[u] = in[perm_sorted[t + u < j ? t + u : j - 1]];
+        for (int u = 0; u < kVgTrip; ++u) p[u] = in[perm_sorted[t + u < j ? t + u : j - 1]];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < kVgTrip; ++u)
             if (t + u < j) {
                 sx = __fadd_rn(sx, p[u].x);
                 sy = __fadd_rn(sy, p[u].y);
