@@ -66,12 +66,14 @@ __global__ void __launch_bounds__(kBlock)
 // issued together, the adds stay in order.  The grid is sized for n leaves; lanes beyond the
 // scan's total (read from the device) leave at once, so no host round trip precedes the launch.
 constexpr int kVgTrip = 8;
+constexpr unsigned kVgWaveAvg = 24;  // more points per leaf on average: one WAVE per leaf (below)
 __global__ void __launch_bounds__(kBlock)
     k_vg_centroid(const float4 *__restrict__ in, const unsigned *__restrict__ perm_sorted,
                   const unsigned *__restrict__ heads, const unsigned *__restrict__ n_leaves,
-                  float4 *__restrict__ out) {
+                  unsigned n_valid, float4 *__restrict__ out) {
     const unsigned slot = blockIdx.x * kBlock + threadIdx.x;
-    if (slot >= *n_leaves) return;
+    const unsigned leaves = *n_leaves;
+    if (slot >= leaves || n_valid > kVgWaveAvg * (unsigned long long) leaves) return;  // big leaves: the wave kernel
     const unsigned i = heads[slot], j = heads[slot + 1];
     float sx = 0.f, sy = 0.f, sz = 0.f;
     for (unsigned t = i; t < j; t += kVgTrip) {
@@ -89,6 +91,47 @@ __global__ void __launch_bounds__(kBlock)
     const float cnt = (float) (j - i);
     out[slot] = make_float4(__fdiv_rn(sx, cnt), __fdiv_rn(sy, cnt), __fdiv_rn(sz, cnt),
                             __uint_as_float(slot));
+}
+
+// Coarse grids (tens to thousands of points per leaf): one wave per leaf.  The sum must still be
+// formed one point after the other, but the 64 lanes fetch 64 points at a time (the gather is the
+// slow part) into LDS and lane 0 adds them in order; with one LANE per leaf a wave waited for its
+// largest leaf while each lane gathered alone (168 us for the 0.8 m grid of a 1M-point cloud).
+__global__ void __launch_bounds__(kBlock)
+    k_vg_centroid_wave(const float4 *__restrict__ in, const unsigned *__restrict__ perm_sorted,
+                       const unsigned *__restrict__ heads, const unsigned *__restrict__ n_leaves,
+                       unsigned n_valid, float4 *__restrict__ out) {
+    const unsigned leaves = *n_leaves;
+    if (n_valid <= kVgWaveAvg * (unsigned long long) leaves) return;  // small leaves: the lane kernel
+    __shared__ float s_p[kBlock / 64][3][64];
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned waves_total = gridDim.x * (kBlock / 64);
+    for (unsigned slot = blockIdx.x * (kBlock / 64) + wave; slot < leaves; slot += waves_total) {
+        const unsigned i = heads[slot], j = heads[slot + 1];
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (unsigned t = i; t < j; t += 64) {
+            if (t + lane < j) {
+                const float4 p = in[perm_sorted[t + lane]];
+                s_p[wave][0][lane] = p.x;
+                s_p[wave][1][lane] = p.y;
+                s_p[wave][2][lane] = p.z;
+            }
+            // (a wave's LDS traffic is in order: no barrier between its own write and read)
+            if (lane == 0) {
+                const unsigned m = j - t < 64u ? j - t : 64u;
+                for (unsigned u = 0; u < m; ++u) {
+                    sx = __fadd_rn(sx, s_p[wave][0][u]);
+                    sy = __fadd_rn(sy, s_p[wave][1][u]);
+                    sz = __fadd_rn(sz, s_p[wave][2][u]);
+                }
+            }
+        }
+        if (lane == 0) {
+            const float cnt = (float) (j - i);
+            out[slot] = make_float4(__fdiv_rn(sx, cnt), __fdiv_rn(sy, cnt), __fdiv_rn(sz, cnt),
+                                    __uint_as_float(slot));
+        }
+    }
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -161,8 +204,13 @@ int voxel_downsample_dev(wm_ctx *ctx, const float4 *in, size_t n, float leaf, fl
     unsigned *heads = perm;  // the sort's input permutation is dead by now
     hipLaunchKernelGGL(k_vg_heads, dim3(blocks), dim3(kBlock), 0, ctx->stream, idx2, idx, seg,
                        (unsigned) n, invalid, heads);
+    // two launches, one of which leaves at once: which one is decided on the device from the
+    // average leaf size (the leaf count is not on the host yet, and fetching it first would cost
+    // more than the idle launch)
     hipLaunchKernelGGL(k_vg_centroid, dim3(blocks), dim3(kBlock), 0, ctx->stream, in, perm2, heads,
-                       seg + n, out);
+                       seg + n, (unsigned) valid, out);
+    hipLaunchKernelGGL(k_vg_centroid_wave, dim3(2048), dim3(kBlock), 0, ctx->stream, in, perm2, heads,
+                       seg + n, (unsigned) valid, out);
     WM_HIP(ctx, hipGetLastError());
     unsigned *h_total = (unsigned *) pinned_scratch(ctx, 0);
     if (!h_total) return WM_ERR_HIP;

@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("leaf", [0.05, 0.1, 0.4, 0.8])
+# fine leaves take the lane-per-leaf centroid kernel, coarse ones (> 24 points per leaf on
+# average) the wave-per-leaf one; 5 m and 40 m leaves hold thousands of points each
+@pytest.mark.parametrize("leaf", [0.05, 0.1, 0.4, 0.8, 5.0, 40.0])
 def test_voxel_grid_bit_exact(ctx, oracle, testscan, leaf):
     got = ctx.voxel_downsample(testscan, leaf)
     want = oracle.voxel_grid(testscan, leaf)
@@ -25,6 +27,7 @@ def test_voxel_grid_bit_exact(ctx, oracle, testscan, leaf):
 def test_voxel_grid_synthetic_and_edge_cases(ctx, oracle):
     pts = synth.scene(200000, seed=3)
     assert np.array_equal(ctx.voxel_downsample(pts, 0.25), oracle.voxel_grid(pts, 0.25))
+    assert np.array_equal(ctx.voxel_downsample(pts, 3.0), oracle.voxel_grid(pts, 3.0))   # big leaves
     bad = pts[:5000].copy()
     bad[::50, 0] = np.nan
     assert np.array_equal(ctx.voxel_downsample(bad, 0.5), oracle.voxel_grid(bad, 0.5))
