@@ -173,36 +173,18 @@ __global__ void __launch_bounds__(kBlock)
     if (keys[i] != kEmptyKey && (i + 1 == n || keys[i + 1] == kEmptyKey)) heads[seg[n]] = i + 1;
 }
 
-// one lane per voxel (compacted: every lane of a wave has a voxel, and the waves spread over
-// the whole device): statistics in ascending point order, then the PCL covariance conditioning.
-constexpr int kVoxStatBlock = 64;
-__global__ void __launch_bounds__(kVoxStatBlock)
-    k_ndt_voxel_stats(const float4 *__restrict__ pts, const unsigned long long *__restrict__ keys,
-                      const unsigned *__restrict__ perm, const unsigned *__restrict__ heads,
-                      unsigned nvox, NdtVoxel *__restrict__ vox, float4 *__restrict__ meanf,
-                      unsigned long long *__restrict__ vkey, unsigned *__restrict__ n_valid) {
-    const unsigned slot = blockIdx.x * kVoxStatBlock + threadIdx.x;
-    if (slot >= nvox) return;
-    const unsigned i = heads[slot], j = heads[slot + 1];
-    const unsigned long long key = keys[i];
-    double s[3] = {0, 0, 0}, pp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 4
-    for (unsigned t = i; t < j; ++t) {
-        const float4 p = pts[perm[t]];
-        const double d[3] = {(double) p.x, (double) p.y, (double) p.z};
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            s[a] += d[a];
-#pragma unroll
-            for (int b = 0; b < 3; ++b) pp[a * 3 + b] += d[a] * d[b];
-        }
-    }
-    const double nn = (double) (j - i);
+// mean, covariance, PCL's eigenvalue conditioning and the inverse of one voxel from its sums
+// (s = sum p, pp = sum p p^T over `count` points); writes the voxel's records
+__device__ inline void ndt_voxel_finish(unsigned slot, unsigned long long key, unsigned count, const double *s,
+                                        const double *pp, NdtVoxel *__restrict__ vox,
+                                        float4 *__restrict__ meanf, unsigned long long *__restrict__ vkey,
+                                        unsigned *__restrict__ n_valid) {
+    const double nn = (double) count;
     NdtVoxel v;
     bool valid = false;
 #pragma unroll
     for (int a = 0; a < 3; ++a) v.mean[a] = s[a] / nn;
-    if (j - i >= 6) {  // min_points_per_voxel_
+    if (count >= 6) {  // min_points_per_voxel_
         double cov[9], evals[3], evecs[9];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
@@ -240,6 +222,82 @@ __global__ void __launch_bounds__(kVoxStatBlock)
     meanf[slot] = make_float4((float) v.mean[0], (float) v.mean[1], (float) v.mean[2], 0.0f);
     vkey[slot] = valid ? key : kEmptyKey;
     if (valid) atomicAdd(n_valid, 1u);
+}
+
+// one lane per voxel (compacted: every lane of a wave has a voxel, and the waves spread over
+// the whole device): statistics in ascending point order, then the PCL covariance conditioning.
+// (Grids with up to kVoxWaveAvg points per voxel on average; coarser ones: the wave kernel below.)
+constexpr int kVoxStatBlock = 64;
+constexpr unsigned kVoxWaveAvg = 192;
+__global__ void __launch_bounds__(kVoxStatBlock)
+    k_ndt_voxel_stats(const float4 *__restrict__ pts, const unsigned long long *__restrict__ keys,
+                      const unsigned *__restrict__ perm, const unsigned *__restrict__ heads,
+                      unsigned nvox, NdtVoxel *__restrict__ vox, float4 *__restrict__ meanf,
+                      unsigned long long *__restrict__ vkey, unsigned *__restrict__ n_valid) {
+    const unsigned slot = blockIdx.x * kVoxStatBlock + threadIdx.x;
+    if (slot >= nvox) return;
+    const unsigned i = heads[slot], j = heads[slot + 1];
+    const unsigned long long key = keys[i];
+    double s[3] = {0, 0, 0}, pp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+    for (unsigned t = i; t < j; ++t) {
+        const float4 p = pts[perm[t]];
+        const double d[3] = {(double) p.x, (double) p.y, (double) p.z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            s[a] += d[a];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) pp[a * 3 + b] = fma(d[a], d[b], pp[a * 3 + b]);
+        }
+    }
+    ndt_voxel_finish(slot, key, j - i, s, pp, vox, meanf, vkey, n_valid);
+}
+
+// Coarse grids (PCL's default NDT resolution of 5 m puts thousands of points in a voxel): one WAVE
+// per voxel.  The sums are still formed one point after the other, but 64 points are gathered at a
+// time into LDS and the twelve sums (3 of p, 9 of p p^T) advance in twelve lanes side by side,
+// each adding the points in order -- the same additions as the lane kernel, in the same order.
+// (One lane per voxel took 0.9-1.2 ms for the 5 m grid of a 1M-point cloud: a few hundred lanes
+// each walking thousands of points.)
+__global__ void __launch_bounds__(kBlock)
+    k_ndt_voxel_stats_wave(const float4 *__restrict__ pts, const unsigned long long *__restrict__ keys,
+                           const unsigned *__restrict__ perm, const unsigned *__restrict__ heads,
+                           unsigned nvox, NdtVoxel *__restrict__ vox, float4 *__restrict__ meanf,
+                           unsigned long long *__restrict__ vkey, unsigned *__restrict__ n_valid) {
+    __shared__ float s_p[kBlock / 64][3][64];
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned waves_total = gridDim.x * (kBlock / 64);
+    // lane 0..2: sum of p[lane] (times 1); lane 3..11: sum of p[a] * p[b]
+    const unsigned ia = lane < 3 ? lane : (lane < 12 ? (lane - 3) / 3 : 0);
+    const unsigned ib = lane < 3 ? 0 : (lane < 12 ? (lane - 3) % 3 : 0);
+    const bool product = lane >= 3;
+    for (unsigned slot = blockIdx.x * (kBlock / 64) + wave; slot < nvox; slot += waves_total) {
+        const unsigned i = heads[slot], j = heads[slot + 1];
+        double acc = 0.0;
+        for (unsigned t = i; t < j; t += 64) {
+            if (t + lane < j) {
+                const float4 p = pts[perm[t + lane]];
+                s_p[wave][0][lane] = p.x;
+                s_p[wave][1][lane] = p.y;
+                s_p[wave][2][lane] = p.z;
+            }
+            // (a wave's LDS traffic is in order: no barrier between its own write and read)
+            if (lane < 12) {
+                const unsigned m = j - t < 64u ? j - t : 64u;
+                for (unsigned u = 0; u < m; ++u) {
+                    const double x = (double) s_p[wave][ia][u];
+                    const double y = product ? (double) s_p[wave][ib][u] : 1.0;
+                    acc = fma(x, y, acc);  // y = 1: exactly acc + x
+                }
+            }
+        }
+        double s[3], pp[9];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s[k] = __shfl(acc, k);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) pp[k] = __shfl(acc, 3 + k);
+        if (lane == 0) ndt_voxel_finish(slot, keys[i], j - i, s, pp, vox, meanf, vkey, n_valid);
+    }
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -590,10 +648,15 @@ static int ndt_build(wm_ctx *ctx, double res) {
         unsigned *heads = p1;  // the sort's input permutation is dead by now
         hipLaunchKernelGGL(k_ndt_heads, dim3(blocks), dim3(kBlock), 0, ctx->stream, k2, flags, seg, (unsigned) n,
                            heads);
-        hipLaunchKernelGGL(k_ndt_voxel_stats, dim3((nvox + kVoxStatBlock - 1) / kVoxStatBlock),
-                           dim3(kVoxStatBlock), 0, ctx->stream, pts, k2, p2, heads, nvox,
-                           ctx->ndt_vox.as<NdtVoxel>(), ctx->ndt_meanf.as<float4>(),
-                           ctx->ndt_vkey.as<unsigned long long>(), d_nvalid);
+        if ((unsigned long long) n > (unsigned long long) kVoxWaveAvg * nvox)
+            hipLaunchKernelGGL(k_ndt_voxel_stats_wave, dim3(nvox < 8192u ? (nvox + 3u) / 4u : 2048u), dim3(kBlock),
+                               0, ctx->stream, pts, k2, p2, heads, nvox, ctx->ndt_vox.as<NdtVoxel>(),
+                               ctx->ndt_meanf.as<float4>(), ctx->ndt_vkey.as<unsigned long long>(), d_nvalid);
+        else
+            hipLaunchKernelGGL(k_ndt_voxel_stats, dim3((nvox + kVoxStatBlock - 1) / kVoxStatBlock),
+                               dim3(kVoxStatBlock), 0, ctx->stream, pts, k2, p2, heads, nvox,
+                               ctx->ndt_vox.as<NdtVoxel>(), ctx->ndt_meanf.as<float4>(),
+                               ctx->ndt_vkey.as<unsigned long long>(), d_nvalid);
         hipLaunchKernelGGL(k_ndt_hash_insert, dim3((nvox + kBlock - 1) / kBlock), dim3(kBlock), 0,
                            ctx->stream, ctx->ndt_vkey.as<unsigned long long>(), nvox,
                            ctx->ndt_hkeys.as<unsigned long long>(), ctx->ndt_hvals.as<unsigned>(),

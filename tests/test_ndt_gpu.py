@@ -10,7 +10,9 @@ from libwave_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("res", [0.3, 1.0])
+# res = 5 (PCL's default) and 12: hundreds to thousands of points per voxel, i.e. the
+# wave-per-voxel statistics kernel; the finer grids take the lane-per-voxel one
+@pytest.mark.parametrize("res", [0.3, 1.0, 5.0, 12.0])
 def test_ndt_derivatives_match_oracle(wm, ctx, oracle, testscan, res):
     P = np.eye(4)
     P[0, 3] = 0.2
