@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(kBlock)
         }
     double o[9];
     inv3(t, o);
-    // component-major (nine arrays of n): the objective kernel, which reads these ~270 times per
+    // component-major (nine arrays of n): the objective kernel, which reads these ~170 times per
     // registration, then gets fully coalesced 8-byte loads instead of a 72-byte stride per lane
 #pragma unroll
     for (int a = 0; a < 9; ++a) mahal[(size_t) a * n + i] = o[a];
