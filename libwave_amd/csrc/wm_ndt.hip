@@ -20,6 +20,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "wm_internal.hpp"
+#include "wm_sort.hpp"
 
 #include <chrono>
 #include <float.h>
@@ -55,30 +56,49 @@ __device__ __forceinline__ unsigned ndt_hash(unsigned long long x) {
     return (unsigned) x;
 }
 
+// The voxel lattice over the target's bounding box.  Points are SORTED by their linear cell
+// number in it, (k * ny + j) * nx + i -- the same order as (k, j, i) -- which needs only
+// log2(cells) key bits: two to four radix passes instead of the eight of a 64-bit key.  The
+// (k, j, i) key of a voxel (hash grid, dense table) is rebuilt from it once per voxel.
+struct NdtLattice {
+    int lo[3];                  // cell of the bounding box's low corner
+    unsigned long long nx, ny;  // cells along x, y
+    unsigned long long cells;   // nx * ny * nz = the "no cell" key of non-finite points (sorts last)
+};
+
 __global__ void __launch_bounds__(kBlock)
-    k_ndt_key(const float4 *__restrict__ pts, unsigned n, float inv, unsigned long long *keys,
+    k_ndt_key(const float4 *__restrict__ pts, unsigned n, float inv, NdtLattice L, unsigned long long *keys,
               unsigned *perm) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float4 p = pts[i];
-    unsigned long long key = kEmptyKey;  // non-finite points sort last
+    unsigned long long key = L.cells;
     if (p.x == p.x) {
-        const int a = (int) floorf(__fmul_rn(p.x, inv));
-        const int b = (int) floorf(__fmul_rn(p.y, inv));
-        const int c = (int) floorf(__fmul_rn(p.z, inv));
-        // sort order (k, j, i): k in the top bits
-        key = ndt_key(c, b, a);
+        const long long a = (long long) floorf(__fmul_rn(p.x, inv)) - L.lo[0];
+        const long long b = (long long) floorf(__fmul_rn(p.y, inv)) - L.lo[1];
+        const long long c = (long long) floorf(__fmul_rn(p.z, inv)) - L.lo[2];
+        key = ((unsigned long long) c * L.ny + (unsigned long long) b) * L.nx + (unsigned long long) a;
     }
     keys[i] = key;
     perm[i] = i;
 }
 
+__device__ __forceinline__ unsigned long long ndt_key_of_cell(unsigned long long cell, const NdtLattice &L) {
+    const unsigned long long row = cell / L.nx;
+    const int a = (int) (cell - row * L.nx) + L.lo[0];
+    const unsigned long long lay = row / L.ny;
+    const int b = (int) (row - lay * L.ny) + L.lo[1];
+    const int c = (int) lay + L.lo[2];
+    return ndt_key(c, b, a);  // k in the top bits
+}
+
 __global__ void __launch_bounds__(kBlock)
-    k_ndt_flags(const unsigned long long *__restrict__ keys, unsigned n, unsigned *flags) {
+    k_ndt_flags(const unsigned long long *__restrict__ keys, unsigned n, unsigned long long invalid,
+                unsigned *flags) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const unsigned long long k = keys[i];
-    flags[i] = (k != kEmptyKey && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+    flags[i] = (k != invalid && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
 }
 
 // symmetric 3x3 eigen-decomposition (cyclic Jacobi), eigenvalues ascending
@@ -166,17 +186,19 @@ __device__ inline bool inverse3(const double *m, double *o) {
 // finite point (seg[n] = n_voxels, the scan's total)
 __global__ void __launch_bounds__(kBlock)
     k_ndt_heads(const unsigned long long *__restrict__ keys, const unsigned *__restrict__ flags,
-                const unsigned *__restrict__ seg, unsigned n, unsigned *__restrict__ heads) {
+                const unsigned *__restrict__ seg, unsigned n, unsigned long long invalid,
+                unsigned *__restrict__ heads) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     if (flags[i]) heads[seg[i]] = i;
-    if (keys[i] != kEmptyKey && (i + 1 == n || keys[i + 1] == kEmptyKey)) heads[seg[n]] = i + 1;
+    if (keys[i] != invalid && (i + 1 == n || keys[i + 1] == invalid)) heads[seg[n]] = i + 1;
 }
 
 // mean, covariance, PCL's eigenvalue conditioning and the inverse of one voxel from its sums
 // (s = sum p, pp = sum p p^T over `count` points); writes the voxel's records
-__device__ inline void ndt_voxel_finish(unsigned slot, unsigned long long key, unsigned count, const double *s,
-                                        const double *pp, NdtVoxel *__restrict__ vox,
+__device__ inline void ndt_voxel_finish(unsigned slot, unsigned long long cell, const NdtLattice &L,
+                                        unsigned count, const double *s, const double *pp,
+                                        NdtVoxel *__restrict__ vox,
                                         float4 *__restrict__ meanf, unsigned long long *__restrict__ vkey,
                                         unsigned *__restrict__ n_valid) {
     const double nn = (double) count;
@@ -220,7 +242,7 @@ __device__ inline void ndt_voxel_finish(unsigned slot, unsigned long long key, u
     vox[slot] = v;
     // the radius test of the derivative passes runs on float means (PCL's kd-tree of centroids)
     meanf[slot] = make_float4((float) v.mean[0], (float) v.mean[1], (float) v.mean[2], 0.0f);
-    vkey[slot] = valid ? key : kEmptyKey;
+    vkey[slot] = valid ? ndt_key_of_cell(cell, L) : kEmptyKey;
     if (valid) atomicAdd(n_valid, 1u);
 }
 
@@ -232,7 +254,7 @@ constexpr unsigned kVoxWaveAvg = 192;
 __global__ void __launch_bounds__(kVoxStatBlock)
     k_ndt_voxel_stats(const float4 *__restrict__ pts, const unsigned long long *__restrict__ keys,
                       const unsigned *__restrict__ perm, const unsigned *__restrict__ heads,
-                      unsigned nvox, NdtVoxel *__restrict__ vox, float4 *__restrict__ meanf,
+                      unsigned nvox, NdtLattice L, NdtVoxel *__restrict__ vox, float4 *__restrict__ meanf,
                       unsigned long long *__restrict__ vkey, unsigned *__restrict__ n_valid) {
     const unsigned slot = blockIdx.x * kVoxStatBlock + threadIdx.x;
     if (slot >= nvox) return;
@@ -250,7 +272,7 @@ __global__ void __launch_bounds__(kVoxStatBlock)
             for (int b = 0; b < 3; ++b) pp[a * 3 + b] = fma(d[a], d[b], pp[a * 3 + b]);
         }
     }
-    ndt_voxel_finish(slot, key, j - i, s, pp, vox, meanf, vkey, n_valid);
+    ndt_voxel_finish(slot, key, L, j - i, s, pp, vox, meanf, vkey, n_valid);
 }
 
 // Coarse grids (PCL's default NDT resolution of 5 m puts thousands of points in a voxel): one WAVE
@@ -262,7 +284,7 @@ __global__ void __launch_bounds__(kVoxStatBlock)
 __global__ void __launch_bounds__(kBlock)
     k_ndt_voxel_stats_wave(const float4 *__restrict__ pts, const unsigned long long *__restrict__ keys,
                            const unsigned *__restrict__ perm, const unsigned *__restrict__ heads,
-                           unsigned nvox, NdtVoxel *__restrict__ vox, float4 *__restrict__ meanf,
+                           unsigned nvox, NdtLattice L, NdtVoxel *__restrict__ vox, float4 *__restrict__ meanf,
                            unsigned long long *__restrict__ vkey, unsigned *__restrict__ n_valid) {
     __shared__ float s_p[kBlock / 64][3][64];
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -296,7 +318,7 @@ __global__ void __launch_bounds__(kBlock)
         for (int k = 0; k < 3; ++k) s[k] = __shfl(acc, k);
 #pragma unroll
         for (int k = 0; k < 9; ++k) pp[k] = __shfl(acc, 3 + k);
-        if (lane == 0) ndt_voxel_finish(slot, keys[i], j - i, s, pp, vox, meanf, vkey, n_valid);
+        if (lane == 0) ndt_voxel_finish(slot, keys[i], L, j - i, s, pp, vox, meanf, vkey, n_valid);
     }
 }
 
@@ -617,13 +639,38 @@ static int ndt_build(wm_ctx *ctx, double res) {
     unsigned long long *k1 = ctx->ndt_keys.as<unsigned long long>(), *k2 = ctx->ndt_keys2.as<unsigned long long>();
     unsigned *p1 = ctx->vg_perm.as<unsigned>(), *p2 = ctx->vg_perm2.as<unsigned>();
     unsigned *flags = ctx->vg_idx.as<unsigned>(), *seg = ctx->vg_seg.as<unsigned>();
+    // the lattice of voxels over the target's bounding box (cell numbers from the same float
+    // product as the keys)
+    NdtLattice L{};
+    unsigned long long dimv[3];
+    {
+        const float inv = 1.0f / (float) res;
+        const Bbox &bb = ctx->tgt_bbox;
+        for (int d = 0; d < 3; ++d) {
+            L.lo[d] = (int) floorf(bb.lo[d] * inv);
+            const long long dd = (long long) floorf(bb.hi[d] * inv) - L.lo[d] + 1;
+            if (ctx->n_tgt > 0 && (dd < 1 || dd > (1ll << 20))) {  // ndt_key holds 21 bits per axis
+                ctx->last_error = "NDT: the target spans more than 2^20 voxels along an axis";
+                return WM_ERR_ARG;
+            }
+            dimv[d] = ctx->n_tgt > 0 ? (unsigned long long) dd : 1ull;
+        }
+        L.nx = dimv[0];
+        L.ny = dimv[1];
+        L.cells = dimv[0] * dimv[1] * dimv[2];
+    }
+    unsigned key_bits = 1;
+    while (key_bits < 64 && (L.cells >> key_bits) != 0ull) ++key_bits;
     hipLaunchKernelGGL(k_ndt_key, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, (unsigned) n,
-                       1.0f / (float) res, k1, p1);
+                       1.0f / (float) res, L, k1, p1);
     size_t tmp = 0;
-    WM_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp, k1, k2, p1, p2, n, 0, 64, ctx->stream));
+    WM_HIP(ctx, sort_pairs_low_bits(nullptr, tmp, k1, k2, p1, p2, n, key_bits, ctx->stream,
+                                    (size_t) ctx->tune_radix_min));
     WM_HIP(ctx, ctx->vg_tmp.reserve(tmp));
-    WM_HIP(ctx, rocprim::radix_sort_pairs(ctx->vg_tmp.p, tmp, k1, k2, p1, p2, n, 0, 64, ctx->stream));
-    hipLaunchKernelGGL(k_ndt_flags, dim3(blocks), dim3(kBlock), 0, ctx->stream, k2, (unsigned) n, flags);
+    WM_HIP(ctx, sort_pairs_low_bits(ctx->vg_tmp.p, tmp, k1, k2, p1, p2, n, key_bits, ctx->stream,
+                                    (size_t) ctx->tune_radix_min));
+    hipLaunchKernelGGL(k_ndt_flags, dim3(blocks), dim3(kBlock), 0, ctx->stream, k2, (unsigned) n, L.cells,
+                       flags);
     WM_TRY(exclusive_scan(ctx, flags, n, seg));
     unsigned *h_word = (unsigned *) pinned_scratch(ctx, 0);
     if (!h_word) return WM_ERR_HIP;
@@ -647,14 +694,14 @@ static int ndt_build(wm_ctx *ctx, double res) {
     if (nvox > 0) {
         unsigned *heads = p1;  // the sort's input permutation is dead by now
         hipLaunchKernelGGL(k_ndt_heads, dim3(blocks), dim3(kBlock), 0, ctx->stream, k2, flags, seg, (unsigned) n,
-                           heads);
+                           L.cells, heads);
         if ((unsigned long long) n > (unsigned long long) kVoxWaveAvg * nvox)
             hipLaunchKernelGGL(k_ndt_voxel_stats_wave, dim3(nvox < 8192u ? (nvox + 3u) / 4u : 2048u), dim3(kBlock),
-                               0, ctx->stream, pts, k2, p2, heads, nvox, ctx->ndt_vox.as<NdtVoxel>(),
+                               0, ctx->stream, pts, k2, p2, heads, nvox, L, ctx->ndt_vox.as<NdtVoxel>(),
                                ctx->ndt_meanf.as<float4>(), ctx->ndt_vkey.as<unsigned long long>(), d_nvalid);
         else
             hipLaunchKernelGGL(k_ndt_voxel_stats, dim3((nvox + kVoxStatBlock - 1) / kVoxStatBlock),
-                               dim3(kVoxStatBlock), 0, ctx->stream, pts, k2, p2, heads, nvox,
+                               dim3(kVoxStatBlock), 0, ctx->stream, pts, k2, p2, heads, nvox, L,
                                ctx->ndt_vox.as<NdtVoxel>(), ctx->ndt_meanf.as<float4>(),
                                ctx->ndt_vkey.as<unsigned long long>(), d_nvalid);
         hipLaunchKernelGGL(k_ndt_hash_insert, dim3((nvox + kBlock - 1) / kBlock), dim3(kBlock), 0,
