@@ -744,8 +744,16 @@ static int compute_covariances(wm_ctx *ctx, int k, double eps) {
     if (!(ctx->gicp_cov_src_valid && same)) {
         // source: its own grid; covariances stored in Morton (src_sorted) order
         WM_HIP(ctx, ctx->gicp_c1.reserve((ctx->n_src > 0 ? ctx->n_src : 1) * 9 * sizeof(double)));
-        double occ = 0;
+        double occ = 0, vol = 1;
+        for (int d = 0; d < 3; ++d) vol *= fmax((double) ctx->src_bbox.hi[d] - ctx->src_bbox.lo[d], 1e-3);
         float h = choose_cell(ctx->src_bbox, ctx->n_src);
+        // a source like the previous one (consecutive scans of one sensor): start from the cell
+        // size that was tuned for it, which usually passes the occupancy check at once and saves
+        // the second build (the level-0 grid of the target does the same)
+        if (ctx->tuned_src_h > 0 && ctx->tuned_src_n > 0) {
+            const double rn = (double) ctx->n_src / (double) ctx->tuned_src_n, rv = vol / ctx->tuned_src_vol;
+            if (rn > 0.8 && rn < 1.25 && rv > 0.6 && rv < 1.6) h = (float) ctx->tuned_src_h;
+        }
         WM_TRY(build_grid_level(ctx, ctx->src_orig.as<float4>(), ctx->n_src_input, ctx->src_bbox, h,
                                 &ctx->src_grid, &occ));
         if (occ > 6.0 || (occ > 0 && occ < 1.5)) {
@@ -753,6 +761,9 @@ static int compute_covariances(wm_ctx *ctx, int k, double eps) {
             WM_TRY(build_grid_level(ctx, ctx->src_orig.as<float4>(), ctx->n_src_input, ctx->src_bbox, h,
                                     &ctx->src_grid, nullptr));
         }
+        ctx->tuned_src_h = h;
+        ctx->tuned_src_n = ctx->n_src;
+        ctx->tuned_src_vol = vol;
         const float4 *q = ctx->src_sorted.as<float4>();
         WM_TRY(launch_cov_k(ctx, ctx->src_grid.d, q, ctx->n_src, ctx->src_orig.as<float4>(), k, eps,
                             ctx->gicp_c1.as<double>(), 0));

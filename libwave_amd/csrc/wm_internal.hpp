@@ -140,6 +140,8 @@ struct wm_ctx {
     float tune_r_light = 12.0f;  // lane-serial vs cooperative scan threshold, in level-0 cells
     double tuned_h = 0, tuned_vol = 0;  // last auto-tuned level-0 cell size and its cloud
     size_t tuned_n = 0;
+    double tuned_src_h = 0, tuned_src_vol = 0;  // the same for the source grid of the GICP covariances
+    size_t tuned_src_n = 0;
 
     // scratch
     wm::DevBuf staging, cell_of, counts, block_sums, bbox_buf;
