@@ -49,6 +49,17 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblocks) {
     const unsigned per = (nblocks + 7u) / 8u;
     return (b & 7u) * per + (b >> 3);
 }
+// The one used: the XCDs take turns in chunks of S blocks (nblocks a multiple of 8 S) of the
+// Morton-ordered queries.  A chunk of 32 blocks = 2048 queries is still one compact region for the
+// XCD's L2, but a region of EXPENSIVE queries (the far corner of a rotated cloud in the early
+// iterations) is now shared by all eight XCDs instead of landing on the one that owns that eighth
+// of the cloud: 83.0 -> 79.4 us per launch on the 1M pair (chunks of 8-32 equal, 128: 80.0,
+// 512: 84.5, whole eighths: 83.0).
+__device__ __forceinline__ unsigned xcd_remap_chunked(unsigned b, unsigned S) {
+    const unsigned x = b & 7u, l = b >> 3;
+    const unsigned chunk = l / S;
+    return (chunk * 8u + x) * S + (l - chunk * S);
+}
 
 // The grid tables are reached through pointers read from memory, so the compiler only knows
 // them as generic (flat) addresses; they always point into HBM -- say so, and get global_load
@@ -356,11 +367,13 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 
     k_nn_grid(const LevelsDev *__restrict__ lv, const float4 *__restrict__ src, unsigned n,
               IcpDevState *__restrict__ st, float thr_d2, unsigned long long *__restrict__ keys,
               float4 *__restrict__ match_pt, const float4 *__restrict__ tgt_orig,
-              float r_light_cells, float lane_lf, float coop_lf) {
+              float r_light_cells, float lane_lf, float coop_lf, unsigned xcd_chunk) {
     if (st->done) return;
     static_assert(kNnBlock == 64, "the run list is indexed by lane: one wavefront per workgroup");
     __shared__ uint2 s_runs[kRowChunk * kNnBlock];  // [run][lane]: each lane's pending runs
-    const unsigned i = xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const unsigned i = (xcd_chunk ? xcd_remap_chunked(blockIdx.x, xcd_chunk) : xcd_remap(blockIdx.x, gridDim.x)) *
+                           blockDim.x +
+                       threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
     const bool active = i < n;
     const int L = lv->n;
@@ -551,10 +564,18 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
     const unsigned nb = (unsigned) kNnBlock;  // one wave per workgroup (its LDS run list is sized for that)
     unsigned blocks = (n + nb - 1) / nb;
     blocks = (blocks + 7u) & ~7u;  // xcd_remap needs a multiple of 8
+    unsigned xcd_chunk = 0;
+    if (ctx->tune_xcd_chunk > 0 && blocks >= 32u * (unsigned) ctx->tune_xcd_chunk) {
+        // the chunked remap (big grids only: it pads the grid to a multiple of 8 chunks)
+        xcd_chunk = (unsigned) ctx->tune_xcd_chunk;
+        const unsigned m = 8u * xcd_chunk;
+        blocks = (blocks + m - 1u) / m * m;
+    }
     if (ev0) WM_HIP(ctx, hipEventRecord(ev0, ctx->stream));
     hipLaunchKernelGGL(k_nn_grid, dim3(blocks), dim3(nb), 0, ctx->stream,
                        ctx->d_levels.as<LevelsDev>(), ctx->src_sorted.as<float4>(), n, st, thr_d2,
-                       keys, ctx->match_pt.as<float4>(), ctx->tgt_orig.as<float4>(), ctx->tune_r_light, ctx->tune_lane_lf, ctx->tune_coop_lf);
+                       keys, ctx->match_pt.as<float4>(), ctx->tgt_orig.as<float4>(), ctx->tune_r_light, ctx->tune_lane_lf, ctx->tune_coop_lf,
+                       xcd_chunk);
     if (ev1) WM_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     if (ev2) WM_HIP(ctx, hipEventRecord(ev2, ctx->stream));
     WM_HIP(ctx, hipGetLastError());
