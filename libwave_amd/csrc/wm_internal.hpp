@@ -137,7 +137,7 @@ struct wm_ctx {
     bool trace = false;
     float tune_lane_lf = 0.2f;   // lane-serial scan: finest level with cell size >= this x radius
     float tune_coop_lf = 0.5f;   // cooperative scan: finest level with cell size >= this x radius
-    float tune_r_light = 12.0f;  // lane-serial vs cooperative scan threshold, in level-0 cells
+    float tune_r_light = 16.0f;  // lane-serial vs cooperative scan threshold, in level-0 cells (12-24 within 1 %)
     double tuned_h = 0, tuned_vol = 0;  // last auto-tuned level-0 cell size and its cloud
     size_t tuned_n = 0;
     double tuned_src_h = 0, tuned_src_vol = 0;  // the same for the source grid of the GICP covariances
