@@ -189,6 +189,7 @@ struct wm_ctx {
     float tune_knn_r0 = 0.f;     // first radius of the k-NN (covariance) scan in cells; 0 = by k (1.0 up to k = 12, else 1.5)
     int tune_radix_min = 512 << 10;  // sorts of more items take rocPRIM's onesweep radix path (wm_sort.hpp)
     int tune_xcd_chunk = 32;     // search kernel: XCDs take turns in chunks of this many workgroups (0: one eighth each)
+    int tune_scan = 1;           // exclusive scans: rocPRIM look-back scan (1) or the three-kernel scan (0)
     int tune_spin_us = 80;       // wait_flag: busy-poll this long before polling with yields
     int tune_ndt_blocks = 1024;  // workgroups (= partial rows) of one NDT derivative pass
     int tune_gicp_blocks = 512;  // workgroups (= partial rows) of one GICP objective evaluation
