@@ -631,6 +631,7 @@ int wm_ctx_create(wm_ctx **out, int device) {
         if (v >= 0.25f && v <= 8.f) ctx->tune_knn_r0 = v;
     }
     if (const char *e = getenv("WM_TUNE_SPIN_US")) ctx->tune_spin_us = atoi(e);
+    if (const char *e = getenv("WM_TUNE_XCD_REVERSE")) ctx->tune_xcd_reverse = atoi(e);
     if (const char *e = getenv("WM_TUNE_SCAN")) ctx->tune_scan = atoi(e);
     if (const char *e = getenv("WM_TUNE_XCD_CHUNK")) ctx->tune_xcd_chunk = atoi(e);
     if (const char *e = getenv("WM_TUNE_RADIX_MIN")) ctx->tune_radix_min = atoi(e);

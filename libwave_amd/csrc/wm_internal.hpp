@@ -190,6 +190,7 @@ struct wm_ctx {
     int tune_radix_min = 512 << 10;  // sorts of more items take rocPRIM's onesweep radix path (wm_sort.hpp)
     int tune_xcd_chunk = 32;     // search kernel: XCDs take turns in chunks of this many workgroups (0: one eighth each)
     int tune_scan = 1;           // exclusive scans: rocPRIM look-back scan (1) or the three-kernel scan (0)
+    int tune_xcd_reverse = 0;    // search kernel: hand the workgroups out back to front (experiment)
     int tune_spin_us = 80;       // wait_flag: busy-poll this long before polling with yields
     int tune_ndt_blocks = 1024;  // workgroups (= partial rows) of one NDT derivative pass
     int tune_gicp_blocks = 512;  // workgroups (= partial rows) of one GICP objective evaluation

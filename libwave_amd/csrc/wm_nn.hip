@@ -371,8 +371,10 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 
     if (st->done) return;
     static_assert(kNnBlock == 64, "the run list is indexed by lane: one wavefront per workgroup");
     __shared__ uint2 s_runs[kRowChunk * kNnBlock];  // [run][lane]: each lane's pending runs
-    const unsigned i = (xcd_chunk ? xcd_remap_chunked(blockIdx.x, xcd_chunk) : xcd_remap(blockIdx.x, gridDim.x)) *
-                           blockDim.x +
+    const bool rev = (xcd_chunk >> 31) != 0u;  // experiment: hand the queries out back to front
+    const unsigned chunk_sz = xcd_chunk & 0x7FFFFFFFu;
+    const unsigned bidx = rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+    const unsigned i = (chunk_sz ? xcd_remap_chunked(bidx, chunk_sz) : xcd_remap(bidx, gridDim.x)) * blockDim.x +
                        threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
     const bool active = i < n;
@@ -575,7 +577,7 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
     hipLaunchKernelGGL(k_nn_grid, dim3(blocks), dim3(nb), 0, ctx->stream,
                        ctx->d_levels.as<LevelsDev>(), ctx->src_sorted.as<float4>(), n, st, thr_d2,
                        keys, ctx->match_pt.as<float4>(), ctx->tgt_orig.as<float4>(), ctx->tune_r_light, ctx->tune_lane_lf, ctx->tune_coop_lf,
-                       xcd_chunk);
+                       xcd_chunk | (ctx->tune_xcd_reverse ? 0x80000000u : 0u));
     if (ev1) WM_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     if (ev2) WM_HIP(ctx, hipEventRecord(ev2, ctx->stream));
     WM_HIP(ctx, hipGetLastError());
