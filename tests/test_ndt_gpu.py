@@ -191,3 +191,25 @@ def test_sharded_ndt_equals_unsharded(wm, world):
     ctxs[0].ndt_set_shard(0, 1)
     again = ctxs[0].ndt_align(res=1.0)
     assert np.array_equal(again["T"], want["T"])
+
+
+def test_sharded_ndt_failing_reduce_aborts_cleanly(wm):
+    """A reduce callback that reports failure aborts the registration with an error (never a
+    half-reduced result), and the context works again once the shard setting is cleared."""
+    ref, tgt, _ = synth.pair(20000, seed=5)
+    c = wm.Context(0)
+    c.set_source(ref)
+    c.set_target(tgt)
+    want = c.ndt_align(res=1.0)
+    calls = []
+
+    def failing(vals, n, _user):
+        calls.append(n)
+        return 1
+    c.ndt_set_shard(0, 2, wm.ALLREDUCE_FN(failing))
+    with pytest.raises(wm.WmError) as e:
+        c.ndt_align(res=1.0)
+    assert "all-reduce callback failed" in str(e.value) and calls == [28]
+    c.ndt_set_shard(0, 1)
+    again = c.ndt_align(res=1.0)
+    assert again["rc"] == want["rc"] and np.array_equal(again["T"], want["T"])
