@@ -312,9 +312,10 @@ int wm_icp_shard_poll(wm_ctx *ctx, int *done, double T_out[16], wm_icp_stats *st
  * counterpart -- PCL's NDT is single-threaded).  Every rank sets the SAME two clouds and builds
  * the same voxel model (cheap: < 0.5 ms at 2M points); the Morton-ordered source is dealt out
  * to the ranks in chunks of 4096 points, round-robin (every rank works on the whole scene at
- * 1/world density: equal work), rank r evaluates its chunks in every derivative pass, and the 28
- * sums of that pass (score, gradient, upper triangle of the Hessian) are summed over the ranks by
- * `reduce` before the Newton / More-Thuente logic sees them.  `reduce` must leave bit-identical
+ * 1/world density: equal work), rank r evaluates its chunks in every derivative pass, and the
+ * sums of that pass -- n = 28 (score, gradient, upper triangle of the Hessian) or n = 7 (score,
+ * gradient: the line search's passes) -- are summed over the ranks by `reduce` before the
+ * Newton / More-Thuente logic sees them.  `reduce` must leave bit-identical
  * values on every rank (an RCCL / gloo all-reduce does): all ranks then take the same decisions
  * and return the same transform, with no broadcast.  It is called on the thread that called
  * wm_ndt_align, with a host array; return 0 on success (anything else aborts the registration

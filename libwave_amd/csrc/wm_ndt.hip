@@ -30,6 +30,7 @@ namespace wm {
 
 constexpr unsigned kNdtChunkLog2 = 12;  // sharded NDT: ranks take turns in chunks of 4096 source points
 constexpr int kNdtAcc = 28;  // score, 6 gradient entries, the 21 of the Hessian's upper triangle
+constexpr int kNdtAccGrad = 7;  // score + gradient (the line search's passes)
 __host__ __device__ constexpr int ndt_tri(int i, int j) {  // (i <= j) -> accumulator slot
     return 7 + i * 6 - i * (i - 1) / 2 + (j - i);
 }
@@ -392,9 +393,10 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))
                  const float4 *__restrict__ meanf, const unsigned long long *__restrict__ hkeys, const unsigned *__restrict__ hvals,
                  unsigned mask, NdtDense dense, NdtArgs A, double *__restrict__ partials) {
     __shared__ unsigned s_near[27 * kBlock];  // per-lane lists, pass 1 -> pass 2 (lane-private)
-    double acc[kNdtAcc];
+    constexpr int NA = HESS ? kNdtAcc : kNdtAccGrad;  // a gradient pass carries (and ships) 7 sums, not 28
+    double acc[NA];
 #pragma unroll
-    for (int k = 0; k < kNdtAcc; ++k) acc[k] = 0.0;
+    for (int k = 0; k < NA; ++k) acc[k] = 0.0;
     // n = local count (a multiple of the chunk when sharded); the global index interleaves the
     // ranks chunk by chunk, so every rank works on a uniform sample of the Morton-ordered cloud
     for (unsigned loc = blockIdx.x * kBlock + threadIdx.x; loc < n; loc += gridDim.x * kBlock) {
@@ -603,19 +605,19 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))
     }
     // fixed-order reduction: wave xor-tree, then the 4 waves through LDS
 #pragma unroll
-    for (int k = 0; k < kNdtAcc; ++k)
+    for (int k = 0; k < NA; ++k)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off);
-    __shared__ double lds[kBlock / 64][kNdtAcc];
+    __shared__ double lds[kBlock / 64][NA];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0)
 #pragma unroll
-        for (int k = 0; k < kNdtAcc; ++k) lds[wave][k] = acc[k];
+        for (int k = 0; k < NA; ++k) lds[wave][k] = acc[k];
     __syncthreads();
-    if (threadIdx.x < kNdtAcc) {
+    if (threadIdx.x < NA) {
         double s = 0;
         for (int w = 0; w < kBlock / 64; ++w) s += lds[w][threadIdx.x];
-        partials[(size_t) blockIdx.x * kNdtAcc + threadIdx.x] = s;
+        partials[(size_t) blockIdx.x * NA + threadIdx.x] = s;
     }
 }
 
@@ -872,7 +874,8 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
     }
     const auto t_launch1 = std::chrono::steady_clock::now();
     // sums over blocks, formed on the device (fixed order); 224 bytes come back
-    if (fast_fetch_sum(ctx, ctx->h_ndt, partials, (unsigned) nb, kNdtAcc) != WM_OK) {
+    const int n_acc = hess ? kNdtAcc : kNdtAccGrad;
+    if (fast_fetch_sum(ctx, ctx->h_ndt, partials, (unsigned) nb, (unsigned) n_acc) != WM_OK) {
         ctx->last_error = "ndt_eval: HIP error";
         *rc = WM_ERR_HIP;
         return 0;
@@ -887,9 +890,9 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
     }
     E.kernel_ms += ms;
     E.evals += 1;
-    double a[kNdtAcc];
-    for (int k = 0; k < kNdtAcc; ++k) a[k] = ctx->h_ndt[k];
-    if (sharded && ctx->ndt_reduce(a, kNdtAcc, ctx->ndt_reduce_user) != 0) {
+    double a[kNdtAcc] = {0};
+    for (int k = 0; k < n_acc; ++k) a[k] = ctx->h_ndt[k];
+    if (sharded && ctx->ndt_reduce(a, n_acc, ctx->ndt_reduce_user) != 0) {
         ctx->last_error = "ndt_eval: the all-reduce callback failed";
         *rc = WM_ERR_STATE;
         return 0;
