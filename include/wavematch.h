@@ -186,6 +186,10 @@ int wm_icp_info(wm_ctx *ctx, int method, const double T_result[16], double lin_c
  * wm_icp_align call that ran with profile >= 1; returns the number written. */
 int wm_get_iteration_times(wm_ctx *ctx, float *nn_ms, int cap);
 
+/* Developer aid: shader-clock stamps of the last solve kernel of the last align (start, rows
+ * added, statistics expanded, solve + stopping rules done). */
+int wm_debug_solve_cycles(wm_ctx *ctx, unsigned long long out[8]);
+
 /* PCL's icp.correspondences_ after align (read by estimateLUM / estimateCensi,
  * icp_pcl_functions.cpp:191, icp.cpp:213): per source point (caller's order)
  * the matched target index (caller's order; -1 = none) and squared distance. */

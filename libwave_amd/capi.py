@@ -137,6 +137,7 @@ def lib():
                                          C.POINTER(C.c_int)]
         L.wm_ndt_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]
         L.wm_get_iteration_times.argtypes = [C.c_void_p, _fp, C.c_int]
+        L.wm_debug_solve_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.wm_get_correspondences.argtypes = [C.c_void_p, _ip, _fp, C.c_size_t]
         L.wm_nn_search.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int, _ip, _fp, C.c_size_t, _fp]
         L.wm_icp_stats_for.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
@@ -417,6 +418,11 @@ class Context:
         d["T"] = T
         d["done"] = bool(done.value)
         return d
+
+    def solve_cycles(self):
+        buf = (C.c_uint64 * 8)()
+        lib().wm_debug_solve_cycles(self._h, buf)
+        return [int(v) for v in buf]
 
     def iteration_times(self, cap=1024):
         buf = np.zeros(cap, np.float32)

@@ -795,8 +795,9 @@ void wm_gicp_default_params(wm_gicp_params *p) {
 int wm_gicp_covariances(wm_ctx *ctx, int k, double eps, double *cov_source, double *cov_target) {
     if (!ctx || k < 1 || k > 32) return WM_ERR_ARG;
     if (ctx->n_src_input == 0 || ctx->n_tgt_input == 0) return WM_ERR_STATE;
-    if ((size_t) k > ctx->n_src || (size_t) k > ctx->n_tgt) return WM_NOT_CONVERGED;
     WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_TRY(finalize_clouds(ctx));
+    if ((size_t) k > ctx->n_src || (size_t) k > ctx->n_tgt) return WM_NOT_CONVERGED;
     WM_TRY(compute_covariances(ctx, k, eps));
     if (cov_target)
         WM_TRY(copy_to_caller(ctx, cov_target, ctx->gicp_c2.p, ctx->n_tgt_input * 9 * sizeof(double)));
@@ -822,6 +823,7 @@ int wm_gicp_align(wm_ctx *ctx, const wm_gicp_params *prm, double T_out[16], wm_g
     if (stats) memset(stats, 0, sizeof(*stats));
     if (ctx->n_src_input == 0 || ctx->n_tgt_input == 0) return WM_ERR_STATE;
     WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_TRY(finalize_clouds(ctx, prm->max_corr, WM_NN_AUTO));
     // PCL: "Number of points in cloud is less than k_correspondences_" -> no alignment
     if ((size_t) prm->corr_rand > ctx->n_src || (size_t) prm->corr_rand > ctx->n_tgt) return WM_NOT_CONVERGED;
     WM_TRY(compute_covariances(ctx, prm->corr_rand, prm->gicp_epsilon));
@@ -898,8 +900,9 @@ int wm_gicp_eval(wm_ctx *ctx, const wm_gicp_params *prm, const double T_pair[16]
                  double *f, double g[6], int *n_pairs) {
     if (!ctx || !prm || !T_pair || !x || !f) return WM_ERR_ARG;
     if (ctx->n_src_input == 0 || ctx->n_tgt_input == 0) return WM_ERR_STATE;
-    if ((size_t) prm->corr_rand > ctx->n_src || (size_t) prm->corr_rand > ctx->n_tgt) return WM_NOT_CONVERGED;
     WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_TRY(finalize_clouds(ctx, prm->max_corr, WM_NN_AUTO));
+    if ((size_t) prm->corr_rand > ctx->n_src || (size_t) prm->corr_rand > ctx->n_tgt) return WM_NOT_CONVERGED;
     WM_TRY(compute_covariances(ctx, prm->corr_rand, prm->gicp_epsilon));
     const size_t n = ctx->n_src;
     WM_HIP(ctx, ctx->gicp_mahal.reserve(n * 9 * sizeof(double)));

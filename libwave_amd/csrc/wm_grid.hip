@@ -53,7 +53,6 @@ int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, f
 // ------------------------------------------------------------------ bbox
 // One partial per workgroup: out[8 b + 0..2] = min, [3..5] = max (as floats), [6] = valid count.
 // The host reduces the partials (it waits for the result anyway); no same-address atomics.
-constexpr int kBboxBlocks = 512;
 __global__ void __launch_bounds__(kBlock) k_bbox(const float4 *pts, size_t n, float *out) {
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     unsigned cnt = 0;
@@ -113,20 +112,18 @@ __global__ void __launch_bounds__(kBlock) k_bbox(const float4 *pts, size_t n, fl
     }
 }
 
-int compute_bbox(wm_ctx *ctx, const float4 *pts, size_t n, Bbox *out, size_t *n_valid) {
-    for (int d = 0; d < 3; ++d) out->lo[d] = out->hi[d] = 0.f;
-    *n_valid = 0;
-    if (n == 0) return WM_OK;
+int launch_bbox(wm_ctx *ctx, const float4 *pts, size_t n, float *partials_dev, unsigned *blocks_out) {
     unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
     if (blocks > (unsigned) kBboxBlocks) blocks = kBboxBlocks;
-    // partials in device memory, fetched into pinned memory by one wavefront (fast_fetch)
-    float *res = (float *) pinned_scratch(ctx, 8 * sizeof(float) * kBboxBlocks);
-    if (!res) return WM_ERR_HIP;
-    WM_HIP(ctx, ctx->bbox_buf.reserve(8 * sizeof(float) * kBboxBlocks));
-    hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, n,
-                       ctx->bbox_buf.as<float>());
+    *blocks_out = blocks;
+    if (n == 0) return WM_OK;
+    hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, n, partials_dev);
     WM_HIP(ctx, hipGetLastError());
-    WM_TRY(fast_fetch(ctx, res, ctx->bbox_buf.p, 8 * sizeof(float) * blocks));
+    return WM_OK;
+}
+
+void finish_bbox(const float *res, unsigned blocks, Bbox *out, size_t *n_valid) {
+    for (int d = 0; d < 3; ++d) out->lo[d] = out->hi[d] = 0.f;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     size_t cnt = 0;
     for (unsigned b = 0; b < blocks; ++b) {
@@ -145,6 +142,20 @@ int compute_bbox(wm_ctx *ctx, const float4 *pts, size_t n, Bbox *out, size_t *n_
             out->lo[d] = lo[d];
             out->hi[d] = hi[d];
         }
+}
+
+int compute_bbox(wm_ctx *ctx, const float4 *pts, size_t n, Bbox *out, size_t *n_valid) {
+    for (int d = 0; d < 3; ++d) out->lo[d] = out->hi[d] = 0.f;
+    *n_valid = 0;
+    if (n == 0) return WM_OK;
+    // partials in device memory, fetched into pinned memory by one wavefront (fast_fetch)
+    float *res = (float *) pinned_scratch(ctx, 8 * sizeof(float) * kBboxBlocks);
+    if (!res) return WM_ERR_HIP;
+    WM_HIP(ctx, ctx->bbox_buf.reserve(8 * sizeof(float) * kBboxBlocks));
+    unsigned blocks = 0;
+    WM_TRY(launch_bbox(ctx, pts, n, ctx->bbox_buf.as<float>(), &blocks));
+    WM_TRY(fast_fetch(ctx, res, ctx->bbox_buf.p, 8 * sizeof(float) * blocks));
+    finish_bbox(res, blocks, out, n_valid);
     return WM_OK;
 }
 
@@ -184,30 +195,32 @@ struct MortonKey {  // Morton code of a 2^bits-per-axis cell (source ordering)
     }
 };
 
+// histogram of the cells; the value the atomic returns is the point's rank inside its cell, so the
+// scatter needs no second round of atomics (the order inside a cell is the atomics' arrival order:
+// arbitrary, and irrelevant -- the search's keys carry the original index)
 template <class KeyFn>
 __global__ void __launch_bounds__(kBlock) k_count(const float4 *pts, size_t n, KeyFn key,
-                                                   unsigned *cell_of, unsigned *counts) {
+                                                   unsigned *cell_of, unsigned *rank_of, unsigned *counts) {
     size_t i = (size_t) blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     float4 p = pts[i];
-    unsigned c = kNoIdx;
+    unsigned c = kNoIdx, r = 0;
     if (p.x == p.x) {
         c = key(p);
-        atomicAdd(&counts[c], 1u);
+        r = atomicAdd(&counts[c], 1u);
     }
     cell_of[i] = c;
+    rank_of[i] = r;
 }
 
 __global__ void __launch_bounds__(kBlock) k_scatter(const float4 *pts, size_t n,
-                                                     const unsigned *cell_of,
-                                                     const unsigned *cell_start, unsigned *fill,
-                                                     float4 *out) {
+                                                     const unsigned *cell_of, const unsigned *rank_of,
+                                                     const unsigned *cell_start, float4 *out) {
     size_t i = (size_t) blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     unsigned c = cell_of[i];
     if (c == kNoIdx) return;
-    unsigned pos = cell_start[c] + atomicAdd(&fill[c], 1u);
-    out[pos] = pts[i];
+    out[cell_start[c] + rank_of[i]] = pts[i];
 }
 
 // ------------------------------------------------------- exclusive scan
@@ -328,19 +341,18 @@ int exclusive_scan(wm_ctx *ctx, const unsigned *in, size_t n, unsigned *out) {
 template <class KeyFn>
 static int counting_sort(wm_ctx *ctx, const float4 *pts, size_t n, KeyFn key, size_t ncells,
                          unsigned *cell_start /* ncells+1 */, float4 *out) {
-    WM_HIP(ctx, ctx->cell_of.reserve(n * sizeof(unsigned)));
+    WM_HIP(ctx, ctx->cell_of.reserve(2 * n * sizeof(unsigned)));
     WM_HIP(ctx, ctx->counts.reserve(ncells * sizeof(unsigned)));
     unsigned *counts = ctx->counts.as<unsigned>();
-    unsigned *cell_of = ctx->cell_of.as<unsigned>();
+    unsigned *cell_of = ctx->cell_of.as<unsigned>(), *rank_of = cell_of + n;
     WM_HIP(ctx, hipMemsetAsync(counts, 0, ncells * sizeof(unsigned), ctx->stream));
     unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_count<KeyFn>), dim3(blocks), dim3(kBlock), 0, ctx->stream,
-                       pts, n, key, cell_of, counts);
+                       pts, n, key, cell_of, rank_of, counts);
     WM_HIP(ctx, hipGetLastError());
     WM_TRY(exclusive_scan(ctx, counts, ncells, cell_start));
-    WM_HIP(ctx, hipMemsetAsync(counts, 0, ncells * sizeof(unsigned), ctx->stream));
-    hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, n, cell_of,
-                       cell_start, counts, out);
+    hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, n, cell_of, rank_of,
+                       cell_start, out);
     WM_HIP(ctx, hipGetLastError());
     return WM_OK;
 }
@@ -614,7 +626,13 @@ static int build_level0(wm_ctx *ctx) {
         const double rn = (double) ctx->n_tgt / (double) ctx->tuned_n;
         const double rv = vol / ctx->tuned_vol;
         if (rn > 0.8 && rn < 1.25 && rv > 0.6 && rv < 1.6) h = clamp_h(ctx->tuned_h);
+        // a cloud this close to the one the cell size was measured on: build with it and skip the
+        // occupancy check (a device -> host round trip) -- but look again every 16th time.  The cell
+        // size only steers the search's work, never its result.
+        if (rn > 0.9 && rn < 1.1 && rv > 0.8 && rv < 1.25 && ++ctx->tuned_uses < 16)
+            return build_grid_level(ctx, pts, n, bb, (float) h, &ctx->levels[0], nullptr);
     }
+    ctx->tuned_uses = 0;
     double occ = 0;
     for (int it = 0; it < 3; ++it) {
         WM_TRY(build_grid_level(ctx, pts, n, bb, (float) h, &ctx->levels[0], &occ));

@@ -27,7 +27,6 @@
 
 namespace wm {
 
-constexpr int kAcc = 18;  // 17 statistics + the number of source points this rank handled
 constexpr int kMaxStatBlocks = 256;
 constexpr int kStatUnroll = 4;  // points per thread per trip of the statistics kernel
 
@@ -203,10 +202,16 @@ __host__ __device__ inline void icp_apply_stats(IcpDevState *st, const double *s
         return;
     }
     double Tk[16], Tc[16], Tn[16];
+#ifdef __HIP_DEVICE_COMPILE__
+    st->dbg[4] = clock64();
+#endif
     if (mode == WM_ICP_SVD)
-        umeyama_from_stats(stats, Tk);
+        umeyama_from_stats(stats, Tk, st->svd_warm ? st->svd_v : nullptr);
     else
         gn6_from_stats(stats, Tk);
+#ifdef __HIP_DEVICE_COMPILE__
+    st->dbg[5] = clock64();
+#endif
 #pragma unroll
     for (int k = 0; k < 16; ++k) Tc[k] = st->T[k];
     mat4_mul(Tk, Tc, Tn);
@@ -257,50 +262,125 @@ __host__ __device__ inline void icp_apply_stats(IcpDevState *st, const double *s
     st->prev_mse = mse;
 }
 
+// Pre-reduction for very many partial rows (fused statistics of clouds beyond ~1M points per GPU,
+// or one-wave workgroups): block b adds rows [128 b, 128 b + 128) in a fixed order -> out row b.
+constexpr int kPreRows = 128;
+__global__ void __launch_bounds__(kBlock)
+    k_reduce_rows(const double *__restrict__ partials, int rows, const IcpDevState *__restrict__ st,
+                  double *__restrict__ out) {
+    if (st->done) return;
+    constexpr int kLanes = kBlock / kAcc;  // 14 row-lanes x kAcc components
+    __shared__ double lds[kLanes][kAcc];
+    const int c = threadIdx.x % kAcc, r = threadIdx.x / kAcc;
+    const int r0 = blockIdx.x * kPreRows, r1 = min(r0 + kPreRows, rows);
+    if (r < kLanes) {
+        double v[(kPreRows + kLanes - 1) / kLanes];
+        int k = 0;
+#pragma unroll
+        for (int b = r0 + r, u = 0; u < (kPreRows + kLanes - 1) / kLanes; b += kLanes, ++u, ++k)
+            v[u] = b < r1 ? partials[(size_t) b * kAcc + c] : 0.0;
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < (kPreRows + kLanes - 1) / kLanes; ++u) s += v[u];
+        lds[r][c] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kAcc) {
+        double t = 0.0;
+#pragma unroll
+        for (int l = 0; l < kLanes; ++l) t += lds[l][threadIdx.x];
+        out[(size_t) blockIdx.x * kAcc + threadIdx.x] = t;
+    }
+}
+
 // PHASE 1: sum partials -> st->stats.   PHASE 2: solve + criteria from st->stats.
 // Single GPU launches <1|2>; the sharded path launches <1>, all-reduces
 // st->stats over RCCL, then launches <2>.
-template <int PHASES>
-__global__ void __launch_bounds__(kBlock)
+// THREADS = 256 for the few rows of k_icp_stats, 1024 for the thousands of rows the fused search
+// kernel leaves (one row per workgroup).
+template <int PHASES, int THREADS>
+__global__ void __launch_bounds__(THREADS)
     k_reduce_solve(const double *__restrict__ partials, int nblocks, IcpDevState *st,
                    double *stats_io) {
     // The solve runs in ONE lane and touches two dozen fields of the state: read from HBM one
     // dependent access at a time that is most of this kernel's ~10 us.  So the whole state is
     // staged in LDS by all threads (one round trip), worked on there, and written back whole.
     __shared__ IcpDevState s_st;
+    const unsigned long long t_start = clock64();
     static_assert(sizeof(IcpDevState) % 4 == 0, "word-wise staging");
     constexpr unsigned kWords = sizeof(IcpDevState) / 4;
-    for (unsigned w = threadIdx.x; w < kWords; w += kBlock)
-        reinterpret_cast<unsigned *>(&s_st)[w] = reinterpret_cast<const unsigned *>(st)[w];
-    constexpr int kRows = kBlock / kAcc;  // row-lanes x kAcc components <= 256 threads
+    // (the state's loads are issued here and land in LDS after the rows' loads have been issued
+    // too: one memory round trip for both, not two)
+    constexpr unsigned kStage = (kWords + THREADS - 1) / THREADS;
+    unsigned stage[kStage];
+#pragma unroll
+    for (unsigned k = 0; k < kStage; ++k) {
+        const unsigned w = threadIdx.x + k * THREADS;
+        stage[k] = w < kWords ? reinterpret_cast<const unsigned *>(st)[w] : 0u;
+    }
+    constexpr int kRows = THREADS / kAcc;  // row-lanes x kAcc components <= THREADS threads
+    constexpr int kGroups = 8;
     __shared__ double lds[kRows][kAcc];
+    __shared__ double lds2[kGroups][kAcc];
+    __shared__ double tot[kAcc];
     if (PHASES & 1) {
+        // thread (r, c) adds rows r, r + kRows, ... of column c: a wave reads 64 consecutive
+        // doubles per load; 16 independent accumulators keep 16 loads in flight (every dependent
+        // load -> add would cost a memory latency)
         const int c = threadIdx.x % kAcc, r = threadIdx.x / kAcc;
         if (r < kRows) {
-            // 8 independent accumulators: keeps 8 loads in flight instead of one
-            // dependent load->add chain per partial (which costs a memory latency each)
-            double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            int b = r;
-            for (; b + 7 * kRows < nblocks; b += 8 * kRows) {
+            constexpr int U = 16;
+            double s[U];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) s[u] += partials[(size_t) (b + u * kRows) * kAcc + c];
+            for (int u = 0; u < U; ++u) s[u] = 0.0;
+            for (int b = r; b < nblocks; b += U * kRows) {  // every batch: U loads, then U adds
+                double v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int bb = b + u * kRows;
+                    v[u] = bb < nblocks ? partials[(size_t) bb * kAcc + c] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) s[u] += v[u];
             }
-            for (int u = 0; b < nblocks; b += kRows, ++u) s[u] += partials[(size_t) b * kAcc + c];
-            lds[r][c] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+#pragma unroll
+            for (int w = U / 2; w > 0; w >>= 1)
+#pragma unroll
+                for (int u = 0; u < w; ++u) s[u] += s[u + w];
+            lds[r][c] = s[0];
+        }
+    }
+#pragma unroll
+    for (unsigned k = 0; k < kStage; ++k) {
+        const unsigned w = threadIdx.x + k * THREADS;
+        if (w < kWords) reinterpret_cast<unsigned *>(&s_st)[w] = stage[k];
+    }
+    if (PHASES & 1) {
+        const int c = threadIdx.x % kAcc;
+        __syncthreads();
+        if (threadIdx.x < kGroups * kAcc) {  // row-lanes g, g + 8, ... of column c
+            const int g = threadIdx.x / kAcc;
+            double t = 0.0;
+            for (int sl = g; sl < kRows; sl += kGroups) t += lds[sl][c];
+            lds2[g][c] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < kAcc) {
+            double t = 0.0;
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g) t += lds2[g][threadIdx.x];
+            tot[threadIdx.x] = t;
         }
     }
     __syncthreads();
     if (s_st.done) return;  // (uniform: every thread reads the staged copy)
     if (threadIdx.x == 0) {
+        s_st.dbg[0] = t_start;
+        s_st.dbg[1] = clock64();  // state staged, rows added
         if (PHASES & 1) {
             double a[kAcc];
 #pragma unroll
-            for (int k = 0; k < kAcc; ++k) {
-                double t = 0;
-#pragma unroll
-                for (int sl = 0; sl < kRows; ++sl) t += lds[sl][k];
-                a[k] = t;
-            }
+            for (int k = 0; k < kAcc; ++k) a[k] = tot[k];
             double ex[kStatsLen];
             expand_stats(s_st.mode, a, ex);
 #pragma unroll
@@ -317,11 +397,13 @@ __global__ void __launch_bounds__(kBlock)
             double stats[kStatsLen];
 #pragma unroll
             for (int k = 0; k < kStatsLen; ++k) stats[k] = s_st.stats[k];
+            s_st.dbg[2] = clock64();
             icp_apply_stats(&s_st, stats);
         }
+        s_st.dbg[3] = clock64();
     }
     __syncthreads();
-    for (unsigned w = threadIdx.x; w < kWords; w += kBlock)
+    for (unsigned w = threadIdx.x; w < kWords; w += THREADS)
         reinterpret_cast<unsigned *>(st)[w] = reinterpret_cast<const unsigned *>(&s_st)[w];
 }
 
@@ -365,11 +447,46 @@ static int launch_stats(wm_ctx *ctx, int mode) {
     return WM_OK;
 }
 
+// Sum `rows` partial rows (ctx->partials) and run the requested phases of the iteration's solve.
+template <int PHASES>
+static int launch_reduce_solve(wm_ctx *ctx, unsigned rows, double *stats_io) {
+    IcpDevState *st = ctx->d_state.as<IcpDevState>();
+    const double *part = ctx->partials.as<double>();
+    if (rows > 2048u) {  // one workgroup cannot add that many rows quickly: 128 rows -> 1 first
+        const unsigned rows2 = (rows + kPreRows - 1) / kPreRows;
+        WM_HIP(ctx, ctx->partials2.reserve((size_t) rows2 * kAcc * sizeof(double)));
+        hipLaunchKernelGGL(k_reduce_rows, dim3(rows2), dim3(kBlock), 0, ctx->stream, part, (int) rows, st,
+                           ctx->partials2.as<double>());
+        part = ctx->partials2.as<double>();
+        rows = rows2;
+    }
+    if (rows > 512u)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<PHASES, 1024>), dim3(1), dim3(1024), 0, ctx->stream,
+                           part, (int) rows, st, stats_io);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<PHASES, kBlock>), dim3(1), dim3(kBlock), 0, ctx->stream,
+                           part, (int) rows, st, stats_io);
+    WM_HIP(ctx, hipGetLastError());
+    return WM_OK;
+}
+
+// one iteration's correspondence search + statistics on the grid: fused (the search kernel leaves
+// the partial rows) or as two passes; *rows = partial rows to add up
+static int launch_search_and_stats(wm_ctx *ctx, float thr, int mode, hipEvent_t e0, hipEvent_t e1,
+                                   hipEvent_t e1b, unsigned *rows) {
+    if (ctx->tune_fuse_stats) return launch_nn_grid(ctx, thr, e0, e1, e1b, mode, rows);
+    WM_TRY(launch_nn_grid(ctx, thr, e0, e1, e1b));
+    WM_TRY(launch_stats(ctx, mode));
+    *rows = (unsigned) stat_blocks(ctx->n_src);
+    return WM_OK;
+}
+
 static int prepare_work(wm_ctx *ctx) {
     const size_t n = ctx->n_src > 0 ? ctx->n_src : 1;
     WM_HIP(ctx, ctx->keys.reserve(n * sizeof(unsigned long long)));
     WM_HIP(ctx, ctx->match_pt.reserve(n * sizeof(float4)));
-    WM_HIP(ctx, ctx->partials.reserve((size_t) kMaxStatBlocks * kAcc * sizeof(double)));
+    // rows of the fused search + statistics kernel: one per workgroup (at most one per 64 queries, plus grid padding)
+    WM_HIP(ctx, ctx->partials.reserve((n / 64 + 1024) * kAcc * sizeof(double)));
     WM_HIP(ctx, ctx->d_state.reserve(sizeof(IcpDevState)));
     if (!ctx->h_state)
         WM_HIP(ctx, hipHostMalloc((void **) &ctx->h_state, sizeof(IcpDevState), hipHostMallocDefault));
@@ -571,6 +688,7 @@ static hipEvent_t get_event(wm_ctx *ctx, size_t k) {
 }
 
 int nn_pass(wm_ctx *ctx, const double T[16], float thr_d2, double max_corr, bool predict) {
+    WM_TRY(finalize_clouds(ctx, max_corr, WM_NN_AUTO));
     WM_TRY(prepare_work(ctx));
     const bool brute = use_brute(ctx, WM_NN_AUTO) || ctx->n_tgt == 0;
     if (!brute) WM_TRY(ensure_levels(ctx, max_corr));
@@ -583,6 +701,64 @@ int nn_pass(wm_ctx *ctx, const double T[16], float thr_d2, double max_corr, bool
         WM_TRY(launch_nn_grid(ctx, thr_d2, nullptr, nullptr, nullptr));
     WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return WM_OK;
+}
+
+int finalize_clouds(wm_ctx *ctx, double max_corr, int nn_method) {
+    if (ctx->src_pending || ctx->tgt_pending) {
+        // ONE round trip for both clouds' partials (they sit in one device buffer)
+        float *res = (float *) pinned_scratch(ctx, 2 * 8 * sizeof(float) * kBboxBlocks);
+        if (!res) return WM_ERR_HIP;
+        const size_t slot = 8 * (size_t) kBboxBlocks;
+        if (ctx->src_pending && ctx->tgt_pending) {
+            WM_TRY(fast_fetch(ctx, res, ctx->cloud_bbox.p, 2 * slot * sizeof(float)));
+        } else if (ctx->src_pending) {
+            WM_TRY(fast_fetch(ctx, res, ctx->cloud_bbox.p, 8 * sizeof(float) * ctx->src_bbox_blocks));
+        } else {
+            WM_TRY(fast_fetch(ctx, res + slot, ctx->cloud_bbox.as<float>() + slot,
+                              8 * sizeof(float) * ctx->tgt_bbox_blocks));
+        }
+    }
+    bool forked = false;
+    if (ctx->src_pending) {
+        ctx->src_pending = false;
+        const float *res = (const float *) ctx->h_scratch;
+        size_t valid = 0;
+        finish_bbox(res, ctx->src_bbox_blocks, &ctx->src_bbox, &valid);
+        if (ctx->trace)
+            fprintf(stderr, "[wm] source: valid=%zu lo=(%g %g %g) hi=(%g %g %g)\n", valid, ctx->src_bbox.lo[0],
+                    ctx->src_bbox.lo[1], ctx->src_bbox.lo[2], ctx->src_bbox.hi[0], ctx->src_bbox.hi[1],
+                    ctx->src_bbox.hi[2]);
+        // the Morton sort of the source is independent of the target's grid build: side stream
+        hipStream_t main_stream = ctx->stream;
+        const bool side = ctx->tune_two_streams && ctx->side_stream && ctx->tgt_pending && max_corr > 0;
+        if (side) {
+            WM_HIP(ctx, hipEventRecord(ctx->ev_fork, main_stream));
+            WM_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+            ctx->stream = ctx->side_stream;
+        }
+        const int rc = morton_sort(ctx, ctx->src_orig.as<float4>(), ctx->n_src_input, ctx->src_bbox, valid,
+                                   ctx->src_sorted.as<float4>());
+        ctx->stream = main_stream;
+        if (rc != WM_OK) return rc;
+        if (side) {
+            WM_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
+            forked = true;
+        }
+        ctx->n_src = valid;
+        WM_TRACE(ctx, "source: sorted");
+    }
+    if (ctx->tgt_pending) {
+        ctx->tgt_pending = false;
+        const float *res = (const float *) ctx->h_scratch + 8 * (size_t) kBboxBlocks;
+        size_t valid = 0;
+        finish_bbox(res, ctx->tgt_bbox_blocks, &ctx->tgt_bbox, &valid);
+        ctx->n_tgt = valid;
+    }
+    int rc = WM_OK;
+    if (max_corr > 0 && ctx->n_src > 0 && ctx->n_tgt > 0 && !use_brute(ctx, nn_method))
+        rc = ensure_levels(ctx, max_corr);
+    if (forked) WM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    return rc;
 }
 
 }  // namespace wm
@@ -620,6 +796,9 @@ int wm_ctx_create(wm_ctx **out, int device) {
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&ctx->ev_a) != hipSuccess || hipEventCreate(&ctx->ev_b) != hipSuccess) {
         delete ctx;
         return WM_ERR_HIP;
@@ -633,6 +812,10 @@ int wm_ctx_create(wm_ctx **out, int device) {
     if (const char *e = getenv("WM_TUNE_SPIN_US")) ctx->tune_spin_us = atoi(e);
     if (const char *e = getenv("WM_TUNE_XCD_REVERSE")) ctx->tune_xcd_reverse = atoi(e);
     if (const char *e = getenv("WM_TUNE_SCAN")) ctx->tune_scan = atoi(e);
+    if (const char *e = getenv("WM_TUNE_TWO_STREAMS")) ctx->tune_two_streams = atoi(e);
+    if (const char *e = getenv("WM_TUNE_FUSE_STATS")) ctx->tune_fuse_stats = atoi(e);
+    if (const char *e = getenv("WM_TUNE_NN_WAVES")) ctx->tune_nn_waves = atoi(e);
+    if (const char *e = getenv("WM_TUNE_FAST_SOLVE")) ctx->tune_fast_solve = atoi(e);
     if (const char *e = getenv("WM_TUNE_XCD_CHUNK")) ctx->tune_xcd_chunk = atoi(e);
     if (const char *e = getenv("WM_TUNE_RADIX_MIN")) ctx->tune_radix_min = atoi(e);
     if (const char *e = getenv("WM_TUNE_NDT_BLOCKS")) {
@@ -677,13 +860,13 @@ void wm_ctx_destroy(wm_ctx *ctx) {
     (void) hipSetDevice(ctx->device);
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->src_sorted, &ctx->tgt_orig, &ctx->staging, &ctx->cell_of, &ctx->counts,
-                      &ctx->block_sums, &ctx->bbox_buf, &ctx->keys, &ctx->keys_bak, &ctx->match_pt, &ctx->match_pt_bak, &ctx->d_levels, &ctx->ndt_keys, &ctx->ndt_keys2,
+                      &ctx->block_sums, &ctx->bbox_buf, &ctx->cloud_bbox, &ctx->keys, &ctx->keys_bak, &ctx->match_pt, &ctx->match_pt_bak, &ctx->d_levels, &ctx->ndt_keys, &ctx->ndt_keys2,
                       &ctx->ndt_vox, &ctx->ndt_vkey, &ctx->ndt_hkeys, &ctx->ndt_hvals, &ctx->ndt_dense, &ctx->ndt_meanf, &ctx->src_orig,
                       &ctx->gicp_c1, &ctx->gicp_c2, &ctx->gicp_mahal, &ctx->src_grid.pts,
                       &ctx->src_grid.cell_start, &ctx->vg_idx, &ctx->vg_idx2, &ctx->vg_perm,
                       &ctx->vg_perm2, &ctx->vg_tmp, &ctx->vg_seg, &ctx->io_a, &ctx->io_b, &ctx->ds_ref,
                       &ctx->ds_tgt, &ctx->match_ref, &ctx->match_tgt,
-                      &ctx->partials, &ctx->corr_tmp_idx, &ctx->corr_tmp_d2, &ctx->d_state};
+                      &ctx->partials, &ctx->partials2, &ctx->corr_tmp_idx, &ctx->corr_tmp_d2, &ctx->d_state};
     for (DevBuf *b : bufs) b->release();
     for (auto &l : ctx->levels) {
         l.pts.release();
@@ -697,6 +880,9 @@ void wm_ctx_destroy(wm_ctx *ctx) {
     for (hipEvent_t e : ctx->ev_pool) (void) hipEventDestroy(e);
     if (ctx->ev_a) (void) hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) (void) hipEventDestroy(ctx->ev_b);
+    if (ctx->ev_fork) (void) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void) hipEventDestroy(ctx->ev_join);
+    if (ctx->side_stream) (void) hipStreamDestroy(ctx->side_stream);
     if (ctx->own_stream) (void) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -712,6 +898,11 @@ int wm_set_grid_cell(wm_ctx *ctx, float grid_cell) {
 
 int wm_cloud_sizes(const wm_ctx *ctx, size_t *n_source, size_t *n_target) {
     if (!ctx) return WM_ERR_ARG;
+    if (ctx->src_pending || ctx->tgt_pending) {  // counts of finite points: the pending reductions' results
+        wm_ctx *c = const_cast<wm_ctx *>(ctx);
+        WM_HIP(c, hipSetDevice(c->device));
+        WM_TRY(finalize_clouds(c));
+    }
     if (n_source) *n_source = ctx->n_src;
     if (n_target) *n_target = ctx->n_tgt;
     return WM_OK;
@@ -723,22 +914,19 @@ int wm_set_source(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem
     ctx->have_corr = false;
     ctx->n_src_input = n;
     ctx->n_src = 0;
+    ctx->src_pending = false;
     if (n == 0) return WM_OK;
-    // pack (caller order, kept for GICP's k-NN covariances), then Morton-order
+    // pack (caller order, kept for GICP's k-NN covariances) and launch the bounding-box reduction;
+    // the Morton order is produced by finalize_clouds once the box has been fetched
     ctx->gicp_cov_src_valid = false;
-    DevBuf &tmp = ctx->src_orig;
-    WM_HIP(ctx, tmp.reserve(n * sizeof(float4)));
+    WM_HIP(ctx, ctx->src_orig.reserve(n * sizeof(float4)));
     WM_HIP(ctx, ctx->src_sorted.reserve(n * sizeof(float4)));
+    WM_HIP(ctx, ctx->cloud_bbox.reserve(2 * 8 * sizeof(float) * kBboxBlocks));
     if (ctx->trace) fprintf(stderr, "[wm] set_source: n=%zu stride=%zu mem=%d ptr=%p\n", n, stride, mem, pts);
-    WM_TRY(pack_cloud(ctx, pts, n, stride, mem, tmp.as<float4>()));
+    WM_TRY(pack_cloud(ctx, pts, n, stride, mem, ctx->src_orig.as<float4>()));
     WM_TRACE(ctx, "set_source: packed");
-    Bbox &bb = ctx->src_bbox;
-    size_t valid = 0;
-    WM_TRY(compute_bbox(ctx, tmp.as<float4>(), n, &bb, &valid));
-    if (ctx->trace) fprintf(stderr, "[wm] set_source: bbox valid=%zu lo=(%g %g %g) hi=(%g %g %g)\n", valid, bb.lo[0], bb.lo[1], bb.lo[2], bb.hi[0], bb.hi[1], bb.hi[2]);
-    WM_TRY(morton_sort(ctx, tmp.as<float4>(), n, bb, valid, ctx->src_sorted.as<float4>()));
-    WM_TRACE(ctx, "set_source: sorted");
-    ctx->n_src = valid;
+    WM_TRY(launch_bbox(ctx, ctx->src_orig.as<float4>(), n, ctx->cloud_bbox.as<float>(), &ctx->src_bbox_blocks));
+    ctx->src_pending = true;
     return WM_OK;
 }
 
@@ -750,17 +938,19 @@ int wm_set_target(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem
     ctx->gicp_cov_tgt_valid = false;
     ctx->n_tgt_input = n;
     ctx->n_tgt = 0;
+    ctx->tgt_pending = false;
     for (auto &l : ctx->levels) l.built = false;
     ctx->n_levels = 0;
     ctx->levels_max_corr = -1;
     if (n == 0) return WM_OK;
     WM_HIP(ctx, ctx->tgt_orig.reserve(n * sizeof(float4)));
+    WM_HIP(ctx, ctx->cloud_bbox.reserve(2 * 8 * sizeof(float) * kBboxBlocks));
     WM_TRY(pack_cloud(ctx, pts, n, stride, mem, ctx->tgt_orig.as<float4>()));
-    size_t valid = 0;
-    WM_TRY(compute_bbox(ctx, ctx->tgt_orig.as<float4>(), n, &ctx->tgt_bbox, &valid));
-    ctx->n_tgt = valid;
-    // the search grid is built by the first caller that searches (ensure_levels in the ICP / GICP /
-    // search entry points): an NDT registration never needs it
+    WM_TRY(launch_bbox(ctx, ctx->tgt_orig.as<float4>(), n, ctx->cloud_bbox.as<float>() + 8 * kBboxBlocks,
+                       &ctx->tgt_bbox_blocks));
+    ctx->tgt_pending = true;
+    // the search grid is built by the first caller that searches (finalize_clouds / ensure_levels in
+    // the ICP / GICP / search entry points): an NDT registration never needs it
     return WM_OK;
 }
 
@@ -788,6 +978,7 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
         return ctx->n_tgt_input == 0 && ctx->n_src_input == 0 ? WM_ERR_STATE
                                                                : WM_TOO_FEW_CORRESPONDENCES;
     }
+    WM_TRY(finalize_clouds(ctx, p->max_corr, p->nn_method));
     if (ctx->n_src == 0 || ctx->n_tgt == 0) {
         if (stats) stats->state = WM_CONV_NO_CORRESPONDENCES;
         return WM_TOO_FEW_CORRESPONDENCES;
@@ -800,12 +991,12 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
     mat4_identity(I);
     const double prev = (p->carry_state && ctx->prev_mse >= 0) ? ctx->prev_mse : DBL_MAX;
     init_state(ctx->h_state, I, p, prev);
+    ctx->h_state->svd_warm = ctx->tune_fast_solve ? 1 : 0;
     WM_TRY(upload_state(ctx));
 
     const int max_it = p->force_iterations > 0 ? p->force_iterations : p->max_iter;
     const int nb = stat_blocks(ctx->n_src);
     ctx->iter_nn_ms.clear();
-    IcpDevState *dst = ctx->d_state.as<IcpDevState>();
     WM_HIP(ctx, hipEventRecord(ctx->ev_a, ctx->stream));
     int launched = 0;
     size_t ev_used = 0;
@@ -825,16 +1016,16 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
                     (void) get_event(ctx, ev_used - 1);
                 }
             }
+            unsigned rows = (unsigned) nb;
             if (brute) {
                 WM_TRY(launch_nn_brute(ctx, thr, e0, e1));
                 if (e1b) WM_HIP(ctx, hipEventRecord(e1b, ctx->stream));
+                WM_TRY(launch_stats(ctx, p->mode));
             } else {
-                WM_TRY(launch_nn_grid(ctx, thr, e0, e1, e1b));
+                WM_TRY(launch_search_and_stats(ctx, thr, p->mode, e0, e1, e1b, &rows));
             }
-            WM_TRY(launch_stats(ctx, p->mode));
             if (e2) WM_HIP(ctx, hipEventRecord(e2, ctx->stream));
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<3>), dim3(1), dim3(kBlock), 0,
-                               ctx->stream, ctx->partials.as<double>(), nb, dst, (double *) nullptr);
+            WM_TRY(launch_reduce_solve<3>(ctx, rows, nullptr));
             if (e3) WM_HIP(ctx, hipEventRecord(e3, ctx->stream));
         }
         WM_HIP(ctx, hipGetLastError());
@@ -992,6 +1183,7 @@ int wm_icp_shard_begin(wm_ctx *ctx, const wm_icp_params *p, double x_lo, double 
     if (!ctx || !p || !(p->max_corr > 0) || !(x_lo < x_hi)) return WM_ERR_ARG;
     if (ctx->n_src_input == 0) return WM_ERR_STATE;
     WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_TRY(finalize_clouds(ctx, p->max_corr, p->nn_method));
     WM_TRY(prepare_work(ctx));
     ctx->shard_brute = use_brute(ctx, p->nn_method) || ctx->n_tgt == 0;
     if (!ctx->shard_brute) WM_TRY(ensure_levels(ctx, p->max_corr));
@@ -1000,6 +1192,7 @@ int wm_icp_shard_begin(wm_ctx *ctx, const wm_icp_params *p, double x_lo, double 
     double I[16];
     mat4_identity(I);
     init_state(ctx->h_state, I, p, DBL_MAX);
+    ctx->h_state->svd_warm = ctx->tune_fast_solve ? 1 : 0;
     ctx->h_state->slab_on = 1;
     ctx->h_state->slab_lo = x_lo < -3.0e38 ? -INFINITY : (float) x_lo;
     ctx->h_state->slab_hi = x_hi > 3.0e38 ? INFINITY : (float) x_hi;
@@ -1025,29 +1218,24 @@ int wm_icp_shard_local_stats(wm_ctx *ctx, void *stats_dev) {
         e1 = get_event(ctx, 2 * k + 1);
         ctx->iter_nn_ms.push_back(-1.f);
     }
+    unsigned rows = 0;
     if (ctx->n_src > 0) {
-        if (ctx->shard_brute)
+        if (ctx->shard_brute) {
             WM_TRY(launch_nn_brute(ctx, ctx->shard_thr, e0, e1));
-        else
-            WM_TRY(launch_nn_grid(ctx, ctx->shard_thr, e0, e1, nullptr));
-        WM_TRY(launch_stats(ctx, ctx->shard_params.mode));
+            WM_TRY(launch_stats(ctx, ctx->shard_params.mode));
+            rows = (unsigned) stat_blocks(ctx->n_src);
+        } else {
+            WM_TRY(launch_search_and_stats(ctx, ctx->shard_thr, ctx->shard_params.mode, e0, e1, nullptr, &rows));
+        }
     }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<1>), dim3(1), dim3(kBlock), 0, ctx->stream,
-                       ctx->partials.as<double>(), ctx->n_src > 0 ? stat_blocks(ctx->n_src) : 0,
-                       ctx->d_state.as<IcpDevState>(), static_cast<double *>(stats_dev));
-    WM_HIP(ctx, hipGetLastError());
-    return WM_OK;
+    return launch_reduce_solve<1>(ctx, rows, static_cast<double *>(stats_dev));
 }
 
 int wm_icp_shard_apply(wm_ctx *ctx, const void *stats_dev) {
     if (!ctx || !stats_dev) return WM_ERR_ARG;
     if (!ctx->shard_active) return WM_ERR_STATE;
     WM_HIP(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<2>), dim3(1), dim3(kBlock), 0, ctx->stream,
-                       (const double *) nullptr, 0, ctx->d_state.as<IcpDevState>(),
-                       const_cast<double *>(static_cast<const double *>(stats_dev)));
-    WM_HIP(ctx, hipGetLastError());
-    return WM_OK;
+    return launch_reduce_solve<2>(ctx, 0, const_cast<double *>(static_cast<const double *>(stats_dev)));
 }
 
 int wm_icp_shard_poll(wm_ctx *ctx, int *done, double T_out[16], wm_icp_stats *stats) {
@@ -1105,6 +1293,7 @@ int wm_host_icp_create(wm_host_icp **out, const wm_icp_params *p, size_t expect_
     double I[16];
     mat4_identity(I);
     init_state(&h->st, I, p, DBL_MAX);
+    h->st.svd_warm = 1;
     h->st.expect_owned = (double) expect_owned_total;
     *out = h;
     return WM_OK;
@@ -1136,6 +1325,12 @@ int wm_host_icp_get(const wm_host_icp *h, int *done, double T_out[16], wm_icp_st
     return WM_OK;
 }
 
+int wm_debug_solve_cycles(wm_ctx *ctx, unsigned long long out[8]) {
+    if (!ctx || !out || !ctx->h_state) return WM_ERR_ARG;
+    for (int k = 0; k < 8; ++k) out[k] = ctx->h_state->dbg[k];
+    return WM_OK;
+}
+
 int wm_get_iteration_times(wm_ctx *ctx, float *nn_ms, int cap) {
     if (!ctx || !nn_ms || cap < 0) return 0;
     int n = (int) ctx->iter_nn_ms.size();
@@ -1156,6 +1351,7 @@ int wm_nn_search(wm_ctx *ctx, const double T[16], double max_corr, int nn_method
     if (!ctx || !T || !(max_corr > 0)) return WM_ERR_ARG;
     if (ctx->n_src_input == 0 || ctx->n_tgt_input == 0) return WM_ERR_STATE;
     WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_TRY(finalize_clouds(ctx, max_corr, nn_method & ~WM_NN_WARM));
     WM_TRY(prepare_work(ctx));
     const bool warm = (nn_method & WM_NN_WARM) && ctx->have_corr;
     nn_method &= ~WM_NN_WARM;
@@ -1190,10 +1386,7 @@ int wm_icp_stats_for(wm_ctx *ctx, const double T[16], int mode, double stats[WM_
     init_state(ctx->h_state, T, &p, DBL_MAX);
     WM_TRY(upload_state(ctx));
     WM_TRY(launch_stats(ctx, mode));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<1>), dim3(1), dim3(kBlock), 0, ctx->stream,
-                       ctx->partials.as<double>(), stat_blocks(ctx->n_src),
-                       ctx->d_state.as<IcpDevState>(), (double *) nullptr);
-    WM_HIP(ctx, hipGetLastError());
+    WM_TRY(launch_reduce_solve<1>(ctx, (unsigned) stat_blocks(ctx->n_src), nullptr));
     WM_TRY(download_state(ctx));
     memcpy(stats, ctx->h_state->stats, sizeof(double) * WM_STATS_LEN);
     return WM_OK;

@@ -17,6 +17,7 @@ namespace wm {
 constexpr int kMaxLevels = 6;
 constexpr int kBlock = 256;
 constexpr unsigned kNoIdx = 0xFFFFFFFFu;
+constexpr int kAcc = 18;  // ICP statistics per partial row: 17 sums + the number of source points this rank handled
 
 // ----------------------------------------------------------- error handling
 #define WM_HIP(ctx, call)                                                              \
@@ -108,6 +109,9 @@ struct IcpDevState {
     double rot_thr, trans_thr, fit_eps;
     unsigned queue_count[kMaxLevels + 1];
     unsigned long long deferred_total;
+    int svd_warm;      // warm-started SVD on (tune_fast_solve)
+    double svd_v[10];  // V of the last iteration's SVD (+ a valid flag): the next one starts from it
+    unsigned long long dbg[8];  // developer: cycle stamps of the last solve kernel (wm_debug_solve_cycles)
 };
 
 struct Bbox {
@@ -120,6 +124,14 @@ struct Bbox {
 struct wm_ctx {
     int device = 0;
     hipStream_t stream = nullptr, own_stream = nullptr;
+    hipStream_t side_stream = nullptr;      // the source's Morton sort runs here, beside the target's grid build
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // wm_set_source / wm_set_target only pack the cloud and LAUNCH its bounding-box reduction; the
+    // host fetches both results in one round trip when the first consumer needs them (finalize_clouds)
+    bool src_pending = false, tgt_pending = false;
+    unsigned src_bbox_blocks = 0, tgt_bbox_blocks = 0;
+    wm::DevBuf cloud_bbox;                  // [2][kBboxBlocks][8] floats: source slot, target slot
+    unsigned tuned_uses = 0;                // level-0 builds that trusted the cached cell size since the last check
     std::string last_error;
 
     // source (wave `ref`): Morton-ordered float4, .w = caller's index
@@ -146,7 +158,7 @@ struct wm_ctx {
     // scratch
     wm::DevBuf staging, cell_of, counts, block_sums, bbox_buf;
     wm::DevBuf match_pt, match_pt_bak;  // float4 per (sorted) source point: its match's xyz
-    wm::DevBuf keys, partials, corr_tmp_idx, corr_tmp_d2, d_levels;
+    wm::DevBuf keys, partials, partials2, corr_tmp_idx, corr_tmp_d2, d_levels;
     wm::DevBuf vg_idx, vg_idx2, vg_perm, vg_perm2, vg_tmp, vg_seg, io_a, io_b, ds_ref, ds_tgt, match_ref, match_tgt;
     wm::DevBuf d_state;
     wm::IcpDevState *h_state = nullptr;  // pinned
@@ -191,6 +203,10 @@ struct wm_ctx {
     int tune_xcd_chunk = 32;     // search kernel: XCDs take turns in chunks of this many workgroups (0: one eighth each)
     int tune_scan = 1;           // exclusive scans: rocPRIM look-back scan (1) or the three-kernel scan (0)
     int tune_xcd_reverse = 0;    // search kernel: hand the workgroups out back to front (experiment)
+    int tune_two_streams = 1;    // source Morton sort on a side stream beside the target's grid build
+    int tune_fuse_stats = 1;     // ICP statistics summed in the tail of the search kernel (0: separate k_icp_stats pass)
+    int tune_nn_waves = 1;       // wavefronts per workgroup of the fused search + statistics kernel (1, 4, 5, 10)
+    int tune_fast_solve = 1;     // experiment knob for the solve kernel
     int tune_spin_us = 80;       // wait_flag: busy-poll this long before polling with yields
     int tune_ndt_blocks = 1024;  // workgroups (= partial rows) of one NDT derivative pass
     int tune_gicp_blocks = 512;  // workgroups (= partial rows) of one GICP objective evaluation
@@ -210,6 +226,15 @@ namespace wm {
 // ---- wm_grid.hip
 int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, float4 *out);
 int compute_bbox(wm_ctx *ctx, const float4 *pts, size_t n, Bbox *out, size_t *n_valid);
+// the two halves of compute_bbox: enqueue the reduction into `partials_dev` (kBboxBlocks * 8 floats),
+// and finish it on the host from the fetched partials
+constexpr int kBboxBlocks = 512;
+int launch_bbox(wm_ctx *ctx, const float4 *pts, size_t n, float *partials_dev, unsigned *blocks_out);
+void finish_bbox(const float *partials_host, unsigned blocks, Bbox *out, size_t *n_valid);
+// Fetch what wm_set_source / wm_set_target left pending (bounding boxes, finite-point counts), then
+// Morton-sort the source on the side stream while -- when max_corr > 0 and the search will use the
+// grid -- the target's level ladder is built on the main stream; both are joined before returning.
+int finalize_clouds(wm_ctx *ctx, double max_corr = -1.0, int nn_method = 0);
 int build_grid_level(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, float h,
                      GridLevel *lvl, double *avg_occupancy);
 int morton_sort(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, size_t n_valid,
@@ -252,7 +277,10 @@ int voxel_downsample_dev(wm_ctx *ctx, const float4 *in, size_t n, float leaf, fl
 int transform_cloud_dev(wm_ctx *ctx, const float4 *in, size_t n, const double T[16], float4 *out);
 
 // ---- wm_nn.hip
-int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2);
+// stats_mode < 0: search only; WM_ICP_SVD / WM_ICP_GN6: the search kernel also reduces the ICP
+// statistics of the iteration to *rows_out rows of kAcc doubles in ctx->partials
+int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2,
+                   int stats_mode = -1, unsigned *rows_out = nullptr);
 int launch_nn_brute(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1);
 float threshold_d2(double max_corr);
 float threshold_d2_strict(double max_corr);

@@ -50,6 +50,31 @@ WM_HD double det3(const double *m) {
 // compile-time indices only (every loop fully unrolled) so that on the GPU the
 // working set lives in registers, not scratch.
 namespace detail {
+// 1 / sqrt(x) and 1 / x for x well inside the normal range.  On the GPU these run in ONE lane of the
+// solve kernel, where a correctly rounded f64 division or square root is a ~60-instruction dependent
+// chain (scale, estimate, refine, fix up): the hardware estimate plus two Newton steps gives full
+// double precision in a dozen.  A Jacobi rotation does not need more (any (c, s) with
+// c^2 + s^2 = 1 to rounding is a valid rotation; t only steers convergence).
+WM_HD double fast_rsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - (0.5 * x) * (y * y));
+    y = y * (1.5 - (0.5 * x) * (y * y));
+    return y;
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
+WM_HD double fast_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(x);
+    y = y * (2.0 - x * y);
+    y = y * (2.0 - x * y);
+    return y;
+#else
+    return 1.0 / x;
+#endif
+}
 template <int I, int J>
 WM_HD bool jacobi_pair(double *W, double *V) {
     double alpha = 0, beta = 0, gamma = 0;
@@ -63,11 +88,20 @@ WM_HD bool jacobi_pair(double *W, double *V) {
     if (fabs(gamma) <= 1e-300 || gamma * gamma <= (2.3e-16 * 2.3e-16) * (alpha * beta)) return false;
     // tan of the rotation angle, smaller root: with zeta = (beta - alpha) / (2 gamma),
     //   t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) = sign(d g) |g| / (|d| + sqrt(d^2 + g^2)),
-    // d = beta - alpha, g = 2 gamma -- one square root and one division instead of two and two
-    // (this runs in a single GPU lane: every f64 division / root is a few hundred cycles)
+    // d = beta - alpha, g = 2 gamma
     const double d = beta - alpha, g = 2.0 * gamma;
-    const double t = ((d >= 0) == (g >= 0) ? fabs(g) : -fabs(g)) / (fabs(d) + sqrt(d * d + g * g));
-    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+    const double h2 = d * d + g * g;
+    double t, c;
+    if (h2 > 1e-280 && h2 < 1e280) {
+        const double hyp = h2 * fast_rsqrt(h2);
+        const double ta = fabs(g) * fast_rcp(fabs(d) + hyp);
+        t = ((d >= 0) == (g >= 0)) ? ta : -ta;
+        c = fast_rsqrt(1.0 + t * t);
+    } else {  // far out of range: the slow, scale-safe forms
+        t = ((d >= 0) == (g >= 0) ? fabs(g) : -fabs(g)) / (fabs(d) + sqrt(d * d + g * g));
+        c = 1.0 / sqrt(1.0 + t * t);
+    }
+    const double s = c * t;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const double wi = W[k * 3 + I], wj = W[k * 3 + J];
@@ -98,12 +132,25 @@ WM_HD void swap_cols_if_less(double *sv, double *W, double *V) {  // ensure sv[I
 }
 }  // namespace detail
 
-WM_HD void svd3(const double *A, double *U, double *S, double *V) {
+// V0 (may be null): an orthogonal matrix to start from -- the V of a nearby matrix's SVD (the
+// previous ICP iteration's): the columns of A V0 are then almost orthogonal already and one sweep
+// plus the checking sweep do, instead of five or six.
+WM_HD void svd3(const double *A, double *U, double *S, double *V, const double *V0 = nullptr) {
     double W[9];
+    if (V0) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        W[i] = A[i];
-        V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        for (int i = 0; i < 9; ++i) V[i] = V0[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                W[i * 3 + j] = A[i * 3] * V0[j] + A[i * 3 + 1] * V0[3 + j] + A[i * 3 + 2] * V0[6 + j];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            W[i] = A[i];
+            V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        }
     }
     for (int sweep = 0; sweep < 60; ++sweep) {
         bool r0 = detail::jacobi_pair<0, 1>(W, V);
@@ -113,7 +160,10 @@ WM_HD void svd3(const double *A, double *U, double *S, double *V) {
     }
     double sv[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) sv[j] = sqrt(W[j] * W[j] + W[3 + j] * W[3 + j] + W[6 + j] * W[6 + j]);
+    for (int j = 0; j < 3; ++j) {
+        const double n2 = W[j] * W[j] + W[3 + j] * W[3 + j] + W[6 + j] * W[6 + j];
+        sv[j] = (n2 > 1e-280 && n2 < 1e280) ? n2 * detail::fast_rsqrt(n2) : sqrt(n2);
+    }
     detail::swap_cols_if_less<0, 1>(sv, W, V);
     detail::swap_cols_if_less<0, 2>(sv, W, V);
     detail::swap_cols_if_less<1, 2>(sv, W, V);
@@ -121,12 +171,15 @@ WM_HD void svd3(const double *A, double *U, double *S, double *V) {
     const bool h0 = (sv[0] > 1e-300);
     const bool h1 = h0 && (sv[1] > 1e-300 && sv[1] > 1e-14 * smax);
     const bool h2 = h1 && (sv[2] > 1e-300 && sv[2] > 1e-14 * smax);
+    // (one reciprocal per column, not one division per entry: this runs in a single GPU lane)
+    const double i0 = h0 ? detail::fast_rcp(sv[0]) : 0.0, i1 = h1 ? detail::fast_rcp(sv[1]) : 0.0,
+                 i2 = h2 ? detail::fast_rcp(sv[2]) : 0.0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         S[k] = sv[k];
-        U[k * 3 + 0] = h0 ? W[k * 3 + 0] / sv[0] : 0.0;
-        U[k * 3 + 1] = h1 ? W[k * 3 + 1] / sv[1] : 0.0;
-        U[k * 3 + 2] = h2 ? W[k * 3 + 2] / sv[2] : 0.0;
+        U[k * 3 + 0] = W[k * 3 + 0] * i0;
+        U[k * 3 + 1] = W[k * 3 + 1] * i1;
+        U[k * 3 + 2] = W[k * 3 + 2] * i2;
     }
     if (!h0) {  // zero matrix
 #pragma unroll
@@ -284,19 +337,27 @@ WM_HD void rodrigues(const double *w, double *R) {
 // sigma = (1/n) sum (q-qm)(p-pm)^T = Sqp/n - qm pm^T; R = U diag(1,1,det(U)det(V)) V^T;
 // t = qm - R pm.  [PCL registration/impl/transformation_estimation_svd.hpp ->
 // Eigen/src/Geometry/Umeyama.h], driven by wave_matching/src/icp.cpp:126.
-WM_HD void umeyama_from_stats(const double *st, double *T) {
+// Vwarm (may be null): in, an orthogonal starting basis for the SVD (see svd3) unless Vwarm[9]
+// is 0; out, this call's V and Vwarm[9] = 1.
+WM_HD void umeyama_from_stats(const double *st, double *T, double *Vwarm = nullptr) {
     const double n = st[kSvdN];
     double pm[3], qm[3], sigma[9], U[9], S[3], V[9], R[9];
+    const double one_over_n = 1.0 / n;  // as Eigen's umeyama does (means and sigma are scaled by it)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        pm[i] = st[kSvdSp + i] / n;
-        qm[i] = st[kSvdSq + i] / n;
+        pm[i] = st[kSvdSp + i] * one_over_n;
+        qm[i] = st[kSvdSq + i] * one_over_n;
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) sigma[i * 3 + j] = st[kSvdSqp + i * 3 + j] / n - qm[i] * pm[j];
-    svd3(sigma, U, S, V);
+        for (int j = 0; j < 3; ++j) sigma[i * 3 + j] = st[kSvdSqp + i * 3 + j] * one_over_n - qm[i] * pm[j];
+    svd3(sigma, U, S, V, (Vwarm && Vwarm[9] != 0.0) ? Vwarm : nullptr);
+    if (Vwarm) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Vwarm[i] = V[i];
+        Vwarm[9] = 1.0;
+    }
     const double s2 = (det3(U) * det3(V) < 0) ? -1.0 : 1.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i)

@@ -1094,6 +1094,7 @@ int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *prm, double T_out[16], wm_ndt
     if (stats) memset(stats, 0, sizeof(*stats));
     if (ctx->n_src_input == 0 || ctx->n_tgt_input == 0) return WM_ERR_STATE;
     WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_TRY(finalize_clouds(ctx));
     WM_HIP(ctx, ctx->partials.reserve((size_t) kNdtBlocks * kNdtAcc * sizeof(double)));
     if (!ctx->ndt_built || ctx->ndt_res != prm->res) WM_TRY(ndt_build(ctx, prm->res));
     NdtEval E;
@@ -1157,6 +1158,7 @@ int wm_ndt_derivatives(wm_ctx *ctx, const wm_ndt_params *prm, const double pose[
     if (!ctx || !prm || !pose || !score || !(prm->res > 0)) return WM_ERR_ARG;
     if (ctx->n_src_input == 0 || ctx->n_tgt_input == 0) return WM_ERR_STATE;
     WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_TRY(finalize_clouds(ctx));
     WM_HIP(ctx, ctx->partials.reserve((size_t) kNdtBlocks * kNdtAcc * sizeof(double)));
     if (!ctx->ndt_built || ctx->ndt_res != prm->res) WM_TRY(ndt_build(ctx, prm->res));
     NdtEval E;

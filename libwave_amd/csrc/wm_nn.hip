@@ -348,6 +348,48 @@ __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, fl
     return wave_min_u64(mine);
 }
 
+// ------------------------------------------------- fused ICP statistics
+// The search kernel ends with every lane holding its query (under the current pose), its
+// match and d2 -- exactly what the statistics of the ICP step are summed from (wm_icp.hip:
+// n, sum p, sum q, sum q p^T, sum d2 | GN: n, sum p, A^T A, J^T r, sum d2; + the number of
+// points this rank handled).  Summing them here deletes a 40 MB stream and a launch per iteration.
+//
+// Wave reduction of kAcc doubles by recursive halving: at the step for lane bit M a lane keeps one
+// half of its values and sends the other half to lane ^ M, so the 18 values cost 9+5+3+2+1+1 = 21
+// exchanges instead of 18 x 6.  The order of the additions is fixed by the lane numbers: the sums
+// are bit-reproducible.  Afterwards component k sits in v[0] of the one lane acc_comp_of_lane()
+// names (bit 0 clear; the other lanes hold padding zeros).
+template <int C, int M>
+__device__ __forceinline__ void acc_halve(double (&v)[kAcc], unsigned lane) {
+    constexpr int H = (C + 1) / 2;
+    const bool up = (lane & (unsigned) M) != 0u;
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        const double lo = v[i];
+        const double hi = (H + i < C) ? v[H + i] : 0.0;
+        const double send = up ? lo : hi, keep = up ? hi : lo;
+        v[i] = keep + __shfl_xor(send, M);
+    }
+    if constexpr (M > 1) acc_halve<H, M / 2>(v, lane);
+}
+__device__ __forceinline__ int acc_comp_of_lane(unsigned lane) {
+    // follows acc_halve's (static) array sizes 18 -> 9 -> 5 -> 3 -> 2 -> 1 -> 1; `valid` = how many
+    // leading entries of this lane's array are real components (the rest is zero padding)
+    int c = kAcc, base = 0, valid = kAcc;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        const int h = (c + 1) / 2;
+        if (lane & (unsigned) m) {
+            base += h;
+            valid -= h;
+        } else {
+            valid = valid < h ? valid : h;
+        }
+        c = h;
+    }
+    return valid >= 1 ? base : -1;
+}
+
 // One lane per query: a certified radius search over a ladder of uniform grids
 // (cell size x2 per level).
 //   r <- the distance, under the NEW pose, to the point this query matched in the previous
@@ -362,20 +404,26 @@ __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, fl
 // query's own lane (scan_box).  Longer ones are handed to the whole wavefront, one query at a
 // time (coop_scan_box), seeded with the radius its Morton neighbour needed.
 // The radius, level and pruning choices change the work, never the result.
-constexpr int kNnBlock = 64;  // one wave per block: finest dispatch granularity, smallest tail
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5)))
+// W wavefronts per workgroup, each with its own 64 queries and its own run list (the waves never
+// talk to each other during the search).  STATS < 0: search only, one wave per workgroup (finest
+// dispatch granularity, smallest tail).  STATS = WM_ICP_SVD / WM_ICP_GN6: the workgroup also
+// reduces the ICP statistics of its 64 W queries to ONE row of `partials` ([gridDim.x][kAcc]; W
+// waves per workgroup keep the number of rows the solve kernel has to add up small).
+template <int W, int STATS>
+__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5, 5)))
     k_nn_grid(const LevelsDev *__restrict__ lv, const float4 *__restrict__ src, unsigned n,
               IcpDevState *__restrict__ st, float thr_d2, unsigned long long *__restrict__ keys,
               float4 *__restrict__ match_pt, const float4 *__restrict__ tgt_orig,
-              float r_light_cells, float lane_lf, float coop_lf, unsigned xcd_chunk) {
+              float r_light_cells, float lane_lf, float coop_lf, unsigned xcd_chunk,
+              double *__restrict__ partials) {
     if (st->done) return;
-    static_assert(kNnBlock == 64, "the run list is indexed by lane: one wavefront per workgroup");
-    __shared__ uint2 s_runs[kRowChunk * kNnBlock];  // [run][lane]: each lane's pending runs
+    __shared__ uint2 s_runs_all[W * kRowChunk * 64];  // per wave [run][lane]: each lane's pending runs
+    uint2 *s_runs = s_runs_all + (threadIdx.x >> 6) * (kRowChunk * 64);
     const bool rev = (xcd_chunk >> 31) != 0u;  // experiment: hand the queries out back to front
     const unsigned chunk_sz = xcd_chunk & 0x7FFFFFFFu;
     const unsigned bidx = rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
-    const unsigned i = (chunk_sz ? xcd_remap_chunked(bidx, chunk_sz) : xcd_remap(bidx, gridDim.x)) * blockDim.x +
-                       threadIdx.x;
+    const unsigned row = chunk_sz ? xcd_remap_chunked(bidx, chunk_sz) : xcd_remap(bidx, gridDim.x);
+    const unsigned i = row * blockDim.x + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
     const bool active = i < n;
     const int L = lv->n;
@@ -483,6 +531,66 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 
         match_pt[i] = make_float4(bqx, bqy, bqz, 0.f);
     }
     if (lane == 0 && n_heavy) atomicAdd(&st->queue_count[1], n_heavy);  // stats only
+    if constexpr (STATS >= 0) {
+        // this lane's terms (same arithmetic as k_icp_stats, wm_icp.hip)
+        double a[kAcc];
+#pragma unroll
+        for (int k = 0; k < kAcc; ++k) a[k] = 0.0;
+        if (mine) {
+            a[17] = 1.0;
+            if ((unsigned) best != kNoIdx) {
+                const double px = qx, py = qy, pz = qz, tx = bqx, ty = bqy, tz = bqz;
+                a[0] = 1.0;
+                a[1] = px;
+                a[2] = py;
+                a[3] = pz;
+                if constexpr (STATS == WM_ICP_SVD) {
+                    a[4] = tx;
+                    a[5] = ty;
+                    a[6] = tz;
+                    a[7] = tx * px;
+                    a[8] = tx * py;
+                    a[9] = tx * pz;
+                    a[10] = ty * px;
+                    a[11] = ty * py;
+                    a[12] = ty * pz;
+                    a[13] = tz * px;
+                    a[14] = tz * py;
+                    a[15] = tz * pz;
+                } else {
+                    const double rx = px - tx, ry = py - ty, rz = pz - tz;
+                    a[4] = py * py + pz * pz;
+                    a[5] = -px * py;
+                    a[6] = -px * pz;
+                    a[7] = px * px + pz * pz;
+                    a[8] = -py * pz;
+                    a[9] = px * px + py * py;
+                    a[10] = rx;
+                    a[11] = ry;
+                    a[12] = rz;
+                    a[13] = py * rz - pz * ry;
+                    a[14] = pz * rx - px * rz;
+                    a[15] = px * ry - py * rx;
+                }
+                a[16] = (double) __uint_as_float((unsigned) (best >> 32));
+            }
+        }
+        acc_halve<kAcc, 32>(a, lane);
+        const int comp = acc_comp_of_lane(lane);
+        if constexpr (W == 1) {
+            if (comp >= 0) partials[(size_t) row * kAcc + comp] = a[0];
+        } else {
+            __shared__ double s_part[W][kAcc];
+            if (comp >= 0) s_part[threadIdx.x >> 6][comp] = a[0];
+            __syncthreads();
+            if (threadIdx.x < kAcc) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < W; ++w) t += s_part[w][threadIdx.x];
+                partials[(size_t) row * kAcc + threadIdx.x] = t;
+            }
+        }
+    }
 }
 
 // ----------------------------------------------------------- brute force
@@ -558,26 +666,56 @@ float threshold_d2_strict(double max_corr) {
     return f;
 }
 
-int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2) {
+template <int W, int STATS>
+static void launch_nn_grid_t(wm_ctx *ctx, unsigned blocks, float thr_d2, unsigned xcd_chunk) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_grid<W, STATS>), dim3(blocks), dim3(64 * W), 0, ctx->stream,
+                       ctx->d_levels.as<LevelsDev>(), ctx->src_sorted.as<float4>(), (unsigned) ctx->n_src,
+                       ctx->d_state.as<IcpDevState>(), thr_d2, ctx->keys.as<unsigned long long>(),
+                       ctx->match_pt.as<float4>(), ctx->tgt_orig.as<float4>(), ctx->tune_r_light,
+                       ctx->tune_lane_lf, ctx->tune_coop_lf, xcd_chunk, ctx->partials.as<double>());
+}
+
+// stats_mode < 0: search only.  WM_ICP_SVD / WM_ICP_GN6: the search kernel also leaves the ICP
+// statistics of this iteration as *rows_out rows of kAcc doubles in ctx->partials.
+int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2,
+                   int stats_mode, unsigned *rows_out) {
     const unsigned n = (unsigned) ctx->n_src;
+    if (rows_out) *rows_out = 0;
     if (n == 0) return WM_OK;
-    IcpDevState *st = ctx->d_state.as<IcpDevState>();
-    unsigned long long *keys = ctx->keys.as<unsigned long long>();
-    const unsigned nb = (unsigned) kNnBlock;  // one wave per workgroup (its LDS run list is sized for that)
+    // waves per workgroup: 1 for a plain search; the fused statistics want few partial rows
+    int W = 1;
+    if (stats_mode >= 0) {
+        W = ctx->tune_nn_waves;
+        if (stats_mode != WM_ICP_SVD || (W != 1 && W != 5 && W != 10)) W = 4;
+    }
+    const unsigned nb = 64u * (unsigned) W;
     unsigned blocks = (n + nb - 1) / nb;
     blocks = (blocks + 7u) & ~7u;  // xcd_remap needs a multiple of 8
     unsigned xcd_chunk = 0;
-    if (ctx->tune_xcd_chunk > 0 && blocks >= 32u * (unsigned) ctx->tune_xcd_chunk) {
-        // the chunked remap (big grids only: it pads the grid to a multiple of 8 chunks)
-        xcd_chunk = (unsigned) ctx->tune_xcd_chunk;
+    // the chunked remap (big grids only: it pads the grid to a multiple of 8 chunks); a chunk is
+    // tune_xcd_chunk x 64 consecutive queries whatever the workgroup size
+    const unsigned chunk_blocks = ctx->tune_xcd_chunk > 0 ? ((unsigned) ctx->tune_xcd_chunk + W - 1) / W : 0u;
+    if (chunk_blocks > 0 && blocks >= 32u * chunk_blocks) {
+        xcd_chunk = chunk_blocks;
         const unsigned m = 8u * xcd_chunk;
         blocks = (blocks + m - 1u) / m * m;
     }
+    if (stats_mode >= 0) {
+        WM_HIP(ctx, ctx->partials.reserve((size_t) blocks * kAcc * sizeof(double)));
+        if (rows_out) *rows_out = blocks;
+    }
+    xcd_chunk |= ctx->tune_xcd_reverse ? 0x80000000u : 0u;
     if (ev0) WM_HIP(ctx, hipEventRecord(ev0, ctx->stream));
-    hipLaunchKernelGGL(k_nn_grid, dim3(blocks), dim3(nb), 0, ctx->stream,
-                       ctx->d_levels.as<LevelsDev>(), ctx->src_sorted.as<float4>(), n, st, thr_d2,
-                       keys, ctx->match_pt.as<float4>(), ctx->tgt_orig.as<float4>(), ctx->tune_r_light, ctx->tune_lane_lf, ctx->tune_coop_lf,
-                       xcd_chunk | (ctx->tune_xcd_reverse ? 0x80000000u : 0u));
+    if (stats_mode < 0)
+        launch_nn_grid_t<1, -1>(ctx, blocks, thr_d2, xcd_chunk);
+    else if (stats_mode == WM_ICP_SVD) {
+        if (W == 4) launch_nn_grid_t<4, WM_ICP_SVD>(ctx, blocks, thr_d2, xcd_chunk);
+        else if (W == 1) launch_nn_grid_t<1, WM_ICP_SVD>(ctx, blocks, thr_d2, xcd_chunk);
+        else if (W == 5) launch_nn_grid_t<5, WM_ICP_SVD>(ctx, blocks, thr_d2, xcd_chunk);
+        else launch_nn_grid_t<10, WM_ICP_SVD>(ctx, blocks, thr_d2, xcd_chunk);
+    } else {
+        launch_nn_grid_t<4, WM_ICP_GN6>(ctx, blocks, thr_d2, xcd_chunk);
+    }
     if (ev1) WM_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     if (ev2) WM_HIP(ctx, hipEventRecord(ev2, ctx->stream));
     WM_HIP(ctx, hipGetLastError());
