@@ -189,6 +189,12 @@ int wm_get_iteration_times(wm_ctx *ctx, float *nn_ms, int cap);
 /* Developer aid: shader-clock stamps of the last solve kernel of the last align (start, rows
  * added, statistics expanded, solve + stopping rules done). */
 int wm_debug_solve_cycles(wm_ctx *ctx, unsigned long long out[8]);
+/* Developer aid: per-query work of the grid search.  out == NULL arms the log for the first
+ * `iterations` iterations of the next wm_icp_align on the current clouds (0 disarms and frees it);
+ * out != NULL copies the log ([iteration][query in Morton order]: trips of the candidate loop in
+ * bits 0-15, row chunks in bits 16-23, scan passes in bits 24-30, bit 31 = handed to the
+ * wave-cooperative path) and returns the number of iterations recorded. */
+int wm_debug_cost_log(wm_ctx *ctx, int iterations, unsigned *out, size_t cap);
 
 /* PCL's icp.correspondences_ after align (read by estimateLUM / estimateCensi,
  * icp_pcl_functions.cpp:191, icp.cpp:213): per source point (caller's order)

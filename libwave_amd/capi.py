@@ -138,6 +138,7 @@ def lib():
         L.wm_ndt_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]
         L.wm_get_iteration_times.argtypes = [C.c_void_p, _fp, C.c_int]
         L.wm_debug_solve_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.wm_debug_cost_log.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.wm_get_correspondences.argtypes = [C.c_void_p, _ip, _fp, C.c_size_t]
         L.wm_nn_search.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int, _ip, _fp, C.c_size_t, _fp]
         L.wm_icp_stats_for.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
@@ -418,6 +419,16 @@ class Context:
         d["T"] = T
         d["done"] = bool(done.value)
         return d
+
+    def cost_log_arm(self, iterations):
+        self._check(lib().wm_debug_cost_log(self._h, iterations, None, 0), "wm_debug_cost_log")
+
+    def cost_log_fetch(self, iterations, n):
+        buf = np.zeros((iterations, n), np.uint32)
+        k = lib().wm_debug_cost_log(self._h, iterations, buf.ctypes.data_as(C.c_void_p), buf.size)
+        if k < 0:
+            raise WmError("wm_debug_cost_log: %d" % k)
+        return buf[:k]
 
     def solve_cycles(self):
         buf = (C.c_uint64 * 8)()

@@ -814,7 +814,7 @@ int wm_ctx_create(wm_ctx **out, int device) {
     if (const char *e = getenv("WM_TUNE_SCAN")) ctx->tune_scan = atoi(e);
     if (const char *e = getenv("WM_TUNE_TWO_STREAMS")) ctx->tune_two_streams = atoi(e);
     if (const char *e = getenv("WM_TUNE_FUSE_STATS")) ctx->tune_fuse_stats = atoi(e);
-    if (const char *e = getenv("WM_TUNE_NN_WAVES")) ctx->tune_nn_waves = atoi(e);
+    if (const char *e = getenv("WM_TUNE_NN_BALANCED")) ctx->tune_nn_balanced = atoi(e);
     if (const char *e = getenv("WM_TUNE_FAST_SOLVE")) ctx->tune_fast_solve = atoi(e);
     if (const char *e = getenv("WM_TUNE_XCD_CHUNK")) ctx->tune_xcd_chunk = atoi(e);
     if (const char *e = getenv("WM_TUNE_RADIX_MIN")) ctx->tune_radix_min = atoi(e);
@@ -866,7 +866,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
                       &ctx->src_grid.cell_start, &ctx->vg_idx, &ctx->vg_idx2, &ctx->vg_perm,
                       &ctx->vg_perm2, &ctx->vg_tmp, &ctx->vg_seg, &ctx->io_a, &ctx->io_b, &ctx->ds_ref,
                       &ctx->ds_tgt, &ctx->match_ref, &ctx->match_tgt,
-                      &ctx->partials, &ctx->partials2, &ctx->corr_tmp_idx, &ctx->corr_tmp_d2, &ctx->d_state};
+                      &ctx->partials, &ctx->partials2, &ctx->cost_log, &ctx->corr_tmp_idx, &ctx->corr_tmp_d2, &ctx->d_state};
     for (DevBuf *b : bufs) b->release();
     for (auto &l : ctx->levels) {
         l.pts.release();
@@ -1323,6 +1323,28 @@ int wm_host_icp_get(const wm_host_icp *h, int *done, double T_out[16], wm_icp_st
         stats->owned_violations = h->st.owned_violations;
     }
     return WM_OK;
+}
+
+int wm_debug_cost_log(wm_ctx *ctx, int iterations, unsigned *out, size_t cap) {
+    if (!ctx || iterations < 0) return WM_ERR_ARG;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    if (!out) {  // arm: the next align records the search cost of its first `iterations` iterations
+        WM_TRY(finalize_clouds(ctx));
+        if (iterations == 0) {
+            WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->cost_log.release();
+            ctx->cost_log_cap = 0;
+            return WM_OK;
+        }
+        WM_HIP(ctx, ctx->cost_log.reserve((size_t) iterations * (ctx->n_src > 0 ? ctx->n_src : 1) * 4));
+        ctx->cost_log_iter = 0;
+        ctx->cost_log_cap = iterations;
+        return WM_OK;
+    }
+    const size_t need = (size_t) ctx->cost_log_iter * ctx->n_src;
+    if (cap < need) return WM_ERR_ARG;
+    WM_TRY(copy_to_caller(ctx, out, ctx->cost_log.p, need * 4));
+    return ctx->cost_log_iter;
 }
 
 int wm_debug_solve_cycles(wm_ctx *ctx, unsigned long long out[8]) {

@@ -158,6 +158,8 @@ struct wm_ctx {
     // scratch
     wm::DevBuf staging, cell_of, counts, block_sums, bbox_buf;
     wm::DevBuf match_pt, match_pt_bak;  // float4 per (sorted) source point: its match's xyz
+    wm::DevBuf cost_log;                    // developer: per-query search cost of every iteration (wm_debug_cost_log)
+    int cost_log_iter = 0, cost_log_cap = 0;
     wm::DevBuf keys, partials, partials2, corr_tmp_idx, corr_tmp_d2, d_levels;
     wm::DevBuf vg_idx, vg_idx2, vg_perm, vg_perm2, vg_tmp, vg_seg, io_a, io_b, ds_ref, ds_tgt, match_ref, match_tgt;
     wm::DevBuf d_state;
@@ -205,7 +207,7 @@ struct wm_ctx {
     int tune_xcd_reverse = 0;    // search kernel: hand the workgroups out back to front (experiment)
     int tune_two_streams = 1;    // source Morton sort on a side stream beside the target's grid build
     int tune_fuse_stats = 1;     // ICP statistics summed in the tail of the search kernel (0: separate k_icp_stats pass)
-    int tune_nn_waves = 1;       // wavefronts per workgroup of the fused search + statistics kernel (1, 4, 5, 10)
+    int tune_nn_balanced = 1;    // search kernel: wave-pooled candidate trips (0: every lane walks its own)
     int tune_fast_solve = 1;     // experiment knob for the solve kernel
     int tune_spin_us = 80;       // wait_flag: busy-poll this long before polling with yields
     int tune_ndt_blocks = 1024;  // workgroups (= partial rows) of one NDT derivative pass

@@ -114,10 +114,11 @@ __device__ __forceinline__ unsigned long long scan_run(const float4 *__restrict_
 // Pruning changes the work, never the result.
 constexpr int kRowChunk = 6;
 constexpr int kLayeredRows = 18;  // boxes with more (y,z) rows than this are walked layer by layer
+template <bool COST>
 __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float qx, float qy,
                                                        float qz, float r, unsigned long long best,
                                                        float *margin, uint2 *runs, unsigned lane,
-                                                       bool allow_layered) {
+                                                       bool allow_layered, unsigned &cost) {
     const float big = 4.0e6f;  // clamp in float so far-away queries cannot overflow the int cast
     const float fx = fminf(fmaxf((qx - g.ox) * g.inv_h, -big), big);
     const float fy = fminf(fmaxf((qy - g.oy) * g.inv_h, -big), big);
@@ -150,6 +151,7 @@ __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float q
         // past a run's end are harmless, see scan_run).  No barrier: a lane only reads back
         // what it wrote itself, and LDS operations of one wave execute in order.
         unsigned cnt = 0;
+        if constexpr (COST) cost += 1u << 16;  // (developer statistics: chunks in bits 16-23, trips below)
 #pragma unroll
         for (int u = 0; u < kRowChunk; ++u)
             if (re[u] > rs[u]) runs[cnt++ * 64u + lane] = make_uint2(rs[u], re[u]);
@@ -172,6 +174,7 @@ __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float q
             const unsigned long long m = a < b ? a : b;
             best = m < best ? m : best;
             j += 4;
+            if constexpr (COST) cost += 1u;
             if (j >= e && ++idx < cnt) {
                 const uint2 run = runs[idx * 64u + lane];
                 j = run.x;
@@ -269,6 +272,201 @@ __device__ __forceinline__ float rl_f(float v, int lane) {
 }
 __device__ __forceinline__ unsigned rl_u(unsigned v, int lane) {
     return (unsigned) __builtin_amdgcn_readlane((int) v, lane);
+}
+
+// ------------------------------------------------- balanced walk (wave-level work sharing)
+// The lane scan above makes a wavefront wait for its slowest lane: in the aligned state a query
+// needs 3.3 trips of the candidate loop on average but the slowest of 64 needs 8.4 (measured:
+// scripts/dev/dev_cost_model.py), so 60 % of the lanes idle through the loop that is most of the
+// kernel -- on the vector ALU and on the L1 address path alike.  Here the wavefront pools the work
+// instead: every lane lists its trips (four consecutive points of one of its runs) in LDS, and
+// all 64 lanes then take trips off the pooled list, whoever's they are -- ceil(sum / 64) rounds
+// instead of max-over-lanes.  A trip's result goes to its query's slot by an LDS atomic min on
+// the 64-bit key, so the order in which candidates are seen still does not matter: same results.
+// This needs all control flow around the walk to be wave-uniform (a lane that has finished its
+// own search keeps working on the others'): the pass and row loops run while ANY lane has work,
+// and a lane without work contributes empty rows.
+constexpr int kBalCap = 1024;  // pooled trips per chunk of rows; beyond that (rare) every lane walks its own
+// rows per chunk of the balanced walk: 2 / 3 / 4 / 6 / 8 / 12 rows measured 73.1 / 70.8 / 72.7 / 73.5 /
+// 79.5 / 101 us per launch on the 1M pair (more rows per chunk = more registers and, with the walk
+// balanced anyway, nothing gained from batching more look-ups)
+constexpr int kBalRowChunk = 3;
+struct BalLds {                // per wavefront
+    unsigned items[kBalCap + 1];    // (owner lane << 26) | offset of the trip's first point; [kBalCap] = dump slot
+    float4 q[64];                   // the queries
+    unsigned long long base[64];    // address of the point array (level) each query scans
+    unsigned long long best[64];    // running arg-min per query
+};
+
+// inclusive prefix sum over the 64 lanes (DPP row shifts inside rows of 16, then the row totals
+// are broadcast into the following rows: no LDS traffic, six dependent VALU steps)
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
+    v += (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v += (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// ubase: the point array all live lanes scan when they are on the same level (the usual case),
+// nullptr when the levels differ (then L.base[owner] says which)
+template <bool COST, int RC>
+__device__ __forceinline__ void balanced_walk(BalLds &L, const unsigned (&rs)[RC],
+                                              const unsigned (&re)[RC], unsigned lane,
+                                              const float4 *pts, const float4 *ubase, float qx, float qy,
+                                              float qz, unsigned long long &best, unsigned &cost) {
+    unsigned len[RC], t = 0, longest = 0;
+#pragma unroll
+    for (int u = 0; u < RC; ++u) {
+        len[u] = (unsigned) max((int) (re[u] - rs[u]), 0);
+        t += (len[u] + 3u) >> 2;
+        longest = max(longest, len[u]);
+    }
+    const unsigned incl = wave_incl_scan(t);
+    const unsigned T = rl_u(incl, 63);
+    if (T == 0u) return;  // (wave-uniform)
+    if constexpr (COST) cost += t;
+    if (T > (unsigned) kBalCap) {  // too much for the list: every lane for itself
+#pragma unroll
+        for (int u = 0; u < RC; ++u) best = scan_run(pts, rs[u], re[u], qx, qy, qz, best);
+        return;
+    }
+    unsigned off = incl - t;
+    const unsigned tag = lane << 26;
+    if (__ballot(longest > 8u) == 0ull) {
+        // every run is one or two trips (the usual case): straight-line code, entries that do not
+        // exist go to a dump slot past the list
+#pragma unroll
+        for (int u = 0; u < RC; ++u) {
+            L.items[len[u] > 0u ? off : (unsigned) kBalCap] = tag | rs[u];
+            L.items[len[u] > 4u ? off + 1u : (unsigned) kBalCap] = tag | (rs[u] + 4u);
+            off += (len[u] + 3u) >> 2;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < RC; ++u)
+            for (unsigned j = rs[u]; j < re[u]; j += 4u) L.items[off++] = tag | j;
+    }
+    L.best[lane] = best;
+    __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave execute in order; this only stops the compiler)
+    for (unsigned k0 = 0; k0 < T; k0 += 64u) {
+        const unsigned k = k0 + lane;
+        if (k < T) {
+            const unsigned it = L.items[k];
+            const unsigned owner = it >> 26, j = it & 0x3FFFFFFu;
+            const float4 q = L.q[owner];
+            const gp_f4 p = (gp_f4) (ubase ? ubase : (const float4 *) L.base[owner]) + j;
+            const f4v t0 = p[0], t1 = p[1], t2 = p[2], t3 = p[3];
+            const unsigned long long k0_ = make_key(canon_d2v(q.x, q.y, q.z, t0), __float_as_uint(t0.w));
+            const unsigned long long k1_ = make_key(canon_d2v(q.x, q.y, q.z, t1), __float_as_uint(t1.w));
+            const unsigned long long k2_ = make_key(canon_d2v(q.x, q.y, q.z, t2), __float_as_uint(t2.w));
+            const unsigned long long k3_ = make_key(canon_d2v(q.x, q.y, q.z, t3), __float_as_uint(t3.w));
+            const unsigned long long a = k0_ < k1_ ? k0_ : k1_, b = k2_ < k3_ ? k2_ : k3_;
+            atomicMin(&L.best[owner], a < b ? a : b);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    best = L.best[lane];
+}
+
+// scan_box with wave-uniform loops (see above); `live` = this lane has a search of its own going
+template <bool COST, int RC>
+__device__ __forceinline__ unsigned long long scan_box_bal(const GridDev &g, bool live, float qx, float qy,
+                                                           float qz, float r, unsigned long long best,
+                                                           float *margin, BalLds &L, unsigned lane,
+                                                           bool allow_layered, const float4 *ubase,
+                                                           unsigned &cost) {
+    const float big = 4.0e6f;
+    const float fx = fminf(fmaxf((qx - g.ox) * g.inv_h, -big), big);
+    const float fy = fminf(fmaxf((qy - g.oy) * g.inv_h, -big), big);
+    const float fz = fminf(fmaxf((qz - g.oz) * g.inv_h, -big), big);
+    const float rc = r * g.inv_h + g.slack;
+    const int x0 = (int) floorf(fx - rc), x1 = (int) floorf(fx + rc);
+    const int y0 = (int) floorf(fy - rc), y1 = (int) floorf(fy + rc);
+    const int z0 = (int) floorf(fz - rc), z1 = (int) floorf(fz + rc);
+    const float mx = fminf(fx - (float) x0, (float) (x1 + 1) - fx);
+    const float my = fminf(fy - (float) y0, (float) (y1 + 1) - fy);
+    const float mz = fminf(fz - (float) z0, (float) (z1 + 1) - fz);
+    *margin = (fminf(mx, fminf(my, mz)) - g.slack) * g.h;
+    const int xa = max(x0, 0), xb = min(x1, g.nx - 1);
+    const int ya = max(y0, 0), yb = min(y1, g.ny - 1);
+    const int za = max(z0, 0), zb = min(z1, g.nz - 1);
+    const bool has = live && !(xa > xb || ya > yb || za > zb);
+    auto lookup_and_walk = [&](const unsigned (&a0)[RC], const unsigned (&a1)[RC]) {
+        unsigned rs[RC], re[RC];
+#pragma unroll
+        for (int u = 0; u < RC; ++u) {
+            rs[u] = ldc(g.cell_start, a0[u]);
+            re[u] = ldc(g.cell_start, a1[u]);
+        }
+        if constexpr (COST) cost += has ? 1u << 16 : 0u;
+        balanced_walk<COST, RC>(L, rs, re, lane, g.pts, ubase, qx, qy, qz, best, cost);
+    };
+    const bool layered =
+        allow_layered && __popcll(__ballot(has && (yb - ya + 1) * (zb - za + 1) > kLayeredRows)) >= 8;
+    if (layered) {
+        for (int kz = 0;; ++kz) {
+            const int zz = za + kz;
+            const bool zact = has && zz <= zb;
+            if (__ballot(zact) == 0ull) break;
+            const float Rb =
+                __builtin_amdgcn_sqrtf(__uint_as_float((unsigned) (best >> 32))) * g.inv_h * 1.00001f;
+            const float lim = Rb + g.slack;
+            const float lim2 = lim * lim, c0 = Rb * Rb + 2.f * g.slack * lim;
+            const float rz = fmaxf(fmaxf((float) zz - fz, fz - (float) (zz + 1)), 0.f);
+            const float rz2 = rz * rz;
+            const float hy = __builtin_amdgcn_sqrtf(fmaxf(lim2 - rz2, 0.f)) * 1.00001f;
+            const bool zin = zact && !(rz2 > lim2);
+            const int yl = zin ? max(ya, __float2int_rd(fy - hy)) : 1;
+            const int yh = zin ? min(yb, __float2int_rd(fy + hy)) : 0;
+            const unsigned basez = (unsigned) zz * g.ny * g.nx;
+            for (int yc = yl; __ballot(yc <= yh) != 0ull; yc += RC) {
+                unsigned a0[RC], a1[RC];
+#pragma unroll
+                for (int u = 0; u < RC; ++u) {
+                    const int yy = yc + u;
+                    const float yf = (float) yy;
+                    const float ry = fmaxf(fmaxf(yf - fy, fy - (yf + 1.f)), 0.f);
+                    const float rho2 = ry * ry + rz2;
+                    const float hx = __builtin_amdgcn_sqrtf(fmaxf(c0 - rho2, 0.f)) * 1.00001f + g.slack;
+                    const int xl = max(xa, __float2int_rd(fx - hx)), xh = min(xb, __float2int_rd(fx + hx));
+                    const bool ok = yy <= yh && !(rho2 > lim2) && xl <= xh;
+                    const unsigned base = basez + (unsigned) yy * g.nx;
+                    a0[u] = ok ? base + xl : 0u;
+                    a1[u] = ok ? base + xh + 1 : 0u;
+                }
+                lookup_and_walk(a0, a1);
+            }
+        }
+        return best;
+    }
+    int yy = ya, zz = has ? za : zb + 1;  // row cursor; a lane without rows is past its last one
+    while (__ballot(zz <= zb) != 0ull) {
+        const float Rb =
+            __builtin_amdgcn_sqrtf(__uint_as_float((unsigned) (best >> 32))) * g.inv_h * 1.00001f;
+        const float lim = Rb + g.slack;
+        const float lim2 = lim * lim, c0 = Rb * Rb + 2.f * g.slack * lim;
+        unsigned a0[RC], a1[RC];
+#pragma unroll
+        for (int u = 0; u < RC; ++u) {
+            const float ry = fmaxf(fmaxf((float) yy - fy, fy - (float) (yy + 1)), 0.f);
+            const float rz = fmaxf(fmaxf((float) zz - fz, fz - (float) (zz + 1)), 0.f);
+            const float rho2 = ry * ry + rz * rz;
+            const float hx = __builtin_amdgcn_sqrtf(fmaxf(c0 - rho2, 0.f)) * 1.00001f + g.slack;
+            const int xl = max(xa, __float2int_rd(fx - hx)), xh = min(xb, __float2int_rd(fx + hx));
+            const bool ok = zz <= zb && !(rho2 > lim2) && xl <= xh;
+            const unsigned base = ((unsigned) zz * g.ny + yy) * g.nx;
+            a0[u] = ok ? base + xl : 0u;
+            a1[u] = ok ? base + xh + 1 : 0u;
+            const bool wrap = yy >= yb;
+            yy = wrap ? ya : yy + 1;
+            zz += (wrap && zz <= zb) ? 1 : 0;
+        }
+        lookup_and_walk(a0, a1);
+    }
+    return best;
 }
 
 // Wave-cooperative version of scan_box for ONE query (q, r, best are wave-uniform):
@@ -404,21 +602,22 @@ __device__ __forceinline__ int acc_comp_of_lane(unsigned lane) {
 // query's own lane (scan_box).  Longer ones are handed to the whole wavefront, one query at a
 // time (coop_scan_box), seeded with the radius its Morton neighbour needed.
 // The radius, level and pruning choices change the work, never the result.
-// W wavefronts per workgroup, each with its own 64 queries and its own run list (the waves never
-// talk to each other during the search).  STATS < 0: search only, one wave per workgroup (finest
-// dispatch granularity, smallest tail).  STATS = WM_ICP_SVD / WM_ICP_GN6: the workgroup also
-// reduces the ICP statistics of its 64 W queries to ONE row of `partials` ([gridDim.x][kAcc]; W
-// waves per workgroup keep the number of rows the solve kernel has to add up small).
-template <int W, int STATS>
-__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5, 5)))
+// One wavefront per workgroup (finest dispatch granularity, smallest tail; workgroups of 4 / 5 /
+// 10 waves cost the search 7 / 30 / 55 %).  STATS < 0: search only.  STATS = WM_ICP_SVD /
+// WM_ICP_GN6: the wave also reduces the ICP statistics of its 64 queries to ONE row of `partials`
+// ([gridDim.x][kAcc]).  BAL: the wave pools its lanes' candidate trips (balanced walk, above);
+// otherwise every lane walks its own (kept for targets of 2^26 points and more, and for comparison).
+template <int STATS, bool BAL, bool COST = false, int RC = kBalRowChunk>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
     k_nn_grid(const LevelsDev *__restrict__ lv, const float4 *__restrict__ src, unsigned n,
               IcpDevState *__restrict__ st, float thr_d2, unsigned long long *__restrict__ keys,
               float4 *__restrict__ match_pt, const float4 *__restrict__ tgt_orig,
               float r_light_cells, float lane_lf, float coop_lf, unsigned xcd_chunk,
-              double *__restrict__ partials) {
+              double *__restrict__ partials, unsigned *__restrict__ cost_out) {
     if (st->done) return;
-    __shared__ uint2 s_runs_all[W * kRowChunk * 64];  // per wave [run][lane]: each lane's pending runs
-    uint2 *s_runs = s_runs_all + (threadIdx.x >> 6) * (kRowChunk * 64);
+    unsigned cost = 0;
+    // per wave: [run][lane] = each lane's pending runs (lane scan), or the pooled trip list (balanced walk)
+    __shared__ uint2 s_runs[BAL ? 1 : kRowChunk * 64];
     const bool rev = (xcd_chunk >> 31) != 0u;  // experiment: hand the queries out back to front
     const unsigned chunk_sz = xcd_chunk & 0x7FFFFFFFu;
     const unsigned bidx = rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
@@ -427,6 +626,7 @@ __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5, 
     const unsigned lane = threadIdx.x & 63u;
     const bool active = i < n;
     const int L = lv->n;
+    const int L_levels = L;
     const float h0 = lv->g[0].h;
     const float rmax = sqrtf(thr_d2) * 1.0001f + 1e-6f;
     const float r_light = r_light_cells * h0;  // larger radii go to the cooperative path
@@ -475,12 +675,51 @@ __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5, 
         }
         r = fminf(r, rmax);
         heavy = r > r_light;
+    }
+    if constexpr (BAL) {
+        __shared__ BalLds s_bal;
+        BalLds &L = s_bal;
+        L.q[lane] = make_float4(qx, qy, qz, 0.f);
+        bool live = mine && !heavy;
+        for (int pass = 0; pass < 32 && __ballot(live) != 0ull; ++pass) {
+            int l = 0;
+            while (l < L_levels - 1 && lv->g[l].h < lane_lf * r) ++l;
+            // all live lanes on one level (always, once the clouds are close): the level's
+            // description comes through scalar loads into SGPRs instead of eleven VGPRs per lane
+            // (one level at a time, lanes of the other levels working along, was slower: 77.6 vs
+            // 73.4 us per launch)
+            const unsigned long long lv_mask = __ballot(live);
+            const int l0 = __builtin_amdgcn_readlane(l, __ffsll((long long) lv_mask) - 1);
+            float margin;
+            if (__ballot(live && l != l0) == 0ull) {
+                const GridDev g = lv->g[l0];
+                best = scan_box_bal<COST, RC>(g, live, qx, qy, qz, r, best, &margin, L, lane, have_prev, g.pts, cost);
+            } else {
+                const GridDev g = lv->g[l];
+                L.base[lane] = (unsigned long long) g.pts;
+                best = scan_box_bal<COST, RC>(g, live, qx, qy, qz, r, best, &margin, L, lane, have_prev, nullptr, cost);
+            }
+            if (live) {
+                if constexpr (COST) cost += 1u << 24;
+                const float bd2 = __uint_as_float((unsigned) (best >> 32));
+                if (margin > 0.f && (bd2 <= margin * margin || thr_d2 <= margin * margin)) {
+                    live = false;
+                } else {
+                    const float rn = ((unsigned) best != kNoIdx) ? sqrtf(bd2) * 1.0001f + 1e-6f : 2.0f * r;
+                    r = fminf(fmaxf(rn, 1.25f * r), rmax);
+                    heavy = r > r_light;
+                    live = !heavy;
+                }
+            }
+        }
+    } else if (mine) {
         for (int pass = 0; !heavy && pass < 32; ++pass) {
             int l = 0;
             while (l < L - 1 && lv->g[l].h < lane_lf * r) ++l;
             const GridDev g = lv->g[l];
             float margin;
-            best = scan_box(g, qx, qy, qz, r, best, &margin, s_runs, lane, have_prev);
+            best = scan_box<COST>(g, qx, qy, qz, r, best, &margin, s_runs, lane, have_prev, cost);
+            if constexpr (COST) cost += 1u << 24;  // passes
             const float bd2 = __uint_as_float((unsigned) (best >> 32));
             if (margin > 0.f && (bd2 <= margin * margin || thr_d2 <= margin * margin)) break;
             // not certified: the radius must GROW (a query sitting on a cell face can have a
@@ -531,6 +770,9 @@ __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5, 
         match_pt[i] = make_float4(bqx, bqy, bqz, 0.f);
     }
     if (lane == 0 && n_heavy) atomicAdd(&st->queue_count[1], n_heavy);  // stats only
+    if constexpr (COST) {
+        if (active) cost_out[i] = mine ? (cost | (heavy ? 0x80000000u : 0u)) : 0u;
+    }
     if constexpr (STATS >= 0) {
         // this lane's terms (same arithmetic as k_icp_stats, wm_icp.hip)
         double a[kAcc];
@@ -577,19 +819,7 @@ __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5, 
         }
         acc_halve<kAcc, 32>(a, lane);
         const int comp = acc_comp_of_lane(lane);
-        if constexpr (W == 1) {
-            if (comp >= 0) partials[(size_t) row * kAcc + comp] = a[0];
-        } else {
-            __shared__ double s_part[W][kAcc];
-            if (comp >= 0) s_part[threadIdx.x >> 6][comp] = a[0];
-            __syncthreads();
-            if (threadIdx.x < kAcc) {
-                double t = 0.0;
-#pragma unroll
-                for (int w = 0; w < W; ++w) t += s_part[w][threadIdx.x];
-                partials[(size_t) row * kAcc + threadIdx.x] = t;
-            }
-        }
+        if (comp >= 0) partials[(size_t) row * kAcc + comp] = a[0];
     }
 }
 
@@ -666,13 +896,14 @@ float threshold_d2_strict(double max_corr) {
     return f;
 }
 
-template <int W, int STATS>
+template <int STATS, bool BAL, bool COST = false, int RC = kBalRowChunk>
 static void launch_nn_grid_t(wm_ctx *ctx, unsigned blocks, float thr_d2, unsigned xcd_chunk) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_grid<W, STATS>), dim3(blocks), dim3(64 * W), 0, ctx->stream,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_grid<STATS, BAL, COST, RC>), dim3(blocks), dim3(64), 0, ctx->stream,
                        ctx->d_levels.as<LevelsDev>(), ctx->src_sorted.as<float4>(), (unsigned) ctx->n_src,
                        ctx->d_state.as<IcpDevState>(), thr_d2, ctx->keys.as<unsigned long long>(),
                        ctx->match_pt.as<float4>(), ctx->tgt_orig.as<float4>(), ctx->tune_r_light,
-                       ctx->tune_lane_lf, ctx->tune_coop_lf, xcd_chunk, ctx->partials.as<double>());
+                       ctx->tune_lane_lf, ctx->tune_coop_lf, xcd_chunk, ctx->partials.as<double>(),
+                       ctx->cost_log.p ? ctx->cost_log.as<unsigned>() + (size_t) ctx->cost_log_iter * ctx->n_src : nullptr);
 }
 
 // stats_mode < 0: search only.  WM_ICP_SVD / WM_ICP_GN6: the search kernel also leaves the ICP
@@ -682,21 +913,12 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
     const unsigned n = (unsigned) ctx->n_src;
     if (rows_out) *rows_out = 0;
     if (n == 0) return WM_OK;
-    // waves per workgroup: 1 for a plain search; the fused statistics want few partial rows
-    int W = 1;
-    if (stats_mode >= 0) {
-        W = ctx->tune_nn_waves;
-        if (stats_mode != WM_ICP_SVD || (W != 1 && W != 5 && W != 10)) W = 4;
-    }
-    const unsigned nb = 64u * (unsigned) W;
-    unsigned blocks = (n + nb - 1) / nb;
+    unsigned blocks = (n + 63u) / 64u;
     blocks = (blocks + 7u) & ~7u;  // xcd_remap needs a multiple of 8
     unsigned xcd_chunk = 0;
-    // the chunked remap (big grids only: it pads the grid to a multiple of 8 chunks); a chunk is
-    // tune_xcd_chunk x 64 consecutive queries whatever the workgroup size
-    const unsigned chunk_blocks = ctx->tune_xcd_chunk > 0 ? ((unsigned) ctx->tune_xcd_chunk + W - 1) / W : 0u;
-    if (chunk_blocks > 0 && blocks >= 32u * chunk_blocks) {
-        xcd_chunk = chunk_blocks;
+    if (ctx->tune_xcd_chunk > 0 && blocks >= 32u * (unsigned) ctx->tune_xcd_chunk) {
+        // the chunked remap (big grids only: it pads the grid to a multiple of 8 chunks)
+        xcd_chunk = (unsigned) ctx->tune_xcd_chunk;
         const unsigned m = 8u * xcd_chunk;
         blocks = (blocks + m - 1u) / m * m;
     }
@@ -705,16 +927,22 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
         if (rows_out) *rows_out = blocks;
     }
     xcd_chunk |= ctx->tune_xcd_reverse ? 0x80000000u : 0u;
+    // the balanced walk packs (lane, point offset) into 32 bits: targets below 2^26 points
+    const bool bal = ctx->tune_nn_balanced && ctx->n_tgt_input < (1u << 26) - 8u;
     if (ev0) WM_HIP(ctx, hipEventRecord(ev0, ctx->stream));
-    if (stats_mode < 0)
-        launch_nn_grid_t<1, -1>(ctx, blocks, thr_d2, xcd_chunk);
-    else if (stats_mode == WM_ICP_SVD) {
-        if (W == 4) launch_nn_grid_t<4, WM_ICP_SVD>(ctx, blocks, thr_d2, xcd_chunk);
-        else if (W == 1) launch_nn_grid_t<1, WM_ICP_SVD>(ctx, blocks, thr_d2, xcd_chunk);
-        else if (W == 5) launch_nn_grid_t<5, WM_ICP_SVD>(ctx, blocks, thr_d2, xcd_chunk);
-        else launch_nn_grid_t<10, WM_ICP_SVD>(ctx, blocks, thr_d2, xcd_chunk);
+    if (stats_mode == WM_ICP_SVD && ctx->cost_log.p && ctx->cost_log_iter < ctx->cost_log_cap) {
+        if (bal) launch_nn_grid_t<WM_ICP_SVD, true, true>(ctx, blocks, thr_d2, xcd_chunk);  // developer statistics
+        else launch_nn_grid_t<WM_ICP_SVD, false, true>(ctx, blocks, thr_d2, xcd_chunk);
+        ctx->cost_log_iter++;
+    } else if (stats_mode < 0) {
+        if (bal) launch_nn_grid_t<-1, true>(ctx, blocks, thr_d2, xcd_chunk);
+        else launch_nn_grid_t<-1, false>(ctx, blocks, thr_d2, xcd_chunk);
+    } else if (stats_mode == WM_ICP_SVD) {
+        if (bal) launch_nn_grid_t<WM_ICP_SVD, true>(ctx, blocks, thr_d2, xcd_chunk);
+        else launch_nn_grid_t<WM_ICP_SVD, false>(ctx, blocks, thr_d2, xcd_chunk);
     } else {
-        launch_nn_grid_t<4, WM_ICP_GN6>(ctx, blocks, thr_d2, xcd_chunk);
+        if (bal) launch_nn_grid_t<WM_ICP_GN6, true>(ctx, blocks, thr_d2, xcd_chunk);
+        else launch_nn_grid_t<WM_ICP_GN6, false>(ctx, blocks, thr_d2, xcd_chunk);
     }
     if (ev1) WM_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     if (ev2) WM_HIP(ctx, hipEventRecord(ev2, ctx->stream));

@@ -53,6 +53,10 @@ for cfg in sys.argv[1:] or ["-"]:
               cfg, float(np.median(ts)), min(ts), r["align_ms"], r1["nn_ms"] / max(r1["nn_launches"], 1) * 1e3,
               r2["nn_ms"] / ITERS * 1e3, r2["stats_ms"] / ITERS * 1e3, r2["solve_ms"] / ITERS * 1e3, dT,
               float(np.linalg.norm(T[:3, 3] - T_gt[:3, 3]))), flush=True)
+    it = ctx.iteration_times() * 1e3
+    step(1)
+    it = ctx.iteration_times() * 1e3
+    print('    nn us by iteration:', ' '.join('%d:%.0f' % (k, it[k]) for k in (0, 1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 20, 30, 49) if k < len(it)), flush=True)
     c = ctx.solve_cycles()
     print('    solve kernel cycles: rows+stage %d, expand %d, pre-svd %d, svd %d, rest-of-apply %d' % (
         c[1] - c[0], c[2] - c[1], c[4] - c[2], c[5] - c[4], c[3] - c[5]), flush=True)
