@@ -37,8 +37,12 @@ class GICPMatcher : public Matcher<PCLPointCloudPtr> {
  public:
     explicit GICPMatcher(GICPMatcherParams params1);
     GICPMatcher(const GICPMatcher &other);  // for MultiMatcher; the copy gets its own context
+    GICPMatcher &operator=(const GICPMatcher &other);
     ~GICPMatcher();
 
+    // As in the reference (gicp.cpp:37-55): with res > 0 the cloud is voxel-filtered HERE and the
+    // filtered copy is what match() registers (later changes of the caller's cloud are not seen);
+    // with res <= 0 the handle is kept and the cloud is read by match().
     void setRef(const PCLPointCloudPtr &ref);
     void setTarget(const PCLPointCloudPtr &target);
     bool match();  // blocks until the registration is done; true when it converged
@@ -48,6 +52,7 @@ class GICPMatcher : public Matcher<PCLPointCloudPtr> {
     int device;
     PCLPointCloudPtr ref, target;
     GICPMatcherParams params;
+    bool ref_on_device, target_on_device;  // res > 0: the filtered snapshot already sits in the context
     bool ensureContext();
 };
 

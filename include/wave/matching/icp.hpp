@@ -19,11 +19,13 @@
 #define WAVE_MATCHING_ICP_HPP
 
 #include <string>
+#include <vector>
 
 #include "wave/matching/matcher.hpp"
 #include "wave/matching/pcl_common.hpp"
 
-struct wm_ctx;  // include/wavematch.h
+struct wm_ctx;    // include/wavematch.h
+struct wm_multi;  // include/wavematch.h
 
 namespace wave {
 
@@ -66,8 +68,20 @@ class ICPMatcher : public Matcher<PCLPointCloudPtr> {
     // HIP device ordinal new matchers bind to (default: env WAVE_MATCHING_DEVICE, else 0)
     static void setDefaultDevice(int device);
 
+    // Spread ONE registration over several GPUs of the node (no reference counterpart; full-resolution
+    // matches only, params.res <= 0): the target is cut into equal-count x-slabs, one per device, every
+    // device searches the source points that fall into its slab, and the per-iteration statistics are
+    // summed by an RCCL all-reduce over xGMI inside the library (wm_multi_icp_align).  The result is the
+    // single-GPU result up to summation order.  An empty list or a single device restores the default
+    // path; a list that names one device several times runs that many ranks on it with a host-side
+    // exchange (for testing without several GPUs).  estimateInfo() needs the correspondences of a
+    // single-device match and leaves `information` untouched after a multi-device one.
+    void setDevices(const std::vector<int> &devices);
+
  private:
     wm_ctx *ctx;  // created in the thread that first needs it
+    wm_multi *multi;  // setDevices: one context + RCCL communicator per device, created on first use
+    std::vector<int> devices;
     int device;
     bool converged;
     PCLPointCloudPtr ref, target;

@@ -35,8 +35,12 @@ class NDTMatcher : public Matcher<PCLPointCloudPtr> {
  public:
     explicit NDTMatcher(NDTMatcherParams params1);
     NDTMatcher(const NDTMatcher &other);
+    NDTMatcher &operator=(const NDTMatcher &other);
     ~NDTMatcher();
 
+    // As in the reference (ndt.cpp:48-56): setTarget builds the voxel model of the target at once (PCL's
+    // setInputTarget does), and later match() calls on the same target reuse it; the ref handle is
+    // kept and the cloud is read by match().
     void setRef(const PCLPointCloudPtr &ref);
     void setTarget(const PCLPointCloudPtr &target);
     bool match();  // blocks; true when the Newton iteration converged
@@ -46,7 +50,7 @@ class NDTMatcher : public Matcher<PCLPointCloudPtr> {
     int device;
     PCLPointCloudPtr ref, target;
     NDTMatcherParams params;
-    bool ref_dirty, target_dirty;  // which clouds must be uploaded before the next align
+    bool target_on_device;  // the target and its voxel model are in the context (setTarget put them there)
     bool ensureContext();
 };
 

@@ -253,6 +253,11 @@ int wm_gicp_align(wm_ctx *ctx, const wm_gicp_params *p, double T_out[16], wm_gic
 int wm_gicp_match(wm_ctx *ctx, const void *ref, size_t n_ref, const void *target, size_t n_target,
                   size_t stride_bytes, int mem, const wm_gicp_params *p, float res, double T_out[16],
                   wm_gicp_stats *stats);
+/* GICPMatcher::setRef / setTarget with res > 0 (wave_matching/src/gicp.cpp:38-45, 48-55): VoxelGrid
+ * the cloud on the device and make the FILTERED copy the registration's source / target -- at the
+ * time of the call (a snapshot, as the reference's filtered copy is). */
+int wm_set_source_filtered(wm_ctx *ctx, const void *pts, size_t n, size_t stride_bytes, int mem, float leaf);
+int wm_set_target_filtered(wm_ctx *ctx, const void *pts, size_t n, size_t stride_bytes, int mem, float leaf);
 /* OptimizationFunctorWithIndices::fdf once: pairs + Mahalanobis matrices formed with
  * T_pair as one outer iteration does, then f and gradient at x = (t, roll, pitch, yaw). */
 int wm_gicp_eval(wm_ctx *ctx, const wm_gicp_params *p, const double T_pair[16], const double x[6],
@@ -277,6 +282,8 @@ typedef struct {
     int converged, iterations, n_voxels, evaluations;
     double score;          /* trans_probability_: score / number of source points */
     float deriv_kernel_ms; /* summed device time of the derivative kernel; 0 unless WM_NDT_PROFILE=1 */
+    int model_builds;      /* voxel models this context has built so far (an unchanged target keeps its
+                              model across align calls, as PCL's setInputTarget does) */
 } wm_ndt_stats;
 
 void wm_ndt_default_params(wm_ndt_params *p);
@@ -285,6 +292,10 @@ void wm_ndt_default_params(wm_ndt_params *p);
  * wm_set_target; the voxel statistics of setInputTarget (ndt.cpp:55) are (re)built on
  * device when the target or `res` changed. */
 int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *p, double T_out[16], wm_ndt_stats *stats);
+/* pcl::NormalDistributionsTransform::setInputTarget builds the voxel grid when it is called
+ * (wave_matching/src/ndt.cpp:55): the model of the current target at resolution `res`, now; later
+ * wm_ndt_align calls with the same target and res reuse it. */
+int wm_ndt_build_model(wm_ctx *ctx, double res);
 /* computeDerivatives at pose (tx,ty,tz,rx,ry,rz): score, gradient(6), Hessian(36) */
 int wm_ndt_derivatives(wm_ctx *ctx, const wm_ndt_params *p, const double pose[6], double *score,
                        double grad[6], double hess[36], int *n_voxels);
@@ -332,6 +343,56 @@ int wm_icp_shard_poll(wm_ctx *ctx, int *done, double T_out[16], wm_icp_stats *st
  * with WM_ERR_STATE).  world = 1 or reduce = NULL restores the single-GPU behaviour. */
 typedef int (*wm_allreduce_fn)(double *vals, int n, void *user);
 int wm_ndt_set_shard(wm_ctx *ctx, int rank, int world, wm_allreduce_fn reduce, void *user);
+
+/* ------------------------------------------ sharded registration, driven from C (RCCL inside)
+ * A wm_comm is one rank's handle on a group of `world` ranks, one GPU each, whose exchange step is
+ * an RCCL all-reduce over xGMI on the calling context's stream (librccl is linked into this
+ * library).  No reference counterpart: libwave's only parallelism is one matcher per thread
+ * (wave_matching/include/wave/matching/multi_matcher.hpp:32).
+ *   wm_comm_get_unique_id + wm_comm_init_rank   one rank per process (or thread): rank 0 creates the
+ *        128-byte id, the launcher hands it to every rank (bench.py: torch.distributed broadcast;
+ *        MPI_Bcast; a file), every rank calls init_rank on its device.   = ncclCommInitRank
+ *   wm_comm_init_all     all ranks in one process, `devices[r]` for rank r.  = ncclCommInitAll
+ *   wm_comm_init_local   test stand-in: `n` ranks on ONE device whose all-reduce is a host-side sum
+ *        in rank order at a barrier (each rank must run on its own thread). */
+typedef struct wm_comm wm_comm;
+#define WM_COMM_ID_BYTES 128
+int wm_comm_get_unique_id(void *id_out /* WM_COMM_ID_BYTES */);
+int wm_comm_init_rank(wm_comm **out, int device, const void *id, int rank, int world);
+int wm_comm_init_all(wm_comm **comms /* [n] */, const int *devices, int n);
+int wm_comm_init_local(wm_comm **comms /* [n] */, int n, int device);
+void wm_comm_destroy(wm_comm *comm);
+int wm_comm_rank(const wm_comm *comm);
+int wm_comm_world(const wm_comm *comm);
+
+/* pcl::IterativeClosestPoint::align (wave_matching/src/icp.cpp:126-129) as ONE registration over
+ * all ranks of `comm`.  Collective: every rank calls it with the same two (full) clouds and
+ * parameters, on its own context (`mem` = where the clouds live for THIS rank).  Inside the call:
+ * equal-count x-slabs of the target from a histogram (identical on all ranks, no communication),
+ * this rank's slab + max_corr halo of the target and its band of the source compacted on the
+ * device, the index over them, then per iteration search + local sums -> ncclAllReduce of
+ * WM_STATS_LEN doubles -> solve, all enqueued on the context's stream.  Every rank returns the same
+ * transform and status.  comm == NULL or a world of 1 is plain wm_set_source + wm_set_target +
+ * wm_icp_align. */
+int wm_icp_align_sharded(wm_ctx *ctx, wm_comm *comm, const void *ref, size_t n_ref, const void *target,
+                         size_t n_target, size_t stride_bytes, int mem, const wm_icp_params *p,
+                         double T_out[16], wm_icp_stats *stats);
+
+/* Sharded NDT with the exchange on the device: like wm_ndt_set_shard, but the sums of every
+ * derivative pass are all-reduced in HBM over `comm` (RCCL) before the host fetches them -- no
+ * callback, no host bounce.  comm == NULL switches sharding off. */
+int wm_ndt_set_comm(wm_ctx *ctx, wm_comm *comm);
+
+/* All ranks in ONE process: one context and one worker thread per device, RCCL communicators from
+ * ncclCommInitAll (emulate != 0: `n_devices` ranks on devices[0] with the host stand-in exchange).
+ * wm_multi_icp_align runs one sharded registration of two HOST clouds (every rank uploads them over
+ * its own PCIe link) and returns rank 0's result. */
+typedef struct wm_multi wm_multi;
+int wm_multi_create(wm_multi **out, const int *devices, int n_devices, int emulate);
+void wm_multi_destroy(wm_multi *m);
+int wm_multi_size(const wm_multi *m);
+int wm_multi_icp_align(wm_multi *m, const void *ref, size_t n_ref, const void *target, size_t n_target,
+                       size_t stride_bytes, const wm_icp_params *p, double T_out[16], wm_icp_stats *stats);
 
 /* Host-only twin of the per-iteration solve + PCL stopping rules (no GPU touched):
  * the very function the device runs after the all-reduce, callable on the CPU so

@@ -66,7 +66,8 @@ class NdtParams(C.Structure):
 
 class NdtStats(C.Structure):
     _fields_ = [("converged", C.c_int), ("iterations", C.c_int), ("n_voxels", C.c_int),
-                ("evaluations", C.c_int), ("score", C.c_double), ("deriv_kernel_ms", C.c_float)]
+                ("evaluations", C.c_int), ("score", C.c_double), ("deriv_kernel_ms", C.c_float),
+                ("model_builds", C.c_int)]
 
 
 _dp = C.POINTER(C.c_double)
@@ -137,6 +138,27 @@ def lib():
                                          C.POINTER(C.c_int)]
         L.wm_ndt_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]
         L.wm_get_iteration_times.argtypes = [C.c_void_p, _fp, C.c_int]
+        L.wm_comm_get_unique_id.argtypes = [C.c_void_p]
+        L.wm_comm_init_rank.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.wm_comm_init_all.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]
+        L.wm_comm_init_local.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int]
+        L.wm_comm_destroy.argtypes = [C.c_void_p]
+        L.wm_comm_destroy.restype = None
+        L.wm_comm_rank.argtypes = [C.c_void_p]
+        L.wm_comm_world.argtypes = [C.c_void_p]
+        L.wm_icp_align_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                           C.c_size_t, C.c_size_t, C.c_int, C.POINTER(IcpParams), _dp,
+                                           C.POINTER(IcpStats)]
+        L.wm_ndt_set_comm.argtypes = [C.c_void_p, C.c_void_p]
+        L.wm_ndt_build_model.argtypes = [C.c_void_p, C.c_double]
+        L.wm_set_source_filtered.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_float]
+        L.wm_set_target_filtered.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_float]
+        L.wm_multi_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int]
+        L.wm_multi_destroy.argtypes = [C.c_void_p]
+        L.wm_multi_destroy.restype = None
+        L.wm_multi_size.argtypes = [C.c_void_p]
+        L.wm_multi_icp_align.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                         C.c_size_t, C.POINTER(IcpParams), _dp, C.POINTER(IcpStats)]
         L.wm_debug_solve_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.wm_debug_cost_log.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.wm_get_correspondences.argtypes = [C.c_void_p, _ip, _fp, C.c_size_t]
@@ -371,7 +393,7 @@ class Context:
                                             C.byref(s)), "wm_ndt_align")
         return dict(rc=rc, T=T if rc == WM_OK else None, converged=bool(s.converged),
                     iterations=s.iterations, n_voxels=s.n_voxels, evaluations=s.evaluations,
-                    score=s.score, deriv_kernel_ms=s.deriv_kernel_ms)
+                    score=s.score, deriv_kernel_ms=s.deriv_kernel_ms, model_builds=s.model_builds)
 
     def ndt_derivatives(self, pose, params=None, **kw):
         p = params or ndt_params(**kw)
@@ -419,6 +441,27 @@ class Context:
         d["T"] = T
         d["done"] = bool(done.value)
         return d
+
+    def icp_align_sharded(self, comm, ref, target, params=None, **kw):
+        """wm_icp_align_sharded: one registration over all ranks of `comm` (a Comm or None)."""
+        p = params or icp_params(**kw)
+        rp, rn, rs, rm, k1 = _cloud_arg(ref)
+        tp, tn, ts, tm, k2 = _cloud_arg(target)
+        if rs != ts or rm != tm:
+            raise WmError("ref and target must share stride and memory space")
+        T = np.zeros((4, 4), np.float64)
+        s = IcpStats()
+        rc = self._check(lib().wm_icp_align_sharded(self._h, comm.handle if comm is not None else None,
+                                                    C.c_void_p(rp), rn, C.c_void_p(tp), tn, rs, rm,
+                                                    C.byref(p), T.ctypes.data_as(_dp), C.byref(s)),
+                         "wm_icp_align_sharded")
+        d = self._stats_dict(rc, T, s)
+        d["owned_violations"] = s.owned_violations
+        return d
+
+    def ndt_set_comm(self, comm):
+        self._check(lib().wm_ndt_set_comm(self._h, comm.handle if comm is not None else None),
+                    "wm_ndt_set_comm")
 
     def cost_log_arm(self, iterations):
         self._check(lib().wm_debug_cost_log(self._h, iterations, None, 0), "wm_debug_cost_log")
@@ -511,3 +554,79 @@ def gn6_from_stats(stats):
     T = np.zeros((4, 4))
     rc = lib().wm_gn6_from_stats(st.ctypes.data_as(_dp), T.ctypes.data_as(_dp))
     return rc, T
+
+
+class Comm:
+    """One rank's wm_comm (RCCL communicator, or the single-GPU stand-in)."""
+
+    def __init__(self, handle):
+        self.handle = C.c_void_p(handle)
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        rc = lib().wm_comm_get_unique_id(buf)
+        if rc != 0:
+            raise WmError("wm_comm_get_unique_id: %d" % rc)
+        return buf.raw
+
+    @classmethod
+    def init_rank(cls, device, uid, rank, world):
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(uid), 128)
+        rc = lib().wm_comm_init_rank(C.byref(h), device, buf, rank, world)
+        if rc != 0:
+            raise WmError("wm_comm_init_rank: %d" % rc)
+        return cls(h.value)
+
+    @classmethod
+    def init_local(cls, n, device=0):
+        arr = (C.c_void_p * n)()
+        rc = lib().wm_comm_init_local(arr, n, device)
+        if rc != 0:
+            raise WmError("wm_comm_init_local: %d" % rc)
+        return [cls(arr[i]) for i in range(n)]
+
+    @property
+    def rank(self):
+        return lib().wm_comm_rank(self.handle)
+
+    @property
+    def world(self):
+        return lib().wm_comm_world(self.handle)
+
+    def close(self):
+        if self.handle:
+            lib().wm_comm_destroy(self.handle)
+            self.handle = None
+
+
+class Multi:
+    """wm_multi: all ranks of a sharded registration in this process (one thread per device)."""
+
+    def __init__(self, devices, emulate=False):
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = lib().wm_multi_create(C.byref(h), arr, len(devices), int(emulate))
+        if rc != 0:
+            raise WmError("wm_multi_create: %d (%s)" % (rc, lib().wm_strerror(rc).decode()))
+        self._h = h
+
+    def icp_align(self, ref, target, params=None, **kw):
+        p = params or icp_params(**kw)
+        ref = np.ascontiguousarray(ref, np.float32)
+        target = np.ascontiguousarray(target, np.float32)
+        T = np.zeros((4, 4), np.float64)
+        s = IcpStats()
+        rc = lib().wm_multi_icp_align(self._h, ref.ctypes.data_as(C.c_void_p), len(ref),
+                                      target.ctypes.data_as(C.c_void_p), len(target), ref.strides[0],
+                                      C.byref(p), T.ctypes.data_as(_dp), C.byref(s))
+        if rc < 0:
+            raise WmError("wm_multi_icp_align: %d (%s)" % (rc, lib().wm_strerror(rc).decode()))
+        return dict(rc=rc, T=T, converged=s.converged, iterations=s.iterations, state=s.state,
+                    n_corr=s.n_corr, mse=s.mse, align_ms=s.align_ms, owned_violations=s.owned_violations)
+
+    def close(self):
+        if self._h:
+            lib().wm_multi_destroy(self._h)
+            self._h = None

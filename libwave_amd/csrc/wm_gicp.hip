@@ -948,19 +948,34 @@ int wm_gicp_match(wm_ctx *ctx, const void *ref, size_t n_ref, const void *target
         WM_TRY(wm_set_target(ctx, target, n_target, stride, mem));
         return wm_gicp_align(ctx, p, T_out, stats);
     }
-    const size_t cap_r = n_ref > 0 ? n_ref : 1, cap_t = n_target > 0 ? n_target : 1;
-    WM_HIP(ctx, ctx->match_ref.reserve(cap_r * sizeof(float4)));
-    WM_HIP(ctx, ctx->match_tgt.reserve(cap_t * sizeof(float4)));
-    WM_HIP(ctx, ctx->ds_ref.reserve(cap_r * sizeof(float4)));
-    WM_HIP(ctx, ctx->ds_tgt.reserve(cap_t * sizeof(float4)));
-    WM_TRY(pack_cloud(ctx, ref, n_ref, stride, mem, ctx->match_ref.as<float4>()));
-    WM_TRY(pack_cloud(ctx, target, n_target, stride, mem, ctx->match_tgt.as<float4>()));
-    size_t nr = 0, nt = 0;
-    WM_TRY(voxel_downsample_dev(ctx, ctx->match_ref.as<float4>(), n_ref, res, ctx->ds_ref.as<float4>(), &nr));
-    WM_TRY(voxel_downsample_dev(ctx, ctx->match_tgt.as<float4>(), n_target, res, ctx->ds_tgt.as<float4>(), &nt));
-    WM_TRY(wm_set_source(ctx, ctx->ds_ref.p, nr, sizeof(float4), WM_MEM_DEVICE));
-    WM_TRY(wm_set_target(ctx, ctx->ds_tgt.p, nt, sizeof(float4), WM_MEM_DEVICE));
+    WM_TRY(wm_set_source_filtered(ctx, ref, n_ref, stride, mem, res));
+    WM_TRY(wm_set_target_filtered(ctx, target, n_target, stride, mem, res));
     return wm_gicp_align(ctx, p, T_out, stats);
+}
+
+// GICPMatcher::setRef / setTarget with res > 0 (gicp.cpp:38-45, 48-55): the cloud is voxel-filtered
+// and the FILTERED copy becomes the registration's input at the time of the call (a snapshot: later
+// changes of the caller's cloud are not seen).
+static int set_filtered(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, float leaf, bool source) {
+    if (!ctx || (n > 0 && !pts) || stride < 12 || (stride & 3) || n > 0x7FFFFFF0u || !(leaf > 0)) return WM_ERR_ARG;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf &raw = source ? ctx->match_ref : ctx->match_tgt, &ds = source ? ctx->ds_ref : ctx->ds_tgt;
+    const size_t cap = n > 0 ? n : 1;
+    WM_HIP(ctx, raw.reserve(cap * sizeof(float4)));
+    WM_HIP(ctx, ds.reserve(cap * sizeof(float4)));
+    WM_TRY(pack_cloud(ctx, pts, n, stride, mem, raw.as<float4>()));
+    size_t nf = 0;
+    WM_TRY(voxel_downsample_dev(ctx, raw.as<float4>(), n, leaf, ds.as<float4>(), &nf));
+    return source ? wm_set_source(ctx, ds.p, nf, sizeof(float4), WM_MEM_DEVICE)
+                  : wm_set_target(ctx, ds.p, nf, sizeof(float4), WM_MEM_DEVICE);
+}
+
+int wm_set_source_filtered(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, float leaf) {
+    return set_filtered(ctx, pts, n, stride, mem, leaf, true);
+}
+
+int wm_set_target_filtered(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, float leaf) {
+    return set_filtered(ctx, pts, n, stride, mem, leaf, false);
 }
 
 }  // extern "C"

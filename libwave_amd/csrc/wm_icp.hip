@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(1024)
         for (int g = 0; g < 8; ++g) r += s2[g][t];
         dst[t] = r;
     }
-    if (t < 64) {
+    if (t < 64 && flag) {
         __threadfence_system();
         if (t == 0) *(volatile unsigned *) flag = seq;
     }
@@ -644,6 +644,14 @@ int fast_fetch_sum(wm_ctx *ctx, double *dst_pinned, const double *src_dev, unsig
                        ctx->h_sig, seq);
     WM_HIP(ctx, hipGetLastError());
     return wait_flag(ctx, seq);
+}
+
+int sum_to_device(wm_ctx *ctx, double *dst_dev, const double *src_dev, unsigned rows, unsigned k) {
+    if (k < 1 || k > 32 || rows < 1) return WM_ERR_ARG;
+    hipLaunchKernelGGL(k_sum_fetch, dim3(1), dim3(1024), 0, ctx->stream, dst_dev, src_dev, rows, k,
+                       (unsigned *) nullptr, 0u);
+    WM_HIP(ctx, hipGetLastError());
+    return WM_OK;
 }
 
 static int download_state(wm_ctx *ctx) {
@@ -812,6 +820,7 @@ int wm_ctx_create(wm_ctx **out, int device) {
     if (const char *e = getenv("WM_TUNE_SPIN_US")) ctx->tune_spin_us = atoi(e);
     if (const char *e = getenv("WM_TUNE_XCD_REVERSE")) ctx->tune_xcd_reverse = atoi(e);
     if (const char *e = getenv("WM_TUNE_SCAN")) ctx->tune_scan = atoi(e);
+    if (const char *e = getenv("WM_SHARD_FORCE")) ctx->tune_force_shard = atoi(e);
     if (const char *e = getenv("WM_TUNE_TWO_STREAMS")) ctx->tune_two_streams = atoi(e);
     if (const char *e = getenv("WM_TUNE_FUSE_STATS")) ctx->tune_fuse_stats = atoi(e);
     if (const char *e = getenv("WM_TUNE_NN_BALANCED")) ctx->tune_nn_balanced = atoi(e);
@@ -836,6 +845,10 @@ int wm_ctx_create(wm_ctx **out, int device) {
     if (const char *e = getenv("WM_TUNE_COOP_LF")) {
         const float v = (float) atof(e);
         if (v > 0) ctx->tune_coop_lf = v;
+    }
+    if (const char *e = getenv("WM_TUNE_R0")) {
+        const float v = (float) atof(e);
+        if (v > 0) ctx->tune_r0 = v;
     }
     if (const char *e = getenv("WM_TUNE_R_LIGHT")) {  // developer tuning knob
         const float v = (float) atof(e);
@@ -866,7 +879,9 @@ void wm_ctx_destroy(wm_ctx *ctx) {
                       &ctx->src_grid.cell_start, &ctx->vg_idx, &ctx->vg_idx2, &ctx->vg_perm,
                       &ctx->vg_perm2, &ctx->vg_tmp, &ctx->vg_seg, &ctx->io_a, &ctx->io_b, &ctx->ds_ref,
                       &ctx->ds_tgt, &ctx->match_ref, &ctx->match_tgt,
-                      &ctx->partials, &ctx->partials2, &ctx->cost_log, &ctx->corr_tmp_idx, &ctx->corr_tmp_d2, &ctx->d_state};
+                      &ctx->partials, &ctx->partials2, &ctx->cost_log, &ctx->shard_ref, &ctx->shard_tgt,
+                      &ctx->shard_ref_band, &ctx->shard_tgt_band, &ctx->shard_misc, &ctx->shard_flags, &ctx->shard_pos_t,
+                      &ctx->shard_pos_s, &ctx->shard_stats, &ctx->ndt_sum_dev, &ctx->corr_tmp_idx, &ctx->corr_tmp_d2, &ctx->d_state};
     for (DevBuf *b : bufs) b->release();
     for (auto &l : ctx->levels) {
         l.pts.release();
@@ -1180,8 +1195,10 @@ int wm_icp_match(wm_ctx *ctx, const void *ref, size_t n_ref, const void *target,
 // ------------------------------------------------ sharded (multi-GPU) stepping
 int wm_icp_shard_begin(wm_ctx *ctx, const wm_icp_params *p, double x_lo, double x_hi,
                        size_t expect_owned_total) {
-    if (!ctx || !p || !(p->max_corr > 0) || !(x_lo < x_hi)) return WM_ERR_ARG;
-    if (ctx->n_src_input == 0) return WM_ERR_STATE;
+    // (an empty slab, x_lo == x_hi, and an empty band of the source are legitimate for a rank of a
+    // sharded registration: it contributes zeros)
+    if (!ctx || !p || !(p->max_corr > 0) || !(x_lo <= x_hi)) return WM_ERR_ARG;
+    if (ctx->n_src_input == 0 && expect_owned_total == 0) return WM_ERR_STATE;
     WM_HIP(ctx, hipSetDevice(ctx->device));
     WM_TRY(finalize_clouds(ctx, p->max_corr, p->nn_method));
     WM_TRY(prepare_work(ctx));

@@ -149,6 +149,7 @@ struct wm_ctx {
     bool trace = false;
     float tune_lane_lf = 0.2f;   // lane-serial scan: finest level with cell size >= this x radius
     float tune_coop_lf = 0.5f;   // cooperative scan: finest level with cell size >= this x radius
+    float tune_r0 = 0.5f;        // first radius of an unseeded search, in level-0 cells
     float tune_r_light = 16.0f;  // lane-serial vs cooperative scan threshold, in level-0 cells (12-24 within 1 %)
     double tuned_h = 0, tuned_vol = 0;  // last auto-tuned level-0 cell size and its cloud
     size_t tuned_n = 0;
@@ -205,6 +206,7 @@ struct wm_ctx {
     int tune_xcd_chunk = 32;     // search kernel: XCDs take turns in chunks of this many workgroups (0: one eighth each)
     int tune_scan = 1;           // exclusive scans: rocPRIM look-back scan (1) or the three-kernel scan (0)
     int tune_xcd_reverse = 0;    // search kernel: hand the workgroups out back to front (experiment)
+    int tune_force_shard = 0;    // WM_SHARD_FORCE=1: a one-rank RCCL group still runs the sharded loop (plumbing check)
     int tune_two_streams = 1;    // source Morton sort on a side stream beside the target's grid build
     int tune_fuse_stats = 1;     // ICP statistics summed in the tail of the search kernel (0: separate k_icp_stats pass)
     int tune_nn_balanced = 1;    // search kernel: wave-pooled candidate trips (0: every lane walks its own)
@@ -213,10 +215,15 @@ struct wm_ctx {
     int tune_ndt_blocks = 1024;  // workgroups (= partial rows) of one NDT derivative pass
     int tune_gicp_blocks = 512;  // workgroups (= partial rows) of one GICP objective evaluation
     bool ndt_built = false;
+    int ndt_model_builds = 0;    // voxel models built so far (wm_ndt_stats.model_builds)
     double ndt_res = -1;
     unsigned ndt_nvox = 0, ndt_nvalid = 0, ndt_hmask = 0;
 
     // sharded (multi-GPU) stepping
+    wm::DevBuf shard_ref, shard_tgt, shard_ref_band, shard_tgt_band, shard_misc, shard_flags, shard_pos_t,
+        shard_pos_s, shard_stats, ndt_sum_dev;
+    float shard_lo = 0, shard_hi = 0;
+    struct wm_comm *ndt_comm = nullptr;    // wm_ndt_set_comm: the derivative passes' sums are all-reduced on the device
     bool shard_active = false;
     wm_icp_params shard_params{};
     float shard_thr = 0;
@@ -247,6 +254,10 @@ int ensure_levels(wm_ctx *ctx, double max_corr);
 int fast_fetch(wm_ctx *ctx, void *dst_pinned, const void *src_dev, size_t bytes);
 // column sums of a [rows][k] f64 block (k <= 32), reduced on the device, k doubles delivered
 int fast_fetch_sum(wm_ctx *ctx, double *dst_pinned, const double *src_dev, unsigned rows, unsigned k);
+// the same column sums left in DEVICE memory (no signal): what an all-reduce then works on
+int sum_to_device(wm_ctx *ctx, double *dst_dev, const double *src_dev, unsigned rows, unsigned k);
+// ---- wm_shard.hip: sum `n` doubles in device memory over the ranks of `comm`, on the context's stream
+int comm_allreduce(wm_ctx *ctx, struct wm_comm *comm, double *dev, int n);
 // developer tracing (env WM_TRACE=1): drain the stream and print a marker, so that a GPU fault can
 // be pinned to the stage that was running
 #define WM_TRACE(ctx, what)                                                     \

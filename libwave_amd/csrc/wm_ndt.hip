@@ -827,7 +827,7 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
     // this rank's share of the Morton-ordered source (all of it unless wm_ndt_set_shard): chunks
     // of 4096 points dealt out round-robin, so every rank sees the whole scene at 1/world density
     // (contiguous slices would give the ranks different neighbour counts, i.e. different times)
-    const bool sharded = ctx->ndt_world > 1 && ctx->ndt_reduce;
+    const bool sharded = ctx->ndt_world > 1 && (ctx->ndt_reduce || ctx->ndt_comm);
     const unsigned n_total = (unsigned) ctx->n_src;
     const unsigned s_rank = sharded ? (unsigned) ctx->ndt_rank : 0u, s_world = sharded ? (unsigned) ctx->ndt_world : 1u;
     unsigned n = n_total;
@@ -875,7 +875,17 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
     const auto t_launch1 = std::chrono::steady_clock::now();
     // sums over blocks, formed on the device (fixed order); 224 bytes come back
     const int n_acc = hess ? kNdtAcc : kNdtAccGrad;
-    if (fast_fetch_sum(ctx, ctx->h_ndt, partials, (unsigned) nb, (unsigned) n_acc) != WM_OK) {
+    if (sharded && ctx->ndt_comm) {
+        // sums over blocks -> device buffer -> all-reduce over the ranks on the stream (RCCL) -> host
+        if (ctx->ndt_sum_dev.reserve(64 * sizeof(double)) != hipSuccess ||
+            sum_to_device(ctx, ctx->ndt_sum_dev.as<double>(), partials, (unsigned) nb, (unsigned) n_acc) != WM_OK ||
+            comm_allreduce(ctx, ctx->ndt_comm, ctx->ndt_sum_dev.as<double>(), n_acc) != WM_OK ||
+            fast_fetch(ctx, ctx->h_ndt, ctx->ndt_sum_dev.p, (size_t) n_acc * sizeof(double)) != WM_OK) {
+            if (ctx->last_error.empty()) ctx->last_error = "ndt_eval: device all-reduce failed";
+            *rc = WM_ERR_HIP;
+            return 0;
+        }
+    } else if (fast_fetch_sum(ctx, ctx->h_ndt, partials, (unsigned) nb, (unsigned) n_acc) != WM_OK) {
         ctx->last_error = "ndt_eval: HIP error";
         *rc = WM_ERR_HIP;
         return 0;
@@ -892,7 +902,7 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
     E.evals += 1;
     double a[kNdtAcc] = {0};
     for (int k = 0; k < n_acc; ++k) a[k] = ctx->h_ndt[k];
-    if (sharded && ctx->ndt_reduce(a, n_acc, ctx->ndt_reduce_user) != 0) {
+    if (sharded && !ctx->ndt_comm && ctx->ndt_reduce(a, n_acc, ctx->ndt_reduce_user) != 0) {
         ctx->last_error = "ndt_eval: the all-reduce callback failed";
         *rc = WM_ERR_STATE;
         return 0;
@@ -1089,6 +1099,30 @@ int wm_ndt_set_shard(wm_ctx *ctx, int rank, int world, wm_allreduce_fn reduce, v
     return WM_OK;
 }
 
+// pcl::NormalDistributionsTransform::setInputTarget builds the voxel grid at once (ndt.cpp:55):
+// later align() calls on the same target reuse it.
+int wm_ndt_build_model(wm_ctx *ctx, double res) {
+    if (!ctx || !(res > 0)) return WM_ERR_ARG;
+    if (ctx->n_tgt_input == 0) return WM_ERR_STATE;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_TRY(finalize_clouds(ctx));
+    if (!ctx->ndt_built || ctx->ndt_res != res) {
+        WM_TRY(ndt_build(ctx, res));
+        ctx->ndt_model_builds++;
+    }
+    return WM_OK;
+}
+
+int wm_ndt_set_comm(wm_ctx *ctx, struct wm_comm *comm) {
+    if (!ctx) return WM_ERR_ARG;
+    ctx->ndt_comm = comm;
+    ctx->ndt_reduce = nullptr;
+    ctx->ndt_reduce_user = nullptr;
+    ctx->ndt_rank = comm ? wm_comm_rank(comm) : 0;
+    ctx->ndt_world = comm ? wm_comm_world(comm) : 1;
+    return WM_OK;
+}
+
 int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *prm, double T_out[16], wm_ndt_stats *stats) {
     if (!ctx || !prm || !T_out || !(prm->res > 0) || !(prm->step_size > 0)) return WM_ERR_ARG;
     if (stats) memset(stats, 0, sizeof(*stats));
@@ -1096,7 +1130,10 @@ int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *prm, double T_out[16], wm_ndt
     WM_HIP(ctx, hipSetDevice(ctx->device));
     WM_TRY(finalize_clouds(ctx));
     WM_HIP(ctx, ctx->partials.reserve((size_t) kNdtBlocks * kNdtAcc * sizeof(double)));
-    if (!ctx->ndt_built || ctx->ndt_res != prm->res) WM_TRY(ndt_build(ctx, prm->res));
+    if (!ctx->ndt_built || ctx->ndt_res != prm->res) {
+        WM_TRY(ndt_build(ctx, prm->res));
+        ctx->ndt_model_builds++;
+    }
     NdtEval E;
     E.ctx = ctx;
     E.prm = prm;
@@ -1138,6 +1175,7 @@ int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *prm, double T_out[16], wm_ndt
         stats->converged = converged;
         stats->iterations = iter;
         stats->n_voxels = (int) ctx->ndt_nvalid;
+        stats->model_builds = ctx->ndt_model_builds;
         stats->evaluations = E.evals;
         stats->score = ctx->n_src > 0 ? score / (double) ctx->n_src_input : 0;
         stats->deriv_kernel_ms = E.kernel_ms;
@@ -1160,7 +1198,10 @@ int wm_ndt_derivatives(wm_ctx *ctx, const wm_ndt_params *prm, const double pose[
     WM_HIP(ctx, hipSetDevice(ctx->device));
     WM_TRY(finalize_clouds(ctx));
     WM_HIP(ctx, ctx->partials.reserve((size_t) kNdtBlocks * kNdtAcc * sizeof(double)));
-    if (!ctx->ndt_built || ctx->ndt_res != prm->res) WM_TRY(ndt_build(ctx, prm->res));
+    if (!ctx->ndt_built || ctx->ndt_res != prm->res) {
+        WM_TRY(ndt_build(ctx, prm->res));
+        ctx->ndt_model_builds++;
+    }
     NdtEval E;
     E.ctx = ctx;
     E.prm = prm;

@@ -612,7 +612,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
     k_nn_grid(const LevelsDev *__restrict__ lv, const float4 *__restrict__ src, unsigned n,
               IcpDevState *__restrict__ st, float thr_d2, unsigned long long *__restrict__ keys,
               float4 *__restrict__ match_pt, const float4 *__restrict__ tgt_orig,
-              float r_light_cells, float lane_lf, float coop_lf, unsigned xcd_chunk,
+              float r_light_cells, float lane_lf, float coop_lf, float r0_cells, unsigned xcd_chunk,
               double *__restrict__ partials, unsigned *__restrict__ cost_out) {
     if (st->done) return;
     unsigned cost = 0;
@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
     // a point of another rank's slab is left untouched: its key / match keep whatever this
     // rank last found for it (still a valid candidate if it ever comes back)
     if (mine) {
-        r = 0.5f * h0;
+        r = r0_cells * h0;
         if (prev != ~0ull) {
             const unsigned pidx = (unsigned) prev;
             r = rmax;  // nothing (close enough) to start from: the full radius
@@ -902,7 +902,7 @@ static void launch_nn_grid_t(wm_ctx *ctx, unsigned blocks, float thr_d2, unsigne
                        ctx->d_levels.as<LevelsDev>(), ctx->src_sorted.as<float4>(), (unsigned) ctx->n_src,
                        ctx->d_state.as<IcpDevState>(), thr_d2, ctx->keys.as<unsigned long long>(),
                        ctx->match_pt.as<float4>(), ctx->tgt_orig.as<float4>(), ctx->tune_r_light,
-                       ctx->tune_lane_lf, ctx->tune_coop_lf, xcd_chunk, ctx->partials.as<double>(),
+                       ctx->tune_lane_lf, ctx->tune_coop_lf, ctx->tune_r0, xcd_chunk, ctx->partials.as<double>(),
                        ctx->cost_log.p ? ctx->cost_log.as<unsigned>() + (size_t) ctx->cost_log_iter * ctx->n_src : nullptr);
 }
 

@@ -20,21 +20,49 @@ GICPMatcherParams::GICPMatcherParams(const std::string &config_path) {
 
 GICPMatcher::GICPMatcher(GICPMatcherParams params1)
     : ctx(nullptr), device(shim::defaultDevice()), ref(shim::emptyCloud()), target(shim::emptyCloud()),
-      params(params1) {
+      params(params1), ref_on_device(false), target_on_device(false) {
     resolution = params.res > 0 ? params.res : -1.0f;
 }
 
+// A copy shares parameters and cloud handles, never device state (a filtered snapshot held by the
+// original's context is re-made from the handle the next time the copy matches).
 GICPMatcher::GICPMatcher(const GICPMatcher &o)
     : Matcher<PCLPointCloudPtr>(o), ctx(nullptr), device(o.device), ref(o.ref), target(o.target),
-      params(o.params) {}
+      params(o.params), ref_on_device(false), target_on_device(false) {}
+
+GICPMatcher &GICPMatcher::operator=(const GICPMatcher &o) {
+    if (this == &o) return *this;
+    shim::release(ctx);
+    Matcher<PCLPointCloudPtr>::operator=(o);
+    device = o.device;
+    ref = o.ref;
+    target = o.target;
+    params = o.params;
+    ref_on_device = target_on_device = false;
+    return *this;
+}
 
 GICPMatcher::~GICPMatcher() { shim::release(ctx); }
 
 bool GICPMatcher::ensureContext() { return shim::acquire(ctx, device); }
 
-void GICPMatcher::setRef(const PCLPointCloudPtr &cloud) { ref = cloud; }
+void GICPMatcher::setRef(const PCLPointCloudPtr &cloud) {
+    ref = cloud;
+    ref_on_device = false;
+    if (resolution > 0 && ensureContext())  // gicp.cpp:38-42: filter now, register the filtered copy
+        ref_on_device = shim::succeeded(wm_set_source_filtered(ctx, cloudData(ref), cloudSize(ref), kCloudStride,
+                                                               WM_MEM_HOST, resolution),
+                                        "wm_set_source_filtered", ctx);
+}
 
-void GICPMatcher::setTarget(const PCLPointCloudPtr &cloud) { target = cloud; }
+void GICPMatcher::setTarget(const PCLPointCloudPtr &cloud) {
+    target = cloud;
+    target_on_device = false;
+    if (resolution > 0 && ensureContext())  // gicp.cpp:48-52
+        target_on_device = shim::succeeded(wm_set_target_filtered(ctx, cloudData(target), cloudSize(target),
+                                                                  kCloudStride, WM_MEM_HOST, resolution),
+                                           "wm_set_target_filtered", ctx);
+}
 
 bool GICPMatcher::match() {
     if (!ensureContext()) return false;
@@ -46,9 +74,25 @@ bool GICPMatcher::match() {
     // fit_eps goes to setEuclideanFitnessEpsilon (gicp.cpp:34), which PCL-GICP's loop never reads
     double T[16];
     wm_gicp_stats stats;
-    const int rc = wm_gicp_match(ctx, cloudData(ref), cloudSize(ref), cloudData(target), cloudSize(target),
-                                 kCloudStride, WM_MEM_HOST, &p, resolution, T, &stats);
-    if (!shim::succeeded(rc, "wm_gicp_match", ctx)) return false;
+    // clouds that are not in the context yet: res <= 0 (handles are read now, as PCL reads its aliased
+    // inputs in align), or a copy of a matcher / a context that could not be opened at set time
+    if (!ref_on_device) {
+        const int rs = resolution > 0 ? wm_set_source_filtered(ctx, cloudData(ref), cloudSize(ref), kCloudStride,
+                                                               WM_MEM_HOST, resolution)
+                                      : wm_set_source(ctx, cloudData(ref), cloudSize(ref), kCloudStride, WM_MEM_HOST);
+        if (!shim::succeeded(rs, "wm_set_source", ctx)) return false;
+        ref_on_device = resolution > 0;
+    }
+    if (!target_on_device) {
+        const int rt = resolution > 0 ? wm_set_target_filtered(ctx, cloudData(target), cloudSize(target), kCloudStride,
+                                                               WM_MEM_HOST, resolution)
+                                      : wm_set_target(ctx, cloudData(target), cloudSize(target), kCloudStride,
+                                                      WM_MEM_HOST);
+        if (!shim::succeeded(rt, "wm_set_target", ctx)) return false;
+        target_on_device = resolution > 0;
+    }
+    const int rc = wm_gicp_align(ctx, &p, T, &stats);
+    if (!shim::succeeded(rc, "wm_gicp_align", ctx)) return false;
     shim::toAffine(T, result);
     return true;
 }

@@ -29,7 +29,7 @@ ICPMatcherParams::ICPMatcherParams(const std::string &config_path) {
 }
 
 ICPMatcher::ICPMatcher(ICPMatcherParams params1)
-    : params(params1), ctx(nullptr), device(shim::defaultDevice()), converged(false),
+    : params(params1), ctx(nullptr), multi(nullptr), device(shim::defaultDevice()), converged(false),
       ref(shim::emptyCloud()), target(shim::emptyCloud()) {
     resolution = params.res;
 }
@@ -37,14 +37,17 @@ ICPMatcher::ICPMatcher(ICPMatcherParams params1)
 // Copies share parameters and cloud handles, never device state: like the PCL members of the
 // reference class, a context belongs to one object (and is created by the thread that uses it).
 ICPMatcher::ICPMatcher(const ICPMatcher &o)
-    : Matcher<PCLPointCloudPtr>(o), params(o.params), ctx(nullptr), device(o.device), converged(false),
-      ref(o.ref), target(o.target) {}
+    : Matcher<PCLPointCloudPtr>(o), params(o.params), ctx(nullptr), multi(nullptr), devices(o.devices),
+      device(o.device), converged(false), ref(o.ref), target(o.target) {}
 
 ICPMatcher &ICPMatcher::operator=(const ICPMatcher &o) {
     if (this == &o) return *this;
     shim::release(ctx);
+    if (multi) wm_multi_destroy(multi);
+    multi = nullptr;
     Matcher<PCLPointCloudPtr>::operator=(o);
     params = o.params;
+    devices = o.devices;
     device = o.device;
     converged = false;
     ref = o.ref;
@@ -52,7 +55,21 @@ ICPMatcher &ICPMatcher::operator=(const ICPMatcher &o) {
     return *this;
 }
 
-ICPMatcher::~ICPMatcher() { shim::release(ctx); }
+ICPMatcher::~ICPMatcher() {
+    shim::release(ctx);
+    if (multi) wm_multi_destroy(multi);
+}
+
+void ICPMatcher::setDevices(const std::vector<int> &list) {
+    if (multi) wm_multi_destroy(multi);
+    multi = nullptr;
+    devices = list;
+    if (devices.size() == 1) {  // a plain single-device matcher on that device
+        if (devices[0] != device) shim::release(ctx);
+        device = devices[0];
+        devices.clear();
+    }
+}
 
 bool ICPMatcher::ensureContext() { return shim::acquire(ctx, device); }
 
@@ -62,7 +79,6 @@ void ICPMatcher::setTarget(const PCLPointCloudPtr &cloud) { target = cloud; }
 
 bool ICPMatcher::match() {
     converged = false;
-    if (!ensureContext()) return false;
     wm_icp_params p;
     wm_icp_default_params(&p);
     p.max_corr = params.max_corr;  // setMaxCorrespondenceDistance,  icp.cpp:47
@@ -72,6 +88,26 @@ bool ICPMatcher::match() {
     p.carry_state = 1;             // one PCL object per matcher: its criteria remember the last MSE
     double T[16];
     wm_icp_stats stats;
+    if (devices.size() > 1 && !(params.res > 0)) {  // one registration over several GPUs (setDevices)
+        if (!multi) {
+            bool repeated = false;
+            for (size_t a = 0; a < devices.size(); ++a)
+                for (size_t b = a + 1; b < devices.size(); ++b) repeated = repeated || devices[a] == devices[b];
+            const int rc0 = wm_multi_create(&multi, devices.data(), (int) devices.size(), repeated ? 1 : 0);
+            if (rc0 != WM_OK) {
+                LOG_ERROR("ICPMatcher: cannot open the device group (%s)", wm_strerror(rc0));
+                multi = nullptr;
+                return false;
+            }
+        }
+        const int rcm = wm_multi_icp_align(multi, cloudData(ref), cloudSize(ref), cloudData(target),
+                                           cloudSize(target), kCloudStride, &p, T, &stats);
+        if (!shim::succeeded(rcm, "wm_multi_icp_align", nullptr)) return false;
+        shim::toAffine(T, result);
+        return true;  // (converged stays false: no correspondences on one device for estimateInfo)
+    }
+    if (devices.size() > 1) LOG_INFO("ICPMatcher: voxel-filtered matches run on one device; using device %d", device);
+    if (!ensureContext()) return false;
     const int rc = wm_icp_match(ctx, cloudData(ref), cloudSize(ref), cloudData(target), cloudSize(target),
                                 kCloudStride, WM_MEM_HOST, &p, params.res, params.multiscale_steps, T,
                                 &stats);

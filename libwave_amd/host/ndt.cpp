@@ -12,7 +12,7 @@ NDTMatcherParams::NDTMatcherParams(const std::string &config_path) {
 
 NDTMatcher::NDTMatcher(NDTMatcherParams params1)
     : ctx(nullptr), device(shim::defaultDevice()), ref(shim::emptyCloud()), target(shim::emptyCloud()),
-      params(params1), ref_dirty(true), target_dirty(true) {
+      params(params1), target_on_device(false) {
     if (params.res < params.min_res) {  // ndt.cpp:23-26: refuse, say so, carry on with the floor
         LOG_ERROR("Invalid resolution given, using minimum");
         params.res = params.min_res;
@@ -22,32 +22,51 @@ NDTMatcher::NDTMatcher(NDTMatcherParams params1)
 
 NDTMatcher::NDTMatcher(const NDTMatcher &o)
     : Matcher<PCLPointCloudPtr>(o), ctx(nullptr), device(o.device), ref(o.ref), target(o.target),
-      params(o.params), ref_dirty(true), target_dirty(true) {}
+      params(o.params), target_on_device(false) {}
+
+NDTMatcher &NDTMatcher::operator=(const NDTMatcher &o) {
+    if (this == &o) return *this;
+    shim::release(ctx);
+    Matcher<PCLPointCloudPtr>::operator=(o);
+    device = o.device;
+    ref = o.ref;
+    target = o.target;
+    params.step_size = o.params.step_size;  // (member-wise: min_res is const)
+    params.max_iter = o.params.max_iter;
+    params.t_eps = o.params.t_eps;
+    params.res = o.params.res;
+    target_on_device = false;
+    return *this;
+}
 
 NDTMatcher::~NDTMatcher() { shim::release(ctx); }
 
 bool NDTMatcher::ensureContext() { return shim::acquire(ctx, device); }
 
-// The handles are only remembered here; the clouds cross to the device inside match(), so a
-// caller may still fill them after setRef / setTarget (as with the reference's aliasing).
-void NDTMatcher::setRef(const PCLPointCloudPtr &cloud) {
-    ref = cloud;
-    ref_dirty = true;
-}
+void NDTMatcher::setRef(const PCLPointCloudPtr &cloud) { ref = cloud; }  // read by match() (PCL aliases it)
 
 void NDTMatcher::setTarget(const PCLPointCloudPtr &cloud) {
     target = cloud;
-    target_dirty = true;
+    target_on_device = false;
+    if (!ensureContext()) return;
+    // ndt.cpp:55: setInputTarget builds the voxel grid now
+    target_on_device =
+        shim::succeeded(wm_set_target(ctx, cloudData(target), cloudSize(target), kCloudStride, WM_MEM_HOST),
+                        "wm_set_target", ctx) &&
+        (cloudSize(target) == 0 || shim::succeeded(wm_ndt_build_model(ctx, params.res), "wm_ndt_build_model", ctx));
 }
 
 bool NDTMatcher::match() {
     if (!ensureContext()) return false;
     if (!shim::succeeded(wm_set_source(ctx, cloudData(ref), cloudSize(ref), kCloudStride, WM_MEM_HOST),
-                         "wm_set_source", ctx) ||
-        !shim::succeeded(wm_set_target(ctx, cloudData(target), cloudSize(target), kCloudStride, WM_MEM_HOST),
-                         "wm_set_target", ctx))
+                         "wm_set_source", ctx))
         return false;
-    ref_dirty = target_dirty = false;
+    if (!target_on_device) {  // a copy of a matcher, or a context that could not be opened at set time
+        if (!shim::succeeded(wm_set_target(ctx, cloudData(target), cloudSize(target), kCloudStride, WM_MEM_HOST),
+                             "wm_set_target", ctx))
+            return false;
+        target_on_device = true;
+    }
 
     wm_ndt_params p;
     wm_ndt_default_params(&p);

@@ -33,7 +33,7 @@ for name in ("sq1", "sq2", "sq3", "ta1", "ta2", "tcp1", "tcp2", "tlb"):
         print(name, "missing"); continue
     per = collections.OrderedDict()
     for row in csv.DictReader(open(path)):
-        if not row["Kernel_Name"].startswith("wm::k_nn_grid"): continue
+        if "k_nn_grid" not in row["Kernel_Name"]: continue
         per.setdefault(int(row["Dispatch_Id"]), {})[row["Counter_Name"]] = float(row["Counter_Value"])
     ids = sorted(per)[-50:]  # the last registration
     names = sorted(per[ids[0]]) if ids else []

@@ -236,6 +236,74 @@ AddCase c_keep("ICPTest.failedMatchKeepsResult", [] {
     EXPECT((m.getResult().matrix() - before).norm() < 1e-15);
 });
 
+// ---- call-order semantics of the reference wrappers
+// gicp.cpp:37-55: with res > 0, setRef / setTarget filter the cloud WHEN CALLED and register the copy
+AddCase c_gicp_snapshot("GICPTest.setRefSnapshotsTheFilteredCloud", [] {
+    const auto scan = loadScan();
+    wave::GICPMatcherParams p;  // res = 0.1
+    auto ref = boost::make_shared<pcl::PointCloud<pcl::PointXYZ>>(*scan);
+    auto target = shifted(scan, translationX(0.2));
+    wave::GICPMatcher m(p);
+    m.setup(ref, target);
+    *ref = *shifted(scan, translationX(400.0));     // the matcher holds its own filtered copies
+    *target = *shifted(scan, translationX(-400.0));
+    EXPECT(m.match());
+    EXPECT(distanceTo(translationX(0.2), m.getResult()) < 0.1);
+    // assignment: the assigned-to matcher releases its context and rebuilds from the handles
+    wave::GICPMatcher other(p);
+    other = m;
+    *ref = *scan;
+    *target = *shifted(scan, translationX(0.2));
+    other.setup(ref, target);
+    EXPECT(other.match());
+    EXPECT(distanceTo(translationX(0.2), other.getResult()) < 0.1);
+});
+
+// ndt.cpp:53-56: setTarget builds the voxel model at once; match() reads the ref (aliased) each time
+AddCase c_ndt_eager("NDTTest.setTargetBuildsTheModelAtOnce", [] {
+    const auto scan = loadScan();
+    wave::NDTMatcherParams p(configOf("ndt"));
+    p.res = 0.3f;
+    auto ref = boost::make_shared<pcl::PointCloud<pcl::PointXYZ>>(*scan);
+    auto target = shifted(scan, translationX(0.2));
+    wave::NDTMatcher m(p);
+    m.setup(ref, target);
+    *target = *shifted(scan, translationX(300.0));  // too late: the model was built from the first content
+    EXPECT(m.match());
+    EXPECT(distanceTo(translationX(0.2), m.getResult()) < 0.12);
+    const auto first = m.getResult().matrix();
+    EXPECT(m.match());                               // same target, same model, same answer
+    EXPECT((m.getResult().matrix() - first).norm() < 1e-12);
+    wave::NDTMatcher copy(p);
+    copy = m;                                        // handles only: reads the (now moved) target itself
+    *target = *shifted(scan, translationX(0.2));
+    copy.setup(ref, target);
+    EXPECT(copy.match());
+    EXPECT(distanceTo(translationX(0.2), copy.getResult()) < 0.12);
+});
+
+// One registration spread over several ranks (ICPMatcher::setDevices; naming device 0 twice or
+// four times runs the ranks on it with the library's host-side exchange): the single-GPU answer
+AddCase c_icp_devices("ICPTest.setDevicesShardsOneRegistration", [] {
+    const auto ref = loadScan();
+    auto target = shifted(ref, translationX(0.2));
+    wave::ICPMatcherParams p(configOf("icp"));
+    p.res = -1;
+    wave::ICPMatcher one(p), many(p);
+    one.setup(ref, target);
+    EXPECT(one.match());
+    for (int ranks : {2, 4}) {
+        many.setDevices(std::vector<int>((size_t) ranks, 0));
+        many.setup(ref, target);
+        EXPECT(many.match());
+        EXPECT((many.getResult().matrix() - one.getResult().matrix()).norm() < 1e-6);
+    }
+    many.setDevices({0});
+    many.setup(ref, target);
+    EXPECT(many.match());
+    EXPECT((many.getResult().matrix() - one.getResult().matrix()).norm() < 1e-12);
+});
+
 // ---------------------------------------------------------------------- MultiMatcher
 wave::ICPMatcherParams singleScale() {
     wave::ICPMatcherParams p;

@@ -213,3 +213,23 @@ def test_sharded_ndt_failing_reduce_aborts_cleanly(wm):
     c.ndt_set_shard(0, 1)
     again = c.ndt_align(res=1.0)
     assert again["rc"] == want["rc"] and np.array_equal(again["T"], want["T"])
+
+
+def test_unchanged_target_keeps_its_voxel_model(wm, ctx):
+    """PCL's setInputTarget builds the voxel grid once (wave_matching/src/ndt.cpp:53-56): a second
+    align on the same target launches no voxel-statistics kernels; a new target does."""
+    import ctypes as C
+    ref, tgt, _ = synth.pair(30000, seed=21, mode="resample")
+    ctx.set_target(tgt)
+    assert wm.lib().wm_ndt_build_model(ctx._h, C.c_double(1.0)) == 0
+    ctx.set_source(ref)
+    a = ctx.ndt_align(res=1.0, step_size=0.1, max_iter=15)
+    ctx.set_source(ref)
+    b = ctx.ndt_align(res=1.0, step_size=0.1, max_iter=15)
+    assert a["model_builds"] == 1 and b["model_builds"] == 1
+    assert np.array_equal(a["T"], b["T"])
+    ctx.set_target(tgt)
+    c = ctx.ndt_align(res=1.0, step_size=0.1, max_iter=15)
+    assert c["model_builds"] == 2 and np.array_equal(a["T"], c["T"])
+    d = ctx.ndt_align(res=2.0, step_size=0.1, max_iter=15)  # another resolution: another model
+    assert d["model_builds"] == 3
