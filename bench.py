@@ -3,17 +3,23 @@
 
   metric : point-cloud registrations/sec (1M<->1M pts, ICP, 50 iterations)
   step   : ONE full registration through the C ABI with both clouds already resident
-           in HBM: wm_set_source (Morton order) + wm_set_target (grid build) +
-           wm_icp_align (50 forced iterations: correspondence search, statistics
-           reduction, Umeyama solve, all on device).
-  N > 1  : one process per GPU (torch.distributed / RCCL).  The registration is sharded:
-           every rank indexes one x-slab of the target (+ max_corr halo), handles the
-           source points that fall into its slab, and the 32-double statistics block is
-           all-reduced once per iteration (weak scaling: N x 1M points per cloud).
+           in HBM ("device-resident"): wm_set_source (pack, Morton order) + wm_set_target
+           (pack, grid ladder) + wm_icp_align (50 forced iterations: correspondence search
+           with the iteration's statistics fused into its tail, row reduction, Umeyama
+           solve, all on device).  The same registration from HOST clouds (H2D inside the
+           step, pageable and pinned) is reported beside it in config.host_clouds; it is
+           never `value`.
+  N > 1  : one process per GPU.  The registration is sharded INSIDE the library
+           (wm_icp_align_sharded, libwave_amd/csrc/wm_shard.hip): slab planning on the
+           device, the iteration loop in C++, one ncclAllReduce (RCCL over xGMI) of 32
+           doubles per iteration on the context's stream.  torch.distributed only carries
+           the 128-byte RCCL id to the ranks and the barriers around the timed region.
+           Weak scaling: N x 1M points per cloud.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with two extra
-objects: "roofline" (correspondence kernel vs the HBM roof) and "cpu_baseline"
-(the CPU oracle timed on this box's host cores, N == 1 only).
+Prints ONE JSON line on rank 0 (contract in the task statement), with extra objects:
+"roofline" (correspondence kernel vs the HBM roof), "cpu_baseline" (the CPU oracle timed on
+this box's host cores: 1 core, and the MultiMatcher pattern on all usable cores) and
+"other_configs" (BASELINE configs[2] GICP 500k and configs[3] NDT 2M) -- N == 1 only.
 """
 import argparse
 import json
@@ -26,6 +32,7 @@ import os
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ.setdefault(_v, "4")
 import sys
+import threading
 import time
 
 import numpy as np
@@ -33,7 +40,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s copy-measured)
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s copy-measured)
+F64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector FP64 (half the 157.3 TFLOP/s FP32 vector rate)
 
 
 def parse():
@@ -45,14 +53,50 @@ def parse():
     ap.add_argument("--iters", type=int, default=50, help="forced ICP iterations per registration")
     ap.add_argument("--max-corr", type=float, default=3.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=20, help="oracle iterations timed for the baseline")
     return ap.parse_args()
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, cut by the container's CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_description():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    flags = "unknown"
+    try:
+        for line in open(os.path.join(ROOT, "oracle", "Makefile")):
+            if line.startswith("CFLAGS"):
+                flags = line.split("=", 1)[1].strip()
+    except Exception:
+        pass
+    return {"cpu_model": model, "logical_cpus": os.cpu_count(), "usable_cpus": usable_cpus(),
+            "compiler": "gcc", "flags": flags}
+
+
 def cpu_baseline(ref, tgt, iters_full, max_corr, cpu_iters):
-    """The CPU oracle (oracle/: kd-tree exact NN + Umeyama, single thread like PCL) on a
-    bounded sample of the same workload: tree build + `cpu_iters` iterations are timed,
-    then scaled to the `iters_full`-iteration registration."""
+    """The CPU oracle (oracle/: kd-tree exact NN + Umeyama, single thread like PCL) on a bounded
+    sample of the same workload.  (i) one core: tree build + `cpu_iters` iterations timed, scaled to
+    the `iters_full`-iteration registration.  (ii) the reference's own parallelism -- MultiMatcher,
+    one independent registration per thread (multi_matcher.hpp:32) -- on all usable cores: every
+    thread builds its tree and runs 2 iterations of the same pair at the same time (memory-bandwidth
+    and cache contention included), scaled the same way."""
     from oracle import oracle_py as O
     O.lib()
     t0 = time.perf_counter()
@@ -63,14 +107,41 @@ def cpu_baseline(ref, tgt, iters_full, max_corr, cpu_iters):
     t_run = time.perf_counter() - t0
     per_iter = max(t_run - t_build, 1e-9) / cpu_iters
     t_full = t_build + per_iter * iters_full
-    return {
+    out = {
         "value": 1.0 / t_full, "unit": "registrations/s", "cores": 1, "kind": "port",
         "sample": "same %d<->%d clouds; kd-tree build (%.2f s) + %d of %d iterations timed "
                   "(%.3f s/iter), scaled to %d iterations" % (len(ref), len(tgt), t_build,
                                                               cpu_iters, iters_full, per_iter,
                                                               iters_full),
-        "seconds_per_registration": t_full, "host_cpus": os.cpu_count(),
+        "seconds_per_registration": t_full, "host": cpu_description(),
     }
+    nthr = usable_cpus()
+    if nthr > 1:
+        it_a, it_b = 1, 3
+        walls = {}
+
+        def worker(k, iters):
+            t = time.perf_counter()
+            O.icp_align(ref, tgt, max_corr=max_corr, force_iterations=iters)
+            walls[(k, iters)] = time.perf_counter() - t
+        for iters in (it_a, it_b):
+            th = [threading.Thread(target=worker, args=(k, iters)) for k in range(nthr)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+        wa = float(np.mean([walls[(k, it_a)] for k in range(nthr)]))
+        wb = float(np.mean([walls[(k, it_b)] for k in range(nthr)]))
+        it_c = max((wb - wa) / (it_b - it_a), 1e-9)   # one iteration, all cores busy
+        build_c = max(wa - it_a * it_c, 0.0)           # one tree build, all cores busy
+        t_reg = build_c + it_c * iters_full
+        out["all_cores"] = {
+            "value": nthr / t_reg, "unit": "registrations/s", "cores": nthr,
+            "pattern": "MultiMatcher: one independent registration per thread, %d threads" % nthr,
+            "sample": "every thread: tree build + %d, then + %d iterations of the same pair, concurrently; "
+                      "%.2f s build, %.3f s/iter under load, scaled to %d iterations" % (it_a, it_b, build_c, it_c,
+                                                                                        iters_full),
+            "seconds_per_registration_per_thread": t_reg,
+        }
+    return out
 
 
 def measured_copy_bandwidth(torch, dev):
@@ -94,19 +165,116 @@ def measured_copy_bandwidth(torch, dev):
     return 2.0 * n * 4 / (ms * 1e-3) / 1e9
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per launch of the correspondence kernel from the committed PMC summary
-    (profiles/pmc_latest.json, written by scripts/gpu_pmc.sh + scripts/pmc_to_json.py from
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same bench command).
-    FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B for wide
-    coalesced 16-B/lane reads); WRITE_SIZE is taken as reported.  None if not available."""
-    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+def pmc_summary():
+    """Committed PMC summary of this bench command (profiles/pmc_latest.json, written by
+    scripts/gpu_pmc.sh + scripts/pmc_to_json.py from separate rocprofv3 --pmc passes)."""
     try:
-        with open(path) as f:
-            d = json.load(f)["k_nn_grid"]
-        return (2.0 * d["FETCH_SIZE_kb_per_dispatch"] + d["WRITE_SIZE_kb_per_dispatch"]) * 1024.0
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            return json.load(f)
     except Exception:
+        return {}
+
+
+def pmc_traffic_bytes(pmc):
+    """HBM bytes per launch of the correspondence kernel: FETCH_SIZE doubled (MI355X_MICROARCH.md:
+    gfx950 tallies 128-B requests at 64 B for wide coalesced reads) + WRITE_SIZE as reported."""
+    d = pmc.get("k_nn_grid")
+    if not d or "FETCH_SIZE_kb_per_dispatch" not in d:
         return None
+    return (2.0 * d["FETCH_SIZE_kb_per_dispatch"] + d["WRITE_SIZE_kb_per_dispatch"]) * 1024.0
+
+
+def other_configs(torch, dev, capi, synth, pmc, with_cpu):
+    """BASELINE configs[2] (GICP 500k<->500k) and configs[3] (NDT 2M, 0.5 m voxels): ms per
+    registration (device-resident clouds), the dominant kernel against its roof, and the CPU oracle
+    at a size it finishes in seconds."""
+    out = []
+    os.environ["WM_GICP_PROFILE"] = "1"
+    os.environ["WM_NDT_PROFILE"] = "1"
+    prof = capi.Context(0)   # event timing around every objective / derivative kernel (slower host side)
+    del os.environ["WM_GICP_PROFILE"], os.environ["WM_NDT_PROFILE"]
+    ctx = capi.Context(0)
+
+    def median_ms(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return float(np.median(ts)), r
+
+    # ---- configs[2]
+    n = 500_000
+    ref, tgt, T_gt = synth.pair(n, seed=42)
+    d_ref, d_tgt = torch.from_numpy(ref).to(dev), torch.from_numpy(tgt).to(dev)
+
+    def gicp(c):
+        c.set_source(d_ref)
+        c.set_target(d_tgt)
+        return c.gicp_align()
+    ms, r = median_ms(lambda: gicp(ctx))
+    rp = gicp(prof)
+    ev = max(rp["evaluations"], 1)
+    us = rp["fdf_kernel_ms"] / ev * 1e3
+    bytes_eval = 112.0 * n  # 16 source + 16 match + 8 key + 72 Mahalanobis per pair
+    e = {"config": "GICPMatcher 500k<->500k, k = 10 covariances (BASELINE configs[2])",
+         "ms_per_registration": ms, "registrations_per_s": 1e3 / ms, "outer_iterations": r["iterations"],
+         "objective_evaluations": r["evaluations"],
+         "translation_error_m": float(np.linalg.norm(r["T"][:3, 3] - T_gt[:3, 3])) if r["T"] is not None else None,
+         "roofline": {"bound": "hbm", "kernel": "wm::k_gicp_fdf (objective + gradient, one per BFGS evaluation)",
+                      "achieved": bytes_eval / (us * 1e-6) / 1e9 if us > 0 else None, "peak": HBM_PEAK_GBS,
+                      "unit": "GB/s", "frac": bytes_eval / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us > 0 else None,
+                      "algorithmic_bytes_per_launch": bytes_eval, "avg_launch_us": us, "launches_timed": ev}}
+    if with_cpu:
+        from oracle import oracle_py as O
+        m = 20_000
+        rs, ts_, _ = synth.pair(m, seed=42)
+        t0 = time.perf_counter()
+        O.gicp_align(rs, ts_)
+        e["cpu_baseline"] = {"seconds_per_registration": time.perf_counter() - t0, "cores": 1, "kind": "port",
+                             "sample": "the oracle's GICP on a %d<->%d pair of the same scene (the 500k pair takes minutes)" % (m, m)}
+    out.append(e)
+    del d_ref, d_tgt
+
+    # ---- configs[3]
+    n = 2_000_000
+    ref, tgt, T_gt = synth.pair(n, seed=42, pattern="rings")
+    d_ref, d_tgt = torch.from_numpy(ref).to(dev), torch.from_numpy(tgt).to(dev)
+
+    def ndt(c):
+        c.set_source(d_ref)
+        c.set_target(d_tgt)
+        return c.ndt_align(res=0.5)
+    ms, r = median_ms(lambda: ndt(ctx))
+    rp = ndt(prof)
+    ev = max(rp["evaluations"], 1)
+    us = rp["deriv_kernel_ms"] / ev * 1e3
+    e = {"config": "NDTMatcher 2M-point 64-ring scan pair, 0.5 m voxels (BASELINE configs[3])",
+         "ms_per_registration": ms, "registrations_per_s": 1e3 / ms, "iterations": r["iterations"],
+         "derivative_passes": r["evaluations"], "n_voxels": r["n_voxels"],
+         "translation_error_m": float(np.linalg.norm(r["T"][:3, 3] - T_gt[:3, 3])) if r["T"] is not None else None}
+    fl = pmc.get("k_ndt_derivs", {}).get("f64_flops_per_source_point")
+    roof = {"bound": "f64-valu", "kernel": "wm::k_ndt_derivs (score + gradient + Hessian passes, averaged)",
+            "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "avg_launch_us": us, "launches_timed": ev,
+            "flops_per_source_point": fl, "flops_source": pmc.get("tag")}
+    if fl and us > 0:
+        roof["achieved"] = fl * n / (us * 1e-6) / 1e12
+        roof["frac"] = roof["achieved"] / F64_VALU_PEAK_TFLOPS
+    e["roofline"] = roof
+    if with_cpu:
+        from oracle import oracle_py as O
+        m = 100_000
+        rs, ts_, _ = synth.pair(m, seed=42, pattern="rings")
+        t0 = time.perf_counter()
+        O.ndt_align(rs, ts_, res=0.5)
+        e["cpu_baseline"] = {"seconds_per_registration": time.perf_counter() - t0, "cores": 1, "kind": "port",
+                             "sample": "the oracle's NDT on a %d<->%d pair of the same scene" % (m, m)}
+    out.append(e)
+    ctx.close()
+    prof.close()
+    return out
 
 
 def main():
@@ -124,6 +292,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     force_sharded = os.environ.get("WM_BENCH_FORCE_SHARDED") == "1"  # plumbing check at N=1
+    if force_sharded:
+        os.environ["WM_SHARD_FORCE"] = "1"
     if world > 1 or (force_sharded and "RANK" in os.environ):
         # (a one-rank group under torch.distributed.run still sends every iteration's block
         # through RCCL: the whole N > 1 code path on a single GPU)
@@ -142,28 +312,29 @@ def main():
     # world == 1 is the plain 1M<->1M pair of BASELINE configs[1]
     ref, tgt, T_gt = synth.pair_tiled(a.points, world, seed=42)
     dev = torch.device("cuda", local_rank)
+    d_ref = torch.from_numpy(ref).to(dev)
+    d_tgt = torch.from_numpy(tgt).to(dev)
+    ctx = capi.Context(local_rank)
+    comm = None
+    torch.cuda.synchronize()
 
-    if world == 1 and not force_sharded:
-        d_ref = torch.from_numpy(ref).to(dev)
-        d_tgt = torch.from_numpy(tgt).to(dev)
-        ctx = capi.Context(local_rank)
-        torch.cuda.synchronize()
-
-        def step(profile):
-            ctx.set_source(d_ref)
-            ctx.set_target(d_tgt)
+    if dist is None:
+        def step(profile, r_=d_ref, t_=d_tgt):
+            ctx.set_source(r_)
+            ctx.set_target(t_)
             return ctx.icp_align(max_corr=a.max_corr, force_iterations=a.iters,
                                  nn_method=capi.WM_NN_GRID, profile=profile, carry_state=0)
         parallelism = "single"
     else:
-        from libwave_amd import sharding
-        eng = sharding.GpuShardEngine(local_rank, ref, tgt, rank, world, a.max_corr)
-        drv = sharding.ShardedIcp(eng, dist, dev)
+        # the RCCL id: made by rank 0, handed to every rank (the one thing torch.distributed carries)
+        uid = [capi.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = capi.Comm.init_rank(local_rank, uid[0], rank, world)
 
         def step(profile):
-            eng.rebuild()
-            return drv.align(max_corr=a.max_corr, force_iterations=a.iters, profile=profile)
-        parallelism = "target-slab x%d + all-reduce(32 f64)/iter" % world
+            return ctx.icp_align_sharded(comm, d_ref, d_tgt, max_corr=a.max_corr, force_iterations=a.iters,
+                                         nn_method=capi.WM_NN_GRID, profile=profile, carry_state=0)
+        parallelism = "target x-slabs x%d + ncclAllReduce(32 f64)/iteration inside the library" % world
 
     for _ in range(a.warmup):
         r = step(1)
@@ -176,9 +347,9 @@ def main():
     step_ms = []
     for k in range(a.steps):
         # HIP events around every launch of the correspondence kernel cost a barrier packet
-        # each, so they bracket the launches of ONE timed step in three (at least the last);
-        # the others run exactly as a caller's registration would
-        timed = (k % 3 == 2) or k == a.steps - 1
+        # each (~0.4 ms per registration), so they bracket the launches of ONE timed step in five
+        # (at least the last); the others run exactly as a caller's registration would
+        timed = (k % 5 == 4) or k == a.steps - 1
         t_step = time.perf_counter()
         r = step(1 if timed else 0)
         step_ms.append((time.perf_counter() - t_step) * 1e3)  # (align blocks: host time = step time)
@@ -205,6 +376,7 @@ def main():
         pts_per_launch = a.points  # queries handled by one rank's launch
         alg_bytes = 32.0 * pts_per_launch  # 12N + 12M + 8N with N = M
         achieved = alg_bytes / (nn_us * 1e-6) / 1e9 if nn_us > 0 else 0.0
+        pmc = pmc_summary() if world == 1 else {}
         out = {
             "metric": "point-cloud registrations/sec (1M<->1M pts, ICP)",
             "value": value, "unit": "registrations/s", "n_gpus": world, "steps": a.steps,
@@ -212,11 +384,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "ICPMatcher %d<->%d synthetic XYZ clouds (BASELINE configs[%d]), "
-                            "%d forced iterations, max_corr=%g, res=-1; step = set_source + "
-                            "set_target (index build) + align" % (n_total, n_total,
-                                                                 1 if world == 1 else 4,
-                                                                 a.iters, a.max_corr),
+                "workload": "ICPMatcher %d<->%d synthetic XYZ clouds (BASELINE configs[%d]), DEVICE-RESIDENT "
+                            "(both clouds in HBM before the timed region), %d forced iterations, max_corr=%g, "
+                            "res=-1; step = set_source + set_target (index build) + align" % (
+                                n_total, n_total, 1 if world == 1 else 4, a.iters, a.max_corr),
                 "arithmetic": "f32 points and distances, f64 reductions and solve",
                 "scene": "base scene x%d tiled along x at constant density; T_gt rotation / %d" % (world, world),
                 "points_per_cloud_total": n_total, "points_per_gpu": a.points,
@@ -224,28 +395,50 @@ def main():
                 "registrations_per_s_raw": regs_per_s_raw,
                 "icp_iterations_per_s": regs_per_s_raw * a.iters,
                 "final_translation_error_m": err_t, "grid_cell_m": r.get("grid_cell"),
-                "deferred_queries_per_registration": r.get("deferred"),
                 "ms_each_step_rank0": [round(t, 3) for t in step_ms],
             },
             "roofline": {
-                "bound": "hbm", "kernel": "wm::k_nn_grid (correspondence search)",
+                "bound": "hbm", "kernel": "wm::k_nn_grid (correspondence search + the iteration's statistics)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_bytes() if world == 1 else None,
+                "traffic": pmc_traffic_bytes(pmc) if world == 1 else None,
+                "traffic_source": ("profiles/pmc_latest.json, tag %s (separate rocprofv3 --pmc passes of this "
+                                   "command; a committed measurement, not this run's)" % pmc.get("tag")) if pmc else None,
                 "peak_measured_copy": measured_copy_bandwidth(torch, dev) if world == 1 else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_us": nn_us, "launches_timed": nn_launches,
-                "note": "the kernel streams 64 B/point (source, previous key + match in; key + match "
-                        "out) and gathers its candidates out of L1/L2 (hit rate ~89 %); per-iteration "
-                        "PMC (profiles/r01d_pmc_k_nn_grid_per_iteration.csv): VALU ~50 % and texture "
-                        "addresser ~59 % busy, ~66 % of lanes active -- a dependent chain of small "
-                        "gathers, not an HBM stream",
+                "note": "an exact gather search: the kernel streams 64 B/point (source, previous key + match in; "
+                        "key + match out) and takes its candidates out of L1/L2; what binds is the vector ALU and "
+                        "the L1 address path of the candidate walk (DESIGN.md section 4.1 / 5, "
+                        "profiles/r02*_pmc_k_nn_grid_per_iteration.csv), not HBM",
             },
         }
+        if world == 1:
+            # the same registration from HOST clouds: H2D of both clouds inside the step
+            hc = {}
+            for name, (hr, ht) in (("pageable", (ref, tgt)),
+                                   ("pinned", (torch.from_numpy(ref).pin_memory().numpy(),
+                                               torch.from_numpy(tgt).pin_memory().numpy()))):
+                for _ in range(2):
+                    step(0, hr, ht)
+                ts = []
+                for _ in range(max(3, min(a.steps, 6))):
+                    t1 = time.perf_counter()
+                    step(0, hr, ht)
+                    ts.append((time.perf_counter() - t1) * 1e3)
+                hc[name] = {"ms_per_registration": float(np.median(ts)), "registrations_per_s": 1e3 / float(np.median(ts))}
+            hc["note"] = "wm_set_source / wm_set_target with WM_MEM_HOST: 2 x 16 MB cross PCIe inside the step"
+            out["config"]["host_clouds"] = hc
+        if world == 1 and not a.no_other_configs:
+            out["other_configs"] = other_configs(torch, dev, capi, synth, pmc, not a.no_cpu_baseline)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ref, tgt, a.iters, a.max_corr, a.cpu_iters)
             out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            if "all_cores" in out["cpu_baseline"]:
+                out["config"]["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline"]["all_cores"]["value"]
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -296,6 +296,10 @@ struct BalLds {                // per wavefront
     float4 q[64];                   // the queries
     unsigned long long base[64];    // address of the point array (level) each query scans
     unsigned long long best[64];    // running arg-min per query
+    // values a lane needs again only after its search (the key it started from, its seed's
+    // coordinates): parked here instead of in five registers the compiler would spill to scratch
+    unsigned long long seeded[64];
+    float bq[3][64];
 };
 
 // inclusive prefix sum over the 64 lanes (DPP row shifts inside rows of 16, then the row totals
@@ -312,6 +316,15 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
 
 // ubase: the point array all live lanes scan when they are on the same level (the usual case),
 // nullptr when the levels differ (then L.base[owner] says which)
+template <bool B>
+struct BalHolder {
+    BalLds v;
+};
+template <>
+struct BalHolder<false> {
+    int unused;
+};
+
 template <bool COST, int RC>
 __device__ __forceinline__ void balanced_walk(BalLds &L, const unsigned (&rs)[RC],
                                               const unsigned (&re)[RC], unsigned lane,
@@ -618,6 +631,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
     unsigned cost = 0;
     // per wave: [run][lane] = each lane's pending runs (lane scan), or the pooled trip list (balanced walk)
     __shared__ uint2 s_runs[BAL ? 1 : kRowChunk * 64];
+    __shared__ BalHolder<BAL> s_hold;
     const bool rev = (xcd_chunk >> 31) != 0u;  // experiment: hand the queries out back to front
     const unsigned chunk_sz = xcd_chunk & 0x7FFFFFFFu;
     const unsigned bidx = rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
@@ -677,9 +691,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
         heavy = r > r_light;
     }
     if constexpr (BAL) {
-        __shared__ BalLds s_bal;
-        BalLds &L = s_bal;
+        BalLds &L = s_hold.v;
         L.q[lane] = make_float4(qx, qy, qz, 0.f);
+        // parked until the search is over (see BalLds)
+        L.seeded[lane] = seeded;
+        L.bq[0][lane] = bqx;
+        L.bq[1][lane] = bqy;
+        L.bq[2][lane] = bqz;
+        asm volatile("" ::: "memory");
         bool live = mine && !heavy;
         for (int pass = 0; pass < 32 && __ballot(live) != 0ull; ++pass) {
             int l = 0;
@@ -756,8 +775,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
         seed = ((unsigned) ub != kNoIdx) ? 1.25f * sqrtf(__uint_as_float((unsigned) (ub >> 32))) : ur;
         if ((int) lane == sl) best = ub;
     }
+    // (the lane number and the query index are formed again here, from mbcnt: kept from the top of
+    // the kernel they -- and the LDS addresses derived from them -- were three registers the
+    // compiler spilled to scratch, 16 MB of extra writes and reads per launch)
+    const unsigned lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const unsigned i_e = BAL ? row * 64u + lane_e : i;
+    if constexpr (BAL) {
+        asm volatile("" ::: "memory");
+        BalLds &L = s_hold.v;
+        seeded = L.seeded[lane_e];
+        bqx = L.bq[0][lane_e];
+        bqy = L.bq[1][lane_e];
+        bqz = L.bq[2][lane_e];
+    }
     if (mine) {
-        keys[i] = best;
+        keys[i_e] = best;
         // the match's coordinates ride along for the statistics kernel and for the next
         // iteration's seed; a new winner's are read from the caller-ordered target copy
         // (its key carries the original index)
@@ -767,11 +799,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
             bqy = c.y;
             bqz = c.z;
         }
-        match_pt[i] = make_float4(bqx, bqy, bqz, 0.f);
+        match_pt[i_e] = make_float4(bqx, bqy, bqz, 0.f);
     }
     if (lane == 0 && n_heavy) atomicAdd(&st->queue_count[1], n_heavy);  // stats only
     if constexpr (COST) {
-        if (active) cost_out[i] = mine ? (cost | (heavy ? 0x80000000u : 0u)) : 0u;
+        if (active) cost_out[i_e] = mine ? (cost | (heavy ? 0x80000000u : 0u)) : 0u;
     }
     if constexpr (STATS >= 0) {
         // this lane's terms (same arithmetic as k_icp_stats, wm_icp.hip)

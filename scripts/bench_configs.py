@@ -76,7 +76,7 @@ def run_gicp(ctx, dev, timed, synth, torch):
 
 
 def run_ndt(ctx, dev, timed, synth, torch):
-    ref, tgt, T_gt = synth.pair(2_000_000, seed=42)
+    ref, tgt, T_gt = synth.pair(2_000_000, seed=42, pattern="rings")  # 64-ring lidar sampling (KITTI-like)
     d_ref, d_tgt = torch.from_numpy(ref).to(dev), torch.from_numpy(tgt).to(dev)
 
     calls = []  # per-call wall time of every C-ABI call (ms), to spot a one-off slow call

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun): everything profiles/ holds for one tag, in one call --
+# kernel stats of the bench command, its PMC passes, the per-iteration PMC of the search kernel,
+# and the NDT derivative kernel's SQ / f64 counters.     usage: scripts/gpu_capture_all.sh <tag>
+set -u
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$ROOT"
+bash scripts/gpu_profile.sh ${TAG}_stats > /dev/null 2>&1
+bash scripts/gpu_pmc.sh ${TAG}_pmc > /dev/null 2>&1
+bash scripts/gpu_pmc_detail.sh ${TAG}_detail > /dev/null 2>&1
+bash scripts/gpu_pmc_ndt.sh ${TAG}_ndt > /dev/null 2>&1
+python scripts/pmc_to_json.py gpurun_out/${TAG}_pmc gpurun_out/${TAG}_pmc/pmc_latest.json gpurun_out/${TAG}_ndt > /dev/null
+python bench.py > gpurun_out/${TAG}_bench_line_noprof.json 2> /dev/null
+ls gpurun_out/${TAG}_*

@@ -18,11 +18,12 @@ run() {  # name, counters...
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_SALU
 run sq2 SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 run sq3 SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAVES
+run f64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64
 cd "$ROOT"
 python3 - "$OUT" <<'PY'
 import csv, sys, collections, os
 out = sys.argv[1]
-for name in ("sq1", "sq2", "sq3"):
+for name in ("sq1", "sq2", "sq3", "f64"):
     path = os.path.join(out, name + "_counters.csv")
     if not os.path.exists(path):
         print(name, "missing"); continue

@@ -19,5 +19,32 @@ for name in ("fetch", "write", "sq", "tcc"):
         d = out.setdefault(k, {"dispatches": int(dispatches)})
         unit = "_kb" if counter in ("FETCH_SIZE", "WRITE_SIZE") else ""
         d[counter + unit + "_per_dispatch"] = float(per)
+out["tag"] = os.path.basename(os.path.normpath(tag_dir))
+# optional third argument: the NDT counter directory (scripts/gpu_pmc_ndt.sh): f64 flops per source point
+# of the derivative kernel = (ADD + MUL + 2 FMA) wave-instructions x 64 lanes x the active-lane fraction
+if len(sys.argv) > 3:
+    nd = sys.argv[3]
+    tot = {}
+    disp = 0
+    for name in ("f64", "sq2"):
+        path = os.path.join(nd, name + "_summary.csv")
+        if not os.path.exists(path):
+            continue
+        for line in open(path).read().splitlines()[1:]:
+            kernel, dispatches, counter, total, _per = line.rsplit(",", 4)
+            if "k_ndt_derivs" in kernel:
+                tot[counter] = tot.get(counter, 0.0) + float(total)
+                if counter == "SQ_INSTS_VALU_FMA_F64":
+                    disp += int(dispatches)
+    if "SQ_INSTS_VALU_FMA_F64" in tot and disp:
+        # SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 16) is 4.0 with all 64 lanes active
+        lanes = tot.get("SQ_THREAD_CYCLES_VALU", 0.0) / max(tot.get("SQ_ACTIVE_INST_VALU", 0.0) * 64.0, 1.0) \
+            if "SQ_THREAD_CYCLES_VALU" in tot else 1.0
+        winst = tot.get("SQ_INSTS_VALU_ADD_F64", 0) + tot.get("SQ_INSTS_VALU_MUL_F64", 0) + 2 * tot["SQ_INSTS_VALU_FMA_F64"]
+        n_points = float(os.environ.get("NDT_POINTS", "2000000"))
+        out["k_ndt_derivs"] = {"dispatches": disp, "f64_wave_flop_instructions_per_dispatch": winst / disp,
+                               "active_lane_fraction": lanes,
+                               "f64_flops_per_source_point": winst / disp * 64.0 * lanes / n_points,
+                               "source": os.path.basename(os.path.normpath(nd))}
 json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
 print(json.dumps(out.get("k_nn_grid", {}), indent=1))
