@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(kBlock)
                 c[b * 3 + a] = c[a * 3 + b];
             }
     double U[9], S[3], V[9];
-    svd3(c, U, S, V);
+    svd3<false>(c, U, S, V);  // IEEE operations only: the oracle reproduces these matrices bit for bit
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -259,14 +259,29 @@ struct FdfArgs {
     float B[12];  // base_transformation_
 };
 
-// a[0] = sum r^T M r, a[1..3] = sum M r, a[4..12] = sum p_base (M r)^T; count separately
+// Double-double accumulation (error-free TwoSum of every term into a (hi, lo) pair): the thirteen
+// sums come out as the correctly rounded value of the EXACT sum of their terms (up to ~1e-26
+// relative), whatever the order they were added in.  Why it matters here and nowhere else: PCL's
+// BFGS stops at a gradient tolerance of 1e-2 on this objective, evaluated through a float-quantised
+// transform, so a last-bit difference in f or the gradient can flip a line-search branch and move the
+// stopping point by millimetres.  With order-independent sums the CPU oracle (sequential) and this
+// kernel (strided lanes, wave and block trees) agree bit for bit, and so does every decision after.
+__device__ __forceinline__ void dd_add(double &hi, double &lo, double x) {
+    const double s = hi + x;
+    const double bb = s - hi;
+    lo += (hi - (s - bb)) + (x - bb);
+    hi = s;
+}
+
+// a[0] = sum r^T M r, a[1..3] = sum M r, a[4..12] = sum p_base (M r)^T; count separately.
+// partials: [block][kGicpAcc][2] = (hi, lo) pairs
 __global__ void __launch_bounds__(kBlock)
     k_gicp_fdf(const float4 *__restrict__ src, unsigned n,
                const unsigned long long *__restrict__ keys, const float4 *__restrict__ tgt,
                const double *__restrict__ mahal, FdfArgs A, double *__restrict__ partials) {
-    double a[kGicpAcc];
+    double hi[kGicpAcc], lo[kGicpAcc];
 #pragma unroll
-    for (int k = 0; k < kGicpAcc; ++k) a[k] = 0.0;
+    for (int k = 0; k < kGicpAcc; ++k) hi[k] = lo[k] = 0.0;
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         // everything this pair needs is loaded up front (one round trip); an unmatched point
         // (rare) wastes its loads
@@ -284,32 +299,69 @@ __global__ void __launch_bounds__(kBlock)
         double temp[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) temp[r] = M[r * 3] * res[0] + M[r * 3 + 1] * res[1] + M[r * 3 + 2] * res[2];
-        a[0] += res[0] * temp[0] + res[1] * temp[1] + res[2] * temp[2];
+        dd_add(hi[0], lo[0], res[0] * temp[0] + res[1] * temp[1] + res[2] * temp[2]);
         const float pbx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.B[0], p.x), __fmul_rn(A.B[1], p.y)), __fmul_rn(A.B[2], p.z)), A.B[3]);
         const float pby = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.B[4], p.x), __fmul_rn(A.B[5], p.y)), __fmul_rn(A.B[6], p.z)), A.B[7]);
         const float pbz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.B[8], p.x), __fmul_rn(A.B[9], p.y)), __fmul_rn(A.B[10], p.z)), A.B[11]);
         const double pb[3] = {(double) pbx, (double) pby, (double) pbz};
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            a[1 + r] += temp[r];
+            dd_add(hi[1 + r], lo[1 + r], temp[r]);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) a[4 + r * 3 + c] += pb[r] * temp[c];
+            for (int c = 0; c < 3; ++c) dd_add(hi[4 + r * 3 + c], lo[4 + r * 3 + c], pb[r] * temp[c]);
         }
     }
 #pragma unroll
     for (int k = 0; k < kGicpAcc; ++k)
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) a[k] += __shfl_down(a[k], off);
-    __shared__ double lds[kBlock / 64][kGicpAcc];
+        for (int off = 32; off > 0; off >>= 1) {
+            const double h2 = __shfl_down(hi[k], off), l2 = __shfl_down(lo[k], off);
+            dd_add(hi[k], lo[k], h2);
+            lo[k] += l2;
+        }
+    __shared__ double lds[kBlock / 64][kGicpAcc][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0)
 #pragma unroll
-        for (int k = 0; k < kGicpAcc; ++k) lds[wave][k] = a[k];
+        for (int k = 0; k < kGicpAcc; ++k) {
+            lds[wave][k][0] = hi[k];
+            lds[wave][k][1] = lo[k];
+        }
     __syncthreads();
     if (threadIdx.x < kGicpAcc) {
-        double s = 0;
-        for (int w = 0; w < kBlock / 64; ++w) s += lds[w][threadIdx.x];
-        partials[(size_t) blockIdx.x * kGicpAcc + threadIdx.x] = s;
+        double h = 0, l = 0;
+        for (int w = 0; w < kBlock / 64; ++w) {
+            dd_add(h, l, lds[w][threadIdx.x][0]);
+            l += lds[w][threadIdx.x][1];
+        }
+        partials[((size_t) blockIdx.x * kGicpAcc + threadIdx.x) * 2] = h;
+        partials[((size_t) blockIdx.x * kGicpAcc + threadIdx.x) * 2 + 1] = l;
+    }
+}
+
+// The block pairs -> kGicpAcc doubles in pinned memory: one wave per sum adds the rows' (hi, lo)
+// pairs in double-double, lane 0 rounds hi + lo once; then the fence + flag of fast_fetch.
+__global__ void __launch_bounds__(1024)
+    k_gicp_sum_fetch(double *dst, const double *__restrict__ src, unsigned rows, unsigned *flag, unsigned seq) {
+    const unsigned c = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (c < (unsigned) kGicpAcc) {
+        double h = 0, l = 0;
+        for (unsigned r = lane; r < rows; r += 64u) {
+            dd_add(h, l, src[((size_t) r * kGicpAcc + c) * 2]);
+            l += src[((size_t) r * kGicpAcc + c) * 2 + 1];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double h2 = __shfl_down(h, off), l2 = __shfl_down(l, off);
+            dd_add(h, l, h2);
+            l += l2;
+        }
+        if (lane == 0) dst[c] = h + l;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        __threadfence_system();
+        if (threadIdx.x == 0) *(volatile unsigned *) flag = seq;
     }
 }
 
@@ -437,7 +489,10 @@ static double gicp_fdf(GicpFn &F, const double x[6], double g[6]) {
                        n, ctx->keys.as<unsigned long long>(), ctx->match_pt.as<float4>(),
                        ctx->gicp_mahal.as<double>(), A, ctx->partials.as<double>());
     if (ctx->gicp_profile) (void) hipEventRecord(ctx->ev_b, ctx->stream);
-    if (fast_fetch_sum(ctx, ctx->h_gicp, ctx->partials.as<double>(), (unsigned) nb, kGicpAcc) != WM_OK) {
+    if (fast_fetch_custom(ctx, [&](unsigned *flag, unsigned seq) {
+            hipLaunchKernelGGL(k_gicp_sum_fetch, dim3(1), dim3(1024), 0, ctx->stream, ctx->h_gicp,
+                               ctx->partials.as<double>(), (unsigned) nb, flag, seq);
+        }) != WM_OK) {
         F.rc = WM_ERR_HIP;
         return 0;
     }
@@ -454,6 +509,16 @@ static double gicp_fdf(GicpFn &F, const double x[6], double g[6]) {
         for (int k = 0; k < 3; ++k) g[k] = a[1 + k] * 2.0 / m;
         for (int k = 0; k < 9; ++k) Racc[k] = a[4 + k] * 2.0 / m;
         r_derivative(x, Racc, g);
+    }
+    if (const char *path = getenv("WM_GICP_TRACE")) {  // developer: every evaluation, in hex floats
+        if (FILE *fp = fopen(path, "a")) {
+            fprintf(fp, "%d", F.m);
+            for (int k = 0; k < 6; ++k) fprintf(fp, " %a", x[k]);
+            fprintf(fp, " | %a |", a[0] / m);
+            if (g) for (int k = 0; k < 6; ++k) fprintf(fp, " %a", g[k]);
+            fprintf(fp, "\n");
+            fclose(fp);
+        }
     }
     return a[0] / m;
 }
@@ -829,7 +894,7 @@ int wm_gicp_align(wm_ctx *ctx, const wm_gicp_params *prm, double T_out[16], wm_g
     WM_TRY(compute_covariances(ctx, prm->corr_rand, prm->gicp_epsilon));
     const size_t n = ctx->n_src;
     WM_HIP(ctx, ctx->gicp_mahal.reserve(n * 9 * sizeof(double)));
-    WM_HIP(ctx, ctx->partials.reserve((size_t) kGicpBlocksMax * kGicpAcc * sizeof(double) + 64));
+    WM_HIP(ctx, ctx->partials.reserve((size_t) kGicpBlocksMax * kGicpAcc * 2 * sizeof(double) + 64));
     const float thr = threshold_d2_strict(prm->max_corr);
     double base[16];
     mat4_identity(base);
@@ -906,7 +971,7 @@ int wm_gicp_eval(wm_ctx *ctx, const wm_gicp_params *prm, const double T_pair[16]
     WM_TRY(compute_covariances(ctx, prm->corr_rand, prm->gicp_epsilon));
     const size_t n = ctx->n_src;
     WM_HIP(ctx, ctx->gicp_mahal.reserve(n * 9 * sizeof(double)));
-    WM_HIP(ctx, ctx->partials.reserve((size_t) kGicpBlocksMax * kGicpAcc * sizeof(double) + 64));
+    WM_HIP(ctx, ctx->partials.reserve((size_t) kGicpBlocksMax * kGicpAcc * 2 * sizeof(double) + 64));
     double Td[16];
     Mat3d R;
     for (int i = 0; i < 16; ++i) Td[i] = (double) (float) T_pair[i];

@@ -568,6 +568,18 @@ static int wait_flag(wm_ctx *ctx, unsigned seq) {
     return WM_OK;
 }
 
+int fast_fetch_begin(wm_ctx *ctx, unsigned **flag, unsigned *seq) {
+    if (!ctx->h_sig) {
+        WM_HIP(ctx, hipHostMalloc((void **) &ctx->h_sig, 64, hipHostMallocDefault));
+        *ctx->h_sig = 0;
+    }
+    *flag = ctx->h_sig;
+    *seq = ++ctx->sig_seq;
+    return WM_OK;
+}
+
+int fast_fetch_wait(wm_ctx *ctx, unsigned seq) { return wait_flag(ctx, seq); }
+
 int fast_fetch(wm_ctx *ctx, void *dst_pinned, const void *src_dev, size_t bytes) {
     if (bytes & 3) return WM_ERR_ARG;
     if (!ctx->h_sig) {

@@ -254,6 +254,18 @@ int ensure_levels(wm_ctx *ctx, double max_corr);
 int fast_fetch(wm_ctx *ctx, void *dst_pinned, const void *src_dev, size_t bytes);
 // column sums of a [rows][k] f64 block (k <= 32), reduced on the device, k doubles delivered
 int fast_fetch_sum(wm_ctx *ctx, double *dst_pinned, const double *src_dev, unsigned rows, unsigned k);
+// a caller-supplied producer kernel that ends with fast_fetch's fence + flag protocol (it gets the
+// flag's address and the sequence number to write); waits for it
+int fast_fetch_begin(wm_ctx *ctx, unsigned **flag, unsigned *seq);
+int fast_fetch_wait(wm_ctx *ctx, unsigned seq);
+template <class Launch>
+inline int fast_fetch_custom(wm_ctx *ctx, Launch launch) {
+    unsigned *flag = nullptr, seq = 0;
+    WM_TRY(fast_fetch_begin(ctx, &flag, &seq));
+    launch(flag, seq);
+    WM_HIP(ctx, hipGetLastError());
+    return fast_fetch_wait(ctx, seq);
+}
 // the same column sums left in DEVICE memory (no signal): what an all-reduce then works on
 int sum_to_device(wm_ctx *ctx, double *dst_dev, const double *src_dev, unsigned rows, unsigned k);
 // ---- wm_shard.hip: sum `n` doubles in device memory over the ranks of `comm`, on the context's stream

@@ -75,7 +75,11 @@ WM_HD double fast_rcp(double x) {
     return 1.0 / x;
 #endif
 }
-template <int I, int J>
+// FAST: the reciprocal / square-root estimates above (the ICP solve, one GPU lane).  !FAST: IEEE
+// divisions and square roots only -- every operation correctly rounded, so the CPU oracle, which
+// states the same algorithm in the same order (oracle/linalg.c: wmo_svd3_jacobi), reproduces the
+// result bit for bit (the GICP covariances, whose last bits steer PCL's loosely converged BFGS).
+template <int I, int J, bool FAST>
 WM_HD bool jacobi_pair(double *W, double *V) {
     double alpha = 0, beta = 0, gamma = 0;
 #pragma unroll
@@ -92,7 +96,7 @@ WM_HD bool jacobi_pair(double *W, double *V) {
     const double d = beta - alpha, g = 2.0 * gamma;
     const double h2 = d * d + g * g;
     double t, c;
-    if (h2 > 1e-280 && h2 < 1e280) {
+    if (FAST && h2 > 1e-280 && h2 < 1e280) {
         const double hyp = h2 * fast_rsqrt(h2);
         const double ta = fabs(g) * fast_rcp(fabs(d) + hyp);
         t = ((d >= 0) == (g >= 0)) ? ta : -ta;
@@ -135,6 +139,7 @@ WM_HD void swap_cols_if_less(double *sv, double *W, double *V) {  // ensure sv[I
 // V0 (may be null): an orthogonal matrix to start from -- the V of a nearby matrix's SVD (the
 // previous ICP iteration's): the columns of A V0 are then almost orthogonal already and one sweep
 // plus the checking sweep do, instead of five or six.
+template <bool FAST = true>
 WM_HD void svd3(const double *A, double *U, double *S, double *V, const double *V0 = nullptr) {
     double W[9];
     if (V0) {
@@ -153,16 +158,16 @@ WM_HD void svd3(const double *A, double *U, double *S, double *V, const double *
         }
     }
     for (int sweep = 0; sweep < 60; ++sweep) {
-        bool r0 = detail::jacobi_pair<0, 1>(W, V);
-        bool r1 = detail::jacobi_pair<0, 2>(W, V);
-        bool r2 = detail::jacobi_pair<1, 2>(W, V);
+        bool r0 = detail::jacobi_pair<0, 1, FAST>(W, V);
+        bool r1 = detail::jacobi_pair<0, 2, FAST>(W, V);
+        bool r2 = detail::jacobi_pair<1, 2, FAST>(W, V);
         if (!(r0 || r1 || r2)) break;
     }
     double sv[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const double n2 = W[j] * W[j] + W[3 + j] * W[3 + j] + W[6 + j] * W[6 + j];
-        sv[j] = (n2 > 1e-280 && n2 < 1e280) ? n2 * detail::fast_rsqrt(n2) : sqrt(n2);
+        sv[j] = (FAST && n2 > 1e-280 && n2 < 1e280) ? n2 * detail::fast_rsqrt(n2) : sqrt(n2);
     }
     detail::swap_cols_if_less<0, 1>(sv, W, V);
     detail::swap_cols_if_less<0, 2>(sv, W, V);
@@ -171,15 +176,25 @@ WM_HD void svd3(const double *A, double *U, double *S, double *V, const double *
     const bool h0 = (sv[0] > 1e-300);
     const bool h1 = h0 && (sv[1] > 1e-300 && sv[1] > 1e-14 * smax);
     const bool h2 = h1 && (sv[2] > 1e-300 && sv[2] > 1e-14 * smax);
-    // (one reciprocal per column, not one division per entry: this runs in a single GPU lane)
-    const double i0 = h0 ? detail::fast_rcp(sv[0]) : 0.0, i1 = h1 ? detail::fast_rcp(sv[1]) : 0.0,
-                 i2 = h2 ? detail::fast_rcp(sv[2]) : 0.0;
+    if (FAST) {
+        // (one reciprocal per column, not one division per entry: this runs in a single GPU lane)
+        const double i0 = h0 ? detail::fast_rcp(sv[0]) : 0.0, i1 = h1 ? detail::fast_rcp(sv[1]) : 0.0,
+                     i2 = h2 ? detail::fast_rcp(sv[2]) : 0.0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        S[k] = sv[k];
-        U[k * 3 + 0] = W[k * 3 + 0] * i0;
-        U[k * 3 + 1] = W[k * 3 + 1] * i1;
-        U[k * 3 + 2] = W[k * 3 + 2] * i2;
+        for (int k = 0; k < 3; ++k) {
+            S[k] = sv[k];
+            U[k * 3 + 0] = W[k * 3 + 0] * i0;
+            U[k * 3 + 1] = W[k * 3 + 1] * i1;
+            U[k * 3 + 2] = W[k * 3 + 2] * i2;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            S[k] = sv[k];
+            U[k * 3 + 0] = h0 ? W[k * 3 + 0] / sv[0] : 0.0;
+            U[k * 3 + 1] = h1 ? W[k * 3 + 1] / sv[1] : 0.0;
+            U[k * 3 + 2] = h2 ? W[k * 3 + 2] / sv[2] : 0.0;
+        }
     }
     if (!h0) {  // zero matrix
 #pragma unroll

@@ -252,14 +252,17 @@ __device__ inline void ndt_voxel_finish(unsigned slot, unsigned long long cell, 
 // (Grids with up to kVoxWaveAvg points per voxel on average; coarser ones: the wave kernel below.)
 constexpr int kVoxStatBlock = 64;
 constexpr unsigned kVoxWaveAvg = 192;
+constexpr unsigned kVoxLaneMax = 128;  // voxels with more points than this always go to the wave kernel
 __global__ void __launch_bounds__(kVoxStatBlock)
     k_ndt_voxel_stats(const float4 *__restrict__ pts, const unsigned long long *__restrict__ keys,
                       const unsigned *__restrict__ perm, const unsigned *__restrict__ heads,
-                      unsigned nvox, NdtLattice L, NdtVoxel *__restrict__ vox, float4 *__restrict__ meanf,
-                      unsigned long long *__restrict__ vkey, unsigned *__restrict__ n_valid) {
+                      unsigned nvox, unsigned max_count, NdtLattice L, NdtVoxel *__restrict__ vox,
+                      float4 *__restrict__ meanf, unsigned long long *__restrict__ vkey,
+                      unsigned *__restrict__ n_valid) {
     const unsigned slot = blockIdx.x * kVoxStatBlock + threadIdx.x;
     if (slot >= nvox) return;
     const unsigned i = heads[slot], j = heads[slot + 1];
+    if (j - i > max_count) return;  // a crowded voxel: the wave kernel's
     const unsigned long long key = keys[i];
     double s[3] = {0, 0, 0}, pp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 4
@@ -285,8 +288,9 @@ __global__ void __launch_bounds__(kVoxStatBlock)
 __global__ void __launch_bounds__(kBlock)
     k_ndt_voxel_stats_wave(const float4 *__restrict__ pts, const unsigned long long *__restrict__ keys,
                            const unsigned *__restrict__ perm, const unsigned *__restrict__ heads,
-                           unsigned nvox, NdtLattice L, NdtVoxel *__restrict__ vox, float4 *__restrict__ meanf,
-                           unsigned long long *__restrict__ vkey, unsigned *__restrict__ n_valid) {
+                           unsigned nvox, unsigned min_count, NdtLattice L, NdtVoxel *__restrict__ vox,
+                           float4 *__restrict__ meanf, unsigned long long *__restrict__ vkey,
+                           unsigned *__restrict__ n_valid) {
     __shared__ float s_p[kBlock / 64][3][64];
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned waves_total = gridDim.x * (kBlock / 64);
@@ -296,6 +300,7 @@ __global__ void __launch_bounds__(kBlock)
     const bool product = lane >= 3;
     for (unsigned slot = blockIdx.x * (kBlock / 64) + wave; slot < nvox; slot += waves_total) {
         const unsigned i = heads[slot], j = heads[slot + 1];
+        if (j - i < min_count) continue;  // (wave-uniform) a small voxel: the lane kernel's
         double acc = 0.0;
         for (unsigned t = i; t < j; t += 64) {
             if (t + lane < j) {
@@ -697,15 +702,21 @@ static int ndt_build(wm_ctx *ctx, double res) {
         unsigned *heads = p1;  // the sort's input permutation is dead by now
         hipLaunchKernelGGL(k_ndt_heads, dim3(blocks), dim3(kBlock), 0, ctx->stream, k2, flags, seg, (unsigned) n,
                            L.cells, heads);
-        if ((unsigned long long) n > (unsigned long long) kVoxWaveAvg * nvox)
-            hipLaunchKernelGGL(k_ndt_voxel_stats_wave, dim3(nvox < 8192u ? (nvox + 3u) / 4u : 2048u), dim3(kBlock),
-                               0, ctx->stream, pts, k2, p2, heads, nvox, L, ctx->ndt_vox.as<NdtVoxel>(),
-                               ctx->ndt_meanf.as<float4>(), ctx->ndt_vkey.as<unsigned long long>(), d_nvalid);
-        else
+        // Coarse grids go to the wave kernel whole.  Finer ones go to the lane kernel -- except their
+        // crowded voxels: a lidar's rings put thousands of points into the voxels next to the sensor
+        // (1 700 in a 0.5 m voxel of a 2M-point 64-ring scan whose average is 100), and one lane
+        // walking those alone held the whole launch back (552 us; both kernels form the same sums in
+        // the same order, so who takes a voxel does not change the model).
+        const bool coarse = (unsigned long long) n > (unsigned long long) kVoxWaveAvg * nvox;
+        const unsigned split = coarse ? 0u : kVoxLaneMax;
+        if (!coarse)
             hipLaunchKernelGGL(k_ndt_voxel_stats, dim3((nvox + kVoxStatBlock - 1) / kVoxStatBlock),
-                               dim3(kVoxStatBlock), 0, ctx->stream, pts, k2, p2, heads, nvox, L,
+                               dim3(kVoxStatBlock), 0, ctx->stream, pts, k2, p2, heads, nvox, split, L,
                                ctx->ndt_vox.as<NdtVoxel>(), ctx->ndt_meanf.as<float4>(),
                                ctx->ndt_vkey.as<unsigned long long>(), d_nvalid);
+        hipLaunchKernelGGL(k_ndt_voxel_stats_wave, dim3(nvox < 8192u ? (nvox + 3u) / 4u : 2048u), dim3(kBlock), 0,
+                           ctx->stream, pts, k2, p2, heads, nvox, split + 1u, L, ctx->ndt_vox.as<NdtVoxel>(),
+                           ctx->ndt_meanf.as<float4>(), ctx->ndt_vkey.as<unsigned long long>(), d_nvalid);
         hipLaunchKernelGGL(k_ndt_hash_insert, dim3((nvox + kBlock - 1) / kBlock), dim3(kBlock), 0,
                            ctx->stream, ctx->ndt_vkey.as<unsigned long long>(), nvox,
                            ctx->ndt_hkeys.as<unsigned long long>(), ctx->ndt_hvals.as<unsigned>(),

@@ -21,6 +21,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 
 void wmo_gicp_default_params(wmo_gicp_params *p) {
@@ -68,7 +69,7 @@ int wmo_gicp_covariances(const float *xyz, int n, int k, double eps, double *cov
                 cov[a * 3 + b] -= mean[a] * mean[b];
                 cov[b * 3 + a] = cov[a * 3 + b];
             }
-        wmo_svd(3, cov, U, S, V);
+        wmo_svd3_jacobi(cov, U, S, V);
         for (a = 0; a < 9; ++a) out[a] = 0;
         for (j = 0; j < 3; ++j) {
             double v = (j == 2) ? eps : 1.0;
@@ -163,11 +164,26 @@ static void r_derivative(const double x[6], const double Racc[9], double g[6]) {
         }
 }
 
+/* The sums of the objective are formed in double-double (error-free TwoSum of every term into a
+ * (hi, lo) pair, one final rounding): the correctly rounded value of the exact sum of the terms,
+ * whatever the order.  Eigen / PCL add plain doubles in index order; the difference is the last
+ * bit -- but PCL's BFGS stops at a gradient tolerance of 1e-2, and a last-bit difference can flip a
+ * line-search branch and move the stopping point by millimetres.  An order-independent sum is what
+ * lets a parallel implementation (the HIP kernel adds in a strided tree order) make exactly the
+ * decisions this sequential loop makes. */
+static void dd_add(double *hi, double *lo, double x) {
+    const double s = *hi + x;
+    const double bb = s - *hi;
+    *lo += (*hi - (s - bb)) + (x - bb);
+    *hi = s;
+}
+
 double wmo_gicp_fdf(const float *src, const float *tgt, const int *src_idx, const int *tgt_idx,
                     const double *mahal, int m, const double base[16], const double x[6],
                     double g[6]) {
     float T[16], Bf[16];
-    double f = 0, gt[3] = {0, 0, 0}, Racc[9] = {0};
+    double hi[13] = {0}, lo[13] = {0};
+    double f, gt[3], Racc[9];
     int i, a, b;
     state_to_matrix_f(base, x, T);
     for (i = 0; i < 16; ++i) Bf[i] = (float) base[i];
@@ -181,16 +197,19 @@ double wmo_gicp_fdf(const float *src, const float *tgt, const int *src_idx, cons
         res[1] = pp[1] - pt[1];
         res[2] = pp[2] - pt[2];
         for (a = 0; a < 3; ++a) temp[a] = M[a * 3] * res[0] + M[a * 3 + 1] * res[1] + M[a * 3 + 2] * res[2];
-        f += res[0] * temp[0] + res[1] * temp[1] + res[2] * temp[2];
+        dd_add(&hi[0], &lo[0], res[0] * temp[0] + res[1] * temp[1] + res[2] * temp[2]);
         mul_pt_f(Bf, ps, pb);
         for (a = 0; a < 3; ++a) {
-            gt[a] += temp[a];
-            for (b = 0; b < 3; ++b) Racc[a * 3 + b] += (double) pb[a] * temp[b];
+            dd_add(&hi[1 + a], &lo[1 + a], temp[a]);
+            for (b = 0; b < 3; ++b) dd_add(&hi[4 + a * 3 + b], &lo[4 + a * 3 + b], (double) pb[a] * temp[b]);
         }
     }
+    f = hi[0] + lo[0];
+    for (a = 0; a < 3; ++a) gt[a] = hi[1 + a] + lo[1 + a];
+    for (a = 0; a < 9; ++a) Racc[a] = hi[4 + a] + lo[4 + a];
     if (g) {
         for (a = 0; a < 3; ++a) g[a] = gt[a] * 2.0 / m;
-        for (a = 0; a < 9; ++a) Racc[a] *= 2.0 / m;
+        for (a = 0; a < 9; ++a) Racc[a] = Racc[a] * 2.0 / m;
         r_derivative(x, Racc, g);
     }
     return f / m;
@@ -209,8 +228,23 @@ typedef struct {
 } gicp_fn;
 
 static double fn_fdf(gicp_fn *F, const double x[6], double g[6]) {
+    double f;
+    const char *path = getenv("WMO_GICP_TRACE"); /* developer: every evaluation, in hex floats */
     F->evals++;
-    return wmo_gicp_fdf(F->src, F->tgt, F->si, F->ti, F->mahal, F->m, F->base, x, g);
+    f = wmo_gicp_fdf(F->src, F->tgt, F->si, F->ti, F->mahal, F->m, F->base, x, g);
+    if (path) {
+        FILE *fp = fopen(path, "a");
+        if (fp) {
+            int k;
+            fprintf(fp, "%d", F->m);
+            for (k = 0; k < 6; ++k) fprintf(fp, " %a", x[k]);
+            fprintf(fp, " | %a |", f);
+            if (g) for (k = 0; k < 6; ++k) fprintf(fp, " %a", g[k]);
+            fprintf(fp, "\n");
+            fclose(fp);
+        }
+    }
+    return f;
 }
 
 typedef struct {
@@ -495,6 +529,23 @@ static int bfgs_minimize(gicp_fn *F, double x[6], int max_inner, double *f_out) 
     return inner;
 }
 
+/* Eigen's fixed-size 3x3 inverse (Eigen/src/LU/InverseImpl.h: cofactors times 1 / determinant),
+ * which PCL's `(C2 + R C1 R^T).inverse()` resolves to */
+static void inv3_cofactor(const double *m, double *o) {
+    const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8],
+                 c02 = m[3] * m[7] - m[4] * m[6];
+    const double id = 1.0 / (m[0] * c00 + m[1] * c01 + m[2] * c02);
+    o[0] = c00 * id;
+    o[1] = (m[2] * m[7] - m[1] * m[8]) * id;
+    o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c01 * id;
+    o[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+    o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c02 * id;
+    o[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+    o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
 int wmo_gicp_align(const float *src, int n, const float *tgt, int m, const wmo_gicp_params *prm,
                    double T_out[16], wmo_gicp_result *res) {
     double *C1 = (double *) malloc(sizeof(double) * 9 * (n > 0 ? n : 1));
@@ -543,7 +594,7 @@ int wmo_gicp_align(const float *src, int n, const float *tgt, int m, const wmo_g
                         for (c = 0; c < 3; ++c) s += Mx[a * 3 + c] * R[b * 3 + c];
                         tmp[a * 3 + b] = s + c2[a * 3 + b]; /* R*C1*R' + C2 */
                     }
-                wmo_inverse(3, tmp, mahal + 9 * i);
+                inv3_cofactor(tmp, mahal + 9 * i);
                 si[cnt] = i;
                 ti[cnt] = j;
                 ++cnt;
@@ -554,9 +605,11 @@ int wmo_gicp_align(const float *src, int n, const float *tgt, int m, const wmo_g
         x[0] = T[3];
         x[1] = T[7];
         x[2] = T[11];
-        x[3] = atan2(T[9], T[10]);
-        x[4] = asin(-T[8]);
-        x[5] = atan2(T[4], T[0]);
+        /* PCL (C++, <cmath>): unqualified atan2 / asin on Eigen::Matrix4f entries resolve to the
+         * FLOAT overloads; the results are then widened into the Vector6d */
+        x[3] = (double) atan2f(T[9], T[10]);
+        x[4] = (double) asinf(-T[8]);
+        x[5] = (double) atan2f(T[4], T[0]);
         F.src = src;
         F.tgt = tgt;
         F.si = si;

@@ -351,3 +351,112 @@ void wmo_euler_angles_012(const double R[9], double e[3]) {
     e[1] = -e[1];
     e[2] = -e[2];
 }
+
+/* One-sided (Hestenes) Jacobi SVD of a 3x3 matrix, cyclic sweeps over the column pairs (0,1), (0,2),
+ * (1,2): A = U diag(S) V^T, S descending, U completed to an orthonormal basis when A is rank
+ * deficient.  Stated with IEEE operations only and in a fixed order, so that the HIP build of the
+ * same published algorithm (libwave_amd/csrc/wm_math.hpp: svd3<false>) reproduces it bit for bit:
+ * GICP's covariances go through it, and their last bits steer PCL's loosely converged BFGS
+ * (gradient tolerance 1e-2) -- see tests/test_gicp_gpu.py.  (Eigen's JacobiSVD, which PCL calls, is
+ * a two-sided Jacobi with its own operation order: all three agree to ~1e-15.) */
+static int jacobi_pair3(double *W, double *V, int I, int J) {
+    double alpha = 0, beta = 0, gamma = 0, d, g, t, c, s;
+    int k;
+    for (k = 0; k < 3; ++k) {
+        alpha += W[k * 3 + I] * W[k * 3 + I];
+        beta += W[k * 3 + J] * W[k * 3 + J];
+        gamma += W[k * 3 + I] * W[k * 3 + J];
+    }
+    if (fabs(gamma) <= 1e-300 || gamma * gamma <= (2.3e-16 * 2.3e-16) * (alpha * beta)) return 0;
+    d = beta - alpha;
+    g = 2.0 * gamma;
+    t = ((d >= 0) == (g >= 0) ? fabs(g) : -fabs(g)) / (fabs(d) + sqrt(d * d + g * g));
+    c = 1.0 / sqrt(1.0 + t * t);
+    s = c * t;
+    for (k = 0; k < 3; ++k) {
+        const double wi = W[k * 3 + I], wj = W[k * 3 + J];
+        const double vi = V[k * 3 + I], vj = V[k * 3 + J];
+        W[k * 3 + I] = c * wi - s * wj;
+        W[k * 3 + J] = s * wi + c * wj;
+        V[k * 3 + I] = c * vi - s * vj;
+        V[k * 3 + J] = s * vi + c * vj;
+    }
+    return 1;
+}
+
+static void swap_cols3(double *sv, double *W, double *V, int I, int J) { /* ensure sv[I] >= sv[J] */
+    int k;
+    if (sv[J] > sv[I]) {
+        double t = sv[I];
+        sv[I] = sv[J];
+        sv[J] = t;
+        for (k = 0; k < 3; ++k) {
+            t = W[k * 3 + I];
+            W[k * 3 + I] = W[k * 3 + J];
+            W[k * 3 + J] = t;
+            t = V[k * 3 + I];
+            V[k * 3 + I] = V[k * 3 + J];
+            V[k * 3 + J] = t;
+        }
+    }
+}
+
+void wmo_svd3_jacobi(const double *A, double *U, double *S, double *V) {
+    double W[9], sv[3], smax;
+    int i, j, k, sweep, h0, h1, h2;
+    for (i = 0; i < 9; ++i) {
+        W[i] = A[i];
+        V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    }
+    for (sweep = 0; sweep < 60; ++sweep) {
+        const int r0 = jacobi_pair3(W, V, 0, 1);
+        const int r1 = jacobi_pair3(W, V, 0, 2);
+        const int r2 = jacobi_pair3(W, V, 1, 2);
+        if (!(r0 || r1 || r2)) break;
+    }
+    for (j = 0; j < 3; ++j) sv[j] = sqrt(W[j] * W[j] + W[3 + j] * W[3 + j] + W[6 + j] * W[6 + j]);
+    swap_cols3(sv, W, V, 0, 1);
+    swap_cols3(sv, W, V, 0, 2);
+    swap_cols3(sv, W, V, 1, 2);
+    smax = sv[0];
+    h0 = (sv[0] > 1e-300);
+    h1 = h0 && (sv[1] > 1e-300 && sv[1] > 1e-14 * smax);
+    h2 = h1 && (sv[2] > 1e-300 && sv[2] > 1e-14 * smax);
+    for (k = 0; k < 3; ++k) {
+        S[k] = sv[k];
+        U[k * 3 + 0] = h0 ? W[k * 3 + 0] / sv[0] : 0.0;
+        U[k * 3 + 1] = h1 ? W[k * 3 + 1] / sv[1] : 0.0;
+        U[k * 3 + 2] = h2 ? W[k * 3 + 2] / sv[2] : 0.0;
+    }
+    if (!h0) {
+        for (i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        return;
+    }
+    if (!h1) { /* any unit vector orthogonal to u0: drop the smallest component */
+        const double a0 = U[0], a1 = U[3], a2 = U[6];
+        double e0 = 0, e1 = 0, e2 = 0, d, v0, v1, v2, n;
+        if (fabs(a0) <= fabs(a1) && fabs(a0) <= fabs(a2)) {
+            e0 = 1;
+            d = a0;
+        } else if (fabs(a1) <= fabs(a2)) {
+            e1 = 1;
+            d = a1;
+        } else {
+            e2 = 1;
+            d = a2;
+        }
+        v0 = e0 - d * a0;
+        v1 = e1 - d * a1;
+        v2 = e2 - d * a2;
+        n = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
+        U[1] = v0 / n;
+        U[4] = v1 / n;
+        U[7] = v2 / n;
+    }
+    if (!h2) {
+        const double a0 = U[0], a1 = U[3], a2 = U[6], b0 = U[1], b1 = U[4], b2 = U[7];
+        U[2] = a1 * b2 - a2 * b1;
+        U[5] = a2 * b0 - a0 * b2;
+        U[8] = a0 * b1 - a1 * b0;
+    }
+}

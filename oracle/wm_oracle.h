@@ -194,6 +194,8 @@ int wmo_ndt_align(const float *src, int n, const float *tgt, int m,
 /* ----------------------------------------------------------- small linalg */
 /* exposed for unit tests */
 void wmo_svd(int n, const double *A, double *U, double *S, double *V);
+/* one-sided Jacobi SVD of a 3x3, IEEE operations in a fixed order (GICP covariances) */
+void wmo_svd3_jacobi(const double *A, double *U, double *S, double *V);
 void wmo_sym_eig(int n, const double *A, double *evals, double *evecs);
 int wmo_inverse(int n, const double *A, double *Ainv);
 void wmo_umeyama(const float *src, const float *dst, int n, int float_sums, double T[16]);

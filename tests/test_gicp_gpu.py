@@ -19,11 +19,11 @@ def test_gicp_covariances_match_oracle(wm, ctx, oracle, k):
     cs, ct = ctx.gicp_covariances(k=k, eps=1e-3)
     ocs = oracle.gicp_covariances(ref, k=k, eps=1e-3)
     oct_ = oracle.gicp_covariances(tgt, k=k, eps=1e-3)
-    # same neighbours (exact k-NN, (d2, index) order) and same SVD => same matrices;
-    # degenerate neighbourhoods (repeated singular values) have a non-unique basis
+    # same neighbours (exact k-NN, (d2, index) order), same sums, and the same one-sided Jacobi SVD
+    # stated with IEEE operations in the same order on both sides (wm_math.hpp svd3<false> /
+    # oracle/linalg.c wmo_svd3_jacobi): the matrices are BIT-identical
     for got, want in ((cs, ocs), (ct, oct_)):
-        err = np.abs(got - want).reshape(len(got), -1).max(1)
-        assert (err > 1e-9).mean() < 2e-3, (err > 1e-9).mean()
+        assert np.array_equal(got, want), float(np.abs(got - want).max())
         ev = np.linalg.eigvalsh(got[:200])
         np.testing.assert_allclose(ev, np.tile([1e-3, 1, 1], (200, 1)), atol=1e-9)
 
@@ -42,8 +42,7 @@ def test_gicp_covariances_with_nonfinite_target_points(wm, ctx, oracle):
     ctx.set_source(ref)
     ctx.set_target(tgt_nan)
     _, ct = ctx.gicp_covariances(k=10, eps=1e-3)
-    err = np.abs(ct[keep] - want).reshape(keep.sum(), -1).max(1)
-    assert (err > 1e-9).mean() < 2e-3
+    assert np.array_equal(ct[keep], want)
     # and the all-finite route (grid order) on the same finite points
     ctx.set_target(tgt[keep])
     _, ct2 = ctx.gicp_covariances(k=10, eps=1e-3)
@@ -66,12 +65,10 @@ def test_reference_gicp_cases(wm, ctx, oracle, testscan, name, res, tx):
     assert got["rc"] == 0 and got["converged"] and want["converged"]
     assert np.linalg.norm(got["T"] - P) < 0.1            # gicp_tests.cpp:36 threshold
     assert got["n_corr"] == want["n_corr"]
-    # PCL's outer stop test (r_eps = 1e-8 on the float-stored rotation) fires only when the
-    # rotation block is bit-stable, so a last-bit difference in the reduction order can move
-    # the stopping iteration by one; the transform itself is what parity is judged on
-    assert abs(got["iterations"] - want["iterations"]) <= 1
-    dt, ang = pose_error(got["T"], want["T"])
-    assert dt <= TOL_T and ang <= TOL_R, (dt, ang)
+    # every sum of the objective is order-independent (double-double) and every other operation is
+    # IEEE in the same order on both sides: the two paths take the same decisions throughout
+    assert got["iterations"] == want["iterations"] and got["inner_total"] == want["inner_total"]
+    assert np.array_equal(got["T"], want["T"])
 
 
 def test_gicp_objective_and_gradient_match_oracle(wm, ctx, oracle):
@@ -94,32 +91,32 @@ def test_gicp_objective_and_gradient_match_oracle(wm, ctx, oracle):
     si = np.nonzero(keep)[0].astype(np.int32)
     M[si] = np.linalg.inv(C2[oi[si]] + R @ C1[si] @ R.T)
     of, og = oracle.gicp_fdf(ref, tgt, si, oi[si], M, np.eye(4), x)
-    assert abs(f - of) <= 1e-9 * abs(of)
-    np.testing.assert_allclose(g, og, rtol=1e-8, atol=1e-8 * np.abs(og).max())
+    assert abs(f - of) <= 1e-12 * abs(of)   # (M through numpy's inverse here: last-bit differences in the terms)
+    np.testing.assert_allclose(g, og, rtol=1e-10, atol=1e-10 * np.abs(og).max())
 
 
 def test_gicp_on_noisy_synthetic_pair(wm, ctx, oracle):
     """BASELINE config 3 shape (resample pair with noise), small enough for the oracle.
-    On noisy data PCL's inner optimiser (BFGS, gradient tolerance 1e-2, objective evaluated
-    through a float-quantised transform) stops wherever its line search lands: last-bit
-    differences in the reduction order change the path, so two faithful implementations
-    agree only to ~1e-3 m in the weakly constrained (sliding) directions.  Bit-level parity
-    is asserted on the pieces (covariances, pairs, f, gradient: tests above); here the
-    outcome is checked against the oracle at that sensitivity and against ground truth."""
-    ref, tgt, T_gt = synth.pair(30000, seed=21)
-    ctx.set_source(ref)
-    ctx.set_target(tgt)
-    one = ctx.gicp_align(force_iterations=1)
-    one_o = oracle.gicp_align(ref, tgt, force_iterations=1)
-    dt, ang = pose_error(one["T"], one_o["T"])   # first outer iteration: identical path
-    assert one["n_corr"] == one_o["n_corr"] and dt <= 1e-6 and ang <= 1e-6, (dt, ang)
-    got = ctx.gicp_align()
-    want = oracle.gicp_align(ref, tgt)
-    assert got["rc"] == 0 and got["converged"]
-    dt, ang = pose_error(got["T"], want["T"])
-    assert dt <= 3e-3 and ang <= 3e-4, (dt, ang)
-    dt, ang = pose_error(got["T"], T_gt)
-    assert dt < 5e-3 and ang < 1e-3
+    PCL's inner optimiser (BFGS, gradient tolerance 1e-2, objective evaluated through a
+    float-quantised transform) stops wherever its line search lands, so a last-bit difference in f
+    or the gradient used to move the result by millimetres (round 1: 3e-3 m vs the oracle).  Now the
+    objective's sums are order-independent (double-double accumulation on both sides) and the
+    covariances come from the same IEEE-only Jacobi SVD: the HIP path and the oracle make the same
+    evaluations (scripts/dev/dev_gicp_trace.py: 113 of 113 identical in hex) and return the same
+    float matrix.  north_star's bar is 1e-4 m / 1e-4 rad; asserted here: identical."""
+    for n, seed in ((30000, 21), (20000, 7), (40000, 5)):
+        ref, tgt, T_gt = synth.pair(n, seed=seed)
+        ctx.set_source(ref)
+        ctx.set_target(tgt)
+        got = ctx.gicp_align()
+        want = oracle.gicp_align(ref, tgt)
+        assert got["rc"] == 0 and got["converged"] and want["converged"]
+        assert got["n_corr"] == want["n_corr"]
+        assert got["iterations"] == want["iterations"] and got["inner_total"] == want["inner_total"]
+        assert got["f"] == want["f"]
+        assert np.array_equal(got["T"], want["T"])
+        dt, ang = pose_error(got["T"], T_gt)
+        assert dt < 5e-3 and ang < 1e-3
 
 
 def test_gicp_too_few_points(wm, ctx):
