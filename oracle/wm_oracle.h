@@ -6,14 +6,22 @@
  * transformPointCloud) plus libwave's own information-matrix estimators
  * (wave_matching/src/icp.cpp:167-397, wave_matching/src/icp_pcl_functions.cpp:51-289).
  *
- * PARITY STATUS: "parity unpinned".  PCL / Eigen / FLANN are not vendored in the
- * reference tree and are not installed in the build image, and the reference
- * ships no golden transforms; its tests only assert |T - T_gt|_F < 0.1
- * (wave_matching/tests/icp_tests.cpp:37,59-61).  This oracle is pinned to
+ * PARITY STATUS: "parity unpinned" BY THE REFERENCE -- PCL / Eigen / FLANN are not vendored in
+ * the reference tree and are not installed in the build image, and the reference ships no golden
+ * transforms; its tests only assert |T - T_gt|_F < 0.1 / 0.12
+ * (wave_matching/tests/icp_tests.cpp:37,59-61).  What this oracle IS pinned to:
  *   (1) those reference-test assertions on the reference's own fixture
- *       (tests/golden/testscan.pcd), and
- *   (2) an independent numpy/scipy restatement (tests/golden/make_golden.py)
- *       whose outputs are committed as tests/golden/ JSON files.
+ *       (tests/golden/testscan.pcd, sha256 c22245b9...);
+ *   (2) independent numpy / scipy restatements whose outputs are committed under tests/golden/:
+ *       icp_golden.json (make_golden.py: ICP + VoxelGrid with cKDTree and numpy SVD; final 4x4s,
+ *       iteration counts, stop states) and gicp_ndt_golden.json (make_golden_gicp_ndt.py: NDT voxel
+ *       model, score / gradient / Hessian from rotation-matrix derivative products -- not from the
+ *       tabulated entries restated here --, the optimum a converged NDT reaches; GICP covariances,
+ *       objective, gradient and the registration's fixed point).  tests/test_oracle_cpu.py and
+ *       tests/test_golden_gicp_ndt_cpu.py hold the oracle to them; the HIP path is held to the
+ *       same files (tests/test_golden_gicp_ndt_gpu.py, tests/test_match_gpu.py);
+ *   (3) optionally, a system PCL: oracle/pcl_ref/ builds a PCL-backed third opinion when PCL >= 1.8
+ *       is installed (it is not in this image; tests/test_pcl_third_opinion.py skips without it).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * link or call this library.  The product path (libwave_amd/csrc) never does.

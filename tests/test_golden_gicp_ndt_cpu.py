@@ -1,0 +1,72 @@
+"""The C oracle against the independent numpy / scipy restatement of PCL's NDT and GICP arithmetic
+(tests/golden/gicp_ndt_golden.json, written by tests/golden/make_golden_gicp_ndt.py): voxel model,
+score / gradient / Hessian against derivatives formed from rotation-matrix products (including the one
+entry PCL has wrong), the optimum a converged NDT must reach, GICP covariances, objective, gradient,
+and the registration's fixed point.  Runs on the CPU."""
+import numpy as np
+import pytest
+
+import golden_checks as G
+
+GOLD = G.golden()
+
+
+@pytest.mark.parametrize("name", sorted(GOLD["ndt"]))
+def test_oracle_ndt_voxel_model_and_derivatives(oracle, testscan, name):
+    c = GOLD["ndt"][name]
+    target, _ = G.shifted(testscan, c["tx"])
+    grid = oracle.NdtGrid(target, c["res"])
+    ijk, mean, icov, cnt = grid.export()
+    look = {tuple(int(v) for v in k): i for i, k in enumerate(ijk)}
+    for v in c["first_voxels"]:
+        i = look[tuple(v["ijk"])]
+        assert cnt[i] == v["n"]
+        np.testing.assert_allclose(mean[i], v["mean"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(icov[i], v["icov"], rtol=1e-6, atol=1e-6 * np.abs(v["icov"]).max())
+    src = testscan[::c["source_stride"]]
+
+    def derivs(pose, sign):
+        s, g, H = grid.derivatives(src, pose, oracle.ndt_params(res=c["res"], pcl_d1_sign=sign))
+        return s, g, H, grid.size()
+    G.check_ndt_derivatives(c, derivs)
+
+
+@pytest.mark.parametrize("name", [n for n in sorted(GOLD["ndt"]) if "optimum_T" in GOLD["ndt"][n]])
+def test_oracle_ndt_reaches_the_independent_optimum(oracle, testscan, name):
+    c = GOLD["ndt"][name]
+    target, _ = G.shifted(testscan, c["tx"])
+    got = oracle.ndt_align(testscan, target, res=c["res"], step_size=3, max_iter=100, t_eps=1e-8)
+    assert got["converged"]
+    dt, ang = G.pose_err(got["T"], c["optimum_T"])
+    assert dt <= 1e-4 and ang <= 1e-4, (dt, ang)
+
+
+@pytest.mark.parametrize("name", sorted(GOLD["gicp"]))
+def test_oracle_gicp_pieces_and_fixed_point(oracle, testscan, name):
+    c = GOLD["gicp"][name]
+    target, P = G.shifted(testscan, c["tx"])
+    a = testscan if c["res"] < 0 else oracle.voxel_grid(testscan, c["res"])
+    b = target if c["res"] < 0 else oracle.voxel_grid(target, c["res"])
+    assert len(a) == c["n_ref"] and len(b) == c["n_target"]
+    C1, C2 = oracle.gicp_covariances(a), oracle.gicp_covariances(b)
+    np.testing.assert_allclose(C1[:4], c["cov_ref_first4"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(C2[:4], c["cov_target_first4"], rtol=0, atol=1e-9)
+    # (whole-cloud checksum: a handful of neighbourhoods with tied k-th neighbours or repeated singular
+    # values have no unique answer, hence 1e-6 and not 1e-9)
+    assert abs(np.abs(C1).sum() - c["cov_ref_checksum"]) <= 1e-6 * c["cov_ref_checksum"]
+    assert abs(np.abs(C2).sum() - c["cov_target_checksum"]) <= 1e-6 * c["cov_target_checksum"]
+    # objective and gradient at the probe state, pairs = nearest neighbours under the identity
+    j, _ = oracle.KdTree(b).nn(a)
+    M = np.linalg.inv(C2[j] + C1)
+    si = np.arange(len(a), dtype=np.int32)
+    f, g = oracle.gicp_fdf(a, b, si, j, M, np.eye(4), np.array(c["probe"]["x"]))
+    # (2e-5: the voxel-filtered clouds are lattices of centroids, where a few source points have two
+    # equidistant nearest neighbours -- cKDTree and the oracle's kd-tree may pick different ones)
+    assert abs(f - c["probe"]["f"]) <= 2e-5 * abs(c["probe"]["f"])
+    GG = np.array(c["probe"]["grad"])
+    np.testing.assert_allclose(g, GG, rtol=1e-4, atol=2e-5 * np.abs(GG).max())
+    # the whole registration ends at the fixed point of pair -> minimise -> re-pair
+    got = oracle.gicp_align(a, b)
+    assert got["converged"] and np.linalg.norm(got["T"] - P) < 0.1
+    dt, ang = G.pose_err(got["T"], c["fixed_point_T"])
+    assert dt <= 1e-4 and ang <= 1e-4, (dt, ang)
