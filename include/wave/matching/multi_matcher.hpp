@@ -14,7 +14,9 @@
 #ifndef WAVE_MULTI_MATCHER_HPP
 #define WAVE_MULTI_MATCHER_HPP
 
+#include <algorithm>
 #include <condition_variable>
+#include <cstdlib>
 #include <deque>
 #include <memory>
 #include <mutex>
@@ -33,7 +35,12 @@ class MultiMatcher {
     MultiMatcher(int n_threads = std::thread::hardware_concurrency(), int queue_s = 10,
                  R params = R())
         : capacity_(queue_s > 0 ? static_cast<size_t>(queue_s) : 1), config_(params) {
-        const int crew = n_threads > 0 ? n_threads : 1;
+        // The reference's default is one worker per hardware thread (each runs single-threaded PCL).
+        // Here a worker is a host thread feeding ONE GPU: a few fill it (16 workers: 7 600
+        // registrations/s at 10k points against 2 300 with one), and hundreds -- 256 on an MI355X
+        // host -- only fight over the cores while they wait.  The crew is capped (default 16; env
+        // WAVE_MATCHING_MAX_WORKERS or setMaxWorkers() to change it).
+        const int crew = std::max(1, std::min(n_threads > 0 ? n_threads : 1, maxWorkers()));
         workers_.reserve(crew);
         for (int w = 0; w < crew; ++w) workers_.emplace_back([this] { work(); });
     }
@@ -46,6 +53,19 @@ class MultiMatcher {
         jobs_changed_.notify_all();
         for (auto &w : workers_) w.join();
     }
+
+    /** Upper bound on the worker crew of matchers constructed afterwards (<= 0: back to the default). */
+    static void setMaxWorkers(int n) { maxWorkersSetting() = n; }
+    static int maxWorkers() {
+        if (maxWorkersSetting() > 0) return maxWorkersSetting();
+        if (const char *e = std::getenv("WAVE_MATCHING_MAX_WORKERS")) {
+            const int v = std::atoi(e);
+            if (v > 0) return v;
+        }
+        return 16;
+    }
+    /** Number of worker threads of this pool. */
+    int workers() const { return static_cast<int>(workers_.size()); }
 
     MultiMatcher(const MultiMatcher &) = delete;
     MultiMatcher &operator=(const MultiMatcher &) = delete;
@@ -117,6 +137,11 @@ class MultiMatcher {
             finished_.push_back(out);
             --unfinished_;
         }
+    }
+
+    static int &maxWorkersSetting() {
+        static int setting = 0;
+        return setting;
     }
 
     const size_t capacity_;

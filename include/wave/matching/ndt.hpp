@@ -45,11 +45,19 @@ class NDTMatcher : public Matcher<PCLPointCloudPtr> {
     void setTarget(const PCLPointCloudPtr &target);
     bool match();  // blocks; true when the Newton iteration converged
 
+    // PCL 1.8's NDT initialises its More-Thuente loop flag so that the loop body never runs (the step
+    // is Newton's, its norm clamped to step_size); later PCL releases run the search.  The reference
+    // asks for "PCL 1.8" without pinning a patch level, and on its own smallDisplacement test the
+    // clamped-only variant wanders off, so the search runs by default here.  true (or env
+    // WAVE_NDT_PCL18_STEP_RULE=1) selects the literal 1.8 behaviour for matchers constructed afterwards.
+    static void setPcl18StepRule(bool on);
+
  private:
     wm_ctx *ctx;
     int device;
     PCLPointCloudPtr ref, target;
     NDTMatcherParams params;
+    bool pcl18_step_rule;
     bool target_on_device;  // the target and its voxel model are in the context (setTarget put them there)
     bool ensureContext();
 };

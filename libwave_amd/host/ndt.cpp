@@ -2,6 +2,8 @@
 // wave_matching/src/ndt.cpp:6-65).
 #include "wave/matching/ndt.hpp"
 
+#include <cstdlib>
+
 #include "shim.hpp"
 
 namespace wave {
@@ -10,9 +12,23 @@ NDTMatcherParams::NDTMatcherParams(const std::string &config_path) {
     shim::loadYaml(config_path, {{"step_size", &step_size}, {"max_iter", &max_iter}, {"t_eps", &t_eps}, {"res", &res}});
 }
 
+namespace {
+int &pcl18Setting() {
+    static int setting = -1;  // -1: follow the environment
+    return setting;
+}
+bool pcl18StepRule() {
+    if (pcl18Setting() >= 0) return pcl18Setting() != 0;
+    const char *e = std::getenv("WAVE_NDT_PCL18_STEP_RULE");
+    return e && std::atoi(e) != 0;
+}
+}  // namespace
+
+void NDTMatcher::setPcl18StepRule(bool on) { pcl18Setting() = on ? 1 : 0; }
+
 NDTMatcher::NDTMatcher(NDTMatcherParams params1)
     : ctx(nullptr), device(shim::defaultDevice()), ref(shim::emptyCloud()), target(shim::emptyCloud()),
-      params(params1), target_on_device(false) {
+      params(params1), pcl18_step_rule(pcl18StepRule()), target_on_device(false) {
     if (params.res < params.min_res) {  // ndt.cpp:23-26: refuse, say so, carry on with the floor
         LOG_ERROR("Invalid resolution given, using minimum");
         params.res = params.min_res;
@@ -22,7 +38,7 @@ NDTMatcher::NDTMatcher(NDTMatcherParams params1)
 
 NDTMatcher::NDTMatcher(const NDTMatcher &o)
     : Matcher<PCLPointCloudPtr>(o), ctx(nullptr), device(o.device), ref(o.ref), target(o.target),
-      params(o.params), target_on_device(false) {}
+      params(o.params), pcl18_step_rule(o.pcl18_step_rule), target_on_device(false) {}
 
 NDTMatcher &NDTMatcher::operator=(const NDTMatcher &o) {
     if (this == &o) return *this;
@@ -35,6 +51,7 @@ NDTMatcher &NDTMatcher::operator=(const NDTMatcher &o) {
     params.max_iter = o.params.max_iter;
     params.t_eps = o.params.t_eps;
     params.res = o.params.res;
+    pcl18_step_rule = o.pcl18_step_rule;
     target_on_device = false;
     return *this;
 }
@@ -74,6 +91,7 @@ bool NDTMatcher::match() {
     p.step_size = params.step_size;  // setStepSize,              ndt.cpp:31
     p.t_eps = params.t_eps;          // setTransformationEpsilon, ndt.cpp:30
     p.max_iter = params.max_iter;    // setMaximumIterations,     ndt.cpp:33
+    p.skip_line_search = pcl18_step_rule ? 1 : 0;
     double T[16];
     wm_ndt_stats stats;
     if (!shim::succeeded(wm_ndt_align(ctx, &p, T, &stats), "wm_ndt_align", ctx)) return false;

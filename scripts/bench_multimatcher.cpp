@@ -1,0 +1,97 @@
+// Throughput of the drop-in wave::MultiMatcher<ICPMatcher, ICPMatcherParams> on one MI355X -- the
+// reference's own way of scaling (one matcher per worker thread, wave_matching/include/wave/
+// matching/multi_matcher.hpp:29-96; there every worker runs single-threaded PCL, here every worker
+// feeds the GPU through its own context and stream).  Synthetic pairs (ground + walls + boxes, the
+// target a shifted re-sampling), full-resolution ICP with the reference's default stopping rules.
+//
+//   bench_multimatcher <points per cloud> <pairs> <workers> [<workers> ...]
+// prints one JSON line per worker count.  Built by libwave_amd/host/Makefile.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "wave/matching/icp.hpp"
+#include "wave/matching/multi_matcher.hpp"
+
+namespace {
+
+wave::PCLPointCloudPtr scene(int n, unsigned seed, float dx) {
+    auto c = boost::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
+    std::mt19937 rng(seed);
+    std::uniform_real_distribution<float> u(0.f, 1.f);
+    std::normal_distribution<float> noise(0.f, 0.01f);
+    c->points.resize((size_t) n);
+    for (int i = 0; i < n; ++i) {
+        pcl::PointXYZ p;
+        const float pick = u(rng);
+        if (pick < 0.5f) {  // ground
+            p.x = -20.f + 40.f * u(rng);
+            p.y = -15.f + 30.f * u(rng);
+            p.z = noise(rng);
+        } else if (pick < 0.8f) {  // four walls
+            const int side = (int) (4.f * u(rng)) & 3;
+            const float t = u(rng);
+            p.x = side == 0 ? -20.f : side == 1 ? 20.f : -20.f + 40.f * t;
+            p.y = side == 2 ? -15.f : side == 3 ? 15.f : -15.f + 30.f * t;
+            p.z = 6.f * u(rng);
+        } else {  // a few boxes
+            const int b = (int) (8.f * u(rng)) & 7;
+            p.x = -16.f + 4.5f * (float) b + 1.5f * u(rng);
+            p.y = -10.f + 2.6f * (float) b + 1.0f * u(rng);
+            p.z = 1.5f * u(rng);
+        }
+        p.x += dx;
+        c->points[(size_t) i] = p;
+    }
+    return c;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc < 4) {
+        std::fprintf(stderr, "usage: %s <points> <pairs> <workers>...\n", argv[0]);
+        return 2;
+    }
+    const int n = std::atoi(argv[1]), pairs = std::atoi(argv[2]);
+    wave::ICPMatcherParams params;
+    params.res = -1;  // full resolution: the clouds go to the device as they are
+    params.multiscale_steps = 0;
+    std::vector<wave::PCLPointCloudPtr> refs, targets;
+    for (int k = 0; k < 4; ++k) {  // four distinct pairs, reused round-robin
+        refs.push_back(scene(n, 100u + (unsigned) k, 0.f));
+        targets.push_back(scene(n, 200u + (unsigned) k, 0.15f));
+    }
+    for (int a = 3; a < argc; ++a) {
+        const int workers = std::atoi(argv[a]);
+        wave::MultiMatcher<wave::ICPMatcher, wave::ICPMatcherParams>::setMaxWorkers(workers);
+        wave::MultiMatcher<wave::ICPMatcher, wave::ICPMatcherParams> pool(workers, 2 * workers, params);
+        auto drain = [&](int count) {
+            int got = 0, ok = 0;
+            for (int j = 0; j < count; ++j) pool.insert(j, refs[(size_t) j % 4], targets[(size_t) j % 4]);
+            while (got < count) {
+                int id;
+                Eigen::Affine3d T;
+                wave::Mat6 info;
+                if (pool.getResult(&id, &T, &info)) {
+                    ++got;
+                    ok += std::abs(T.translation()(0) - 0.15) < 0.05;
+                } else {
+                    std::this_thread::yield();
+                }
+            }
+            return ok;
+        };
+        drain(2 * workers);  // warm-up: contexts, allocations, the tuned grid cell
+        const auto t0 = std::chrono::steady_clock::now();
+        const int ok = drain(pairs);
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("{\"bench\": \"wave::MultiMatcher<ICPMatcher>\", \"points\": %d, \"workers\": %d, \"pairs\": %d, "
+                    "\"seconds\": %.4f, \"registrations_per_s\": %.1f, \"recovered_shift\": %d}\n",
+                    n, pool.workers(), pairs, s, pairs / s, ok);
+        std::fflush(stdout);
+    }
+    return 0;
+}

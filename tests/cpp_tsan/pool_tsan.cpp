@@ -1,0 +1,73 @@
+// ThreadSanitizer job for wave::MultiMatcher's pool (the reference has no race
+// detection; its pool juggles three mutex / queue pairs, impl/multi_matcher_impl.hpp:9-93).  The
+// pool is exercised with a matcher that needs no device -- the same template, the same queueing,
+// producers and a consumer racing the workers -- under -fsanitize=thread (tests/test_pool_tsan_cpu.py).
+#include <atomic>
+#include <cstdio>
+#include <set>
+#include <thread>
+
+#include "wave/matching/multi_matcher.hpp"
+
+namespace {
+
+struct FakeParams {
+    int spin = 200;
+};
+
+// what MultiMatcher asks of a matcher: construct from params, setup, match, estimateInfo,
+// getResult, getInfo
+class FakeMatcher : public wave::Matcher<wave::PCLPointCloudPtr> {
+ public:
+    explicit FakeMatcher(FakeParams p) : spin_(p.spin) {}
+    void setRef(const wave::PCLPointCloudPtr &c) { ref_ = c; }
+    void setTarget(const wave::PCLPointCloudPtr &c) { target_ = c; }
+    bool match() {
+        double acc = 0;
+        for (int k = 0; k < spin_; ++k) acc += (double) ref_->points.size() * 1e-9 * k;
+        result = wave::Affine3::Identity();
+        result.translation()(0) = (double) ref_->points.size() + acc * 0;
+        return true;
+    }
+
+ private:
+    int spin_;
+    wave::PCLPointCloudPtr ref_, target_;
+};
+
+}  // namespace
+
+int main() {
+    const int kJobs = 400;
+    wave::MultiMatcher<FakeMatcher, FakeParams> pool(6, 4, FakeParams());
+    std::atomic<int> got{0};
+    std::set<int> ids;
+    std::thread consumer([&] {
+        while (got.load() < kJobs) {
+            int id;
+            Eigen::Affine3d T;
+            wave::Mat6 info;
+            if (pool.getResult(&id, &T, &info)) {
+                if ((int) T.translation()(0) != id % 50 + 1) std::printf("wrong payload for %d\n", id);
+                ids.insert(id);
+                ++got;
+            } else {
+                std::this_thread::yield();
+            }
+        }
+    });
+    std::thread producers[2];
+    for (int p = 0; p < 2; ++p)
+        producers[p] = std::thread([&, p] {
+            for (int j = p; j < kJobs; j += 2) {
+                auto c = boost::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
+                c->points.resize((size_t) (j % 50 + 1));
+                pool.insert(j, c, c);
+            }
+        });
+    for (auto &t : producers) t.join();
+    consumer.join();
+    const bool ok = pool.done() && (int) ids.size() == kJobs;
+    std::printf("%s: %zu distinct results, done=%d\n", ok ? "OK" : "FAILED", ids.size(), pool.done() ? 1 : 0);
+    return ok ? 0 : 1;
+}
