@@ -413,7 +413,7 @@ def main():
                         "profiles/r02*_pmc_k_nn_grid_per_iteration.csv), not HBM",
             },
         }
-        if world == 1:
+        if world == 1 and dist is None:
             # the same registration from HOST clouds: H2D of both clouds inside the step
             hc = {}
             for name, (hr, ht) in (("pageable", (ref, tgt)),
