@@ -273,6 +273,40 @@ __device__ __forceinline__ void dd_add(double &hi, double &lo, double x) {
     hi = s;
 }
 
+template <int C, int M>
+__device__ __forceinline__ void dd_halve(double (&hi)[kGicpAcc], double (&lo)[kGicpAcc], unsigned lane) {
+    constexpr int H = (C + 1) / 2;
+    const bool up = (lane & (unsigned) M) != 0u;
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        const double h_lo = hi[i], l_lo = lo[i];
+        const double h_hi = (H + i < C) ? hi[H + i] : 0.0, l_hi = (H + i < C) ? lo[H + i] : 0.0;
+        const double sh = up ? h_lo : h_hi, sl = up ? l_lo : l_hi;  // the half this lane gives away
+        double kh = up ? h_hi : h_lo, kl = up ? l_hi : l_lo;        // the half it keeps
+        const double rh = __shfl_xor(sh, M), rl = __shfl_xor(sl, M);
+        dd_add(kh, kl, rh);
+        kl += rl;
+        hi[i] = kh;
+        lo[i] = kl;
+    }
+    if constexpr (M > 1) dd_halve<H, M / 2>(hi, lo, lane);
+}
+__device__ __forceinline__ int dd_comp_of_lane(unsigned lane) {
+    int c = kGicpAcc, base = 0, valid = kGicpAcc;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        const int h = (c + 1) / 2;
+        if (lane & (unsigned) m) {
+            base += h;
+            valid -= h;
+        } else {
+            valid = valid < h ? valid : h;
+        }
+        c = h;
+    }
+    return valid >= 1 ? base : -1;
+}
+
 // a[0] = sum r^T M r, a[1..3] = sum M r, a[4..12] = sum p_base (M r)^T; count separately.
 // partials: [block][kGicpAcc][2] = (hi, lo) pairs
 __global__ void __launch_bounds__(kBlock)
@@ -311,22 +345,17 @@ __global__ void __launch_bounds__(kBlock)
             for (int c = 0; c < 3; ++c) dd_add(hi[4 + r * 3 + c], lo[4 + r * 3 + c], pb[r] * temp[c]);
         }
     }
-#pragma unroll
-    for (int k = 0; k < kGicpAcc; ++k)
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double h2 = __shfl_down(hi[k], off), l2 = __shfl_down(lo[k], off);
-            dd_add(hi[k], lo[k], h2);
-            lo[k] += l2;
-        }
-    __shared__ double lds[kBlock / 64][kGicpAcc][2];
+    // wave reduction by recursive halving (as the search kernel's statistics, wm_nn.hip): at the
+    // step for lane bit M a lane keeps one half of its pairs and sends the other half to lane ^ M --
+    // 7+4+2+1+1+1 = 16 pair exchanges instead of 13 x 6.  Component k ends in the lane dd_comp_of_lane names.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0)
-#pragma unroll
-        for (int k = 0; k < kGicpAcc; ++k) {
-            lds[wave][k][0] = hi[k];
-            lds[wave][k][1] = lo[k];
-        }
+    dd_halve<kGicpAcc, 32>(hi, lo, (unsigned) lane);
+    __shared__ double lds[kBlock / 64][kGicpAcc][2];
+    const int comp = dd_comp_of_lane((unsigned) lane);
+    if (comp >= 0) {
+        lds[wave][comp][0] = hi[0];
+        lds[wave][comp][1] = lo[0];
+    }
     __syncthreads();
     if (threadIdx.x < kGicpAcc) {
         double h = 0, l = 0;

@@ -213,7 +213,7 @@ struct wm_ctx {
     int tune_fast_solve = 1;     // experiment knob for the solve kernel
     int tune_spin_us = 80;       // wait_flag: busy-poll this long before polling with yields
     int tune_ndt_blocks = 1024;  // workgroups (= partial rows) of one NDT derivative pass
-    int tune_gicp_blocks = 512;  // workgroups (= partial rows) of one GICP objective evaluation
+    int tune_gicp_blocks = 256;  // workgroups (= partial rows) of one GICP objective evaluation (double-double sums: 512 / 256 / 128 / 64 -> 6.9 / 6.4 / 7.3 / 9.6 ms per 500k registration)
     bool ndt_built = false;
     int ndt_model_builds = 0;    // voxel models built so far (wm_ndt_stats.model_builds)
     double ndt_res = -1;
