@@ -195,6 +195,10 @@ int wm_debug_solve_cycles(wm_ctx *ctx, unsigned long long out[8]);
  * bits 0-15, row chunks in bits 16-23, scan passes in bits 24-30, bit 31 = handed to the
  * wave-cooperative path) and returns the number of iterations recorded. */
 int wm_debug_cost_log(wm_ctx *ctx, int iterations, unsigned *out, size_t cap);
+/* with the cost log armed: per iteration, shader-clock cycle sums over the waves of the search kernel's
+ * phases -- out[8 k + 0..7] = walk, pooled rounds, walks, prologue, pass loop, cooperative phase + stores,
+ * statistics tail, waves.  Returns the number of iterations copied. */
+int wm_debug_phase_log(wm_ctx *ctx, unsigned long long *out, int iterations);
 
 /* PCL's icp.correspondences_ after align (read by estimateLUM / estimateCensi,
  * icp_pcl_functions.cpp:191, icp.cpp:213): per source point (caller's order)

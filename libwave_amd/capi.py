@@ -161,6 +161,7 @@ def lib():
                                          C.c_size_t, C.POINTER(IcpParams), _dp, C.POINTER(IcpStats)]
         L.wm_debug_solve_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.wm_debug_cost_log.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.wm_debug_phase_log.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.wm_get_correspondences.argtypes = [C.c_void_p, _ip, _fp, C.c_size_t]
         L.wm_nn_search.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int, _ip, _fp, C.c_size_t, _fp]
         L.wm_icp_stats_for.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
@@ -472,6 +473,11 @@ class Context:
         if k < 0:
             raise WmError("wm_debug_cost_log: %d" % k)
         return buf[:k]
+
+    def phase_log_fetch(self, iterations):
+        buf = np.zeros((iterations, 8), np.uint64)
+        k = lib().wm_debug_phase_log(self._h, buf.ctypes.data_as(C.c_void_p), iterations)
+        return buf[:max(k, 0)]
 
     def solve_cycles(self):
         buf = (C.c_uint64 * 8)()

@@ -891,7 +891,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
                       &ctx->src_grid.cell_start, &ctx->vg_idx, &ctx->vg_idx2, &ctx->vg_perm,
                       &ctx->vg_perm2, &ctx->vg_tmp, &ctx->vg_seg, &ctx->io_a, &ctx->io_b, &ctx->ds_ref,
                       &ctx->ds_tgt, &ctx->match_ref, &ctx->match_tgt,
-                      &ctx->partials, &ctx->partials2, &ctx->cost_log, &ctx->shard_ref, &ctx->shard_tgt,
+                      &ctx->partials, &ctx->partials2, &ctx->cost_log, &ctx->phase_log, &ctx->shard_ref, &ctx->shard_tgt,
                       &ctx->shard_ref_band, &ctx->shard_tgt_band, &ctx->shard_misc, &ctx->shard_flags, &ctx->shard_pos_t,
                       &ctx->shard_pos_s, &ctx->shard_stats, &ctx->ndt_sum_dev, &ctx->corr_tmp_idx, &ctx->corr_tmp_d2, &ctx->d_state};
     for (DevBuf *b : bufs) b->release();
@@ -1362,10 +1362,13 @@ int wm_debug_cost_log(wm_ctx *ctx, int iterations, unsigned *out, size_t cap) {
         if (iterations == 0) {
             WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
             ctx->cost_log.release();
+            ctx->phase_log.release();
             ctx->cost_log_cap = 0;
             return WM_OK;
         }
         WM_HIP(ctx, ctx->cost_log.reserve((size_t) iterations * (ctx->n_src > 0 ? ctx->n_src : 1) * 4));
+        WM_HIP(ctx, ctx->phase_log.reserve((size_t) iterations * 8 * sizeof(unsigned long long)));
+        WM_HIP(ctx, hipMemsetAsync(ctx->phase_log.p, 0, (size_t) iterations * 8 * sizeof(unsigned long long), ctx->stream));
         ctx->cost_log_iter = 0;
         ctx->cost_log_cap = iterations;
         return WM_OK;
@@ -1374,6 +1377,14 @@ int wm_debug_cost_log(wm_ctx *ctx, int iterations, unsigned *out, size_t cap) {
     if (cap < need) return WM_ERR_ARG;
     WM_TRY(copy_to_caller(ctx, out, ctx->cost_log.p, need * 4));
     return ctx->cost_log_iter;
+}
+
+int wm_debug_phase_log(wm_ctx *ctx, unsigned long long *out, int iterations) {
+    if (!ctx || !out || iterations < 0 || !ctx->phase_log.p) return WM_ERR_ARG;
+    if (iterations > ctx->cost_log_iter) iterations = ctx->cost_log_iter;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_TRY(copy_to_caller(ctx, out, ctx->phase_log.p, (size_t) iterations * 8 * sizeof(unsigned long long)));
+    return iterations;
 }
 
 int wm_debug_solve_cycles(wm_ctx *ctx, unsigned long long out[8]) {

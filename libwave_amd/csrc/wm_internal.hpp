@@ -159,6 +159,7 @@ struct wm_ctx {
     // scratch
     wm::DevBuf staging, cell_of, counts, block_sums, bbox_buf;
     wm::DevBuf match_pt, match_pt_bak;  // float4 per (sorted) source point: its match's xyz
+    wm::DevBuf phase_log;                   // developer: per-iteration phase cycle sums of the search kernel
     wm::DevBuf cost_log;                    // developer: per-query search cost of every iteration (wm_debug_cost_log)
     int cost_log_iter = 0, cost_log_cap = 0;
     wm::DevBuf keys, partials, partials2, corr_tmp_idx, corr_tmp_d2, d_levels;

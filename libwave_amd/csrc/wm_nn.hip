@@ -329,7 +329,9 @@ template <bool COST, int RC>
 __device__ __forceinline__ void balanced_walk(BalLds &L, const unsigned (&rs)[RC],
                                               const unsigned (&re)[RC], unsigned lane,
                                               const float4 *pts, const float4 *ubase, float qx, float qy,
-                                              float qz, unsigned long long &best, unsigned &cost) {
+                                              float qz, unsigned long long &best, unsigned &cost,
+                                              unsigned long long *prof) {
+    const unsigned long long prof_t0 = COST ? clock64() : 0ull;
     unsigned len[RC], t = 0, longest = 0;
 #pragma unroll
     for (int u = 0; u < RC; ++u) {
@@ -382,6 +384,11 @@ __device__ __forceinline__ void balanced_walk(BalLds &L, const unsigned (&rs)[RC
     }
     __builtin_amdgcn_wave_barrier();
     best = L.best[lane];
+    if constexpr (COST) {
+        prof[0] += clock64() - prof_t0;  // walk (list building + rounds)
+        prof[1] += (T + 63u) / 64u;      // rounds
+        prof[2] += 1;                    // walks
+    }
 }
 
 // scan_box with wave-uniform loops (see above); `live` = this lane has a search of its own going
@@ -390,7 +397,7 @@ __device__ __forceinline__ unsigned long long scan_box_bal(const GridDev &g, boo
                                                            float qz, float r, unsigned long long best,
                                                            float *margin, BalLds &L, unsigned lane,
                                                            bool allow_layered, const float4 *ubase,
-                                                           unsigned &cost) {
+                                                           unsigned &cost, unsigned long long *prof) {
     const float big = 4.0e6f;
     const float fx = fminf(fmaxf((qx - g.ox) * g.inv_h, -big), big);
     const float fy = fminf(fmaxf((qy - g.oy) * g.inv_h, -big), big);
@@ -415,7 +422,7 @@ __device__ __forceinline__ unsigned long long scan_box_bal(const GridDev &g, boo
             re[u] = ldc(g.cell_start, a1[u]);
         }
         if constexpr (COST) cost += has ? 1u << 16 : 0u;
-        balanced_walk<COST, RC>(L, rs, re, lane, g.pts, ubase, qx, qy, qz, best, cost);
+        balanced_walk<COST, RC>(L, rs, re, lane, g.pts, ubase, qx, qy, qz, best, cost, prof);
     };
     const bool layered =
         allow_layered && __popcll(__ballot(has && (yb - ya + 1) * (zb - za + 1) > kLayeredRows)) >= 8;
@@ -626,24 +633,31 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
               IcpDevState *__restrict__ st, float thr_d2, unsigned long long *__restrict__ keys,
               float4 *__restrict__ match_pt, const float4 *__restrict__ tgt_orig,
               float r_light_cells, float lane_lf, float coop_lf, float r0_cells, unsigned xcd_chunk,
-              double *__restrict__ partials, unsigned *__restrict__ cost_out) {
+              double *__restrict__ partials, unsigned *__restrict__ cost_out,
+              unsigned long long *__restrict__ phase_out) {
     if (st->done) return;
     unsigned cost = 0;
+    // developer (COST): shader-clock cycles of this wave's phases, added into phase_out[8] by lane 0:
+    // [0] walk, [1] rounds, [2] walks, [3] prologue, [4] pass loop, [5] cooperative phase + stores,
+    // [6] statistics tail, [7] waves
+    unsigned long long prof[3] = {0ull, 0ull, 0ull};
+    const unsigned long long prof_start = COST ? clock64() : 0ull;
     // per wave: [run][lane] = each lane's pending runs (lane scan), or the pooled trip list (balanced walk)
     __shared__ uint2 s_runs[BAL ? 1 : kRowChunk * 64];
     __shared__ BalHolder<BAL> s_hold;
     const bool rev = (xcd_chunk >> 31) != 0u;  // experiment: hand the queries out back to front
     const unsigned chunk_sz = xcd_chunk & 0x7FFFFFFFu;
     const unsigned bidx = rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
-    const unsigned row = chunk_sz ? xcd_remap_chunked(bidx, chunk_sz) : xcd_remap(bidx, gridDim.x);
-    const unsigned i = row * blockDim.x + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
-    const bool active = i < n;
     const int L = lv->n;
     const int L_levels = L;
     const float h0 = lv->g[0].h;
     const float rmax = sqrtf(thr_d2) * 1.0001f + 1e-6f;
     const float r_light = r_light_cells * h0;  // larger radii go to the cooperative path
+    const bool have_prev = st->have_prev != 0;  // wave-uniform
+    const unsigned row = chunk_sz ? xcd_remap_chunked(bidx, chunk_sz) : xcd_remap(bidx, gridDim.x);
+    const unsigned i = row * 64u + lane;
+    const bool active = i < n;
     float qx = 0.f, qy = 0.f, qz = 0.f, r = 0.f;
     float bqx = 0.f, bqy = 0.f, bqz = 0.f;  // coordinates of the previous iteration's match
     unsigned long long best = make_key(thr_d2, kNoIdx);
@@ -653,7 +667,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
     // the query and its seed (previous key + previous match coordinates) are three
     // independent streams: all three loads are issued before the first use -- one memory round
     // trip, not three dependent ones
-    const bool have_prev = st->have_prev != 0;  // wave-uniform
     unsigned long long prev = ~0ull;
     float4 tp = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) {
@@ -690,6 +703,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
         r = fminf(r, rmax);
         heavy = r > r_light;
     }
+    const unsigned long long prof_pro = COST ? clock64() : 0ull;
     if constexpr (BAL) {
         BalLds &L = s_hold.v;
         L.q[lane] = make_float4(qx, qy, qz, 0.f);
@@ -712,11 +726,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
             float margin;
             if (__ballot(live && l != l0) == 0ull) {
                 const GridDev g = lv->g[l0];
-                best = scan_box_bal<COST, RC>(g, live, qx, qy, qz, r, best, &margin, L, lane, have_prev, g.pts, cost);
+                best = scan_box_bal<COST, RC>(g, live, qx, qy, qz, r, best, &margin, L, lane, have_prev, g.pts, cost, prof);
             } else {
                 const GridDev g = lv->g[l];
                 L.base[lane] = (unsigned long long) g.pts;
-                best = scan_box_bal<COST, RC>(g, live, qx, qy, qz, r, best, &margin, L, lane, have_prev, nullptr, cost);
+                best = scan_box_bal<COST, RC>(g, live, qx, qy, qz, r, best, &margin, L, lane, have_prev, nullptr, cost, prof);
             }
             if (live) {
                 if constexpr (COST) cost += 1u << 24;
@@ -748,6 +762,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
             heavy = r > r_light;
         }
     }
+    const unsigned long long prof_pass = COST ? clock64() : 0ull;
     // ---- cooperative phase: the wave takes its heavy queries one at a time
     unsigned long long todo = __ballot(heavy);
     const unsigned n_heavy = __popcll(todo);
@@ -802,6 +817,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
         match_pt[i_e] = make_float4(bqx, bqy, bqz, 0.f);
     }
     if (lane == 0 && n_heavy) atomicAdd(&st->queue_count[1], n_heavy);  // stats only
+    const unsigned long long prof_store = COST ? clock64() : 0ull;
     if constexpr (COST) {
         if (active) cost_out[i_e] = mine ? (cost | (heavy ? 0x80000000u : 0u)) : 0u;
     }
@@ -852,6 +868,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
         acc_halve<kAcc, 32>(a, lane);
         const int comp = acc_comp_of_lane(lane);
         if (comp >= 0) partials[(size_t) row * kAcc + comp] = a[0];
+    }
+    if constexpr (COST) {
+        if (lane_e == 0 && phase_out) {
+            const unsigned long long t_end = clock64();
+            atomicAdd(&phase_out[0], prof[0]);
+            atomicAdd(&phase_out[1], prof[1]);
+            atomicAdd(&phase_out[2], prof[2]);
+            atomicAdd(&phase_out[3], prof_pro - prof_start);
+            atomicAdd(&phase_out[4], prof_pass - prof_pro);
+            atomicAdd(&phase_out[5], prof_store - prof_pass);
+            atomicAdd(&phase_out[6], t_end - prof_store);
+            atomicAdd(&phase_out[7], 1ull);
+        }
     }
 }
 
@@ -935,7 +964,8 @@ static void launch_nn_grid_t(wm_ctx *ctx, unsigned blocks, float thr_d2, unsigne
                        ctx->d_state.as<IcpDevState>(), thr_d2, ctx->keys.as<unsigned long long>(),
                        ctx->match_pt.as<float4>(), ctx->tgt_orig.as<float4>(), ctx->tune_r_light,
                        ctx->tune_lane_lf, ctx->tune_coop_lf, ctx->tune_r0, xcd_chunk, ctx->partials.as<double>(),
-                       ctx->cost_log.p ? ctx->cost_log.as<unsigned>() + (size_t) ctx->cost_log_iter * ctx->n_src : nullptr);
+                       ctx->cost_log.p ? ctx->cost_log.as<unsigned>() + (size_t) ctx->cost_log_iter * ctx->n_src : nullptr,
+                       ctx->phase_log.p ? ctx->phase_log.as<unsigned long long>() + 8 * (size_t) ctx->cost_log_iter : nullptr);
 }
 
 // stats_mode < 0: search only.  WM_ICP_SVD / WM_ICP_GN6: the search kernel also leaves the ICP

@@ -38,6 +38,11 @@ n = ctx.sizes()[0]
 ctx.cost_log_arm(ITERS)
 ctx.icp_align(max_corr=3.0, force_iterations=ITERS, nn_method=capi.WM_NN_GRID, profile=0, carry_state=0)
 log = ctx.cost_log_fetch(ITERS, n)
+ph = ctx.phase_log_fetch(ITERS).astype(np.float64)
+print("phase cycles per wave (instrumented kernel): it  prologue passloop [walk rounds/walk walks] coop+stores tail")
+for i in (0, 1, 3, 8, 14, 30, 49):
+    w = max(ph[i, 7], 1)
+    print("  %2d  %6.0f %7.0f [%6.0f %.2f %.2f] %6.0f %6.0f" % (i, ph[i, 3] / w, ph[i, 4] / w, ph[i, 0] / w, ph[i, 1] / max(ph[i, 2], 1), ph[i, 2] / w, ph[i, 5] / w, ph[i, 6] / w))
 print("iterations logged", log.shape)
 trips = (log & 0xFFFF).astype(np.int64)
 chunks = ((log >> 16) & 0xFF).astype(np.int64)
