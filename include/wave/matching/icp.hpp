@@ -19,6 +19,7 @@
 #define WAVE_MATCHING_ICP_HPP
 
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "wave/matching/matcher.hpp"
@@ -77,6 +78,28 @@ class ICPMatcher : public Matcher<PCLPointCloudPtr> {
     // exchange (for testing without several GPUs).  estimateInfo() needs the correspondences of a
     // single-device match and leaves `information` untouched after a multi-device one.
     void setDevices(const std::vector<int> &devices);
+
+    // MANY registrations in one device launch -- what wave::MultiMatcher's workers use when pairs are
+    // queued up (no reference counterpart; the reference's worker loop registers them one after the
+    // other, impl/multi_matcher_impl.hpp:45-53).  Every pair goes through exactly what that loop does
+    // with it -- setRef, setTarget, match(), estimateInfo() -- but a whole registration runs inside one
+    // compute unit of the GPU with the target cloud in its LDS, 256 at a time (wm_icp_batch_match).
+    // Limits: a full-resolution matcher (params.res <= 0) on a single device, and targets of at most
+    // maxBatchTargetPoints() points -- batchable() says whether a pair qualifies.  Each pair starts
+    // with fresh stopping criteria (a matcher used pair by pair carries PCL's last MSE over into the
+    // next align; which pair follows which in a MultiMatcher is a matter of thread timing anyway).
+    // out[k] = {match() result, getResult(), getInfo()} as the worker loop would have read them after
+    // pair k: a failed match leaves the transform of the pair before it, as `result` is left alone.
+    struct BatchOutcome {
+        EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+        bool matched;
+        Eigen::Affine3d transform;
+        Mat6 info;
+    };
+    typedef std::vector<BatchOutcome, Eigen::aligned_allocator<BatchOutcome>> BatchOutcomes;
+    static size_t maxBatchTargetPoints();
+    bool batchable(const PCLPointCloudPtr &ref, const PCLPointCloudPtr &target) const;
+    bool matchBatch(const std::vector<std::pair<PCLPointCloudPtr, PCLPointCloudPtr>> &pairs, BatchOutcomes &out);
 
  private:
     wm_ctx *ctx;  // created in the thread that first needs it

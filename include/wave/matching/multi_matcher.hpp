@@ -21,6 +21,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "wave/matching/matcher.hpp"
@@ -110,32 +111,91 @@ class MultiMatcher {
         Mat6 info;
     };
 
+    // Matchers that can register many pairs in one device launch (ICPMatcher::matchBatch) get
+    // everything that is waiting in the queue at once -- up to kBatch pairs: one compute unit each
+    // on a 256-CU MI355X -- instead of one pair per trip.
+    static constexpr size_t kBatch = 256;
+    template <typename M>
+    static auto takeBatch(M &matcher, std::deque<Job> &jobs, std::vector<Job> &taken, int)
+        -> decltype(matcher.batchable(jobs.front().ref, jobs.front().target), void()) {
+        while (!jobs.empty() && taken.size() < kBatch && matcher.batchable(jobs.front().ref, jobs.front().target)) {
+            taken.push_back(jobs.front());
+            jobs.pop_front();
+        }
+    }
+    template <typename M>
+    static void takeBatch(M &, std::deque<Job> &, std::vector<Job> &, long) {}
+    template <typename M>
+    auto runBatch(M &matcher, const std::vector<Job> &taken, int)
+        -> decltype(matcher.matchBatch(std::declval<const std::vector<std::pair<PCLPointCloudPtr, PCLPointCloudPtr>> &>(),
+                                       std::declval<typename M::BatchOutcomes &>()),
+                    bool()) {
+        std::vector<std::pair<PCLPointCloudPtr, PCLPointCloudPtr>> pairs;
+        pairs.reserve(taken.size());
+        for (const Job &j : taken) pairs.emplace_back(j.ref, j.target);
+        typename M::BatchOutcomes got;
+        if (!matcher.matchBatch(pairs, got) || got.size() != taken.size()) return false;
+        std::lock_guard<std::mutex> hold(lock_);
+        for (size_t k = 0; k < taken.size(); ++k) {
+            Outcome out;
+            out.id = taken[k].id;
+            out.transform = got[k].transform;
+            out.info = got[k].info;
+            finished_.push_back(out);
+            --unfinished_;
+        }
+        return true;
+    }
+    template <typename M>
+    bool runBatch(M &, const std::vector<Job> &, long) {
+        return false;
+    }
+
+    void registerOne(T &matcher, const Job &job) {
+        matcher.setup(job.ref, job.target);
+        matcher.match();
+        matcher.estimateInfo();
+
+        Outcome out;
+        out.id = job.id;
+        out.transform = matcher.getResult();
+        out.info = matcher.getInfo();
+        std::lock_guard<std::mutex> hold(lock_);
+        finished_.push_back(out);
+        --unfinished_;
+    }
+
     // worker body: the matcher lives on this thread's stack, so its device context is created
     // (lazily, at the first match) by the thread that uses it
     void work() {
         T matcher{R(config_)};
+        std::vector<Job> taken;
         for (;;) {
             Job job;
+            taken.clear();
             {
                 std::unique_lock<std::mutex> hold(lock_);
                 jobs_changed_.wait(hold, [this] { return closing_ || !jobs_.empty(); });
                 if (closing_) return;
-                job = jobs_.front();
-                jobs_.pop_front();
+                takeBatch(matcher, jobs_, taken, 0);
+                if (taken.size() < 2) {  // nothing to gain from a launch of one (or the matcher has no batch path)
+                    if (taken.empty()) {
+                        job = jobs_.front();
+                        jobs_.pop_front();
+                    } else {
+                        job = taken.front();
+                        taken.clear();
+                    }
+                }
             }
-            jobs_changed_.notify_all();  // a slot is free for insert()
+            jobs_changed_.notify_all();  // slots are free for insert()
+            if (!taken.empty()) {
+                if (runBatch(matcher, taken, 0)) continue;
+                for (const Job &j : taken) registerOne(matcher, j);  // (the device refused: one by one)
+                continue;
+            }
 
-            matcher.setup(job.ref, job.target);
-            matcher.match();
-            matcher.estimateInfo();
-
-            Outcome out;
-            out.id = job.id;
-            out.transform = matcher.getResult();
-            out.info = matcher.getInfo();
-            std::lock_guard<std::mutex> hold(lock_);
-            finished_.push_back(out);
-            --unfinished_;
+            registerOne(matcher, job);
         }
     }
 

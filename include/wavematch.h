@@ -154,6 +154,28 @@ int wm_icp_match(wm_ctx *ctx, const void *ref, size_t n_ref, const void *target,
                  size_t stride_bytes, int mem, const wm_icp_params *p, float res,
                  int multiscale_steps, double T_out[16], wm_icp_stats *stats);
 
+/* Many SMALL registrations in one launch -- the throughput path under wave::MultiMatcher
+ * (wave_matching/include/wave/matching/multi_matcher.hpp:29-96; worker loop impl/
+ * multi_matcher_impl.hpp:45-53: setRef, setTarget, match, estimateInfo per queued pair).  Every item
+ * is ICPMatcher::match()'s full-resolution branch (icp.cpp:123-131: align on the clouds as given,
+ * stopping criteria fresh) and, with with_info = 1, the estimator whose result estimateInfo() always
+ * ends with (icp.cpp:135-142 -> estimateLUMold, icp_pcl_functions.cpp:51-179).  One workgroup per
+ * item keeps the item's whole target cloud in its compute unit's LDS, so a target may have at most
+ * WM_BATCH_MAX_TARGET_POINTS points (WM_ERR_ARG otherwise: register such pairs one by one).
+ * Results per item k: status[k] (what wm_icp_align would have returned), T_out + 16 k (written
+ * when status[k] == WM_OK), info_out + 36 k (with_info; written whenever the item ran), stats[k].
+ * T_out, info_out, stats may be NULL.  The call returns WM_OK when the batch ran. */
+#define WM_BATCH_MAX_TARGET_POINTS 10240
+typedef struct {
+    const void *src;    /* wave `ref`    */
+    size_t n_src;
+    const void *target; /* wave `target` */
+    size_t n_target;
+} wm_batch_item;
+int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, size_t stride_bytes,
+                       int mem, const wm_icp_params *p, int with_info, double *T_out,
+                       double *info_out, wm_icp_stats *stats, int *status);
+
 /* pcl::VoxelGrid<PointXYZ>::filter on device (icp.cpp:81-90,106-113; gicp.cpp:39-40,
  * 49-50): float centroid per occupied leaf, ascending leaf index; `out` must hold
  * `cap` points of `out_stride` bytes. */

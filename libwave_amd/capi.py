@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwavematch_hip.so")
 
 WM_OK, WM_NOT_CONVERGED, WM_TOO_FEW = 0, 1, 2
+WM_BATCH_MAX_TARGET_POINTS = 10240  # wm_icp_batch_match: one target cloud has to fit one CU's LDS
 WM_MEM_HOST, WM_MEM_DEVICE = 0, 1
 WM_ICP_SVD, WM_ICP_GN6 = 0, 1
 WM_NN_AUTO, WM_NN_GRID, WM_NN_BRUTE = 0, 1, 2
@@ -43,6 +44,10 @@ class IcpStats(C.Structure):
                 ("solve_ms", C.c_float), ("nn_launches", C.c_int), ("nn_levels", C.c_int),
                 ("deferred", C.c_uint64), ("grid_cell", C.c_float),
                 ("owned_violations", C.c_int)]
+
+
+class BatchItem(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("n_src", C.c_size_t), ("target", C.c_void_p), ("n_target", C.c_size_t)]
 
 
 class GicpParams(C.Structure):
@@ -104,6 +109,9 @@ def lib():
         L.wm_icp_match.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                    C.c_size_t, C.c_int, C.POINTER(IcpParams), C.c_float, C.c_int,
                                    _dp, C.POINTER(IcpStats)]
+        L.wm_icp_batch_match.argtypes = [C.c_void_p, C.POINTER(BatchItem), C.c_int, C.c_size_t, C.c_int,
+                                         C.POINTER(IcpParams), C.c_int, _dp, _dp, C.POINTER(IcpStats),
+                                         C.POINTER(C.c_int)]
         L.wm_voxel_downsample.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
                                           C.c_float, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t,
                                           C.POINTER(C.c_size_t)]
@@ -307,6 +315,37 @@ class Context:
                                             T.ctypes.data_as(_dp), C.byref(s)), "wm_icp_match")
         self.n_src, self.n_tgt = self.sizes()
         return self._stats_dict(rc, T, s)
+
+    def icp_batch_match(self, pairs, with_info=True, params=None, **kw):
+        """Many small full-resolution registrations (+ estimateLUMold) in one launch
+        (wm_icp_batch_match).  pairs: [(ref, target), ...]; -> list of dicts as icp_align's, plus
+        'info' (6x6) when with_info."""
+        p = params or icp_params(**kw)
+        n = len(pairs)
+        items = (BatchItem * max(n, 1))()
+        keep = []
+        stride = mem = None
+        for k, (ref, tgt) in enumerate(pairs):
+            pr, nr, sr, mr, k1 = _cloud_arg(ref)
+            pt, nt, stt, mt, k2 = _cloud_arg(tgt)
+            assert sr == stt and mr == mt and (stride in (None, sr)) and (mem in (None, mr))
+            stride, mem = sr, mr
+            keep += [k1, k2]
+            items[k].src, items[k].n_src, items[k].target, items[k].n_target = pr, nr, pt, nt
+        T = np.zeros((max(n, 1), 4, 4), np.float64)
+        info = np.zeros((max(n, 1), 6, 6), np.float64)
+        stats = (IcpStats * max(n, 1))()
+        status = (C.c_int * max(n, 1))()
+        self._check(lib().wm_icp_batch_match(self._h, items, n, stride or 16, mem or WM_MEM_HOST, C.byref(p),
+                                             1 if with_info else 0, T.ctypes.data_as(_dp),
+                                             info.ctypes.data_as(_dp), stats, status), "wm_icp_batch_match")
+        out = []
+        for k in range(n):
+            d = self._stats_dict(status[k], T[k].copy(), stats[k])
+            if with_info:
+                d["info"] = info[k].copy()
+            out.append(d)
+        return out
 
     def voxel_downsample(self, cloud, leaf):
         ptr, n, stride, mem, keep = _cloud_arg(cloud)

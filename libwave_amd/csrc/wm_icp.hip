@@ -13,6 +13,7 @@
 //      the loop.  In the multi-GPU path the 32-double statistics block is what
 //      the RCCL all-reduce carries between (2) and (3).
 #include "wm_internal.hpp"
+#include "wm_icp_step.hpp"
 
 #include <chrono>
 #include <thread>
@@ -131,135 +132,6 @@ __global__ void __launch_bounds__(kBlock)
         for (int w = 0; w < kBlock / 64; ++w) s += lds[w][threadIdx.x];
         partials[(size_t) blockIdx.x * kAcc + threadIdx.x] = s;
     }
-}
-
-// expand the 17 compact accumulators to the public 32-slot layout
-__device__ __host__ inline void expand_stats(int mode, const double *a, double *st) {
-#pragma unroll
-    for (int k = 0; k < kStatsLen; ++k) st[k] = 0.0;
-    st[kStatsLen - 1] = a[17];  // source points handled (ownership check of the sharded path)
-    if (mode == WM_ICP_SVD) {
-        st[kSvdN] = a[0];
-        for (int k = 0; k < 3; ++k) st[kSvdSp + k] = a[1 + k];
-        for (int k = 0; k < 3; ++k) st[kSvdSq + k] = a[4 + k];
-        for (int k = 0; k < 9; ++k) st[kSvdSqp + k] = a[7 + k];
-        st[kSvdSd2] = a[16];
-    } else {
-        const double n = a[0], sx = a[1], sy = a[2], sz = a[3];
-        double H[36];
-#pragma unroll
-        for (int k = 0; k < 36; ++k) H[k] = 0;
-        H[0] = H[7] = H[14] = n;
-        H[0 * 6 + 4] = sz;
-        H[0 * 6 + 5] = -sy;
-        H[1 * 6 + 3] = -sz;
-        H[1 * 6 + 5] = sx;
-        H[2 * 6 + 3] = sy;
-        H[2 * 6 + 4] = -sx;
-        H[3 * 6 + 3] = a[4];
-        H[3 * 6 + 4] = a[5];
-        H[3 * 6 + 5] = a[6];
-        H[4 * 6 + 4] = a[7];
-        H[4 * 6 + 5] = a[8];
-        H[5 * 6 + 5] = a[9];
-        st[kGnN] = n;
-        st[kGnSd2] = a[16];
-        int k = 0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-                if (j >= i) st[kGnH + k++] = H[i * 6 + j];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) st[kGnG + i] = a[10 + i];
-    }
-}
-
-// The solve + stopping rules of one ICP iteration, from the (all-reduced) statistics.
-// Runs as lane 0 of k_reduce_solve on the GPU and as plain host code in
-// wm_host_icp_apply (the sharded path's CPU tests drive exactly this function).
-__host__ __device__ inline void icp_apply_stats(IcpDevState *st, const double *stats_in) {
-
-    // work on a register copy: every st-> access is a global round trip
-    double stats[kStatsLen];
-#pragma unroll
-    for (int k = 0; k < kStatsLen; ++k) stats[k] = stats_in[k];
-    const int mode = st->mode;
-    const double n = stats[0];
-    const double sd2 = mode == WM_ICP_SVD ? stats[kSvdSd2] : stats[kGnSd2];
-    const double mse = n > 0 ? sd2 / n : 0.0;
-    st->n_corr = (int) n;
-    st->mse = mse;
-    if (st->expect_owned > 0 && stats[kStatsLen - 1] != st->expect_owned) st->owned_violations += 1;
-    // bookkeeping for the next iteration's queues
-    st->deferred_total += st->queue_count[1];
-#pragma unroll
-    for (int l = 0; l <= kMaxLevels; ++l) st->queue_count[l] = 0;
-    if (n < 3.0) {  // PCL: min_number_correspondences_ = 3
-        st->state = WM_CONV_NO_CORRESPONDENCES;
-        st->converged = 0;
-        st->done = 1;
-        return;
-    }
-    double Tk[16], Tc[16], Tn[16];
-#ifdef __HIP_DEVICE_COMPILE__
-    st->dbg[4] = clock64();
-#endif
-    if (mode == WM_ICP_SVD)
-        umeyama_from_stats(stats, Tk, st->svd_warm ? st->svd_v : nullptr);
-    else
-        gn6_from_stats(stats, Tk);
-#ifdef __HIP_DEVICE_COMPILE__
-    st->dbg[5] = clock64();
-#endif
-#pragma unroll
-    for (int k = 0; k < 16; ++k) Tc[k] = st->T[k];
-    mat4_mul(Tk, Tc, Tn);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        st->T[k] = Tn[k];
-        st->Tk[k] = Tk[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 12; ++k) st->Tf[k] = (float) Tn[k];
-    const int iter = st->iter + 1;
-    st->iter = iter;
-    st->have_prev = 1;
-    const int max_iter = st->max_iter;
-
-    // pcl::registration::DefaultConvergenceCriteria::hasConverged()
-    if (st->forced) {
-        if (iter >= max_iter) {
-            st->converged = 1;
-            st->state = WM_CONV_FORCED;
-            st->done = 1;
-        }
-        st->prev_mse = mse;
-        return;
-    }
-    if (iter >= max_iter) {
-        st->converged = 1;
-        st->state = WM_CONV_ITERATIONS;
-        st->done = 1;
-        return;
-    }
-    const double prev_mse = st->prev_mse;
-    const double cos_angle = 0.5 * (Tk[0] + Tk[5] + Tk[10] - 1.0);
-    const double tsq = Tk[3] * Tk[3] + Tk[7] * Tk[7] + Tk[11] * Tk[11];
-    int state = WM_CONV_NOT_CONVERGED;
-    if (cos_angle >= st->rot_thr && tsq <= st->trans_thr)
-        state = WM_CONV_TRANSFORM;
-    else if (fabs(mse - prev_mse) < 1e-12)
-        state = WM_CONV_ABS_MSE;
-    else if (fabs(mse - prev_mse) / prev_mse < st->fit_eps)
-        state = WM_CONV_REL_MSE;
-    if (state != WM_CONV_NOT_CONVERGED) {
-        st->converged = 1;
-        st->state = state;
-        st->done = 1;
-        return;
-    }
-    st->prev_mse = mse;
 }
 
 // Pre-reduction for very many partial rows (fused statistics of clouds beyond ~1M points per GPU,
@@ -895,6 +767,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
                       &ctx->shard_ref_band, &ctx->shard_tgt_band, &ctx->shard_misc, &ctx->shard_flags, &ctx->shard_pos_t,
                       &ctx->shard_pos_s, &ctx->shard_stats, &ctx->ndt_sum_dev, &ctx->corr_tmp_idx, &ctx->corr_tmp_d2, &ctx->d_state};
     for (DevBuf *b : bufs) b->release();
+    small_batch_release(ctx);
     for (auto &l : ctx->levels) {
         l.pts.release();
         l.cell_start.release();

@@ -159,6 +159,7 @@ struct wm_ctx {
     // scratch
     wm::DevBuf staging, cell_of, counts, block_sums, bbox_buf;
     wm::DevBuf match_pt, match_pt_bak;  // float4 per (sorted) source point: its match's xyz
+    void *small_batch = nullptr;            // wm_small.hip: staging of the batched small registrations
     wm::DevBuf phase_log;                   // developer: per-iteration phase cycle sums of the search kernel
     wm::DevBuf cost_log;                    // developer: per-query search cost of every iteration (wm_debug_cost_log)
     int cost_log_iter = 0, cost_log_cap = 0;
@@ -308,6 +309,7 @@ int transform_cloud_dev(wm_ctx *ctx, const float4 *in, size_t n, const double T[
 int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2,
                    int stats_mode = -1, unsigned *rows_out = nullptr);
 int launch_nn_brute(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1);
+void small_batch_release(wm_ctx *ctx);
 float threshold_d2(double max_corr);
 float threshold_d2_strict(double max_corr);
 

@@ -1,0 +1,704 @@
+// wm_small.hip -- whole registrations of SMALL clouds inside one compute unit, many per launch.
+//
+// wave::MultiMatcher (wave_matching/include/wave/matching/multi_matcher.hpp:29-96, worker loop
+// impl/multi_matcher_impl.hpp:45-53) is the reference's way to throughput: one single-threaded PCL
+// registration per core.  A 10 000-point pair (BASELINE configs[0]) is 157 wavefronts of work per
+// iteration -- 3 % of an MI355X -- and one registration through wm_icp_align is a chain of ~100
+// DEPENDENT launches of 3-7 us each: sixteen workers on sixteen streams top out at ~5 000
+// registrations/s whatever the number of hardware queues (measured: 4 / 8 / 16 / 24 queues -> 5 200 /
+// 3 400 / 2 900 / 2 400), with the chip mostly idle.  Here the unit of parallelism is the pair, not
+// the point: ONE workgroup of 1 024 lanes runs one whole registration --
+//   ICPMatcher::match()'s full-resolution branch       wave_matching/src/icp.cpp:123-131
+//   + the estimator whose result estimateInfo() keeps  icp.cpp:135-142 -> estimateLUMold,
+//                                                      icp_pcl_functions.cpp:51-179
+// -- and a launch carries one workgroup per queued pair, so 256 pairs fill the 256 CUs and nothing
+// crosses a launch boundary:
+//   1. the target cloud is counting-sorted by cell INTO LDS (x, y, z floats + a 16-bit original
+//      index per point: 14 B x 10 240 points = 140 KB of the CU's 160 KB; 4 096 cells, 16-bit starts);
+//   2. every iteration each lane takes source points in turn: PCL's float transform, an exact 1-NN
+//      search over the cell rows overlapping a certified ball (radius = distance to the previous
+//      iteration's match under the new pose, so one scan certifies), the same 64-bit
+//      (d2 bits, index) arg-min key as wm_nn.hip -- hence the same correspondences, bit for bit --
+//      and the iteration's 17 sums in double;
+//   3. a fixed-order reduction over the 16 wavefronts, then lane 0 runs the very solve + stopping rules
+//      of the big path (icp_apply_stats, wm_icp_step.hpp) on a state that lives in LDS;
+//   4. after the last iteration the LUMold normal equations and residual, same arithmetic as
+//      wm_info.hip.
+// Nothing but the source points, a 16-bit seed per source point and the 500-byte result ever
+// leaves the CU.  Latency of ONE registration is worse than wm_icp_align's (one CU instead of a
+// hundred); this path is for queues of pairs.
+#include "wm_icp_step.hpp"
+#include "wm_internal.hpp"
+
+#include <float.h>
+#include <math.h>
+#include <string.h>
+
+#include <new>
+
+namespace wm {
+
+constexpr int kSmThreads = 1024;
+constexpr int kSmWaves = kSmThreads / 64;
+constexpr int kSmMaxTgt = WM_BATCH_MAX_TARGET_POINTS;  // 10 240
+constexpr int kSmPer = kSmMaxTgt / kSmThreads;
+constexpr int kSmCells = 4096;
+constexpr int kSmRedW = 18;
+static_assert(kSmMaxTgt % kSmThreads == 0 && kSmCells % kSmThreads == 0, "layout");
+
+struct SmallPair {  // one registration of the batch (device table)
+    const unsigned char *src, *tgt;  // caller-layout points in device memory
+    unsigned n_src, n_tgt;
+    unsigned short *seed;  // n_src entries: LDS slot of each source point's last match (0xFFFF none)
+};
+
+struct SmallParams {
+    unsigned stride;        // bytes between points
+    float thr_d2;           // ICP gate: d2 <= max_corr^2      (pcl CorrespondenceEstimation)
+    float thr_d2_strict;    // LUMold gate: d2 < max_corr^2    (icp_pcl_functions.cpp:76-80)
+    float r0_cells;         // first radius of an unseeded search, in cells
+    int with_info;          // 0: none; 1: LUMold
+    int iter_cap;           // safety net over the state's own max_iter
+};
+
+struct SmallOut {
+    double T[16];
+    double info[36];
+    double mse, prev_mse;
+    int iterations, converged, state, n_corr;
+    int info_degenerate, n_target_valid;
+    float cell;
+    int pad;
+};
+
+struct SmallLds {
+    float x[kSmMaxTgt], y[kSmMaxTgt], z[kSmMaxTgt];  // cell-sorted target
+    unsigned short idx[kSmMaxTgt];                   // caller's index of each
+    unsigned short cstart[kSmCells + 8];             // first slot of every cell (+ end)
+    double red[kSmWaves][kSmRedW];
+    double sum[kSmRedW];
+    float boxf[kSmWaves][8];
+    unsigned wsum[kSmWaves];
+    float ox, oy, oz, h, inv_h;
+    int nx, ny, nz;
+    double D[6];
+    IcpDevState st;
+};
+static_assert(sizeof(SmallLds) <= 160 * 1024, "one workgroup's LDS");
+
+__device__ __forceinline__ unsigned long long sm_key(float d2, unsigned idx) {
+    return ((unsigned long long) __float_as_uint(d2) << 32) | idx;
+}
+__device__ __forceinline__ float sm_d2(float qx, float qy, float qz, float tx, float ty, float tz) {
+    const float dx = qx - tx, dy = qy - ty, dz = qz - tz;  // (as canon_d2, wm_nn.hip)
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+// PCL's float transform of a source point: ((m00*x + m01*y) + m02*z) + m03
+__device__ __forceinline__ void sm_xform(const float (&T)[12], float px, float py, float pz, float &x,
+                                         float &y, float &z) {
+    x = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[0], px), __fmul_rn(T[1], py)), __fmul_rn(T[2], pz)), T[3]);
+    y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[4], px), __fmul_rn(T[5], py)), __fmul_rn(T[6], pz)), T[7]);
+    z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[8], px), __fmul_rn(T[9], py)), __fmul_rn(T[10], pz)), T[11]);
+}
+
+struct SmGrid {  // (wave-uniform: lives in scalar registers)
+    float ox, oy, oz, inv_h, h;
+    int nx, ny, nz;
+};
+
+__device__ __forceinline__ int sm_cell1(float v, float o, float inv_h, int n) {
+    const float f = floorf(fminf(fmaxf((v - o) * inv_h, -1.0f), (float) n));
+    const int c = (int) f;
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
+
+// Exact nearest neighbour of (qx, qy, qz) among the LDS-resident points: every cell row that meets
+// the box around ball(q, r) is walked; the result is certified when the best distance is inside r
+// (then nothing outside the box can beat it), else r doubles up to rmax.  `best` comes in as the
+// gate (or the seed's key); candidates only ever lower it.
+__device__ __forceinline__ void sm_search(const SmallLds &L, const SmGrid &g, float qx, float qy, float qz,
+                                          float r, float rmax, unsigned long long &best, unsigned &bslot) {
+    for (;;) {
+        // (the box is a little larger than the ball: it has to hold against the rounding of q -+ r
+        // at the cloud's coordinates, half an ulp of |q|)
+        const float rb = r * 1.001f + 1e-6f + 2.5e-7f * fmaxf(fabsf(qx), fmaxf(fabsf(qy), fabsf(qz)));
+        const int x0 = sm_cell1(qx - rb, g.ox, g.inv_h, g.nx), x1 = sm_cell1(qx + rb, g.ox, g.inv_h, g.nx);
+        const int y0 = sm_cell1(qy - rb, g.oy, g.inv_h, g.ny), y1 = sm_cell1(qy + rb, g.oy, g.inv_h, g.ny);
+        const int z0 = sm_cell1(qz - rb, g.oz, g.inv_h, g.nz), z1 = sm_cell1(qz + rb, g.oz, g.inv_h, g.nz);
+        unsigned bhi = (unsigned) (best >> 32);
+        for (int cz = z0; cz <= z1; ++cz)
+            for (int cy = y0; cy <= y1; ++cy) {
+                const int row = (cz * g.ny + cy) * g.nx;
+                const unsigned s = L.cstart[row + x0], e = L.cstart[row + x1 + 1];
+                for (unsigned j = s; j < e; ++j) {
+                    const float d2 = sm_d2(qx, qy, qz, L.x[j], L.y[j], L.z[j]);
+                    if (__float_as_uint(d2) <= bhi) {  // (d2 >= 0: bit order = numeric order)
+                        const unsigned long long k = sm_key(d2, L.idx[j]);
+                        if (k < best) {
+                            best = k;
+                            bslot = j;
+                            bhi = (unsigned) (k >> 32);
+                        }
+                    }
+                }
+            }
+        if (r >= rmax || sqrtf(__uint_as_float(bhi)) <= r) return;
+        r = fminf(2.0f * r, rmax);
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void sm_block_sum(double (&a)[N], SmallLds &L, unsigned tid) {
+    static_assert(N <= kSmRedW, "reduction scratch");
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a[k] += __shfl_down(a[k], off);
+    const unsigned lane = tid & 63u, wave = tid >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < N; ++k) L.red[wave][k] = a[k];
+    __syncthreads();
+    if (tid < (unsigned) N) {
+        double s = 0;
+        for (int w = 0; w < kSmWaves; ++w) s += L.red[w][tid];  // fixed order
+        L.sum[tid] = s;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ bool sm_load_point(const unsigned char *base, unsigned i, unsigned stride, float &x,
+                                              float &y, float &z) {
+    const float *p = reinterpret_cast<const float *>(base + (size_t) i * stride);
+    x = p[0];
+    y = p[1];
+    z = p[2];
+    return isfinite(x) && isfinite(y) && isfinite(z);  // (non-finite points are dropped, as k_pack does)
+}
+
+__global__ void __launch_bounds__(kSmThreads)
+    k_icp_small(const SmallPair *__restrict__ pairs, SmallParams P, IcpDevState st0, SmallOut *__restrict__ out) {
+    __shared__ SmallLds L;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const SmallPair pr = pairs[blockIdx.x];
+    const unsigned n_tgt = pr.n_tgt < (unsigned) kSmMaxTgt ? pr.n_tgt : (unsigned) kSmMaxTgt;  // (host checked)
+
+    // ---- 1. the target into LDS: bounding box -> grid -> counting sort by cell
+    {
+        float lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY;
+        for (unsigned i = tid; i < n_tgt; i += kSmThreads) {
+            float x, y, z;
+            if (sm_load_point(pr.tgt, i, P.stride, x, y, z)) {
+                lo0 = fminf(lo0, x), lo1 = fminf(lo1, y), lo2 = fminf(lo2, z);
+                hi0 = fmaxf(hi0, x), hi1 = fmaxf(hi1, y), hi2 = fmaxf(hi2, z);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo0 = fminf(lo0, __shfl_xor(lo0, off)), lo1 = fminf(lo1, __shfl_xor(lo1, off));
+            lo2 = fminf(lo2, __shfl_xor(lo2, off)), hi0 = fmaxf(hi0, __shfl_xor(hi0, off));
+            hi1 = fmaxf(hi1, __shfl_xor(hi1, off)), hi2 = fmaxf(hi2, __shfl_xor(hi2, off));
+        }
+        if (lane == 0) {
+            L.boxf[wave][0] = lo0, L.boxf[wave][1] = lo1, L.boxf[wave][2] = lo2;
+            L.boxf[wave][3] = hi0, L.boxf[wave][4] = hi1, L.boxf[wave][5] = hi2;
+        }
+        for (unsigned c = tid; c < (kSmCells + 8) / 2; c += kSmThreads) reinterpret_cast<unsigned *>(L.cstart)[c] = 0u;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < kSmWaves; ++w) {
+                lo0 = fminf(lo0, L.boxf[w][0]), lo1 = fminf(lo1, L.boxf[w][1]), lo2 = fminf(lo2, L.boxf[w][2]);
+                hi0 = fmaxf(hi0, L.boxf[w][3]), hi1 = fmaxf(hi1, L.boxf[w][4]), hi2 = fmaxf(hi2, L.boxf[w][5]);
+            }
+            int nx = 1, ny = 1, nz = 1;
+            float h = 1.0f;
+            if (lo0 <= hi0) {  // at least one finite point
+                const float ex = hi0 - lo0, ey = hi1 - lo1, ez = hi2 - lo2;
+                const float big = fmaxf(ex, fmaxf(ey, ez));
+                const float tiny = fmaxf(big * 1e-6f, 1e-30f);
+                h = cbrtf(fmaxf(ex, tiny) * fmaxf(ey, tiny) * fmaxf(ez, tiny) / (float) kSmCells);
+                h = fmaxf(h, tiny);
+                // the finest cubic cells that fit the table (any size is exact; this one is quick)
+                for (int it = 0; it < 400; ++it) {
+                    const float fx = floorf(ex / h) + 1.0f, fy = floorf(ey / h) + 1.0f, fz = floorf(ez / h) + 1.0f;
+                    if (fx * fy * fz <= (float) kSmCells) {
+                        nx = (int) fx, ny = (int) fy, nz = (int) fz;
+                        break;
+                    }
+                    h *= 1.06f;
+                }
+                if (nx * ny * nz > kSmCells || !(h > 0.0f) || !isfinite(h)) nx = ny = nz = 1, h = fmaxf(big, 1.0f);
+            } else {
+                lo0 = lo1 = lo2 = 0.0f;
+            }
+            L.ox = lo0, L.oy = lo1, L.oz = lo2, L.h = h, L.inv_h = 1.0f / h;
+            L.nx = nx, L.ny = ny, L.nz = nz;
+            L.st = st0;
+        }
+        __syncthreads();
+    }
+    SmGrid g;
+    g.ox = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, L.ox)));
+    g.oy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, L.oy)));
+    g.oz = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, L.oz)));
+    g.h = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, L.h)));
+    g.inv_h = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, L.inv_h)));
+    g.nx = __builtin_amdgcn_readfirstlane(L.nx);
+    g.ny = __builtin_amdgcn_readfirstlane(L.ny);
+    g.nz = __builtin_amdgcn_readfirstlane(L.nz);
+    {
+        // count: two 16-bit counters per LDS word; the returned old value is the point's rank in its cell
+        unsigned cr[kSmPer];
+        unsigned *cw = reinterpret_cast<unsigned *>(L.cstart);
+#pragma unroll
+        for (int k = 0; k < kSmPer; ++k) {
+            const unsigned i = tid + (unsigned) k * kSmThreads;
+            cr[k] = ~0u;
+            float x, y, z;
+            if (i < n_tgt && sm_load_point(pr.tgt, i, P.stride, x, y, z)) {
+                const unsigned c = (unsigned) ((sm_cell1(z, g.oz, g.inv_h, g.nz) * g.ny + sm_cell1(y, g.oy, g.inv_h, g.ny)) * g.nx +
+                                               sm_cell1(x, g.ox, g.inv_h, g.nx));
+                const unsigned sh = (c & 1u) * 16u;
+                const unsigned old = atomicAdd(&cw[c >> 1], 1u << sh);
+                cr[k] = (c << 16) | ((old >> sh) & 0xFFFFu);
+            }
+        }
+        __syncthreads();
+        // exclusive scan of the 4 096 counts, in place (4 per lane)
+        constexpr int E = kSmCells / kSmThreads;
+        unsigned v[E], s = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            v[e] = L.cstart[E * tid + e];
+            s += v[e];
+        }
+        unsigned incl = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = __shfl_up(incl, off);
+            if (lane >= (unsigned) off) incl += t;
+        }
+        if (lane == 63) L.wsum[wave] = incl;
+        __syncthreads();
+        unsigned run = incl - s;
+        for (unsigned w = 0; w < wave; ++w) run += L.wsum[w];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            L.cstart[E * tid + e] = (unsigned short) run;
+            run += v[e];
+        }
+        if (tid == kSmThreads - 1) L.cstart[kSmCells] = (unsigned short) run;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kSmPer; ++k) {
+            if (cr[k] == ~0u) continue;
+            const unsigned i = tid + (unsigned) k * kSmThreads;
+            float x, y, z;
+            (void) sm_load_point(pr.tgt, i, P.stride, x, y, z);
+            const unsigned slot = (unsigned) L.cstart[cr[k] >> 16] + (cr[k] & 0xFFFFu);
+            L.x[slot] = x, L.y[slot] = y, L.z[slot] = z;
+            L.idx[slot] = (unsigned short) i;
+        }
+        __syncthreads();
+    }
+    const float rmax = sqrtf(P.thr_d2) * 1.0001f + 1e-6f;
+
+    // ---- 2./3. the iterations
+    for (int guard = 0; guard < P.iter_cap; ++guard) {
+        if (L.st.done) break;  // (uniform: written by lane 0 before the barrier that ended the last trip)
+        float Tf[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Tf[k] = L.st.Tf[k];
+        const bool have_prev = L.st.have_prev != 0;
+        const int mode = L.st.mode;
+        double a[kAcc];
+#pragma unroll
+        for (int k = 0; k < kAcc; ++k) a[k] = 0.0;
+        for (unsigned q = tid; q < pr.n_src; q += kSmThreads) {
+            float sx, sy, sz;
+            if (!sm_load_point(pr.src, q, P.stride, sx, sy, sz)) continue;
+            float qx, qy, qz;
+            sm_xform(Tf, sx, sy, sz, qx, qy, qz);
+            unsigned long long best = sm_key(P.thr_d2, kNoIdx);
+            unsigned bslot = 0xFFFFu;
+            float r = P.r0_cells * g.h;
+            if (have_prev) {
+                // the point matched in the previous iteration is a real candidate: its distance under
+                // the NEW pose bounds the new neighbour's, so one scan of that ball certifies
+                const unsigned ps = pr.seed[q];
+                r = rmax;
+                if (ps != 0xFFFFu) {
+                    const float d2b = sm_d2(qx, qy, qz, L.x[ps], L.y[ps], L.z[ps]);
+                    if (d2b <= P.thr_d2) {
+                        best = sm_key(d2b, L.idx[ps]);
+                        bslot = ps;
+                        r = fmaxf(sqrtf(d2b) * 1.0001f + 1e-6f, 0.05f * g.h);
+                    }
+                }
+            }
+            sm_search(L, g, qx, qy, qz, fminf(r, rmax), rmax, best, bslot);
+            const bool matched = (unsigned) best != kNoIdx;
+            pr.seed[q] = (unsigned short) (matched ? bslot : 0xFFFFu);
+            a[17] += 1.0;
+            if (!matched) continue;
+            // the iteration's sums, as k_icp_stats (wm_icp.hip) forms them
+            const double px = qx, py = qy, pz = qz, tx = L.x[bslot], ty = L.y[bslot], tz = L.z[bslot];
+            a[0] += 1.0;
+            a[1] += px;
+            a[2] += py;
+            a[3] += pz;
+            if (mode == WM_ICP_SVD) {
+                a[4] += tx;
+                a[5] += ty;
+                a[6] += tz;
+                a[7] += tx * px;
+                a[8] += tx * py;
+                a[9] += tx * pz;
+                a[10] += ty * px;
+                a[11] += ty * py;
+                a[12] += ty * pz;
+                a[13] += tz * px;
+                a[14] += tz * py;
+                a[15] += tz * pz;
+            } else {
+                const double rx = px - tx, ry = py - ty, rz = pz - tz;
+                a[4] += py * py + pz * pz;
+                a[5] += -px * py;
+                a[6] += -px * pz;
+                a[7] += px * px + pz * pz;
+                a[8] += -py * pz;
+                a[9] += px * px + py * py;
+                a[10] += rx;
+                a[11] += ry;
+                a[12] += rz;
+                a[13] += py * rz - pz * ry;
+                a[14] += pz * rx - px * rz;
+                a[15] += px * ry - py * rx;
+            }
+            a[16] += (double) __uint_as_float((unsigned) (best >> 32));
+        }
+        sm_block_sum<kAcc>(a, L, tid);
+        if (tid == 0) {
+            double ex[kStatsLen];
+            expand_stats(mode, L.sum, ex);
+            icp_apply_stats(&L.st, ex);
+        }
+        __syncthreads();
+    }
+
+    // ---- 4. estimateLUMold on the aligned cloud (icp_pcl_functions.cpp:51-179; arithmetic of wm_info.hip)
+    const bool with_info = P.with_info != 0;
+    if (with_info) {
+        float Tf[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Tf[k] = (float) L.st.T[k];
+        const float rmax_s = sqrtf(P.thr_d2_strict) * 1.0001f + 1e-6f;
+        const bool have_prev = L.st.have_prev != 0;
+        double a[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = 0.0;
+        for (unsigned q = tid; q < pr.n_src; q += kSmThreads) {
+            float sx, sy, sz;
+            if (!sm_load_point(pr.src, q, P.stride, sx, sy, sz)) continue;
+            float px, py, pz;
+            sm_xform(Tf, sx, sy, sz, px, py, pz);
+            unsigned long long best = sm_key(P.thr_d2_strict, kNoIdx);
+            unsigned bslot = 0xFFFFu;
+            float r = rmax_s;
+            const unsigned ps = have_prev ? (unsigned) pr.seed[q] : 0xFFFFu;
+            if (ps != 0xFFFFu) {
+                const float d2b = sm_d2(px, py, pz, L.x[ps], L.y[ps], L.z[ps]);
+                if (d2b <= P.thr_d2_strict) {
+                    best = sm_key(d2b, L.idx[ps]);
+                    bslot = ps;
+                    r = fmaxf(sqrtf(d2b) * 1.0001f + 1e-6f, 0.05f * g.h);
+                }
+            } else if (!have_prev) {
+                r = P.r0_cells * g.h;
+            }
+            sm_search(L, g, px, py, pz, fminf(r, rmax_s), rmax_s, best, bslot);
+            const bool matched = (unsigned) best != kNoIdx;
+            pr.seed[q] = (unsigned short) (matched ? bslot : 0xFFFFu);
+            if (!matched) continue;
+            const float tx = L.x[bslot], ty = L.y[bslot], tz = L.z[bslot];
+            const float av0 = __fmul_rn(0.5f, __fadd_rn(px, tx)), av1 = __fmul_rn(0.5f, __fadd_rn(py, ty)),
+                        av2 = __fmul_rn(0.5f, __fadd_rn(pz, tz));
+            const float df0 = __fsub_rn(px, tx), df1 = __fsub_rn(py, ty), df2 = __fsub_rn(pz, tz);
+            a[0] += 1.0;
+            a[1] += av0;
+            a[2] += av1;
+            a[3] += av2;
+            a[4] += __fmul_rn(av0, av2);
+            a[5] += __fmul_rn(av0, av1);
+            a[6] += __fmul_rn(av1, av2);
+            a[7] += __fadd_rn(__fmul_rn(av1, av1), __fmul_rn(av2, av2));
+            a[8] += __fadd_rn(__fmul_rn(av0, av0), __fmul_rn(av1, av1));
+            a[9] += __fadd_rn(__fmul_rn(av0, av0), __fmul_rn(av2, av2));
+            a[10] += df0;
+            a[11] += df1;
+            a[12] += df2;
+            a[13] += __fsub_rn(__fmul_rn(av1, df2), __fmul_rn(av2, df1));
+            a[14] += __fsub_rn(__fmul_rn(av0, df1), __fmul_rn(av1, df0));
+            a[15] += __fsub_rn(__fmul_rn(av2, df0), __fmul_rn(av0, df2));
+        }
+        sm_block_sum<16>(a, L, tid);
+        double MM[36];
+        if (tid == 0) {
+            const double *s = L.sum;
+#pragma unroll
+            for (int k = 0; k < 36; ++k) MM[k] = 0.0;
+#define M_(r, c) MM[(r) * 6 + (c)]
+            M_(0, 4) = -s[2];
+            M_(0, 5) = s[3];
+            M_(1, 3) = -s[3];
+            M_(1, 4) = s[1];
+            M_(2, 3) = s[2];
+            M_(2, 5) = -s[1];
+            M_(3, 4) = -s[4];
+            M_(3, 5) = -s[5];
+            M_(4, 5) = -s[6];
+            M_(3, 3) = s[7];
+            M_(4, 4) = s[8];
+            M_(5, 5) = s[9];
+            M_(0, 0) = M_(1, 1) = M_(2, 2) = (double) (float) (int) s[0];
+            M_(4, 0) = M_(0, 4);
+            M_(5, 0) = M_(0, 5);
+            M_(3, 1) = M_(1, 3);
+            M_(4, 1) = M_(1, 4);
+            M_(3, 2) = M_(2, 3);
+            M_(5, 2) = M_(2, 5);
+            M_(4, 3) = M_(3, 4);
+            M_(5, 3) = M_(3, 5);
+            M_(5, 4) = M_(4, 5);
+#undef M_
+            double MMinv[36];
+            inverse<6>(MM, MMinv);
+            for (int r = 0; r < 6; ++r) {
+                double d = 0;
+                for (int c = 0; c < 6; ++c) d += MMinv[r * 6 + c] * s[10 + c];
+                L.D[r] = d;
+            }
+        }
+        __syncthreads();
+        double D[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) D[k] = L.D[k];
+        double ss[1] = {0.0};
+        for (unsigned q = tid; q < pr.n_src; q += kSmThreads) {
+            const unsigned bslot = pr.seed[q];
+            float sx, sy, sz;
+            if (!sm_load_point(pr.src, q, P.stride, sx, sy, sz) || bslot == 0xFFFFu) continue;
+            float px, py, pz;
+            sm_xform(Tf, sx, sy, sz, px, py, pz);
+            const float tx = L.x[bslot], ty = L.y[bslot], tz = L.z[bslot];
+            const float av0 = __fmul_rn(0.5f, __fadd_rn(px, tx)), av1 = __fmul_rn(0.5f, __fadd_rn(py, ty)),
+                        av2 = __fmul_rn(0.5f, __fadd_rn(pz, tz));
+            const float df0 = __fsub_rn(px, tx), df1 = __fsub_rn(py, ty), df2 = __fsub_rn(pz, tz);
+            const double e0 = df0 - (D[0] + av2 * D[5] - av1 * D[4]);
+            const double e1 = df1 - (D[1] + av0 * D[4] - av2 * D[3]);
+            const double e2 = df2 - (D[2] + av1 * D[3] - av0 * D[5]);
+            ss[0] += (double) (float) (e0 * e0 + e1 * e1 + e2 * e2);
+        }
+        sm_block_sum<1>(ss, L, tid);
+        if (tid == 0) {
+            const float s2 = (float) L.sum[0];
+            const bool bad = (s2 < 0.0000000000001f || !isfinite(s2));
+            // estimateLUMold falls through its failure branch (icp_pcl_functions.cpp:170-178)
+            const float inv = 1.0f / s2;
+            SmallOut &o = out[blockIdx.x];
+            for (int k = 0; k < 36; ++k) o.info[k] = MM[k] * inv;
+            o.info_degenerate = bad ? 1 : 0;
+        }
+    }
+    if (tid == 0) {
+        SmallOut &o = out[blockIdx.x];
+        const IcpDevState &s = L.st;
+        for (int k = 0; k < 16; ++k) o.T[k] = s.T[k];
+        o.mse = s.mse;
+        o.prev_mse = s.prev_mse;
+        o.iterations = s.iter;
+        o.converged = s.converged;
+        o.state = s.state;
+        o.n_corr = s.n_corr;
+        o.n_target_valid = (int) L.cstart[kSmCells];
+        o.cell = g.h;
+        if (!with_info) o.info_degenerate = 0;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+struct SmallBatch {
+    DevBuf d_stage;     // [table | clouds | seeds]
+    DevBuf d_out;
+    void *h_stage = nullptr;  // pinned mirror of table + clouds
+    size_t h_stage_cap = 0;
+    void *h_out = nullptr;
+    size_t h_out_cap = 0;
+};
+
+static SmallBatch *small_of(wm_ctx *ctx) {
+    if (!ctx->small_batch) ctx->small_batch = new (std::nothrow) SmallBatch();
+    return static_cast<SmallBatch *>(ctx->small_batch);
+}
+
+void small_batch_release(wm_ctx *ctx) {
+    SmallBatch *b = static_cast<SmallBatch *>(ctx->small_batch);
+    if (!b) return;
+    b->d_stage.release();
+    b->d_out.release();
+    if (b->h_stage) (void) hipHostFree(b->h_stage);
+    if (b->h_out) (void) hipHostFree(b->h_out);
+    delete b;
+    ctx->small_batch = nullptr;
+}
+
+static int pinned_reserve(wm_ctx *ctx, void **p, size_t *cap, size_t bytes) {
+    if (bytes <= *cap) return WM_OK;
+    if (*p) (void) hipHostFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    WM_HIP(ctx, hipHostMalloc(p, want, hipHostMallocDefault));
+    *cap = want;
+    return WM_OK;
+}
+
+}  // namespace wm
+
+using namespace wm;
+
+extern "C" {
+
+int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, size_t stride, int mem,
+                       const wm_icp_params *p, int with_info, double *T_out, double *info_out,
+                       wm_icp_stats *stats, int *status) {
+    if (!ctx || !p || !status || n_items < 0 || (n_items > 0 && !items) || stride < 12 || (stride & 3)) return WM_ERR_ARG;
+    if (!(p->max_corr > 0) || (p->mode != WM_ICP_SVD && p->mode != WM_ICP_GN6)) return WM_ERR_ARG;
+    if (p->force_iterations <= 0 && p->max_iter <= 0) return WM_ERR_ARG;
+    if (with_info != 0 && with_info != 1) return WM_ERR_ARG;
+    if (n_items == 0) return WM_OK;
+    size_t cloud_bytes = 0, seeds = 0;
+    int live = 0;
+    for (int k = 0; k < n_items; ++k) {
+        const wm_batch_item &it = items[k];
+        if ((it.n_src > 0 && !it.src) || (it.n_target > 0 && !it.target)) return WM_ERR_ARG;
+        if (it.n_target > (size_t) kSmMaxTgt || it.n_src > 0x7FFFFFF0u) return WM_ERR_ARG;
+        if (it.n_src == 0 || it.n_target == 0) continue;  // (answered on the host, below)
+        cloud_bytes += ((it.n_src * stride + 15) & ~(size_t) 15) + ((it.n_target * stride + 15) & ~(size_t) 15);
+        seeds += (it.n_src + 7) & ~(size_t) 7;
+        ++live;
+    }
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    SmallBatch *B = small_of(ctx);
+    if (!B) return WM_ERR_NOMEM;
+    if (stats) memset(stats, 0, sizeof(*stats) * (size_t) n_items);
+    for (int k = 0; k < n_items; ++k) {
+        // PCL: an empty input cloud -> "Not enough correspondences"; match() returns false
+        const wm_batch_item &it = items[k];
+        status[k] = (it.n_src == 0 || it.n_target == 0) ? (it.n_src == 0 && it.n_target == 0 ? WM_ERR_STATE : WM_TOO_FEW_CORRESPONDENCES) : WM_OK;
+        if (status[k] != WM_OK && stats) stats[k].state = WM_CONV_NO_CORRESPONDENCES;
+    }
+    if (live == 0) return WM_OK;
+
+    const size_t table_bytes = ((size_t) live * sizeof(SmallPair) + 255) & ~(size_t) 255;
+    const size_t up_bytes = table_bytes + (mem == WM_MEM_HOST ? cloud_bytes : 0);
+    const size_t dev_bytes = table_bytes + (mem == WM_MEM_HOST ? cloud_bytes : 0) + seeds * sizeof(unsigned short);
+    WM_HIP(ctx, B->d_stage.reserve(dev_bytes));
+    WM_HIP(ctx, B->d_out.reserve((size_t) live * sizeof(SmallOut)));
+    WM_TRY(pinned_reserve(ctx, &B->h_stage, &B->h_stage_cap, up_bytes));
+    WM_TRY(pinned_reserve(ctx, &B->h_out, &B->h_out_cap, (size_t) live * sizeof(SmallOut)));
+    // the stream may still be reading the staging buffer for the previous batch
+    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+    unsigned char *h = static_cast<unsigned char *>(B->h_stage);
+    unsigned char *d = B->d_stage.as<unsigned char>();
+    SmallPair *table = reinterpret_cast<SmallPair *>(h);
+    size_t off = table_bytes;
+    unsigned short *seed_base = reinterpret_cast<unsigned short *>(d + table_bytes + (mem == WM_MEM_HOST ? cloud_bytes : 0));
+    size_t seed_off = 0;
+    int row = 0;
+    for (int k = 0; k < n_items; ++k) {
+        const wm_batch_item &it = items[k];
+        if (status[k] != WM_OK) continue;
+        SmallPair &t = table[row++];
+        t.n_src = (unsigned) it.n_src;
+        t.n_tgt = (unsigned) it.n_target;
+        if (mem == WM_MEM_HOST) {
+            memcpy(h + off, it.src, it.n_src * stride);
+            t.src = d + off;
+            off += (it.n_src * stride + 15) & ~(size_t) 15;
+            memcpy(h + off, it.target, it.n_target * stride);
+            t.tgt = d + off;
+            off += (it.n_target * stride + 15) & ~(size_t) 15;
+        } else {
+            t.src = static_cast<const unsigned char *>(it.src);
+            t.tgt = static_cast<const unsigned char *>(it.target);
+        }
+        t.seed = seed_base + seed_off;
+        seed_off += (it.n_src + 7) & ~(size_t) 7;
+    }
+    WM_HIP(ctx, hipMemcpyAsync(d, h, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+
+    double I[16];
+    mat4_identity(I);
+    IcpDevState st0;
+    memset(&st0, 0, sizeof(st0));
+    for (int k = 0; k < 16; ++k) st0.T[k] = I[k];
+    for (int k = 0; k < 12; ++k) st0.Tf[k] = (float) I[k];
+    mat4_identity(st0.Tk);
+    st0.prev_mse = DBL_MAX;  // every pair starts with fresh stopping criteria
+    st0.forced = p->force_iterations > 0;
+    st0.max_iter = st0.forced ? p->force_iterations : p->max_iter;
+    st0.mode = p->mode;
+    st0.rot_thr = 1.0 - p->t_eps;
+    st0.trans_thr = p->t_eps;
+    st0.fit_eps = p->fit_eps;
+    st0.svd_warm = ctx->tune_fast_solve ? 1 : 0;
+    SmallParams P;
+    memset(&P, 0, sizeof(P));
+    P.stride = (unsigned) stride;
+    P.thr_d2 = threshold_d2(p->max_corr);
+    P.thr_d2_strict = threshold_d2_strict(p->max_corr);
+    P.r0_cells = 0.5f;
+    P.with_info = with_info;
+    P.iter_cap = st0.max_iter + 1;
+    WM_HIP(ctx, hipEventRecord(ctx->ev_a, ctx->stream));
+    hipLaunchKernelGGL(k_icp_small, dim3((unsigned) live), dim3(kSmThreads), 0, ctx->stream,
+                       reinterpret_cast<const SmallPair *>(d), P, st0, B->d_out.as<SmallOut>());
+    WM_HIP(ctx, hipGetLastError());
+    WM_HIP(ctx, hipEventRecord(ctx->ev_b, ctx->stream));
+    WM_HIP(ctx, hipMemcpyAsync(B->h_out, B->d_out.p, (size_t) live * sizeof(SmallOut), hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    (void) hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b);
+
+    const SmallOut *o = static_cast<const SmallOut *>(B->h_out);
+    row = 0;
+    for (int k = 0; k < n_items; ++k) {
+        if (status[k] != WM_OK) continue;
+        const SmallOut &r = o[row++];
+        if (stats) {
+            wm_icp_stats &s = stats[k];
+            s.converged = r.converged;
+            s.iterations = r.iterations;
+            s.state = r.state;
+            s.n_corr = r.n_corr;
+            s.mse = r.mse;
+            s.prev_mse = r.prev_mse;
+            s.align_ms = ms;  // (the whole batch's launch)
+            s.nn_levels = 1;
+            s.grid_cell = r.cell;
+        }
+        if (r.state == WM_CONV_NO_CORRESPONDENCES)
+            status[k] = WM_TOO_FEW_CORRESPONDENCES;
+        else if (!r.converged)
+            status[k] = WM_NOT_CONVERGED;
+        else if (T_out)
+            memcpy(T_out + 16 * (size_t) k, r.T, sizeof(r.T));
+        // estimateLUMold runs whatever match() returned (icp.cpp:135-142 has no hasConverged() guard on it)
+        if (with_info && info_out) memcpy(info_out + 36 * (size_t) k, r.info, sizeof(r.info));
+    }
+    return WM_OK;
+}
+
+}  // extern "C"

@@ -118,6 +118,66 @@ bool ICPMatcher::match() {
     return true;
 }
 
+namespace {
+void storeInfo(const double in[36], Mat6 &out) {
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) out(r, c) = in[6 * r + c];
+}
+void warnIfDegenerate(int degenerate) {
+    if (degenerate) LOG_ERROR("Covariance matrix calculation was unsuccessful");
+}
+}  // namespace
+
+// ---- many pairs, one launch
+size_t ICPMatcher::maxBatchTargetPoints() { return WM_BATCH_MAX_TARGET_POINTS; }
+
+bool ICPMatcher::batchable(const PCLPointCloudPtr &r, const PCLPointCloudPtr &t) const {
+    return !(params.res > 0) && devices.size() <= 1 && r && t && cloudSize(t) <= maxBatchTargetPoints();
+}
+
+bool ICPMatcher::matchBatch(const std::vector<std::pair<PCLPointCloudPtr, PCLPointCloudPtr>> &pairs,
+                            BatchOutcomes &out) {
+    out.clear();
+    if (pairs.empty()) return true;
+    for (const auto &pr : pairs)
+        if (!batchable(pr.first, pr.second)) return false;
+    if (!ensureContext()) return false;
+    wm_icp_params p;
+    wm_icp_default_params(&p);
+    p.max_corr = params.max_corr;  // as match() sets them (icp.cpp:47-50)
+    p.max_iter = params.max_iter;
+    p.t_eps = params.t_eps;
+    p.fit_eps = params.fit_eps;
+    const size_t n = pairs.size();
+    std::vector<wm_batch_item> items(n);
+    for (size_t k = 0; k < n; ++k) {
+        items[k].src = cloudData(pairs[k].first);
+        items[k].n_src = cloudSize(pairs[k].first);
+        items[k].target = cloudData(pairs[k].second);
+        items[k].n_target = cloudSize(pairs[k].second);
+    }
+    std::vector<double> T(16 * n), info(36 * n);
+    std::vector<int> status(n, WM_ERR_STATE);
+    // estimateInfo(): whatever estimator is configured, the switch without `break` (icp.cpp:136-141)
+    // ends in estimateLUMold, whose result is the one that stays in `information`
+    const int rc = wm_icp_batch_match(ctx, items.data(), (int) n, kCloudStride, WM_MEM_HOST, &p, 1, T.data(),
+                                      info.data(), nullptr, status.data());
+    if (!shim::succeeded(rc, "wm_icp_batch_match", ctx)) return false;
+    out.resize(n);
+    for (size_t k = 0; k < n; ++k) {
+        ref = pairs[k].first;
+        target = pairs[k].second;
+        converged = status[k] == WM_OK;
+        if (converged) shim::toAffine(&T[16 * k], result);  // anything else leaves `result` as it was (icp.cpp:132)
+        if (status[k] >= 0 && items[k].n_src > 0 && items[k].n_target > 0) storeInfo(&info[36 * k], information);
+        out[k].matched = converged;
+        out[k].transform = result;
+        out[k].info = information;
+    }
+    converged = false;  // (no correspondences are kept on the device for a later estimateLUM / estimateCensi)
+    return true;
+}
+
 // ---- information matrix
 // The reference's dispatch (icp.cpp:136-141) is a switch without `break`: LUM runs all three
 // estimators, CENSI the last two, and whatever was asked for, LUMold writes `information` last.
@@ -129,15 +189,6 @@ void ICPMatcher::estimateInfo() {
     if (first <= ICPMatcherParams::LUMold) estimateLUMold();
 }
 
-namespace {
-void storeInfo(const double in[36], Mat6 &out) {
-    for (int r = 0; r < 6; ++r)
-        for (int c = 0; c < 6; ++c) out(r, c) = in[6 * r + c];
-}
-void warnIfDegenerate(int degenerate) {
-    if (degenerate) LOG_ERROR("Covariance matrix calculation was unsuccessful");
-}
-}  // namespace
 
 void ICPMatcher::estimateLUM() {
     if (!ctx || !converged) return;  // hasConverged() guard of icp_pcl_functions.cpp:190

@@ -6,6 +6,10 @@
 //
 //   bench_multimatcher <points per cloud> <pairs> <workers> [<workers> ...]
 // prints one JSON line per worker count.  Built by libwave_amd/host/Makefile.
+// Environment: BENCH_QUEUE = capacity of the job queue (default 2 x workers, as small as the
+// reference's default of 10 suggests; a worker takes everything that is queued -- up to 256 pairs --
+// into one device launch when the clouds fit the batched path, so deep queues are what fill the GPU).
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -67,9 +71,13 @@ int main(int argc, char **argv) {
     for (int a = 3; a < argc; ++a) {
         const int workers = std::atoi(argv[a]);
         wave::MultiMatcher<wave::ICPMatcher, wave::ICPMatcherParams>::setMaxWorkers(workers);
-        wave::MultiMatcher<wave::ICPMatcher, wave::ICPMatcherParams> pool(workers, 2 * workers, params);
+        const char *qenv = std::getenv("BENCH_QUEUE");
+        const int queue = qenv && std::atoi(qenv) > 0 ? std::atoi(qenv) : 2 * workers;
+        wave::MultiMatcher<wave::ICPMatcher, wave::ICPMatcherParams> pool(workers, queue, params);
+        double shift_sum = 0;
         auto drain = [&](int count) {
             int got = 0, ok = 0;
+            shift_sum = 0;
             for (int j = 0; j < count; ++j) pool.insert(j, refs[(size_t) j % 4], targets[(size_t) j % 4]);
             while (got < count) {
                 int id;
@@ -78,19 +86,21 @@ int main(int argc, char **argv) {
                 if (pool.getResult(&id, &T, &info)) {
                     ++got;
                     ok += std::abs(T.translation()(0) - 0.15) < 0.05;
+                    shift_sum += T.translation()(0);
                 } else {
                     std::this_thread::yield();
                 }
             }
             return ok;
         };
-        drain(2 * workers);  // warm-up: contexts, allocations, the tuned grid cell
+        drain(std::max(2 * workers, std::min(queue, pairs)));  // warm-up: contexts, allocations, the tuned grid cell
         const auto t0 = std::chrono::steady_clock::now();
         const int ok = drain(pairs);
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        std::printf("{\"bench\": \"wave::MultiMatcher<ICPMatcher>\", \"points\": %d, \"workers\": %d, \"pairs\": %d, "
-                    "\"seconds\": %.4f, \"registrations_per_s\": %.1f, \"recovered_shift\": %d}\n",
-                    n, pool.workers(), pairs, s, pairs / s, ok);
+        std::printf("{\"bench\": \"wave::MultiMatcher<ICPMatcher>\", \"points\": %d, \"workers\": %d, \"queue\": %d, "
+                    "\"pairs\": %d, \"seconds\": %.4f, \"registrations_per_s\": %.1f, \"recovered_shift\": %d, "
+                    "\"mean_shift_x\": %.4f}\n",
+                    n, pool.workers(), queue, pairs, s, pairs / s, ok, shift_sum / pairs);
         std::fflush(stdout);
     }
     return 0;

@@ -337,6 +337,93 @@ AddCase c_multi_run("MultiTest.simultaneousmatching", [] {
     EXPECT(!pool.getResult(&id, &T, &info));
 });
 
+// The batched path under the pool (ICPMatcher::matchBatch, wm_icp_batch_match): full-resolution
+// matchers on small clouds take everything that is queued into one launch.  Every pair must come out
+// as a matcher used on that pair alone gives it: match() + estimateInfo() of the worker loop
+// (impl/multi_matcher_impl.hpp:45-53).
+wave::PCLPointCloudPtr subsample(const wave::PCLPointCloudPtr &c, size_t every, float dx) {
+    auto out = boost::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
+    for (size_t i = 0; i < c->points.size(); i += every) {
+        pcl::PointXYZ p = c->points[i];
+        p.x += dx;
+        out->points.push_back(p);
+    }
+    out->width = (uint32_t) out->points.size();
+    out->height = 1;
+    return out;
+}
+
+AddCase c_batch_direct("ICPTest.matchBatchEqualsOneByOne", [] {
+    const auto scan = loadScan();
+    wave::ICPMatcherParams p;
+    p.res = -1;
+    std::vector<std::pair<wave::PCLPointCloudPtr, wave::PCLPointCloudPtr>> pairs;
+    for (int k = 0; k < 5; ++k) pairs.emplace_back(subsample(scan, 8 + k, 0.f), subsample(scan, 7 + k, 0.05f * (float) k));
+    pairs.emplace_back(subsample(scan, 9, 0.f), subsample(scan, 9, 400.f));  // nothing within max_corr: match() fails
+    pairs.emplace_back(subsample(scan, 11, 0.f), subsample(scan, 10, 0.1f));
+    wave::ICPMatcher batch(p);
+    for (const auto &pr : pairs) EXPECT(batch.batchable(pr.first, pr.second));
+    EXPECT(!batch.batchable(scan, scan));  // 50k+ points: beyond one compute unit's LDS
+    wave::ICPMatcher::BatchOutcomes got;
+    EXPECT(batch.matchBatch(pairs, got));
+    EXPECT(got.size() == pairs.size());
+    wave::Affine3 last = wave::Affine3::Identity();
+    for (size_t k = 0; k < pairs.size() && k < got.size(); ++k) {
+        wave::ICPMatcher one(p);  // a fresh matcher: fresh stopping criteria, as every batch item has
+        one.setup(pairs[k].first, pairs[k].second);
+        const bool ok = one.match();
+        one.estimateInfo();
+        EXPECT(ok == got[k].matched);
+        EXPECT(ok == (k != 5));
+        if (ok) {
+            EXPECT(distanceTo(one.getResult(), got[k].transform) < 1e-9);
+            EXPECT((one.getInfo() - got[k].info).norm() <= 1e-5 * one.getInfo().norm());
+            last = got[k].transform;
+        } else {
+            EXPECT(distanceTo(last, got[k].transform) == 0.0);  // `result` is left alone (icp.cpp:132)
+        }
+    }
+    wave::ICPMatcherParams filtered;
+    filtered.res = 0.1f;
+    EXPECT(!wave::ICPMatcher(filtered).batchable(pairs[0].first, pairs[0].second));
+});
+
+AddCase c_multi_batch("MultiTest.queuedPairsShareOneLaunch", [] {
+    const auto scan = loadScan();
+    wave::ICPMatcherParams p;
+    p.res = -1;
+    std::vector<wave::PCLPointCloudPtr> refs, targets;
+    for (int k = 0; k < 6; ++k) {
+        refs.push_back(subsample(scan, 8 + (size_t) k, 0.f));
+        targets.push_back(subsample(scan, 7 + (size_t) k, 0.04f * (float) k));
+    }
+    std::vector<wave::Affine3, Eigen::aligned_allocator<wave::Affine3>> want;
+    std::vector<wave::Mat6, Eigen::aligned_allocator<wave::Mat6>> want_info;
+    for (int k = 0; k < 6; ++k) {
+        wave::ICPMatcher one(p);
+        one.setup(refs[(size_t) k], targets[(size_t) k]);
+        EXPECT(one.match());
+        one.estimateInfo();
+        want.push_back(one.getResult());
+        want_info.push_back(one.getInfo());
+    }
+    wave::MultiMatcher<wave::ICPMatcher, wave::ICPMatcherParams> pool(2, 64, p);
+    const int jobs = 150;
+    for (int j = 0; j < jobs; ++j) pool.insert(j, refs[(size_t) j % 6], targets[(size_t) j % 6]);
+    while (!pool.done()) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    std::set<int> seen;
+    int id = -1;
+    Eigen::Affine3d T;
+    wave::Mat6 info;
+    while (pool.getResult(&id, &T, &info)) {
+        seen.insert(id);
+        EXPECT(id >= 0 && id < jobs);
+        EXPECT(distanceTo(want[(size_t) id % 6], T) < 1e-9);
+        EXPECT((want_info[(size_t) id % 6] - info).norm() <= 1e-5 * info.norm());
+    }
+    EXPECT(seen.size() == (size_t) jobs);
+});
+
 }  // namespace
 
 int main(int argc, char **argv) {

@@ -1,0 +1,109 @@
+"""Many small registrations per launch (wm_icp_batch_match, csrc/wm_small.hip): every item must
+equal what the reference does for that pair -- ICPMatcher::match()'s full-resolution branch
+(wave_matching/src/icp.cpp:123-131) followed by estimateInfo() (icp.cpp:135-142, whose result is
+estimateLUMold's, icp_pcl_functions.cpp:51-179) -- as restated by the oracle, and must equal the
+one-pair-at-a-time device path."""
+import numpy as np
+import pytest
+import torch  # (before the HIP library is loaded: see test_fullsize_gpu.py)
+
+from helpers import pose_error
+from libwave_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _pairs(sizes, seed0=100):
+    out = []
+    for k, n in enumerate(sizes):
+        ref, tgt, T_gt = synth.pair(n, seed=seed0 + k, mode="resample")
+        out.append((ref, tgt, T_gt))
+    return out
+
+
+def test_batch_items_match_the_oracle_and_the_single_path(wm, ctx, oracle):
+    """BASELINE configs[0]-sized pairs (10 000 points) and smaller ones, default stopping rules."""
+    pairs = _pairs([10000, 10000, 7000, 2500, 10240, 64])
+    got = ctx.icp_batch_match([(r, t) for r, t, _ in pairs], with_info=True, max_corr=3.0, max_iter=100)
+    assert len(got) == len(pairs)
+    for (ref, tgt, T_gt), g in zip(pairs, got):
+        want = oracle.IcpMatch(ref, tgt, res=-1.0, multiscale_steps=0, incremental_float=0)
+        assert g["rc"] == 0 and want.ok and g["converged"]
+        assert (g["iterations"], g["state"]) == (want.r.iterations, wm.CONV_NAMES.get(want.r.state, want.r.state))
+        assert g["n_corr"] == want.r.n_corr
+        dt, ang = pose_error(g["T"], want.T)
+        assert dt <= 1e-7 and ang <= 1e-8, (dt, ang)
+        olumold, _ = want.lumold(3.0)
+        np.testing.assert_allclose(g["info"], olumold, rtol=2e-4, atol=1e-6 * np.abs(olumold).max())
+        # the one-pair device path: same correspondences, sums in another order
+        one = ctx.icp_match(ref, tgt, res=-1.0, max_corr=3.0, max_iter=100, carry_state=0)
+        assert (one["iterations"], one["state"], one["n_corr"]) == (g["iterations"], g["state"], g["n_corr"])
+        dt, ang = pose_error(g["T"], one["T"])
+        assert dt <= 1e-9 and ang <= 1e-10, (dt, ang)
+        rc, lumold, _ = ctx.icp_info(wm.WM_INFO_LUMOLD, max_corr=3.0)
+        np.testing.assert_allclose(g["info"], lumold, rtol=1e-5, atol=1e-9 * np.abs(lumold).max())
+
+
+@pytest.mark.parametrize("mode", ["svd", "gn6"])
+def test_batch_forced_iterations(wm, ctx, oracle, mode):
+    m = wm.WM_ICP_SVD if mode == "svd" else wm.WM_ICP_GN6
+    pairs = _pairs([10000, 4000, 9000], seed0=300)
+    got = ctx.icp_batch_match([(r, t) for r, t, _ in pairs], with_info=False, max_corr=3.0, force_iterations=20, mode=m)
+    for (ref, tgt, _), g in zip(pairs, got):
+        want = oracle.icp_align(ref, tgt, max_corr=3.0, force_iterations=20, incremental_float=0,
+                                mode=1 if mode == "gn6" else 0)
+        assert g["rc"] == 0 and g["state"] == "FORCED" and g["iterations"] == 20
+        assert g["n_corr"] == want["n_corr"]
+        dt, ang = pose_error(g["T"], want["T"])
+        assert dt <= 1e-7 and ang <= 1e-8, (dt, ang)
+
+
+def test_batch_edge_cases(wm, ctx, oracle):
+    rng = np.random.default_rng(7)
+    ref, tgt, _ = synth.pair(3000, seed=5, mode="resample")
+    far = (tgt + np.array([500.0, 0, 0], np.float32)).astype(np.float32)       # nothing within max_corr
+    holes = ref.copy()
+    holes[::7, 1] = np.nan                                                      # non-finite points are dropped
+    holes_t = tgt.copy()
+    holes_t[::5, 0] = np.inf
+    flat = np.zeros((500, 3), np.float32)
+    flat[:, :2] = rng.uniform(-5, 5, (500, 2))                                  # a plane: one layer of cells
+    same = np.tile(np.array([[1.0, 2.0, 3.0]], np.float32), (100, 1))           # all points identical
+    empty = np.zeros((0, 3), np.float32)
+    pairs = [(ref, far), (holes, holes_t), (flat, flat + np.float32(0.01)), (same, same), (empty, tgt), (ref, empty),
+             (ref[:2], tgt)]
+    got = ctx.icp_batch_match(pairs, with_info=True, max_corr=3.0, max_iter=50)
+    assert got[0]["rc"] == wm.WM_TOO_FEW and got[0]["state"] == "NO_CORRESPONDENCES"
+    keep_r, keep_t = np.isfinite(holes).all(1), np.isfinite(holes_t).all(1)
+    want = oracle.icp_align(holes[keep_r], holes_t[keep_t], max_corr=3.0, max_iter=50, incremental_float=0)
+    assert got[1]["rc"] == 0 and (got[1]["iterations"], got[1]["n_corr"]) == (want["iterations"], want["n_corr"])
+    dt, ang = pose_error(got[1]["T"], want["T"])
+    assert dt <= 1e-7 and ang <= 1e-8
+    want = oracle.icp_align(flat, flat + np.float32(0.01), max_corr=3.0, max_iter=50, incremental_float=0)
+    assert got[2]["rc"] == 0 and got[2]["iterations"] == want["iterations"]
+    dt, ang = pose_error(got[2]["T"], want["T"])
+    assert dt <= 1e-6 and ang <= 1e-6
+    assert got[3]["rc"] in (0, wm.WM_NOT_CONVERGED)                             # degenerate: must not hang
+    assert got[4]["rc"] == wm.WM_TOO_FEW and got[5]["rc"] == wm.WM_TOO_FEW
+    assert got[6]["rc"] == wm.WM_TOO_FEW                        # < 3 correspondences (PCL)
+
+
+def test_batch_rejects_targets_beyond_the_lds_budget(wm, ctx):
+    ref, tgt, _ = synth.pair(wm.WM_BATCH_MAX_TARGET_POINTS + 1, seed=1, mode="resample")
+    with pytest.raises(wm.WmError):
+        ctx.icp_batch_match([(ref, tgt)], max_corr=3.0)
+
+
+def test_batch_of_many_fills_the_device(wm, ctx, oracle):
+    """300 pairs (more workgroups than CUs), device-resident clouds; spot-checked against the oracle."""
+    pairs = _pairs([4096] * 6, seed0=900)
+    dev = [(torch.from_numpy(r).cuda(), torch.from_numpy(t).cuda()) for r, t, _ in pairs]
+    got = ctx.icp_batch_match([dev[k % 6] for k in range(300)], with_info=True, max_corr=3.0, max_iter=100)
+    for k in range(300):
+        assert got[k]["rc"] == 0
+        assert np.array_equal(got[k]["T"], got[k % 6]["T"]) and np.array_equal(got[k]["info"], got[k % 6]["info"])
+    for k in (0, 5):
+        ref, tgt, _ = pairs[k]
+        want = oracle.icp_align(ref, tgt, max_corr=3.0, max_iter=100, incremental_float=0)
+        dt, ang = pose_error(got[k]["T"], want["T"])
+        assert dt <= 1e-7 and ang <= 1e-8
