@@ -19,7 +19,8 @@
 Prints ONE JSON line on rank 0 (contract in the task statement), with extra objects:
 "roofline" (correspondence kernel vs the HBM roof), "cpu_baseline" (the CPU oracle timed on
 this box's host cores: 1 core, and the MultiMatcher pattern on all usable cores) and
-"other_configs" (BASELINE configs[2] GICP 500k and configs[3] NDT 2M) -- N == 1 only.
+"other_configs" (BASELINE configs[2] GICP 500k, configs[3] NDT 2M and configs[0] 10k pairs in
+batches of 256) -- N == 1 only.
 """
 import argparse
 import json
@@ -271,6 +272,39 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu):
         O.ndt_align(rs, ts_, res=0.5)
         e["cpu_baseline"] = {"seconds_per_registration": time.perf_counter() - t0, "cores": 1, "kind": "port",
                              "sample": "the oracle's NDT on a %d<->%d pair of the same scene" % (m, m)}
+    out.append(e)
+    del d_ref, d_tgt
+
+    # ---- configs[0]: the reference's own size, registered the MultiMatcher way -- a queue of pairs.
+    # One launch takes 256 pairs (one compute unit each, target cloud in LDS: csrc/wm_small.hip);
+    # every item is match() + estimateInfo() of the reference's worker loop.
+    n, B = 10_000, 256
+    base = [synth.pair(n, seed=100 + k, mode="resample")[:2] for k in range(8)]
+    host_pairs = [base[k % 8] for k in range(B)]
+    dev_clouds = [(torch.from_numpy(r).to(dev), torch.from_numpy(t).to(dev)) for r, t in base]
+    dev_pairs = [dev_clouds[k % 8] for k in range(B)]
+    ms_h, got = median_ms(lambda: ctx.icp_batch_match(host_pairs, with_info=True, max_corr=3.0, max_iter=100), reps=5)
+    ms_d, got = median_ms(lambda: ctx.icp_batch_match(dev_pairs, with_info=True, max_corr=3.0, max_iter=100), reps=5)
+    ctx.set_source(base[0][0])
+    ctx.set_target(base[0][1])
+    ms_one, one = median_ms(lambda: ctx.icp_match(base[0][0], base[0][1], res=-1.0, max_corr=3.0, max_iter=100, carry_state=0))
+    e = {"config": "ICPMatcher 10k<->10k (BASELINE configs[0]), %d queued pairs per launch: match() + estimateInfo() each, "
+                   "PCL's default stopping rules" % B,
+         "pairs_per_launch": B,
+         "registrations_per_s": B / (ms_h * 1e-3), "ms_per_batch": ms_h,
+         "registrations_per_s_device_resident_clouds": B / (ms_d * 1e-3),
+         "kernel_ms_per_batch": got[0]["align_ms"], "iterations_first_items": [g["iterations"] for g in got[:8]],
+         "all_converged": all(g["rc"] == 0 for g in got),
+         "one_pair_at_a_time_ms": ms_one, "one_pair_iterations": one["iterations"],
+         "note": "host clouds: 2 x 160 kB per pair cross PCIe inside the timed call (one worker thread; "
+                 "libwave_amd/host/bench_multimatcher runs the C++ wave::MultiMatcher pool on top of this)"}
+    if with_cpu:
+        from oracle import oracle_py as O
+        t0 = time.perf_counter()
+        m = O.IcpMatch(base[0][0], base[0][1], res=-1.0, multiscale_steps=0, incremental_float=0)
+        m.lumold(3.0)
+        e["cpu_baseline"] = {"seconds_per_registration": time.perf_counter() - t0, "cores": 1, "kind": "port",
+                             "sample": "the oracle's match() + estimateLUMold on one of the pairs"}
     out.append(e)
     ctx.close()
     prof.close()

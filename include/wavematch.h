@@ -165,7 +165,7 @@ int wm_icp_match(wm_ctx *ctx, const void *ref, size_t n_ref, const void *target,
  * Results per item k: status[k] (what wm_icp_align would have returned), T_out + 16 k (written
  * when status[k] == WM_OK), info_out + 36 k (with_info; written whenever the item ran), stats[k].
  * T_out, info_out, stats may be NULL.  The call returns WM_OK when the batch ran. */
-#define WM_BATCH_MAX_TARGET_POINTS 10240
+#define WM_BATCH_MAX_TARGET_POINTS 10000
 typedef struct {
     const void *src;    /* wave `ref`    */
     size_t n_src;

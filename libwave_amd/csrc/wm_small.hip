@@ -14,7 +14,7 @@
 // -- and a launch carries one workgroup per queued pair, so 256 pairs fill the 256 CUs and nothing
 // crosses a launch boundary:
 //   1. the target cloud is counting-sorted by cell INTO LDS (x, y, z floats + a 16-bit original
-//      index per point: 14 B x 10 240 points = 140 KB of the CU's 160 KB; 4 096 cells, 16-bit starts);
+//      index per point: 14 B x 10 000 points = 140 kB of the CU's 160 KB; 8 192 cells, 16-bit starts);
 //   2. every iteration each lane takes source points in turn: PCL's float transform, an exact 1-NN
 //      search over the cell rows overlapping a certified ball (radius = distance to the previous
 //      iteration's match under the new pose, so one scan certifies), the same 64-bit
@@ -32,6 +32,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -40,16 +41,18 @@ namespace wm {
 
 constexpr int kSmThreads = 1024;
 constexpr int kSmWaves = kSmThreads / 64;
-constexpr int kSmMaxTgt = WM_BATCH_MAX_TARGET_POINTS;  // 10 240
-constexpr int kSmPer = kSmMaxTgt / kSmThreads;
-constexpr int kSmCells = 4096;
+constexpr int kSmMaxTgt = WM_BATCH_MAX_TARGET_POINTS;  // 10 000
+constexpr int kSmPer = (kSmMaxTgt + kSmThreads - 1) / kSmThreads;
+constexpr int kSmCells = 8192;
 constexpr int kSmRedW = 18;
-static_assert(kSmMaxTgt % kSmThreads == 0 && kSmCells % kSmThreads == 0, "layout");
+constexpr size_t kSmSortMax = 16384;  // source clouds up to this size are put in cell order (14-bit index in the sort key)
+static_assert(kSmCells % kSmThreads == 0, "layout");
 
 struct SmallPair {  // one registration of the batch (device table)
     const unsigned char *src, *tgt;  // caller-layout points in device memory
     unsigned n_src, n_tgt;
     unsigned short *seed;  // n_src entries: LDS slot of each source point's last match (0xFFFF none)
+    float4 *sorted;        // n_src entries of scratch: the source packed (x, y, z, index bits), in cell order up to kSmSortMax points
 };
 
 struct SmallParams {
@@ -69,10 +72,11 @@ struct SmallOut {
     int info_degenerate, n_target_valid;
     float cell;
     int pad;
+    unsigned long long cyc[4];  // developer: shader-clock cycles of the LAST iteration's query loop / reduction / solve, and of the set-up
 };
 
 struct SmallLds {
-    float x[kSmMaxTgt], y[kSmMaxTgt], z[kSmMaxTgt];  // cell-sorted target
+    float xyz[3 * kSmMaxTgt];                        // cell-sorted target, (x, y, z) per point
     unsigned short idx[kSmMaxTgt];                   // caller's index of each
     unsigned short cstart[kSmCells + 8];             // first slot of every cell (+ end)
     double red[kSmWaves][kSmRedW];
@@ -130,14 +134,25 @@ __device__ __forceinline__ void sm_search(const SmallLds &L, const SmGrid &g, fl
             for (int cy = y0; cy <= y1; ++cy) {
                 const int row = (cz * g.ny + cy) * g.nx;
                 const unsigned s = L.cstart[row + x0], e = L.cstart[row + x1 + 1];
-                for (unsigned j = s; j < e; ++j) {
-                    const float d2 = sm_d2(qx, qy, qz, L.x[j], L.y[j], L.z[j]);
-                    if (__float_as_uint(d2) <= bhi) {  // (d2 >= 0: bit order = numeric order)
-                        const unsigned long long k = sm_key(d2, L.idx[j]);
-                        if (k < best) {
-                            best = k;
-                            bslot = j;
-                            bhi = (unsigned) (k >> 32);
+                // four candidates per trip, their twelve LDS reads in flight together (a lone dependent
+                // read per candidate is what this loop would otherwise wait for); the last trip repeats
+                // the run's last point, which changes nothing
+                for (unsigned j = s; j < e; j += 4u) {
+                    unsigned jj[4];
+                    float d2[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) jj[u] = j + (unsigned) u < e ? j + (unsigned) u : e - 1u;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) d2[u] = sm_d2(qx, qy, qz, L.xyz[3u * jj[u]], L.xyz[3u * jj[u] + 1u], L.xyz[3u * jj[u] + 2u]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (__float_as_uint(d2[u]) <= bhi) {  // (d2 >= 0: bit order = numeric order)
+                            const unsigned long long k = sm_key(d2[u], L.idx[jj[u]]);
+                            if (k < best) {
+                                best = k;
+                                bslot = jj[u];
+                                bhi = (unsigned) (k >> 32);
+                            }
                         }
                     }
                 }
@@ -176,67 +191,67 @@ __device__ __forceinline__ bool sm_load_point(const unsigned char *base, unsigne
     return isfinite(x) && isfinite(y) && isfinite(z);  // (non-finite points are dropped, as k_pack does)
 }
 
-__global__ void __launch_bounds__(kSmThreads)
-    k_icp_small(const SmallPair *__restrict__ pairs, SmallParams P, IcpDevState st0, SmallOut *__restrict__ out) {
-    __shared__ SmallLds L;
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const SmallPair pr = pairs[blockIdx.x];
-    const unsigned n_tgt = pr.n_tgt < (unsigned) kSmMaxTgt ? pr.n_tgt : (unsigned) kSmMaxTgt;  // (host checked)
-
-    // ---- 1. the target into LDS: bounding box -> grid -> counting sort by cell
-    {
-        float lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY;
-        for (unsigned i = tid; i < n_tgt; i += kSmThreads) {
-            float x, y, z;
-            if (sm_load_point(pr.tgt, i, P.stride, x, y, z)) {
-                lo0 = fminf(lo0, x), lo1 = fminf(lo1, y), lo2 = fminf(lo2, z);
-                hi0 = fmaxf(hi0, x), hi1 = fmaxf(hi1, y), hi2 = fmaxf(hi2, z);
-            }
+// Bounding box of a cloud's finite points and the finest grid of cubic cells over it that has at most
+// `max_cells` cells; every lane returns the same grid.  (Any cell size gives exact searches; this
+// choice is quick.)  `count` = number of finite points.
+__device__ __forceinline__ SmGrid sm_fit_grid(SmallLds &L, const unsigned char *pts, unsigned n, unsigned stride,
+                                              int max_cells, unsigned tid, unsigned &count) {
+    const unsigned lane = tid & 63u, wave = tid >> 6;
+    float lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY;
+    unsigned cnt = 0;
+    for (unsigned i = tid; i < n; i += kSmThreads) {
+        float x, y, z;
+        if (sm_load_point(pts, i, stride, x, y, z)) {
+            lo0 = fminf(lo0, x), lo1 = fminf(lo1, y), lo2 = fminf(lo2, z);
+            hi0 = fmaxf(hi0, x), hi1 = fmaxf(hi1, y), hi2 = fmaxf(hi2, z);
+            ++cnt;
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            lo0 = fminf(lo0, __shfl_xor(lo0, off)), lo1 = fminf(lo1, __shfl_xor(lo1, off));
-            lo2 = fminf(lo2, __shfl_xor(lo2, off)), hi0 = fmaxf(hi0, __shfl_xor(hi0, off));
-            hi1 = fmaxf(hi1, __shfl_xor(hi1, off)), hi2 = fmaxf(hi2, __shfl_xor(hi2, off));
-        }
-        if (lane == 0) {
-            L.boxf[wave][0] = lo0, L.boxf[wave][1] = lo1, L.boxf[wave][2] = lo2;
-            L.boxf[wave][3] = hi0, L.boxf[wave][4] = hi1, L.boxf[wave][5] = hi2;
-        }
-        for (unsigned c = tid; c < (kSmCells + 8) / 2; c += kSmThreads) reinterpret_cast<unsigned *>(L.cstart)[c] = 0u;
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < kSmWaves; ++w) {
-                lo0 = fminf(lo0, L.boxf[w][0]), lo1 = fminf(lo1, L.boxf[w][1]), lo2 = fminf(lo2, L.boxf[w][2]);
-                hi0 = fmaxf(hi0, L.boxf[w][3]), hi1 = fmaxf(hi1, L.boxf[w][4]), hi2 = fmaxf(hi2, L.boxf[w][5]);
-            }
-            int nx = 1, ny = 1, nz = 1;
-            float h = 1.0f;
-            if (lo0 <= hi0) {  // at least one finite point
-                const float ex = hi0 - lo0, ey = hi1 - lo1, ez = hi2 - lo2;
-                const float big = fmaxf(ex, fmaxf(ey, ez));
-                const float tiny = fmaxf(big * 1e-6f, 1e-30f);
-                h = cbrtf(fmaxf(ex, tiny) * fmaxf(ey, tiny) * fmaxf(ez, tiny) / (float) kSmCells);
-                h = fmaxf(h, tiny);
-                // the finest cubic cells that fit the table (any size is exact; this one is quick)
-                for (int it = 0; it < 400; ++it) {
-                    const float fx = floorf(ex / h) + 1.0f, fy = floorf(ey / h) + 1.0f, fz = floorf(ez / h) + 1.0f;
-                    if (fx * fy * fz <= (float) kSmCells) {
-                        nx = (int) fx, ny = (int) fy, nz = (int) fz;
-                        break;
-                    }
-                    h *= 1.06f;
-                }
-                if (nx * ny * nz > kSmCells || !(h > 0.0f) || !isfinite(h)) nx = ny = nz = 1, h = fmaxf(big, 1.0f);
-            } else {
-                lo0 = lo1 = lo2 = 0.0f;
-            }
-            L.ox = lo0, L.oy = lo1, L.oz = lo2, L.h = h, L.inv_h = 1.0f / h;
-            L.nx = nx, L.ny = ny, L.nz = nz;
-            L.st = st0;
-        }
-        __syncthreads();
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo0 = fminf(lo0, __shfl_xor(lo0, off)), lo1 = fminf(lo1, __shfl_xor(lo1, off));
+        lo2 = fminf(lo2, __shfl_xor(lo2, off)), hi0 = fmaxf(hi0, __shfl_xor(hi0, off));
+        hi1 = fmaxf(hi1, __shfl_xor(hi1, off)), hi2 = fmaxf(hi2, __shfl_xor(hi2, off));
+        cnt += __shfl_xor(cnt, off);
+    }
+    __syncthreads();  // (the scratch may still be read from the previous call)
+    if (lane == 0) {
+        L.boxf[wave][0] = lo0, L.boxf[wave][1] = lo1, L.boxf[wave][2] = lo2;
+        L.boxf[wave][3] = hi0, L.boxf[wave][4] = hi1, L.boxf[wave][5] = hi2;
+        L.wsum[wave] = cnt;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < kSmWaves; ++w) {
+            lo0 = fminf(lo0, L.boxf[w][0]), lo1 = fminf(lo1, L.boxf[w][1]), lo2 = fminf(lo2, L.boxf[w][2]);
+            hi0 = fmaxf(hi0, L.boxf[w][3]), hi1 = fmaxf(hi1, L.boxf[w][4]), hi2 = fmaxf(hi2, L.boxf[w][5]);
+            cnt += L.wsum[w];
+        }
+        int nx = 1, ny = 1, nz = 1;
+        float h = 1.0f;
+        if (lo0 <= hi0) {  // at least one finite point
+            const float ex = hi0 - lo0, ey = hi1 - lo1, ez = hi2 - lo2;
+            const float big = fmaxf(ex, fmaxf(ey, ez));
+            const float tiny = fmaxf(big * 1e-6f, 1e-30f);
+            h = cbrtf(fmaxf(ex, tiny) * fmaxf(ey, tiny) * fmaxf(ez, tiny) / (float) max_cells);
+            h = fmaxf(h, tiny);
+            for (int it = 0; it < 400; ++it) {
+                const float fx = floorf(ex / h) + 1.0f, fy = floorf(ey / h) + 1.0f, fz = floorf(ez / h) + 1.0f;
+                if (fx * fy * fz <= (float) max_cells) {
+                    nx = (int) fx, ny = (int) fy, nz = (int) fz;
+                    break;
+                }
+                h *= 1.06f;
+            }
+            if (nx * ny * nz > max_cells || !(h > 0.0f) || !isfinite(h)) nx = ny = nz = 1, h = fmaxf(big, 1.0f);
+        } else {
+            lo0 = lo1 = lo2 = 0.0f;
+        }
+        L.ox = lo0, L.oy = lo1, L.oz = lo2, L.h = h, L.inv_h = 1.0f / h;
+        L.nx = nx, L.ny = ny, L.nz = nz;
+        L.wsum[0] = cnt;
+    }
+    __syncthreads();
     SmGrid g;
     g.ox = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, L.ox)));
     g.oy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, L.oy)));
@@ -246,6 +261,116 @@ __global__ void __launch_bounds__(kSmThreads)
     g.nx = __builtin_amdgcn_readfirstlane(L.nx);
     g.ny = __builtin_amdgcn_readfirstlane(L.ny);
     g.nz = __builtin_amdgcn_readfirstlane(L.nz);
+    count = (unsigned) __builtin_amdgcn_readfirstlane((int) L.wsum[0]);
+    return g;
+}
+
+// One query as the iterations read it: the packed source point (x, y, z, index bits) and the LDS slot of
+// its last match, both from the pair's HBM scratch (global, not flat, loads: these never point into LDS).
+struct SmQuery {
+    float x, y, z;
+    unsigned seed;
+};
+typedef float sm_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ SmQuery sm_fetch(const SmallPair &pr, unsigned q) {
+    const sm_f4v v = ((const __attribute__((address_space(1))) sm_f4v *) pr.sorted)[q];
+    SmQuery c;
+    c.x = v.x, c.y = v.y, c.z = v.z;
+    c.seed = ((const __attribute__((address_space(1))) unsigned short *) pr.seed)[q];
+    return c;
+}
+// for (q = tid; q < n_q; q += 1 024) body(q, query) -- with the NEXT query's two loads issued before the
+// current one is searched: a lane has ten queries per iteration and nothing else to hide their HBM
+// round trips behind (16 wavefronts per CU; without this 70 us of a 100 us iteration were those waits)
+template <class F>
+__device__ __forceinline__ void sm_for_queries(const SmallPair &pr, unsigned n_q, unsigned tid, F &&body) {
+    unsigned q = tid;
+    bool has = q < n_q;
+    SmQuery cur = {0.f, 0.f, 0.f, 0xFFFFu};
+    if (has) cur = sm_fetch(pr, q);
+    while (has) {
+        const unsigned qn = q + kSmThreads;
+        const bool hn = qn < n_q;
+        SmQuery nxt = cur;
+        if (hn) nxt = sm_fetch(pr, qn);
+        body(q, cur);
+        q = qn;
+        cur = nxt;
+        has = hn;
+    }
+}
+
+__device__ __forceinline__ unsigned sm_cell_of(const SmGrid &g, float x, float y, float z) {
+    return (unsigned) ((sm_cell1(z, g.oz, g.inv_h, g.nz) * g.ny + sm_cell1(y, g.oy, g.inv_h, g.ny)) * g.nx +
+                       sm_cell1(x, g.ox, g.inv_h, g.nx));
+}
+
+__global__ void __launch_bounds__(kSmThreads)
+    k_icp_small(const SmallPair *__restrict__ pairs, SmallParams P, IcpDevState st0, SmallOut *__restrict__ out) {
+    __shared__ SmallLds L;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const SmallPair pr = pairs[blockIdx.x];
+    const unsigned long long cyc_begin = clock64();
+    const unsigned n_tgt = pr.n_tgt < (unsigned) kSmMaxTgt ? pr.n_tgt : (unsigned) kSmMaxTgt;  // (host checked)
+
+    if (tid == 0) L.st = st0;
+
+    // ---- 0. the source in cell order (of a grid over its own bounding box): neighbouring lanes then
+    // search neighbouring cells -- the same LDS rows (broadcast reads instead of bank conflicts) for a
+    // similar number of trips.  The order is a bitonic sort, in the LDS the target will occupy, of the
+    // unique keys (cell << 14 | index): deterministic, so the sums of a pair do not depend on timing.
+    // The sorted copy (x, y, z, index bits) lives in HBM scratch; clouds beyond 16 384 points keep
+    // the caller's order (packed all the same: the iterations read one layout).
+    unsigned n_q = pr.n_src;  // queries per iteration
+    if (pr.n_src > (unsigned) kSmSortMax) {
+        for (unsigned i = tid; i < pr.n_src; i += kSmThreads) {
+            float x, y, z;
+            if (!sm_load_point(pr.src, i, P.stride, x, y, z)) x = y = z = __builtin_nanf("");
+            pr.sorted[i] = make_float4(x, y, z, __uint_as_float(i));
+        }
+        __threadfence_block();
+        __syncthreads();
+    } else {
+        unsigned n_fin;
+        const SmGrid gs = sm_fit_grid(L, pr.src, pr.n_src, P.stride, kSmCells, tid, n_fin);
+        unsigned N = 2048;
+        while (N < pr.n_src) N <<= 1;
+        unsigned *K = reinterpret_cast<unsigned *>(L.xyz);  // (120 KB)
+        for (unsigned i = tid; i < N; i += kSmThreads) {
+            unsigned key = ~0u;
+            float x, y, z;
+            if (i < pr.n_src && sm_load_point(pr.src, i, P.stride, x, y, z)) key = (sm_cell_of(gs, x, y, z) << 14) | i;
+            K[i] = key;
+        }
+        for (unsigned k = 2; k <= N; k <<= 1)
+            for (unsigned j = k >> 1; j > 0; j >>= 1) {
+                __syncthreads();
+                for (unsigned t = tid; t < N / 2; t += kSmThreads) {
+                    const unsigned i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));
+                    const unsigned a = K[i], b = K[i + j];
+                    if ((a > b) == ((i & k) == 0u)) {
+                        K[i] = b;
+                        K[i + j] = a;
+                    }
+                }
+            }
+        __syncthreads();
+        for (unsigned q = tid; q < n_fin; q += kSmThreads) {
+            const unsigned i = K[q] & 0x3FFFu;
+            float x, y, z;
+            (void) sm_load_point(pr.src, i, P.stride, x, y, z);
+            pr.sorted[q] = make_float4(x, y, z, __uint_as_float(i));
+        }
+        n_q = n_fin;
+        __threadfence_block();
+        __syncthreads();
+    }
+
+    // ---- 1. the target into LDS: bounding box -> grid -> counting sort by cell
+    unsigned n_tgt_fin;
+    const SmGrid g = sm_fit_grid(L, pr.tgt, n_tgt, P.stride, kSmCells, tid, n_tgt_fin);
+    for (unsigned c = tid; c < (kSmCells + 8) / 2; c += kSmThreads) reinterpret_cast<unsigned *>(L.cstart)[c] = 0u;
+    __syncthreads();
     {
         // count: two 16-bit counters per LDS word; the returned old value is the point's rank in its cell
         unsigned cr[kSmPer];
@@ -256,15 +381,14 @@ __global__ void __launch_bounds__(kSmThreads)
             cr[k] = ~0u;
             float x, y, z;
             if (i < n_tgt && sm_load_point(pr.tgt, i, P.stride, x, y, z)) {
-                const unsigned c = (unsigned) ((sm_cell1(z, g.oz, g.inv_h, g.nz) * g.ny + sm_cell1(y, g.oy, g.inv_h, g.ny)) * g.nx +
-                                               sm_cell1(x, g.ox, g.inv_h, g.nx));
+                const unsigned c = sm_cell_of(g, x, y, z);
                 const unsigned sh = (c & 1u) * 16u;
                 const unsigned old = atomicAdd(&cw[c >> 1], 1u << sh);
                 cr[k] = (c << 16) | ((old >> sh) & 0xFFFFu);
             }
         }
         __syncthreads();
-        // exclusive scan of the 4 096 counts, in place (4 per lane)
+        // exclusive scan of the 8 192 counts, in place (8 per lane)
         constexpr int E = kSmCells / kSmThreads;
         unsigned v[E], s = 0;
 #pragma unroll
@@ -296,12 +420,14 @@ __global__ void __launch_bounds__(kSmThreads)
             float x, y, z;
             (void) sm_load_point(pr.tgt, i, P.stride, x, y, z);
             const unsigned slot = (unsigned) L.cstart[cr[k] >> 16] + (cr[k] & 0xFFFFu);
-            L.x[slot] = x, L.y[slot] = y, L.z[slot] = z;
+            L.xyz[3u * slot] = x, L.xyz[3u * slot + 1u] = y, L.xyz[3u * slot + 2u] = z;
             L.idx[slot] = (unsigned short) i;
         }
         __syncthreads();
     }
     const float rmax = sqrtf(P.thr_d2) * 1.0001f + 1e-6f;
+    const unsigned long long cyc_setup = clock64() - cyc_begin;
+    unsigned long long cyc_loop = 0, cyc_red = 0, cyc_solve = 0;
 
     // ---- 2./3. the iterations
     for (int guard = 0; guard < P.iter_cap; ++guard) {
@@ -314,21 +440,21 @@ __global__ void __launch_bounds__(kSmThreads)
         double a[kAcc];
 #pragma unroll
         for (int k = 0; k < kAcc; ++k) a[k] = 0.0;
-        for (unsigned q = tid; q < pr.n_src; q += kSmThreads) {
-            float sx, sy, sz;
-            if (!sm_load_point(pr.src, q, P.stride, sx, sy, sz)) continue;
+        const unsigned long long t0 = clock64();
+        sm_for_queries(pr, n_q, tid, [&](unsigned q, const SmQuery &c) {
+            if (!(c.x == c.x)) return;  // (a non-finite point of a cloud too large to be sorted)
             float qx, qy, qz;
-            sm_xform(Tf, sx, sy, sz, qx, qy, qz);
+            sm_xform(Tf, c.x, c.y, c.z, qx, qy, qz);
             unsigned long long best = sm_key(P.thr_d2, kNoIdx);
             unsigned bslot = 0xFFFFu;
             float r = P.r0_cells * g.h;
             if (have_prev) {
                 // the point matched in the previous iteration is a real candidate: its distance under
                 // the NEW pose bounds the new neighbour's, so one scan of that ball certifies
-                const unsigned ps = pr.seed[q];
+                const unsigned ps = c.seed;
                 r = rmax;
                 if (ps != 0xFFFFu) {
-                    const float d2b = sm_d2(qx, qy, qz, L.x[ps], L.y[ps], L.z[ps]);
+                    const float d2b = sm_d2(qx, qy, qz, L.xyz[3u * ps], L.xyz[3u * ps + 1u], L.xyz[3u * ps + 2u]);
                     if (d2b <= P.thr_d2) {
                         best = sm_key(d2b, L.idx[ps]);
                         bslot = ps;
@@ -340,9 +466,9 @@ __global__ void __launch_bounds__(kSmThreads)
             const bool matched = (unsigned) best != kNoIdx;
             pr.seed[q] = (unsigned short) (matched ? bslot : 0xFFFFu);
             a[17] += 1.0;
-            if (!matched) continue;
+            if (!matched) return;
             // the iteration's sums, as k_icp_stats (wm_icp.hip) forms them
-            const double px = qx, py = qy, pz = qz, tx = L.x[bslot], ty = L.y[bslot], tz = L.z[bslot];
+            const double px = qx, py = qy, pz = qz, tx = L.xyz[3u * bslot], ty = L.xyz[3u * bslot + 1u], tz = L.xyz[3u * bslot + 2u];
             a[0] += 1.0;
             a[1] += px;
             a[2] += py;
@@ -376,14 +502,17 @@ __global__ void __launch_bounds__(kSmThreads)
                 a[15] += px * ry - py * rx;
             }
             a[16] += (double) __uint_as_float((unsigned) (best >> 32));
-        }
+        });
+        const unsigned long long t1 = clock64();
         sm_block_sum<kAcc>(a, L, tid);
+        const unsigned long long t2 = clock64();
         if (tid == 0) {
             double ex[kStatsLen];
             expand_stats(mode, L.sum, ex);
             icp_apply_stats(&L.st, ex);
         }
         __syncthreads();
+        cyc_loop = t1 - t0, cyc_red = t2 - t1, cyc_solve = clock64() - t2;
     }
 
     // ---- 4. estimateLUMold on the aligned cloud (icp_pcl_functions.cpp:51-179; arithmetic of wm_info.hip)
@@ -397,17 +526,16 @@ __global__ void __launch_bounds__(kSmThreads)
         double a[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) a[k] = 0.0;
-        for (unsigned q = tid; q < pr.n_src; q += kSmThreads) {
-            float sx, sy, sz;
-            if (!sm_load_point(pr.src, q, P.stride, sx, sy, sz)) continue;
+        sm_for_queries(pr, n_q, tid, [&](unsigned q, const SmQuery &c) {
+            if (!(c.x == c.x)) return;
             float px, py, pz;
-            sm_xform(Tf, sx, sy, sz, px, py, pz);
+            sm_xform(Tf, c.x, c.y, c.z, px, py, pz);
             unsigned long long best = sm_key(P.thr_d2_strict, kNoIdx);
             unsigned bslot = 0xFFFFu;
             float r = rmax_s;
-            const unsigned ps = have_prev ? (unsigned) pr.seed[q] : 0xFFFFu;
+            const unsigned ps = have_prev ? c.seed : 0xFFFFu;
             if (ps != 0xFFFFu) {
-                const float d2b = sm_d2(px, py, pz, L.x[ps], L.y[ps], L.z[ps]);
+                const float d2b = sm_d2(px, py, pz, L.xyz[3u * ps], L.xyz[3u * ps + 1u], L.xyz[3u * ps + 2u]);
                 if (d2b <= P.thr_d2_strict) {
                     best = sm_key(d2b, L.idx[ps]);
                     bslot = ps;
@@ -419,8 +547,8 @@ __global__ void __launch_bounds__(kSmThreads)
             sm_search(L, g, px, py, pz, fminf(r, rmax_s), rmax_s, best, bslot);
             const bool matched = (unsigned) best != kNoIdx;
             pr.seed[q] = (unsigned short) (matched ? bslot : 0xFFFFu);
-            if (!matched) continue;
-            const float tx = L.x[bslot], ty = L.y[bslot], tz = L.z[bslot];
+            if (!matched) return;
+            const float tx = L.xyz[3u * bslot], ty = L.xyz[3u * bslot + 1u], tz = L.xyz[3u * bslot + 2u];
             const float av0 = __fmul_rn(0.5f, __fadd_rn(px, tx)), av1 = __fmul_rn(0.5f, __fadd_rn(py, ty)),
                         av2 = __fmul_rn(0.5f, __fadd_rn(pz, tz));
             const float df0 = __fsub_rn(px, tx), df1 = __fsub_rn(py, ty), df2 = __fsub_rn(pz, tz);
@@ -440,7 +568,7 @@ __global__ void __launch_bounds__(kSmThreads)
             a[13] += __fsub_rn(__fmul_rn(av1, df2), __fmul_rn(av2, df1));
             a[14] += __fsub_rn(__fmul_rn(av0, df1), __fmul_rn(av1, df0));
             a[15] += __fsub_rn(__fmul_rn(av2, df0), __fmul_rn(av0, df2));
-        }
+        });
         sm_block_sum<16>(a, L, tid);
         double MM[36];
         if (tid == 0) {
@@ -484,13 +612,12 @@ __global__ void __launch_bounds__(kSmThreads)
 #pragma unroll
         for (int k = 0; k < 6; ++k) D[k] = L.D[k];
         double ss[1] = {0.0};
-        for (unsigned q = tid; q < pr.n_src; q += kSmThreads) {
-            const unsigned bslot = pr.seed[q];
-            float sx, sy, sz;
-            if (!sm_load_point(pr.src, q, P.stride, sx, sy, sz) || bslot == 0xFFFFu) continue;
+        sm_for_queries(pr, n_q, tid, [&](unsigned, const SmQuery &c) {
+            const unsigned bslot = c.seed;
+            if (!(c.x == c.x) || bslot == 0xFFFFu) return;
             float px, py, pz;
-            sm_xform(Tf, sx, sy, sz, px, py, pz);
-            const float tx = L.x[bslot], ty = L.y[bslot], tz = L.z[bslot];
+            sm_xform(Tf, c.x, c.y, c.z, px, py, pz);
+            const float tx = L.xyz[3u * bslot], ty = L.xyz[3u * bslot + 1u], tz = L.xyz[3u * bslot + 2u];
             const float av0 = __fmul_rn(0.5f, __fadd_rn(px, tx)), av1 = __fmul_rn(0.5f, __fadd_rn(py, ty)),
                         av2 = __fmul_rn(0.5f, __fadd_rn(pz, tz));
             const float df0 = __fsub_rn(px, tx), df1 = __fsub_rn(py, ty), df2 = __fsub_rn(pz, tz);
@@ -498,7 +625,7 @@ __global__ void __launch_bounds__(kSmThreads)
             const double e1 = df1 - (D[1] + av0 * D[4] - av2 * D[3]);
             const double e2 = df2 - (D[2] + av1 * D[3] - av0 * D[5]);
             ss[0] += (double) (float) (e0 * e0 + e1 * e1 + e2 * e2);
-        }
+        });
         sm_block_sum<1>(ss, L, tid);
         if (tid == 0) {
             const float s2 = (float) L.sum[0];
@@ -520,8 +647,9 @@ __global__ void __launch_bounds__(kSmThreads)
         o.converged = s.converged;
         o.state = s.state;
         o.n_corr = s.n_corr;
-        o.n_target_valid = (int) L.cstart[kSmCells];
+        o.n_target_valid = (int) n_tgt_fin;
         o.cell = g.h;
+        o.cyc[0] = cyc_loop, o.cyc[1] = cyc_red, o.cyc[2] = cyc_solve, o.cyc[3] = cyc_setup;
         if (!with_info) o.info_degenerate = 0;
     }
 }
@@ -577,7 +705,7 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
     if (p->force_iterations <= 0 && p->max_iter <= 0) return WM_ERR_ARG;
     if (with_info != 0 && with_info != 1) return WM_ERR_ARG;
     if (n_items == 0) return WM_OK;
-    size_t cloud_bytes = 0, seeds = 0;
+    size_t cloud_bytes = 0, seeds = 0, sorted_pts = 0;
     int live = 0;
     for (int k = 0; k < n_items; ++k) {
         const wm_batch_item &it = items[k];
@@ -586,6 +714,7 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
         if (it.n_src == 0 || it.n_target == 0) continue;  // (answered on the host, below)
         cloud_bytes += ((it.n_src * stride + 15) & ~(size_t) 15) + ((it.n_target * stride + 15) & ~(size_t) 15);
         seeds += (it.n_src + 7) & ~(size_t) 7;
+        sorted_pts += it.n_src;
         ++live;
     }
     WM_HIP(ctx, hipSetDevice(ctx->device));
@@ -602,7 +731,8 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
 
     const size_t table_bytes = ((size_t) live * sizeof(SmallPair) + 255) & ~(size_t) 255;
     const size_t up_bytes = table_bytes + (mem == WM_MEM_HOST ? cloud_bytes : 0);
-    const size_t dev_bytes = table_bytes + (mem == WM_MEM_HOST ? cloud_bytes : 0) + seeds * sizeof(unsigned short);
+    const size_t seed_bytes = (seeds * sizeof(unsigned short) + 15) & ~(size_t) 15;
+    const size_t dev_bytes = table_bytes + (mem == WM_MEM_HOST ? cloud_bytes : 0) + seed_bytes + sorted_pts * sizeof(float4);
     WM_HIP(ctx, B->d_stage.reserve(dev_bytes));
     WM_HIP(ctx, B->d_out.reserve((size_t) live * sizeof(SmallOut)));
     WM_TRY(pinned_reserve(ctx, &B->h_stage, &B->h_stage_cap, up_bytes));
@@ -615,7 +745,8 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
     SmallPair *table = reinterpret_cast<SmallPair *>(h);
     size_t off = table_bytes;
     unsigned short *seed_base = reinterpret_cast<unsigned short *>(d + table_bytes + (mem == WM_MEM_HOST ? cloud_bytes : 0));
-    size_t seed_off = 0;
+    float4 *sorted_base = reinterpret_cast<float4 *>(reinterpret_cast<unsigned char *>(seed_base) + seed_bytes);
+    size_t seed_off = 0, sorted_off = 0;
     int row = 0;
     for (int k = 0; k < n_items; ++k) {
         const wm_batch_item &it = items[k];
@@ -636,6 +767,8 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
         }
         t.seed = seed_base + seed_off;
         seed_off += (it.n_src + 7) & ~(size_t) 7;
+        t.sorted = sorted_base + sorted_off;
+        sorted_off += it.n_src;
     }
     WM_HIP(ctx, hipMemcpyAsync(d, h, up_bytes, hipMemcpyHostToDevice, ctx->stream));
 
@@ -688,6 +821,9 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
             s.align_ms = ms;  // (the whole batch's launch)
             s.nn_levels = 1;
             s.grid_cell = r.cell;
+            // (developer: kilocycles of the last iteration's query loop / reduction / solve; set-up in coarse_ms)
+            s.nn_ms = (float) r.cyc[0] * 1e-3f, s.stats_ms = (float) r.cyc[1] * 1e-3f, s.solve_ms = (float) r.cyc[2] * 1e-3f;
+            s.coarse_ms = (float) r.cyc[3] * 1e-3f;
         }
         if (r.state == WM_CONV_NO_CORRESPONDENCES)
             status[k] = WM_TOO_FEW_CORRESPONDENCES;

@@ -23,7 +23,7 @@ def _pairs(sizes, seed0=100):
 
 def test_batch_items_match_the_oracle_and_the_single_path(wm, ctx, oracle):
     """BASELINE configs[0]-sized pairs (10 000 points) and smaller ones, default stopping rules."""
-    pairs = _pairs([10000, 10000, 7000, 2500, 10240, 64])
+    pairs = _pairs([10000, 10000, 7000, 2500, 9999, 64])
     got = ctx.icp_batch_match([(r, t) for r, t, _ in pairs], with_info=True, max_corr=3.0, max_iter=100)
     assert len(got) == len(pairs)
     for (ref, tgt, T_gt), g in zip(pairs, got):
@@ -86,6 +86,22 @@ def test_batch_edge_cases(wm, ctx, oracle):
     assert got[3]["rc"] in (0, wm.WM_NOT_CONVERGED)                             # degenerate: must not hang
     assert got[4]["rc"] == wm.WM_TOO_FEW and got[5]["rc"] == wm.WM_TOO_FEW
     assert got[6]["rc"] == wm.WM_TOO_FEW                        # < 3 correspondences (PCL)
+
+
+def test_batch_source_larger_than_the_sort_window(wm, ctx, oracle):
+    """Sources beyond 16 384 points keep the caller's order (only the TARGET has to fit the LDS)."""
+    ref, _, _ = synth.pair(20000, seed=11, mode="resample")
+    _, tgt, _ = synth.pair(9000, seed=11, mode="resample")
+    holes = ref.copy()
+    holes[::9, 2] = np.nan
+    got = ctx.icp_batch_match([(ref, tgt), (holes, tgt)], with_info=True, max_corr=3.0, max_iter=60)
+    for cloud, g in zip((ref, holes[np.isfinite(holes).all(1)]), got):
+        want = oracle.IcpMatch(cloud, tgt, res=-1.0, multiscale_steps=0, incremental_float=0, max_corr=3.0, max_iter=60)
+        assert g["rc"] == 0 and (g["iterations"], g["n_corr"]) == (want.r.iterations, want.r.n_corr)
+        dt, ang = pose_error(g["T"], want.T)
+        assert dt <= 1e-7 and ang <= 1e-8, (dt, ang)
+        olumold, _ = want.lumold(3.0)
+        np.testing.assert_allclose(g["info"], olumold, rtol=2e-4, atol=1e-6 * np.abs(olumold).max())
 
 
 def test_batch_rejects_targets_beyond_the_lds_budget(wm, ctx):
