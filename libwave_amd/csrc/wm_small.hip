@@ -29,6 +29,7 @@
 // hundred); this path is for queues of pairs.
 #include "wm_icp_step.hpp"
 #include "wm_internal.hpp"
+#include "wm_wave.hpp"
 
 #include <float.h>
 #include <math.h>
@@ -52,6 +53,7 @@ struct SmallPair {  // one registration of the batch (device table)
     const unsigned char *src, *tgt;  // caller-layout points in device memory
     unsigned n_src, n_tgt;
     unsigned short *seed;  // n_src entries: LDS slot of each source point's last match (0xFFFF none)
+    double *csum;          // ceil(n_src / 64) rows of kAcc doubles of scratch: every 64-query chunk's sums
     float4 *sorted;        // n_src entries of scratch: the source packed (x, y, z, index bits), in cell order up to kSmSortMax points
 };
 
@@ -76,13 +78,14 @@ struct SmallOut {
 };
 
 struct SmallLds {
-    float xyz[3 * kSmMaxTgt];                        // cell-sorted target, (x, y, z) per point
-    unsigned short idx[kSmMaxTgt];                   // caller's index of each
+    float xyz[3 * (kSmMaxTgt + 4)];                  // cell-sorted target, (x, y, z) per point (+ 4 far sentinels)
+    unsigned short idx[kSmMaxTgt + 4];               // caller's index of each
     unsigned short cstart[kSmCells + 8];             // first slot of every cell (+ end)
     double red[kSmWaves][kSmRedW];
     double sum[kSmRedW];
     float boxf[kSmWaves][8];
     unsigned wsum[kSmWaves];
+    unsigned ticket;  // next chunk of 64 queries (the iterations hand them to whichever wavefront is free)
     float ox, oy, oz, h, inv_h;
     int nx, ny, nz;
     double D[6];
@@ -134,26 +137,27 @@ __device__ __forceinline__ void sm_search(const SmallLds &L, const SmGrid &g, fl
             for (int cy = y0; cy <= y1; ++cy) {
                 const int row = (cz * g.ny + cy) * g.nx;
                 const unsigned s = L.cstart[row + x0], e = L.cstart[row + x1 + 1];
-                // four candidates per trip, their twelve LDS reads in flight together (a lone dependent
-                // read per candidate is what this loop would otherwise wait for); the last trip repeats
-                // the run's last point, which changes nothing
+                // four candidates per trip, their twelve LDS reads in flight together.  No clamp at the end of
+                // the run: what follows it are real points of the next cells (or the far sentinels
+                // after the last point), and an extra real candidate cannot hurt an arg-min over the
+                // target.  The update is a rare branch behind one unsigned min of the four d2.
                 for (unsigned j = s; j < e; j += 4u) {
-                    unsigned jj[4];
+                    const float *t = &L.xyz[3u * j];
                     float d2[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) jj[u] = j + (unsigned) u < e ? j + (unsigned) u : e - 1u;
+                    for (int u = 0; u < 4; ++u) d2[u] = sm_d2(qx, qy, qz, t[3 * u], t[3 * u + 1], t[3 * u + 2]);
+                    const unsigned m01 = min(__float_as_uint(d2[0]), __float_as_uint(d2[1]));
+                    const unsigned m23 = min(__float_as_uint(d2[2]), __float_as_uint(d2[3]));
+                    if (min(m01, m23) <= bhi) {  // (d2 >= 0: bit order = numeric order)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) d2[u] = sm_d2(qx, qy, qz, L.xyz[3u * jj[u]], L.xyz[3u * jj[u] + 1u], L.xyz[3u * jj[u] + 2u]);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (__float_as_uint(d2[u]) <= bhi) {  // (d2 >= 0: bit order = numeric order)
-                            const unsigned long long k = sm_key(d2[u], L.idx[jj[u]]);
+                        for (int u = 0; u < 4; ++u) {
+                            const unsigned long long k = sm_key(d2[u], L.idx[j + (unsigned) u]);
                             if (k < best) {
                                 best = k;
-                                bslot = jj[u];
-                                bhi = (unsigned) (k >> 32);
+                                bslot = j + (unsigned) u;
                             }
                         }
+                        bhi = (unsigned) (best >> 32);
                     }
                 }
             }
@@ -313,7 +317,10 @@ __global__ void __launch_bounds__(kSmThreads)
     const unsigned long long cyc_begin = clock64();
     const unsigned n_tgt = pr.n_tgt < (unsigned) kSmMaxTgt ? pr.n_tgt : (unsigned) kSmMaxTgt;  // (host checked)
 
-    if (tid == 0) L.st = st0;
+    if (tid == 0) {
+        L.st = st0;
+        L.ticket = kSmWaves;
+    }
 
     // ---- 0. the source in cell order (of a grid over its own bounding box): neighbouring lanes then
     // search neighbouring cells -- the same LDS rows (broadcast reads instead of bank conflicts) for a
@@ -423,9 +430,15 @@ __global__ void __launch_bounds__(kSmThreads)
             L.xyz[3u * slot] = x, L.xyz[3u * slot + 1u] = y, L.xyz[3u * slot + 2u] = z;
             L.idx[slot] = (unsigned short) i;
         }
+        if (tid < 4u) {  // far sentinels behind the last point (see sm_search)
+            const unsigned slot = n_tgt_fin + tid;
+            L.xyz[3u * slot] = L.xyz[3u * slot + 1u] = L.xyz[3u * slot + 2u] = INFINITY;
+            L.idx[slot] = 0xFFFFu;
+        }
         __syncthreads();
     }
     const float rmax = sqrtf(P.thr_d2) * 1.0001f + 1e-6f;
+    const unsigned nchunks = (n_q + 63u) / 64u;
     const unsigned long long cyc_setup = clock64() - cyc_begin;
     unsigned long long cyc_loop = 0, cyc_red = 0, cyc_solve = 0;
 
@@ -438,10 +451,8 @@ __global__ void __launch_bounds__(kSmThreads)
         const bool have_prev = L.st.have_prev != 0;
         const int mode = L.st.mode;
         double a[kAcc];
-#pragma unroll
-        for (int k = 0; k < kAcc; ++k) a[k] = 0.0;
         const unsigned long long t0 = clock64();
-        sm_for_queries(pr, n_q, tid, [&](unsigned q, const SmQuery &c) {
+        auto one_query = [&](unsigned q, const SmQuery &c) {
             if (!(c.x == c.x)) return;  // (a non-finite point of a cloud too large to be sorted)
             float qx, qy, qz;
             sm_xform(Tf, c.x, c.y, c.z, qx, qy, qz);
@@ -502,14 +513,57 @@ __global__ void __launch_bounds__(kSmThreads)
                 a[15] += px * ry - py * rx;
             }
             a[16] += (double) __uint_as_float((unsigned) (best >> 32));
-        });
+        };
+        // Chunks of 64 consecutive (cell-ordered) queries go to whichever wavefront is free: the first
+        // sixteen by wave number, the rest by a ticket in LDS -- static shares left the slowest wave
+        // 45 % behind the first.  A chunk's sums are reduced inside its wavefront (recursive halving,
+        // wm_wave.hpp) into a row of their own, so which wave took which chunk cannot change a bit of
+        // the result; the next chunk's ticket is drawn, and its loads issued, before this chunk's search.
+        {
+            unsigned c = wave;
+            bool has = c < nchunks;
+            unsigned q = c * 64u + lane;
+            SmQuery cur = {0.f, 0.f, 0.f, 0xFFFFu};
+            if (has && q < n_q) cur = sm_fetch(pr, q);
+            while (has) {
+                unsigned cn = 0;
+                if (lane == 0) cn = atomicAdd(&L.ticket, 1u);
+                cn = (unsigned) __builtin_amdgcn_readfirstlane((int) cn);
+                const bool hn = cn < nchunks;
+                const unsigned qn = cn * 64u + lane;
+                SmQuery nxt = cur;
+                if (hn && qn < n_q) nxt = sm_fetch(pr, qn);
+#pragma unroll
+                for (int k = 0; k < kAcc; ++k) a[k] = 0.0;
+                if (q < n_q) one_query(q, cur);
+                acc_halve<kAcc, 32>(a, lane);
+                const int comp = acc_comp_of_lane(lane);
+                if (comp >= 0) pr.csum[(size_t) c * kAcc + comp] = a[0];
+                c = cn, q = qn, cur = nxt, has = hn;
+            }
+        }
         const unsigned long long t1 = clock64();
-        sm_block_sum<kAcc>(a, L, tid);
+        __threadfence_block();
+        __syncthreads();
+        if (tid < (unsigned) (kSmWaves * kAcc)) {  // the rows added in a fixed order: 16 interleaved partial sums, then those
+            const unsigned w = tid / (unsigned) kAcc, k = tid % (unsigned) kAcc;
+            double sum = 0;
+            for (unsigned c = w; c < nchunks; c += kSmWaves) sum += ((const __attribute__((address_space(1))) double *) pr.csum)[(size_t) c * kAcc + k];
+            L.red[w][k] = sum;
+        }
+        __syncthreads();
+        if (tid < (unsigned) kAcc) {
+            double sum = 0;
+            for (int w = 0; w < kSmWaves; ++w) sum += L.red[w][tid];
+            L.sum[tid] = sum;
+        }
+        __syncthreads();
         const unsigned long long t2 = clock64();
         if (tid == 0) {
             double ex[kStatsLen];
             expand_stats(mode, L.sum, ex);
             icp_apply_stats(&L.st, ex);
+            L.ticket = kSmWaves;
         }
         __syncthreads();
         cyc_loop = t1 - t0, cyc_red = t2 - t1, cyc_solve = clock64() - t2;
@@ -705,7 +759,7 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
     if (p->force_iterations <= 0 && p->max_iter <= 0) return WM_ERR_ARG;
     if (with_info != 0 && with_info != 1) return WM_ERR_ARG;
     if (n_items == 0) return WM_OK;
-    size_t cloud_bytes = 0, seeds = 0, sorted_pts = 0;
+    size_t cloud_bytes = 0, seeds = 0, sorted_pts = 0, chunk_rows = 0;
     int live = 0;
     for (int k = 0; k < n_items; ++k) {
         const wm_batch_item &it = items[k];
@@ -715,6 +769,7 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
         cloud_bytes += ((it.n_src * stride + 15) & ~(size_t) 15) + ((it.n_target * stride + 15) & ~(size_t) 15);
         seeds += (it.n_src + 7) & ~(size_t) 7;
         sorted_pts += it.n_src;
+        chunk_rows += (it.n_src + 63) / 64;
         ++live;
     }
     WM_HIP(ctx, hipSetDevice(ctx->device));
@@ -732,7 +787,8 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
     const size_t table_bytes = ((size_t) live * sizeof(SmallPair) + 255) & ~(size_t) 255;
     const size_t up_bytes = table_bytes + (mem == WM_MEM_HOST ? cloud_bytes : 0);
     const size_t seed_bytes = (seeds * sizeof(unsigned short) + 15) & ~(size_t) 15;
-    const size_t dev_bytes = table_bytes + (mem == WM_MEM_HOST ? cloud_bytes : 0) + seed_bytes + sorted_pts * sizeof(float4);
+    const size_t dev_bytes = table_bytes + (mem == WM_MEM_HOST ? cloud_bytes : 0) + seed_bytes + sorted_pts * sizeof(float4) +
+                             chunk_rows * kAcc * sizeof(double);
     WM_HIP(ctx, B->d_stage.reserve(dev_bytes));
     WM_HIP(ctx, B->d_out.reserve((size_t) live * sizeof(SmallOut)));
     WM_TRY(pinned_reserve(ctx, &B->h_stage, &B->h_stage_cap, up_bytes));
@@ -746,8 +802,12 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
     size_t off = table_bytes;
     unsigned short *seed_base = reinterpret_cast<unsigned short *>(d + table_bytes + (mem == WM_MEM_HOST ? cloud_bytes : 0));
     float4 *sorted_base = reinterpret_cast<float4 *>(reinterpret_cast<unsigned char *>(seed_base) + seed_bytes);
-    size_t seed_off = 0, sorted_off = 0;
+    double *csum_base = reinterpret_cast<double *>(sorted_base + sorted_pts);
+    size_t seed_off = 0, sorted_off = 0, csum_off = 0;
     int row = 0;
+    // host clouds: copied into the pinned mirror and sent in slices of ~2 MB, so that the DMA of one
+    // slice runs while the next is being copied (the table goes last, once it is complete)
+    size_t sent = table_bytes;
     for (int k = 0; k < n_items; ++k) {
         const wm_batch_item &it = items[k];
         if (status[k] != WM_OK) continue;
@@ -761,6 +821,10 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
             memcpy(h + off, it.target, it.n_target * stride);
             t.tgt = d + off;
             off += (it.n_target * stride + 15) & ~(size_t) 15;
+            if (off - sent >= ((size_t) 2 << 20)) {
+                WM_HIP(ctx, hipMemcpyAsync(d + sent, h + sent, off - sent, hipMemcpyHostToDevice, ctx->stream));
+                sent = off;
+            }
         } else {
             t.src = static_cast<const unsigned char *>(it.src);
             t.tgt = static_cast<const unsigned char *>(it.target);
@@ -769,8 +833,11 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
         seed_off += (it.n_src + 7) & ~(size_t) 7;
         t.sorted = sorted_base + sorted_off;
         sorted_off += it.n_src;
+        t.csum = csum_base + csum_off;
+        csum_off += ((it.n_src + 63) / 64) * kAcc;
     }
-    WM_HIP(ctx, hipMemcpyAsync(d, h, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (off > sent) WM_HIP(ctx, hipMemcpyAsync(d + sent, h + sent, off - sent, hipMemcpyHostToDevice, ctx->stream));
+    WM_HIP(ctx, hipMemcpyAsync(d, h, table_bytes, hipMemcpyHostToDevice, ctx->stream));
 
     double I[16];
     mat4_identity(I);
