@@ -1,10 +1,15 @@
 // wave::MultiMatcher<MatcherT, ParamsT>: a fixed crew of worker threads registering queued
 // (ref, target) pairs concurrently.
 //
-// On the MI355X back end concurrency is what fills the GPU when the clouds are small: every
-// worker builds its OWN matcher inside its thread, i.e. its own wm_ctx with its own HIP stream,
-// so kernels of different registrations overlap on the device (scripts/bench_multimatcher.py:
-// 10k-point pairs go from ~1 900 to ~5 600 registrations/s with 8 workers).
+// On the MI355X back end a worker is a host thread feeding the GPU through its OWN matcher (its
+// own wm_ctx and HIP stream), so registrations of different workers overlap on the device.  For small
+// clouds that alone leaves the chip idle between tiny kernels (10k-point pairs: ~5 000
+// registrations/s however many workers), so a worker whose matcher can register many pairs in one
+// launch (ICPMatcher::matchBatch: full-resolution matchers, targets up to 10 000 points) takes
+// EVERYTHING that is queued -- up to 256 pairs, one compute unit each -- per trip: 80 000
+// registrations/s with one worker, 110 000-145 000 with two to four (libwave_amd/host/
+// bench_multimatcher, BENCH_QUEUE=2048).  Queue depth is what feeds it: construct the pool with a
+// queue of a few hundred pairs rather than the reference's default of 10.
 //
 // Public surface as in the reference (wave_matching/include/wave/matching/multi_matcher.hpp:
 // 29-96): construct with (n_threads, queue_size, params); insert(id, ref, target) blocks while
