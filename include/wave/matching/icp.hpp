@@ -83,9 +83,10 @@ class ICPMatcher : public Matcher<PCLPointCloudPtr> {
     // queued up (no reference counterpart; the reference's worker loop registers them one after the
     // other, impl/multi_matcher_impl.hpp:45-53).  Every pair goes through exactly what that loop does
     // with it -- setRef, setTarget, match(), estimateInfo() -- but a whole registration runs inside one
-    // compute unit of the GPU with the target cloud in its LDS, 256 at a time (wm_icp_batch_match).
+    // compute unit of the GPU, 256 at a time (wm_icp_batch_match): with the target cloud in that unit's
+    // LDS up to 10 000 points, in cache-resident HBM scratch beyond.
     // Limits: a full-resolution matcher (params.res <= 0) on a single device, and targets of at most
-    // maxBatchTargetPoints() points -- batchable() says whether a pair qualifies.  Each pair starts
+    // maxBatchTargetPoints() = 50 000 points -- batchable() says whether a pair qualifies.  Each pair starts
     // with fresh stopping criteria (a matcher used pair by pair carries PCL's last MSE over into the
     // next align; which pair follows which in a MultiMatcher is a matter of thread timing anyway).
     // out[k] = {match() result, getResult(), getInfo()} as the worker loop would have read them after

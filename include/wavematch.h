@@ -160,12 +160,15 @@ int wm_icp_match(wm_ctx *ctx, const void *ref, size_t n_ref, const void *target,
  * is ICPMatcher::match()'s full-resolution branch (icp.cpp:123-131: align on the clouds as given,
  * stopping criteria fresh) and, with with_info = 1, the estimator whose result estimateInfo() always
  * ends with (icp.cpp:135-142 -> estimateLUMold, icp_pcl_functions.cpp:51-179).  One workgroup per
- * item keeps the item's whole target cloud in its compute unit's LDS, so a target may have at most
- * WM_BATCH_MAX_TARGET_POINTS points (WM_ERR_ARG otherwise: register such pairs one by one).
+ * item: a target of up to WM_BATCH_LDS_TARGET_POINTS points lives, cell-sorted, in its compute
+ * unit's LDS for the whole registration; larger ones, up to WM_BATCH_MAX_TARGET_POINTS (16-bit slots
+ * and indices), in HBM scratch that the L2 / Infinity Cache keep close (same code, ~3x slower per
+ * point).  Beyond that: WM_ERR_ARG -- register such pairs one by one.
  * Results per item k: status[k] (what wm_icp_align would have returned), T_out + 16 k (written
  * when status[k] == WM_OK), info_out + 36 k (with_info; written whenever the item ran), stats[k].
  * T_out, info_out, stats may be NULL.  The call returns WM_OK when the batch ran. */
-#define WM_BATCH_MAX_TARGET_POINTS 10000
+#define WM_BATCH_LDS_TARGET_POINTS 10000
+#define WM_BATCH_MAX_TARGET_POINTS 65535
 typedef struct {
     const void *src;    /* wave `ref`    */
     size_t n_src;

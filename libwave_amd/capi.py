@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwavematch_hip.so")
 
 WM_OK, WM_NOT_CONVERGED, WM_TOO_FEW = 0, 1, 2
-WM_BATCH_MAX_TARGET_POINTS = 10000  # wm_icp_batch_match: one target cloud has to fit one CU's LDS
+WM_BATCH_LDS_TARGET_POINTS = 10000  # wm_icp_batch_match: targets up to this size live in one CU's LDS,
+WM_BATCH_MAX_TARGET_POINTS = 65535  # larger ones (up to this) in HBM scratch
 WM_MEM_HOST, WM_MEM_DEVICE = 0, 1
 WM_ICP_SVD, WM_ICP_GN6 = 0, 1
 WM_NN_AUTO, WM_NN_GRID, WM_NN_BRUTE = 0, 1, 2

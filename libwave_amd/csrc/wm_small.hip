@@ -37,23 +37,36 @@
 #include <string.h>
 
 #include <new>
+#include <type_traits>
+#include <vector>
 
 namespace wm {
 
 constexpr int kSmThreads = 1024;
 constexpr int kSmWaves = kSmThreads / 64;
-constexpr int kSmMaxTgt = WM_BATCH_MAX_TARGET_POINTS;  // 10 000
+constexpr int kSmMaxTgt = WM_BATCH_LDS_TARGET_POINTS;  // 10 000: the target lives in LDS
+constexpr int kSmMaxTgtHbm = WM_BATCH_MAX_TARGET_POINTS;  // 65 535: ... in the pair's HBM scratch (16-bit slots and indices)
 constexpr int kSmPer = (kSmMaxTgt + kSmThreads - 1) / kSmThreads;
-constexpr int kSmCells = 8192;
+constexpr int kSmCells = 8192;       // LDS variant: 16-bit cell starts, 16 KB
+constexpr int kSmCellsHbm = 32768;   // HBM variant: 32-bit cell starts in scratch
 constexpr int kSmRedW = 18;
-constexpr size_t kSmSortMax = 16384;  // source clouds up to this size are put in cell order (14-bit index in the sort key)
-static_assert(kSmCells % kSmThreads == 0, "layout");
+// source clouds of up to 2^bits points are put in cell order by a sort in LDS: 64 KB of keys in the space the
+// LDS target will occupy (14-bit index in the key), 128 KB when the target stays in HBM (15-bit index)
+template <bool INLDS>
+constexpr unsigned kSmSortBits = INLDS ? 14u : 15u;
+static_assert(kSmCells % kSmThreads == 0 && kSmCellsHbm % kSmThreads == 0, "layout");
 
 struct SmallPair {  // one registration of the batch (device table)
     const unsigned char *src, *tgt;  // caller-layout points in device memory
     unsigned n_src, n_tgt;
     unsigned short *seed;  // n_src entries: LDS slot of each source point's last match (0xFFFF none)
     double *csum;          // ceil(n_src / 64) rows of kAcc doubles of scratch: every 64-query chunk's sums
+    // HBM variant only: the cell-sorted target (x, y, z per point + 4 sentinels; caller's index of each; first slot of
+    // every cell + end) and, during the build, every point's (cell << 16 | rank)
+    float *txyz;
+    unsigned short *tidx;
+    unsigned *tcs;
+    unsigned *trank;
     float4 *sorted;        // n_src entries of scratch: the source packed (x, y, z, index bits), in cell order up to kSmSortMax points
 };
 
@@ -77,21 +90,48 @@ struct SmallOut {
     unsigned long long cyc[4];  // developer: shader-clock cycles of the LAST iteration's query loop / reduction / solve, and of the set-up
 };
 
-struct SmallLds {
+#define WM_SMALL_LDS_COMMON                                                                                  \
+    double red[kSmWaves][kSmRedW];                                                                             \
+    double sum[kSmRedW];                                                                                       \
+    float boxf[kSmWaves][8];                                                                                   \
+    unsigned wsum[kSmWaves];                                                                                   \
+    unsigned ticket; /* next chunk of 64 queries (the iterations hand them to whichever wavefront is free) */ \
+    float ox, oy, oz, h, inv_h;                                                                                \
+    int nx, ny, nz;                                                                                            \
+    double D[6];                                                                                               \
+    IcpDevState st;
+
+struct SmallLds {  // the target in LDS
     float xyz[3 * (kSmMaxTgt + 4)];                  // cell-sorted target, (x, y, z) per point (+ 4 far sentinels)
     unsigned short idx[kSmMaxTgt + 4];               // caller's index of each
     unsigned short cstart[kSmCells + 8];             // first slot of every cell (+ end)
-    double red[kSmWaves][kSmRedW];
-    double sum[kSmRedW];
-    float boxf[kSmWaves][8];
-    unsigned wsum[kSmWaves];
-    unsigned ticket;  // next chunk of 64 queries (the iterations hand them to whichever wavefront is free)
-    float ox, oy, oz, h, inv_h;
-    int nx, ny, nz;
-    double D[6];
-    IcpDevState st;
+    WM_SMALL_LDS_COMMON
 };
-static_assert(sizeof(SmallLds) <= 160 * 1024, "one workgroup's LDS");
+struct SmallLdsH {  // the target in HBM scratch: LDS only holds the source's sort and the shared state
+    unsigned sortbuf[1u << 15];
+    WM_SMALL_LDS_COMMON
+};
+#undef WM_SMALL_LDS_COMMON
+__device__ __forceinline__ unsigned *sm_sort_region(SmallLds &L) { return reinterpret_cast<unsigned *>(L.xyz); }  // (120 KB)
+__device__ __forceinline__ unsigned *sm_sort_region(SmallLdsH &L) { return L.sortbuf; }
+
+// Where the cell-sorted target is read from.  c(j, k) = coordinate k of slot j, idx(j) = the caller's index of
+// the point in slot j, cs(c) = first slot of cell c.
+struct SmTgtLds {
+    const SmallLds *L;
+    __device__ __forceinline__ float c(unsigned j, unsigned k) const { return L->xyz[3u * j + k]; }
+    __device__ __forceinline__ unsigned idx(unsigned j) const { return L->idx[j]; }
+    __device__ __forceinline__ unsigned cs(unsigned cell) const { return L->cstart[cell]; }
+};
+struct SmTgtHbm {  // (global, not flat, loads: L2 / MALL resident scratch); the cell starts are copied into LDS
+    const __attribute__((address_space(1))) float *xyz;
+    const __attribute__((address_space(1))) unsigned short *idxp;
+    const unsigned short *csl;  // 16-bit starts in the LDS the source's sort used
+    __device__ __forceinline__ float c(unsigned j, unsigned k) const { return xyz[3u * j + k]; }
+    __device__ __forceinline__ unsigned idx(unsigned j) const { return idxp[j]; }
+    __device__ __forceinline__ unsigned cs(unsigned cell) const { return csl[cell]; }
+};
+static_assert(sizeof(SmallLds) <= 160 * 1024 && sizeof(SmallLdsH) <= 160 * 1024, "one workgroup's LDS");
 
 __device__ __forceinline__ unsigned long long sm_key(float d2, unsigned idx) {
     return ((unsigned long long) __float_as_uint(d2) << 32) | idx;
@@ -123,7 +163,8 @@ __device__ __forceinline__ int sm_cell1(float v, float o, float inv_h, int n) {
 // the box around ball(q, r) is walked; the result is certified when the best distance is inside r
 // (then nothing outside the box can beat it), else r doubles up to rmax.  `best` comes in as the
 // gate (or the seed's key); candidates only ever lower it.
-__device__ __forceinline__ void sm_search(const SmallLds &L, const SmGrid &g, float qx, float qy, float qz,
+template <class TG>
+__device__ __forceinline__ void sm_search(const TG &tg, const SmGrid &g, float qx, float qy, float qz,
                                           float r, float rmax, unsigned long long &best, unsigned &bslot) {
     for (;;) {
         // (the box is a little larger than the ball: it has to hold against the rounding of q -+ r
@@ -136,22 +177,21 @@ __device__ __forceinline__ void sm_search(const SmallLds &L, const SmGrid &g, fl
         for (int cz = z0; cz <= z1; ++cz)
             for (int cy = y0; cy <= y1; ++cy) {
                 const int row = (cz * g.ny + cy) * g.nx;
-                const unsigned s = L.cstart[row + x0], e = L.cstart[row + x1 + 1];
+                const unsigned s = tg.cs((unsigned) (row + x0)), e = tg.cs((unsigned) (row + x1 + 1));
                 // four candidates per trip, their twelve LDS reads in flight together.  No clamp at the end of
                 // the run: what follows it are real points of the next cells (or the far sentinels
                 // after the last point), and an extra real candidate cannot hurt an arg-min over the
                 // target.  The update is a rare branch behind one unsigned min of the four d2.
                 for (unsigned j = s; j < e; j += 4u) {
-                    const float *t = &L.xyz[3u * j];
                     float d2[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) d2[u] = sm_d2(qx, qy, qz, t[3 * u], t[3 * u + 1], t[3 * u + 2]);
+                    for (int u = 0; u < 4; ++u) d2[u] = sm_d2(qx, qy, qz, tg.c(j + (unsigned) u, 0), tg.c(j + (unsigned) u, 1), tg.c(j + (unsigned) u, 2));
                     const unsigned m01 = min(__float_as_uint(d2[0]), __float_as_uint(d2[1]));
                     const unsigned m23 = min(__float_as_uint(d2[2]), __float_as_uint(d2[3]));
                     if (min(m01, m23) <= bhi) {  // (d2 >= 0: bit order = numeric order)
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            const unsigned long long k = sm_key(d2[u], L.idx[j + (unsigned) u]);
+                            const unsigned long long k = sm_key(d2[u], tg.idx(j + (unsigned) u));
                             if (k < best) {
                                 best = k;
                                 bslot = j + (unsigned) u;
@@ -166,8 +206,8 @@ __device__ __forceinline__ void sm_search(const SmallLds &L, const SmGrid &g, fl
     }
 }
 
-template <int N>
-__device__ __forceinline__ void sm_block_sum(double (&a)[N], SmallLds &L, unsigned tid) {
+template <int N, class LDS>
+__device__ __forceinline__ void sm_block_sum(double (&a)[N], LDS &L, unsigned tid) {
     static_assert(N <= kSmRedW, "reduction scratch");
 #pragma unroll
     for (int k = 0; k < N; ++k)
@@ -198,7 +238,8 @@ __device__ __forceinline__ bool sm_load_point(const unsigned char *base, unsigne
 // Bounding box of a cloud's finite points and the finest grid of cubic cells over it that has at most
 // `max_cells` cells; every lane returns the same grid.  (Any cell size gives exact searches; this
 // choice is quick.)  `count` = number of finite points.
-__device__ __forceinline__ SmGrid sm_fit_grid(SmallLds &L, const unsigned char *pts, unsigned n, unsigned stride,
+template <class LDS>
+__device__ __forceinline__ SmGrid sm_fit_grid(LDS &L, const unsigned char *pts, unsigned n, unsigned stride,
                                               int max_cells, unsigned tid, unsigned &count) {
     const unsigned lane = tid & 63u, wave = tid >> 6;
     float lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY;
@@ -309,13 +350,19 @@ __device__ __forceinline__ unsigned sm_cell_of(const SmGrid &g, float x, float y
                        sm_cell1(x, g.ox, g.inv_h, g.nx));
 }
 
+template <bool INLDS>
 __global__ void __launch_bounds__(kSmThreads)
     k_icp_small(const SmallPair *__restrict__ pairs, SmallParams P, IcpDevState st0, SmallOut *__restrict__ out) {
-    __shared__ SmallLds L;
+    using LDS = typename std::conditional<INLDS, SmallLds, SmallLdsH>::type;
+    using TG = typename std::conditional<INLDS, SmTgtLds, SmTgtHbm>::type;
+    constexpr unsigned kSortMax = 1u << kSmSortBits<INLDS>;
+    constexpr int kCells = INLDS ? kSmCells : kSmCellsHbm;
+    __shared__ LDS L;
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const SmallPair pr = pairs[blockIdx.x];
     const unsigned long long cyc_begin = clock64();
-    const unsigned n_tgt = pr.n_tgt < (unsigned) kSmMaxTgt ? pr.n_tgt : (unsigned) kSmMaxTgt;  // (host checked)
+    constexpr unsigned kMaxT = INLDS ? (unsigned) kSmMaxTgt : (unsigned) kSmMaxTgtHbm;
+    const unsigned n_tgt = pr.n_tgt < kMaxT ? pr.n_tgt : kMaxT;  // (host checked)
 
     if (tid == 0) {
         L.st = st0;
@@ -325,11 +372,11 @@ __global__ void __launch_bounds__(kSmThreads)
     // ---- 0. the source in cell order (of a grid over its own bounding box): neighbouring lanes then
     // search neighbouring cells -- the same LDS rows (broadcast reads instead of bank conflicts) for a
     // similar number of trips.  The order is a bitonic sort, in the LDS the target will occupy, of the
-    // unique keys (cell << 14 | index): deterministic, so the sums of a pair do not depend on timing.
-    // The sorted copy (x, y, z, index bits) lives in HBM scratch; clouds beyond 16 384 points keep
+    // unique keys (cell << 14 or 15 | index): deterministic, so the sums of a pair do not depend on timing.
+    // The sorted copy (x, y, z, index bits) lives in HBM scratch; clouds beyond 16 384 (32 768) points keep
     // the caller's order (packed all the same: the iterations read one layout).
     unsigned n_q = pr.n_src;  // queries per iteration
-    if (pr.n_src > (unsigned) kSmSortMax) {
+    if (pr.n_src > kSortMax) {
         for (unsigned i = tid; i < pr.n_src; i += kSmThreads) {
             float x, y, z;
             if (!sm_load_point(pr.src, i, P.stride, x, y, z)) x = y = z = __builtin_nanf("");
@@ -342,11 +389,11 @@ __global__ void __launch_bounds__(kSmThreads)
         const SmGrid gs = sm_fit_grid(L, pr.src, pr.n_src, P.stride, kSmCells, tid, n_fin);
         unsigned N = 2048;
         while (N < pr.n_src) N <<= 1;
-        unsigned *K = reinterpret_cast<unsigned *>(L.xyz);  // (120 KB)
+        unsigned *K = sm_sort_region(L);
         for (unsigned i = tid; i < N; i += kSmThreads) {
             unsigned key = ~0u;
             float x, y, z;
-            if (i < pr.n_src && sm_load_point(pr.src, i, P.stride, x, y, z)) key = (sm_cell_of(gs, x, y, z) << 14) | i;
+            if (i < pr.n_src && sm_load_point(pr.src, i, P.stride, x, y, z)) key = (sm_cell_of(gs, x, y, z) << kSmSortBits<INLDS>) | i;
             K[i] = key;
         }
         for (unsigned k = 2; k <= N; k <<= 1)
@@ -363,7 +410,7 @@ __global__ void __launch_bounds__(kSmThreads)
             }
         __syncthreads();
         for (unsigned q = tid; q < n_fin; q += kSmThreads) {
-            const unsigned i = K[q] & 0x3FFFu;
+            const unsigned i = K[q] & (kSortMax - 1u);
             float x, y, z;
             (void) sm_load_point(pr.src, i, P.stride, x, y, z);
             pr.sorted[q] = make_float4(x, y, z, __uint_as_float(i));
@@ -373,37 +420,96 @@ __global__ void __launch_bounds__(kSmThreads)
         __syncthreads();
     }
 
-    // ---- 1. the target into LDS: bounding box -> grid -> counting sort by cell
+    // ---- 1. the target cell-sorted -- into LDS, or into the pair's HBM scratch when it is too large for that:
+    // bounding box -> grid -> counting sort by cell
     unsigned n_tgt_fin;
-    const SmGrid g = sm_fit_grid(L, pr.tgt, n_tgt, P.stride, kSmCells, tid, n_tgt_fin);
-    for (unsigned c = tid; c < (kSmCells + 8) / 2; c += kSmThreads) reinterpret_cast<unsigned *>(L.cstart)[c] = 0u;
-    __syncthreads();
-    {
-        // count: two 16-bit counters per LDS word; the returned old value is the point's rank in its cell
-        unsigned cr[kSmPer];
-        unsigned *cw = reinterpret_cast<unsigned *>(L.cstart);
-#pragma unroll
-        for (int k = 0; k < kSmPer; ++k) {
-            const unsigned i = tid + (unsigned) k * kSmThreads;
-            cr[k] = ~0u;
-            float x, y, z;
-            if (i < n_tgt && sm_load_point(pr.tgt, i, P.stride, x, y, z)) {
-                const unsigned c = sm_cell_of(g, x, y, z);
-                const unsigned sh = (c & 1u) * 16u;
-                const unsigned old = atomicAdd(&cw[c >> 1], 1u << sh);
-                cr[k] = (c << 16) | ((old >> sh) & 0xFFFFu);
-            }
-        }
+    const SmGrid g = sm_fit_grid(L, pr.tgt, n_tgt, P.stride, kCells, tid, n_tgt_fin);
+    TG tg;
+    if constexpr (INLDS) {
+        tg.L = &L;
+        for (unsigned c = tid; c < (kSmCells + 8) / 2; c += kSmThreads) reinterpret_cast<unsigned *>(L.cstart)[c] = 0u;
         __syncthreads();
-        // exclusive scan of the 8 192 counts, in place (8 per lane)
-        constexpr int E = kSmCells / kSmThreads;
-        unsigned v[E], s = 0;
+        {
+            // count: two 16-bit counters per LDS word; the returned old value is the point's rank in its cell
+            unsigned cr[kSmPer];
+            unsigned *cw = reinterpret_cast<unsigned *>(L.cstart);
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            v[e] = L.cstart[E * tid + e];
-            s += v[e];
+            for (int k = 0; k < kSmPer; ++k) {
+                const unsigned i = tid + (unsigned) k * kSmThreads;
+                cr[k] = ~0u;
+                float x, y, z;
+                if (i < n_tgt && sm_load_point(pr.tgt, i, P.stride, x, y, z)) {
+                    const unsigned c = sm_cell_of(g, x, y, z);
+                    const unsigned sh = (c & 1u) * 16u;
+                    const unsigned old = atomicAdd(&cw[c >> 1], 1u << sh);
+                    cr[k] = (c << 16) | ((old >> sh) & 0xFFFFu);
+                }
+            }
+            __syncthreads();
+            // exclusive scan of the 8 192 counts, in place (8 per lane)
+            constexpr int E = kSmCells / kSmThreads;
+            unsigned v[E], s = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                v[e] = L.cstart[E * tid + e];
+                s += v[e];
+            }
+            unsigned incl = s;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned t = __shfl_up(incl, off);
+                if (lane >= (unsigned) off) incl += t;
+            }
+            if (lane == 63) L.wsum[wave] = incl;
+            __syncthreads();
+            unsigned run = incl - s;
+            for (unsigned w = 0; w < wave; ++w) run += L.wsum[w];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                L.cstart[E * tid + e] = (unsigned short) run;
+                run += v[e];
+            }
+            if (tid == kSmThreads - 1) L.cstart[kSmCells] = (unsigned short) run;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kSmPer; ++k) {
+                if (cr[k] == ~0u) continue;
+                const unsigned i = tid + (unsigned) k * kSmThreads;
+                float x, y, z;
+                (void) sm_load_point(pr.tgt, i, P.stride, x, y, z);
+                const unsigned slot = (unsigned) L.cstart[cr[k] >> 16] + (cr[k] & 0xFFFFu);
+                L.xyz[3u * slot] = x, L.xyz[3u * slot + 1u] = y, L.xyz[3u * slot + 2u] = z;
+                L.idx[slot] = (unsigned short) i;
+            }
+            if (tid < 4u) {  // far sentinels behind the last point (see sm_search)
+                const unsigned slot = n_tgt_fin + tid;
+                L.xyz[3u * slot] = L.xyz[3u * slot + 1u] = L.xyz[3u * slot + 2u] = INFINITY;
+                L.idx[slot] = 0xFFFFu;
+            }
+            __syncthreads();
         }
-        unsigned incl = s;
+    } else {
+        unsigned *cs = pr.tcs;
+        for (unsigned c = tid; c < (unsigned) kCells + 8u; c += kSmThreads) cs[c] = 0u;
+        __threadfence_block();
+        __syncthreads();
+        // count: the atomic's old value is the point's rank in its cell; (cell << 16 | rank) kept in scratch
+        for (unsigned i = tid; i < n_tgt; i += kSmThreads) {
+            unsigned cr = ~0u;
+            float x, y, z;
+            if (sm_load_point(pr.tgt, i, P.stride, x, y, z)) {
+                const unsigned c = sm_cell_of(g, x, y, z);
+                cr = (c << 16) | (atomicAdd(&cs[c], 1u) & 0xFFFFu);
+            }
+            pr.trank[i] = cr;
+        }
+        __threadfence_block();
+        __syncthreads();
+        // exclusive scan of the 32 768 counts, in place (32 consecutive per lane)
+        constexpr int E = kSmCellsHbm / kSmThreads;
+        unsigned sum = 0;
+        for (int e = 0; e < E; ++e) sum += ((const __attribute__((address_space(1))) unsigned *) cs)[E * tid + e];
+        unsigned incl = sum;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const unsigned t = __shfl_up(incl, off);
@@ -411,31 +517,39 @@ __global__ void __launch_bounds__(kSmThreads)
         }
         if (lane == 63) L.wsum[wave] = incl;
         __syncthreads();
-        unsigned run = incl - s;
+        unsigned run = incl - sum;
         for (unsigned w = 0; w < wave; ++w) run += L.wsum[w];
-#pragma unroll
         for (int e = 0; e < E; ++e) {
-            L.cstart[E * tid + e] = (unsigned short) run;
-            run += v[e];
+            const unsigned v = cs[E * tid + e];
+            cs[E * tid + e] = run;
+            run += v;
         }
-        if (tid == kSmThreads - 1) L.cstart[kSmCells] = (unsigned short) run;
+        if (tid == kSmThreads - 1) cs[kCells] = run;
+        __threadfence_block();
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kSmPer; ++k) {
-            if (cr[k] == ~0u) continue;
-            const unsigned i = tid + (unsigned) k * kSmThreads;
+        for (unsigned i = tid; i < n_tgt; i += kSmThreads) {
+            const unsigned cr = pr.trank[i];
+            if (cr == ~0u) continue;
             float x, y, z;
             (void) sm_load_point(pr.tgt, i, P.stride, x, y, z);
-            const unsigned slot = (unsigned) L.cstart[cr[k] >> 16] + (cr[k] & 0xFFFFu);
-            L.xyz[3u * slot] = x, L.xyz[3u * slot + 1u] = y, L.xyz[3u * slot + 2u] = z;
-            L.idx[slot] = (unsigned short) i;
+            const unsigned slot = cs[cr >> 16] + (cr & 0xFFFFu);
+            pr.txyz[3u * slot] = x, pr.txyz[3u * slot + 1u] = y, pr.txyz[3u * slot + 2u] = z;
+            pr.tidx[slot] = (unsigned short) i;
         }
         if (tid < 4u) {  // far sentinels behind the last point (see sm_search)
             const unsigned slot = n_tgt_fin + tid;
-            L.xyz[3u * slot] = L.xyz[3u * slot + 1u] = L.xyz[3u * slot + 2u] = INFINITY;
-            L.idx[slot] = 0xFFFFu;
+            pr.txyz[3u * slot] = pr.txyz[3u * slot + 1u] = pr.txyz[3u * slot + 2u] = INFINITY;
+            pr.tidx[slot] = 0xFFFFu;
         }
+        __threadfence_block();
         __syncthreads();
+        tg.xyz = (const __attribute__((address_space(1))) float *) pr.txyz;
+        tg.idxp = (const __attribute__((address_space(1))) unsigned short *) pr.tidx;
+        // the 32 769 cell starts fit 16 bits (<= 65 535 points): into the LDS the source's sort has left
+        unsigned short *csl = reinterpret_cast<unsigned short *>(L.sortbuf);
+        for (unsigned c = tid; c <= (unsigned) kCells; c += kSmThreads) csl[c] = (unsigned short) cs[c];
+        __syncthreads();
+        tg.csl = csl;
     }
     const float rmax = sqrtf(P.thr_d2) * 1.0001f + 1e-6f;
     const unsigned nchunks = (n_q + 63u) / 64u;
@@ -465,21 +579,21 @@ __global__ void __launch_bounds__(kSmThreads)
                 const unsigned ps = c.seed;
                 r = rmax;
                 if (ps != 0xFFFFu) {
-                    const float d2b = sm_d2(qx, qy, qz, L.xyz[3u * ps], L.xyz[3u * ps + 1u], L.xyz[3u * ps + 2u]);
+                    const float d2b = sm_d2(qx, qy, qz, tg.c(ps, 0), tg.c(ps, 1), tg.c(ps, 2));
                     if (d2b <= P.thr_d2) {
-                        best = sm_key(d2b, L.idx[ps]);
+                        best = sm_key(d2b, tg.idx(ps));
                         bslot = ps;
                         r = fmaxf(sqrtf(d2b) * 1.0001f + 1e-6f, 0.05f * g.h);
                     }
                 }
             }
-            sm_search(L, g, qx, qy, qz, fminf(r, rmax), rmax, best, bslot);
+            sm_search(tg, g, qx, qy, qz, fminf(r, rmax), rmax, best, bslot);
             const bool matched = (unsigned) best != kNoIdx;
             pr.seed[q] = (unsigned short) (matched ? bslot : 0xFFFFu);
             a[17] += 1.0;
             if (!matched) return;
             // the iteration's sums, as k_icp_stats (wm_icp.hip) forms them
-            const double px = qx, py = qy, pz = qz, tx = L.xyz[3u * bslot], ty = L.xyz[3u * bslot + 1u], tz = L.xyz[3u * bslot + 2u];
+            const double px = qx, py = qy, pz = qz, tx = tg.c(bslot, 0), ty = tg.c(bslot, 1), tz = tg.c(bslot, 2);
             a[0] += 1.0;
             a[1] += px;
             a[2] += py;
@@ -589,20 +703,20 @@ __global__ void __launch_bounds__(kSmThreads)
             float r = rmax_s;
             const unsigned ps = have_prev ? c.seed : 0xFFFFu;
             if (ps != 0xFFFFu) {
-                const float d2b = sm_d2(px, py, pz, L.xyz[3u * ps], L.xyz[3u * ps + 1u], L.xyz[3u * ps + 2u]);
+                const float d2b = sm_d2(px, py, pz, tg.c(ps, 0), tg.c(ps, 1), tg.c(ps, 2));
                 if (d2b <= P.thr_d2_strict) {
-                    best = sm_key(d2b, L.idx[ps]);
+                    best = sm_key(d2b, tg.idx(ps));
                     bslot = ps;
                     r = fmaxf(sqrtf(d2b) * 1.0001f + 1e-6f, 0.05f * g.h);
                 }
             } else if (!have_prev) {
                 r = P.r0_cells * g.h;
             }
-            sm_search(L, g, px, py, pz, fminf(r, rmax_s), rmax_s, best, bslot);
+            sm_search(tg, g, px, py, pz, fminf(r, rmax_s), rmax_s, best, bslot);
             const bool matched = (unsigned) best != kNoIdx;
             pr.seed[q] = (unsigned short) (matched ? bslot : 0xFFFFu);
             if (!matched) return;
-            const float tx = L.xyz[3u * bslot], ty = L.xyz[3u * bslot + 1u], tz = L.xyz[3u * bslot + 2u];
+            const float tx = tg.c(bslot, 0), ty = tg.c(bslot, 1), tz = tg.c(bslot, 2);
             const float av0 = __fmul_rn(0.5f, __fadd_rn(px, tx)), av1 = __fmul_rn(0.5f, __fadd_rn(py, ty)),
                         av2 = __fmul_rn(0.5f, __fadd_rn(pz, tz));
             const float df0 = __fsub_rn(px, tx), df1 = __fsub_rn(py, ty), df2 = __fsub_rn(pz, tz);
@@ -671,7 +785,7 @@ __global__ void __launch_bounds__(kSmThreads)
             if (!(c.x == c.x) || bslot == 0xFFFFu) return;
             float px, py, pz;
             sm_xform(Tf, c.x, c.y, c.z, px, py, pz);
-            const float tx = L.xyz[3u * bslot], ty = L.xyz[3u * bslot + 1u], tz = L.xyz[3u * bslot + 2u];
+            const float tx = tg.c(bslot, 0), ty = tg.c(bslot, 1), tz = tg.c(bslot, 2);
             const float av0 = __fmul_rn(0.5f, __fadd_rn(px, tx)), av1 = __fmul_rn(0.5f, __fadd_rn(py, ty)),
                         av2 = __fmul_rn(0.5f, __fadd_rn(pz, tz));
             const float df0 = __fsub_rn(px, tx), df1 = __fsub_rn(py, ty), df2 = __fsub_rn(pz, tz);
@@ -712,6 +826,7 @@ __global__ void __launch_bounds__(kSmThreads)
 struct SmallBatch {
     DevBuf d_stage;     // [table | clouds | seeds]
     DevBuf d_out;
+    DevBuf d_big;       // HBM-resident targets: cell-sorted copies, cell starts, ranks
     void *h_stage = nullptr;  // pinned mirror of table + clouds
     size_t h_stage_cap = 0;
     void *h_out = nullptr;
@@ -728,6 +843,7 @@ void small_batch_release(wm_ctx *ctx) {
     if (!b) return;
     b->d_stage.release();
     b->d_out.release();
+    b->d_big.release();
     if (b->h_stage) (void) hipHostFree(b->h_stage);
     if (b->h_out) (void) hipHostFree(b->h_out);
     delete b;
@@ -759,17 +875,28 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
     if (p->force_iterations <= 0 && p->max_iter <= 0) return WM_ERR_ARG;
     if (with_info != 0 && with_info != 1) return WM_ERR_ARG;
     if (n_items == 0) return WM_OK;
-    size_t cloud_bytes = 0, seeds = 0, sorted_pts = 0, chunk_rows = 0;
-    int live = 0;
+    size_t cloud_bytes = 0, seeds = 0, sorted_pts = 0, chunk_rows = 0, big_bytes = 0;
+    int live = 0, n_lds = 0, n_hbm = 0;
+    auto big_need = [](size_t n_target) {  // scratch of one HBM-resident target, 16-byte aligned pieces
+        const size_t a = ((n_target + 4) * 12 + 15) & ~(size_t) 15, b = ((n_target + 4) * 2 + 15) & ~(size_t) 15;
+        const size_t c = ((size_t) kSmCellsHbm + 8) * 4, e = (n_target * 4 + 15) & ~(size_t) 15;
+        return a + b + c + e;
+    };
     for (int k = 0; k < n_items; ++k) {
         const wm_batch_item &it = items[k];
         if ((it.n_src > 0 && !it.src) || (it.n_target > 0 && !it.target)) return WM_ERR_ARG;
-        if (it.n_target > (size_t) kSmMaxTgt || it.n_src > 0x7FFFFFF0u) return WM_ERR_ARG;
+        if (it.n_target > (size_t) kSmMaxTgtHbm || it.n_src > 0x7FFFFFF0u) return WM_ERR_ARG;
         if (it.n_src == 0 || it.n_target == 0) continue;  // (answered on the host, below)
         cloud_bytes += ((it.n_src * stride + 15) & ~(size_t) 15) + ((it.n_target * stride + 15) & ~(size_t) 15);
         seeds += (it.n_src + 7) & ~(size_t) 7;
         sorted_pts += it.n_src;
         chunk_rows += (it.n_src + 63) / 64;
+        if (it.n_target > (size_t) kSmMaxTgt) {
+            big_bytes += big_need(it.n_target);
+            ++n_hbm;
+        } else {
+            ++n_lds;
+        }
         ++live;
     }
     WM_HIP(ctx, hipSetDevice(ctx->device));
@@ -791,6 +918,7 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
                              chunk_rows * kAcc * sizeof(double);
     WM_HIP(ctx, B->d_stage.reserve(dev_bytes));
     WM_HIP(ctx, B->d_out.reserve((size_t) live * sizeof(SmallOut)));
+    if (big_bytes) WM_HIP(ctx, B->d_big.reserve(big_bytes));
     WM_TRY(pinned_reserve(ctx, &B->h_stage, &B->h_stage_cap, up_bytes));
     WM_TRY(pinned_reserve(ctx, &B->h_out, &B->h_out_cap, (size_t) live * sizeof(SmallOut)));
     // the stream may still be reading the staging buffer for the previous batch
@@ -803,15 +931,19 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
     unsigned short *seed_base = reinterpret_cast<unsigned short *>(d + table_bytes + (mem == WM_MEM_HOST ? cloud_bytes : 0));
     float4 *sorted_base = reinterpret_cast<float4 *>(reinterpret_cast<unsigned char *>(seed_base) + seed_bytes);
     double *csum_base = reinterpret_cast<double *>(sorted_base + sorted_pts);
-    size_t seed_off = 0, sorted_off = 0, csum_off = 0;
-    int row = 0;
+    size_t seed_off = 0, sorted_off = 0, csum_off = 0, big_off = 0;
+    // rows of the table: the LDS-resident items first, then the HBM-resident ones (a launch each)
+    std::vector<int> row_of((size_t) n_items, -1);
+    int next_lds = 0, next_hbm = n_lds;
     // host clouds: copied into the pinned mirror and sent in slices of ~2 MB, so that the DMA of one
     // slice runs while the next is being copied (the table goes last, once it is complete)
     size_t sent = table_bytes;
     for (int k = 0; k < n_items; ++k) {
         const wm_batch_item &it = items[k];
         if (status[k] != WM_OK) continue;
-        SmallPair &t = table[row++];
+        const bool big = it.n_target > (size_t) kSmMaxTgt;
+        row_of[(size_t) k] = big ? next_hbm++ : next_lds++;
+        SmallPair &t = table[row_of[(size_t) k]];
         t.n_src = (unsigned) it.n_src;
         t.n_tgt = (unsigned) it.n_target;
         if (mem == WM_MEM_HOST) {
@@ -835,6 +967,18 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
         sorted_off += it.n_src;
         t.csum = csum_base + csum_off;
         csum_off += ((it.n_src + 63) / 64) * kAcc;
+        t.txyz = nullptr, t.tidx = nullptr, t.tcs = nullptr, t.trank = nullptr;
+        if (big) {
+            unsigned char *b = B->d_big.as<unsigned char>() + big_off;
+            t.txyz = reinterpret_cast<float *>(b);
+            b += ((it.n_target + 4) * 12 + 15) & ~(size_t) 15;
+            t.tidx = reinterpret_cast<unsigned short *>(b);
+            b += ((it.n_target + 4) * 2 + 15) & ~(size_t) 15;
+            t.tcs = reinterpret_cast<unsigned *>(b);
+            b += ((size_t) kSmCellsHbm + 8) * 4;
+            t.trank = reinterpret_cast<unsigned *>(b);
+            big_off += big_need(it.n_target);
+        }
     }
     if (off > sent) WM_HIP(ctx, hipMemcpyAsync(d + sent, h + sent, off - sent, hipMemcpyHostToDevice, ctx->stream));
     WM_HIP(ctx, hipMemcpyAsync(d, h, table_bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -863,8 +1007,12 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
     P.with_info = with_info;
     P.iter_cap = st0.max_iter + 1;
     WM_HIP(ctx, hipEventRecord(ctx->ev_a, ctx->stream));
-    hipLaunchKernelGGL(k_icp_small, dim3((unsigned) live), dim3(kSmThreads), 0, ctx->stream,
-                       reinterpret_cast<const SmallPair *>(d), P, st0, B->d_out.as<SmallOut>());
+    if (n_lds)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_small<true>), dim3((unsigned) n_lds), dim3(kSmThreads), 0, ctx->stream,
+                           reinterpret_cast<const SmallPair *>(d), P, st0, B->d_out.as<SmallOut>());
+    if (n_hbm)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_small<false>), dim3((unsigned) n_hbm), dim3(kSmThreads), 0, ctx->stream,
+                           reinterpret_cast<const SmallPair *>(d) + n_lds, P, st0, B->d_out.as<SmallOut>() + n_lds);
     WM_HIP(ctx, hipGetLastError());
     WM_HIP(ctx, hipEventRecord(ctx->ev_b, ctx->stream));
     WM_HIP(ctx, hipMemcpyAsync(B->h_out, B->d_out.p, (size_t) live * sizeof(SmallOut), hipMemcpyDeviceToHost, ctx->stream));
@@ -873,10 +1021,9 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
     (void) hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b);
 
     const SmallOut *o = static_cast<const SmallOut *>(B->h_out);
-    row = 0;
     for (int k = 0; k < n_items; ++k) {
         if (status[k] != WM_OK) continue;
-        const SmallOut &r = o[row++];
+        const SmallOut &r = o[row_of[(size_t) k]];
         if (stats) {
             wm_icp_stats &s = stats[k];
             s.converged = r.converged;

@@ -129,7 +129,12 @@ void warnIfDegenerate(int degenerate) {
 }  // namespace
 
 // ---- many pairs, one launch
-size_t ICPMatcher::maxBatchTargetPoints() { return WM_BATCH_MAX_TARGET_POINTS; }
+// wm_icp_batch_match takes targets of up to WM_BATCH_MAX_TARGET_POINTS = 65 535 points, but near that size
+// the one-workgroup registration (target in HBM scratch: 256 pairs x 60 000 points no longer fit the
+// Infinity Cache) is no faster than a registration of its own on the whole device.  Measured, 256 pairs per
+// launch against the stream-per-worker pool: 20 000 points 43 000 pairs/s against 7 700, 30 000 points
+// 24 500 against 5 200, 45 000 points 7 800 against 3 800, 60 000 points ~3 000 against ~3 500.
+size_t ICPMatcher::maxBatchTargetPoints() { return 50000; }
 
 bool ICPMatcher::batchable(const PCLPointCloudPtr &r, const PCLPointCloudPtr &t) const {
     return !(params.res > 0) && devices.size() <= 1 && r && t && cloudSize(t) <= maxBatchTargetPoints();

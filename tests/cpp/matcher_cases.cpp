@@ -363,7 +363,9 @@ AddCase c_batch_direct("ICPTest.matchBatchEqualsOneByOne", [] {
     pairs.emplace_back(subsample(scan, 11, 0.f), subsample(scan, 10, 0.1f));
     wave::ICPMatcher batch(p);
     for (const auto &pr : pairs) EXPECT(batch.batchable(pr.first, pr.second));
-    EXPECT(!batch.batchable(scan, scan));  // 50k+ points: beyond one compute unit's LDS
+    EXPECT(!batch.batchable(scan, scan));  // 55k points: the pool registers those one by one (faster there)
+    pairs.emplace_back(subsample(scan, 2, 0.f), subsample(scan, 2, 0.2f));  // 27.5k points: the target stays in HBM
+    EXPECT(batch.batchable(pairs.back().first, pairs.back().second));
     wave::ICPMatcher::BatchOutcomes got;
     EXPECT(batch.matchBatch(pairs, got));
     EXPECT(got.size() == pairs.size());
@@ -374,7 +376,7 @@ AddCase c_batch_direct("ICPTest.matchBatchEqualsOneByOne", [] {
         const bool ok = one.match();
         one.estimateInfo();
         EXPECT(ok == got[k].matched);
-        EXPECT(ok == (k != 5));
+        EXPECT(ok == (k != 5));  // (pair 5: nothing within max_corr)
         if (ok) {
             EXPECT(distanceTo(one.getResult(), got[k].transform) < 1e-9);
             EXPECT((one.getInfo() - got[k].info).norm() <= 1e-5 * one.getInfo().norm());

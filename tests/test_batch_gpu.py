@@ -104,7 +104,32 @@ def test_batch_source_larger_than_the_sort_window(wm, ctx, oracle):
         np.testing.assert_allclose(g["info"], olumold, rtol=2e-4, atol=1e-6 * np.abs(olumold).max())
 
 
-def test_batch_rejects_targets_beyond_the_lds_budget(wm, ctx):
+def test_batch_targets_beyond_the_lds_stay_in_hbm(wm, ctx, oracle, testscan):
+    """Targets of 10 001 ... 65 535 points: the same kernel with the cell-sorted target in HBM scratch.
+    Mixed with LDS-resident items in one call; the reference's own scan (55 067 points) among them."""
+    a = synth.pair(30000, seed=21, mode="resample")
+    b = synth.pair(12000, seed=22, mode="resample")
+    c = synth.pair(8000, seed=23, mode="resample")
+    perturb = np.eye(4)
+    perturb[0, 3] = 0.2
+    scan_t = oracle.transform_cloud_d(testscan, perturb)
+    holes = a[1].copy()
+    holes[::11, 0] = np.nan
+    pairs = [(a[0], a[1]), (c[0], c[1]), (b[0], b[1]), (testscan, scan_t), (a[0], holes)]
+    got = ctx.icp_batch_match(pairs, with_info=True, max_corr=3.0, max_iter=100)
+    for (ref, tgt), g in zip(pairs, got):
+        keep = np.isfinite(tgt).all(1)
+        want = oracle.IcpMatch(ref, tgt[keep], res=-1.0, multiscale_steps=0, incremental_float=0)
+        assert g["rc"] == 0 and want.ok
+        assert (g["iterations"], g["n_corr"]) == (want.r.iterations, want.r.n_corr)
+        dt, ang = pose_error(g["T"], want.T)
+        assert dt <= 1e-6 and ang <= 1e-7, (dt, ang)
+        olumold, _ = want.lumold(3.0)
+        np.testing.assert_allclose(g["info"], olumold, rtol=2e-4, atol=1e-6 * np.abs(olumold).max())
+    assert np.linalg.norm(got[3]["T"] - perturb) < 0.1     # wave_matching/tests/icp_tests.cpp:59-61
+
+
+def test_batch_rejects_targets_beyond_sixteen_bit_slots(wm, ctx):
     ref, tgt, _ = synth.pair(wm.WM_BATCH_MAX_TARGET_POINTS + 1, seed=1, mode="resample")
     with pytest.raises(wm.WmError):
         ctx.icp_batch_match([(ref, tgt)], max_corr=3.0)
