@@ -703,6 +703,7 @@ int wm_ctx_create(wm_ctx **out, int device) {
     }
     if (const char *e = getenv("WM_TUNE_SPIN_US")) ctx->tune_spin_us = atoi(e);
     if (const char *e = getenv("WM_TUNE_XCD_REVERSE")) ctx->tune_xcd_reverse = atoi(e);
+    if (const char *e = getenv("WM_TUNE_NN_WALK_FILTER")) ctx->tune_nn_walk_filter = atoi(e);
     if (const char *e = getenv("WM_TUNE_SCAN")) ctx->tune_scan = atoi(e);
     if (const char *e = getenv("WM_SHARD_FORCE")) ctx->tune_force_shard = atoi(e);
     if (const char *e = getenv("WM_TUNE_TWO_STREAMS")) ctx->tune_two_streams = atoi(e);

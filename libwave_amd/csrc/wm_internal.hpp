@@ -207,6 +207,7 @@ struct wm_ctx {
     int tune_radix_min = 512 << 10;  // sorts of more items take rocPRIM's onesweep radix path (wm_sort.hpp)
     int tune_xcd_chunk = 32;     // search kernel: XCDs take turns in chunks of this many workgroups (0: one eighth each)
     int tune_scan = 1;           // exclusive scans: rocPRIM look-back scan (1) or the three-kernel scan (0)
+    int tune_nn_walk_filter = 1;  // balanced walk: LDS atomic only for trips that can improve the owner's best
     int tune_xcd_reverse = 0;    // search kernel: hand the workgroups out back to front (experiment)
     int tune_force_shard = 0;    // WM_SHARD_FORCE=1: a one-rank RCCL group still runs the sharded loop (plumbing check)
     int tune_two_streams = 1;    // source Morton sort on a side stream beside the target's grid build

@@ -331,7 +331,7 @@ __device__ __forceinline__ void balanced_walk(BalLds &L, const unsigned (&rs)[RC
                                               const unsigned (&re)[RC], unsigned lane,
                                               const float4 *pts, const float4 *ubase, float qx, float qy,
                                               float qz, unsigned long long &best, unsigned &cost,
-                                              unsigned long long *prof) {
+                                              unsigned long long *prof, bool filter) {
     const unsigned long long prof_t0 = COST ? clock64() : 0ull;
     unsigned len[RC], t = 0, longest = 0;
 #pragma unroll
@@ -366,6 +366,10 @@ __device__ __forceinline__ void balanced_walk(BalLds &L, const unsigned (&rs)[RC
             for (unsigned j = rs[u]; j < re[u]; j += 4u) L.items[off++] = tag | j;
     }
     L.best[lane] = best;
+    // the owner's best d2 at the start of the walk rides along with its query: a worker builds the four
+    // 64-bit keys and issues the LDS atomic only when one of its candidates can get under it -- rarely,
+    // once the clouds are close (the seed is usually the neighbour).  A stale bound lets more through, never less.
+    reinterpret_cast<unsigned *>(&L.q[lane])[3] = filter ? (unsigned) (best >> 32) : 0x7F800000u;
     __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave execute in order; this only stops the compiler)
     for (unsigned k0 = 0; k0 < T; k0 += 64u) {
         const unsigned k = k0 + lane;
@@ -375,12 +379,15 @@ __device__ __forceinline__ void balanced_walk(BalLds &L, const unsigned (&rs)[RC
             const float4 q = L.q[owner];
             const gp_f4 p = (gp_f4) (ubase ? ubase : (const float4 *) L.base[owner]) + j;
             const f4v t0 = p[0], t1 = p[1], t2 = p[2], t3 = p[3];
-            const unsigned long long k0_ = make_key(canon_d2v(q.x, q.y, q.z, t0), __float_as_uint(t0.w));
-            const unsigned long long k1_ = make_key(canon_d2v(q.x, q.y, q.z, t1), __float_as_uint(t1.w));
-            const unsigned long long k2_ = make_key(canon_d2v(q.x, q.y, q.z, t2), __float_as_uint(t2.w));
-            const unsigned long long k3_ = make_key(canon_d2v(q.x, q.y, q.z, t3), __float_as_uint(t3.w));
-            const unsigned long long a = k0_ < k1_ ? k0_ : k1_, b = k2_ < k3_ ? k2_ : k3_;
-            atomicMin(&L.best[owner], a < b ? a : b);
+            const float d0 = canon_d2v(q.x, q.y, q.z, t0), d1 = canon_d2v(q.x, q.y, q.z, t1);
+            const float d2 = canon_d2v(q.x, q.y, q.z, t2), d3 = canon_d2v(q.x, q.y, q.z, t3);
+            const unsigned m = min(min(__float_as_uint(d0), __float_as_uint(d1)), min(__float_as_uint(d2), __float_as_uint(d3)));
+            if (m <= __float_as_uint(q.w)) {  // (d2 >= 0: bit order = numeric order)
+                const unsigned long long k0_ = make_key(d0, __float_as_uint(t0.w)), k1_ = make_key(d1, __float_as_uint(t1.w));
+                const unsigned long long k2_ = make_key(d2, __float_as_uint(t2.w)), k3_ = make_key(d3, __float_as_uint(t3.w));
+                const unsigned long long a = k0_ < k1_ ? k0_ : k1_, b = k2_ < k3_ ? k2_ : k3_;
+                atomicMin(&L.best[owner], a < b ? a : b);
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -398,7 +405,7 @@ __device__ __forceinline__ unsigned long long scan_box_bal(const GridDev &g, boo
                                                            float qz, float r, unsigned long long best,
                                                            float *margin, BalLds &L, unsigned lane,
                                                            bool allow_layered, const float4 *ubase,
-                                                           unsigned &cost, unsigned long long *prof) {
+                                                           unsigned &cost, unsigned long long *prof, bool filter) {
     const float big = 4.0e6f;
     const float fx = fminf(fmaxf((qx - g.ox) * g.inv_h, -big), big);
     const float fy = fminf(fmaxf((qy - g.oy) * g.inv_h, -big), big);
@@ -423,7 +430,7 @@ __device__ __forceinline__ unsigned long long scan_box_bal(const GridDev &g, boo
             re[u] = ldc(g.cell_start, a1[u]);
         }
         if constexpr (COST) cost += has ? 1u << 16 : 0u;
-        balanced_walk<COST, RC>(L, rs, re, lane, g.pts, ubase, qx, qy, qz, best, cost, prof);
+        balanced_walk<COST, RC>(L, rs, re, lane, g.pts, ubase, qx, qy, qz, best, cost, prof, filter);
     };
     const bool layered =
         allow_layered && __popcll(__ballot(has && (yb - ya + 1) * (zb - za + 1) > kLayeredRows)) >= 8;
@@ -613,7 +620,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
     __shared__ uint2 s_runs[BAL ? 1 : kRowChunk * 64];
     __shared__ BalHolder<BAL> s_hold;
     const bool rev = (xcd_chunk >> 31) != 0u;  // experiment: hand the queries out back to front
-    const unsigned chunk_sz = xcd_chunk & 0x7FFFFFFFu;
+    const unsigned chunk_sz = xcd_chunk & 0x3FFFFFFFu;
+    const bool walk_filter = ((xcd_chunk >> 30) & 1u) != 0u;  // see balanced_walk
     const unsigned bidx = rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
     const unsigned lane = threadIdx.x & 63u;
     const int L = lv->n;
@@ -693,11 +701,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
             float margin;
             if (__ballot(live && l != l0) == 0ull) {
                 const GridDev g = lv->g[l0];
-                best = scan_box_bal<COST, RC>(g, live, qx, qy, qz, r, best, &margin, L, lane, have_prev, g.pts, cost, prof);
+                best = scan_box_bal<COST, RC>(g, live, qx, qy, qz, r, best, &margin, L, lane, have_prev, g.pts, cost, prof, walk_filter);
             } else {
                 const GridDev g = lv->g[l];
                 L.base[lane] = (unsigned long long) g.pts;
-                best = scan_box_bal<COST, RC>(g, live, qx, qy, qz, r, best, &margin, L, lane, have_prev, nullptr, cost, prof);
+                best = scan_box_bal<COST, RC>(g, live, qx, qy, qz, r, best, &margin, L, lane, have_prev, nullptr, cost, prof, walk_filter);
             }
             if (live) {
                 if constexpr (COST) cost += 1u << 24;
@@ -956,6 +964,7 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
         if (rows_out) *rows_out = blocks;
     }
     xcd_chunk |= ctx->tune_xcd_reverse ? 0x80000000u : 0u;
+    xcd_chunk |= ctx->tune_nn_walk_filter ? 0x40000000u : 0u;
     // the balanced walk packs (lane, point offset) into 32 bits: targets below 2^26 points
     const bool bal = ctx->tune_nn_balanced && ctx->n_tgt_input < (1u << 26) - 8u;
     if (ev0) WM_HIP(ctx, hipEventRecord(ev0, ctx->stream));

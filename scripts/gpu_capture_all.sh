@@ -12,4 +12,11 @@ bash scripts/gpu_pmc_detail.sh ${TAG}_detail > /dev/null 2>&1
 bash scripts/gpu_pmc_ndt.sh ${TAG}_ndt > /dev/null 2>&1
 python scripts/pmc_to_json.py gpurun_out/${TAG}_pmc gpurun_out/${TAG}_pmc/pmc_latest.json gpurun_out/${TAG}_ndt > /dev/null
 python bench.py > gpurun_out/${TAG}_bench_line_noprof.json 2> /dev/null
+# the C++ wave::MultiMatcher pool: batched (deep queue) and stream-per-worker (queue of 2 x workers)
+( cd libwave_amd/host
+  for n in 10000 30000; do
+    BENCH_QUEUE=2048 timeout 120 ./bench_multimatcher $n 6000 1 2 4
+    timeout 120 ./bench_multimatcher $n 2000 4 16
+  done
+  timeout 120 ./bench_multimatcher 100000 600 4 16 ) > gpurun_out/${TAG}_multimatcher_cpp.jsonl 2> /dev/null
 ls gpurun_out/${TAG}_*
