@@ -35,11 +35,57 @@ class FakeMatcher : public wave::Matcher<wave::PCLPointCloudPtr> {
     wave::PCLPointCloudPtr ref_, target_;
 };
 
+// ... and one that, like wave::ICPMatcher, can register several queued pairs per trip: the pool's
+// batched branch (takeBatch / runBatch) under the same race detector.  Odd-sized clouds are "not
+// batchable", so batches and single registrations interleave.
+class FakeBatchMatcher : public FakeMatcher {
+ public:
+    explicit FakeBatchMatcher(FakeParams p) : FakeMatcher(p) {}
+    struct BatchOutcome {
+        EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+        bool matched;
+        Eigen::Affine3d transform;
+        wave::Mat6 info;
+    };
+    typedef std::vector<BatchOutcome, Eigen::aligned_allocator<BatchOutcome>> BatchOutcomes;
+    bool batchable(const wave::PCLPointCloudPtr &r, const wave::PCLPointCloudPtr &) const { return r->points.size() % 2 == 0; }
+    bool matchBatch(const std::vector<std::pair<wave::PCLPointCloudPtr, wave::PCLPointCloudPtr>> &pairs, BatchOutcomes &out) {
+        out.resize(pairs.size());
+        for (size_t k = 0; k < pairs.size(); ++k) {
+            out[k].matched = true;
+            out[k].transform = wave::Affine3::Identity();
+            out[k].transform.translation()(0) = (double) pairs[k].first->points.size();
+            out[k].info = wave::Mat6::Identity();
+        }
+        batches.fetch_add(1);
+        batched_pairs.fetch_add((int) pairs.size());
+        return true;
+    }
+    static std::atomic<int> batches, batched_pairs;
+};
+std::atomic<int> FakeBatchMatcher::batches{0}, FakeBatchMatcher::batched_pairs{0};
+
+template <class Pool>
+int drive(Pool &pool, int kJobs);
+
 }  // namespace
 
 int main() {
     const int kJobs = 400;
-    wave::MultiMatcher<FakeMatcher, FakeParams> pool(6, 4, FakeParams());
+    wave::MultiMatcher<FakeMatcher, FakeParams> plain(6, 4, FakeParams());
+    wave::MultiMatcher<FakeBatchMatcher, FakeParams> batched(3, 64, FakeParams());
+    const int bad = drive(plain, kJobs) + drive(batched, kJobs);
+    std::printf("batched pool: %d launches for %d pairs\n", FakeBatchMatcher::batches.load(), FakeBatchMatcher::batched_pairs.load());
+    if (FakeBatchMatcher::batched_pairs.load() == 0) {
+        std::printf("FAILED: the batched branch never ran\n");
+        return 1;
+    }
+    return bad;
+}
+
+namespace {
+template <class Pool>
+int drive(Pool &pool, int kJobs) {
     std::atomic<int> got{0};
     std::set<int> ids;
     std::thread consumer([&] {
@@ -71,3 +117,4 @@ int main() {
     std::printf("%s: %zu distinct results, done=%d\n", ok ? "OK" : "FAILED", ids.size(), pool.done() ? 1 : 0);
     return ok ? 0 : 1;
 }
+}  // namespace
