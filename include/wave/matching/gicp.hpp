@@ -36,6 +36,8 @@ struct GICPMatcherParams {
 class GICPMatcher : public Matcher<PCLPointCloudPtr> {
  public:
     explicit GICPMatcher(GICPMatcherParams params1);
+    // HIP device of the matchers the calling thread constructs from now on (see ICPMatcher::setThreadDevice)
+    static void setThreadDevice(int device);
     GICPMatcher(const GICPMatcher &other);  // for MultiMatcher; the copy gets its own context
     GICPMatcher &operator=(const GICPMatcher &other);
     ~GICPMatcher();

@@ -68,6 +68,9 @@ class ICPMatcher : public Matcher<PCLPointCloudPtr> {
 
     // HIP device ordinal new matchers bind to (default: env WAVE_MATCHING_DEVICE, else 0)
     static void setDefaultDevice(int device);
+    // ... and for the matchers the CALLING THREAD constructs from now on (wave::MultiMatcher spreads its
+    // workers over the devices of a node with it); a negative ordinal returns to the default
+    static void setThreadDevice(int device);
 
     // Spread ONE registration over several GPUs of the node (no reference counterpart; full-resolution
     // matches only, params.res <= 0): the target is cut into equal-count x-slabs, one per device, every

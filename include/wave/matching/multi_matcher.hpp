@@ -48,7 +48,11 @@ class MultiMatcher {
         // WAVE_MATCHING_MAX_WORKERS or setMaxWorkers() to change it).
         const int crew = std::max(1, std::min(n_threads > 0 ? n_threads : 1, maxWorkers()));
         workers_.reserve(crew);
-        for (int w = 0; w < crew; ++w) workers_.emplace_back([this] { work(); });
+        const std::vector<int> devs = devices();
+        for (int w = 0; w < crew; ++w) {
+            const int dev = devs.empty() ? -1 : devs[(size_t) w % devs.size()];
+            workers_.emplace_back([this, dev] { work(dev); });
+        }
     }
 
     ~MultiMatcher() {
@@ -69,6 +73,27 @@ class MultiMatcher {
             if (v > 0) return v;
         }
         return 16;
+    }
+    /** HIP devices the workers of pools constructed afterwards are dealt onto, round robin (one pool
+     *  feeding all GPUs of a node: registrations are independent, so throughput scales with the
+     *  devices -- the "replicas" way of using several GPUs; ONE registration over several GPUs is
+     *  ICPMatcher::setDevices).  Empty: every worker uses the default device.  Env
+     *  WAVE_MATCHING_DEVICES="0,1,2,3" does the same.  Needs a matcher type with a static
+     *  setThreadDevice(int) (ICPMatcher, GICPMatcher, NDTMatcher). */
+    static void setDevices(const std::vector<int> &list) { deviceSetting() = list; }
+    static std::vector<int> devices() {
+        if (!deviceSetting().empty()) return deviceSetting();
+        std::vector<int> out;
+        if (const char *e = std::getenv("WAVE_MATCHING_DEVICES")) {
+            for (const char *p = e; *p;) {
+                char *end = nullptr;
+                const long v = std::strtol(p, &end, 10);
+                if (end == p) break;
+                if (v >= 0) out.push_back((int) v);
+                p = *end == ',' ? end + 1 : end;
+            }
+        }
+        return out;
     }
     /** Number of worker threads of this pool. */
     int workers() const { return static_cast<int>(workers_.size()); }
@@ -172,7 +197,15 @@ class MultiMatcher {
 
     // worker body: the matcher lives on this thread's stack, so its device context is created
     // (lazily, at the first match) by the thread that uses it
-    void work() {
+    template <typename M>
+    static auto bindThread(int device, int) -> decltype(M::setThreadDevice(device), void()) {
+        M::setThreadDevice(device);
+    }
+    template <typename M>
+    static void bindThread(int, long) {}
+
+    void work(int device) {
+        if (device >= 0) bindThread<T>(device, 0);
         T matcher{R(config_)};
         std::vector<Job> taken;
         for (;;) {
@@ -204,6 +237,10 @@ class MultiMatcher {
         }
     }
 
+    static std::vector<int> &deviceSetting() {
+        static std::vector<int> setting;
+        return setting;
+    }
     static int &maxWorkersSetting() {
         static int setting = 0;
         return setting;

@@ -34,6 +34,8 @@ struct NDTMatcherParams {
 class NDTMatcher : public Matcher<PCLPointCloudPtr> {
  public:
     explicit NDTMatcher(NDTMatcherParams params1);
+    // HIP device of the matchers the calling thread constructs from now on (see ICPMatcher::setThreadDevice)
+    static void setThreadDevice(int device);
     NDTMatcher(const NDTMatcher &other);
     NDTMatcher &operator=(const NDTMatcher &other);
     ~NDTMatcher();

@@ -18,6 +18,8 @@ GICPMatcherParams::GICPMatcherParams(const std::string &config_path) {
                                  {"fit_eps", &fit_eps_unused}});
 }
 
+void GICPMatcher::setThreadDevice(int device) { shim::setThreadDevice(device); }
+
 GICPMatcher::GICPMatcher(GICPMatcherParams params1)
     : ctx(nullptr), device(shim::defaultDevice()), ref(shim::emptyCloud()), target(shim::emptyCloud()),
       params(params1), ref_on_device(false), target_on_device(false) {

@@ -9,6 +9,7 @@
 namespace wave {
 
 void ICPMatcher::setDefaultDevice(int device) { shim::setDefaultDevice(device); }
+void ICPMatcher::setThreadDevice(int device) { shim::setThreadDevice(device); }
 
 ICPMatcherParams::ICPMatcherParams(const std::string &config_path) {
     int estimator = 0;

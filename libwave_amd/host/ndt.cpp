@@ -26,6 +26,8 @@ bool pcl18StepRule() {
 
 void NDTMatcher::setPcl18StepRule(bool on) { pcl18Setting() = on ? 1 : 0; }
 
+void NDTMatcher::setThreadDevice(int device) { shim::setThreadDevice(device); }
+
 NDTMatcher::NDTMatcher(NDTMatcherParams params1)
     : ctx(nullptr), device(shim::defaultDevice()), ref(shim::emptyCloud()), target(shim::emptyCloud()),
       params(params1), pcl18_step_rule(pcl18StepRule()), target_on_device(false) {

@@ -7,15 +7,18 @@ namespace shim {
 
 namespace {
 int g_device_override = -1;
+thread_local int t_device_override = -1;
 }
 
 int defaultDevice() {
+    if (t_device_override >= 0) return t_device_override;
     if (g_device_override >= 0) return g_device_override;
     const char *env = std::getenv("WAVE_MATCHING_DEVICE");
     return env ? std::atoi(env) : 0;
 }
 
 void setDefaultDevice(int device) { g_device_override = device; }
+void setThreadDevice(int device) { t_device_override = device; }
 
 bool acquire(wm_ctx *&ctx, int device) {
     if (ctx) return true;

@@ -18,6 +18,7 @@ namespace shim {
 // WAVE_MATCHING_DEVICE, else 0
 int defaultDevice();
 void setDefaultDevice(int device);
+void setThreadDevice(int device);  // matchers constructed by the calling thread from now on (< 0: back to the default)
 
 // Creates the context on first use, in the calling thread.  false (and a LOG_ERROR) if the
 // device cannot be opened; the matcher then reports "no match".

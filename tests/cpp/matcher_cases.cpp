@@ -426,6 +426,30 @@ AddCase c_multi_batch("MultiTest.queuedPairsShareOneLaunch", [] {
     EXPECT(seen.size() == (size_t) jobs);
 });
 
+// One pool over the GPUs of a node: the workers are dealt onto the listed devices (here the one
+// device this box has, named twice -- the binding goes through the same per-thread default).
+AddCase c_multi_devices("MultiTest.workersDealtOverDevices", [] {
+    typedef wave::MultiMatcher<wave::ICPMatcher, wave::ICPMatcherParams> Pool;
+    Pool::setDevices({0, 0});
+    EXPECT(Pool::devices().size() == 2u);
+    {
+        Pool pool(4, 16, singleScale());
+        const auto scan = loadScan();
+        for (int k = 0; k < 6; ++k) pool.insert(k, scan, scan);
+        while (!pool.done()) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        int id = -1, seen = 0;
+        Eigen::Affine3d T;
+        wave::Mat6 info;
+        while (pool.getResult(&id, &T, &info)) {
+            ++seen;
+            EXPECT(distanceTo(wave::Affine3::Identity(), T) < 1e-6);
+        }
+        EXPECT(seen == 6);
+    }
+    Pool::setDevices({});
+    wave::ICPMatcher::setThreadDevice(-1);
+});
+
 }  // namespace
 
 int main(int argc, char **argv) {
