@@ -166,7 +166,10 @@ int wm_icp_match(wm_ctx *ctx, const void *ref, size_t n_ref, const void *target,
  * point).  Beyond that: WM_ERR_ARG -- register such pairs one by one.
  * Results per item k: status[k] (what wm_icp_align would have returned), T_out + 16 k (written
  * when status[k] == WM_OK), info_out + 36 k (with_info; written whenever the item ran), stats[k].
- * T_out, info_out, stats may be NULL.  The call returns WM_OK when the batch ran. */
+ * T_out, info_out, stats may be NULL.  The call returns WM_OK when the batch ran.  In stats[k],
+ * align_ms is the device time of the whole launch; nn_ms / stats_ms / solve_ms / coarse_ms carry a
+ * developer aid instead of times: shader-clock kilocycles of the item's LAST iteration (query loop,
+ * row sum, solve) and of its set-up. */
 #define WM_BATCH_LDS_TARGET_POINTS 10000
 #define WM_BATCH_MAX_TARGET_POINTS 65535
 typedef struct {
