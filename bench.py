@@ -19,8 +19,8 @@
 Prints ONE JSON line on rank 0 (contract in the task statement), with extra objects:
 "roofline" (correspondence kernel vs the HBM roof), "cpu_baseline" (the CPU oracle timed on
 this box's host cores: 1 core, and the MultiMatcher pattern on all usable cores) and
-"other_configs" (BASELINE configs[2] GICP 500k, configs[3] NDT 2M and configs[0] 10k pairs in
-batches of 256) -- N == 1 only.
+"other_configs" (BASELINE configs[2] GICP 500k, configs[3] NDT 2M, configs[0] 10k pairs in
+batches of 256, and default-parameter matches of 55k pairs in batches of 128) -- N == 1 only.
 """
 import argparse
 import json
@@ -305,6 +305,33 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu):
         m.lumold(3.0)
         e["cpu_baseline"] = {"seconds_per_registration": time.perf_counter() - t0, "cores": 1, "kind": "port",
                              "sample": "the oracle's match() + estimateLUMold on one of the pairs"}
+    out.append(e)
+    del dev_clouds, dev_pairs
+
+    # ---- the reference's DEFAULT matcher parameters (voxel filter 0.1 m + three coarser scales,
+    # icp.hpp:54,59 -> icp.cpp:77-104) on scan-sized pairs, again a queue of them: all clouds of a call
+    # go through pcl::VoxelGrid at once (cloud number above the leaf index in one sort key), then one
+    # resident registration per pair and scale
+    n, B = 55_000, 128
+    base = [synth.pair(n, seed=200 + k, mode="resample")[:2] for k in range(4)]
+    host_pairs = [base[k % 4] for k in range(B)]
+    kw = dict(with_info=True, res=0.1, multiscale_steps=3, max_corr=3.0, max_iter=100)
+    ms_h, got = median_ms(lambda: ctx.icp_batch_match(host_pairs, **kw), reps=3)
+    ms_one, one = median_ms(lambda: ctx.icp_match(base[0][0], base[0][1], res=0.1, multiscale_steps=3, max_corr=3.0,
+                                                  max_iter=100, carry_state=0))
+    e = {"config": "ICPMatcher with its default parameters (res 0.1, multiscale_steps 3) on 55k<->55k pairs, %d queued pairs "
+                   "per call: match() + estimateInfo() each" % B,
+         "pairs_per_call": B, "registrations_per_s": B / (ms_h * 1e-3), "ms_per_batch": ms_h,
+         "all_converged": all(g["rc"] == 0 for g in got), "one_pair_at_a_time_ms": ms_one,
+         "finest_scale_points": got[0]["n_corr"],
+         "note": "host clouds (2 x 0.9 MB per pair cross PCIe inside the timed call), one worker thread"}
+    if with_cpu:
+        from oracle import oracle_py as O
+        t0 = time.perf_counter()
+        m = O.IcpMatch(base[0][0], base[0][1], res=0.1, multiscale_steps=3, incremental_float=0)
+        m.lumold(3.0)
+        e["cpu_baseline"] = {"seconds_per_registration": time.perf_counter() - t0, "cores": 1, "kind": "port",
+                             "sample": "the oracle's match() (4 scales) + estimateLUMold on one of the pairs"}
     out.append(e)
     ctx.close()
     prof.close()

@@ -88,8 +88,11 @@ class ICPMatcher : public Matcher<PCLPointCloudPtr> {
     // with it -- setRef, setTarget, match(), estimateInfo() -- but a whole registration runs inside one
     // compute unit of the GPU, 256 at a time (wm_icp_batch_match): with the target cloud in that unit's
     // LDS up to 10 000 points, in cache-resident HBM scratch beyond.
-    // Limits: a full-resolution matcher (params.res <= 0) on a single device, and targets of at most
-    // maxBatchTargetPoints() = 50 000 points -- batchable() says whether a pair qualifies.  Each pair starts
+    // Voxel-filtered matchers (params.res > 0, single- or multiscale) are batched too: all clouds of the
+    // batch go through pcl::VoxelGrid in one pass of device-wide kernels, scale by scale.
+    // Limits: a single device; full-resolution targets of at most maxBatchTargetPoints() = 50 000 points,
+    // raw clouds of at most 200 000 points when they are filtered first -- batchable() says whether a pair
+    // qualifies.  Each pair starts
     // with fresh stopping criteria (a matcher used pair by pair carries PCL's last MSE over into the
     // next align; which pair follows which in a MultiMatcher is a matter of thread timing anyway).
     // out[k] = {match() result, getResult(), getInfo()} as the worker loop would have read them after

@@ -5,7 +5,8 @@
 // own wm_ctx and HIP stream), so registrations of different workers overlap on the device.  For small
 // clouds that alone leaves the chip idle between tiny kernels (10k-point pairs: ~5 000
 // registrations/s however many workers), so a worker whose matcher can register many pairs in one
-// launch (ICPMatcher::matchBatch: full-resolution matchers, targets up to 50 000 points) takes
+// launch (ICPMatcher::matchBatch: full-resolution targets up to 50 000 points, voxel-filtered matchers
+// on scans up to 200 000) takes
 // EVERYTHING that is queued -- up to 256 pairs, one compute unit each -- per trip: 80 000
 // registrations/s with one worker, 110 000-145 000 with two to four at 10 000 points, 14 000-22 000 at
 // 30 000 (libwave_amd/host/bench_multimatcher, BENCH_QUEUE=2048).  Queue depth is what feeds it: construct the pool with a

@@ -154,22 +154,30 @@ int wm_icp_match(wm_ctx *ctx, const void *ref, size_t n_ref, const void *target,
                  size_t stride_bytes, int mem, const wm_icp_params *p, float res,
                  int multiscale_steps, double T_out[16], wm_icp_stats *stats);
 
-/* Many SMALL registrations in one launch -- the throughput path under wave::MultiMatcher
+/* Many registrations per launch -- the throughput path under wave::MultiMatcher
  * (wave_matching/include/wave/matching/multi_matcher.hpp:29-96; worker loop impl/
  * multi_matcher_impl.hpp:45-53: setRef, setTarget, match, estimateInfo per queued pair).  Every item
- * is ICPMatcher::match()'s full-resolution branch (icp.cpp:123-131: align on the clouds as given,
- * stopping criteria fresh) and, with with_info = 1, the estimator whose result estimateInfo() always
- * ends with (icp.cpp:135-142 -> estimateLUMold, icp_pcl_functions.cpp:51-179).  One workgroup per
- * item: a target of up to WM_BATCH_LDS_TARGET_POINTS points lives, cell-sorted, in its compute
- * unit's LDS for the whole registration; larger ones, up to WM_BATCH_MAX_TARGET_POINTS (16-bit slots
- * and indices), in HBM scratch that the L2 / Infinity Cache keep close (same code, ~3x slower per
- * point).  Beyond that: WM_ERR_ARG -- register such pairs one by one.
- * Results per item k: status[k] (what wm_icp_align would have returned), T_out + 16 k (written
- * when status[k] == WM_OK), info_out + 36 k (with_info; written whenever the item ran), stats[k].
- * T_out, info_out, stats may be NULL.  The call returns WM_OK when the batch ran.  In stats[k],
- * align_ms is the device time of the whole launch; nn_ms / stats_ms / solve_ms / coarse_ms carry a
- * developer aid instead of times: shader-clock kilocycles of the item's LAST iteration (query loop,
- * row sum, solve) and of its set-up. */
+ * is ICPMatcher::match() as wm_icp_match runs it (res, multiscale_steps: the three branches of
+ * icp.cpp:75-133), with stopping criteria that start fresh, and, with with_info = 1, the estimator
+ * whose result estimateInfo() always ends with (icp.cpp:135-142 -> estimateLUMold,
+ * icp_pcl_functions.cpp:51-179, on the clouds of the last align).  One workgroup per item runs a
+ * whole align: a target of up to WM_BATCH_LDS_TARGET_POINTS points lives, cell-sorted, in its compute
+ * unit's LDS; larger ones, up to WM_BATCH_MAX_TARGET_POINTS (16-bit slots and indices), in HBM scratch
+ * that the L2 / Infinity Cache keep close (same code, ~3x slower per point).
+ *   res <= 0: the clouds as given; a target beyond WM_BATCH_MAX_TARGET_POINTS is WM_ERR_ARG
+ *             (register such pairs one by one).
+ *   res > 0 : both clouds of every item go through pcl::VoxelGrid first -- all clouds of the batch in
+ *             one pass of device-wide kernels, the cloud number above the leaf index in one sort key --
+ *             per scale (leaf = 2^i res, i = multiscale_steps .. 0; icp.cpp:77-104) or once
+ *             (multiscale_steps == 0; icp.cpp:105-122); an item that fails at a scale stops there, as
+ *             match() does.  Items whose filtered target is still too large, or whose leaf lattice
+ *             overflows int32, are registered by wm_icp_match inside the call.
+ * Results per item k: status[k] (what wm_icp_match would have returned), T_out + 16 k (written
+ * when status[k] == WM_OK), info_out + 36 k (with_info; written whenever an align of the item ran),
+ * stats[k] (of the item's last align).  T_out, info_out, stats may be NULL.  The call returns WM_OK
+ * when the batch ran.  In stats[k], align_ms is the device time of the launches the item took part
+ * in; nn_ms / stats_ms / solve_ms / coarse_ms carry a developer aid instead of times: shader-clock
+ * kilocycles of the item's LAST iteration (query loop, row sum, solve) and of its set-up. */
 #define WM_BATCH_LDS_TARGET_POINTS 10000
 #define WM_BATCH_MAX_TARGET_POINTS 65535
 typedef struct {
@@ -179,8 +187,17 @@ typedef struct {
     size_t n_target;
 } wm_batch_item;
 int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, size_t stride_bytes,
-                       int mem, const wm_icp_params *p, int with_info, double *T_out,
-                       double *info_out, wm_icp_stats *stats, int *status);
+                       int mem, const wm_icp_params *p, float res, int multiscale_steps,
+                       int with_info, double *T_out, double *info_out, wm_icp_stats *stats,
+                       int *status);
+
+/* pcl::VoxelGrid<PointXYZ>::filter of MANY clouds in one pass (the filter stage of wm_icp_batch_match
+ * with res > 0, exposed): cloud 2 k = items[k].src, 2 k + 1 = items[k].target; their centroids, back
+ * to back in that order, as packed xyz floats in host memory out_xyz (capacity cap_points points),
+ * their counts in n_out[2 n_items].  Same results, bit for bit, as wm_voxel_downsample cloud by cloud
+ * (a leaf lattice beyond int32 is WM_ERR_ARG here). */
+int wm_voxel_downsample_batch(wm_ctx *ctx, const wm_batch_item *items, int n_items, size_t stride_bytes,
+                              int mem, float leaf, float *out_xyz, size_t cap_points, size_t *n_out);
 
 /* pcl::VoxelGrid<PointXYZ>::filter on device (icp.cpp:81-90,106-113; gicp.cpp:39-40,
  * 49-50): float centroid per occupied leaf, ascending leaf index; `out` must hold

@@ -111,8 +111,10 @@ def lib():
                                    C.c_size_t, C.c_int, C.POINTER(IcpParams), C.c_float, C.c_int,
                                    _dp, C.POINTER(IcpStats)]
         L.wm_icp_batch_match.argtypes = [C.c_void_p, C.POINTER(BatchItem), C.c_int, C.c_size_t, C.c_int,
-                                         C.POINTER(IcpParams), C.c_int, _dp, _dp, C.POINTER(IcpStats),
-                                         C.POINTER(C.c_int)]
+                                         C.POINTER(IcpParams), C.c_float, C.c_int, C.c_int, _dp, _dp,
+                                         C.POINTER(IcpStats), C.POINTER(C.c_int)]
+        L.wm_voxel_downsample_batch.argtypes = [C.c_void_p, C.POINTER(BatchItem), C.c_int, C.c_size_t, C.c_int,
+                                                C.c_float, _fp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.wm_voxel_downsample.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
                                           C.c_float, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t,
                                           C.POINTER(C.c_size_t)]
@@ -317,10 +319,10 @@ class Context:
         self.n_src, self.n_tgt = self.sizes()
         return self._stats_dict(rc, T, s)
 
-    def icp_batch_match(self, pairs, with_info=True, params=None, **kw):
-        """Many small full-resolution registrations (+ estimateLUMold) in one launch
-        (wm_icp_batch_match).  pairs: [(ref, target), ...]; -> list of dicts as icp_align's, plus
-        'info' (6x6) when with_info."""
+    def icp_batch_match(self, pairs, with_info=True, res=-1.0, multiscale_steps=0, params=None, **kw):
+        """Many registrations (+ estimateLUMold) per launch (wm_icp_batch_match): ICPMatcher::match()
+        of every pair, res / multiscale_steps as icp_match's.  pairs: [(ref, target), ...]; -> list of
+        dicts as icp_align's, plus 'info' (6x6) when with_info."""
         p = params or icp_params(**kw)
         n = len(pairs)
         items = (BatchItem * max(n, 1))()
@@ -338,6 +340,7 @@ class Context:
         stats = (IcpStats * max(n, 1))()
         status = (C.c_int * max(n, 1))()
         self._check(lib().wm_icp_batch_match(self._h, items, n, stride or 16, mem or WM_MEM_HOST, C.byref(p),
+                                             C.c_float(res), int(multiscale_steps),
                                              1 if with_info else 0, T.ctypes.data_as(_dp),
                                              info.ctypes.data_as(_dp), stats, status), "wm_icp_batch_match")
         out = []
@@ -347,6 +350,32 @@ class Context:
                 d["info"] = info[k].copy()
             out.append(d)
         return out
+
+    def voxel_downsample_batch(self, pairs, leaf):
+        """pcl::VoxelGrid of all clouds of `pairs` in one pass -> [(filtered ref, filtered target), ...]."""
+        n = len(pairs)
+        items = (BatchItem * max(n, 1))()
+        keep, stride, mem, cap = [], None, None, 0
+        for k, (ref, tgt) in enumerate(pairs):
+            pr, nr, sr, mr, k1 = _cloud_arg(ref)
+            pt, nt, stt, mt, k2 = _cloud_arg(tgt)
+            assert sr == stt and mr == mt and (stride in (None, sr)) and (mem in (None, mr))
+            stride, mem = sr, mr
+            keep += [k1, k2]
+            items[k].src, items[k].n_src, items[k].target, items[k].n_target = pr, nr, pt, nt
+            cap += nr + nt
+        out = np.empty((max(cap, 1), 3), np.float32)
+        counts = (C.c_size_t * max(2 * n, 1))()
+        self._check(lib().wm_voxel_downsample_batch(self._h, items, n, stride or 16, mem or WM_MEM_HOST, C.c_float(leaf),
+                                                    out.ctypes.data_as(_fp), cap, counts), "wm_voxel_downsample_batch")
+        res, w = [], 0
+        for k in range(n):
+            a = out[w:w + counts[2 * k]].copy()
+            w += counts[2 * k]
+            b = out[w:w + counts[2 * k + 1]].copy()
+            w += counts[2 * k + 1]
+            res.append((a, b))
+        return res
 
     def voxel_downsample(self, cloud, leaf):
         ptr, n, stride, mem, keep = _cloud_arg(cloud)

@@ -160,6 +160,7 @@ struct wm_ctx {
     wm::DevBuf staging, cell_of, counts, block_sums, bbox_buf;
     wm::DevBuf match_pt, match_pt_bak;  // float4 per (sorted) source point: its match's xyz
     void *small_batch = nullptr;            // wm_small.hip: staging of the batched small registrations
+    void *batch_voxel = nullptr;            // wm_batch.hip: buffers of the batched voxel filter
     wm::DevBuf phase_log;                   // developer: per-iteration phase cycle sums of the search kernel
     wm::DevBuf cost_log;                    // developer: per-query search cost of every iteration (wm_debug_cost_log)
     int cost_log_iter = 0, cost_log_cap = 0;
@@ -311,6 +312,29 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
                    int stats_mode = -1, unsigned *rows_out = nullptr);
 int launch_nn_brute(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1);
 void small_batch_release(wm_ctx *ctx);
+// ---- wm_small.hip / wm_batch.hip: whole registrations inside one workgroup, many per launch
+struct SmallJob {
+    const void *src;
+    size_t n_src;
+    const void *tgt;
+    size_t n_tgt;
+    double prev_mse0;
+};
+struct SmallResult {
+    double T[16];
+    double info[36];
+    double mse, prev_mse;
+    int iterations, converged, state, n_corr, info_degenerate;
+    float cell;
+    unsigned long long cyc[4];
+};
+int small_run(wm_ctx *ctx, const SmallJob *jobs, int n, size_t stride, int mem, const wm_icp_params *p, int with_info,
+              double info_max_corr, SmallResult *res, float *kernel_ms);
+void small_fill_stats(const SmallResult &r, float kernel_ms, wm_icp_stats *s);
+void batch_voxel_release(wm_ctx *ctx);
+int batch_match_scaled(wm_ctx *ctx, const wm_batch_item *items, int n_items, size_t stride, int mem,
+                       const wm_icp_params *p, float res, int multiscale_steps, int with_info, double *T_out,
+                       double *info_out, wm_icp_stats *stats, int *status);
 float threshold_d2(double max_corr);
 float threshold_d2_strict(double max_corr);
 

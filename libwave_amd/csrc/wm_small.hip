@@ -59,6 +59,7 @@ static_assert(kSmCells % kSmThreads == 0 && kSmCellsHbm % kSmThreads == 0, "layo
 struct SmallPair {  // one registration of the batch (device table)
     const unsigned char *src, *tgt;  // caller-layout points in device memory
     unsigned n_src, n_tgt;
+    double prev_mse0;      // the stopping criteria's previous MSE this registration starts with (DBL_MAX: none)
     unsigned short *seed;  // n_src entries: LDS slot of each source point's last match (0xFFFF none)
     double *csum;          // ceil(n_src / 64) rows of kAcc doubles of scratch: every 64-query chunk's sums
     // HBM variant only: the cell-sorted target (x, y, z per point + 4 sentinels; caller's index of each; first slot of
@@ -366,6 +367,7 @@ __global__ void __launch_bounds__(kSmThreads)
 
     if (tid == 0) {
         L.st = st0;
+        L.st.prev_mse = pr.prev_mse0;
         L.ticket = kSmWaves;
     }
 
@@ -863,64 +865,47 @@ static int pinned_reserve(wm_ctx *ctx, void **p, size_t *cap, size_t bytes) {
 
 }  // namespace wm
 
-using namespace wm;
+namespace wm {
 
-extern "C" {
-
-int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, size_t stride, int mem,
-                       const wm_icp_params *p, int with_info, double *T_out, double *info_out,
-                       wm_icp_stats *stats, int *status) {
-    if (!ctx || !p || !status || n_items < 0 || (n_items > 0 && !items) || stride < 12 || (stride & 3)) return WM_ERR_ARG;
-    if (!(p->max_corr > 0) || (p->mode != WM_ICP_SVD && p->mode != WM_ICP_GN6)) return WM_ERR_ARG;
-    if (p->force_iterations <= 0 && p->max_iter <= 0) return WM_ERR_ARG;
-    if (with_info != 0 && with_info != 1) return WM_ERR_ARG;
-    if (n_items == 0) return WM_OK;
+// The resident registrations of `n` jobs (none empty) in one or two launches: LDS-resident targets,
+// then HBM-resident ones.  Clouds in caller memory (host: staged through pinned memory in 2 MB slices,
+// each slice's DMA under the next copy; device: read in place).  res[k] = what the kernel left.
+int small_run(wm_ctx *ctx, const SmallJob *jobs, int n, size_t stride, int mem, const wm_icp_params *p, int with_info,
+              double info_max_corr, SmallResult *res, float *kernel_ms) {
+    if (n <= 0) return WM_OK;
     size_t cloud_bytes = 0, seeds = 0, sorted_pts = 0, chunk_rows = 0, big_bytes = 0;
-    int live = 0, n_lds = 0, n_hbm = 0;
+    int n_lds = 0, n_hbm = 0;
     auto big_need = [](size_t n_target) {  // scratch of one HBM-resident target, 16-byte aligned pieces
         const size_t a = ((n_target + 4) * 12 + 15) & ~(size_t) 15, b = ((n_target + 4) * 2 + 15) & ~(size_t) 15;
         const size_t c = ((size_t) kSmCellsHbm + 8) * 4, e = (n_target * 4 + 15) & ~(size_t) 15;
         return a + b + c + e;
     };
-    for (int k = 0; k < n_items; ++k) {
-        const wm_batch_item &it = items[k];
-        if ((it.n_src > 0 && !it.src) || (it.n_target > 0 && !it.target)) return WM_ERR_ARG;
-        if (it.n_target > (size_t) kSmMaxTgtHbm || it.n_src > 0x7FFFFFF0u) return WM_ERR_ARG;
-        if (it.n_src == 0 || it.n_target == 0) continue;  // (answered on the host, below)
-        cloud_bytes += ((it.n_src * stride + 15) & ~(size_t) 15) + ((it.n_target * stride + 15) & ~(size_t) 15);
+    for (int k = 0; k < n; ++k) {
+        const SmallJob &it = jobs[k];
+        if (it.n_src == 0 || it.n_tgt == 0 || it.n_tgt > (size_t) kSmMaxTgtHbm || it.n_src > 0x7FFFFFF0u) return WM_ERR_ARG;
+        cloud_bytes += ((it.n_src * stride + 15) & ~(size_t) 15) + ((it.n_tgt * stride + 15) & ~(size_t) 15);
         seeds += (it.n_src + 7) & ~(size_t) 7;
         sorted_pts += it.n_src;
         chunk_rows += (it.n_src + 63) / 64;
-        if (it.n_target > (size_t) kSmMaxTgt) {
-            big_bytes += big_need(it.n_target);
+        if (it.n_tgt > (size_t) kSmMaxTgt) {
+            big_bytes += big_need(it.n_tgt);
             ++n_hbm;
         } else {
             ++n_lds;
         }
-        ++live;
     }
-    WM_HIP(ctx, hipSetDevice(ctx->device));
     SmallBatch *B = small_of(ctx);
     if (!B) return WM_ERR_NOMEM;
-    if (stats) memset(stats, 0, sizeof(*stats) * (size_t) n_items);
-    for (int k = 0; k < n_items; ++k) {
-        // PCL: an empty input cloud -> "Not enough correspondences"; match() returns false
-        const wm_batch_item &it = items[k];
-        status[k] = (it.n_src == 0 || it.n_target == 0) ? (it.n_src == 0 && it.n_target == 0 ? WM_ERR_STATE : WM_TOO_FEW_CORRESPONDENCES) : WM_OK;
-        if (status[k] != WM_OK && stats) stats[k].state = WM_CONV_NO_CORRESPONDENCES;
-    }
-    if (live == 0) return WM_OK;
-
-    const size_t table_bytes = ((size_t) live * sizeof(SmallPair) + 255) & ~(size_t) 255;
+    const size_t table_bytes = ((size_t) n * sizeof(SmallPair) + 255) & ~(size_t) 255;
     const size_t up_bytes = table_bytes + (mem == WM_MEM_HOST ? cloud_bytes : 0);
     const size_t seed_bytes = (seeds * sizeof(unsigned short) + 15) & ~(size_t) 15;
     const size_t dev_bytes = table_bytes + (mem == WM_MEM_HOST ? cloud_bytes : 0) + seed_bytes + sorted_pts * sizeof(float4) +
                              chunk_rows * kAcc * sizeof(double);
     WM_HIP(ctx, B->d_stage.reserve(dev_bytes));
-    WM_HIP(ctx, B->d_out.reserve((size_t) live * sizeof(SmallOut)));
+    WM_HIP(ctx, B->d_out.reserve((size_t) n * sizeof(SmallOut)));
     if (big_bytes) WM_HIP(ctx, B->d_big.reserve(big_bytes));
     WM_TRY(pinned_reserve(ctx, &B->h_stage, &B->h_stage_cap, up_bytes));
-    WM_TRY(pinned_reserve(ctx, &B->h_out, &B->h_out_cap, (size_t) live * sizeof(SmallOut)));
+    WM_TRY(pinned_reserve(ctx, &B->h_out, &B->h_out_cap, (size_t) n * sizeof(SmallOut)));
     // the stream may still be reading the staging buffer for the previous batch
     WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
@@ -932,34 +917,32 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
     float4 *sorted_base = reinterpret_cast<float4 *>(reinterpret_cast<unsigned char *>(seed_base) + seed_bytes);
     double *csum_base = reinterpret_cast<double *>(sorted_base + sorted_pts);
     size_t seed_off = 0, sorted_off = 0, csum_off = 0, big_off = 0;
-    // rows of the table: the LDS-resident items first, then the HBM-resident ones (a launch each)
-    std::vector<int> row_of((size_t) n_items, -1);
+    // rows of the table: the LDS-resident jobs first, then the HBM-resident ones (a launch each)
+    std::vector<int> row_of((size_t) n, -1);
     int next_lds = 0, next_hbm = n_lds;
-    // host clouds: copied into the pinned mirror and sent in slices of ~2 MB, so that the DMA of one
-    // slice runs while the next is being copied (the table goes last, once it is complete)
     size_t sent = table_bytes;
-    for (int k = 0; k < n_items; ++k) {
-        const wm_batch_item &it = items[k];
-        if (status[k] != WM_OK) continue;
-        const bool big = it.n_target > (size_t) kSmMaxTgt;
+    for (int k = 0; k < n; ++k) {
+        const SmallJob &it = jobs[k];
+        const bool big = it.n_tgt > (size_t) kSmMaxTgt;
         row_of[(size_t) k] = big ? next_hbm++ : next_lds++;
         SmallPair &t = table[row_of[(size_t) k]];
         t.n_src = (unsigned) it.n_src;
-        t.n_tgt = (unsigned) it.n_target;
+        t.n_tgt = (unsigned) it.n_tgt;
+        t.prev_mse0 = it.prev_mse0;
         if (mem == WM_MEM_HOST) {
             memcpy(h + off, it.src, it.n_src * stride);
             t.src = d + off;
             off += (it.n_src * stride + 15) & ~(size_t) 15;
-            memcpy(h + off, it.target, it.n_target * stride);
+            memcpy(h + off, it.tgt, it.n_tgt * stride);
             t.tgt = d + off;
-            off += (it.n_target * stride + 15) & ~(size_t) 15;
+            off += (it.n_tgt * stride + 15) & ~(size_t) 15;
             if (off - sent >= ((size_t) 2 << 20)) {
                 WM_HIP(ctx, hipMemcpyAsync(d + sent, h + sent, off - sent, hipMemcpyHostToDevice, ctx->stream));
                 sent = off;
             }
         } else {
             t.src = static_cast<const unsigned char *>(it.src);
-            t.tgt = static_cast<const unsigned char *>(it.target);
+            t.tgt = static_cast<const unsigned char *>(it.tgt);
         }
         t.seed = seed_base + seed_off;
         seed_off += (it.n_src + 7) & ~(size_t) 7;
@@ -971,13 +954,13 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
         if (big) {
             unsigned char *b = B->d_big.as<unsigned char>() + big_off;
             t.txyz = reinterpret_cast<float *>(b);
-            b += ((it.n_target + 4) * 12 + 15) & ~(size_t) 15;
+            b += ((it.n_tgt + 4) * 12 + 15) & ~(size_t) 15;
             t.tidx = reinterpret_cast<unsigned short *>(b);
-            b += ((it.n_target + 4) * 2 + 15) & ~(size_t) 15;
+            b += ((it.n_tgt + 4) * 2 + 15) & ~(size_t) 15;
             t.tcs = reinterpret_cast<unsigned *>(b);
             b += ((size_t) kSmCellsHbm + 8) * 4;
             t.trank = reinterpret_cast<unsigned *>(b);
-            big_off += big_need(it.n_target);
+            big_off += big_need(it.n_tgt);
         }
     }
     if (off > sent) WM_HIP(ctx, hipMemcpyAsync(d + sent, h + sent, off - sent, hipMemcpyHostToDevice, ctx->stream));
@@ -990,7 +973,7 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
     for (int k = 0; k < 16; ++k) st0.T[k] = I[k];
     for (int k = 0; k < 12; ++k) st0.Tf[k] = (float) I[k];
     mat4_identity(st0.Tk);
-    st0.prev_mse = DBL_MAX;  // every pair starts with fresh stopping criteria
+    st0.prev_mse = DBL_MAX;  // (replaced per job by its prev_mse0)
     st0.forced = p->force_iterations > 0;
     st0.max_iter = st0.forced ? p->force_iterations : p->max_iter;
     st0.mode = p->mode;
@@ -1002,7 +985,8 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
     memset(&P, 0, sizeof(P));
     P.stride = (unsigned) stride;
     P.thr_d2 = threshold_d2(p->max_corr);
-    P.thr_d2_strict = threshold_d2_strict(p->max_corr);
+    // (estimateLUMold gates with the matcher's max_corr, whatever the scale of the last align: icp_pcl_functions.cpp:76-80)
+    P.thr_d2_strict = threshold_d2_strict(info_max_corr > 0 ? info_max_corr : p->max_corr);
     P.r0_cells = 0.5f;
     P.with_info = with_info;
     P.iter_cap = st0.max_iter + 1;
@@ -1015,30 +999,92 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
                            reinterpret_cast<const SmallPair *>(d) + n_lds, P, st0, B->d_out.as<SmallOut>() + n_lds);
     WM_HIP(ctx, hipGetLastError());
     WM_HIP(ctx, hipEventRecord(ctx->ev_b, ctx->stream));
-    WM_HIP(ctx, hipMemcpyAsync(B->h_out, B->d_out.p, (size_t) live * sizeof(SmallOut), hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(ctx, hipMemcpyAsync(B->h_out, B->d_out.p, (size_t) n * sizeof(SmallOut), hipMemcpyDeviceToHost, ctx->stream));
     WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     float ms = 0;
     (void) hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b);
-
+    if (kernel_ms) *kernel_ms = ms;
     const SmallOut *o = static_cast<const SmallOut *>(B->h_out);
-    for (int k = 0; k < n_items; ++k) {
-        if (status[k] != WM_OK) continue;
+    for (int k = 0; k < n; ++k) {
         const SmallOut &r = o[row_of[(size_t) k]];
-        if (stats) {
-            wm_icp_stats &s = stats[k];
-            s.converged = r.converged;
-            s.iterations = r.iterations;
-            s.state = r.state;
-            s.n_corr = r.n_corr;
-            s.mse = r.mse;
-            s.prev_mse = r.prev_mse;
-            s.align_ms = ms;  // (the whole batch's launch)
-            s.nn_levels = 1;
-            s.grid_cell = r.cell;
-            // (developer: kilocycles of the last iteration's query loop / reduction / solve; set-up in coarse_ms)
-            s.nn_ms = (float) r.cyc[0] * 1e-3f, s.stats_ms = (float) r.cyc[1] * 1e-3f, s.solve_ms = (float) r.cyc[2] * 1e-3f;
-            s.coarse_ms = (float) r.cyc[3] * 1e-3f;
+        SmallResult &q = res[k];
+        memcpy(q.T, r.T, sizeof(q.T));
+        memcpy(q.info, r.info, sizeof(q.info));
+        q.mse = r.mse;
+        q.prev_mse = r.prev_mse;
+        q.iterations = r.iterations;
+        q.converged = r.converged;
+        q.state = r.state;
+        q.n_corr = r.n_corr;
+        q.info_degenerate = r.info_degenerate;
+        q.cell = r.cell;
+        for (int c = 0; c < 4; ++c) q.cyc[c] = r.cyc[c];
+    }
+    return WM_OK;
+}
+
+// what wm_icp_align reports for a finished job
+void small_fill_stats(const SmallResult &r, float kernel_ms, wm_icp_stats *s) {
+    s->converged = r.converged;
+    s->iterations = r.iterations;
+    s->state = r.state;
+    s->n_corr = r.n_corr;
+    s->mse = r.mse;
+    s->prev_mse = r.prev_mse;
+    s->align_ms = kernel_ms;  // (the whole batch's launch)
+    s->nn_levels = 1;
+    s->grid_cell = r.cell;
+    // (developer: kilocycles of the last iteration's query loop / reduction / solve; set-up in coarse_ms)
+    s->nn_ms = (float) r.cyc[0] * 1e-3f, s->stats_ms = (float) r.cyc[1] * 1e-3f, s->solve_ms = (float) r.cyc[2] * 1e-3f;
+    s->coarse_ms = (float) r.cyc[3] * 1e-3f;
+}
+
+}  // namespace wm
+
+using namespace wm;
+
+extern "C" {
+
+int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, size_t stride, int mem,
+                       const wm_icp_params *p, float res, int multiscale_steps, int with_info, double *T_out,
+                       double *info_out, wm_icp_stats *stats, int *status) {
+    if (!ctx || !p || !status || n_items < 0 || (n_items > 0 && !items) || stride < 12 || (stride & 3)) return WM_ERR_ARG;
+    if (!(p->max_corr > 0) || (p->mode != WM_ICP_SVD && p->mode != WM_ICP_GN6)) return WM_ERR_ARG;
+    if (p->force_iterations <= 0 && p->max_iter <= 0) return WM_ERR_ARG;
+    if (with_info != 0 && with_info != 1) return WM_ERR_ARG;
+    if (n_items == 0) return WM_OK;
+    for (int k = 0; k < n_items; ++k) {
+        const wm_batch_item &it = items[k];
+        if ((it.n_src > 0 && !it.src) || (it.n_target > 0 && !it.target) || it.n_src > 0x7FFFFFF0u || it.n_target > 0x7FFFFFF0u)
+            return WM_ERR_ARG;
+        if (!(res > 0) && it.n_target > (size_t) kSmMaxTgtHbm) return WM_ERR_ARG;
+    }
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    if (stats) memset(stats, 0, sizeof(*stats) * (size_t) n_items);
+    if (res > 0)  // the voxel-filtered branches of match(): wm_batch.hip
+        return batch_match_scaled(ctx, items, n_items, stride, mem, p, res, multiscale_steps, with_info, T_out, info_out,
+                                  stats, status);
+    std::vector<SmallJob> jobs;
+    std::vector<int> item_of;
+    for (int k = 0; k < n_items; ++k) {
+        // PCL: an empty input cloud -> "Not enough correspondences"; match() returns false
+        const wm_batch_item &it = items[k];
+        status[k] = (it.n_src == 0 || it.n_target == 0) ? (it.n_src == 0 && it.n_target == 0 ? WM_ERR_STATE : WM_TOO_FEW_CORRESPONDENCES) : WM_OK;
+        if (status[k] != WM_OK) {
+            if (stats) stats[k].state = WM_CONV_NO_CORRESPONDENCES;
+            continue;
         }
+        jobs.push_back(SmallJob{it.src, it.n_src, it.target, it.n_target, DBL_MAX});  // fresh stopping criteria
+        item_of.push_back(k);
+    }
+    if (jobs.empty()) return WM_OK;
+    std::vector<SmallResult> got(jobs.size());
+    float ms = 0;
+    WM_TRY(small_run(ctx, jobs.data(), (int) jobs.size(), stride, mem, p, with_info, p->max_corr, got.data(), &ms));
+    for (size_t j = 0; j < jobs.size(); ++j) {
+        const int k = item_of[j];
+        const SmallResult &r = got[j];
+        if (stats) small_fill_stats(r, ms, &stats[k]);
         if (r.state == WM_CONV_NO_CORRESPONDENCES)
             status[k] = WM_TOO_FEW_CORRESPONDENCES;
         else if (!r.converged)

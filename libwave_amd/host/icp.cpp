@@ -138,7 +138,12 @@ void warnIfDegenerate(int degenerate) {
 size_t ICPMatcher::maxBatchTargetPoints() { return 50000; }
 
 bool ICPMatcher::batchable(const PCLPointCloudPtr &r, const PCLPointCloudPtr &t) const {
-    return !(params.res > 0) && devices.size() <= 1 && r && t && cloudSize(t) <= maxBatchTargetPoints();
+    if (devices.size() > 1 || !r || !t) return false;
+    // voxel-filtered matchers: what counts is the size AFTER the filter, which the batch finds out on the
+    // device (pairs that stay too large are registered one by one inside wm_icp_batch_match); raw scans
+    // of up to 200 000 points are taken
+    if (params.res > 0) return cloudSize(r) <= 200000 && cloudSize(t) <= 200000;
+    return cloudSize(t) <= maxBatchTargetPoints();
 }
 
 bool ICPMatcher::matchBatch(const std::vector<std::pair<PCLPointCloudPtr, PCLPointCloudPtr>> &pairs,
@@ -166,8 +171,8 @@ bool ICPMatcher::matchBatch(const std::vector<std::pair<PCLPointCloudPtr, PCLPoi
     std::vector<int> status(n, WM_ERR_STATE);
     // estimateInfo(): whatever estimator is configured, the switch without `break` (icp.cpp:136-141)
     // ends in estimateLUMold, whose result is the one that stays in `information`
-    const int rc = wm_icp_batch_match(ctx, items.data(), (int) n, kCloudStride, WM_MEM_HOST, &p, 1, T.data(),
-                                      info.data(), nullptr, status.data());
+    const int rc = wm_icp_batch_match(ctx, items.data(), (int) n, kCloudStride, WM_MEM_HOST, &p, params.res,
+                                      params.multiscale_steps, 1, T.data(), info.data(), nullptr, status.data());
     if (!shim::succeeded(rc, "wm_icp_batch_match", ctx)) return false;
     out.resize(n);
     for (size_t k = 0; k < n; ++k) {

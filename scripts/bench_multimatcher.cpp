@@ -6,7 +6,8 @@
 //
 //   bench_multimatcher <points per cloud> <pairs> <workers> [<workers> ...]
 // prints one JSON line per worker count.  Built by libwave_amd/host/Makefile.
-// Environment: BENCH_QUEUE = capacity of the job queue (default 2 x workers, as small as the
+// Environment: BENCH_RES, BENCH_MULTISCALE = ICPMatcherParams::res / multiscale_steps (default -1 / 0);
+// BENCH_QUEUE = capacity of the job queue (default 2 x workers, as small as the
 // reference's default of 10 suggests; a worker takes everything that is queued -- up to 256 pairs --
 // into one device launch when the clouds fit the batched path, so deep queues are what fill the GPU).
 #include <algorithm>
@@ -63,6 +64,9 @@ int main(int argc, char **argv) {
     wave::ICPMatcherParams params;
     params.res = -1;  // full resolution: the clouds go to the device as they are
     params.multiscale_steps = 0;
+    // (BENCH_RES / BENCH_MULTISCALE: the reference's voxel-filtered branches, e.g. its defaults 0.1 / 3)
+    if (const char *e = std::getenv("BENCH_RES")) params.res = (float) std::atof(e);
+    if (const char *e = std::getenv("BENCH_MULTISCALE")) params.multiscale_steps = std::atoi(e);
     std::vector<wave::PCLPointCloudPtr> refs, targets;
     for (int k = 0; k < 4; ++k) {  // four distinct pairs, reused round-robin
         refs.push_back(scene(n, 100u + (unsigned) k, 0.f));

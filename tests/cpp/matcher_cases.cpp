@@ -385,9 +385,42 @@ AddCase c_batch_direct("ICPTest.matchBatchEqualsOneByOne", [] {
             EXPECT(distanceTo(last, got[k].transform) == 0.0);  // `result` is left alone (icp.cpp:132)
         }
     }
-    wave::ICPMatcherParams filtered;
-    filtered.res = 0.1f;
-    EXPECT(!wave::ICPMatcher(filtered).batchable(pairs[0].first, pairs[0].second));
+});
+
+// ... and with the reference's DEFAULT parameters (voxel filter 0.1 m, three coarser scales) and its
+// test configuration (single scale): the whole batch goes through pcl::VoxelGrid at once, scale by scale
+AddCase c_batch_filtered("ICPTest.matchBatchWithVoxelFilterEqualsOneByOne", [] {
+    const auto scan = loadScan();
+    std::vector<std::pair<wave::PCLPointCloudPtr, wave::PCLPointCloudPtr>> pairs;
+    pairs.emplace_back(scan, subsample(scan, 1, 0.2f));
+    pairs.emplace_back(subsample(scan, 3, 0.f), subsample(scan, 2, 0.1f));
+    pairs.emplace_back(scan, subsample(scan, 1, 600.f));  // fails at the coarsest scale
+    pairs.emplace_back(subsample(scan, 2, 0.f), scan);
+    for (int variant = 0; variant < 2; ++variant) {
+        wave::ICPMatcherParams p;  // defaults: res 0.1, multiscale_steps 3
+        if (variant == 1) p = singleScale();
+        wave::ICPMatcher batch(p);
+        for (const auto &pr : pairs) EXPECT(batch.batchable(pr.first, pr.second));
+        wave::ICPMatcher::BatchOutcomes got;
+        EXPECT(batch.matchBatch(pairs, got));
+        EXPECT(got.size() == pairs.size());
+        wave::Affine3 last = wave::Affine3::Identity();
+        for (size_t k = 0; k < pairs.size() && k < got.size(); ++k) {
+            wave::ICPMatcher one(p);
+            one.setup(pairs[k].first, pairs[k].second);
+            const bool ok = one.match();
+            one.estimateInfo();
+            EXPECT(ok == got[k].matched);
+            EXPECT(ok == (k != 2));
+            if (ok) {
+                EXPECT(distanceTo(one.getResult(), got[k].transform) < 1e-7);
+                EXPECT((one.getInfo() - got[k].info).norm() <= 1e-4 * one.getInfo().norm());
+                last = got[k].transform;
+            } else {
+                EXPECT(distanceTo(last, got[k].transform) == 0.0);
+            }
+        }
+    }
 });
 
 AddCase c_multi_batch("MultiTest.queuedPairsShareOneLaunch", [] {

@@ -148,3 +148,66 @@ def test_batch_of_many_fills_the_device(wm, ctx, oracle):
         want = oracle.icp_align(ref, tgt, max_corr=3.0, max_iter=100, incremental_float=0)
         dt, ang = pose_error(got[k]["T"], want["T"])
         assert dt <= 1e-7 and ang <= 1e-8
+
+
+# ---------------------------------------------------------------- the voxel-filtered branches, batched
+def _scan_pairs(oracle, testscan):
+    shift = np.eye(4)
+    shift[0, 3] = 0.2
+    rng = np.random.default_rng(5)
+    jit = (oracle.transform_cloud_d(testscan, shift) + rng.uniform(-0.3, 0.3, testscan.shape)).astype(np.float32)
+    a = synth.pair(30000, seed=41, mode="resample")
+    b = synth.pair(9000, seed=42, mode="resample")
+    holes = a[0].copy()
+    holes[::13, 2] = np.inf
+    return [(testscan, oracle.transform_cloud_d(testscan, shift)), (a[0], a[1]), (testscan, jit), (b[0], b[1]), (holes, a[1]),
+            (testscan, testscan)]
+
+
+@pytest.mark.parametrize("leaf", [0.1, 0.4, 1.6])
+def test_voxel_grid_of_a_whole_batch_is_bit_exact(wm, ctx, oracle, testscan, leaf):
+    """pcl::VoxelGrid of twelve clouds in one pass (one sort key = cloud number above leaf index) against
+    the one-cloud device path, which the oracle pins bit for bit (tests/test_match_gpu.py)."""
+    pairs = _scan_pairs(oracle, testscan)
+    got = ctx.voxel_downsample_batch(pairs, leaf)
+    for (ref, tgt), (fr, ft) in zip(pairs, got):
+        assert np.array_equal(fr, ctx.voxel_downsample(ref, leaf))
+        assert np.array_equal(ft, ctx.voxel_downsample(tgt, leaf))
+    assert np.array_equal(got[0][0], oracle.voxel_grid(testscan, leaf))
+
+
+@pytest.mark.parametrize("res,steps", [(0.1, 0), (0.1, 3), (0.05, 1)])
+def test_batched_filtered_matches_equal_one_by_one(wm, ctx, oracle, testscan, res, steps):
+    """ICPMatcher::match() with a voxel filter (single scale icp.cpp:105-122, multiscale :77-104) +
+    estimateInfo, six pairs per call: every item as wm_icp_match + wm_icp_info give it, and as the oracle does."""
+    pairs = _scan_pairs(oracle, testscan)
+    got = ctx.icp_batch_match(pairs, with_info=True, res=res, multiscale_steps=steps, max_corr=3.0, max_iter=100)
+    for k, ((ref, tgt), g) in enumerate(zip(pairs, got)):
+        one = ctx.icp_match(ref, tgt, res=res, multiscale_steps=steps, max_corr=3.0, max_iter=100, carry_state=0)
+        assert g["rc"] == one["rc"] == 0, (k, g["rc"], one["rc"])
+        assert (g["iterations"], g["state"], g["n_corr"]) == (one["iterations"], one["state"], one["n_corr"]), k
+        dt, ang = pose_error(g["T"], one["T"])
+        assert dt <= 1e-7 and ang <= 1e-8, (k, dt, ang)
+        rc, lumold, _ = ctx.icp_info(wm.WM_INFO_LUMOLD, max_corr=3.0)
+        if np.isfinite(lumold).all() and np.abs(lumold).max() < 1e15:      # (pair 5 is an exact copy: s^2 = 0)
+            np.testing.assert_allclose(g["info"], lumold, rtol=1e-4, atol=1e-8 * np.abs(lumold).max())
+    for k in (0, 2):
+        ref, tgt = pairs[k]
+        want = oracle.IcpMatch(ref, tgt, res=res, multiscale_steps=steps, incremental_float=0)
+        assert want.ok and got[k]["iterations"] == want.r.iterations and got[k]["n_corr"] == want.r.n_corr
+        dt, ang = pose_error(got[k]["T"], want.T)
+        assert dt <= 1e-6 and ang <= 1e-7, (dt, ang)
+        olumold, _ = want.lumold(3.0)
+        np.testing.assert_allclose(got[k]["info"], olumold, rtol=2e-4, atol=1e-6 * np.abs(olumold).max())
+
+
+def test_batched_filtered_match_fails_fast_like_match(wm, ctx, oracle, testscan):
+    """A pair with nothing within max_corr stops at the first scale (icp.cpp:96-98); the others go on."""
+    far = (testscan + np.array([800.0, 0, 0], np.float32)).astype(np.float32)
+    empty = np.zeros((0, 3), np.float32)
+    pairs = [(testscan, far), (testscan, testscan), (empty, testscan), (testscan, empty)]
+    got = ctx.icp_batch_match(pairs, with_info=True, res=0.1, multiscale_steps=3, max_corr=3.0, max_iter=100)
+    one = ctx.icp_match(testscan, far, res=0.1, multiscale_steps=3, max_corr=3.0, max_iter=100, carry_state=0)
+    assert got[0]["rc"] == one["rc"] == wm.WM_TOO_FEW and got[0]["T"] is None
+    assert got[1]["rc"] == 0 and np.linalg.norm(got[1]["T"] - np.eye(4)) < 1e-6
+    assert got[2]["rc"] == wm.WM_TOO_FEW and got[3]["rc"] == wm.WM_TOO_FEW
