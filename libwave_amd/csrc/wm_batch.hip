@@ -513,7 +513,7 @@ static int scaled_sub_batch(wm_ctx *ctx, const wm_batch_item *items, const std::
                 ps[j].alive = false;
                 continue;
             }
-            jobs.push_back(SmallJob{filtered + cl[2 * j].off, nr, filtered + cl[2 * j + 1].off, nt, ps[j].prev_mse});
+            jobs.push_back(SmallJob{filtered + cl[2 * j].off, nr, filtered + cl[2 * j + 1].off, nt, ps[j].prev_mse, 1});
             job_pair.push_back(j);
         }
         if (jobs.empty()) continue;

@@ -319,6 +319,7 @@ struct SmallJob {
     const void *tgt;
     size_t n_tgt;
     double prev_mse0;
+    int presorted;  // the source is already in a spatial order (skips the in-kernel sort)
 };
 struct SmallResult {
     double T[16];

@@ -60,6 +60,8 @@ struct SmallPair {  // one registration of the batch (device table)
     const unsigned char *src, *tgt;  // caller-layout points in device memory
     unsigned n_src, n_tgt;
     double prev_mse0;      // the stopping criteria's previous MSE this registration starts with (DBL_MAX: none)
+    unsigned presorted;    // the source is in a spatial order already (a voxel filter's output: leaf order)
+    unsigned pad0;
     unsigned short *seed;  // n_src entries: LDS slot of each source point's last match (0xFFFF none)
     double *csum;          // ceil(n_src / 64) rows of kAcc doubles of scratch: every 64-query chunk's sums
     // HBM variant only: the cell-sorted target (x, y, z per point + 4 sentinels; caller's index of each; first slot of
@@ -236,20 +238,26 @@ __device__ __forceinline__ bool sm_load_point(const unsigned char *base, unsigne
     return isfinite(x) && isfinite(y) && isfinite(z);  // (non-finite points are dropped, as k_pack does)
 }
 
-// Bounding box of a cloud's finite points and the finest grid of cubic cells over it that has at most
-// `max_cells` cells; every lane returns the same grid.  (Any cell size gives exact searches; this
-// choice is quick.)  `count` = number of finite points.
+// The grid of a cloud: the finest cubic cells, at most `max_cells` of them, over the CORE of its finite
+// points -- their bounding box cut back to mean +- 2.5 standard deviations per axis.  Points outside
+// land in the border cells (cell coordinates are clamped, for points and for search boxes alike, so
+// any box gives exact searches); what the cut buys is cell size: a lidar scan has a few returns at
+// 100 m and most of its points within 20 m, and cells sized for the full box hold hundreds of points
+// where the points are.  Every lane returns the same grid; `count` = number of finite points.
 template <class LDS>
 __device__ __forceinline__ SmGrid sm_fit_grid(LDS &L, const unsigned char *pts, unsigned n, unsigned stride,
                                               int max_cells, unsigned tid, unsigned &count) {
     const unsigned lane = tid & 63u, wave = tid >> 6;
     float lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY;
+    double m1[3] = {0.0, 0.0, 0.0}, m2[3] = {0.0, 0.0, 0.0};
     unsigned cnt = 0;
     for (unsigned i = tid; i < n; i += kSmThreads) {
         float x, y, z;
         if (sm_load_point(pts, i, stride, x, y, z)) {
             lo0 = fminf(lo0, x), lo1 = fminf(lo1, y), lo2 = fminf(lo2, z);
             hi0 = fmaxf(hi0, x), hi1 = fmaxf(hi1, y), hi2 = fmaxf(hi2, z);
+            m1[0] += x, m1[1] += y, m1[2] += z;
+            m2[0] += (double) x * x, m2[1] += (double) y * y, m2[2] += (double) z * z;
             ++cnt;
         }
     }
@@ -259,12 +267,19 @@ __device__ __forceinline__ SmGrid sm_fit_grid(LDS &L, const unsigned char *pts, 
         lo2 = fminf(lo2, __shfl_xor(lo2, off)), hi0 = fmaxf(hi0, __shfl_xor(hi0, off));
         hi1 = fmaxf(hi1, __shfl_xor(hi1, off)), hi2 = fmaxf(hi2, __shfl_xor(hi2, off));
         cnt += __shfl_xor(cnt, off);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            m1[k] += __shfl_xor(m1[k], off);
+            m2[k] += __shfl_xor(m2[k], off);
+        }
     }
     __syncthreads();  // (the scratch may still be read from the previous call)
     if (lane == 0) {
         L.boxf[wave][0] = lo0, L.boxf[wave][1] = lo1, L.boxf[wave][2] = lo2;
         L.boxf[wave][3] = hi0, L.boxf[wave][4] = hi1, L.boxf[wave][5] = hi2;
         L.wsum[wave] = cnt;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) L.red[wave][k] = m1[k], L.red[wave][3 + k] = m2[k];
     }
     __syncthreads();
     if (tid == 0) {
@@ -272,10 +287,19 @@ __device__ __forceinline__ SmGrid sm_fit_grid(LDS &L, const unsigned char *pts, 
             lo0 = fminf(lo0, L.boxf[w][0]), lo1 = fminf(lo1, L.boxf[w][1]), lo2 = fminf(lo2, L.boxf[w][2]);
             hi0 = fmaxf(hi0, L.boxf[w][3]), hi1 = fmaxf(hi1, L.boxf[w][4]), hi2 = fmaxf(hi2, L.boxf[w][5]);
             cnt += L.wsum[w];
+            for (int k = 0; k < 3; ++k) m1[k] += L.red[w][k], m2[k] += L.red[w][3 + k];
         }
         int nx = 1, ny = 1, nz = 1;
         float h = 1.0f;
         if (lo0 <= hi0) {  // at least one finite point
+            float lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
+            for (int k = 0; k < 3; ++k) {  // the core: mean +- 2.5 sigma, inside the bounding box
+                const double mean = m1[k] / cnt, var = m2[k] / cnt - mean * mean;
+                const double sd = var > 0.0 ? sqrt(var) : 0.0;
+                const float a = fmaxf(lo[k], (float) (mean - 2.5 * sd)), b = fminf(hi[k], (float) (mean + 2.5 * sd));
+                if (a <= b) lo[k] = a, hi[k] = b;
+            }
+            lo0 = lo[0], lo1 = lo[1], lo2 = lo[2], hi0 = hi[0], hi1 = hi[1], hi2 = hi[2];
             const float ex = hi0 - lo0, ey = hi1 - lo1, ez = hi2 - lo2;
             const float big = fmaxf(ex, fmaxf(ey, ez));
             const float tiny = fmaxf(big * 1e-6f, 1e-30f);
@@ -376,9 +400,10 @@ __global__ void __launch_bounds__(kSmThreads)
     // similar number of trips.  The order is a bitonic sort, in the LDS the target will occupy, of the
     // unique keys (cell << 14 or 15 | index): deterministic, so the sums of a pair do not depend on timing.
     // The sorted copy (x, y, z, index bits) lives in HBM scratch; clouds beyond 16 384 (32 768) points keep
-    // the caller's order (packed all the same: the iterations read one layout).
+    // the caller's order, and so do sources that come out of a voxel filter (leaf order IS a cell order)
+    // (packed all the same: the iterations read one layout).
     unsigned n_q = pr.n_src;  // queries per iteration
-    if (pr.n_src > kSortMax) {
+    if (pr.n_src > kSortMax || pr.presorted) {
         for (unsigned i = tid; i < pr.n_src; i += kSmThreads) {
             float x, y, z;
             if (!sm_load_point(pr.src, i, P.stride, x, y, z)) x = y = z = __builtin_nanf("");
@@ -929,6 +954,8 @@ int small_run(wm_ctx *ctx, const SmallJob *jobs, int n, size_t stride, int mem, 
         t.n_src = (unsigned) it.n_src;
         t.n_tgt = (unsigned) it.n_tgt;
         t.prev_mse0 = it.prev_mse0;
+        t.presorted = it.presorted ? 1u : 0u;
+        t.pad0 = 0;
         if (mem == WM_MEM_HOST) {
             memcpy(h + off, it.src, it.n_src * stride);
             t.src = d + off;
@@ -1074,7 +1101,7 @@ int wm_icp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
             if (stats) stats[k].state = WM_CONV_NO_CORRESPONDENCES;
             continue;
         }
-        jobs.push_back(SmallJob{it.src, it.n_src, it.target, it.n_target, DBL_MAX});  // fresh stopping criteria
+        jobs.push_back(SmallJob{it.src, it.n_src, it.target, it.n_target, DBL_MAX, 0});  // fresh stopping criteria
         item_of.push_back(k);
     }
     if (jobs.empty()) return WM_OK;
