@@ -101,10 +101,10 @@ int main(int argc, char **argv) {
         const auto t0 = std::chrono::steady_clock::now();
         const int ok = drain(pairs);
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        std::printf("{\"bench\": \"wave::MultiMatcher<ICPMatcher>\", \"points\": %d, \"workers\": %d, \"queue\": %d, "
+        std::printf("{\"bench\": \"wave::MultiMatcher<ICPMatcher>\", \"res\": %g, \"multiscale_steps\": %d, \"points\": %d, \"workers\": %d, \"queue\": %d, "
                     "\"pairs\": %d, \"seconds\": %.4f, \"registrations_per_s\": %.1f, \"recovered_shift\": %d, "
                     "\"mean_shift_x\": %.4f}\n",
-                    n, pool.workers(), queue, pairs, s, pairs / s, ok, shift_sum / pairs);
+                    (double) params.res, params.multiscale_steps, n, pool.workers(), queue, pairs, s, pairs / s, ok, shift_sum / pairs);
         std::fflush(stdout);
     }
     return 0;

@@ -23,6 +23,7 @@ cp(os.path.join(src, tag + "_stats", "kernel_stats.csv"), tag + "_bench_kernel_s
 cp(os.path.join(src, tag + "_stats", "bench_line.json"), tag + "_bench_line.json")
 cp(os.path.join(src, tag + "_bench_line_noprof.json"), tag + "_bench_line_noprof.json")
 cp(os.path.join(src, tag + "_multimatcher_cpp.jsonl"), tag + "_multimatcher_cpp.jsonl")
+cp(os.path.join(src, tag + "_batch_scaled_testscan.txt"), tag + "_batch_scaled_testscan.txt")
 for name in ("fetch", "write", "sq", "tcc"):
     cp(os.path.join(src, tag + "_pmc", name + "_summary.csv"), "%s_pmc_%s_summary.csv" % (tag, name))
 for name in ("sq1", "sq2", "sq3", "f64"):

@@ -18,5 +18,10 @@ python bench.py > gpurun_out/${TAG}_bench_line_noprof.json 2> /dev/null
     BENCH_QUEUE=2048 timeout 120 ./bench_multimatcher $n 6000 1 2 4
     timeout 120 ./bench_multimatcher $n 2000 4 16
   done
-  timeout 120 ./bench_multimatcher 100000 600 4 16 ) > gpurun_out/${TAG}_multimatcher_cpp.jsonl 2> /dev/null
+  timeout 120 ./bench_multimatcher 100000 600 4 16
+  # the reference's default parameters (voxel filter 0.1 m + three coarser scales) and its test configuration (one scale)
+  BENCH_QUEUE=512 BENCH_RES=0.1 BENCH_MULTISCALE=3 timeout 200 ./bench_multimatcher 55000 1500 1 2 4
+  BENCH_RES=0.1 BENCH_MULTISCALE=3 timeout 200 ./bench_multimatcher 55000 600 4 16
+  BENCH_QUEUE=512 BENCH_RES=0.1 BENCH_MULTISCALE=0 timeout 200 ./bench_multimatcher 55000 1500 1 2 ) > gpurun_out/${TAG}_multimatcher_cpp.jsonl 2> /dev/null
+python scripts/dev/dev_batch_scaled.py 128 > gpurun_out/${TAG}_batch_scaled_testscan.txt 2> /dev/null
 ls gpurun_out/${TAG}_*
