@@ -211,3 +211,68 @@ def test_batched_filtered_match_fails_fast_like_match(wm, ctx, oracle, testscan)
     assert got[0]["rc"] == one["rc"] == wm.WM_TOO_FEW and got[0]["T"] is None
     assert got[1]["rc"] == 0 and np.linalg.norm(got[1]["T"] - np.eye(4)) < 1e-6
     assert got[2]["rc"] == wm.WM_TOO_FEW and got[3]["rc"] == wm.WM_TOO_FEW
+
+
+def test_random_batches_equal_one_by_one(wm, ctx):
+    """Forty random pairs per call -- sizes from 3 to 6 000 points, clustered and flat clouds, NaN holes,
+    big offsets -- full resolution and voxel-filtered: every item as the one-pair device path gives it."""
+    rng = np.random.default_rng(2024)
+
+    def cloud(n):
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            c = rng.uniform(-10, 10, (n, 3))
+        elif kind == 1:
+            c = np.c_[rng.uniform(-20, 20, (n, 2)), rng.normal(0, 0.02, n)]
+        elif kind == 2:
+            c = rng.normal(0, 1.0, (n, 3)) * np.array([8.0, 3.0, 0.5]) + np.array([100.0, -50.0, 5.0])
+        else:
+            c = np.r_[rng.normal(0, 0.3, (n - n // 10, 3)), rng.uniform(-80, 80, (n // 10, 3))]   # a dense core + far outliers
+        return c.astype(np.float32)
+
+    pairs = []
+    for _ in range(40):
+        n = int(rng.integers(3, 6000))
+        ref = cloud(n)
+        ang = rng.uniform(-0.03, 0.03)
+        R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32)
+        m = int(rng.integers(3, 6000))
+        sel = rng.integers(0, n, m)
+        tgt = (ref[sel] @ R.T + rng.uniform(-0.2, 0.2, 3).astype(np.float32) + rng.normal(0, 0.01, (m, 3)).astype(np.float32)).astype(np.float32)
+        if rng.random() < 0.3:
+            ref[rng.integers(0, n, max(1, n // 20)), rng.integers(0, 3)] = np.nan
+        pairs.append((ref, tgt))
+    for res, steps in ((-1.0, 0), (0.25, 0), (0.2, 2)):
+        got = ctx.icp_batch_match(pairs, with_info=True, res=res, multiscale_steps=steps, max_corr=3.0, max_iter=60)
+        for k, ((ref, tgt), g) in enumerate(zip(pairs, got)):
+            # a matcher of its own per pair, as a batch item is: PCL's criteria start fresh and keep the
+            # last MSE from scale to scale (carry_state = 1 on a new context)
+            fresh = wm.Context(0)
+            one = fresh.icp_match(ref, tgt, res=res, multiscale_steps=steps, max_corr=3.0, max_iter=60, carry_state=1)
+            fresh.close()
+            assert g["rc"] == one["rc"], (res, steps, k, g["rc"], one["rc"])
+            if one["rc"] != 0:
+                continue
+            assert (g["iterations"], g["n_corr"]) == (one["iterations"], one["n_corr"]), (res, steps, k)
+            dt, ang = pose_error(g["T"], one["T"])
+            assert dt <= 1e-6 and ang <= 1e-7, (res, steps, k, dt, ang)
+
+
+def test_batched_filtered_match_hands_oversized_pairs_to_the_one_pair_path(wm, ctx):
+    """A pair whose FILTERED target still has more than 65 535 points is registered by wm_icp_match inside
+    the call; its neighbours in the batch are not affected."""
+    big = synth.pair(200000, seed=3, mode="resample")
+    small = synth.pair(20000, seed=4, mode="resample")
+    assert len(ctx.voxel_downsample(big[1], 0.05)) > wm.WM_BATCH_MAX_TARGET_POINTS
+    pairs = [(small[0], small[1]), (big[0], big[1]), (small[1], small[0])]
+    got = ctx.icp_batch_match(pairs, with_info=True, res=0.05, multiscale_steps=1, max_corr=3.0, max_iter=60)
+    for k, ((ref, tgt), g) in enumerate(zip(pairs, got)):
+        fresh = wm.Context(0)
+        one = fresh.icp_match(ref, tgt, res=0.05, multiscale_steps=1, max_corr=3.0, max_iter=60, carry_state=1)
+        rc, lumold, _ = fresh.icp_info(wm.WM_INFO_LUMOLD, max_corr=3.0)
+        fresh.close()
+        assert g["rc"] == one["rc"] == 0, k
+        assert (g["iterations"], g["n_corr"]) == (one["iterations"], one["n_corr"]), k
+        dt, ang = pose_error(g["T"], one["T"])
+        assert dt <= 1e-6 and ang <= 1e-7, (k, dt, ang)
+        np.testing.assert_allclose(g["info"], lumold, rtol=1e-4, atol=1e-8 * np.abs(lumold).max())
