@@ -8,7 +8,7 @@
 // launch (ICPMatcher::matchBatch: full-resolution targets up to 50 000 points, voxel-filtered matchers
 // on scans up to 200 000) takes
 // EVERYTHING that is queued -- up to 256 pairs, one compute unit each -- per trip: 80 000
-// registrations/s with one worker, 110 000-145 000 with two to four at 10 000 points, 14 000-22 000 at
+// registrations/s with one worker, 110 000-145 000 with two to four at 10 000 points, 19 000-37 000 at
 // 30 000 (libwave_amd/host/bench_multimatcher, BENCH_QUEUE=2048).  Queue depth is what feeds it: construct the pool with a
 // queue of a few hundred pairs rather than the reference's default of 10.
 //
