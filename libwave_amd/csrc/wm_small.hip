@@ -13,20 +13,26 @@
 //                                                      icp_pcl_functions.cpp:51-179
 // -- and a launch carries one workgroup per queued pair, so 256 pairs fill the 256 CUs and nothing
 // crosses a launch boundary:
+//   0. the source is put in cell order (bitonic sort of unique keys in LDS; a packed copy in HBM
+//      scratch), so that neighbouring lanes search neighbouring cells;
 //   1. the target cloud is counting-sorted by cell INTO LDS (x, y, z floats + a 16-bit original
-//      index per point: 14 B x 10 000 points = 140 kB of the CU's 160 KB; 8 192 cells, 16-bit starts);
-//   2. every iteration each lane takes source points in turn: PCL's float transform, an exact 1-NN
-//      search over the cell rows overlapping a certified ball (radius = distance to the previous
-//      iteration's match under the new pose, so one scan certifies), the same 64-bit
+//      index per point: 14 B x 10 000 points = 140 kB of the CU's 160 KB; 8 192 cells, 16-bit starts;
+//      the grid covers the CORE of the cloud, outliers are clamped into its border cells) --
+//      k_icp_small<true>; targets of up to 65 535 points keep that cell-sorted copy in HBM scratch
+//      (L2 / Infinity Cache resident; only the cell starts live in LDS) -- k_icp_small<false>;
+//   2. every iteration chunks of 64 queries go to whichever wavefront is free: PCL's float transform,
+//      an exact 1-NN search over the cell rows overlapping a certified ball (radius = distance to the
+//      previous iteration's match under the new pose, so one scan certifies), the same 64-bit
 //      (d2 bits, index) arg-min key as wm_nn.hip -- hence the same correspondences, bit for bit --
-//      and the iteration's 17 sums in double;
-//   3. a fixed-order reduction over the 16 wavefronts, then lane 0 runs the very solve + stopping rules
-//      of the big path (icp_apply_stats, wm_icp_step.hpp) on a state that lives in LDS;
+//      and the iteration's 17 sums in double, reduced per chunk so that the result does not depend
+//      on which wavefront took which chunk;
+//   3. a fixed-order sum of the chunk rows, then lane 0 runs the very solve + stopping rules of the
+//      big path (icp_apply_stats, wm_icp_step.hpp) on a state that lives in LDS;
 //   4. after the last iteration the LUMold normal equations and residual, same arithmetic as
 //      wm_info.hip.
-// Nothing but the source points, a 16-bit seed per source point and the 500-byte result ever
-// leaves the CU.  Latency of ONE registration is worse than wm_icp_align's (one CU instead of a
-// hundred); this path is for queues of pairs.
+// Latency of ONE registration is worse than wm_icp_align's (one CU instead of a hundred); this path
+// is for queues of pairs.  The voxel-filtered branches of match() are built on top of it in
+// wm_batch.hip (small_run below is what they call, scale by scale).
 #include "wm_icp_step.hpp"
 #include "wm_internal.hpp"
 #include "wm_wave.hpp"
