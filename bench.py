@@ -305,6 +305,22 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu):
         m.lumold(3.0)
         e["cpu_baseline"] = {"seconds_per_registration": time.perf_counter() - t0, "cores": 1, "kind": "port",
                              "sample": "the oracle's match() + estimateLUMold on one of the pairs"}
+        # ... and the reference's own way to throughput on the host: one registration per thread, all usable cores
+        nthr = usable_cpus()
+        if nthr > 1:
+            per_thread = 4
+
+            def cpu_worker(k):
+                for j in range(per_thread):
+                    r_, t_ = base[(k + j) % 8]
+                    O.IcpMatch(r_, t_, res=-1.0, multiscale_steps=0, incremental_float=0).lumold(3.0)
+            t0 = time.perf_counter()
+            th = [threading.Thread(target=cpu_worker, args=(k,)) for k in range(nthr)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            wall = time.perf_counter() - t0
+            e["cpu_baseline"]["all_cores"] = {"registrations_per_s": nthr * per_thread / wall, "cores": nthr,
+                                              "pattern": "MultiMatcher: %d threads, %d pairs each" % (nthr, per_thread)}
     out.append(e)
     del dev_clouds, dev_pairs
 
