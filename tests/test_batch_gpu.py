@@ -276,3 +276,17 @@ def test_batched_filtered_match_hands_oversized_pairs_to_the_one_pair_path(wm, c
         dt, ang = pose_error(g["T"], one["T"])
         assert dt <= 1e-6 and ang <= 1e-7, (k, dt, ang)
         np.testing.assert_allclose(g["info"], lumold, rtol=1e-4, atol=1e-8 * np.abs(lumold).max())
+
+
+def test_batched_matches_do_not_depend_on_where_the_clouds_live(wm, ctx, oracle, testscan):
+    """Host clouds (staged through pinned memory) and device-resident clouds: the same bits."""
+    pairs = _scan_pairs(oracle, testscan)[:4]
+    dev = [(torch.from_numpy(r).cuda(), torch.from_numpy(t).cuda()) for r, t in pairs]
+    for kw in (dict(res=-1.0, multiscale_steps=0), dict(res=0.1, multiscale_steps=3)):
+        a = ctx.icp_batch_match(pairs[1:], with_info=True, max_corr=3.0, max_iter=100, **kw) if kw["res"] < 0 else \
+            ctx.icp_batch_match(pairs, with_info=True, max_corr=3.0, max_iter=100, **kw)
+        b = ctx.icp_batch_match(dev[1:], with_info=True, max_corr=3.0, max_iter=100, **kw) if kw["res"] < 0 else \
+            ctx.icp_batch_match(dev, with_info=True, max_corr=3.0, max_iter=100, **kw)
+        for x, y in zip(a, b):
+            assert x["rc"] == y["rc"] == 0 and x["iterations"] == y["iterations"]
+            assert np.array_equal(x["T"], y["T"]) and np.array_equal(x["info"], y["info"])
