@@ -550,7 +550,9 @@ int batch_match_scaled(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
                        double *info_out, wm_icp_stats *stats, int *status) {
     const int steps = multiscale_steps > 0 ? multiscale_steps : 0;
     // sub-batches of bounded size: every cloud costs ~70 bytes per point of sort and staging buffers
-    const size_t budget = (size_t) 8 << 20;  // points per sub-batch
+    // (a sub-batch should hold enough pairs to fill the device's 256 compute units with resident
+    // registrations: 16 M points = 145 pairs of two 55 000-point scans, ~1.1 GB of buffers)
+    const size_t budget = (size_t) 16 << 20;  // points per sub-batch
     std::vector<int> idx, one_by_one;
     size_t pts = 0;
     for (int k = 0; k <= n_items; ++k) {
