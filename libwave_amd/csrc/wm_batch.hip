@@ -148,11 +148,11 @@ __global__ void __launch_bounds__(kBlock)
     out[c] = l;
 }
 
-// key = cloud << 32 | leaf index (k_vg_index's); dropped points and the clouds that are not filtered
+// key = cloud << shift | leaf index (k_vg_index's); dropped points and the clouds that are not filtered
 // at this scale get the cloud's `invalid`, which sorts behind its leaves
 __global__ void __launch_bounds__(kBlock)
     k_vb_index(const VbCloud *__restrict__ cl, unsigned n_clouds, unsigned total, const float4 *__restrict__ pts,
-               const VbLeaf *__restrict__ leaf, const unsigned char *__restrict__ skip,
+               const VbLeaf *__restrict__ leaf, const unsigned char *__restrict__ skip, unsigned shift,
                unsigned long long *__restrict__ key, unsigned *__restrict__ perm) {
     const unsigned g = blockIdx.x * kBlock + threadIdx.x;
     if (g >= total) return;
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(kBlock)
         const int i2 = (int) (floorf(__fmul_rn(p.z, l.inv)) - (float) l.mb[2]);
         k = (unsigned) (i0 + i1 * l.dx + i2 * l.dxy);
     }
-    key[g] = ((unsigned long long) c << 32) | k;
+    key[g] = ((unsigned long long) c << shift) | k;  // (shift = bits of the batch's largest leaf count: fewer radix passes)
     perm[g] = g;
 }
 
@@ -194,14 +194,14 @@ constexpr int kVbTrip = 8;
 __global__ void __launch_bounds__(kBlock)
     k_vb_centroid(const VbCloud *__restrict__ cl, const VbLeaf *__restrict__ leaf, const float4 *__restrict__ pts,
                   const unsigned long long *__restrict__ key_sorted, const unsigned *__restrict__ perm_sorted,
-                  const unsigned *__restrict__ heads, const unsigned *__restrict__ seg, unsigned total,
+                  const unsigned *__restrict__ heads, const unsigned *__restrict__ seg, unsigned total, unsigned shift,
                   float4 *__restrict__ out) {
     const unsigned slot = blockIdx.x * kBlock + threadIdx.x;
     if (slot >= seg[total]) return;
     const unsigned i = heads[slot], j = heads[slot + 1];
     const unsigned long long key = key_sorted[i];
-    const unsigned c = (unsigned) (key >> 32);
-    if ((unsigned) key == leaf[c].invalid) return;  // the cloud's dropped points
+    const unsigned c = (unsigned) (key >> shift);
+    if ((unsigned) (key & ((1ull << shift) - 1ull)) == leaf[c].invalid) return;  // the cloud's dropped points
     float sx = 0.f, sy = 0.f, sz = 0.f;
     for (unsigned t = i; t < j; t += kVbTrip) {
         float4 p[kVbTrip];
@@ -302,7 +302,8 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct VoxelBatch {
     wm_ctx *ctx = nullptr;
     BatchVoxel *V = nullptr;
-    unsigned n_pairs = 0, n_clouds = 0, bits = 33;
+    unsigned n_pairs = 0, n_clouds = 0, cloud_bits = 1;
+    std::vector<VbBox> h_box;  // the clouds' bounding boxes on the host: they size the sort key of every scale
     size_t total = 0;
     std::vector<VbCloud> cl;
     std::vector<unsigned> n_out;
@@ -389,8 +390,11 @@ struct VoxelBatch {
         hipLaunchKernelGGL(k_vb_pack, dim3(blocks), dim3(kBlock), 0, ctx->stream, d_cl(), n_clouds, (unsigned) total, (unsigned) stride, packed);
         hipLaunchKernelGGL(k_vb_bbox, dim3(n_clouds), dim3(kVbThreads), 0, ctx->stream, d_cl(), packed, d_box());
         WM_HIP(ctx, hipGetLastError());
-        bits = 33;
-        while ((1ull << (bits - 32)) < n_clouds) ++bits;
+        cloud_bits = 1;
+        while ((1u << cloud_bits) < n_clouds) ++cloud_bits;
+        h_box.resize(n_clouds);
+        WM_HIP(ctx, hipMemcpyAsync(h_box.data(), d_box(), n_clouds * sizeof(VbBox), hipMemcpyDeviceToHost, ctx->stream));
+        WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         n_out.assign(n_clouds, 0);
         return WM_OK;
     }
@@ -405,13 +409,31 @@ struct VoxelBatch {
     // offset, their number into n_out (0xFFFFFFFF: the leaf lattice overflows int32)
     int filter(float leaf) {
         const unsigned blocks = (unsigned) ((total + kBlock - 1) / kBlock), cblocks = (n_clouds + kBlock - 1) / kBlock;
+        // the widest leaf count of the batch at this scale (k_vb_leaf's arithmetic) -> bits of the key's leaf part
+        unsigned shift = 1;
+        {
+            const float inv = 1.0f / leaf;
+            unsigned long long most = 1;
+            for (unsigned c = 0; c < n_clouds; ++c) {
+                const VbBox &b = h_box[c];
+                if (!b.n_valid) continue;
+                unsigned long long cells = 1;
+                for (int d = 0; d < 3; ++d) {
+                    const long long m = (long long) floorf(b.lo[d] * inv), M = (long long) floorf(b.hi[d] * inv);
+                    cells *= (unsigned long long) (M - m + 1);
+                }
+                if (cells <= 2147483647ull && cells > most) most = cells;  // (beyond int32: overflow, key = 0)
+            }
+            while (shift < 32 && (most >> shift) != 0ull) ++shift;
+        }
+        const unsigned bits = shift + cloud_bits;
         WM_HIP(ctx, hipMemcpyAsync(d_skip(), h_skip, n_clouds, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(k_vb_leaf, dim3(cblocks), dim3(kBlock), 0, ctx->stream, d_box(), n_clouds, leaf, d_leaf());
         unsigned long long *key = V->key.as<unsigned long long>(), *key2 = V->key2.as<unsigned long long>();
         unsigned *perm = V->perm.as<unsigned>(), *perm2 = V->perm2.as<unsigned>();
         unsigned *flags = V->flags.as<unsigned>(), *seg = V->seg.as<unsigned>(), *heads = V->heads.as<unsigned>();
         hipLaunchKernelGGL(k_vb_index, dim3(blocks), dim3(kBlock), 0, ctx->stream, d_cl(), n_clouds, (unsigned) total, packed, d_leaf(),
-                           d_skip(), key, perm);
+                           d_skip(), shift, key, perm);
         WM_HIP(ctx, hipGetLastError());
         size_t tmp_bytes = 0;
         WM_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, key, key2, perm, perm2, total, 0u, bits, ctx->stream));
@@ -421,7 +443,7 @@ struct VoxelBatch {
         WM_TRY(exclusive_scan(ctx, flags, total, seg));
         hipLaunchKernelGGL(k_vb_heads, dim3(blocks), dim3(kBlock), 0, ctx->stream, flags, seg, (unsigned) total, heads);
         hipLaunchKernelGGL(k_vb_centroid, dim3(blocks), dim3(kBlock), 0, ctx->stream, d_cl(), d_leaf(), packed, key2, perm2, heads, seg,
-                           (unsigned) total, filtered);
+                           (unsigned) total, shift, filtered);
         hipLaunchKernelGGL(k_vb_counts, dim3(cblocks), dim3(kBlock), 0, ctx->stream, d_cl(), d_box(), d_leaf(), d_skip(), seg, n_clouds,
                            d_nout());
         WM_HIP(ctx, hipGetLastError());
