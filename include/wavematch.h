@@ -132,6 +132,10 @@ typedef struct {
     float grid_cell;     /* level-0 cell size used */
     int owned_violations; /* sharded path: iterations in which the ranks together did not
                              handle every source point (see wm_icp_shard_begin) */
+    int cert_launches;   /* iterations whose correspondences came from the certificate kernel
+                            (k_nn_cert: previous match proved still nearest, search only where the
+                            proof fails) instead of a full search; same correspondences either way */
+    int reserved0;
 } wm_icp_stats;
 
 void wm_icp_default_params(wm_icp_params *p);
@@ -227,6 +231,14 @@ enum { WM_INFO_LUM = 0, WM_INFO_CENSI = 1, WM_INFO_LUMOLD = 2 };
 int wm_icp_info(wm_ctx *ctx, int method, const double T_result[16], double lin_covar,
                 double ang_covar, double max_corr, double info[36], int *degenerate);
 
+/* Tuning knobs by name (tests, benchmarks; the defaults are the product's): "cert_from" (-1: the
+ * certificate kernel takes over once an ICP step is small, -2: never, k >= 0: from iteration k of
+ * every align), "cert_disp" (that step size, in level-0 grid cells), "cert_pad_mul",
+ * "cert_pad_frac", "cert_nb".  None of them changes a result.  WM_ERR_ARG for an unknown name. */
+int wm_set_option(wm_ctx *ctx, const char *name, double value);
+/* developer: out == NULL arms a log of `iterations` launches (0 disarms); otherwise writes, per
+ * launch of the certificate kernel since, how many queries it had to search; returns the count */
+int wm_debug_cert_log(wm_ctx *ctx, int iterations, unsigned *out, int cap);
 /* Per-iteration device time (ms) of the correspondence kernel in the last
  * wm_icp_align call that ran with profile >= 1; returns the number written. */
 int wm_get_iteration_times(wm_ctx *ctx, float *nn_ms, int cap);

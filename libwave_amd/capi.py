@@ -44,7 +44,7 @@ class IcpStats(C.Structure):
                 ("stats_ms", C.c_float),
                 ("solve_ms", C.c_float), ("nn_launches", C.c_int), ("nn_levels", C.c_int),
                 ("deferred", C.c_uint64), ("grid_cell", C.c_float),
-                ("owned_violations", C.c_int)]
+                ("owned_violations", C.c_int), ("cert_launches", C.c_int), ("reserved0", C.c_int)]
 
 
 class BatchItem(C.Structure):
@@ -103,6 +103,8 @@ def lib():
         L.wm_set_source.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
         L.wm_set_target.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
         L.wm_set_grid_cell.argtypes = [C.c_void_p, C.c_float]
+        L.wm_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        L.wm_debug_cert_log.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint), C.c_int]
         L.wm_cloud_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.wm_icp_default_params.argtypes = [C.POINTER(IcpParams)]
         L.wm_icp_default_params.restype = None
@@ -279,6 +281,19 @@ class Context:
         self._check(lib().wm_set_target(self._h, C.c_void_p(ptr), n, stride, mem), "wm_set_target")
         self.n_tgt = n
 
+    def set_option(self, name, value):
+        self._check(lib().wm_set_option(self._h, name.encode(), C.c_double(value)), "wm_set_option")
+
+    def cert_log(self, iterations=None):
+        """cert_log(n): arm a log of n launches of the certificate kernel; cert_log(): the number of
+        queries each launch since had to search."""
+        if iterations is not None:
+            self._check(lib().wm_debug_cert_log(self._h, int(iterations), None, 0), "wm_debug_cert_log")
+            return None
+        out = (C.c_uint * 4096)()
+        k = lib().wm_debug_cert_log(self._h, 0, out, 4096)
+        return [int(out[i]) for i in range(max(k, 0))]
+
     def set_grid_cell(self, h):
         self._check(lib().wm_set_grid_cell(self._h, float(h)), "wm_set_grid_cell")
 
@@ -303,7 +318,7 @@ class Context:
                     nn_ms=s.nn_ms, coarse_ms=s.coarse_ms, stats_ms=s.stats_ms,
                     solve_ms=s.solve_ms, nn_launches=s.nn_launches, nn_levels=s.nn_levels,
                     deferred=s.deferred, grid_cell=s.grid_cell,
-                    owned_violations=s.owned_violations)
+                    owned_violations=s.owned_violations, cert_launches=s.cert_launches)
 
     def icp_match(self, ref, target, res=-1.0, multiscale_steps=0, params=None, **kw):
         """ICPMatcher::match() (icp.cpp:75-133) in one C-ABI call."""

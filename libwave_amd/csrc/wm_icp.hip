@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(kBlock)
 template <int PHASES, int THREADS>
 __global__ void __launch_bounds__(THREADS)
     k_reduce_solve(const double *__restrict__ partials, int nblocks, IcpDevState *st,
-                   double *stats_io) {
+                   double *stats_io, unsigned long long *pub, int pub_slots) {
     // The solve runs in ONE lane and touches two dozen fields of the state: read from HBM one
     // dependent access at a time that is most of this kernel's ~10 us.  So the whole state is
     // staged in LDS by all threads (one round trip), worked on there, and written back whole.
@@ -271,6 +271,18 @@ __global__ void __launch_bounds__(THREADS)
             for (int k = 0; k < kStatsLen; ++k) stats[k] = s_st.stats[k];
             s_st.dbg[2] = clock64();
             icp_apply_stats(&s_st, stats);
+            // what the host steers by while it runs ahead of the device (wm_icp_align): one 8-byte word in
+            // pinned memory -- done flag, iterations finished, the step's size -- in ONE system-scope store
+            // (pub[0]: the latest; pub[k]: iteration k's own record, so that what the host decides from
+            // does not depend on when it looks)
+            if (pub) {
+                const unsigned long long w = ((unsigned long long) (unsigned) s_st.iter << 32) |
+                                             (unsigned long long) __float_as_uint(s_st.step_disp);
+                if (s_st.iter >= 1 && s_st.iter <= pub_slots)
+                    __hip_atomic_store(pub + s_st.iter, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(pub, w | ((unsigned long long) (s_st.done ? 1u : 0u) << 63), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         s_st.dbg[3] = clock64();
     }
@@ -321,7 +333,8 @@ static int launch_stats(wm_ctx *ctx, int mode) {
 
 // Sum `rows` partial rows (ctx->partials) and run the requested phases of the iteration's solve.
 template <int PHASES>
-static int launch_reduce_solve(wm_ctx *ctx, unsigned rows, double *stats_io) {
+static int launch_reduce_solve(wm_ctx *ctx, unsigned rows, double *stats_io, unsigned long long *pub = nullptr,
+                               int pub_slots = 0) {
     IcpDevState *st = ctx->d_state.as<IcpDevState>();
     const double *part = ctx->partials.as<double>();
     if (rows > 2048u) {  // one workgroup cannot add that many rows quickly: 128 rows -> 1 first
@@ -334,10 +347,10 @@ static int launch_reduce_solve(wm_ctx *ctx, unsigned rows, double *stats_io) {
     }
     if (rows > 512u)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<PHASES, 1024>), dim3(1), dim3(1024), 0, ctx->stream,
-                           part, (int) rows, st, stats_io);
+                           part, (int) rows, st, stats_io, pub, pub_slots);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<PHASES, kBlock>), dim3(1), dim3(kBlock), 0, ctx->stream,
-                           part, (int) rows, st, stats_io);
+                           part, (int) rows, st, stats_io, pub, pub_slots);
     WM_HIP(ctx, hipGetLastError());
     return WM_OK;
 }
@@ -368,7 +381,7 @@ static int prepare_work(wm_ctx *ctx) {
 static void init_state(IcpDevState *s, const double *T, const wm_icp_params *p, double prev_mse) {
     memset(s, 0, sizeof(*s));
     for (int k = 0; k < 16; ++k) s->T[k] = T[k];
-    for (int k = 0; k < 12; ++k) s->Tf[k] = (float) T[k];
+    for (int k = 0; k < 12; ++k) s->Tf[k] = s->Tf_prev[k] = (float) T[k];
     mat4_identity(s->Tk);
     s->prev_mse = prev_mse;
     if (p) {
@@ -710,6 +723,20 @@ int wm_ctx_create(wm_ctx **out, int device) {
     if (const char *e = getenv("WM_TUNE_FUSE_STATS")) ctx->tune_fuse_stats = atoi(e);
     if (const char *e = getenv("WM_TUNE_NN_BALANCED")) ctx->tune_nn_balanced = atoi(e);
     if (const char *e = getenv("WM_TUNE_FAST_SOLVE")) ctx->tune_fast_solve = atoi(e);
+    if (const char *e = getenv("WM_TUNE_CERT_FROM")) ctx->tune_cert_from = atoi(e);
+    if (const char *e = getenv("WM_TUNE_CERT_NB")) ctx->tune_cert_nb = atoi(e);
+    if (const char *e = getenv("WM_TUNE_CERT_DISP")) {
+        const float v = (float) atof(e);
+        if (v > 0) ctx->tune_cert_disp = v;
+    }
+    if (const char *e = getenv("WM_TUNE_CERT_PAD_MUL")) {
+        const float v = (float) atof(e);
+        if (v >= 0) ctx->tune_cert_pad_mul = v;
+    }
+    if (const char *e = getenv("WM_TUNE_CERT_PAD_FRAC")) {
+        const float v = (float) atof(e);
+        if (v >= 0) ctx->tune_cert_pad_frac = v;
+    }
     if (const char *e = getenv("WM_TUNE_XCD_CHUNK")) ctx->tune_xcd_chunk = atoi(e);
     if (const char *e = getenv("WM_TUNE_RADIX_MIN")) ctx->tune_radix_min = atoi(e);
     if (const char *e = getenv("WM_TUNE_NDT_BLOCKS")) {
@@ -764,7 +791,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
                       &ctx->src_grid.cell_start, &ctx->vg_idx, &ctx->vg_idx2, &ctx->vg_perm,
                       &ctx->vg_perm2, &ctx->vg_tmp, &ctx->vg_seg, &ctx->io_a, &ctx->io_b, &ctx->ds_ref,
                       &ctx->ds_tgt, &ctx->match_ref, &ctx->match_tgt,
-                      &ctx->partials, &ctx->partials2, &ctx->cost_log, &ctx->phase_log, &ctx->shard_ref, &ctx->shard_tgt,
+                      &ctx->partials, &ctx->partials2, &ctx->nn_bound, &ctx->cert_count, &ctx->cost_log, &ctx->phase_log, &ctx->shard_ref, &ctx->shard_tgt,
                       &ctx->shard_ref_band, &ctx->shard_tgt_band, &ctx->shard_misc, &ctx->shard_flags, &ctx->shard_pos_t,
                       &ctx->shard_pos_s, &ctx->shard_stats, &ctx->ndt_sum_dev, &ctx->corr_tmp_idx, &ctx->corr_tmp_d2, &ctx->d_state};
     for (DevBuf *b : bufs) b->release();
@@ -778,6 +805,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
     if (ctx->h_gicp) (void) hipHostFree(ctx->h_gicp);
     if (ctx->h_ndt) (void) hipHostFree(ctx->h_ndt);
     if (ctx->h_sig) (void) hipHostFree(ctx->h_sig);
+    if (ctx->h_pub) (void) hipHostFree(ctx->h_pub);
     if (ctx->h_scratch) (void) hipHostFree(ctx->h_scratch);
     for (hipEvent_t e : ctx->ev_pool) (void) hipEventDestroy(e);
     if (ctx->ev_a) (void) hipEventDestroy(ctx->ev_a);
@@ -894,47 +922,124 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
     const double prev = (p->carry_state && ctx->prev_mse >= 0) ? ctx->prev_mse : DBL_MAX;
     init_state(ctx->h_state, I, p, prev);
     ctx->h_state->svd_warm = ctx->tune_fast_solve ? 1 : 0;
+    {
+        const Bbox &b = ctx->src_bbox;
+        double d2 = 0;
+        for (int k = 0; k < 3; ++k) {
+            ctx->h_state->src_centre[k] = 0.5f * (b.lo[k] + b.hi[k]);
+            d2 += 0.25 * ((double) b.hi[k] - b.lo[k]) * ((double) b.hi[k] - b.lo[k]);
+        }
+        ctx->h_state->src_radius = (float) sqrt(d2);
+    }
     WM_TRY(upload_state(ctx));
 
     const int max_it = p->force_iterations > 0 ? p->force_iterations : p->max_iter;
     const int nb = stat_blocks(ctx->n_src);
     ctx->iter_nn_ms.clear();
     WM_HIP(ctx, hipEventRecord(ctx->ev_a, ctx->stream));
-    int launched = 0;
+    // The host runs AHEAD of the device, never more than kLag iterations: every solve kernel publishes
+    // (done, iterations finished, the size of its step) in one word of pinned memory, and before
+    // enqueueing iteration `it` the host waits until iteration it - kLag has been published.  The
+    // device always has work queued (no pipeline drain, round 2: one every 8 iterations), iterations
+    // enqueued behind a `done` are no-ops, and the host picks the search kernel of iteration `it` from
+    // the step size iteration it - kLag recorded (its own record, so the choice does not depend on
+    // timing and a registration stays bit-reproducible): the full search (k_nn_grid) while the clouds
+    // still move, the certificate kernel (k_nn_cert) once a step is a small fraction of a grid cell.
+    // The choice changes the work, never the correspondences.
+    constexpr int kLag = 4;
+    if (ctx->h_pub_slots < max_it + 1) {
+        if (ctx->h_pub) (void) hipHostFree(ctx->h_pub);
+        ctx->h_pub = nullptr;
+        ctx->h_pub_slots = 0;
+        WM_HIP(ctx, hipHostMalloc((void **) &ctx->h_pub, sizeof(unsigned long long) * (size_t) (max_it + 2),
+                                  hipHostMallocDefault));
+        ctx->h_pub_slots = max_it + 1;
+    }
+    // (nothing of an earlier align is in flight: each ends with a fetch of the state)
+    memset(ctx->h_pub, 0, sizeof(unsigned long long) * (size_t) (max_it + 1));
+    const bool can_cert = !brute && ctx->tune_fuse_stats && ctx->tune_nn_balanced && ctx->tune_cert_from >= -1 &&
+                          ctx->n_tgt_input < (1u << 26) - 8u && !ctx->cost_log.p;
+    volatile unsigned long long *pub = ctx->h_pub;
+    bool cert_on = false, bounds_valid = false, seen_done = false;
+    const float cert_thr = brute ? 0.f : ctx->tune_cert_disp * ctx->levels[0].d.h;
     size_t ev_used = 0;
-    while (launched < max_it) {
-        const int batch = p->force_iterations > 0 ? max_it : ((max_it - launched) < 8 ? (max_it - launched) : 8);
-        for (int b = 0; b < batch; ++b) {
-            hipEvent_t e0 = nullptr, e1 = nullptr, e1b = nullptr, e2 = nullptr, e3 = nullptr;
-            if (p->profile) {  // 5 pool slots per iteration; level 1 only fills the first two
-                e0 = get_event(ctx, ev_used++);
-                e1 = get_event(ctx, ev_used++);
-                if (p->profile >= 2) {
-                    e1b = get_event(ctx, ev_used++);
-                    e2 = get_event(ctx, ev_used++);
-                    e3 = get_event(ctx, ev_used++);
-                } else {
-                    ev_used += 3;
-                    (void) get_event(ctx, ev_used - 1);
+    ctx->cert_launches = 0;
+    for (int it = 0; it < max_it; ++it) {
+        float seen_disp = -1.f;  // the step size iteration it - kLag published (its own record)
+        if (it >= kLag) {  // wait for it (3 stages as in wait_flag)
+            const unsigned need = (unsigned) (it - kLag + 1);  // iterations finished by then
+            const auto t0 = std::chrono::steady_clock::now();
+            bool yielding = false;
+            for (unsigned spins = 1;; ++spins) {
+                const unsigned long long w = pub[need];
+                if ((unsigned) (w >> 32) == need) {
+                    seen_disp = __builtin_bit_cast(float, (unsigned) w);
+                    break;
+                }
+                if ((pub[0] >> 63) != 0ull) {
+                    seen_done = true;
+                    break;
+                }
+                if (yielding)
+                    std::this_thread::yield();
+                else
+                    __builtin_ia32_pause();
+                if ((spins & 63u) == 0 || yielding) {
+                    const auto waited = std::chrono::steady_clock::now() - t0;
+                    if (waited > std::chrono::milliseconds(20)) {
+                        // a long wait (huge clouds, a shared device): let the runtime block until everything
+                        // enqueued has run -- the record is there then, unless a kernel failed
+                        WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                        const unsigned long long w2 = pub[need];
+                        if ((unsigned) (w2 >> 32) == need) seen_disp = __builtin_bit_cast(float, (unsigned) w2);
+                        else seen_done = true;
+                        break;
+                    }
+                    yielding = waited > std::chrono::microseconds(ctx->tune_spin_us);
                 }
             }
-            unsigned rows = (unsigned) nb;
-            if (brute) {
-                WM_TRY(launch_nn_brute(ctx, thr, e0, e1));
-                if (e1b) WM_HIP(ctx, hipEventRecord(e1b, ctx->stream));
-                WM_TRY(launch_stats(ctx, p->mode));
-            } else {
-                WM_TRY(launch_search_and_stats(ctx, thr, p->mode, e0, e1, e1b, &rows));
-            }
-            if (e2) WM_HIP(ctx, hipEventRecord(e2, ctx->stream));
-            WM_TRY(launch_reduce_solve<3>(ctx, rows, nullptr));
-            if (e3) WM_HIP(ctx, hipEventRecord(e3, ctx->stream));
+            if (seen_done) break;
         }
+        if (can_cert) {
+            if (ctx->tune_cert_from >= 0) {
+                cert_on = it >= ctx->tune_cert_from;
+            } else if (seen_disp >= 0.f) {
+                if (!cert_on && seen_disp < cert_thr) cert_on = true;
+                else if (cert_on && seen_disp > 3.f * cert_thr) cert_on = false;
+            }
+        }
+        hipEvent_t e0 = nullptr, e1 = nullptr, e1b = nullptr, e2 = nullptr, e3 = nullptr;
+        if (p->profile) {  // 5 pool slots per iteration; level 1 only fills the first two
+            e0 = get_event(ctx, ev_used++);
+            e1 = get_event(ctx, ev_used++);
+            if (p->profile >= 2) {
+                e1b = get_event(ctx, ev_used++);
+                e2 = get_event(ctx, ev_used++);
+                e3 = get_event(ctx, ev_used++);
+            } else {
+                ev_used += 3;
+                (void) get_event(ctx, ev_used - 1);
+            }
+        }
+        unsigned rows = (unsigned) nb;
+        if (brute) {
+            WM_TRY(launch_nn_brute(ctx, thr, e0, e1));
+            if (e1b) WM_HIP(ctx, hipEventRecord(e1b, ctx->stream));
+            WM_TRY(launch_stats(ctx, p->mode));
+        } else if (cert_on) {
+            WM_TRY(launch_nn_cert(ctx, thr, e0, e1, e1b, p->mode, &rows, bounds_valid));
+            bounds_valid = true;
+            ctx->cert_launches++;
+        } else {
+            WM_TRY(launch_search_and_stats(ctx, thr, p->mode, e0, e1, e1b, &rows));
+            bounds_valid = false;
+        }
+        if (e2) WM_HIP(ctx, hipEventRecord(e2, ctx->stream));
+        WM_TRY(launch_reduce_solve<3>(ctx, rows, nullptr, ctx->h_pub, ctx->h_pub_slots));
+        if (e3) WM_HIP(ctx, hipEventRecord(e3, ctx->stream));
         WM_HIP(ctx, hipGetLastError());
-        launched += batch;
-        WM_TRY(download_state(ctx));
-        if (ctx->h_state->done) break;
     }
+    WM_TRY(download_state(ctx));
     WM_HIP(ctx, hipEventRecord(ctx->ev_b, ctx->stream));
     WM_HIP(ctx, hipEventSynchronize(ctx->ev_b));
     const IcpDevState &s = *ctx->h_state;
@@ -953,6 +1058,7 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
         stats->nn_levels = brute ? 0 : ctx->n_levels;
         stats->grid_cell = brute ? 0.f : ctx->levels[0].d.h;
         stats->deferred = s.deferred_total;
+        stats->cert_launches = ctx->cert_launches;
         (void) hipEventElapsedTime(&stats->align_ms, ctx->ev_a, ctx->ev_b);
         if (p->profile) {
             // iterations that ran (the rest of the last batch were no-ops)
@@ -1266,6 +1372,45 @@ int wm_debug_solve_cycles(wm_ctx *ctx, unsigned long long out[8]) {
     if (!ctx || !out || !ctx->h_state) return WM_ERR_ARG;
     for (int k = 0; k < 8; ++k) out[k] = ctx->h_state->dbg[k];
     return WM_OK;
+}
+
+int wm_set_option(wm_ctx *ctx, const char *name, double value) {
+    if (!ctx || !name) return WM_ERR_ARG;
+    const std::string k(name);
+    if (k == "cert_from") ctx->tune_cert_from = (int) value;
+    else if (k == "cert_nb") ctx->tune_cert_nb = (int) value;
+    else if (k == "cert_disp" && value > 0) ctx->tune_cert_disp = (float) value;
+    else if (k == "cert_pad_mul" && value >= 0) ctx->tune_cert_pad_mul = (float) value;
+    else if (k == "cert_pad_frac" && value >= 0) ctx->tune_cert_pad_frac = (float) value;
+    else return WM_ERR_ARG;
+    return WM_OK;
+}
+
+int wm_debug_cert_log(wm_ctx *ctx, int iterations, unsigned *out, int cap) {
+    if (!ctx || iterations < 0) return WM_ERR_ARG;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    if (!out) {  // arm: the next aligns count the queries k_nn_cert had to search, launch by launch
+        WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->cert_log_iter = 0;
+        ctx->cert_log_cap = 0;
+        if (iterations == 0) {
+            ctx->cert_count.release();
+            return WM_OK;
+        }
+        WM_HIP(ctx, ctx->cert_count.reserve((size_t) iterations * 64 * sizeof(unsigned)));
+        WM_HIP(ctx, hipMemsetAsync(ctx->cert_count.p, 0, (size_t) iterations * 64 * sizeof(unsigned), ctx->stream));
+        ctx->cert_log_cap = iterations;
+        return WM_OK;
+    }
+    const int n = ctx->cert_log_iter < cap ? ctx->cert_log_iter : cap;
+    std::vector<unsigned> tmp((size_t) (n > 0 ? n : 1) * 64);
+    if (n > 0) WM_TRY(copy_to_caller(ctx, tmp.data(), ctx->cert_count.p, (size_t) n * 64 * sizeof(unsigned)));
+    for (int i = 0; i < n; ++i) {
+        unsigned t = 0;
+        for (int k = 0; k < 64; ++k) t += tmp[(size_t) i * 64 + k];
+        out[i] = t;
+    }
+    return n;
 }
 
 int wm_get_iteration_times(wm_ctx *ctx, float *nn_ms, int cap) {

@@ -97,8 +97,28 @@ __host__ __device__ inline void icp_apply_stats(IcpDevState *st, const double *s
         st->T[k] = Tn[k];
         st->Tk[k] = Tk[k];
     }
+    // how far this step moves the source points at most: |(R_k - I) c + t_k| + |R_k - I|_F rho, with c
+    // and rho the centre and half diagonal of the cloud under the pose the step was computed for
+    // (what decides whether the next searches can be certified instead: k_nn_cert)
+    {
+        const double c0x = st->src_centre[0], c0y = st->src_centre[1], c0z = st->src_centre[2];
+        const double cx = Tc[0] * c0x + Tc[1] * c0y + Tc[2] * c0z + Tc[3];
+        const double cy = Tc[4] * c0x + Tc[5] * c0y + Tc[6] * c0z + Tc[7];
+        const double cz = Tc[8] * c0x + Tc[9] * c0y + Tc[10] * c0z + Tc[11];
+        const double a0 = Tk[0] - 1.0, a5 = Tk[5] - 1.0, a10 = Tk[10] - 1.0;
+        const double dx = a0 * cx + Tk[1] * cy + Tk[2] * cz + Tk[3];
+        const double dy = Tk[4] * cx + a5 * cy + Tk[6] * cz + Tk[7];
+        const double dz = Tk[8] * cx + Tk[9] * cy + a10 * cz + Tk[11];
+        const double fro2 = a0 * a0 + Tk[1] * Tk[1] + Tk[2] * Tk[2] + Tk[4] * Tk[4] + a5 * a5 + Tk[6] * Tk[6] +
+                            Tk[8] * Tk[8] + Tk[9] * Tk[9] + a10 * a10;
+        // (a heuristic's input: float square roots, not two one-lane f64 chains)
+        st->step_disp = sqrtf((float) (dx * dx + dy * dy + dz * dz)) + sqrtf((float) fro2) * st->src_radius;
+    }
 #pragma unroll
-    for (int k = 0; k < 12; ++k) st->Tf[k] = (float) Tn[k];
+    for (int k = 0; k < 12; ++k) {
+        st->Tf_prev[k] = st->Tf[k];
+        st->Tf[k] = (float) Tn[k];
+    }
     const int iter = st->iter + 1;
     st->iter = iter;
     st->have_prev = 1;

@@ -92,6 +92,7 @@ struct GridLevel {
 struct IcpDevState {
     double T[16];   // cumulative source->target
     float Tf[12];   // float rows 0..2 of T (what the correspondence kernel applies)
+    float Tf_prev[12];  // ... of the previous iteration (k_nn_cert: how far the step moved each query)
     double Tk[16];  // last incremental step
     double stats[kStatsLen];
     double mse, prev_mse;
@@ -112,6 +113,10 @@ struct IcpDevState {
     int svd_warm;      // warm-started SVD on (tune_fast_solve)
     double svd_v[10];  // V of the last iteration's SVD (+ a valid flag): the next one starts from it
     unsigned long long dbg[8];  // developer: cycle stamps of the last solve kernel (wm_debug_solve_cycles)
+    float step_disp;   // upper estimate of how far the last step moved the source points (metres)
+    float src_radius;  // half diagonal of the source cloud's bounding box (for step_disp)
+    float src_centre[3];
+    int pad_;
 };
 
 struct Bbox {
@@ -165,6 +170,12 @@ struct wm_ctx {
     wm::DevBuf cost_log;                    // developer: per-query search cost of every iteration (wm_debug_cost_log)
     int cost_log_iter = 0, cost_log_cap = 0;
     wm::DevBuf keys, partials, partials2, corr_tmp_idx, corr_tmp_d2, d_levels;
+    wm::DevBuf nn_bound;                    // float per (sorted) source point: k_nn_cert's lower bound on the distance to every point but the match
+    wm::DevBuf cert_count;                  // developer: unsettled queries per launch of k_nn_cert ([launch][64] partial counts)
+    int cert_log_iter = 0, cert_log_cap = 0;
+    int cert_launches = 0;                  // of the last align
+    unsigned long long *h_pub = nullptr;    // pinned: [0] (done << 63 | iterations finished << 32 | step size bits) of the latest solve, [k] iteration k's own record
+    int h_pub_slots = 0;
     wm::DevBuf vg_idx, vg_idx2, vg_perm, vg_perm2, vg_tmp, vg_seg, io_a, io_b, ds_ref, ds_tgt, match_ref, match_tgt;
     wm::DevBuf d_state;
     wm::IcpDevState *h_state = nullptr;  // pinned
@@ -214,6 +225,10 @@ struct wm_ctx {
     int tune_two_streams = 1;    // source Morton sort on a side stream beside the target's grid build
     int tune_fuse_stats = 1;     // ICP statistics summed in the tail of the search kernel (0: separate k_icp_stats pass)
     int tune_nn_balanced = 1;    // search kernel: wave-pooled candidate trips (0: every lane walks its own)
+    int tune_cert_from = -1;     // k_nn_cert from this iteration of an align on (-1: chosen from the step size, tune_cert_disp; -2: never)
+    float tune_cert_disp = 0.15f;  // ... once a step moves the points by less than this many level-0 cells
+    float tune_cert_pad_mul = 8.f, tune_cert_pad_frac = 0.5f;  // runner-up room of a certified search (see k_nn_cert)
+    int tune_cert_nb = 4;        // batches of 64 queries per workgroup of k_nn_cert (2, 4 or 8)
     int tune_fast_solve = 1;     // experiment knob for the solve kernel
     int tune_spin_us = 80;       // wait_flag: busy-poll this long before polling with yields
     int tune_ndt_blocks = 1024;  // workgroups (= partial rows) of one NDT derivative pass
@@ -311,6 +326,10 @@ int transform_cloud_dev(wm_ctx *ctx, const float4 *in, size_t n, const double T[
 int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2,
                    int stats_mode = -1, unsigned *rows_out = nullptr);
 int launch_nn_brute(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1);
+// the certificate kernel (late iterations): stats_mode as above; bounds_valid = the previous search of
+// this align was launch_nn_cert too (its per-query bounds are still in ctx->nn_bound)
+int launch_nn_cert(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2, int stats_mode,
+                   unsigned *rows_out, bool bounds_valid);
 void small_batch_release(wm_ctx *ctx);
 // ---- wm_small.hip / wm_batch.hip: whole registrations inside one workgroup, many per launch
 struct SmallJob {

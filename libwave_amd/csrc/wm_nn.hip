@@ -326,12 +326,30 @@ struct BalHolder<false> {
     int unused;
 };
 
-template <bool COST, int RC>
+// Runner-up tracking (BOUND): besides the arg-min the search then also reports a lower bound s of
+// the distance from the query to every target point OTHER than its match -- the smaller of the
+// second-smallest distance it saw and the radius it pruned with.  While a later pose moves the
+// query by less than s - |q - match| the match is still the nearest neighbour and no search is
+// needed (k_nn_cert).  To make s useful the scan prunes with min(runner-up, best + pad) instead of
+// best: `pad` is how much room the caller wants (a few times the query's last displacement).
+struct Bound {
+    unsigned second;  // d2 bits of the runner-up so far (a point other than the current best)
+    float pad;        // metres
+    unsigned *lds;    // [64] words of LDS: the runner-ups while the wave's pooled walk is under way
+    bool ok;          // false once a path without runner-up tracking has been taken: no bound to offer
+    // squared prune radius, as float bits
+    __device__ __forceinline__ float prune_r(unsigned long long best) const {
+        const float b = __builtin_amdgcn_sqrtf(__uint_as_float((unsigned) (best >> 32))) * 1.00001f + pad;
+        return fminf(b, __builtin_amdgcn_sqrtf(__uint_as_float(second)) * 1.00001f);
+    }
+};
+
+template <bool COST, int RC, bool BOUND = false>
 __device__ __forceinline__ void balanced_walk(BalLds &L, const unsigned (&rs)[RC],
                                               const unsigned (&re)[RC], unsigned lane,
                                               const float4 *pts, const float4 *ubase, float qx, float qy,
                                               float qz, unsigned long long &best, unsigned &cost,
-                                              unsigned long long *prof, bool filter) {
+                                              unsigned long long *prof, bool filter, Bound *bnd = nullptr) {
     const unsigned long long prof_t0 = COST ? clock64() : 0ull;
     unsigned len[RC], t = 0, longest = 0;
 #pragma unroll
@@ -347,6 +365,7 @@ __device__ __forceinline__ void balanced_walk(BalLds &L, const unsigned (&rs)[RC
     if (T > (unsigned) kBalCap) {  // too much for the list: every lane for itself
 #pragma unroll
         for (int u = 0; u < RC; ++u) best = scan_run(pts, rs[u], re[u], qx, qy, qz, best);
+        if constexpr (BOUND) bnd->ok = false;  // (no runner-up tracked on this path)
         return;
     }
     unsigned off = incl - t;
@@ -369,7 +388,14 @@ __device__ __forceinline__ void balanced_walk(BalLds &L, const unsigned (&rs)[RC
     // the owner's best d2 at the start of the walk rides along with its query: a worker builds the four
     // 64-bit keys and issues the LDS atomic only when one of its candidates can get under it -- rarely,
     // once the clouds are close (the seed is usually the neighbour).  A stale bound lets more through, never less.
-    reinterpret_cast<unsigned *>(&L.q[lane])[3] = filter ? (unsigned) (best >> 32) : 0x7F800000u;
+    if constexpr (BOUND) {
+        // ... under the prune radius, that is: runner-up candidates must get through too
+        const float pr = bnd->prune_r(best);
+        bnd->lds[lane] = bnd->second;
+        reinterpret_cast<unsigned *>(&L.q[lane])[3] = __float_as_uint(pr * pr);
+    } else {
+        reinterpret_cast<unsigned *>(&L.q[lane])[3] = filter ? (unsigned) (best >> 32) : 0x7F800000u;
+    }
     __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave execute in order; this only stops the compiler)
     for (unsigned k0 = 0; k0 < T; k0 += 64u) {
         const unsigned k = k0 + lane;
@@ -386,12 +412,29 @@ __device__ __forceinline__ void balanced_walk(BalLds &L, const unsigned (&rs)[RC
                 const unsigned long long k0_ = make_key(d0, __float_as_uint(t0.w)), k1_ = make_key(d1, __float_as_uint(t1.w));
                 const unsigned long long k2_ = make_key(d2, __float_as_uint(t2.w)), k3_ = make_key(d3, __float_as_uint(t3.w));
                 const unsigned long long a = k0_ < k1_ ? k0_ : k1_, b = k2_ < k3_ ? k2_ : k3_;
-                atomicMin(&L.best[owner], a < b ? a : b);
+                if constexpr (BOUND) {
+                    // the trip's smallest key contends for the owner's best; whichever of the two loses
+                    // is a runner-up candidate, and so is the trip's own second smallest (the global
+                    // runner-up is one trip's winner or the best trip's second).  Meeting the same point
+                    // again (old == mine: the seed, or a point read past a run's end) changes nothing.
+                    const unsigned long long mn = a < b ? a : b;
+                    const unsigned u0 = __float_as_uint(d0), u1 = __float_as_uint(d1), u2 = __float_as_uint(d2),
+                                   u3 = __float_as_uint(d3);
+                    const unsigned lo01 = min(u0, u1), hi01 = max(u0, u1), lo23 = min(u2, u3), hi23 = max(u2, u3);
+                    const unsigned sec = min(max(lo01, lo23), min(hi01, hi23));
+                    const unsigned long long old = atomicMin(&L.best[owner], mn);
+                    unsigned push = sec;
+                    if (old != mn) push = min(push, (unsigned) ((old > mn ? old : mn) >> 32));
+                    atomicMin(&bnd->lds[owner], push);
+                } else {
+                    atomicMin(&L.best[owner], a < b ? a : b);
+                }
             }
         }
     }
     __builtin_amdgcn_wave_barrier();
     best = L.best[lane];
+    if constexpr (BOUND) bnd->second = bnd->lds[lane];
     if constexpr (COST) {
         prof[0] += clock64() - prof_t0;  // walk (list building + rounds)
         prof[1] += (T + 63u) / 64u;      // rounds
@@ -400,12 +443,13 @@ __device__ __forceinline__ void balanced_walk(BalLds &L, const unsigned (&rs)[RC
 }
 
 // scan_box with wave-uniform loops (see above); `live` = this lane has a search of its own going
-template <bool COST, int RC>
+template <bool COST, int RC, bool BOUND = false>
 __device__ __forceinline__ unsigned long long scan_box_bal(const GridDev &g, bool live, float qx, float qy,
                                                            float qz, float r, unsigned long long best,
                                                            float *margin, BalLds &L, unsigned lane,
                                                            bool allow_layered, const float4 *ubase,
-                                                           unsigned &cost, unsigned long long *prof, bool filter) {
+                                                           unsigned &cost, unsigned long long *prof, bool filter,
+                                                           Bound *bnd = nullptr) {
     const float big = 4.0e6f;
     const float fx = fminf(fmaxf((qx - g.ox) * g.inv_h, -big), big);
     const float fy = fminf(fmaxf((qy - g.oy) * g.inv_h, -big), big);
@@ -430,7 +474,13 @@ __device__ __forceinline__ unsigned long long scan_box_bal(const GridDev &g, boo
             re[u] = ldc(g.cell_start, a1[u]);
         }
         if constexpr (COST) cost += has ? 1u << 16 : 0u;
-        balanced_walk<COST, RC>(L, rs, re, lane, g.pts, ubase, qx, qy, qz, best, cost, prof, filter);
+        balanced_walk<COST, RC, BOUND>(L, rs, re, lane, g.pts, ubase, qx, qy, qz, best, cost, prof, filter, bnd);
+    };
+    // radius (cell units) beyond which a point cannot matter: the best distance so far -- or, with
+    // runner-up tracking, the prune radius
+    auto ball_r = [&]() -> float {
+        if constexpr (BOUND) return bnd->prune_r(best) * g.inv_h * 1.00001f;
+        else return __builtin_amdgcn_sqrtf(__uint_as_float((unsigned) (best >> 32))) * g.inv_h * 1.00001f;
     };
     const bool layered =
         allow_layered && __popcll(__ballot(has && (yb - ya + 1) * (zb - za + 1) > kLayeredRows)) >= 8;
@@ -439,8 +489,7 @@ __device__ __forceinline__ unsigned long long scan_box_bal(const GridDev &g, boo
             const int zz = za + kz;
             const bool zact = has && zz <= zb;
             if (__ballot(zact) == 0ull) break;
-            const float Rb =
-                __builtin_amdgcn_sqrtf(__uint_as_float((unsigned) (best >> 32))) * g.inv_h * 1.00001f;
+            const float Rb = ball_r();
             const float lim = Rb + g.slack;
             const float lim2 = lim * lim, c0 = Rb * Rb + 2.f * g.slack * lim;
             const float rz = fmaxf(fmaxf((float) zz - fz, fz - (float) (zz + 1)), 0.f);
@@ -472,8 +521,7 @@ __device__ __forceinline__ unsigned long long scan_box_bal(const GridDev &g, boo
     }
     int yy = ya, zz = has ? za : zb + 1;  // row cursor; a lane without rows is past its last one
     while (__ballot(zz <= zb) != 0ull) {
-        const float Rb =
-            __builtin_amdgcn_sqrtf(__uint_as_float((unsigned) (best >> 32))) * g.inv_h * 1.00001f;
+        const float Rb = ball_r();
         const float lim = Rb + g.slack;
         const float lim2 = lim * lim, c0 = Rb * Rb + 2.f * g.slack * lim;
         unsigned a0[RC], a1[RC];
@@ -581,6 +629,53 @@ __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, fl
 // points this rank handled).  Summing them here deletes a 40 MB stream and a launch per iteration.
 //
 // (the wave reduction by recursive halving: wm_wave.hpp)
+
+// this lane's terms of the iteration's sums (same arithmetic as k_icp_stats, wm_icp.hip)
+template <int STATS>
+__device__ __forceinline__ void icp_terms(double (&a)[kAcc], bool mine, bool matched, float qx, float qy, float qz,
+                                          float bqx, float bqy, float bqz, float d2) {
+#pragma unroll
+    for (int k = 0; k < kAcc; ++k) a[k] = 0.0;
+    if (mine) {
+        a[17] = 1.0;
+        if (matched) {
+            const double px = qx, py = qy, pz = qz, tx = bqx, ty = bqy, tz = bqz;
+            a[0] = 1.0;
+            a[1] = px;
+            a[2] = py;
+            a[3] = pz;
+            if constexpr (STATS == WM_ICP_SVD) {
+                a[4] = tx;
+                a[5] = ty;
+                a[6] = tz;
+                a[7] = tx * px;
+                a[8] = tx * py;
+                a[9] = tx * pz;
+                a[10] = ty * px;
+                a[11] = ty * py;
+                a[12] = ty * pz;
+                a[13] = tz * px;
+                a[14] = tz * py;
+                a[15] = tz * pz;
+            } else {
+                const double rx = px - tx, ry = py - ty, rz = pz - tz;
+                a[4] = py * py + pz * pz;
+                a[5] = -px * py;
+                a[6] = -px * pz;
+                a[7] = px * px + pz * pz;
+                a[8] = -py * pz;
+                a[9] = px * px + py * py;
+                a[10] = rx;
+                a[11] = ry;
+                a[12] = rz;
+                a[13] = py * rz - pz * ry;
+                a[14] = pz * rx - px * rz;
+                a[15] = px * ry - py * rx;
+            }
+            a[16] = (double) d2;
+        }
+    }
+}
 
 // One lane per query: a certified radius search over a ladder of uniform grids
 // (cell size x2 per level).
@@ -789,7 +884,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
             bqy = c.y;
             bqz = c.z;
         }
-        match_pt[i_e] = make_float4(bqx, bqy, bqz, 0.f);
+        match_pt[i_e] = make_float4(bqx, bqy, bqz, __uint_as_float((unsigned) best));  // (.w: the match's index, for k_nn_cert)
     }
     if (lane == 0 && n_heavy) atomicAdd(&st->queue_count[1], n_heavy);  // stats only
     const unsigned long long prof_store = COST ? clock64() : 0ull;
@@ -797,49 +892,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
         if (active) cost_out[i_e] = mine ? (cost | (heavy ? 0x80000000u : 0u)) : 0u;
     }
     if constexpr (STATS >= 0) {
-        // this lane's terms (same arithmetic as k_icp_stats, wm_icp.hip)
         double a[kAcc];
-#pragma unroll
-        for (int k = 0; k < kAcc; ++k) a[k] = 0.0;
-        if (mine) {
-            a[17] = 1.0;
-            if ((unsigned) best != kNoIdx) {
-                const double px = qx, py = qy, pz = qz, tx = bqx, ty = bqy, tz = bqz;
-                a[0] = 1.0;
-                a[1] = px;
-                a[2] = py;
-                a[3] = pz;
-                if constexpr (STATS == WM_ICP_SVD) {
-                    a[4] = tx;
-                    a[5] = ty;
-                    a[6] = tz;
-                    a[7] = tx * px;
-                    a[8] = tx * py;
-                    a[9] = tx * pz;
-                    a[10] = ty * px;
-                    a[11] = ty * py;
-                    a[12] = ty * pz;
-                    a[13] = tz * px;
-                    a[14] = tz * py;
-                    a[15] = tz * pz;
-                } else {
-                    const double rx = px - tx, ry = py - ty, rz = pz - tz;
-                    a[4] = py * py + pz * pz;
-                    a[5] = -px * py;
-                    a[6] = -px * pz;
-                    a[7] = px * px + pz * pz;
-                    a[8] = -py * pz;
-                    a[9] = px * px + py * py;
-                    a[10] = rx;
-                    a[11] = ry;
-                    a[12] = rz;
-                    a[13] = py * rz - pz * ry;
-                    a[14] = pz * rx - px * rz;
-                    a[15] = px * ry - py * rx;
-                }
-                a[16] = (double) __uint_as_float((unsigned) (best >> 32));
-            }
-        }
+        icp_terms<STATS>(a, mine, (unsigned) best != kNoIdx, qx, qy, qz, bqx, bqy, bqz,
+                         __uint_as_float((unsigned) (best >> 32)));
         acc_halve<kAcc, 32>(a, lane);
         const int comp = acc_comp_of_lane(lane);
         if (comp >= 0) partials[(size_t) row * kAcc + comp] = a[0];
@@ -856,6 +911,256 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
             atomicAdd(&phase_out[6], t_end - prof_store);
             atomicAdd(&phase_out[7], 1ull);
         }
+    }
+}
+
+// ------------------------------------------------- certified correspondences (late iterations)
+// Once the clouds are nearly aligned an ICP step moves a source point by far less than the spacing of
+// the target, and almost every query keeps its neighbour.  That can be PROVED per query without a
+// search: the last search of the query left, besides its match m, a lower bound s on the distance
+// from the query to every target point other than m (runner-up tracking, `Bound` above); every pose
+// since has moved the query by a known distance, which is taken off s.  If now
+//     |q - m| < s        (with float-rounding cushions)
+// then every other point is strictly farther than m: m is the exact nearest neighbour, ties
+// included, and the query is SETTLED by a stream read (source point, match, bound: 36 B) and a
+// stream write (key, bound: 12 B).  Queries that fail the test are compacted and searched by the
+// same wave with the pooled walk of k_nn_grid, pruning with min(runner-up, best + pad) so that the
+// bound they leave is worth something (pad = pad_mul x the query's last displacement, at most
+// pad_frac x its seed distance).  Same keys, bit for bit, as a full search of every query.
+//
+// One wave per workgroup handles NB x 64 consecutive (Morton-ordered) queries:
+//   phase 1  NB batches of 64: certificate test, settled queries stored, their terms of the
+//            iteration's sums reduced (recursive halving) and accumulated in the component lanes;
+//   phase 2  the unsettled queries of all batches, listed in LDS in query order, in chunks of 64:
+//            the search (k_nn_grid's pass loop with runner-up tracking), stores, sums.
+// One row of partial sums per workgroup.  bounds_valid = 0: no usable bounds (the previous
+// iteration was searched by k_nn_grid): every query is searched and leaves its bound.
+template <int STATS, int NB>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+    k_nn_cert(const LevelsDev *__restrict__ lv, const float4 *__restrict__ src, unsigned n,
+              IcpDevState *__restrict__ st, float thr_d2, unsigned long long *__restrict__ keys,
+              float4 *__restrict__ match_pt, float *__restrict__ bound, const float4 *__restrict__ tgt_orig,
+              float r_light_cells, float lane_lf, float coop_lf, float r0_cells, unsigned xcd_chunk,
+              double *__restrict__ partials, int bounds_valid, float pad_mul, float pad_frac,
+              unsigned *__restrict__ uns_count) {
+    if (st->done) return;
+    __shared__ BalLds L;
+    __shared__ unsigned s_second[64];
+    __shared__ unsigned short s_list[64 * NB];
+    const unsigned lane = threadIdx.x & 63u;
+    const int Ln = lv->n;
+    const float h0 = lv->g[0].h;
+    const float rmax = sqrtf(thr_d2) * 1.0001f + 1e-6f;
+    const float r_light = r_light_cells * h0;
+    const bool have_prev = st->have_prev != 0;
+    const bool valid = bounds_valid != 0 && have_prev;
+    const unsigned row = xcd_chunk ? xcd_remap_chunked(blockIdx.x, xcd_chunk) : xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned base = row * (64u * NB);
+    const int comp = acc_comp_of_lane(lane);
+    double rowacc = 0.0;
+    unsigned n_uns = 0;  // (wave-uniform)
+    // ---- phase 1: the certificate
+    {
+        float4 p[NB], mp[NB];
+        float sb[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {  // every load of the phase is issued before the first use
+            const unsigned i = base + (unsigned) j * 64u + lane;
+            p[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            mp[j] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoIdx));
+            sb[j] = 0.f;
+            if (i < n && valid) {
+                p[j] = src[i];
+                mp[j] = match_pt[i];
+                sb[j] = bound[i];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const unsigned i = base + (unsigned) j * 64u + lane;
+            const bool act = i < n;
+            bool settled = false;
+            float qx = 0.f, qy = 0.f, qz = 0.f, d2 = 0.f;
+            if (act && valid) {
+                float ox, oy, oz;
+                xform(st->Tf, p[j], qx, qy, qz);
+                xform(st->Tf_prev, p[j], ox, oy, oz);
+                const float ex = qx - ox, ey = qy - oy, ez = qz - oz;
+                const float disp = sqrtf(ex * ex + ey * ey + ez * ez);
+                const unsigned idx = __float_as_uint(mp[j].w);
+                d2 = canon_d2(qx, qy, qz, mp[j]);
+                const float s_new = sb[j] - disp * 1.0001f - 1e-6f;
+                settled = idx != kNoIdx && d2 <= thr_d2 && sqrtf(d2) * 1.0001f + 1e-6f < s_new;
+                if (settled) {
+                    keys[i] = make_key(d2, idx);
+                    bound[i] = s_new;
+                }
+            }
+            const unsigned long long smask = __ballot(settled);
+            if constexpr (STATS >= 0) {
+                if (smask != 0ull) {
+                    double a[kAcc];
+                    icp_terms<STATS>(a, settled, settled, qx, qy, qz, mp[j].x, mp[j].y, mp[j].z, d2);
+                    acc_halve<kAcc, 32>(a, lane);
+                    rowacc += comp >= 0 ? a[0] : 0.0;
+                }
+            }
+            const bool uns = act && !settled;
+            const unsigned long long umask = __ballot(uns);
+            if (uns) {
+                const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned) (umask >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo((unsigned) umask, 0u));
+                s_list[n_uns + before] = (unsigned short) ((unsigned) j * 64u + lane);
+            }
+            n_uns += (unsigned) __popcll(umask);
+        }
+    }
+    if (uns_count && lane == 0 && n_uns) atomicAdd(&uns_count[blockIdx.x & 63u], n_uns);  // developer statistics
+    __builtin_amdgcn_wave_barrier();
+    // ---- phase 2: search what is left, 64 queries at a time
+    unsigned cost = 0;
+    unsigned long long prof[3] = {0ull, 0ull, 0ull};
+    for (unsigned c0 = 0; c0 < n_uns; c0 += 64u) {
+        const bool mine = c0 + lane < n_uns;
+        const unsigned i = base + (mine ? (unsigned) s_list[c0 + lane] : 0u);
+        float qx = 0.f, qy = 0.f, qz = 0.f, r = 0.f, pad = 0.f;
+        float bqx = 0.f, bqy = 0.f, bqz = 0.f;
+        unsigned long long best = make_key(thr_d2, kNoIdx);
+        unsigned long long seeded = best;
+        bool heavy = false;
+        if (mine) {
+            const float4 p = src[i];
+            float4 tp = make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoIdx));
+            if (have_prev) tp = match_pt[i];
+            xform(st->Tf, p, qx, qy, qz);
+            r = r0_cells * h0;
+            if (have_prev) {
+                const unsigned pidx = __float_as_uint(tp.w);
+                r = rmax;
+                if (pidx != kNoIdx) {
+                    const float d2b = canon_d2(qx, qy, qz, tp);
+                    if (d2b <= thr_d2) {
+                        best = seeded = make_key(d2b, pidx);
+                        bqx = tp.x;
+                        bqy = tp.y;
+                        bqz = tp.z;
+                        float ox, oy, oz;
+                        xform(st->Tf_prev, p, ox, oy, oz);
+                        const float ex = qx - ox, ey = qy - oy, ez = qz - oz;
+                        const float sd = sqrtf(d2b);
+                        pad = fminf(pad_mul * sqrtf(ex * ex + ey * ey + ez * ez), pad_frac * sd);
+                        r = fmaxf(sd * 1.0001f + 1e-6f, 0.05f * h0) + pad;
+                    }
+                }
+            }
+            r = fminf(r, rmax);
+            heavy = r > r_light;
+        }
+        Bound bnd;
+        bnd.second = 0x7F800000u;
+        bnd.pad = pad;
+        bnd.lds = s_second;
+        bnd.ok = true;
+        float margin_last = 0.f;
+        L.q[lane] = make_float4(qx, qy, qz, 0.f);
+        L.seeded[lane] = seeded;
+        L.bq[0][lane] = bqx;
+        L.bq[1][lane] = bqy;
+        L.bq[2][lane] = bqz;
+        asm volatile("" ::: "memory");
+        bool live = mine && !heavy;
+        for (int pass = 0; pass < 32 && __ballot(live) != 0ull; ++pass) {
+            int l = 0;
+            while (l < Ln - 1 && lv->g[l].h < lane_lf * r) ++l;
+            const unsigned long long lv_mask = __ballot(live);
+            const int l0 = __builtin_amdgcn_readlane(l, __ffsll((long long) lv_mask) - 1);
+            float margin;
+            if (__ballot(live && l != l0) == 0ull) {
+                const GridDev g = lv->g[l0];
+                best = scan_box_bal<false, kBalRowChunk, true>(g, live, qx, qy, qz, r, best, &margin, L, lane, have_prev,
+                                                                g.pts, cost, prof, true, &bnd);
+            } else {
+                const GridDev g = lv->g[l];
+                L.base[lane] = (unsigned long long) g.pts;
+                best = scan_box_bal<false, kBalRowChunk, true>(g, live, qx, qy, qz, r, best, &margin, L, lane, have_prev,
+                                                                nullptr, cost, prof, true, &bnd);
+            }
+            if (live) {
+                const float bd2 = __uint_as_float((unsigned) (best >> 32));
+                margin_last = margin;
+                if (margin > 0.f && (bd2 <= margin * margin || thr_d2 <= margin * margin)) {
+                    live = false;
+                } else {
+                    const float rn = ((unsigned) best != kNoIdx) ? sqrtf(bd2) * 1.0001f + 1e-6f + pad : 2.0f * r;
+                    r = fminf(fmaxf(rn, 1.25f * r), rmax);
+                    heavy = r > r_light;
+                    live = !heavy;
+                }
+            }
+        }
+        // cooperative phase for radii beyond r_light (k_nn_grid's; no bound comes out of it)
+        unsigned long long todo = __ballot(heavy);
+        float seed = 0.f;
+        while (todo) {
+            const int sl = __ffsll((long long) todo) - 1;
+            todo &= todo - 1;
+            const float ux = rl_f(qx, sl), uy = rl_f(qy, sl), uz = rl_f(qz, sl);
+            float ur = rl_f(r, sl);
+            unsigned long long ub = ((unsigned long long) rl_u((unsigned) (best >> 32), sl) << 32) |
+                                    rl_u((unsigned) best, sl);
+            if ((unsigned) ub == kNoIdx && seed > ur) ur = fminf(seed, rmax);
+            for (int pass = 0; pass < 64; ++pass) {
+                int l = 0;
+                while (l < Ln - 1 && lv->g[l].h < coop_lf * ur) ++l;
+                const GridDev g = lv->g[l];
+                float margin;
+                ub = coop_scan_box(g, ux, uy, uz, ur, ub, lane, &margin);
+                const float bd2 = __uint_as_float((unsigned) (ub >> 32));
+                if (margin > 0.f && (bd2 <= margin * margin || thr_d2 <= margin * margin)) break;
+                if (ur >= rmax) break;
+                const float rn = ((unsigned) ub != kNoIdx) ? sqrtf(bd2) * 1.0001f + 1e-6f : 2.0f * ur;
+                ur = fminf(fmaxf(rn, 1.25f * ur), rmax);
+            }
+            seed = ((unsigned) ub != kNoIdx) ? 1.25f * sqrtf(__uint_as_float((unsigned) (ub >> 32))) : ur;
+            if ((int) lane == sl) {
+                best = ub;
+                bnd.ok = false;
+            }
+        }
+        asm volatile("" ::: "memory");
+        seeded = L.seeded[lane];
+        bqx = L.bq[0][lane];
+        bqy = L.bq[1][lane];
+        bqz = L.bq[2][lane];
+        if (mine) {
+            keys[i] = best;
+            if (best != seeded && (unsigned) best != kNoIdx) {
+                const f4v c = ((gp_f4) tgt_orig)[(unsigned) best];
+                bqx = c.x;
+                bqy = c.y;
+                bqz = c.z;
+            }
+            match_pt[i] = make_float4(bqx, bqy, bqz, __uint_as_float((unsigned) best));
+            // every point but the match is farther than: the runner-up seen, the radius pruned with, and
+            // the faces of the last box scanned
+            float s = 0.f;
+            if (bnd.ok && !heavy && (unsigned) best != kNoIdx && margin_last > 0.f) {
+                const float bd = sqrtf(__uint_as_float((unsigned) (best >> 32)));
+                s = fminf(fminf(sqrtf(__uint_as_float(bnd.second)), bd + pad), margin_last) * 0.9999f - 1e-6f;
+            }
+            bound[i] = s;
+        }
+        if constexpr (STATS >= 0) {
+            double a[kAcc];
+            icp_terms<STATS>(a, mine, (unsigned) best != kNoIdx, qx, qy, qz, bqx, bqy, bqz,
+                             __uint_as_float((unsigned) (best >> 32)));
+            acc_halve<kAcc, 32>(a, lane);
+            rowacc += comp >= 0 ? a[0] : 0.0;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (STATS >= 0) {
+        if (comp >= 0) partials[(size_t) row * kAcc + comp] = rowacc;
     }
 }
 
@@ -910,7 +1215,7 @@ __global__ void __launch_bounds__(kBlock)
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const unsigned idx = (unsigned) keys[i];
-    match_pt[i] = idx == kNoIdx ? make_float4(0.f, 0.f, 0.f, 0.f) : tgt[idx];
+    match_pt[i] = idx == kNoIdx ? make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoIdx)) : tgt[idx];
 }
 
 // largest float whose value, compared as PCL does ((double) d2 > max_corr^2 ->
@@ -982,6 +1287,57 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
         if (bal) launch_nn_grid_t<WM_ICP_GN6, true>(ctx, blocks, thr_d2, xcd_chunk);
         else launch_nn_grid_t<WM_ICP_GN6, false>(ctx, blocks, thr_d2, xcd_chunk);
     }
+    if (ev1) WM_HIP(ctx, hipEventRecord(ev1, ctx->stream));
+    if (ev2) WM_HIP(ctx, hipEventRecord(ev2, ctx->stream));
+    WM_HIP(ctx, hipGetLastError());
+    return WM_OK;
+}
+
+template <int STATS, int NB>
+static void launch_nn_cert_t(wm_ctx *ctx, unsigned blocks, float thr_d2, unsigned xcd_chunk, bool bounds_valid) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_cert<STATS, NB>), dim3(blocks), dim3(64), 0, ctx->stream,
+                       ctx->d_levels.as<LevelsDev>(), ctx->src_sorted.as<float4>(), (unsigned) ctx->n_src,
+                       ctx->d_state.as<IcpDevState>(), thr_d2, ctx->keys.as<unsigned long long>(),
+                       ctx->match_pt.as<float4>(), ctx->nn_bound.as<float>(), ctx->tgt_orig.as<float4>(),
+                       ctx->tune_r_light, ctx->tune_lane_lf, ctx->tune_coop_lf, ctx->tune_r0, xcd_chunk,
+                       ctx->partials.as<double>(), bounds_valid ? 1 : 0, ctx->tune_cert_pad_mul,
+                       ctx->tune_cert_pad_frac,
+                       ctx->cert_count.p && ctx->cert_log_iter < ctx->cert_log_cap
+                           ? ctx->cert_count.as<unsigned>() + 64 * (size_t) ctx->cert_log_iter : nullptr);
+}
+
+template <int NB>
+static void launch_nn_cert_nb(wm_ctx *ctx, unsigned blocks, float thr_d2, unsigned xcd_chunk, bool bounds_valid,
+                              int stats_mode) {
+    if (stats_mode < 0) launch_nn_cert_t<-1, NB>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid);
+    else if (stats_mode == WM_ICP_SVD) launch_nn_cert_t<WM_ICP_SVD, NB>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid);
+    else launch_nn_cert_t<WM_ICP_GN6, NB>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid);
+}
+
+int launch_nn_cert(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2, int stats_mode,
+                   unsigned *rows_out, bool bounds_valid) {
+    const unsigned n = (unsigned) ctx->n_src;
+    if (rows_out) *rows_out = 0;
+    if (n == 0) return WM_OK;
+    const int nb = ctx->tune_cert_nb == 2 ? 2 : (ctx->tune_cert_nb == 8 ? 8 : 4);
+    const unsigned per = 64u * (unsigned) nb;
+    unsigned blocks = (n + per - 1u) / per;
+    blocks = (blocks + 7u) & ~7u;  // xcd_remap needs a multiple of 8
+    unsigned xcd_chunk = 0;
+    if (blocks >= 256u) {  // XCDs take turns in chunks of 8 workgroups (see xcd_remap_chunked)
+        xcd_chunk = 8u;
+        blocks = (blocks + 63u) / 64u * 64u;
+    }
+    WM_HIP(ctx, ctx->nn_bound.reserve(((size_t) n + 64) * sizeof(float)));
+    if (stats_mode >= 0) {
+        WM_HIP(ctx, ctx->partials.reserve((size_t) blocks * kAcc * sizeof(double)));
+        if (rows_out) *rows_out = blocks;
+    }
+    if (ev0) WM_HIP(ctx, hipEventRecord(ev0, ctx->stream));
+    if (nb == 2) launch_nn_cert_nb<2>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid, stats_mode);
+    else if (nb == 8) launch_nn_cert_nb<8>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid, stats_mode);
+    else launch_nn_cert_nb<4>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid, stats_mode);
+    if (ctx->cert_count.p && ctx->cert_log_iter < ctx->cert_log_cap) ctx->cert_log_iter++;
     if (ev1) WM_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     if (ev2) WM_HIP(ctx, hipEventRecord(ev2, ctx->stream));
     WM_HIP(ctx, hipGetLastError());

@@ -56,7 +56,7 @@ for cfg in sys.argv[1:] or ["-"]:
     it = ctx.iteration_times() * 1e3
     step(1)
     it = ctx.iteration_times() * 1e3
-    print('    nn us by iteration:', ' '.join('%d:%.0f' % (k, it[k]) for k in (0, 1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 20, 30, 49) if k < len(it)), flush=True)
+    print('    cert launches %d; nn us by iteration:' % r.get("cert_launches", -1), ' '.join('%d:%.0f' % (k, it[k]) for k in range(len(it))), flush=True)
     c = ctx.solve_cycles()
     print('    solve kernel cycles: rows+stage %d, expand %d, pre-svd %d, svd %d, rest-of-apply %d' % (
         c[1] - c[0], c[2] - c[1], c[4] - c[2], c[5] - c[4], c[3] - c[5]), flush=True)
