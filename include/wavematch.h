@@ -239,6 +239,9 @@ int wm_set_option(wm_ctx *ctx, const char *name, double value);
 /* developer: out == NULL arms a log of `iterations` launches (0 disarms); otherwise writes, per
  * launch of the certificate kernel since, how many queries it had to search; returns the count */
 int wm_debug_cert_log(wm_ctx *ctx, int iterations, unsigned *out, int cap);
+/* developer (armed by wm_debug_cert_log with WM_CERT_PROF set): 64 words per launch -- 16 cycle stamps
+ * of each of four sampled workgroups (see k_nn_cert) */
+int wm_debug_cert_prof(wm_ctx *ctx, unsigned long long *out, int cap);
 /* Per-iteration device time (ms) of the correspondence kernel in the last
  * wm_icp_align call that ran with profile >= 1; returns the number written. */
 int wm_get_iteration_times(wm_ctx *ctx, float *nn_ms, int cap);

@@ -105,6 +105,7 @@ def lib():
         L.wm_set_grid_cell.argtypes = [C.c_void_p, C.c_float]
         L.wm_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         L.wm_debug_cert_log.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint), C.c_int]
+        L.wm_debug_cert_prof.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
         L.wm_cloud_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.wm_icp_default_params.argtypes = [C.POINTER(IcpParams)]
         L.wm_icp_default_params.restype = None
@@ -293,6 +294,11 @@ class Context:
         out = (C.c_uint * 4096)()
         k = lib().wm_debug_cert_log(self._h, 0, out, 4096)
         return [int(out[i]) for i in range(max(k, 0))]
+
+    def cert_prof(self):
+        out = (C.c_uint64 * (64 * 128))()
+        k = lib().wm_debug_cert_prof(self._h, out, 128)
+        return np.array(out[:64 * max(k, 0)], dtype=np.float64).reshape(-1, 4, 16)  # [launch][sampled workgroup][stamp]
 
     def set_grid_cell(self, h):
         self._check(lib().wm_set_grid_cell(self._h, float(h)), "wm_set_grid_cell")

@@ -381,7 +381,7 @@ static int prepare_work(wm_ctx *ctx) {
 static void init_state(IcpDevState *s, const double *T, const wm_icp_params *p, double prev_mse) {
     memset(s, 0, sizeof(*s));
     for (int k = 0; k < 16; ++k) s->T[k] = T[k];
-    for (int k = 0; k < 12; ++k) s->Tf[k] = s->Tf_prev[k] = (float) T[k];
+    for (int k = 0; k < 12; ++k) s->Tf[k] = s->Tf_search[k] = (float) T[k];
     mat4_identity(s->Tk);
     s->prev_mse = prev_mse;
     if (p) {
@@ -725,6 +725,10 @@ int wm_ctx_create(wm_ctx **out, int device) {
     if (const char *e = getenv("WM_TUNE_FAST_SOLVE")) ctx->tune_fast_solve = atoi(e);
     if (const char *e = getenv("WM_TUNE_CERT_FROM")) ctx->tune_cert_from = atoi(e);
     if (const char *e = getenv("WM_TUNE_CERT_NB")) ctx->tune_cert_nb = atoi(e);
+    if (const char *e = getenv("WM_TUNE_CERT_RC")) ctx->tune_cert_rc = atoi(e);
+    if (const char *e = getenv("WM_TUNE_CERT_DBG_SKIP")) ctx->tune_cert_dbg_skip = atoi(e);
+    if (const char *e = getenv("WM_TUNE_NN_EARLY_LOADS")) ctx->tune_nn_early_loads = atoi(e);
+    if (const char *e = getenv("WM_TUNE_NN_NT_STORES")) ctx->tune_nn_nt_stores = atoi(e);
     if (const char *e = getenv("WM_TUNE_CERT_DISP")) {
         const float v = (float) atof(e);
         if (v > 0) ctx->tune_cert_disp = v;
@@ -791,7 +795,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
                       &ctx->src_grid.cell_start, &ctx->vg_idx, &ctx->vg_idx2, &ctx->vg_perm,
                       &ctx->vg_perm2, &ctx->vg_tmp, &ctx->vg_seg, &ctx->io_a, &ctx->io_b, &ctx->ds_ref,
                       &ctx->ds_tgt, &ctx->match_ref, &ctx->match_tgt,
-                      &ctx->partials, &ctx->partials2, &ctx->nn_bound, &ctx->cert_count, &ctx->cost_log, &ctx->phase_log, &ctx->shard_ref, &ctx->shard_tgt,
+                      &ctx->partials, &ctx->partials2, &ctx->nn_bound, &ctx->cert_count, &ctx->cert_prof, &ctx->cost_log, &ctx->phase_log, &ctx->shard_ref, &ctx->shard_tgt,
                       &ctx->shard_ref_band, &ctx->shard_tgt_band, &ctx->shard_misc, &ctx->shard_flags, &ctx->shard_pos_t,
                       &ctx->shard_pos_s, &ctx->shard_stats, &ctx->ndt_sum_dev, &ctx->corr_tmp_idx, &ctx->corr_tmp_d2, &ctx->d_state};
     for (DevBuf *b : bufs) b->release();
@@ -1039,6 +1043,7 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
         if (e3) WM_HIP(ctx, hipEventRecord(e3, ctx->stream));
         WM_HIP(ctx, hipGetLastError());
     }
+    if (ctx->cert_launches > 0) WM_TRY(launch_fix_keys(ctx, thr));
     WM_TRY(download_state(ctx));
     WM_HIP(ctx, hipEventRecord(ctx->ev_b, ctx->stream));
     WM_HIP(ctx, hipEventSynchronize(ctx->ev_b));
@@ -1379,6 +1384,7 @@ int wm_set_option(wm_ctx *ctx, const char *name, double value) {
     const std::string k(name);
     if (k == "cert_from") ctx->tune_cert_from = (int) value;
     else if (k == "cert_nb") ctx->tune_cert_nb = (int) value;
+    else if (k == "cert_rc") ctx->tune_cert_rc = (int) value;
     else if (k == "cert_disp" && value > 0) ctx->tune_cert_disp = (float) value;
     else if (k == "cert_pad_mul" && value >= 0) ctx->tune_cert_pad_mul = (float) value;
     else if (k == "cert_pad_frac" && value >= 0) ctx->tune_cert_pad_frac = (float) value;
@@ -1399,6 +1405,10 @@ int wm_debug_cert_log(wm_ctx *ctx, int iterations, unsigned *out, int cap) {
         }
         WM_HIP(ctx, ctx->cert_count.reserve((size_t) iterations * 64 * sizeof(unsigned)));
         WM_HIP(ctx, hipMemsetAsync(ctx->cert_count.p, 0, (size_t) iterations * 64 * sizeof(unsigned), ctx->stream));
+        if (getenv("WM_CERT_PROF")) {
+            WM_HIP(ctx, ctx->cert_prof.reserve((size_t) iterations * 64 * sizeof(unsigned long long)));
+            WM_HIP(ctx, hipMemsetAsync(ctx->cert_prof.p, 0, (size_t) iterations * 64 * sizeof(unsigned long long), ctx->stream));
+        }
         ctx->cert_log_cap = iterations;
         return WM_OK;
     }
@@ -1410,6 +1420,14 @@ int wm_debug_cert_log(wm_ctx *ctx, int iterations, unsigned *out, int cap) {
         for (int k = 0; k < 64; ++k) t += tmp[(size_t) i * 64 + k];
         out[i] = t;
     }
+    return n;
+}
+
+int wm_debug_cert_prof(wm_ctx *ctx, unsigned long long *out, int cap) {
+    if (!ctx || !out || !ctx->cert_prof.p) return WM_ERR_ARG;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    const int n = ctx->cert_log_iter < cap ? ctx->cert_log_iter : cap;
+    if (n > 0) WM_TRY(copy_to_caller(ctx, out, ctx->cert_prof.p, (size_t) n * 64 * sizeof(unsigned long long)));
     return n;
 }
 

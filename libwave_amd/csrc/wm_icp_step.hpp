@@ -62,6 +62,8 @@ __host__ __device__ inline void icp_apply_stats(IcpDevState *st, const double *s
 #pragma unroll
     for (int k = 0; k < kStatsLen; ++k) stats[k] = stats_in[k];
     const int mode = st->mode;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) st->Tf_search[k] = st->Tf[k];  // (the pose these statistics were searched under)
     const double n = stats[0];
     const double sd2 = mode == WM_ICP_SVD ? stats[kSvdSd2] : stats[kGnSd2];
     const double mse = n > 0 ? sd2 / n : 0.0;
@@ -115,10 +117,7 @@ __host__ __device__ inline void icp_apply_stats(IcpDevState *st, const double *s
         st->step_disp = sqrtf((float) (dx * dx + dy * dy + dz * dz)) + sqrtf((float) fro2) * st->src_radius;
     }
 #pragma unroll
-    for (int k = 0; k < 12; ++k) {
-        st->Tf_prev[k] = st->Tf[k];
-        st->Tf[k] = (float) Tn[k];
-    }
+    for (int k = 0; k < 12; ++k) st->Tf[k] = (float) Tn[k];
     const int iter = st->iter + 1;
     st->iter = iter;
     st->have_prev = 1;

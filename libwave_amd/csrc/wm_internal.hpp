@@ -92,7 +92,7 @@ struct GridLevel {
 struct IcpDevState {
     double T[16];   // cumulative source->target
     float Tf[12];   // float rows 0..2 of T (what the correspondence kernel applies)
-    float Tf_prev[12];  // ... of the previous iteration (k_nn_cert: how far the step moved each query)
+    float Tf_search[12];  // ... the last correspondence search ran under (set by the solve that consumed it): what the keys' d2 refer to
     double Tk[16];  // last incremental step
     double stats[kStatsLen];
     double mse, prev_mse;
@@ -170,8 +170,9 @@ struct wm_ctx {
     wm::DevBuf cost_log;                    // developer: per-query search cost of every iteration (wm_debug_cost_log)
     int cost_log_iter = 0, cost_log_cap = 0;
     wm::DevBuf keys, partials, partials2, corr_tmp_idx, corr_tmp_d2, d_levels;
-    wm::DevBuf nn_bound;                    // float per (sorted) source point: k_nn_cert's lower bound on the distance to every point but the match
+    wm::DevBuf nn_bound;                    // float4 per (sorted) source point, written by k_nn_cert's searches: where the query was (xyz) and a lower bound (w) on its distance, there, to every target point but its match
     wm::DevBuf cert_count;                  // developer: unsettled queries per launch of k_nn_cert ([launch][64] partial counts)
+    wm::DevBuf cert_prof;                   // developer: phase cycle sums per launch of k_nn_cert ([launch][8][8])
     int cert_log_iter = 0, cert_log_cap = 0;
     int cert_launches = 0;                  // of the last align
     unsigned long long *h_pub = nullptr;    // pinned: [0] (done << 63 | iterations finished << 32 | step size bits) of the latest solve, [k] iteration k's own record
@@ -229,6 +230,10 @@ struct wm_ctx {
     float tune_cert_disp = 0.15f;  // ... once a step moves the points by less than this many level-0 cells
     float tune_cert_pad_mul = 8.f, tune_cert_pad_frac = 0.5f;  // runner-up room of a certified search (see k_nn_cert)
     int tune_cert_nb = 4;        // batches of 64 queries per workgroup of k_nn_cert (2, 4 or 8)
+    int tune_cert_rc = 3;        // rows per step of its searches (3 or 6)
+    int tune_cert_dbg_skip = 0;  // developer timing experiment (wrong results): see k_nn_cert
+    int tune_nn_early_loads = 1; // k_nn_grid: the three stream loads issued before the state is looked at
+    int tune_nn_nt_stores = 1;   // search kernels: non-temporal result stores (nothing left dirty in L2 at the kernel boundary)
     int tune_fast_solve = 1;     // experiment knob for the solve kernel
     int tune_spin_us = 80;       // wait_flag: busy-poll this long before polling with yields
     int tune_ndt_blocks = 1024;  // workgroups (= partial rows) of one NDT derivative pass
@@ -326,6 +331,7 @@ int transform_cloud_dev(wm_ctx *ctx, const float4 *in, size_t n, const double T[
 int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2,
                    int stats_mode = -1, unsigned *rows_out = nullptr);
 int launch_nn_brute(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1);
+int launch_fix_keys(wm_ctx *ctx, float thr_d2);  // after certified iterations: every key's distance brought up to date
 // the certificate kernel (late iterations): stats_mode as above; bounds_valid = the previous search of
 // this align was launch_nn_cert too (its per-query bounds are still in ctx->nn_bound)
 int launch_nn_cert(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2, int stats_mode,

@@ -73,6 +73,26 @@ __device__ __forceinline__ float4 ldp(const float4 *p, size_t j) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ unsigned ldc(const unsigned *p, size_t j) { return ((gp_u32) p)[j]; }
+// Result stores.  `nt`: non-temporal -- the line does not stay (dirty) in the XCD's L2, so the kernel
+// boundary behind the search has no write-back to wait for (a search leaves 12-26 MB of results that
+// nothing on this XCD reads again before the next iteration)
+__device__ __forceinline__ void st_f4(float4 *p, float x, float y, float z, float w, bool nt) {
+    f4v v = {x, y, z, w};
+    if (nt) __builtin_nontemporal_store(v, (f4v *) p);
+    else *(f4v *) p = v;
+}
+__device__ __forceinline__ void st_u64(unsigned long long *p, unsigned long long v, bool nt) {
+    if (nt) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+__device__ __forceinline__ void st_f32(float *p, float v, bool nt) {
+    if (nt) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+__device__ __forceinline__ void st_f64(double *p, double v, bool nt) {
+    if (nt) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 __device__ __forceinline__ float canon_d2v(float qx, float qy, float qz, const f4v &t) {
     return canon_d2(qx, qy, qz, make_float4(t.x, t.y, t.z, t.w));
 }
@@ -336,6 +356,7 @@ struct Bound {
     unsigned second;  // d2 bits of the runner-up so far (a point other than the current best)
     float pad;        // metres
     unsigned *lds;    // [64] words of LDS: the runner-ups while the wave's pooled walk is under way
+    float4 *win;      // [64] LDS slots: coordinates (+ index bits) of a candidate that became a query's best
     bool ok;          // false once a path without runner-up tracking has been taken: no bound to offer
     // squared prune radius, as float bits
     __device__ __forceinline__ float prune_r(unsigned long long best) const {
@@ -343,6 +364,55 @@ struct Bound {
         return fminf(b, __builtin_amdgcn_sqrtf(__uint_as_float(second)) * 1.00001f);
     }
 };
+
+// The rounds of a pooled walk: all 64 lanes take trips (owner lane << 26 | offset of four consecutive
+// points) off `items`, whoever's they are, and merge what they find into the owner's slot.
+template <bool BOUND>
+__device__ __forceinline__ void pooled_rounds(BalLds &L, const unsigned *items, unsigned T, unsigned lane,
+                                              const float4 *ubase, Bound *bnd) {
+    for (unsigned k0 = 0; k0 < T; k0 += 64u) {
+        const unsigned k = k0 + lane;
+        if (k < T) {
+            const unsigned it = items[k];
+            const unsigned owner = it >> 26, j = it & 0x3FFFFFFu;
+            const float4 q = L.q[owner];
+            const gp_f4 p = (gp_f4) (ubase ? ubase : (const float4 *) L.base[owner]) + j;
+            const f4v t0 = p[0], t1 = p[1], t2 = p[2], t3 = p[3];
+            const float d0 = canon_d2v(q.x, q.y, q.z, t0), d1 = canon_d2v(q.x, q.y, q.z, t1);
+            const float d2 = canon_d2v(q.x, q.y, q.z, t2), d3 = canon_d2v(q.x, q.y, q.z, t3);
+            const unsigned m = min(min(__float_as_uint(d0), __float_as_uint(d1)), min(__float_as_uint(d2), __float_as_uint(d3)));
+            if (m <= __float_as_uint(q.w)) {  // (d2 >= 0: bit order = numeric order)
+                const unsigned long long k0_ = make_key(d0, __float_as_uint(t0.w)), k1_ = make_key(d1, __float_as_uint(t1.w));
+                const unsigned long long k2_ = make_key(d2, __float_as_uint(t2.w)), k3_ = make_key(d3, __float_as_uint(t3.w));
+                const unsigned long long a = k0_ < k1_ ? k0_ : k1_, b = k2_ < k3_ ? k2_ : k3_;
+                if constexpr (BOUND) {
+                    // the trip's smallest key contends for the owner's best; whichever of the two loses
+                    // is a runner-up candidate, and so is the trip's own second smallest (the global
+                    // runner-up is one trip's winner or the best trip's second).  Meeting the same point
+                    // again (old == mine: the seed, or a point read past a run's end) changes nothing.
+                    const unsigned long long mn = a < b ? a : b;
+                    const unsigned u0 = __float_as_uint(d0), u1 = __float_as_uint(d1), u2 = __float_as_uint(d2),
+                                   u3 = __float_as_uint(d3);
+                    const unsigned lo01 = min(u0, u1), hi01 = max(u0, u1), lo23 = min(u2, u3), hi23 = max(u2, u3);
+                    const unsigned sec = min(max(lo01, lo23), min(hi01, hi23));
+                    const unsigned long long old = atomicMin(&L.best[owner], mn);
+                    unsigned push = sec;
+                    if (old != mn) push = min(push, (unsigned) ((old > mn ? old : mn) >> 32));
+                    atomicMin(&bnd->lds[owner], push);
+                    if (old > mn && bnd->win) {
+                        // a new best: its coordinates go to the owner's slot, tagged with its index, so
+                        // that the owner need not fetch them from memory afterwards (a slot written by
+                        // two winners of one round may hold the loser's: the tag tells)
+                        const f4v c = mn == k0_ ? t0 : (mn == k1_ ? t1 : (mn == k2_ ? t2 : t3));
+                        bnd->win[owner] = make_float4(c.x, c.y, c.z, c.w);
+                    }
+                } else {
+                    atomicMin(&L.best[owner], a < b ? a : b);
+                }
+            }
+        }
+    }
+}
 
 template <bool COST, int RC, bool BOUND = false>
 __device__ __forceinline__ void balanced_walk(BalLds &L, const unsigned (&rs)[RC],
@@ -397,41 +467,7 @@ __device__ __forceinline__ void balanced_walk(BalLds &L, const unsigned (&rs)[RC
         reinterpret_cast<unsigned *>(&L.q[lane])[3] = filter ? (unsigned) (best >> 32) : 0x7F800000u;
     }
     __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave execute in order; this only stops the compiler)
-    for (unsigned k0 = 0; k0 < T; k0 += 64u) {
-        const unsigned k = k0 + lane;
-        if (k < T) {
-            const unsigned it = L.items[k];
-            const unsigned owner = it >> 26, j = it & 0x3FFFFFFu;
-            const float4 q = L.q[owner];
-            const gp_f4 p = (gp_f4) (ubase ? ubase : (const float4 *) L.base[owner]) + j;
-            const f4v t0 = p[0], t1 = p[1], t2 = p[2], t3 = p[3];
-            const float d0 = canon_d2v(q.x, q.y, q.z, t0), d1 = canon_d2v(q.x, q.y, q.z, t1);
-            const float d2 = canon_d2v(q.x, q.y, q.z, t2), d3 = canon_d2v(q.x, q.y, q.z, t3);
-            const unsigned m = min(min(__float_as_uint(d0), __float_as_uint(d1)), min(__float_as_uint(d2), __float_as_uint(d3)));
-            if (m <= __float_as_uint(q.w)) {  // (d2 >= 0: bit order = numeric order)
-                const unsigned long long k0_ = make_key(d0, __float_as_uint(t0.w)), k1_ = make_key(d1, __float_as_uint(t1.w));
-                const unsigned long long k2_ = make_key(d2, __float_as_uint(t2.w)), k3_ = make_key(d3, __float_as_uint(t3.w));
-                const unsigned long long a = k0_ < k1_ ? k0_ : k1_, b = k2_ < k3_ ? k2_ : k3_;
-                if constexpr (BOUND) {
-                    // the trip's smallest key contends for the owner's best; whichever of the two loses
-                    // is a runner-up candidate, and so is the trip's own second smallest (the global
-                    // runner-up is one trip's winner or the best trip's second).  Meeting the same point
-                    // again (old == mine: the seed, or a point read past a run's end) changes nothing.
-                    const unsigned long long mn = a < b ? a : b;
-                    const unsigned u0 = __float_as_uint(d0), u1 = __float_as_uint(d1), u2 = __float_as_uint(d2),
-                                   u3 = __float_as_uint(d3);
-                    const unsigned lo01 = min(u0, u1), hi01 = max(u0, u1), lo23 = min(u2, u3), hi23 = max(u2, u3);
-                    const unsigned sec = min(max(lo01, lo23), min(hi01, hi23));
-                    const unsigned long long old = atomicMin(&L.best[owner], mn);
-                    unsigned push = sec;
-                    if (old != mn) push = min(push, (unsigned) ((old > mn ? old : mn) >> 32));
-                    atomicMin(&bnd->lds[owner], push);
-                } else {
-                    atomicMin(&L.best[owner], a < b ? a : b);
-                }
-            }
-        }
-    }
+    pooled_rounds<BOUND>(L, L.items, T, lane, ubase, bnd);
     __builtin_amdgcn_wave_barrier();
     best = L.best[lane];
     if constexpr (BOUND) bnd->second = bnd->lds[lane];
@@ -543,6 +579,119 @@ __device__ __forceinline__ unsigned long long scan_box_bal(const GridDev &g, boo
         lookup_and_walk(a0, a1);
     }
     return best;
+}
+
+// The same scan for a wave with FEW searches going (the certificate kernel's late iterations: a
+// handful of unsettled queries per wave, boxes of one to nine rows).  scan_box_bal makes every lane
+// step through its own rows three at a time, so a wave with five live lanes still pays a full step
+// -- row chords, look-ups, list, round -- per three rows of its largest box.  Here the ROWS are pooled
+// too: the owners list (owner, row) pairs in LDS, every lane takes one pair -- the row's chord and its
+// two cell_start look-ups, one memory round trip for the whole wave --, the runs found become the
+// pooled trip list, and the rounds follow: one pass over everything, whatever the boxes' shapes.
+// Runner-up tracking as in the BOUND walk; the chords are cut with the prune radius at entry.
+// Returns false (nothing changed) when the job is not small: more than kRowPool rows in the wave,
+// more than kRowsPerLane in one box, or more trips than the list holds; the caller then takes
+// scan_box_bal.  All live lanes must be on level g.
+constexpr unsigned kRowPool = 128, kRowsPerLane = 16, kRowTrips = 512;
+struct RowLds {  // overlays BalLds::items (1025 words)
+    unsigned trips[kRowTrips];
+    unsigned map[kRowPool];   // owner lane | row number << 8
+    int box[5][64];           // per owner: xa, xb, ya, za, rows per z layer
+};
+static_assert(sizeof(RowLds) <= sizeof(unsigned) * (kBalCap + 1), "RowLds overlays BalLds::items");
+
+__device__ __forceinline__ bool scan_box_rows(const GridDev &g, bool live, float qx, float qy, float qz, float r,
+                                              unsigned long long &best, float *margin, BalLds &L, unsigned lane,
+                                              Bound *bnd) {
+    const float big = 4.0e6f;
+    const float fx = fminf(fmaxf((qx - g.ox) * g.inv_h, -big), big);
+    const float fy = fminf(fmaxf((qy - g.oy) * g.inv_h, -big), big);
+    const float fz = fminf(fmaxf((qz - g.oz) * g.inv_h, -big), big);
+    const float rc = r * g.inv_h + g.slack;
+    const int x0 = (int) floorf(fx - rc), x1 = (int) floorf(fx + rc);
+    const int y0 = (int) floorf(fy - rc), y1 = (int) floorf(fy + rc);
+    const int z0 = (int) floorf(fz - rc), z1 = (int) floorf(fz + rc);
+    const int xa = max(x0, 0), xb = min(x1, g.nx - 1);
+    const int ya = max(y0, 0), yb = min(y1, g.ny - 1);
+    const int za = max(z0, 0), zb = min(z1, g.nz - 1);
+    const bool has = live && !(xa > xb || ya > yb || za > zb);
+    const int wy = yb - ya + 1;
+    const unsigned nrows = has ? (unsigned) (wy * (zb - za + 1)) : 0u;
+    const unsigned incl = wave_incl_scan(nrows);
+    const unsigned R = rl_u(incl, 63);
+    if (R > kRowPool || __ballot(nrows > kRowsPerLane) != 0ull) return false;
+    {
+        const float mx = fminf(fx - (float) x0, (float) (x1 + 1) - fx);
+        const float my = fminf(fy - (float) y0, (float) (y1 + 1) - fy);
+        const float mz = fminf(fz - (float) z0, (float) (z1 + 1) - fz);
+        *margin = (fminf(mx, fminf(my, mz)) - g.slack) * g.h;
+    }
+    if (R == 0u) return true;
+    RowLds &W = *reinterpret_cast<RowLds *>(L.items);
+    const float pr = bnd->prune_r(best);
+    L.best[lane] = best;
+    bnd->lds[lane] = bnd->second;
+    reinterpret_cast<unsigned *>(&L.q[lane])[3] = __float_as_uint(pr * pr);
+    W.box[0][lane] = xa;
+    W.box[1][lane] = xb;
+    W.box[2][lane] = ya;
+    W.box[3][lane] = za;
+    W.box[4][lane] = wy;
+    for (unsigned k = 0, off = incl - nrows; k < nrows; ++k) W.map[off + k] = lane | (k << 8);
+    __builtin_amdgcn_wave_barrier();
+    unsigned ttot = 0;  // trips listed and not yet walked (wave-uniform)
+    bool fits = true;
+    for (unsigned b0 = 0; b0 < R; b0 += 64u) {
+        unsigned rs = 0, re = 0, owner = 0;
+        if (b0 + lane < R) {
+            const unsigned m = W.map[b0 + lane];
+            owner = m & 63u;
+            const int k = (int) (m >> 8), wyo = W.box[4][owner];
+            const int yy = W.box[2][owner] + k % wyo, zz = W.box[3][owner] + k / wyo;
+            const float4 q = L.q[owner];
+            const float ofx = fminf(fmaxf((q.x - g.ox) * g.inv_h, -big), big);
+            const float ofy = fminf(fmaxf((q.y - g.oy) * g.inv_h, -big), big);
+            const float ofz = fminf(fmaxf((q.z - g.oz) * g.inv_h, -big), big);
+            // the ball that matters, in cells (q.w = the owner's squared prune radius; cushions for the
+            // approximate square roots as in scan_box_bal)
+            const float Rb = __builtin_amdgcn_sqrtf(q.w) * g.inv_h * 1.00003f;
+            const float lim = Rb + g.slack;
+            const float lim2 = lim * lim, c0 = Rb * Rb + 2.f * g.slack * lim;
+            const float ry = fmaxf(fmaxf((float) yy - ofy, ofy - (float) (yy + 1)), 0.f);
+            const float rz = fmaxf(fmaxf((float) zz - ofz, ofz - (float) (zz + 1)), 0.f);
+            const float rho2 = ry * ry + rz * rz;
+            const float hx = __builtin_amdgcn_sqrtf(fmaxf(c0 - rho2, 0.f)) * 1.00001f + g.slack;
+            const int xl = max(W.box[0][owner], __float2int_rd(ofx - hx)), xh = min(W.box[1][owner], __float2int_rd(ofx + hx));
+            if (!(rho2 > lim2) && xl <= xh) {
+                const unsigned base = ((unsigned) zz * g.ny + yy) * g.nx;
+                rs = ldc(g.cell_start, base + xl);
+                re = ldc(g.cell_start, base + xh + 1);
+            }
+        }
+        const unsigned len = (unsigned) max((int) (re - rs), 0), t = (len + 3u) >> 2;
+        const unsigned incl2 = wave_incl_scan(t);
+        const unsigned Tb = rl_u(incl2, 63);
+        if (Tb > kRowTrips) {  // (cells this crowded are not the small job this path is for)
+            fits = false;
+            break;
+        }
+        if (ttot + Tb > kRowTrips) {
+            __builtin_amdgcn_wave_barrier();
+            pooled_rounds<true>(L, W.trips, ttot, lane, g.pts, bnd);
+            __builtin_amdgcn_wave_barrier();
+            ttot = 0;
+        }
+        unsigned o = ttot + incl2 - t;
+        for (unsigned j = rs; j < re; j += 4u) W.trips[o++] = (owner << 26) | j;
+        ttot += Tb;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (fits) pooled_rounds<true>(L, W.trips, ttot, lane, g.pts, bnd);
+    __builtin_amdgcn_wave_barrier();
+    // (also after a bail-out: whatever the rounds walked so far has been merged, and stays valid)
+    best = L.best[lane];
+    bnd->second = bnd->lds[lane];
+    return fits;
 }
 
 // Wave-cooperative version of scan_box for ONE query (q, r, best are wave-uniform):
@@ -704,6 +853,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
               float r_light_cells, float lane_lf, float coop_lf, float r0_cells, unsigned xcd_chunk,
               double *__restrict__ partials, unsigned *__restrict__ cost_out,
               unsigned long long *__restrict__ phase_out) {
+    // (the wave's life is a chain of memory round trips; the three streams of its chunk -- source
+    // point, previous key, previous match -- need nothing but the block number for their addresses
+    // and are requested before the state is looked at.  Before the first search keys / match_pt hold
+    // nothing meaningful and are not looked at.)
+    const bool early = ((xcd_chunk >> 29) & 1u) != 0u;
+    const bool rev = (xcd_chunk >> 31) != 0u;  // experiment: hand the queries out back to front
+    const unsigned chunk_sz = xcd_chunk & 0x0FFFFFFFu;
+    const bool nt = ((xcd_chunk >> 28) & 1u) != 0u;  // non-temporal result stores
+    const bool walk_filter = ((xcd_chunk >> 30) & 1u) != 0u;  // see balanced_walk
+    const unsigned bidx = rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned row = chunk_sz ? xcd_remap_chunked(bidx, chunk_sz) : xcd_remap(bidx, gridDim.x);
+    const unsigned i = row * 64u + lane;
+    const bool active = i < n;
+    float4 p_e = make_float4(0.f, 0.f, 0.f, 0.f), tp_e = p_e;
+    unsigned long long prev_e = ~0ull;
+    if (early) {
+        const unsigned ic = min(i, n - 1u);
+        p_e = src[ic];
+        prev_e = keys[ic];
+        tp_e = match_pt[ic];
+    }
     if (st->done) return;
     unsigned cost = 0;
     // developer (COST): shader-clock cycles of this wave's phases, added into phase_out[8] by lane 0:
@@ -714,20 +885,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
     // per wave: [run][lane] = each lane's pending runs (lane scan), or the pooled trip list (balanced walk)
     __shared__ uint2 s_runs[BAL ? 1 : kRowChunk * 64];
     __shared__ BalHolder<BAL> s_hold;
-    const bool rev = (xcd_chunk >> 31) != 0u;  // experiment: hand the queries out back to front
-    const unsigned chunk_sz = xcd_chunk & 0x3FFFFFFFu;
-    const bool walk_filter = ((xcd_chunk >> 30) & 1u) != 0u;  // see balanced_walk
-    const unsigned bidx = rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
-    const unsigned lane = threadIdx.x & 63u;
     const int L = lv->n;
     const int L_levels = L;
-    const float h0 = lv->g[0].h;
+    float hl[kMaxLevels];  // the levels' cell sizes (wave-uniform)
+#pragma unroll
+    for (int k = 0; k < kMaxLevels; ++k) hl[k] = lv->g[k < L ? k : 0].h;
+    const float h0 = hl[0];
     const float rmax = sqrtf(thr_d2) * 1.0001f + 1e-6f;
     const float r_light = r_light_cells * h0;  // larger radii go to the cooperative path
     const bool have_prev = st->have_prev != 0;  // wave-uniform
-    const unsigned row = chunk_sz ? xcd_remap_chunked(bidx, chunk_sz) : xcd_remap(bidx, gridDim.x);
-    const unsigned i = row * 64u + lane;
-    const bool active = i < n;
     float qx = 0.f, qy = 0.f, qz = 0.f, r = 0.f;
     float bqx = 0.f, bqy = 0.f, bqz = 0.f;  // coordinates of the previous iteration's match
     unsigned long long best = make_key(thr_d2, kNoIdx);
@@ -740,10 +906,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
     unsigned long long prev = ~0ull;
     float4 tp = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) {
-        const float4 p = src[i];
+        const float4 p = early ? p_e : src[i];
         if (have_prev) {
-            prev = keys[i];
-            tp = match_pt[i];
+            prev = early ? prev_e : keys[i];
+            tp = early ? tp_e : match_pt[i];
         }
         xform(st->Tf, p, qx, qy, qz);
         // sharded registration: only the rank owning this x-slab handles the point
@@ -785,8 +951,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
         asm volatile("" ::: "memory");
         bool live = mine && !heavy;
         for (int pass = 0; pass < 32 && __ballot(live) != 0ull; ++pass) {
-            int l = 0;
-            while (l < L_levels - 1 && lv->g[l].h < lane_lf * r) ++l;
+            int l = 0;  // the finest level whose cell is >= lane_lf * r (cell sizes double from level to level)
+#pragma unroll
+            for (int k = 0; k < kMaxLevels - 1; ++k) l += (k < L_levels - 1 && hl[k] < lane_lf * r) ? 1 : 0;
             // all live lanes on one level (always, once the clouds are close): the level's
             // description comes through scalar loads into SGPRs instead of eleven VGPRs per lane
             // (one level at a time, lanes of the other levels working along, was slower: 77.6 vs
@@ -874,7 +1041,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
         bqz = L.bq[2][lane_e];
     }
     if (mine) {
-        keys[i_e] = best;
+        st_u64(&keys[i_e], best, nt);
         // the match's coordinates ride along for the statistics kernel and for the next
         // iteration's seed; a new winner's are read from the caller-ordered target copy
         // (its key carries the original index)
@@ -884,7 +1051,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
             bqy = c.y;
             bqz = c.z;
         }
-        match_pt[i_e] = make_float4(bqx, bqy, bqz, __uint_as_float((unsigned) best));  // (.w: the match's index, for k_nn_cert)
+        st_f4(&match_pt[i_e], bqx, bqy, bqz, __uint_as_float((unsigned) best), nt);  // (.w: the match's index, for k_nn_cert)
     }
     if (lane == 0 && n_heavy) atomicAdd(&st->queue_count[1], n_heavy);  // stats only
     const unsigned long long prof_store = COST ? clock64() : 0ull;
@@ -897,7 +1064,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
                          __uint_as_float((unsigned) (best >> 32)));
         acc_halve<kAcc, 32>(a, lane);
         const int comp = acc_comp_of_lane(lane);
-        if (comp >= 0) partials[(size_t) row * kAcc + comp] = a[0];
+        if (comp >= 0) st_f64(&partials[(size_t) row * kAcc + comp], a[0], nt);
     }
     if constexpr (COST) {
         if (lane_e == 0 && phase_out) {
@@ -921,9 +1088,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
 // from the query to every target point other than m (runner-up tracking, `Bound` above); every pose
 // since has moved the query by a known distance, which is taken off s.  If now
 //     |q - m| < s        (with float-rounding cushions)
+// (the query's position at that search is kept with s: the distance moved since is taken off s)
 // then every other point is strictly farther than m: m is the exact nearest neighbour, ties
-// included, and the query is SETTLED by a stream read (source point, match, bound: 36 B) and a
-// stream write (key, bound: 12 B).  Queries that fail the test are compacted and searched by the
+// included, and the query is SETTLED by three stream reads (source point, match, position + bound:
+// 48 B) and NO write: its key keeps the match's index, and the distance in it is brought up to
+// date once, when the registration ends (k_fix_keys).  Queries that fail the test are compacted and searched by the
 // same wave with the pooled walk of k_nn_grid, pruning with min(runner-up, best + pad) so that the
 // bound they leave is worth something (pad = pad_mul x the query's last displacement, at most
 // pad_frac x its seed distance).  Same keys, bit for bit, as a full search of every query.
@@ -935,45 +1104,70 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
 //            the search (k_nn_grid's pass loop with runner-up tracking), stores, sums.
 // One row of partial sums per workgroup.  bounds_valid = 0: no usable bounds (the previous
 // iteration was searched by k_nn_grid): every query is searched and leaves its bound.
-template <int STATS, int NB>
+template <int STATS, int NB, int RC>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     k_nn_cert(const LevelsDev *__restrict__ lv, const float4 *__restrict__ src, unsigned n,
               IcpDevState *__restrict__ st, float thr_d2, unsigned long long *__restrict__ keys,
-              float4 *__restrict__ match_pt, float *__restrict__ bound, const float4 *__restrict__ tgt_orig,
+              float4 *__restrict__ match_pt, float4 *__restrict__ bound, const float4 *__restrict__ tgt_orig,
               float r_light_cells, float lane_lf, float coop_lf, float r0_cells, unsigned xcd_chunk,
               double *__restrict__ partials, int bounds_valid, float pad_mul, float pad_frac,
-              unsigned *__restrict__ uns_count) {
+              unsigned *__restrict__ uns_count, unsigned long long *__restrict__ prof_out) {
+    // developer (prof_out): shader-clock stamps of every 512th workgroup's life, 16 per sampled workgroup
+    // (the phases between them: see scripts/dev/dev_cert_prof.py); nothing is recorded otherwise
+    const bool stamp_on = prof_out != nullptr && (blockIdx.x & 511u) == 0u;
+    unsigned long long pt[12];
+#define WM_STAMP(k) do { if (stamp_on) pt[k] = clock64(); } while (0)
+#pragma unroll
+    for (int k = 0; k < 12; ++k) pt[k] = 0ull;
+    WM_STAMP(0);
+    // (the wave's life is a chain of memory round trips: the phase's three streams are requested before
+    // anything else is looked at -- their addresses need nothing but the block number)
+    const unsigned lane = threadIdx.x & 63u;
+    const bool nt = ((xcd_chunk >> 28) & 1u) != 0u;  // non-temporal result stores (st_f4 ...)
+    const unsigned xs = xcd_chunk & 0x03FFFFFFu;
+    const unsigned dbg_skip = (xcd_chunk >> 26) & 3u;  // developer timing experiment (WRONG results): 1 = no phase 2, 2 = phase 2 without its scans
+    const unsigned row = xs ? xcd_remap_chunked(blockIdx.x, xs) : xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned base = row * (64u * NB);
+    float4 p[NB], mp[NB], rf[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const unsigned i = min(base + (unsigned) j * 64u + lane, n - 1u);
+        p[j] = src[i];
+        mp[j] = match_pt[i];  // (meaningless before the first search, and then not looked at)
+        rf[j] = bound[i];
+    }
     if (st->done) return;
     __shared__ BalLds L;
     __shared__ unsigned s_second[64];
+    __shared__ float4 s_win[64];
     __shared__ unsigned short s_list[64 * NB];
-    const unsigned lane = threadIdx.x & 63u;
+    s_win[threadIdx.x & 63u] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoIdx));  // (no winner recorded)
     const int Ln = lv->n;
-    const float h0 = lv->g[0].h;
+    float hl[kMaxLevels];  // the levels' cell sizes (wave-uniform: scalar registers)
+#pragma unroll
+    for (int k = 0; k < kMaxLevels; ++k) hl[k] = lv->g[k < Ln ? k : 0].h;
+    const GridDev g0 = lv->g[0];  // (what the late searches scan: fetched with the rest of the state, not when first needed)
+    const float h0 = hl[0];
     const float rmax = sqrtf(thr_d2) * 1.0001f + 1e-6f;
     const float r_light = r_light_cells * h0;
     const bool have_prev = st->have_prev != 0;
     const bool valid = bounds_valid != 0 && have_prev;
-    const unsigned row = xcd_chunk ? xcd_remap_chunked(blockIdx.x, xcd_chunk) : xcd_remap(blockIdx.x, gridDim.x);
-    const unsigned base = row * (64u * NB);
+    // room a search leaves above its result for the runner-up bound: a few of the last step's sizes
+    // (what the following steps will add up to while the registration converges)
+    const float pad_room = have_prev ? pad_mul * st->step_disp : 0.f;
     const int comp = acc_comp_of_lane(lane);
     double rowacc = 0.0;
     unsigned n_uns = 0;  // (wave-uniform)
+    WM_STAMP(1);  // state in
     // ---- phase 1: the certificate
     {
-        float4 p[NB], mp[NB];
-        float sb[NB];
+        double acc[kAcc];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {  // every load of the phase is issued before the first use
-            const unsigned i = base + (unsigned) j * 64u + lane;
-            p[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            mp[j] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoIdx));
-            sb[j] = 0.f;
-            if (i < n && valid) {
-                p[j] = src[i];
-                mp[j] = match_pt[i];
-                sb[j] = bound[i];
-            }
+        for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
+        bool any = false;
+        if (stamp_on) {  // (when the first batch's three loads have landed)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pt[2] = clock64();
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -982,27 +1176,83 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             bool settled = false;
             float qx = 0.f, qy = 0.f, qz = 0.f, d2 = 0.f;
             if (act && valid) {
-                float ox, oy, oz;
+                // where the query is now, how far that is from where its bound was taken, and how far
+                // its match is: no stores -- a settled query costs three stream reads
                 xform(st->Tf, p[j], qx, qy, qz);
-                xform(st->Tf_prev, p[j], ox, oy, oz);
-                const float ex = qx - ox, ey = qy - oy, ez = qz - oz;
-                const float disp = sqrtf(ex * ex + ey * ey + ez * ez);
+                const float ex = qx - rf[j].x, ey = qy - rf[j].y, ez = qz - rf[j].z;
+                // (v_sqrt_f32, 1 ulp: the comparison carries 1e-4 relative + 1e-6 m of cushion on either side;
+                // the library sqrtf is a twenty-instruction sequence, and this phase is bound by issue)
+                const float disp = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez);
                 const unsigned idx = __float_as_uint(mp[j].w);
                 d2 = canon_d2(qx, qy, qz, mp[j]);
-                const float s_new = sb[j] - disp * 1.0001f - 1e-6f;
-                settled = idx != kNoIdx && d2 <= thr_d2 && sqrtf(d2) * 1.0001f + 1e-6f < s_new;
-                if (settled) {
-                    keys[i] = make_key(d2, idx);
-                    bound[i] = s_new;
-                }
+                settled = idx != kNoIdx && d2 <= thr_d2 &&
+                          __builtin_amdgcn_sqrtf(d2) * 1.0001f + 1e-6f < rf[j].w - disp * 1.0001f - 1e-6f;
             }
-            const unsigned long long smask = __ballot(settled);
             if constexpr (STATS >= 0) {
-                if (smask != 0ull) {
+                // the settled queries' terms: two batches are added lane by lane, then one wave reduction
+                // (all four at once needs 36 more live registers than the kernel has: 92 B of scratch per lane)
+                if ((j & 1) == 0) any = false;
+                any = any || settled;
+                if constexpr (STATS == WM_ICP_SVD) {
+                    // (the first batch of a pair assigns, the second accumulates with fused multiply-adds:
+                    // half the f64 instructions of forming the terms and adding them -- this phase is
+                    // bound by instruction issue, not by HBM)
+                    const double m = settled ? 1.0 : 0.0;
+                    const double px = settled ? (double) qx : 0.0, py = settled ? (double) qy : 0.0,
+                                 pz = settled ? (double) qz : 0.0;
+                    const double tx = settled ? (double) mp[j].x : 0.0, ty = settled ? (double) mp[j].y : 0.0,
+                                 tz = settled ? (double) mp[j].z : 0.0;
+                    const double dd = settled ? (double) d2 : 0.0;
+                    if ((j & 1) == 0) {
+                        acc[0] = m;
+                        acc[1] = px;
+                        acc[2] = py;
+                        acc[3] = pz;
+                        acc[4] = tx;
+                        acc[5] = ty;
+                        acc[6] = tz;
+                        acc[7] = tx * px;
+                        acc[8] = tx * py;
+                        acc[9] = tx * pz;
+                        acc[10] = ty * px;
+                        acc[11] = ty * py;
+                        acc[12] = ty * pz;
+                        acc[13] = tz * px;
+                        acc[14] = tz * py;
+                        acc[15] = tz * pz;
+                        acc[16] = dd;
+                        acc[17] = m;
+                    } else {
+                        acc[0] += m;
+                        acc[1] += px;
+                        acc[2] += py;
+                        acc[3] += pz;
+                        acc[4] += tx;
+                        acc[5] += ty;
+                        acc[6] += tz;
+                        acc[7] = fma(tx, px, acc[7]);
+                        acc[8] = fma(tx, py, acc[8]);
+                        acc[9] = fma(tx, pz, acc[9]);
+                        acc[10] = fma(ty, px, acc[10]);
+                        acc[11] = fma(ty, py, acc[11]);
+                        acc[12] = fma(ty, pz, acc[12]);
+                        acc[13] = fma(tz, px, acc[13]);
+                        acc[14] = fma(tz, py, acc[14]);
+                        acc[15] = fma(tz, pz, acc[15]);
+                        acc[16] += dd;
+                        acc[17] += m;
+                    }
+                } else {
                     double a[kAcc];
                     icp_terms<STATS>(a, settled, settled, qx, qy, qz, mp[j].x, mp[j].y, mp[j].z, d2);
-                    acc_halve<kAcc, 32>(a, lane);
-                    rowacc += comp >= 0 ? a[0] : 0.0;
+#pragma unroll
+                    for (int k = 0; k < kAcc; ++k) acc[k] = ((j & 1) == 0 ? 0.0 : acc[k]) + a[k];
+                }
+                if ((j & 1) == 1 || j == NB - 1) {
+                    if (__ballot(any) != 0ull) {
+                        acc_halve<kAcc, 32>(acc, lane);
+                        rowacc += comp >= 0 ? acc[0] : 0.0;
+                    }
                 }
             }
             const bool uns = act && !settled;
@@ -1010,16 +1260,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             if (uns) {
                 const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned) (umask >> 32),
                                                                   __builtin_amdgcn_mbcnt_lo((unsigned) umask, 0u));
-                s_list[n_uns + before] = (unsigned short) ((unsigned) j * 64u + lane);
+                const unsigned e = n_uns + before;
+                s_list[e] = (unsigned short) ((unsigned) j * 64u + lane);
+                // the first chunk's queries are parked (pose applied, match, displacement) where the
+                // pooled walk will keep its list: phase 2 starts without another round trip to memory
+                if (valid && e < 64u) {
+                    float4 *park = reinterpret_cast<float4 *>(L.items);
+                    park[2u * e] = make_float4(qx, qy, qz, 0.f);
+                    park[2u * e + 1u] = mp[j];
+                }
             }
             n_uns += (unsigned) __popcll(umask);
         }
     }
     if (uns_count && lane == 0 && n_uns) atomicAdd(&uns_count[blockIdx.x & 63u], n_uns);  // developer statistics
     __builtin_amdgcn_wave_barrier();
+    WM_STAMP(3);  // phase 1 done
     // ---- phase 2: search what is left, 64 queries at a time
     unsigned cost = 0;
     unsigned long long prof[3] = {0ull, 0ull, 0ull};
+    if (dbg_skip == 1u && valid) n_uns = 0;
     for (unsigned c0 = 0; c0 < n_uns; c0 += 64u) {
         const bool mine = c0 + lane < n_uns;
         const unsigned i = base + (mine ? (unsigned) s_list[c0 + lane] : 0u);
@@ -1029,10 +1289,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         unsigned long long seeded = best;
         bool heavy = false;
         if (mine) {
-            const float4 p = src[i];
             float4 tp = make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoIdx));
-            if (have_prev) tp = match_pt[i];
-            xform(st->Tf, p, qx, qy, qz);
+            if (valid && c0 == 0u) {  // parked by phase 1
+                const float4 *park = reinterpret_cast<const float4 *>(L.items);
+                const float4 a = park[2u * lane];
+                tp = park[2u * lane + 1u];
+                qx = a.x;
+                qy = a.y;
+                qz = a.z;
+            } else {
+                const float4 p1 = src[i];
+                if (have_prev) tp = match_pt[i];
+                xform(st->Tf, p1, qx, qy, qz);
+            }
             r = r0_cells * h0;
             if (have_prev) {
                 const unsigned pidx = __float_as_uint(tp.w);
@@ -1044,11 +1313,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                         bqx = tp.x;
                         bqy = tp.y;
                         bqz = tp.z;
-                        float ox, oy, oz;
-                        xform(st->Tf_prev, p, ox, oy, oz);
-                        const float ex = qx - ox, ey = qy - oy, ez = qz - oz;
                         const float sd = sqrtf(d2b);
-                        pad = fminf(pad_mul * sqrtf(ex * ex + ey * ey + ez * ez), pad_frac * sd);
+                        pad = fminf(pad_room, pad_frac * sd);
                         r = fmaxf(sd * 1.0001f + 1e-6f, 0.05f * h0) + pad;
                     }
                 }
@@ -1056,10 +1322,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             r = fminf(r, rmax);
             heavy = r > r_light;
         }
+        __builtin_amdgcn_wave_barrier();  // (the parked entries have been read before the walk reuses their LDS)
+        if (c0 == 0u) WM_STAMP(4);  // first chunk: seeds ready
         Bound bnd;
         bnd.second = 0x7F800000u;
         bnd.pad = pad;
         bnd.lds = s_second;
+        bnd.win = s_win;
         bnd.ok = true;
         float margin_last = 0.f;
         L.q[lane] = make_float4(qx, qy, qz, 0.f);
@@ -1068,21 +1337,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         L.bq[1][lane] = bqy;
         L.bq[2][lane] = bqz;
         asm volatile("" ::: "memory");
-        bool live = mine && !heavy;
+        bool live = mine && !heavy && !(dbg_skip == 2u && valid);
         for (int pass = 0; pass < 32 && __ballot(live) != 0ull; ++pass) {
-            int l = 0;
-            while (l < Ln - 1 && lv->g[l].h < lane_lf * r) ++l;
+            int l = 0;  // the finest level whose cell is >= lane_lf * r (cell sizes double from level to level)
+#pragma unroll
+            for (int k = 0; k < kMaxLevels - 1; ++k) l += (k < Ln - 1 && hl[k] < lane_lf * r) ? 1 : 0;
             const unsigned long long lv_mask = __ballot(live);
             const int l0 = __builtin_amdgcn_readlane(l, __ffsll((long long) lv_mask) - 1);
             float margin;
             if (__ballot(live && l != l0) == 0ull) {
-                const GridDev g = lv->g[l0];
-                best = scan_box_bal<false, kBalRowChunk, true>(g, live, qx, qy, qz, r, best, &margin, L, lane, have_prev,
+                const GridDev g = l0 == 0 ? g0 : lv->g[l0];
+                if (!scan_box_rows(g, live, qx, qy, qz, r, best, &margin, L, lane, &bnd))
+                best = scan_box_bal<false, RC, true>(g, live, qx, qy, qz, r, best, &margin, L, lane, have_prev,
                                                                 g.pts, cost, prof, true, &bnd);
             } else {
                 const GridDev g = lv->g[l];
                 L.base[lane] = (unsigned long long) g.pts;
-                best = scan_box_bal<false, kBalRowChunk, true>(g, live, qx, qy, qz, r, best, &margin, L, lane, have_prev,
+                best = scan_box_bal<false, RC, true>(g, live, qx, qy, qz, r, best, &margin, L, lane, have_prev,
                                                                 nullptr, cost, prof, true, &bnd);
             }
             if (live) {
@@ -1098,6 +1369,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 }
             }
         }
+        if (c0 == 0u) WM_STAMP(5);  // first chunk: pass loop done
         // cooperative phase for radii beyond r_light (k_nn_grid's; no bound comes out of it)
         unsigned long long todo = __ballot(heavy);
         float seed = 0.f;
@@ -1132,15 +1404,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         bqx = L.bq[0][lane];
         bqy = L.bq[1][lane];
         bqz = L.bq[2][lane];
+        if (c0 == 0u) WM_STAMP(6);  // first chunk: cooperative phase done
         if (mine) {
-            keys[i] = best;
+            st_u64(&keys[i], best, nt);
             if (best != seeded && (unsigned) best != kNoIdx) {
-                const f4v c = ((gp_f4) tgt_orig)[(unsigned) best];
-                bqx = c.x;
-                bqy = c.y;
-                bqz = c.z;
+                // the new match's coordinates: left in LDS by the lane that found it (the tag says whether
+                // the slot really is this point's), else from the caller-ordered target copy
+                const float4 w = s_win[lane];
+                if (__float_as_uint(w.w) == (unsigned) best) {
+                    bqx = w.x;
+                    bqy = w.y;
+                    bqz = w.z;
+                } else {
+                    const f4v c = ((gp_f4) tgt_orig)[(unsigned) best];
+                    bqx = c.x;
+                    bqy = c.y;
+                    bqz = c.z;
+                }
             }
-            match_pt[i] = make_float4(bqx, bqy, bqz, __uint_as_float((unsigned) best));
+            st_f4(&match_pt[i], bqx, bqy, bqz, __uint_as_float((unsigned) best), nt);
             // every point but the match is farther than: the runner-up seen, the radius pruned with, and
             // the faces of the last box scanned
             float s = 0.f;
@@ -1148,8 +1430,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 const float bd = sqrtf(__uint_as_float((unsigned) (best >> 32)));
                 s = fminf(fminf(sqrtf(__uint_as_float(bnd.second)), bd + pad), margin_last) * 0.9999f - 1e-6f;
             }
-            bound[i] = s;
+            st_f4(&bound[i], qx, qy, qz, s, nt);  // ... seen from HERE
         }
+        if (c0 == 0u) WM_STAMP(7);  // first chunk: winners fetched, results stored
         if constexpr (STATS >= 0) {
             double a[kAcc];
             icp_terms<STATS>(a, mine, (unsigned) best != kNoIdx, qx, qy, qz, bqx, bqy, bqz,
@@ -1157,11 +1440,46 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             acc_halve<kAcc, 32>(a, lane);
             rowacc += comp >= 0 ? a[0] : 0.0;
         }
+        if (c0 == 0u) WM_STAMP(8);  // first chunk: sums reduced
         __builtin_amdgcn_wave_barrier();
     }
+    WM_STAMP(10);
     if constexpr (STATS >= 0) {
-        if (comp >= 0) partials[(size_t) row * kAcc + comp] = rowacc;
+        if (comp >= 0) st_f64(&partials[(size_t) row * kAcc + comp], rowacc, nt);
     }
+    if (stamp_on && lane == 0) {
+        pt[11] = clock64();
+        unsigned long long *o = prof_out + 16 * (blockIdx.x >> 9);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) o[k] = pt[k];
+        o[12] = n_uns;
+    }
+#undef WM_STAMP
+}
+
+// After a registration whose last searches were certified: the settled queries' keys still carry the
+// distance of their last real search.  Bring every key up to date with the pose of the last search
+// (same arithmetic as the search: same bits as if every query had been searched).
+__global__ void __launch_bounds__(kBlock)
+    k_fix_keys(const float4 *__restrict__ src, unsigned n, const IcpDevState *__restrict__ st, float thr_d2,
+               const float4 *__restrict__ match_pt, unsigned long long *__restrict__ keys) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = src[i], m = match_pt[i];
+    const unsigned idx = __float_as_uint(m.w);
+    float qx, qy, qz;
+    xform(st->Tf_search, p, qx, qy, qz);
+    keys[i] = idx == kNoIdx ? make_key(thr_d2, kNoIdx) : make_key(canon_d2(qx, qy, qz, m), idx);
+}
+
+int launch_fix_keys(wm_ctx *ctx, float thr_d2) {
+    const unsigned n = (unsigned) ctx->n_src;
+    if (n == 0) return WM_OK;
+    hipLaunchKernelGGL(k_fix_keys, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream,
+                       ctx->src_sorted.as<float4>(), n, ctx->d_state.as<IcpDevState>(), thr_d2,
+                       ctx->match_pt.as<float4>(), ctx->keys.as<unsigned long long>());
+    WM_HIP(ctx, hipGetLastError());
+    return WM_OK;
 }
 
 // ----------------------------------------------------------- brute force
@@ -1270,6 +1588,8 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
     }
     xcd_chunk |= ctx->tune_xcd_reverse ? 0x80000000u : 0u;
     xcd_chunk |= ctx->tune_nn_walk_filter ? 0x40000000u : 0u;
+    xcd_chunk |= ctx->tune_nn_early_loads ? 0x20000000u : 0u;
+    xcd_chunk |= ctx->tune_nn_nt_stores ? 0x10000000u : 0u;
     // the balanced walk packs (lane, point offset) into 32 bits: targets below 2^26 points
     const bool bal = ctx->tune_nn_balanced && ctx->n_tgt_input < (1u << 26) - 8u;
     if (ev0) WM_HIP(ctx, hipEventRecord(ev0, ctx->stream));
@@ -1293,25 +1613,27 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
     return WM_OK;
 }
 
-template <int STATS, int NB>
+template <int STATS, int NB, int RC>
 static void launch_nn_cert_t(wm_ctx *ctx, unsigned blocks, float thr_d2, unsigned xcd_chunk, bool bounds_valid) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_cert<STATS, NB>), dim3(blocks), dim3(64), 0, ctx->stream,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_cert<STATS, NB, RC>), dim3(blocks), dim3(64), 0, ctx->stream,
                        ctx->d_levels.as<LevelsDev>(), ctx->src_sorted.as<float4>(), (unsigned) ctx->n_src,
                        ctx->d_state.as<IcpDevState>(), thr_d2, ctx->keys.as<unsigned long long>(),
-                       ctx->match_pt.as<float4>(), ctx->nn_bound.as<float>(), ctx->tgt_orig.as<float4>(),
+                       ctx->match_pt.as<float4>(), ctx->nn_bound.as<float4>(), ctx->tgt_orig.as<float4>(),
                        ctx->tune_r_light, ctx->tune_lane_lf, ctx->tune_coop_lf, ctx->tune_r0, xcd_chunk,
                        ctx->partials.as<double>(), bounds_valid ? 1 : 0, ctx->tune_cert_pad_mul,
                        ctx->tune_cert_pad_frac,
                        ctx->cert_count.p && ctx->cert_log_iter < ctx->cert_log_cap
-                           ? ctx->cert_count.as<unsigned>() + 64 * (size_t) ctx->cert_log_iter : nullptr);
+                           ? ctx->cert_count.as<unsigned>() + 64 * (size_t) ctx->cert_log_iter : nullptr,
+                       ctx->cert_prof.p && ctx->cert_log_iter < ctx->cert_log_cap
+                           ? ctx->cert_prof.as<unsigned long long>() + 64 * (size_t) ctx->cert_log_iter : nullptr);
 }
 
-template <int NB>
+template <int NB, int RC>
 static void launch_nn_cert_nb(wm_ctx *ctx, unsigned blocks, float thr_d2, unsigned xcd_chunk, bool bounds_valid,
                               int stats_mode) {
-    if (stats_mode < 0) launch_nn_cert_t<-1, NB>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid);
-    else if (stats_mode == WM_ICP_SVD) launch_nn_cert_t<WM_ICP_SVD, NB>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid);
-    else launch_nn_cert_t<WM_ICP_GN6, NB>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid);
+    if (stats_mode < 0) launch_nn_cert_t<-1, NB, RC>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid);
+    else if (stats_mode == WM_ICP_SVD) launch_nn_cert_t<WM_ICP_SVD, NB, RC>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid);
+    else launch_nn_cert_t<WM_ICP_GN6, NB, RC>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid);
 }
 
 int launch_nn_cert(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2, int stats_mode,
@@ -1328,15 +1650,19 @@ int launch_nn_cert(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
         xcd_chunk = 8u;
         blocks = (blocks + 63u) / 64u * 64u;
     }
-    WM_HIP(ctx, ctx->nn_bound.reserve(((size_t) n + 64) * sizeof(float)));
+    const unsigned xflags = (ctx->tune_nn_nt_stores ? 0x10000000u : 0u) | (((unsigned) ctx->tune_cert_dbg_skip & 3u) << 26);
+    WM_HIP(ctx, ctx->nn_bound.reserve(((size_t) n + 64) * sizeof(float4)));
     if (stats_mode >= 0) {
         WM_HIP(ctx, ctx->partials.reserve((size_t) blocks * kAcc * sizeof(double)));
         if (rows_out) *rows_out = blocks;
     }
     if (ev0) WM_HIP(ctx, hipEventRecord(ev0, ctx->stream));
-    if (nb == 2) launch_nn_cert_nb<2>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid, stats_mode);
-    else if (nb == 8) launch_nn_cert_nb<8>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid, stats_mode);
-    else launch_nn_cert_nb<4>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid, stats_mode);
+    const bool rc6 = ctx->tune_cert_rc == 6, rc4 = ctx->tune_cert_rc == 4;
+    if (nb == 2) launch_nn_cert_nb<2, 3>(ctx, blocks, thr_d2, xcd_chunk | xflags, bounds_valid, stats_mode);
+    else if (nb == 8) launch_nn_cert_nb<8, 3>(ctx, blocks, thr_d2, xcd_chunk | xflags, bounds_valid, stats_mode);
+    else if (rc6) launch_nn_cert_nb<4, 6>(ctx, blocks, thr_d2, xcd_chunk | xflags, bounds_valid, stats_mode);
+    else if (rc4) launch_nn_cert_nb<4, 4>(ctx, blocks, thr_d2, xcd_chunk | xflags, bounds_valid, stats_mode);
+    else launch_nn_cert_nb<4, 3>(ctx, blocks, thr_d2, xcd_chunk | xflags, bounds_valid, stats_mode);
     if (ctx->cert_count.p && ctx->cert_log_iter < ctx->cert_log_cap) ctx->cert_log_iter++;
     if (ev1) WM_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     if (ev2) WM_HIP(ctx, hipEventRecord(ev2, ctx->stream));

@@ -44,7 +44,7 @@ for cfg in sys.argv[1:] or ["-"]:
         ts.append((time.perf_counter() - t0) * 1e3)
     r1 = step(1)
     r2 = step(2)
-    T = r["T"]
+    T = r["T"] if r["T"] is not None else np.zeros((4, 4))
     if ref_T is None:
         ref_T = T
     dT = float(np.abs(T - ref_T).max())
