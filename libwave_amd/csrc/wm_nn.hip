@@ -1084,50 +1084,48 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
 // ------------------------------------------------- certified correspondences (late iterations)
 // Once the clouds are nearly aligned an ICP step moves a source point by far less than the spacing of
 // the target, and almost every query keeps its neighbour.  That can be PROVED per query without a
-// search: the last search of the query left, besides its match m, a lower bound s on the distance
-// from the query to every target point other than m (runner-up tracking, `Bound` above); every pose
-// since has moved the query by a known distance, which is taken off s.  If now
-//     |q - m| < s        (with float-rounding cushions)
-// (the query's position at that search is kept with s: the distance moved since is taken off s)
+// search: the last search of the query left, besides its match m, the query's position and a lower
+// bound s on its distance, there, to every target point other than m (runner-up tracking, `Bound`
+// above).  If now, with disp the distance moved since,
+//     |q - m| < s - disp        (with float-rounding cushions)
 // then every other point is strictly farther than m: m is the exact nearest neighbour, ties
 // included, and the query is SETTLED by three stream reads (source point, match, position + bound:
-// 48 B) and NO write: its key keeps the match's index, and the distance in it is brought up to
-// date once, when the registration ends (k_fix_keys).  Queries that fail the test are compacted and searched by the
-// same wave with the pooled walk of k_nn_grid, pruning with min(runner-up, best + pad) so that the
-// bound they leave is worth something (pad = pad_mul x the query's last displacement, at most
-// pad_frac x its seed distance).  Same keys, bit for bit, as a full search of every query.
+// 48 B) and NO write: its key keeps the match's index, and the distance in it is brought up to date
+// once, when the registration ends (k_fix_keys).  Queries that fail the test are searched with the
+// pooled walk of k_nn_grid, pruning with min(runner-up, best + pad) so that the bound they leave is
+// worth something (pad = pad_mul x the size of the last step, at most pad_frac x the seed distance).
+// Same keys, bit for bit, as a full search of every query.
 //
-// One wave per workgroup handles NB x 64 consecutive (Morton-ordered) queries:
-//   phase 1  NB batches of 64: certificate test, settled queries stored, their terms of the
-//            iteration's sums reduced (recursive halving) and accumulated in the component lanes;
-//   phase 2  the unsettled queries of all batches, listed in LDS in query order, in chunks of 64:
-//            the search (k_nn_grid's pass loop with runner-up tracking), stores, sums.
-// One row of partial sums per workgroup.  bounds_valid = 0: no usable bounds (the previous
-// iteration was searched by k_nn_grid): every query is searched and leaves its bound.
+// A workgroup of four waves handles 4 x NB x 64 consecutive (Morton-ordered) queries:
+//   phase 1  every wave: NB batches of 64 -- certificate test, the settled queries' terms of the
+//            iteration's sums (two batches added lane by lane, then a wave reduction); the unsettled
+//            ones are listed, in query order, in the wave's LDS (the first 64 with their data);
+//   phase 2  the unsettled queries of the whole workgroup in chunks of 64, chunk c by wave c mod 4:
+//            the search, stores, sums.  Once aligned a workgroup has a handful of them: ONE wave
+//            runs one chunk instead of four waves running one each -- the kernel is bound by
+//            instruction issue, and a chunk costs the same whether 3 or 60 of its lanes are live;
+//   the four waves' sums are added in wave order: one row of partial sums per workgroup (a 1M cloud
+//   leaves 984 rows: the solve kernel adds them itself, no row-reduction launch).
+// bounds_valid = 0: no usable bounds (the previous iteration was searched by k_nn_grid): every query
+// is searched and leaves its bound.
+constexpr int kCertWaves = 4;
 template <int STATS, int NB, int RC>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_per_eu(4, 4)))
     k_nn_cert(const LevelsDev *__restrict__ lv, const float4 *__restrict__ src, unsigned n,
               IcpDevState *__restrict__ st, float thr_d2, unsigned long long *__restrict__ keys,
               float4 *__restrict__ match_pt, float4 *__restrict__ bound, const float4 *__restrict__ tgt_orig,
-              float r_light_cells, float lane_lf, float coop_lf, float r0_cells, unsigned xcd_chunk,
+              float r_light_cells, float lane_lf, float coop_lf, float r0_cells, unsigned xflags,
               double *__restrict__ partials, int bounds_valid, float pad_mul, float pad_frac,
               unsigned *__restrict__ uns_count, unsigned long long *__restrict__ prof_out) {
-    // developer (prof_out): shader-clock stamps of every 512th workgroup's life, 16 per sampled workgroup
-    // (the phases between them: see scripts/dev/dev_cert_prof.py); nothing is recorded otherwise
-    const bool stamp_on = prof_out != nullptr && (blockIdx.x & 511u) == 0u;
-    unsigned long long pt[12];
-#define WM_STAMP(k) do { if (stamp_on) pt[k] = clock64(); } while (0)
-#pragma unroll
-    for (int k = 0; k < 12; ++k) pt[k] = 0ull;
-    WM_STAMP(0);
-    // (the wave's life is a chain of memory round trips: the phase's three streams are requested before
+    // (a wave's life is a chain of memory round trips: the phase's three streams are requested before
     // anything else is looked at -- their addresses need nothing but the block number)
     const unsigned lane = threadIdx.x & 63u;
-    const bool nt = ((xcd_chunk >> 28) & 1u) != 0u;  // non-temporal result stores (st_f4 ...)
-    const unsigned xs = xcd_chunk & 0x03FFFFFFu;
-    const unsigned dbg_skip = (xcd_chunk >> 26) & 3u;  // developer timing experiment (WRONG results): 1 = no phase 2, 2 = phase 2 without its scans
-    const unsigned row = xs ? xcd_remap_chunked(blockIdx.x, xs) : xcd_remap(blockIdx.x, gridDim.x);
-    const unsigned base = row * (64u * NB);
+    const unsigned wave = (unsigned) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const bool nt = ((xflags >> 28) & 1u) != 0u;  // non-temporal result stores (st_f4 ...)
+    const unsigned dbg_skip = (xflags >> 26) & 3u;  // developer timing experiment (WRONG results): 1 = no phase 2, 2 = phase 2 without its scans
+    const unsigned row = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned gbase = row * (64u * NB * kCertWaves);  // the workgroup's first query
+    const unsigned base = gbase + wave * (64u * NB);        // the wave's
     float4 p[NB], mp[NB], rf[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -1136,12 +1134,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         mp[j] = match_pt[i];  // (meaningless before the first search, and then not looked at)
         rf[j] = bound[i];
     }
-    if (st->done) return;
-    __shared__ BalLds L;
-    __shared__ unsigned s_second[64];
-    __shared__ float4 s_win[64];
-    __shared__ unsigned short s_list[64 * NB];
-    s_win[threadIdx.x & 63u] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoIdx));  // (no winner recorded)
+    if (st->done) return;  // (uniform over the workgroup)
+    // developer (prof_out): shader-clock stamps of wave 0 of every 256th workgroup, 16 per sample
+    // (the phases between them: scripts/dev/dev_cert_prof.py); nothing is recorded otherwise
+    const bool stamp_on = prof_out != nullptr && (blockIdx.x & 255u) == 0u && wave == 0u;
+    unsigned long long pt[12];
+#define WM_STAMP(k) do { if (stamp_on) pt[k] = clock64(); } while (0)
+#pragma unroll
+    for (int k = 0; k < 12; ++k) pt[k] = 0ull;
+    WM_STAMP(0);
+    __shared__ BalLds s_L[kCertWaves];
+    __shared__ unsigned s_second[kCertWaves][64];
+    __shared__ float4 s_win[kCertWaves][64];
+    __shared__ unsigned short s_list[kCertWaves][64 * NB];
+    __shared__ unsigned s_cnt[kCertWaves];
+    __shared__ double s_rows[kCertWaves][kAcc];
+    BalLds &L = s_L[wave];
+    s_win[wave][lane] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoIdx));  // (no winner recorded)
     const int Ln = lv->n;
     float hl[kMaxLevels];  // the levels' cell sizes (wave-uniform: scalar registers)
 #pragma unroll
@@ -1195,8 +1204,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 any = any || settled;
                 if constexpr (STATS == WM_ICP_SVD) {
                     // (the first batch of a pair assigns, the second accumulates with fused multiply-adds:
-                    // half the f64 instructions of forming the terms and adding them -- this phase is
-                    // bound by instruction issue, not by HBM)
+                    // half the f64 instructions of forming the terms and adding them)
                     const double m = settled ? 1.0 : 0.0;
                     const double px = settled ? (double) qx : 0.0, py = settled ? (double) qy : 0.0,
                                  pz = settled ? (double) qz : 0.0;
@@ -1261,9 +1269,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned) (umask >> 32),
                                                                   __builtin_amdgcn_mbcnt_lo((unsigned) umask, 0u));
                 const unsigned e = n_uns + before;
-                s_list[e] = (unsigned short) ((unsigned) j * 64u + lane);
-                // the first chunk's queries are parked (pose applied, match, displacement) where the
-                // pooled walk will keep its list: phase 2 starts without another round trip to memory
+                s_list[wave][e] = (unsigned short) ((unsigned) j * 64u + lane);
+                // the wave's first 64 are parked (pose applied, match) where its pooled walk will keep
+                // its list: phase 2 starts without another round trip to memory
                 if (valid && e < 64u) {
                     float4 *park = reinterpret_cast<float4 *>(L.items);
                     park[2u * e] = make_float4(qx, qy, qz, 0.f);
@@ -1273,35 +1281,87 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             n_uns += (unsigned) __popcll(umask);
         }
     }
-    if (uns_count && lane == 0 && n_uns) atomicAdd(&uns_count[blockIdx.x & 63u], n_uns);  // developer statistics
-    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) s_cnt[wave] = n_uns;
     WM_STAMP(3);  // phase 1 done
-    // ---- phase 2: search what is left, 64 queries at a time
+    __syncthreads();
+    // ---- phase 2: what is left in the workgroup, 64 queries at a time, chunk c by wave c mod 4
+    unsigned cum[kCertWaves + 1];
+    cum[0] = 0;
+#pragma unroll
+    for (int w = 0; w < kCertWaves; ++w) cum[w + 1] = cum[w] + s_cnt[w];
+    unsigned U = cum[kCertWaves];
+    if (uns_count && threadIdx.x == 0 && U) atomicAdd(&uns_count[blockIdx.x & 63u], U);  // developer statistics
+    if (dbg_skip == 1u && valid) U = 0;
+    const unsigned nchunks = (U + 63u) / 64u;
     unsigned cost = 0;
     unsigned long long prof[3] = {0ull, 0ull, 0ull};
-    if (dbg_skip == 1u && valid) n_uns = 0;
-    for (unsigned c0 = 0; c0 < n_uns; c0 += 64u) {
-        const bool mine = c0 + lane < n_uns;
-        const unsigned i = base + (mine ? (unsigned) s_list[c0 + lane] : 0u);
+    // The wave's first chunk is gathered from the four waves' parked entries BEFORE any wave scans (a
+    // scan overwrites its wave's parking area), and set down again in the wave's own area after the
+    // barrier: query (pose applied), its index, its match.
+    {
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        float4 gtp = make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoIdx));
+        unsigned gi = kNoIdx;
+        const unsigned e = wave * 64u + lane;
+        if (wave < nchunks && e < U) {
+            const unsigned w = (e >= cum[1] ? 1u : 0u) + (e >= cum[2] ? 1u : 0u) + (e >= cum[3] ? 1u : 0u);
+            const unsigned k = e - (w == 0u ? cum[0] : (w == 1u ? cum[1] : (w == 2u ? cum[2] : cum[3])));
+            gi = gbase + w * (64u * NB) + (unsigned) s_list[w][k];
+            if (valid && k < 64u) {
+                const float4 *park = reinterpret_cast<const float4 *>(s_L[w].items);
+                const float4 a = park[2u * k];
+                gtp = park[2u * k + 1u];
+                gx = a.x;
+                gy = a.y;
+                gz = a.z;
+            } else {
+                const float4 p1 = src[gi];
+                if (have_prev) gtp = match_pt[gi];
+                xform(st->Tf, p1, gx, gy, gz);
+            }
+        }
+        __syncthreads();
+        float4 *own = reinterpret_cast<float4 *>(L.items);
+        own[2u * lane] = make_float4(gx, gy, gz, __uint_as_float(gi));
+        own[2u * lane + 1u] = gtp;
+    }
+    for (unsigned c = wave; c < nchunks; c += kCertWaves) {
+        bool mine;
+        unsigned i;
         float qx = 0.f, qy = 0.f, qz = 0.f, r = 0.f, pad = 0.f;
         float bqx = 0.f, bqy = 0.f, bqz = 0.f;
+        float4 tp = make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoIdx));
+        bool from_mem = false;
+        if (c == wave) {
+            const float4 *own = reinterpret_cast<const float4 *>(L.items);
+            const float4 a = own[2u * lane];
+            tp = own[2u * lane + 1u];
+            i = __float_as_uint(a.w);
+            mine = i != kNoIdx;
+            qx = a.x;
+            qy = a.y;
+            qz = a.z;
+            __builtin_amdgcn_wave_barrier();  // (read before the walk reuses this LDS)
+        } else {
+            const unsigned e = c * 64u + lane;
+            mine = e < U;
+            i = 0;
+            if (mine) {
+                const unsigned w = (e >= cum[1] ? 1u : 0u) + (e >= cum[2] ? 1u : 0u) + (e >= cum[3] ? 1u : 0u);
+                const unsigned k = e - (w == 0u ? cum[0] : (w == 1u ? cum[1] : (w == 2u ? cum[2] : cum[3])));
+                i = gbase + w * (64u * NB) + (unsigned) s_list[w][k];
+            }
+            from_mem = mine;
+        }
         unsigned long long best = make_key(thr_d2, kNoIdx);
         unsigned long long seeded = best;
         bool heavy = false;
+        if (from_mem) {
+            const float4 p1 = src[i];
+            if (have_prev) tp = match_pt[i];
+            xform(st->Tf, p1, qx, qy, qz);
+        }
         if (mine) {
-            float4 tp = make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoIdx));
-            if (valid && c0 == 0u) {  // parked by phase 1
-                const float4 *park = reinterpret_cast<const float4 *>(L.items);
-                const float4 a = park[2u * lane];
-                tp = park[2u * lane + 1u];
-                qx = a.x;
-                qy = a.y;
-                qz = a.z;
-            } else {
-                const float4 p1 = src[i];
-                if (have_prev) tp = match_pt[i];
-                xform(st->Tf, p1, qx, qy, qz);
-            }
             r = r0_cells * h0;
             if (have_prev) {
                 const unsigned pidx = __float_as_uint(tp.w);
@@ -1322,13 +1382,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             r = fminf(r, rmax);
             heavy = r > r_light;
         }
-        __builtin_amdgcn_wave_barrier();  // (the parked entries have been read before the walk reuses their LDS)
-        if (c0 == 0u) WM_STAMP(4);  // first chunk: seeds ready
+        if (c == wave) WM_STAMP(4);  // first chunk: seeds ready
         Bound bnd;
         bnd.second = 0x7F800000u;
         bnd.pad = pad;
-        bnd.lds = s_second;
-        bnd.win = s_win;
+        bnd.lds = s_second[wave];
+        bnd.win = s_win[wave];
         bnd.ok = true;
         float margin_last = 0.f;
         L.q[lane] = make_float4(qx, qy, qz, 0.f);
@@ -1348,13 +1407,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             if (__ballot(live && l != l0) == 0ull) {
                 const GridDev g = l0 == 0 ? g0 : lv->g[l0];
                 if (!scan_box_rows(g, live, qx, qy, qz, r, best, &margin, L, lane, &bnd))
-                best = scan_box_bal<false, RC, true>(g, live, qx, qy, qz, r, best, &margin, L, lane, have_prev,
-                                                                g.pts, cost, prof, true, &bnd);
+                    best = scan_box_bal<false, RC, true>(g, live, qx, qy, qz, r, best, &margin, L, lane, have_prev,
+                                                          g.pts, cost, prof, true, &bnd);
             } else {
                 const GridDev g = lv->g[l];
                 L.base[lane] = (unsigned long long) g.pts;
                 best = scan_box_bal<false, RC, true>(g, live, qx, qy, qz, r, best, &margin, L, lane, have_prev,
-                                                                nullptr, cost, prof, true, &bnd);
+                                                      nullptr, cost, prof, true, &bnd);
             }
             if (live) {
                 const float bd2 = __uint_as_float((unsigned) (best >> 32));
@@ -1369,7 +1428,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 }
             }
         }
-        if (c0 == 0u) WM_STAMP(5);  // first chunk: pass loop done
+        if (c == wave) WM_STAMP(5);  // first chunk: pass loop done
         // cooperative phase for radii beyond r_light (k_nn_grid's; no bound comes out of it)
         unsigned long long todo = __ballot(heavy);
         float seed = 0.f;
@@ -1404,22 +1463,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         bqx = L.bq[0][lane];
         bqy = L.bq[1][lane];
         bqz = L.bq[2][lane];
-        if (c0 == 0u) WM_STAMP(6);  // first chunk: cooperative phase done
+        if (c == wave) WM_STAMP(6);  // first chunk: cooperative phase done
         if (mine) {
             st_u64(&keys[i], best, nt);
             if (best != seeded && (unsigned) best != kNoIdx) {
                 // the new match's coordinates: left in LDS by the lane that found it (the tag says whether
                 // the slot really is this point's), else from the caller-ordered target copy
-                const float4 w = s_win[lane];
+                const float4 w = s_win[wave][lane];
                 if (__float_as_uint(w.w) == (unsigned) best) {
                     bqx = w.x;
                     bqy = w.y;
                     bqz = w.z;
                 } else {
-                    const f4v c = ((gp_f4) tgt_orig)[(unsigned) best];
-                    bqx = c.x;
-                    bqy = c.y;
-                    bqz = c.z;
+                    const f4v cc = ((gp_f4) tgt_orig)[(unsigned) best];
+                    bqx = cc.x;
+                    bqy = cc.y;
+                    bqz = cc.z;
                 }
             }
             st_f4(&match_pt[i], bqx, bqy, bqz, __uint_as_float((unsigned) best), nt);
@@ -1432,7 +1491,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             }
             st_f4(&bound[i], qx, qy, qz, s, nt);  // ... seen from HERE
         }
-        if (c0 == 0u) WM_STAMP(7);  // first chunk: winners fetched, results stored
+        if (c == wave) WM_STAMP(7);  // first chunk: winners fetched, results stored
         if constexpr (STATS >= 0) {
             double a[kAcc];
             icp_terms<STATS>(a, mine, (unsigned) best != kNoIdx, qx, qy, qz, bqx, bqy, bqz,
@@ -1440,19 +1499,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             acc_halve<kAcc, 32>(a, lane);
             rowacc += comp >= 0 ? a[0] : 0.0;
         }
-        if (c0 == 0u) WM_STAMP(8);  // first chunk: sums reduced
+        if (c == wave) WM_STAMP(8);  // first chunk: sums reduced
         __builtin_amdgcn_wave_barrier();
     }
     WM_STAMP(10);
     if constexpr (STATS >= 0) {
-        if (comp >= 0) st_f64(&partials[(size_t) row * kAcc + comp], rowacc, nt);
+        // the four waves' sums, added in wave order
+        if (comp >= 0) s_rows[wave][comp] = rowacc;
+        __syncthreads();
+        if (threadIdx.x < (unsigned) kAcc) {
+            double t = s_rows[0][threadIdx.x];
+#pragma unroll
+            for (int w = 1; w < kCertWaves; ++w) t += s_rows[w][threadIdx.x];
+            st_f64(&partials[(size_t) row * kAcc + threadIdx.x], t, nt);
+        }
     }
     if (stamp_on && lane == 0) {
         pt[11] = clock64();
-        unsigned long long *o = prof_out + 16 * (blockIdx.x >> 9);
+        unsigned long long *o = prof_out + 16 * (blockIdx.x >> 8);
 #pragma unroll
         for (int k = 0; k < 12; ++k) o[k] = pt[k];
-        o[12] = n_uns;
+        o[12] = U;
     }
 #undef WM_STAMP
 }
@@ -1615,7 +1682,7 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
 
 template <int STATS, int NB, int RC>
 static void launch_nn_cert_t(wm_ctx *ctx, unsigned blocks, float thr_d2, unsigned xcd_chunk, bool bounds_valid) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_cert<STATS, NB, RC>), dim3(blocks), dim3(64), 0, ctx->stream,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_cert<STATS, NB, RC>), dim3(blocks), dim3(64 * kCertWaves), 0, ctx->stream,
                        ctx->d_levels.as<LevelsDev>(), ctx->src_sorted.as<float4>(), (unsigned) ctx->n_src,
                        ctx->d_state.as<IcpDevState>(), thr_d2, ctx->keys.as<unsigned long long>(),
                        ctx->match_pt.as<float4>(), ctx->nn_bound.as<float4>(), ctx->tgt_orig.as<float4>(),
@@ -1641,28 +1708,19 @@ int launch_nn_cert(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
     const unsigned n = (unsigned) ctx->n_src;
     if (rows_out) *rows_out = 0;
     if (n == 0) return WM_OK;
-    const int nb = ctx->tune_cert_nb == 2 ? 2 : (ctx->tune_cert_nb == 8 ? 8 : 4);
-    const unsigned per = 64u * (unsigned) nb;
+    const int nb = ctx->tune_cert_nb == 2 ? 2 : 4;
+    const unsigned per = 64u * (unsigned) nb * (unsigned) kCertWaves;
     unsigned blocks = (n + per - 1u) / per;
     blocks = (blocks + 7u) & ~7u;  // xcd_remap needs a multiple of 8
-    unsigned xcd_chunk = 0;
-    if (blocks >= 256u) {  // XCDs take turns in chunks of 8 workgroups (see xcd_remap_chunked)
-        xcd_chunk = 8u;
-        blocks = (blocks + 63u) / 64u * 64u;
-    }
-    const unsigned xflags = (ctx->tune_nn_nt_stores ? 0x10000000u : 0u) | (((unsigned) ctx->tune_cert_dbg_skip & 3u) << 26);
     WM_HIP(ctx, ctx->nn_bound.reserve(((size_t) n + 64) * sizeof(float4)));
     if (stats_mode >= 0) {
         WM_HIP(ctx, ctx->partials.reserve((size_t) blocks * kAcc * sizeof(double)));
         if (rows_out) *rows_out = blocks;
     }
+    const unsigned xflags = (ctx->tune_nn_nt_stores ? 0x10000000u : 0u) | (((unsigned) ctx->tune_cert_dbg_skip & 3u) << 26);
     if (ev0) WM_HIP(ctx, hipEventRecord(ev0, ctx->stream));
-    const bool rc6 = ctx->tune_cert_rc == 6, rc4 = ctx->tune_cert_rc == 4;
-    if (nb == 2) launch_nn_cert_nb<2, 3>(ctx, blocks, thr_d2, xcd_chunk | xflags, bounds_valid, stats_mode);
-    else if (nb == 8) launch_nn_cert_nb<8, 3>(ctx, blocks, thr_d2, xcd_chunk | xflags, bounds_valid, stats_mode);
-    else if (rc6) launch_nn_cert_nb<4, 6>(ctx, blocks, thr_d2, xcd_chunk | xflags, bounds_valid, stats_mode);
-    else if (rc4) launch_nn_cert_nb<4, 4>(ctx, blocks, thr_d2, xcd_chunk | xflags, bounds_valid, stats_mode);
-    else launch_nn_cert_nb<4, 3>(ctx, blocks, thr_d2, xcd_chunk | xflags, bounds_valid, stats_mode);
+    if (nb == 2) launch_nn_cert_nb<2, 3>(ctx, blocks, thr_d2, xflags, bounds_valid, stats_mode);
+    else launch_nn_cert_nb<4, 3>(ctx, blocks, thr_d2, xflags, bounds_valid, stats_mode);
     if (ctx->cert_count.p && ctx->cert_log_iter < ctx->cert_log_cap) ctx->cert_log_iter++;
     if (ev1) WM_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     if (ev2) WM_HIP(ctx, hipEventRecord(ev2, ctx->stream));

@@ -25,6 +25,9 @@ first = 50 - len(cnt)
 names = ["state in", "loads in", "phase 1", "seeds", "passes", "coop", "stores", "sums", "-", "end p2", "end"]
 print("cert launches", len(cnt), "; columns: cycles between stamps:", ", ".join(names))
 for k in range(len(cnt)):
+    t0 = min(prof[k, w, 0] for w in range(4) if prof[k, w, 11] != 0)
+    print("it %2d: sampled workgroups start / end (cycles after the first sampled start):" % (first + k),
+          "  ".join("%d: %.0f / %.0f" % (w * 256, prof[k, w, 0] - t0, prof[k, w, 11] - t0) for w in range(4) if prof[k, w, 11] != 0))
     for w in range(4):
         p = prof[k, w]
         if p[11] == 0:
@@ -33,5 +36,5 @@ for k in range(len(cnt)):
         d[d < 0] = 0   # (stamps of skipped phases)
         seg = [p[1] - p[0], p[2] - p[1], p[3] - p[2], p[4] - p[3], p[5] - p[4], p[6] - p[5], p[7] - p[6], p[8] - p[7], 0,
                p[10] - max(p[8], p[3]), p[11] - p[10]]
-        print("it %2d %5.1f us uns %6d | wg %d (uns %3d) total %6.0f :" % (first + k, it[first + k], cnt[k], w * 512, p[12], p[11] - p[0]),
+        print("it %2d %5.1f us uns %6d | wg %d (uns %3d) total %6.0f :" % (first + k, it[first + k], cnt[k], w * 256, p[12], p[11] - p[0]),
               " ".join("%6.0f" % v for v in seg))
