@@ -145,27 +145,6 @@ def cpu_baseline(ref, tgt, iters_full, max_corr, cpu_iters):
     return out
 
 
-def measured_copy_bandwidth(torch, dev):
-    """Device-to-device copy rate of this very box (GB/s, read + write bytes): the practical HBM
-    ceiling to hold next to the 8 TB/s specification (SURVEY 8(d) asks for it in the same run)."""
-    n = 1 << 28  # 1 GiB of f32 in, 1 GiB out
-    a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
-    b = torch.empty_like(a)
-    for _ in range(2):
-        b.copy_(a)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    reps = 10
-    for _ in range(reps):
-        b.copy_(a)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    del a, b
-    return 2.0 * n * 4 / (ms * 1e-3) / 1e9
-
-
 def pmc_summary():
     """Committed PMC summary of this bench command (profiles/pmc_latest.json, written by
     scripts/gpu_pmc.sh + scripts/pmc_to_json.py from separate rocprofv3 --pmc passes)."""
@@ -176,10 +155,10 @@ def pmc_summary():
         return {}
 
 
-def pmc_traffic_bytes(pmc):
-    """HBM bytes per launch of the correspondence kernel: FETCH_SIZE doubled (MI355X_MICROARCH.md:
-    gfx950 tallies 128-B requests at 64 B for wide coalesced reads) + WRITE_SIZE as reported."""
-    d = pmc.get("k_nn_grid")
+def pmc_traffic_bytes(pmc, kernel="k_nn_grid"):
+    """HBM bytes per launch of a kernel: FETCH_SIZE doubled (MI355X_MICROARCH.md: gfx950 tallies
+    128-B requests at 64 B for wide coalesced reads) + WRITE_SIZE as reported."""
+    d = pmc.get(kernel)
     if not d or "FETCH_SIZE_kb_per_dispatch" not in d:
         return None
     return (2.0 * d["FETCH_SIZE_kb_per_dispatch"] + d["WRITE_SIZE_kb_per_dispatch"]) * 1024.0
@@ -421,6 +400,8 @@ def main():
     t0 = time.perf_counter()
     nn_ms = 0.0
     nn_launches = 0
+    cert_ms = 0.0
+    cert_launches = 0
     step_ms = []
     for k in range(a.steps):
         # HIP events around every launch of the correspondence kernel cost a barrier packet
@@ -433,6 +414,8 @@ def main():
         if timed:
             nn_ms += r["nn_ms"]
             nn_launches += r["nn_launches"]
+            cert_ms += r.get("nn_cert_ms", 0.0)
+            cert_launches += r.get("cert_launches", 0)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -474,21 +457,45 @@ def main():
                 "final_translation_error_m": err_t, "grid_cell_m": r.get("grid_cell"),
                 "ms_each_step_rank0": [round(t, 3) for t in step_ms],
             },
-            "roofline": {
-                "bound": "hbm", "kernel": "wm::k_nn_grid (correspondence search + the iteration's statistics)",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_bytes(pmc) if world == 1 else None,
-                "traffic_source": ("profiles/pmc_latest.json, tag %s (separate rocprofv3 --pmc passes of this "
-                                   "command; a committed measurement, not this run's)" % pmc.get("tag")) if pmc else None,
-                "peak_measured_copy": measured_copy_bandwidth(torch, dev) if world == 1 else None,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "avg_launch_us": nn_us, "launches_timed": nn_launches,
-                "note": "an exact gather search: the kernel streams 64 B/point (source, previous key + match in; "
-                        "key + match out) and takes its candidates out of L1/L2; what binds is the vector ALU and "
-                        "the L1 address path of the candidate walk (DESIGN.md section 4.1 / 5, "
-                        "profiles/r02*_pmc_k_nn_grid_per_iteration.csv), not HBM",
-            },
+            "roofline": None,
+        }
+        # The correspondence step of an iteration is ONE launch of one of two kernels: the full search
+        # (k_nn_grid) while the clouds still move, the certificate kernel (k_nn_cert: previous match proved
+        # still nearest, search only where the proof fails) once a step is small.  Both leave the same keys
+        # and carry the iteration's statistics; SURVEY 8(d)'s 32 B x n is the algorithmic traffic of either.
+        peak_copy = ctx.copy_bandwidth() if world == 1 else None
+        grid_launches = nn_launches - cert_launches
+        kernels = []
+        for name, key, ms, launches in (("wm::k_nn_grid", "k_nn_grid", nn_ms - cert_ms, grid_launches),
+                                        ("wm::k_nn_cert", "k_nn_cert", cert_ms, cert_launches)):
+            if launches <= 0:
+                continue
+            us = ms / launches * 1e3
+            tr = pmc_traffic_bytes(pmc, key) if world == 1 else None
+            kernels.append({"name": name, "launches_timed": launches, "avg_launch_us": us,
+                            "share_of_search_time": ms / nn_ms if nn_ms > 0 else None,
+                            "achieved": alg_bytes / (us * 1e-6) / 1e9, "frac": alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                            "traffic": tr,
+                            "hbm_util": (tr / (us * 1e-6) / 1e9 / peak_copy) if (tr and peak_copy) else None})
+        traffic = None
+        if kernels and all(k["traffic"] for k in kernels):
+            traffic = sum(k["traffic"] * k["launches_timed"] for k in kernels) / max(nn_launches, 1)
+        out["roofline"] = {
+            "bound": "hbm",
+            "kernel": "the correspondence step of an ICP iteration: one launch of wm::k_nn_grid or wm::k_nn_cert "
+                      "(search + the iteration's statistics); launch-weighted over both, per kernel in `kernels`",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "hbm_util": (traffic / (nn_us * 1e-6) / 1e9 / peak_copy) if (traffic and peak_copy) else None,
+            "traffic_source": ("profiles/pmc_latest.json, tag %s (separate rocprofv3 --pmc passes of this "
+                               "command; a committed measurement, not this run's)" % pmc.get("tag")) if pmc else None,
+            "peak_measured_copy": peak_copy,
+            "peak_measured_copy_method": "float4 grid-stride copy kernel, 1 GiB in + 1 GiB out, 10 launches (wm_debug_copy_bandwidth)",
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "avg_launch_us": nn_us, "launches_timed": nn_launches, "kernels": kernels,
+            "note": "an exact gather search: what binds is the vector ALU and the L1 address path of the candidate "
+                    "walk (k_nn_grid) and instruction issue + workgroup dispatch (k_nn_cert), not HBM (DESIGN.md "
+                    "sections 4.1 / 5)",
         }
         if world == 1 and dist is None:
             # the same registration from HOST clouds: H2D of both clouds inside the step
@@ -506,6 +513,10 @@ def main():
                 hc[name] = {"ms_per_registration": float(np.median(ts)), "registrations_per_s": 1e3 / float(np.median(ts))}
             hc["note"] = "wm_set_source / wm_set_target with WM_MEM_HOST: 2 x 16 MB cross PCIe inside the step"
             out["config"]["host_clouds"] = hc
+            # SURVEY 8(d) counts the upload of both clouds as part of a registration: that rate, first class
+            out["value_h2d_inclusive"] = hc["pinned"]["registrations_per_s"]
+            out["value_h2d_inclusive_note"] = ("the same registration from pinned HOST clouds (both uploads inside the "
+                                               "timed step); `value` is with the clouds already in HBM")
         if world == 1 and not a.no_other_configs:
             out["other_configs"] = other_configs(torch, dev, capi, synth, pmc, not a.no_cpu_baseline)
         if world == 1 and not a.no_cpu_baseline:

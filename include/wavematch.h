@@ -135,7 +135,7 @@ typedef struct {
     int cert_launches;   /* iterations whose correspondences came from the certificate kernel
                             (k_nn_cert: previous match proved still nearest, search only where the
                             proof fails) instead of a full search; same correspondences either way */
-    int reserved0;
+    float nn_cert_ms;    /* the part of nn_ms spent in those launches (profile >= 1) */
 } wm_icp_stats;
 
 void wm_icp_default_params(wm_icp_params *p);
@@ -231,6 +231,10 @@ enum { WM_INFO_LUM = 0, WM_INFO_CENSI = 1, WM_INFO_LUMOLD = 2 };
 int wm_icp_info(wm_ctx *ctx, int method, const double T_result[16], double lin_covar,
                 double ang_covar, double max_corr, double info[36], int *degenerate);
 
+/* Device-to-device copy rate of this GPU (GB/s, read + write bytes) measured with a plain float4
+ * copy kernel on the context's stream: the practical HBM ceiling to hold next to the 8 TB/s
+ * specification (bench.py's roofline.peak_measured_copy). */
+int wm_debug_copy_bandwidth(wm_ctx *ctx, size_t bytes, int reps, double *gb_per_s);
 /* Tuning knobs by name (tests, benchmarks; the defaults are the product's): "cert_from" (-1: the
  * certificate kernel takes over once an ICP step is small, -2: never, k >= 0: from iteration k of
  * every align), "cert_disp" (that step size, in level-0 grid cells), "cert_pad_mul",

@@ -44,7 +44,7 @@ class IcpStats(C.Structure):
                 ("stats_ms", C.c_float),
                 ("solve_ms", C.c_float), ("nn_launches", C.c_int), ("nn_levels", C.c_int),
                 ("deferred", C.c_uint64), ("grid_cell", C.c_float),
-                ("owned_violations", C.c_int), ("cert_launches", C.c_int), ("reserved0", C.c_int)]
+                ("owned_violations", C.c_int), ("cert_launches", C.c_int), ("nn_cert_ms", C.c_float)]
 
 
 class BatchItem(C.Structure):
@@ -104,6 +104,7 @@ def lib():
         L.wm_set_target.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
         L.wm_set_grid_cell.argtypes = [C.c_void_p, C.c_float]
         L.wm_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        L.wm_debug_copy_bandwidth.argtypes = [C.c_void_p, C.c_size_t, C.c_int, _dp]
         L.wm_debug_cert_log.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint), C.c_int]
         L.wm_debug_cert_prof.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
         L.wm_cloud_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
@@ -282,6 +283,13 @@ class Context:
         self._check(lib().wm_set_target(self._h, C.c_void_p(ptr), n, stride, mem), "wm_set_target")
         self.n_tgt = n
 
+    def copy_bandwidth(self, nbytes=1 << 30, reps=10):
+        """GB/s (read + write) of a float4 device-to-device copy kernel on this GPU."""
+        out = C.c_double(0)
+        self._check(lib().wm_debug_copy_bandwidth(self._h, int(nbytes), int(reps), C.byref(out)),
+                    "wm_debug_copy_bandwidth")
+        return out.value
+
     def set_option(self, name, value):
         self._check(lib().wm_set_option(self._h, name.encode(), C.c_double(value)), "wm_set_option")
 
@@ -324,7 +332,8 @@ class Context:
                     nn_ms=s.nn_ms, coarse_ms=s.coarse_ms, stats_ms=s.stats_ms,
                     solve_ms=s.solve_ms, nn_launches=s.nn_launches, nn_levels=s.nn_levels,
                     deferred=s.deferred, grid_cell=s.grid_cell,
-                    owned_violations=s.owned_violations, cert_launches=s.cert_launches)
+                    owned_violations=s.owned_violations, cert_launches=s.cert_launches,
+                    nn_cert_ms=s.nn_cert_ms)
 
     def icp_match(self, ref, target, res=-1.0, multiscale_steps=0, params=None, **kw):
         """ICPMatcher::match() (icp.cpp:75-133) in one C-ABI call."""

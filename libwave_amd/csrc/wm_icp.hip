@@ -305,6 +305,26 @@ __global__ void __launch_bounds__(kBlock)
     d2[orig] = __uint_as_float((unsigned) (key >> 32));
 }
 
+// a plain float4 copy: what this GPU's HBM delivers to a streaming kernel (read + write).  NT:
+// four loads in flight per lane, non-temporal both ways (scripts/dev/copy_probe.hip: which shape
+// wins varies from box to box by ~10 %, so wm_debug_copy_bandwidth reports the best of three)
+typedef float copy_f4v __attribute__((ext_vector_type(4)));
+template <bool NT>
+__global__ void __launch_bounds__(256) k_copy_f4(const copy_f4v *__restrict__ a, copy_f4v *__restrict__ b, size_t n) {
+    const size_t stride = (size_t) gridDim.x * 256u;
+    size_t i = (size_t) blockIdx.x * 256u + threadIdx.x;
+    if constexpr (NT) {
+        for (; i + 3 * stride < n; i += 4 * stride) {
+            copy_f4v v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(a + i + u * stride);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) __builtin_nontemporal_store(v[u], b + i + u * stride);
+        }
+    }
+    for (; i < n; i += stride) b[i] = a[i];
+}
+
 // ------------------------------------------------------------------ host
 static int stat_blocks(size_t n) {
     size_t b = (n + kBlock - 1) / kBlock;
@@ -968,6 +988,7 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
     const float cert_thr = brute ? 0.f : ctx->tune_cert_disp * ctx->levels[0].d.h;
     size_t ev_used = 0;
     ctx->cert_launches = 0;
+    std::vector<unsigned char> was_cert;
     for (int it = 0; it < max_it; ++it) {
         float seen_disp = -1.f;  // the step size iteration it - kLag published (its own record)
         if (it >= kLag) {  // wait for it (3 stages as in wait_flag)
@@ -1034,6 +1055,10 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
             WM_TRY(launch_nn_cert(ctx, thr, e0, e1, e1b, p->mode, &rows, bounds_valid));
             bounds_valid = true;
             ctx->cert_launches++;
+            if (p->profile) {
+                was_cert.resize((size_t) it + 1, 0);
+                was_cert[(size_t) it] = 1;
+            }
         } else {
             WM_TRY(launch_search_and_stats(ctx, thr, p->mode, e0, e1, e1b, &rows));
             bounds_valid = false;
@@ -1079,6 +1104,7 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
                 }
                 ctx->iter_nn_ms.push_back(a);
                 stats->nn_ms += a;
+                if ((size_t) it < was_cert.size() && was_cert[(size_t) it]) stats->nn_cert_ms += a;
                 stats->coarse_ms += a2;
                 stats->stats_ms += b;
                 stats->solve_ms += c;
@@ -1376,6 +1402,43 @@ int wm_debug_phase_log(wm_ctx *ctx, unsigned long long *out, int iterations) {
 int wm_debug_solve_cycles(wm_ctx *ctx, unsigned long long out[8]) {
     if (!ctx || !out || !ctx->h_state) return WM_ERR_ARG;
     for (int k = 0; k < 8; ++k) out[k] = ctx->h_state->dbg[k];
+    return WM_OK;
+}
+
+int wm_debug_copy_bandwidth(wm_ctx *ctx, size_t bytes, int reps, double *gb_per_s) {
+    if (!ctx || !gb_per_s || bytes < (1u << 20) || reps < 1) return WM_ERR_ARG;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = bytes / sizeof(float4);
+    float4 *a = nullptr, *b = nullptr;
+    WM_HIP(ctx, hipMalloc((void **) &a, n * sizeof(float4)));
+    if (hipMalloc((void **) &b, n * sizeof(float4)) != hipSuccess) {
+        (void) hipFree(a);
+        ctx->last_error = "wm_debug_copy_bandwidth: hipMalloc failed";
+        return WM_ERR_NOMEM;
+    }
+    (void) hipMemsetAsync(a, 0x3c, n * sizeof(float4), ctx->stream);
+    const copy_f4v *ca = reinterpret_cast<const copy_f4v *>(a);
+    copy_f4v *cb = reinterpret_cast<copy_f4v *>(b);
+    float ms = 0;
+    hipError_t e = hipSuccess;
+    for (int shape = 0; shape < 3; ++shape) {
+        const unsigned blocks = shape == 0 ? 1024u : (shape == 1 ? 65536u : 16384u);
+        for (int r = -2; r < reps; ++r) {  // two warm-up launches
+            if (r == 0) (void) hipEventRecord(ctx->ev_a, ctx->stream);
+            if (shape == 2) hipLaunchKernelGGL(k_copy_f4<true>, dim3(blocks), dim3(256), 0, ctx->stream, ca, cb, n);
+            else hipLaunchKernelGGL(k_copy_f4<false>, dim3(blocks), dim3(256), 0, ctx->stream, ca, cb, n);
+        }
+        (void) hipEventRecord(ctx->ev_b, ctx->stream);
+        e = hipEventSynchronize(ctx->ev_b);
+        float t = 0;
+        (void) hipEventElapsedTime(&t, ctx->ev_a, ctx->ev_b);
+        if (e != hipSuccess) break;
+        if (shape == 0 || (t > 0 && t < ms)) ms = t;
+    }
+    (void) hipFree(a);
+    (void) hipFree(b);
+    WM_HIP(ctx, e);
+    *gb_per_s = ms > 0 ? 2.0 * (double) (n * sizeof(float4)) * reps / (ms * 1e-3) / 1e9 : 0.0;
     return WM_OK;
 }
 

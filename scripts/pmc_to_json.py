@@ -47,4 +47,4 @@ if len(sys.argv) > 3:
                                "f64_flops_per_source_point": winst / disp * 64.0 * lanes / n_points,
                                "source": os.path.basename(os.path.normpath(nd))}
 json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
-print(json.dumps(out.get("k_nn_grid", {}), indent=1))
+print(json.dumps({k: out.get(k, {}) for k in ("k_nn_grid", "k_nn_cert")}, indent=1))
