@@ -395,6 +395,7 @@ def main():
     for _ in range(a.warmup):
         r = step(1)
     torch.cuda.synchronize()
+    ar_us = ctx.allreduce_probe(comm) if comm is not None else None
     if dist:
         dist.barrier()
     t0 = time.perf_counter()
@@ -455,6 +456,7 @@ def main():
                 "registrations_per_s_raw": regs_per_s_raw,
                 "icp_iterations_per_s": regs_per_s_raw * a.iters,
                 "final_translation_error_m": err_t, "grid_cell_m": r.get("grid_cell"),
+                "cert_launches_per_registration": r.get("cert_launches"),
                 "ms_each_step_rank0": [round(t, 3) for t in step_ms],
             },
             "roofline": None,
@@ -497,6 +499,16 @@ def main():
                     "walk (k_nn_grid) and instruction issue + workgroup dispatch (k_nn_cert), not HBM (DESIGN.md "
                     "sections 4.1 / 5)",
         }
+        if comm is not None:
+            # where rank 0's time went in the last (event-bracketed) step, and what an all-reduce costs alone
+            out["config"]["sharding"] = {
+                k: r.get(k) for k in ("plan_ms", "compact_ms", "index_ms", "iter_ms", "allreduce_ms", "n_tgt_local",
+                                      "n_src_local", "rccl_ranks", "shard_attempts", "owned_violations", "align_ms")}
+            out["config"]["sharding"]["allreduce_us_isolated"] = ar_us
+            out["config"]["sharding"]["note"] = (
+                "rank 0, last timed step: plan/compact = device time of slab planning and band selection; index = host "
+                "wall time of building the local clouds' order and grid; iter = host wall time of the 50 iterations; "
+                "allreduce = sum of the 50 ncclAllReduce(32 f64) by HIP events; isolated = back-to-back all-reduces alone")
         if world == 1 and dist is None:
             # the same registration from HOST clouds: H2D of both clouds inside the step
             hc = {}

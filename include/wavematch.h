@@ -136,6 +136,16 @@ typedef struct {
                             (k_nn_cert: previous match proved still nearest, search only where the
                             proof fails) instead of a full search; same correspondences either way */
     float nn_cert_ms;    /* the part of nn_ms spent in those launches (profile >= 1) */
+    /* sharded registrations (wm_icp_align_sharded): where this rank's time went, so that a multi-GPU
+       run explains itself.  Device times from HIP events on the context's stream, ms. */
+    float plan_ms;       /* x range + 64 Ki-bin histogram of a fixed sub-sample of the target, slab edges */
+    float compact_ms;    /* this rank's target slab + halo and source band selected out of the full clouds */
+    float index_ms;      /* host wall time: packing, bounding boxes, source order, grid ladder of the LOCAL clouds */
+    float iter_ms;       /* host wall time of the iteration loop (search, sums, all-reduce, solve) */
+    float allreduce_ms;  /* sum over the iterations' all-reduces of WM_STATS_LEN doubles (profile >= 1) */
+    unsigned n_tgt_local, n_src_local; /* points this rank indexed / searched */
+    int rccl_ranks;      /* ncclCommCount of the communicator (0: none or the in-process stand-in) */
+    int shard_attempts;  /* 2 if the registration had to be redone with full source clouds */
 } wm_icp_stats;
 
 void wm_icp_default_params(wm_icp_params *p);
@@ -430,6 +440,8 @@ int wm_comm_init_rank(wm_comm **out, int device, const void *id, int rank, int w
 int wm_comm_init_all(wm_comm **comms /* [n] */, const int *devices, int n);
 int wm_comm_init_local(wm_comm **comms /* [n] */, int n, int device);
 void wm_comm_destroy(wm_comm *comm);
+/* us per all-reduce of WM_STATS_LEN doubles, `reps` back to back on the context's stream (collective) */
+int wm_comm_allreduce_probe(wm_ctx *ctx, wm_comm *comm, int reps, double *us_out);
 int wm_comm_rank(const wm_comm *comm);
 int wm_comm_world(const wm_comm *comm);
 

@@ -44,7 +44,10 @@ class IcpStats(C.Structure):
                 ("stats_ms", C.c_float),
                 ("solve_ms", C.c_float), ("nn_launches", C.c_int), ("nn_levels", C.c_int),
                 ("deferred", C.c_uint64), ("grid_cell", C.c_float),
-                ("owned_violations", C.c_int), ("cert_launches", C.c_int), ("nn_cert_ms", C.c_float)]
+                ("owned_violations", C.c_int), ("cert_launches", C.c_int), ("nn_cert_ms", C.c_float),
+                ("plan_ms", C.c_float), ("compact_ms", C.c_float), ("index_ms", C.c_float), ("iter_ms", C.c_float),
+                ("allreduce_ms", C.c_float), ("n_tgt_local", C.c_uint), ("n_src_local", C.c_uint),
+                ("rccl_ranks", C.c_int), ("shard_attempts", C.c_int)]
 
 
 class BatchItem(C.Structure):
@@ -160,6 +163,7 @@ def lib():
         L.wm_comm_destroy.argtypes = [C.c_void_p]
         L.wm_comm_destroy.restype = None
         L.wm_comm_rank.argtypes = [C.c_void_p]
+        L.wm_comm_allreduce_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _dp]
         L.wm_comm_world.argtypes = [C.c_void_p]
         L.wm_icp_align_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                            C.c_size_t, C.c_size_t, C.c_int, C.POINTER(IcpParams), _dp,
@@ -557,7 +561,17 @@ class Context:
                          "wm_icp_align_sharded")
         d = self._stats_dict(rc, T, s)
         d["owned_violations"] = s.owned_violations
+        for k in ("plan_ms", "compact_ms", "index_ms", "iter_ms", "allreduce_ms", "n_tgt_local", "n_src_local",
+                  "rccl_ranks", "shard_attempts"):
+            d[k] = getattr(s, k)
         return d
+
+    def allreduce_probe(self, comm, reps=50):
+        """us per all-reduce of the 32-double block on `comm`, back to back on this context's stream."""
+        out = C.c_double(0)
+        self._check(lib().wm_comm_allreduce_probe(self._h, comm.handle, int(reps), C.byref(out)),
+                    "wm_comm_allreduce_probe")
+        return out.value
 
     def ndt_set_comm(self, comm):
         self._check(lib().wm_ndt_set_comm(self._h, comm.handle if comm is not None else None),
@@ -728,8 +742,13 @@ class Multi:
                                       C.byref(p), T.ctypes.data_as(_dp), C.byref(s))
         if rc < 0:
             raise WmError("wm_multi_icp_align: %d (%s)" % (rc, lib().wm_strerror(rc).decode()))
-        return dict(rc=rc, T=T, converged=s.converged, iterations=s.iterations, state=s.state,
-                    n_corr=s.n_corr, mse=s.mse, align_ms=s.align_ms, owned_violations=s.owned_violations)
+        d = dict(rc=rc, T=T, converged=s.converged, iterations=s.iterations, state=s.state,
+                 n_corr=s.n_corr, mse=s.mse, align_ms=s.align_ms, owned_violations=s.owned_violations,
+                 cert_launches=s.cert_launches)
+        for k in ("plan_ms", "compact_ms", "index_ms", "iter_ms", "allreduce_ms", "n_tgt_local", "n_src_local",
+                  "rccl_ranks", "shard_attempts"):
+            d[k] = getattr(s, k)   # (rank 0's)
+        return d
 
     def close(self):
         if self._h:

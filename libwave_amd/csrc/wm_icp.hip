@@ -29,6 +29,7 @@
 namespace wm {
 
 constexpr int kMaxStatBlocks = 256;
+static void set_step_scale(wm_ctx *ctx);
 constexpr int kStatUnroll = 4;  // points per thread per trip of the statistics kernel
 
 __device__ __forceinline__ void xform_pt(const float *T, const float4 &p, float &x, float &y,
@@ -258,6 +259,7 @@ __global__ void __launch_bounds__(THREADS)
 #pragma unroll
             for (int k = 0; k < kStatsLen; ++k) s_st.stats[k] = ex[k];
             if (PHASES == 1 && stats_io) {  // the block the all-reduce works on
+                ex[kStatsLen - 2] = s_st.stripe_finite;  // (a free slot of either layout: summed, it is the cloud's count)
 #pragma unroll
                 for (int k = 0; k < kStatsLen; ++k) stats_io[k] = ex[k];
             }
@@ -946,17 +948,21 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
     const double prev = (p->carry_state && ctx->prev_mse >= 0) ? ctx->prev_mse : DBL_MAX;
     init_state(ctx->h_state, I, p, prev);
     ctx->h_state->svd_warm = ctx->tune_fast_solve ? 1 : 0;
-    {
-        const Bbox &b = ctx->src_bbox;
-        double d2 = 0;
-        for (int k = 0; k < 3; ++k) {
-            ctx->h_state->src_centre[k] = 0.5f * (b.lo[k] + b.hi[k]);
-            d2 += 0.25 * ((double) b.hi[k] - b.lo[k]) * ((double) b.hi[k] - b.lo[k]);
-        }
-        ctx->h_state->src_radius = (float) sqrt(d2);
-    }
+    set_step_scale(ctx);
     WM_TRY(upload_state(ctx));
 
+    return icp_run_loop(ctx, p, brute, thr, nullptr, nullptr, T_out, stats);
+}
+
+}  // extern "C"
+
+namespace wm {
+
+// The iteration loop of one registration, from an uploaded state to the fetched result: shared by
+// wm_icp_align (blk == nullptr) and the sharded registration (wm_shard.hip: blk = the WM_STATS_LEN
+// doubles in HBM that are all-reduced over `comm` between a rank's sums and the solve).
+int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_comm *comm, double *blk,
+                 double T_out[16], wm_icp_stats *stats) {
     const int max_it = p->force_iterations > 0 ? p->force_iterations : p->max_iter;
     const int nb = stat_blocks(ctx->n_src);
     ctx->iter_nn_ms.clear();
@@ -987,6 +993,8 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
     bool cert_on = false, bounds_valid = false, seen_done = false;
     const float cert_thr = brute ? 0.f : ctx->tune_cert_disp * ctx->levels[0].d.h;
     size_t ev_used = 0;
+    size_t ev_ar = (size_t) 5 * (size_t) max_it;  // the all-reduce's event pairs sit behind the iterations' slots
+    const bool slab = ctx->h_state->slab_on != 0;
     ctx->cert_launches = 0;
     std::vector<unsigned char> was_cert;
     for (int it = 0; it < max_it; ++it) {
@@ -1052,7 +1060,13 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
             if (e1b) WM_HIP(ctx, hipEventRecord(e1b, ctx->stream));
             WM_TRY(launch_stats(ctx, p->mode));
         } else if (cert_on) {
-            WM_TRY(launch_nn_cert(ctx, thr, e0, e1, e1b, p->mode, &rows, bounds_valid));
+            if (slab && !bounds_valid) {
+                // a rank only ever writes the bounds of the queries it owns at the time: nothing stale
+                // may survive a stretch of full searches (or the start)
+                WM_HIP(ctx, ctx->nn_bound.reserve(((size_t) ctx->n_src + 64) * sizeof(float4)));
+                WM_HIP(ctx, hipMemsetAsync(ctx->nn_bound.p, 0, ((size_t) ctx->n_src + 64) * sizeof(float4), ctx->stream));
+            }
+            WM_TRY(launch_nn_cert(ctx, thr, e0, e1, e1b, p->mode, &rows, bounds_valid || slab));
             bounds_valid = true;
             ctx->cert_launches++;
             if (p->profile) {
@@ -1064,7 +1078,22 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
             bounds_valid = false;
         }
         if (e2) WM_HIP(ctx, hipEventRecord(e2, ctx->stream));
-        WM_TRY(launch_reduce_solve<3>(ctx, rows, nullptr, ctx->h_pub, ctx->h_pub_slots));
+        if (blk) {
+            // sharded: this rank's sums -> all-reduce of the block over the ranks (RCCL on this stream) ->
+            // the same solve on every rank
+            WM_TRY(launch_reduce_solve<1>(ctx, rows, blk));
+            hipEvent_t ea = nullptr, eb = nullptr;
+            if (p->profile) {
+                ea = get_event(ctx, ev_ar++);
+                eb = get_event(ctx, ev_ar++);
+                WM_HIP(ctx, hipEventRecord(ea, ctx->stream));
+            }
+            WM_TRY(comm_allreduce(ctx, comm, blk, WM_STATS_LEN));
+            if (eb) WM_HIP(ctx, hipEventRecord(eb, ctx->stream));
+            WM_TRY(launch_reduce_solve<2>(ctx, 0, blk, ctx->h_pub, ctx->h_pub_slots));
+        } else {
+            WM_TRY(launch_reduce_solve<3>(ctx, rows, nullptr, ctx->h_pub, ctx->h_pub_slots));
+        }
         if (e3) WM_HIP(ctx, hipEventRecord(e3, ctx->stream));
         WM_HIP(ctx, hipGetLastError());
     }
@@ -1089,6 +1118,7 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
         stats->grid_cell = brute ? 0.f : ctx->levels[0].d.h;
         stats->deferred = s.deferred_total;
         stats->cert_launches = ctx->cert_launches;
+        stats->owned_violations = s.owned_violations;
         (void) hipEventElapsedTime(&stats->align_ms, ctx->ev_a, ctx->ev_b);
         if (p->profile) {
             // iterations that ran (the rest of the last batch were no-ops)
@@ -1112,11 +1142,24 @@ int wm_icp_align(wm_ctx *ctx, const wm_icp_params *p, double T_out[16], wm_icp_s
             }
         }
     }
+    if (stats && blk && p->profile) {
+        const int ran = s.iter + (s.state == WM_CONV_NO_CORRESPONDENCES ? 1 : 0);
+        for (int it = 0; it < ran; ++it) {
+            const size_t k = (size_t) 5 * (size_t) max_it + 2 * (size_t) it;
+            if (k + 1 >= ctx->ev_pool.size() || k + 1 >= ev_ar) break;
+            float a = 0;
+            if (hipEventElapsedTime(&a, ctx->ev_pool[k], ctx->ev_pool[k + 1]) == hipSuccess) stats->allreduce_ms += a;
+        }
+    }
     if (s.state == WM_CONV_NO_CORRESPONDENCES) return WM_TOO_FEW_CORRESPONDENCES;
     if (!s.converged) return WM_NOT_CONVERGED;
     memcpy(T_out, s.T, sizeof(s.T));
     return WM_OK;
 }
+
+}  // namespace wm
+
+extern "C" {
 
 static int unpack_correspondences(wm_ctx *ctx, int32_t *match_idx, float *d2, size_t cap) {
     const size_t n_in = ctx->n_src_input;
@@ -1217,12 +1260,28 @@ int wm_icp_match(wm_ctx *ctx, const void *ref, size_t n_ref, const void *target,
 }
 
 // ------------------------------------------------ sharded (multi-GPU) stepping
-int wm_icp_shard_begin(wm_ctx *ctx, const wm_icp_params *p, double x_lo, double x_hi,
-                       size_t expect_owned_total) {
-    // (an empty slab, x_lo == x_hi, and an empty band of the source are legitimate for a rank of a
-    // sharded registration: it contributes zeros)
-    if (!ctx || !p || !(p->max_corr > 0) || !(x_lo <= x_hi)) return WM_ERR_ARG;
-    if (ctx->n_src_input == 0 && expect_owned_total == 0) return WM_ERR_STATE;
+}  // extern "C"
+
+namespace wm {
+
+static void set_step_scale(wm_ctx *ctx) {  // centre and half diagonal of the (local) source cloud: IcpDevState::step_disp
+    const Bbox &b = ctx->src_bbox;
+    double d2 = 0;
+    for (int k = 0; k < 3; ++k) {
+        ctx->h_state->src_centre[k] = 0.5f * (b.lo[k] + b.hi[k]);
+        d2 += 0.25 * ((double) b.hi[k] - b.lo[k]) * ((double) b.hi[k] - b.lo[k]);
+    }
+    ctx->h_state->src_radius = (float) sqrt(d2);
+    if (ctx->n_src == 0 || !(ctx->h_state->src_radius == ctx->h_state->src_radius)) {
+        ctx->h_state->src_radius = 0.f;
+        ctx->h_state->src_centre[0] = ctx->h_state->src_centre[1] = ctx->h_state->src_centre[2] = 0.f;
+    }
+}
+
+// expect < 0: the cloud's count of finite source points arrives in the all-reduced block (the sum of
+// the ranks' stripe_finite); see IcpDevState::expect_owned
+int shard_begin(wm_ctx *ctx, const wm_icp_params *p, double x_lo, double x_hi, double expect, double stripe_finite,
+                bool *brute_out, float *thr_out) {
     WM_HIP(ctx, hipSetDevice(ctx->device));
     WM_TRY(finalize_clouds(ctx, p->max_corr, p->nn_method));
     WM_TRY(prepare_work(ctx));
@@ -1237,14 +1296,34 @@ int wm_icp_shard_begin(wm_ctx *ctx, const wm_icp_params *p, double x_lo, double 
     ctx->h_state->slab_on = 1;
     ctx->h_state->slab_lo = x_lo < -3.0e38 ? -INFINITY : (float) x_lo;
     ctx->h_state->slab_hi = x_hi > 3.0e38 ? INFINITY : (float) x_hi;
-    ctx->h_state->expect_owned = (double) expect_owned_total;
-    // keys double as next iteration's candidates: start from "nothing known"
-    WM_HIP(ctx, hipMemsetAsync(ctx->keys.p, 0xFF, (ctx->n_src > 0 ? ctx->n_src : 1) * sizeof(unsigned long long),
-                               ctx->stream));
+    ctx->h_state->expect_owned = expect;
+    ctx->h_state->stripe_finite = stripe_finite;
+    set_step_scale(ctx);
+    // keys / matches double as next iteration's candidates: start from "nothing known" (a rank only ever
+    // writes the entries of the queries it owns at the time)
+    const size_t n1 = ctx->n_src > 0 ? ctx->n_src : 1;
+    WM_HIP(ctx, hipMemsetAsync(ctx->keys.p, 0xFF, n1 * sizeof(unsigned long long), ctx->stream));
+    WM_HIP(ctx, hipMemsetAsync(ctx->match_pt.p, 0xFF, n1 * sizeof(float4), ctx->stream));
     WM_TRY(upload_state(ctx));
-    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->iter_nn_ms.clear();
     ctx->shard_active = true;
+    if (brute_out) *brute_out = ctx->shard_brute;
+    if (thr_out) *thr_out = ctx->shard_thr;
+    return WM_OK;
+}
+
+}  // namespace wm
+
+extern "C" {
+
+int wm_icp_shard_begin(wm_ctx *ctx, const wm_icp_params *p, double x_lo, double x_hi,
+                       size_t expect_owned_total) {
+    // (an empty slab, x_lo == x_hi, and an empty band of the source are legitimate for a rank of a
+    // sharded registration: it contributes zeros)
+    if (!ctx || !p || !(p->max_corr > 0) || !(x_lo <= x_hi)) return WM_ERR_ARG;
+    if (ctx->n_src_input == 0 && expect_owned_total == 0) return WM_ERR_STATE;
+    WM_TRY(shard_begin(ctx, p, x_lo, x_hi, (double) expect_owned_total, 0.0, nullptr, nullptr));
+    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return WM_OK;
 }
 

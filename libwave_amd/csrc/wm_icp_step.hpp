@@ -69,7 +69,10 @@ __host__ __device__ inline void icp_apply_stats(IcpDevState *st, const double *s
     const double mse = n > 0 ? sd2 / n : 0.0;
     st->n_corr = (int) n;
     st->mse = mse;
-    if (st->expect_owned > 0 && stats[kStatsLen - 1] != st->expect_owned) st->owned_violations += 1;
+    {
+        const double expect = st->expect_owned < 0 ? stats[kStatsLen - 2] : st->expect_owned;
+        if (st->expect_owned != 0 && stats[kStatsLen - 1] != expect) st->owned_violations += 1;
+    }
     // bookkeeping for the next iteration's queues
     st->deferred_total += st->queue_count[1];
 #pragma unroll

@@ -105,7 +105,9 @@ struct IcpDevState {
     // every rank holds only the source points near its slab; the all-reduced count of
     // handled points must equal the cloud size in EVERY iteration, else a point fell
     // outside all bands and the registration has to be redone with full source clouds
-    double expect_owned;
+    double expect_owned;    // > 0: the count to expect; < 0: it arrives in the all-reduced block (slot 30: the sum of
+                            // the ranks' stripe_finite); 0: no check
+    double stripe_finite;   // finite source points in this rank's 1 / world stripe of the (full) source cloud
     int owned_violations;
     double rot_thr, trans_thr, fit_eps;
     unsigned queue_count[kMaxLevels + 1];
@@ -365,6 +367,11 @@ float threshold_d2(double max_corr);
 float threshold_d2_strict(double max_corr);
 
 // ---- wm_icp.hip
+int shard_begin(wm_ctx *ctx, const wm_icp_params *p, double x_lo, double x_hi, double expect, double stripe_finite,
+                bool *brute_out, float *thr_out);
+// the iteration loop of one registration (state already uploaded); blk != nullptr: sharded (see wm_icp.hip)
+int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, struct wm_comm *comm, double *blk,
+                 double T_out[16], wm_icp_stats *stats);
 // one correspondence pass with transform T; `predict` lets the search start from the
 // radii in the current keys
 int nn_pass(wm_ctx *ctx, const double T[16], float thr_d2, double max_corr, bool predict);

@@ -1164,6 +1164,11 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
     // room a search leaves above its result for the runner-up bound: a few of the last step's sizes
     // (what the following steps will add up to while the registration converges)
     const float pad_room = have_prev ? pad_mul * st->step_disp : 0.f;
+    // sharded registration: this rank handles the queries whose transformed x lies in its slab (a query
+    // it does not own is skipped: no test, no search, nothing stored -- whatever this rank knew about
+    // it stays consistent for the day it comes back)
+    const bool slab_on = st->slab_on != 0;
+    const float slab_lo = st->slab_lo, slab_hi = st->slab_hi;
     const int comp = acc_comp_of_lane(lane);
     double rowacc = 0.0;
     unsigned n_uns = 0;  // (wave-uniform)
@@ -1182,12 +1187,15 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
         for (int j = 0; j < NB; ++j) {
             const unsigned i = base + (unsigned) j * 64u + lane;
             const bool act = i < n;
-            bool settled = false;
+            bool settled = false, owned = act;
             float qx = 0.f, qy = 0.f, qz = 0.f, d2 = 0.f;
-            if (act && valid) {
+            if (act) {
+                xform(st->Tf, p[j], qx, qy, qz);
+                if (slab_on && !(qx >= slab_lo && qx < slab_hi)) owned = false;
+            }
+            if (owned && valid) {
                 // where the query is now, how far that is from where its bound was taken, and how far
                 // its match is: no stores -- a settled query costs three stream reads
-                xform(st->Tf, p[j], qx, qy, qz);
                 const float ex = qx - rf[j].x, ey = qy - rf[j].y, ez = qz - rf[j].z;
                 // (v_sqrt_f32, 1 ulp: the comparison carries 1e-4 relative + 1e-6 m of cushion on either side;
                 // the library sqrtf is a twenty-instruction sequence, and this phase is bound by issue)
@@ -1263,7 +1271,7 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
                     }
                 }
             }
-            const bool uns = act && !settled;
+            const bool uns = owned && !settled;
             const unsigned long long umask = __ballot(uns);
             if (uns) {
                 const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned) (umask >> 32),

@@ -103,6 +103,17 @@ def test_icp_8m_in_8_slabs_full_registration(wm):
     assert dt <= 1e-8 and ang <= 1e-9, (dt, ang)
     dt, ang = pose_error(got["T"], T_gt)
     assert dt <= 1e-3 and ang <= 1e-4, (dt, ang)
+    # rank 0's budget: what does NOT shrink with the number of ranks (planning over the sub-sample,
+    # selecting the rank's bands out of the full clouds) against what does (its local index, its
+    # iterations); eight ranks share ONE GPU here, so every figure is inflated alike
+    fixed = got["plan_ms"] + got["compact_ms"]
+    total = fixed + got["index_ms"] + got["iter_ms"]
+    print("8M in 8 slabs, rank 0: plan %.2f + select %.2f ms (do not scale) | index %.2f + iterations %.2f ms | "
+          "local clouds %d / %d points | non-scaling share %.1f %%" % (
+              got["plan_ms"], got["compact_ms"], got["index_ms"], got["iter_ms"], got["n_tgt_local"],
+              got["n_src_local"], 100.0 * fixed / total))
+    assert got["shard_attempts"] == 1 and 0.9e6 < got["n_tgt_local"] < 1.3e6 and 0.9e6 < got["n_src_local"] < 1.3e6
+    assert fixed / total < 0.10
 
 
 def test_ndt_device_allreduce_matches_unsharded(wm):
@@ -132,3 +143,85 @@ def test_ndt_device_allreduce_matches_unsharded(wm):
     assert np.array_equal(outs[0]["T"], outs[1]["T"])
     dt, ang = pose_error(outs[0]["T"], want["T"])
     assert dt <= 1e-6 and ang <= 1e-6, (dt, ang)
+
+
+def test_sharded_certified_iterations_equal_unsharded(wm):
+    """Long enough for the certificate kernel to take over on every rank (ownership by transformed x
+    inside it): the sharded registration still equals the unsharded one, ranks agree bit for bit, and
+    the per-phase budget is filled in."""
+    ref, tgt, _ = synth.pair(80000, seed=23, mode="resample")
+    want = _unsharded(wm, ref, tgt, max_corr=3.0, force_iterations=40, carry_state=0)
+    assert want["cert_launches"] > 0
+    world = 3
+    comms = wm.Comm.init_local(world, 0)
+    outs = [None] * world
+
+    def run(r):
+        c = wm.Context(0)
+        outs[r] = c.icp_align_sharded(comms[r], ref, tgt, max_corr=3.0, force_iterations=40,
+                                      nn_method=wm.WM_NN_GRID, carry_state=0, profile=1)
+        c.close()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for c in reversed(comms):
+        c.close()
+    for o in outs:
+        assert o["rc"] == 0 and o["owned_violations"] == 0 and o["shard_attempts"] == 1
+        assert np.array_equal(o["T"], outs[0]["T"])
+        assert o["n_corr"] == want["n_corr"]
+        assert o["plan_ms"] > 0 and o["compact_ms"] > 0 and o["index_ms"] > 0 and o["iter_ms"] > 0
+        assert 0 < o["n_tgt_local"] < len(tgt) and 0 < o["n_src_local"] < len(ref)
+    assert any(o["cert_launches"] > 0 for o in outs)
+    dt, ang = pose_error(outs[0]["T"], want["T"])
+    assert dt <= 1e-9 and ang <= 1e-9, (dt, ang)
+
+
+def test_sharded_clouds_with_nonfinite_points_and_strides(wm):
+    """Raw-cloud planning: xyz and xyzw strides, NaN / inf points dropped, the cloud's finite count
+    agreed on through the all-reduced block (no ownership violation, one attempt)."""
+    ref, tgt, _ = synth.pair(40000, seed=31, mode="resample")
+    ref = ref.copy()
+    tgt = tgt.copy()
+    ref[::101, 0] = np.nan
+    ref[5::103, 2] = np.inf
+    tgt[::97, 1] = np.nan
+    want = _unsharded(wm, ref, tgt, max_corr=3.0, force_iterations=10, carry_state=0)
+    for cols in (3, 4):
+        r4 = np.zeros((len(ref), cols), np.float32)
+        t4 = np.zeros((len(tgt), cols), np.float32)
+        r4[:, :3] = ref
+        t4[:, :3] = tgt
+        m = wm.Multi([0, 0], emulate=True)
+        got = m.icp_align(r4, t4, max_corr=3.0, force_iterations=10, nn_method=wm.WM_NN_GRID)
+        m.close()
+        assert got["rc"] == 0 and got["owned_violations"] == 0
+        assert got["n_corr"] == want["n_corr"]
+        dt, ang = pose_error(got["T"], want["T"])
+        assert dt <= 1e-9 and ang <= 1e-9
+
+
+def test_bench_sharded_under_torch_distributed_run():
+    """The driver's multi-GPU launch line, on the one GPU a test box has: a one-rank RCCL group under
+    torch.distributed.run drives ncclCommInitRank / the per-iteration ncclAllReduce / the whole sharded
+    path (WM_BENCH_FORCE_SHARDED=1), and the line explains itself (per-phase budget, RCCL rank count)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WM_BENCH_FORCE_SHARDED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(root, "bench.py"),
+           "--gpus", "1", "--steps", "3", "--warmup", "1", "--points", "200000", "--no-cpu-baseline",
+           "--no-other-configs"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    sh = d["config"]["sharding"]
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert sh["rccl_ranks"] == 1 and sh["owned_violations"] == 0 and sh["shard_attempts"] == 1
+    assert sh["allreduce_us_isolated"] > 0 and sh["allreduce_ms"] > 0
+    assert sh["plan_ms"] > 0 and sh["compact_ms"] > 0 and sh["index_ms"] > 0 and sh["iter_ms"] > 0
+    assert d["config"]["final_translation_error_m"] < 2e-3
