@@ -72,14 +72,15 @@ class ICPMatcher : public Matcher<PCLPointCloudPtr> {
     // workers over the devices of a node with it); a negative ordinal returns to the default
     static void setThreadDevice(int device);
 
-    // Spread ONE registration over several GPUs of the node (no reference counterpart; full-resolution
-    // matches only, params.res <= 0): the target is cut into equal-count x-slabs, one per device, every
-    // device searches the source points that fall into its slab, and the per-iteration statistics are
-    // summed by an RCCL all-reduce over xGMI inside the library (wm_multi_icp_align).  The result is the
+    // Spread ONE registration over several GPUs of the node (no reference counterpart): the target is
+    // cut into equal-count x-slabs, one per device, every device searches the source points that fall
+    // into its slab, and the per-iteration statistics are summed by an RCCL all-reduce over xGMI inside
+    // the library (wm_multi_icp_match).  All of match()'s branches -- the default parameters' voxel
+    // filter and scales included: every device filters, the align of every scale is spread -- and
+    // estimateInfo() after it (the estimators' sums are exchanged the same way).  The result is the
     // single-GPU result up to summation order.  An empty list or a single device restores the default
     // path; a list that names one device several times runs that many ranks on it with a host-side
-    // exchange (for testing without several GPUs).  estimateInfo() needs the correspondences of a
-    // single-device match and leaves `information` untouched after a multi-device one.
+    // exchange (for testing without several GPUs).
     void setDevices(const std::vector<int> &devices);
 
     // MANY registrations in one device launch -- what wave::MultiMatcher's workers use when pairs are
@@ -114,6 +115,9 @@ class ICPMatcher : public Matcher<PCLPointCloudPtr> {
     std::vector<int> devices;
     int device;
     bool converged;
+    // what the estimators may use: the correspondences of the last match() of THIS matcher, on one device
+    // (ctx) or over the group (multi); neither after a failed match, a matchBatch() or a change of devices
+    enum { kNone, kOnCtx, kOnMulti } lastMatch;
     PCLPointCloudPtr ref, target;
 
     bool ensureContext();

@@ -448,15 +448,31 @@ int wm_comm_world(const wm_comm *comm);
 /* pcl::IterativeClosestPoint::align (wave_matching/src/icp.cpp:126-129) as ONE registration over
  * all ranks of `comm`.  Collective: every rank calls it with the same two (full) clouds and
  * parameters, on its own context (`mem` = where the clouds live for THIS rank).  Inside the call:
- * equal-count x-slabs of the target from a histogram (identical on all ranks, no communication),
- * this rank's slab + max_corr halo of the target and its band of the source compacted on the
- * device, the index over them, then per iteration search + local sums -> ncclAllReduce of
- * WM_STATS_LEN doubles -> solve, all enqueued on the context's stream.  Every rank returns the same
- * transform and status.  comm == NULL or a world of 1 is plain wm_set_source + wm_set_target +
- * wm_icp_align. */
+ * equal-count x-slabs of the target from a histogram of a fixed sub-sample (identical on all ranks,
+ * no communication), this rank's slab + max_corr halo of the target and its band of the source
+ * selected out of the clouds as the caller laid them out (one pass each), the index over them, then
+ * per iteration search + local sums -> ncclAllReduce of WM_STATS_LEN doubles -> solve, all enqueued
+ * on the context's stream.  Host clouds: with an RCCL communicator rank 0 uploads, the others receive
+ * over xGMI (ncclBroadcast).  Every rank returns the same transform and status; `stats` carries the
+ * rank's per-phase budget.  A rank that fails with a HIP / RCCL error aborts the communicator (its
+ * peers' pending collectives fail instead of waiting for ever); the communicator is finished then.
+ * comm == NULL or a world of 1 is plain wm_set_source + wm_set_target + wm_icp_align. */
 int wm_icp_align_sharded(wm_ctx *ctx, wm_comm *comm, const void *ref, size_t n_ref, const void *target,
                          size_t n_target, size_t stride_bytes, int mem, const wm_icp_params *p,
                          double T_out[16], wm_icp_stats *stats);
+/* ICPMatcher::match() (wave_matching/src/icp.cpp:75-133) over the ranks of `comm`, voxel-filtered
+ * branches included -- the reference's DEFAULT parameters (res 0.1, three coarser scales,
+ * icp.hpp:54,59): every rank filters both clouds itself (deterministic: all hold the same filtered
+ * clouds) and the align of every scale is sharded.  res <= 0: wm_icp_align_sharded. */
+int wm_icp_match_sharded(wm_ctx *ctx, wm_comm *comm, const void *ref, size_t n_ref, const void *target,
+                         size_t n_target, size_t stride_bytes, int mem, const wm_icp_params *p, float res,
+                         int multiscale_steps, double T_out[16], wm_icp_stats *stats);
+/* wm_icp_info after a sharded registration (ICPMatcher::estimateInfo, icp.cpp:135-142).  Collective:
+ * every rank adds up the pairs of the queries it owned, the 16 / 1 / 42 sums are exchanged over `comm`,
+ * every rank finishes the same 6x6.  (wm_icp_info itself refuses after a sharded align: one rank's
+ * pairs alone say nothing.) */
+int wm_icp_info_sharded(wm_ctx *ctx, wm_comm *comm, int method, const double T_result[16], double lin_covar,
+                        double ang_covar, double max_corr, double info_out[36], int *degenerate);
 
 /* Sharded NDT with the exchange on the device: like wm_ndt_set_shard, but the sums of every
  * derivative pass are all-reduced in HBM over `comm` (RCCL) before the host fetches them -- no
@@ -465,14 +481,20 @@ int wm_ndt_set_comm(wm_ctx *ctx, wm_comm *comm);
 
 /* All ranks in ONE process: one context and one worker thread per device, RCCL communicators from
  * ncclCommInitAll (emulate != 0: `n_devices` ranks on devices[0] with the host stand-in exchange).
- * wm_multi_icp_align runs one sharded registration of two HOST clouds (every rank uploads them over
- * its own PCIe link) and returns rank 0's result. */
+ * wm_multi_icp_align runs one sharded registration of two HOST clouds (uploaded once, broadcast over
+ * xGMI) and returns rank 0's result; wm_multi_icp_match is ICPMatcher::match() with its voxel filter
+ * and scales; wm_multi_icp_info the estimators after either. */
 typedef struct wm_multi wm_multi;
 int wm_multi_create(wm_multi **out, const int *devices, int n_devices, int emulate);
 void wm_multi_destroy(wm_multi *m);
 int wm_multi_size(const wm_multi *m);
 int wm_multi_icp_align(wm_multi *m, const void *ref, size_t n_ref, const void *target, size_t n_target,
                        size_t stride_bytes, const wm_icp_params *p, double T_out[16], wm_icp_stats *stats);
+int wm_multi_icp_match(wm_multi *m, const void *ref, size_t n_ref, const void *target, size_t n_target,
+                       size_t stride_bytes, const wm_icp_params *p, float res, int multiscale_steps,
+                       double T_out[16], wm_icp_stats *stats);
+int wm_multi_icp_info(wm_multi *m, int method, const double T_result[16], double lin_covar, double ang_covar,
+                      double max_corr, double info_out[36], int *degenerate);
 
 /* Host-only twin of the per-iteration solve + PCL stopping rules (no GPU touched):
  * the very function the device runs after the all-reduce, callable on the CPU so

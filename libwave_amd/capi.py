@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwavematch_hip.so")
 
 WM_OK, WM_NOT_CONVERGED, WM_TOO_FEW = 0, 1, 2
+WM_ERR_ARG, WM_ERR_HIP, WM_ERR_RCCL, WM_ERR_STATE, WM_ERR_NOMEM = -1, -2, -3, -4, -5
 WM_BATCH_LDS_TARGET_POINTS = 10000  # wm_icp_batch_match: targets up to this size live in one CU's LDS,
 WM_BATCH_MAX_TARGET_POINTS = 65535  # larger ones (up to this) in HBM scratch
 WM_MEM_HOST, WM_MEM_DEVICE = 0, 1
@@ -178,6 +179,10 @@ def lib():
         L.wm_multi_size.argtypes = [C.c_void_p]
         L.wm_multi_icp_align.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                          C.c_size_t, C.POINTER(IcpParams), _dp, C.POINTER(IcpStats)]
+        L.wm_multi_icp_match.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                         C.c_size_t, C.POINTER(IcpParams), C.c_float, C.c_int, _dp, C.POINTER(IcpStats)]
+        L.wm_multi_icp_info.argtypes = [C.c_void_p, C.c_int, _dp, C.c_double, C.c_double, C.c_double, _dp,
+                                        C.POINTER(C.c_int)]
         L.wm_debug_solve_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.wm_debug_cost_log.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.wm_debug_phase_log.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -732,16 +737,31 @@ class Multi:
         self._h = h
 
     def icp_align(self, ref, target, params=None, **kw):
+        return self.icp_match(ref, target, res=-1.0, multiscale_steps=0, params=params, **kw)
+
+    def icp_info(self, method, T=None, lin_covar=0.0, ang_covar=0.0, max_corr=0.0):
+        """wm_multi_icp_info: the estimators after a registration over the group -> (rc, info 6x6, degenerate)"""
+        info = np.zeros((6, 6), np.float64)
+        deg = C.c_int(0)
+        Tp = None if T is None else np.ascontiguousarray(T, np.float64).ctypes.data_as(_dp)
+        rc = lib().wm_multi_icp_info(self._h, int(method), Tp, lin_covar, ang_covar, max_corr,
+                                     info.ctypes.data_as(_dp), C.byref(deg))
+        if rc < 0:
+            raise WmError("wm_multi_icp_info: %d (%s)" % (rc, lib().wm_strerror(rc).decode()))
+        return rc, info, deg.value
+
+    def icp_match(self, ref, target, res=-1.0, multiscale_steps=0, params=None, **kw):
         p = params or icp_params(**kw)
         ref = np.ascontiguousarray(ref, np.float32)
         target = np.ascontiguousarray(target, np.float32)
         T = np.zeros((4, 4), np.float64)
         s = IcpStats()
-        rc = lib().wm_multi_icp_align(self._h, ref.ctypes.data_as(C.c_void_p), len(ref),
+        rc = lib().wm_multi_icp_match(self._h, ref.ctypes.data_as(C.c_void_p), len(ref),
                                       target.ctypes.data_as(C.c_void_p), len(target), ref.strides[0],
-                                      C.byref(p), T.ctypes.data_as(_dp), C.byref(s))
+                                      C.byref(p), C.c_float(res), int(multiscale_steps), T.ctypes.data_as(_dp),
+                                      C.byref(s))
         if rc < 0:
-            raise WmError("wm_multi_icp_align: %d (%s)" % (rc, lib().wm_strerror(rc).decode()))
+            raise WmError("wm_multi_icp_match: %d (%s)" % (rc, lib().wm_strerror(rc).decode()))
         d = dict(rc=rc, T=T, converged=s.converged, iterations=s.iterations, state=s.state,
                  n_corr=s.n_corr, mse=s.mse, align_ms=s.align_ms, owned_violations=s.owned_violations,
                  cert_launches=s.cert_launches)

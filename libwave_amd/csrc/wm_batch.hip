@@ -457,6 +457,19 @@ struct VoxelBatch {
 static int scaled_sub_batch(wm_ctx *ctx, const wm_batch_item *items, const std::vector<int> &idx, size_t stride, int mem,
                             const wm_icp_params *p, float res, int steps, int with_info, double *T_out, double *info_out,
                             wm_icp_stats *stats, int *status, std::vector<int> &one_by_one) {
+    // a sub-batch of empty pairs only (PCL: empty input -> "Not enough correspondences"): nothing to
+    // filter, every item gets its status, the batch has run
+    {
+        size_t total_pts = 0;
+        for (int k : idx) total_pts += items[k].n_src + items[k].n_target;
+        if (total_pts == 0) {
+            for (int k : idx) {
+                status[k] = WM_ERR_STATE;
+                if (stats) stats[k].state = WM_CONV_NO_CORRESPONDENCES;
+            }
+            return WM_OK;
+        }
+    }
     VoxelBatch vb;
     WM_TRY(vb.setup(ctx, items, idx, stride, mem));
     const unsigned n_pairs = vb.n_pairs;
@@ -591,8 +604,11 @@ int batch_match_scaled(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
         }
     }
     for (int k : one_by_one) {  // (leaf lattice beyond int32, or a filtered target beyond the resident kernel)
+        // a pair of its own starts with fresh stopping criteria, but its SCALES carry the last MSE from one
+        // align to the next, as the batched path and the reference's one PCL object do
         wm_icp_params q = *p;
-        q.carry_state = 0;
+        q.carry_state = 1;
+        ctx->prev_mse = -1;
         double T[16];
         wm_icp_stats s;
         const int rc = wm_icp_match(ctx, items[k].src, items[k].n_src, items[k].target, items[k].n_target, stride, mem, &q, res,

@@ -614,13 +614,22 @@ static hipEvent_t get_event(wm_ctx *ctx, size_t k) {
     return ctx->ev_pool[k];
 }
 
-int nn_pass(wm_ctx *ctx, const double T[16], float thr_d2, double max_corr, bool predict) {
+int nn_pass(wm_ctx *ctx, const double T[16], float thr_d2, double max_corr, bool predict, bool slab, float slab_lo,
+            float slab_hi) {
     WM_TRY(finalize_clouds(ctx, max_corr, WM_NN_AUTO));
     WM_TRY(prepare_work(ctx));
     const bool brute = use_brute(ctx, WM_NN_AUTO) || ctx->n_tgt == 0;
     if (!brute) WM_TRY(ensure_levels(ctx, max_corr));
+    float keep_search[12];
+    for (int k = 0; k < 12; ++k) keep_search[k] = ctx->h_state->Tf_search[k];
     init_state(ctx->h_state, T, nullptr, DBL_MAX);
+    for (int k = 0; k < 12; ++k) ctx->h_state->Tf_search[k] = keep_search[k];  // (still what the align's keys refer to)
     ctx->h_state->have_prev = predict ? 1 : 0;
+    if (slab) {  // a rank of a sharded registration searches the queries it owns under this pose
+        ctx->h_state->slab_on = 1;
+        ctx->h_state->slab_lo = slab_lo;
+        ctx->h_state->slab_hi = slab_hi;
+    }
     WM_TRY(upload_state(ctx));
     if (brute)
         WM_TRY(launch_nn_brute(ctx, thr_d2, nullptr, nullptr));
@@ -1106,6 +1115,7 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
     ctx->have_corr = true;
     ctx->last_align_valid = true;
     ctx->last_align_converged = s.converged != 0;
+    ctx->last_align_sharded = blk != nullptr;
     memcpy(ctx->corr_T, s.T, sizeof(s.T));
     if (stats) {
         stats->converged = s.converged;
@@ -1281,7 +1291,7 @@ static void set_step_scale(wm_ctx *ctx) {  // centre and half diagonal of the (l
 // expect < 0: the cloud's count of finite source points arrives in the all-reduced block (the sum of
 // the ranks' stripe_finite); see IcpDevState::expect_owned
 int shard_begin(wm_ctx *ctx, const wm_icp_params *p, double x_lo, double x_hi, double expect, double stripe_finite,
-                bool *brute_out, float *thr_out) {
+                bool *brute_out, float *thr_out, double prev_mse0) {
     WM_HIP(ctx, hipSetDevice(ctx->device));
     WM_TRY(finalize_clouds(ctx, p->max_corr, p->nn_method));
     WM_TRY(prepare_work(ctx));
@@ -1291,7 +1301,7 @@ int shard_begin(wm_ctx *ctx, const wm_icp_params *p, double x_lo, double x_hi, d
     ctx->shard_params = *p;
     double I[16];
     mat4_identity(I);
-    init_state(ctx->h_state, I, p, DBL_MAX);
+    init_state(ctx->h_state, I, p, prev_mse0);
     ctx->h_state->svd_warm = ctx->tune_fast_solve ? 1 : 0;
     ctx->h_state->slab_on = 1;
     ctx->h_state->slab_lo = x_lo < -3.0e38 ? -INFINITY : (float) x_lo;
@@ -1322,7 +1332,7 @@ int wm_icp_shard_begin(wm_ctx *ctx, const wm_icp_params *p, double x_lo, double 
     // sharded registration: it contributes zeros)
     if (!ctx || !p || !(p->max_corr > 0) || !(x_lo <= x_hi)) return WM_ERR_ARG;
     if (ctx->n_src_input == 0 && expect_owned_total == 0) return WM_ERR_STATE;
-    WM_TRY(shard_begin(ctx, p, x_lo, x_hi, (double) expect_owned_total, 0.0, nullptr, nullptr));
+    WM_TRY(shard_begin(ctx, p, x_lo, x_hi, (double) expect_owned_total, 0.0, nullptr, nullptr, DBL_MAX));
     WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return WM_OK;
 }

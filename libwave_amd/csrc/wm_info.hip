@@ -55,7 +55,19 @@ struct InfoArgs {
     double X[3];       // Censi: translation of the result
     double cr, sr, cp, sp, cy, sy;
     double sph[6];     // Censi: diag(lin, ang, ang, lin, ang, ang)
+    // sharded registration: only the pairs of the queries this rank OWNED when they were searched count
+    // (transformed x, under the pose of that search, inside the rank's slab); the ranks' sums are added
+    float Tg[12];
+    int slab_on;
+    float slab_lo, slab_hi;
 };
+
+__device__ __forceinline__ bool info_owned(const InfoArgs &A, const float4 &p) {
+    if (!A.slab_on) return true;
+    float gx, gy, gz;
+    xform_f(A.Tg, p, gx, gy, gz);
+    return gx >= A.slab_lo && gx < A.slab_hi;
+}
 
 // pass 1: a[0]=n, a[1..3]=sum av, a[4..9]=MM(3,4),(3,5),(4,5),(3,3),(4,4),(5,5) terms,
 //         a[10..15]=MZ(0..5)
@@ -68,7 +80,7 @@ __global__ void __launch_bounds__(kBlock)
     for (int k = 0; k < 16; ++k) a[k] = 0.0;
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const unsigned idx = (unsigned) keys[i];
-        if (idx == kNoIdx) continue;
+        if (idx == kNoIdx || !info_owned(A, src[i])) continue;
         float px, py, pz;
         xform_f(A.Tf, src[i], px, py, pz);
         const float4 q = tgt[idx];
@@ -102,7 +114,7 @@ __global__ void __launch_bounds__(kBlock)
     double a[1] = {0.0};
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const unsigned idx = (unsigned) keys[i];
-        if (idx == kNoIdx) continue;
+        if (idx == kNoIdx || !info_owned(A, src[i])) continue;
         float px, py, pz;
         xform_f(A.Tf, src[i], px, py, pz);
         const float4 q = tgt[idx];
@@ -128,7 +140,7 @@ __global__ void __launch_bounds__(kBlock)
     const double X1 = A.X[0], X2 = A.X[1], X3 = A.X[2];
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const unsigned idx = (unsigned) keys[i];
-        if (idx == kNoIdx) continue;
+        if (idx == kNoIdx || !info_owned(A, src[i])) continue;
         const float4 t4 = tgt[idx], s4 = src[i];
         const float Z1 = t4.x, Z2 = t4.y, Z3 = t4.z, Z4 = s4.x, Z5 = s4.y, Z6 = s4.z;
         // spherical-coordinate Jacobians of both points (icp.cpp:225-247)
@@ -309,13 +321,20 @@ __global__ void __launch_bounds__(kBlock)
     block_reduce_store<42>(a, partials);
 }
 
-static int reduce_partials(wm_ctx *ctx, int nblocks, int nacc, double *out) {
+static int reduce_partials(wm_ctx *ctx, int nblocks, int nacc, double *out, wm_comm *comm = nullptr) {
     std::vector<double> h((size_t) nblocks * kInfoAcc);
     WM_TRY(copy_to_caller(ctx, h.data(), ctx->partials.p, h.size() * sizeof(double)));
     for (int k = 0; k < nacc; ++k) {
         double s = 0;
         for (int b = 0; b < nblocks; ++b) s += h[(size_t) b * kInfoAcc + k];  // fixed order
         out[k] = s;
+    }
+    if (comm) {  // sharded: the ranks' sums, added by the exchange (every rank gets the same totals)
+        WM_HIP(ctx, ctx->shard_stats.reserve(64 * sizeof(double)));
+        WM_HIP(ctx, hipMemcpyAsync(ctx->shard_stats.p, out, (size_t) nacc * sizeof(double), hipMemcpyHostToDevice,
+                                   ctx->stream));
+        WM_TRY(comm_allreduce(ctx, comm, ctx->shard_stats.as<double>(), nacc));
+        WM_TRY(copy_to_caller(ctx, out, ctx->shard_stats.p, (size_t) nacc * sizeof(double)));
     }
     return WM_OK;
 }
@@ -345,7 +364,7 @@ static void euler_012(const double *T, double e[3]) {
 }
 
 static int lum_from_current_keys(wm_ctx *ctx, const InfoArgs &args0, double info[36],
-                                 bool lumold_quirk) {
+                                 bool lumold_quirk, wm_comm *comm = nullptr) {
     InfoArgs args = args0;
     const unsigned n = (unsigned) ctx->n_src;
     const int nb = info_blocks(n);
@@ -357,7 +376,7 @@ static int lum_from_current_keys(wm_ctx *ctx, const InfoArgs &args0, double info
                        partials);
     WM_HIP(ctx, hipGetLastError());
     double a[16];
-    WM_TRY(reduce_partials(ctx, nb, 16, a));
+    WM_TRY(reduce_partials(ctx, nb, 16, a, comm));
     double MM[36] = {0}, MZ[6], MMinv[36], D[6];
 #define M_(r, c) MM[(r) * 6 + (c)]
     M_(0, 4) = -a[2];
@@ -395,7 +414,7 @@ static int lum_from_current_keys(wm_ctx *ctx, const InfoArgs &args0, double info
                        partials);
     WM_HIP(ctx, hipGetLastError());
     double ssd[1];
-    WM_TRY(reduce_partials(ctx, nb, 1, ssd));
+    WM_TRY(reduce_partials(ctx, nb, 1, ssd, comm));
     const float ss = (float) ssd[0];
     const bool bad = (ss < 0.0000000000001f || !isfinite(ss));
     if (bad && !lumold_quirk) {  // estimateLUM: identity + return (icp_pcl_functions.cpp:281-285)
@@ -412,10 +431,8 @@ static int lum_from_current_keys(wm_ctx *ctx, const InfoArgs &args0, double info
 
 using namespace wm;
 
-extern "C" {
-
-int wm_icp_info(wm_ctx *ctx, int method, const double T_result[16], double lin_covar,
-                double ang_covar, double max_corr, double info[36], int *degenerate) {
+static int icp_info_impl(wm_ctx *ctx, wm_comm *comm, int method, const double T_result[16], double lin_covar,
+                         double ang_covar, double max_corr, double info[36], int *degenerate) {
     if (!ctx || !info || method < WM_INFO_LUM || method > WM_INFO_LUMOLD) return WM_ERR_ARG;
     if (degenerate) *degenerate = 0;
     if (!ctx->have_corr || !ctx->last_align_valid) return WM_ERR_STATE;
@@ -423,9 +440,19 @@ int wm_icp_info(wm_ctx *ctx, int method, const double T_result[16], double lin_c
     InfoArgs args;
     memset(&args, 0, sizeof(args));
     for (int k = 0; k < 12; ++k) args.Tf[k] = (float) ctx->corr_T[k];
+    const bool sharded = comm != nullptr && ctx->last_align_sharded;
+    if (comm != nullptr && !sharded) return WM_ERR_STATE;
+    if (sharded) {  // the align's own correspondences: owned under the pose of its last search
+        args.slab_on = 1;
+        args.slab_lo = ctx->shard_lo;
+        args.slab_hi = ctx->shard_hi;
+        for (int k = 0; k < 12; ++k) args.Tg[k] = ctx->h_state->Tf_search[k];
+    } else if (ctx->last_align_sharded) {
+        return WM_ERR_STATE;  // a rank's correspondences alone say nothing: wm_icp_info_sharded
+    }
     if (method == WM_INFO_LUM) {
         if (!ctx->last_align_converged) return WM_NOT_CONVERGED;  // information left untouched
-        const int rc = lum_from_current_keys(ctx, args, info, false);
+        const int rc = lum_from_current_keys(ctx, args, info, false, sharded ? comm : nullptr);
         if (rc < 0) return rc;
         if (degenerate) *degenerate = rc;
         return WM_OK;
@@ -442,8 +469,12 @@ int wm_icp_info(wm_ctx *ctx, int method, const double T_result[16], double lin_c
         WM_HIP(ctx, ctx->match_pt_bak.reserve(mb > 0 ? mb : 16));
         WM_HIP(ctx, hipMemcpyAsync(ctx->match_pt_bak.p, ctx->match_pt.p, mb, hipMemcpyDeviceToDevice,
                                    ctx->stream));
-        int rc = nn_pass(ctx, ctx->corr_T, threshold_d2_strict(max_corr), max_corr, true);
-        if (rc == WM_OK) rc = lum_from_current_keys(ctx, args, info, true);
+        // (sharded: the fresh search runs under the final pose, and so does its ownership test)
+        if (sharded)
+            for (int k = 0; k < 12; ++k) args.Tg[k] = args.Tf[k];
+        const float Tf_keep_lo = ctx->shard_lo, Tf_keep_hi = ctx->shard_hi;
+        int rc = nn_pass(ctx, ctx->corr_T, threshold_d2_strict(max_corr), max_corr, true, sharded, Tf_keep_lo, Tf_keep_hi);
+        if (rc == WM_OK) rc = lum_from_current_keys(ctx, args, info, true, sharded ? comm : nullptr);
         WM_HIP(ctx, hipMemcpyAsync(ctx->keys.p, ctx->keys_bak.p, kb, hipMemcpyDeviceToDevice,
                                    ctx->stream));
         WM_HIP(ctx, hipMemcpyAsync(ctx->match_pt.p, ctx->match_pt_bak.p, mb, hipMemcpyDeviceToDevice,
@@ -477,7 +508,7 @@ int wm_icp_info(wm_ctx *ctx, int method, const double T_result[16], double lin_c
                        ctx->tgt_orig.as<float4>(), args, ctx->partials.as<double>());
     WM_HIP(ctx, hipGetLastError());
     double a[42];
-    WM_TRY(reduce_partials(ctx, nb, 42, a));
+    WM_TRY(reduce_partials(ctx, nb, 42, a, sharded ? comm : nullptr));
     double H[36], Mid[36], Hinv[36], t1[36], t2[36];
     int u = 0;
     for (int r = 0; r < 6; ++r)
@@ -491,6 +522,19 @@ int wm_icp_info(wm_ctx *ctx, int method, const double T_result[16], double lin_c
     mat_mul<6>(t1, Hinv, t2);
     inverse<6>(t2, info);
     return WM_OK;
+}
+
+extern "C" {
+
+int wm_icp_info(wm_ctx *ctx, int method, const double T_result[16], double lin_covar,
+                double ang_covar, double max_corr, double info[36], int *degenerate) {
+    return icp_info_impl(ctx, nullptr, method, T_result, lin_covar, ang_covar, max_corr, info, degenerate);
+}
+
+int wm_icp_info_sharded(wm_ctx *ctx, wm_comm *comm, int method, const double T_result[16], double lin_covar,
+                        double ang_covar, double max_corr, double info[36], int *degenerate) {
+    if (!comm) return WM_ERR_ARG;
+    return icp_info_impl(ctx, comm, method, T_result, lin_covar, ang_covar, max_corr, info, degenerate);
 }
 
 }  // extern "C"

@@ -194,6 +194,7 @@ struct wm_ctx {
     bool ndt_profile = false;            // HIP events around every derivative pass (kernel_ms)
     bool gicp_profile = false;           // HIP events around every objective evaluation (fdf_kernel_ms)
     bool have_corr = false, last_align_valid = false, last_align_converged = false;
+    bool last_align_sharded = false;     // the last align was this rank's part of a sharded registration (wm_icp_info_sharded)
     wm::DevBuf keys_bak;
     double corr_T[16];
 
@@ -368,12 +369,13 @@ float threshold_d2_strict(double max_corr);
 
 // ---- wm_icp.hip
 int shard_begin(wm_ctx *ctx, const wm_icp_params *p, double x_lo, double x_hi, double expect, double stripe_finite,
-                bool *brute_out, float *thr_out);
+                bool *brute_out, float *thr_out, double prev_mse0);
 // the iteration loop of one registration (state already uploaded); blk != nullptr: sharded (see wm_icp.hip)
 int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, struct wm_comm *comm, double *blk,
                  double T_out[16], wm_icp_stats *stats);
 // one correspondence pass with transform T; `predict` lets the search start from the
 // radii in the current keys
-int nn_pass(wm_ctx *ctx, const double T[16], float thr_d2, double max_corr, bool predict);
+int nn_pass(wm_ctx *ctx, const double T[16], float thr_d2, double max_corr, bool predict, bool slab = false,
+            float slab_lo = 0.f, float slab_hi = 0.f);
 
 }  // namespace wm

@@ -544,7 +544,8 @@ static int align_sharded_impl(wm_ctx *ctx, wm_comm *comm, const void *ref, size_
         ctx->shard_hi = pl.edges[1];
         bool brute = false;
         float thr = 0.f;
-        WM_TRY(shard_begin(ctx, p, (double) pl.edges[0], (double) pl.edges[1], -1.0, (double) pl.stripe_finite, &brute, &thr));
+        WM_TRY(shard_begin(ctx, p, (double) pl.edges[0], (double) pl.edges[1], -1.0, (double) pl.stripe_finite, &brute, &thr,
+                           (p->carry_state && ctx->prev_mse >= 0) ? ctx->prev_mse : DBL_MAX));
         WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const auto t_host1 = std::chrono::steady_clock::now();
         // ---- the iteration loop: search + local sums -> all-reduce of the block -> solve (wm_icp.hip)
@@ -590,6 +591,66 @@ int wm_icp_align_sharded(wm_ctx *ctx, wm_comm *comm, const void *ref, size_t n_r
     return rc;
 }
 
+// ICPMatcher::match() with a voxel filter (icp.cpp:77-122), sharded: every rank filters both clouds
+// itself (pcl::VoxelGrid of a cloud is one sort -- deterministic, so all ranks hold the same filtered
+// clouds; it is the registration of each scale, the part that grows with the iteration count, that
+// is spread over the ranks), then one sharded align per scale on the filtered, device-resident clouds.
+int wm_icp_match_sharded(wm_ctx *ctx, wm_comm *comm, const void *ref, size_t n_ref, const void *target,
+                         size_t n_target, size_t stride, int mem, const wm_icp_params *p, float res,
+                         int multiscale_steps, double T_out[16], wm_icp_stats *stats) {
+    if (!ctx || !p || !T_out || (n_ref > 0 && !ref) || (n_target > 0 && !target) || stride < 12 || (stride & 3) ||
+        n_ref > 0x7FFFFFF0u || n_target > 0x7FFFFFF0u)
+        return WM_ERR_ARG;
+    if (!(res > 0)) return wm_icp_align_sharded(ctx, comm, ref, n_ref, target, n_target, stride, mem, p, T_out, stats);
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    if (stats) memset(stats, 0, sizeof(*stats));
+    const size_t cap_r = n_ref > 0 ? n_ref : 1, cap_t = n_target > 0 ? n_target : 1;
+    WM_HIP(ctx, ctx->match_ref.reserve(cap_r * sizeof(float4)));
+    WM_HIP(ctx, ctx->match_tgt.reserve(cap_t * sizeof(float4)));
+    WM_HIP(ctx, ctx->ds_ref.reserve(cap_r * sizeof(float4)));
+    WM_HIP(ctx, ctx->ds_tgt.reserve(cap_t * sizeof(float4)));
+    float4 *d_ref = ctx->match_ref.as<float4>(), *d_tgt = ctx->match_tgt.as<float4>();
+    float4 *ds_ref = ctx->ds_ref.as<float4>(), *ds_tgt = ctx->ds_tgt.as<float4>();
+    WM_TRY(pack_cloud(ctx, ref, n_ref, stride, mem, d_ref));
+    WM_TRY(pack_cloud(ctx, target, n_target, stride, mem, d_tgt));
+    wm_icp_params prm = *p;
+    wm_icp_stats last, total;
+    memset(&total, 0, sizeof(total));
+    double running[16];
+    mat4_identity(running);
+    const int steps = multiscale_steps > 0 ? multiscale_steps : 0;
+    VgKnown kr{}, kt{};
+    if (steps > 0) {
+        if (n_ref > 0) WM_TRY(compute_bbox(ctx, d_ref, n_ref, &kr.bb, &kr.valid));
+        if (n_target > 0) WM_TRY(compute_bbox(ctx, d_tgt, n_target, &kt.bb, &kt.valid));
+    }
+    for (int i = steps; i >= 0; --i) {
+        const float leaf = (float) (pow(2, i) * res);  // icp.cpp:80
+        size_t nr = 0, nt = 0;
+        WM_TRY(voxel_downsample_dev(ctx, d_ref, n_ref, leaf, ds_ref, &nr, steps > 0 && n_ref > 0 ? &kr : nullptr));
+        WM_TRY(voxel_downsample_dev(ctx, d_tgt, n_target, leaf, ds_tgt, &nt, steps > 0 && n_target > 0 ? &kt : nullptr));
+        if (steps > 0) {
+            WM_TRY(transform_cloud_dev(ctx, ds_ref, nr, running, ds_ref));  // icp.cpp:84-86
+            prm.max_corr = pow(2, i) * p->max_corr;                          // icp.cpp:93-94
+        }
+        double Ti[16];
+        const int rc = wm_icp_align_sharded(ctx, comm, ds_ref, nr, ds_tgt, nt, sizeof(float4), WM_MEM_DEVICE, &prm, Ti, &last);
+        total.align_ms += last.align_ms;
+        total.nn_ms += last.nn_ms;
+        total.nn_launches += last.nn_launches;
+        if (stats) {
+            *stats = last;
+            stats->align_ms = total.align_ms;
+            stats->nn_ms = total.nn_ms;
+            stats->nn_launches = total.nn_launches;
+        }
+        if (rc != WM_OK) return rc;  // icp.cpp:96-98: fail fast, result untouched (the same verdict on every rank)
+        mat4_mul(Ti, running, running);  // icp.cpp:99-101
+    }
+    memcpy(T_out, running, sizeof(running));
+    return WM_OK;
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------ all ranks in one process
@@ -630,23 +691,57 @@ int wm_multi_size(const wm_multi *m) { return m ? (int) m->ctx.size() : 0; }
 
 int wm_multi_icp_align(wm_multi *m, const void *ref, size_t n_ref, const void *target, size_t n_target,
                        size_t stride, const wm_icp_params *p, double T_out[16], wm_icp_stats *stats) {
+    return wm_multi_icp_match(m, ref, n_ref, target, n_target, stride, p, -1.f, 0, T_out, stats);
+}
+
+int wm_multi_icp_match(wm_multi *m, const void *ref, size_t n_ref, const void *target, size_t n_target,
+                       size_t stride, const wm_icp_params *p, float res, int multiscale_steps, double T_out[16],
+                       wm_icp_stats *stats) {
     if (!m || !p || !T_out) return WM_ERR_ARG;
     const int n = (int) m->ctx.size();
-    if (n == 1) return wm_icp_align_sharded(m->ctx[0], nullptr, ref, n_ref, target, n_target, stride, WM_MEM_HOST, p, T_out, stats);
+    if (n == 1)
+        return wm_icp_match(m->ctx[0], ref, n_ref, target, n_target, stride, WM_MEM_HOST, p, res, multiscale_steps, T_out,
+                            stats);
     std::vector<int> rcs((size_t) n, WM_ERR_STATE);
     std::vector<wm_icp_stats> sts((size_t) n);
     std::vector<double> Ts((size_t) n * 16, 0.0);
     std::vector<std::thread> th;
     for (int r = 0; r < n; ++r)
         th.emplace_back([&, r] {
-            rcs[(size_t) r] = wm_icp_align_sharded(m->ctx[(size_t) r], m->comm[(size_t) r], ref, n_ref, target, n_target,
-                                                   stride, WM_MEM_HOST, p, &Ts[(size_t) r * 16], &sts[(size_t) r]);
+            rcs[(size_t) r] = wm_icp_match_sharded(m->ctx[(size_t) r], m->comm[(size_t) r], ref, n_ref, target, n_target,
+                                                   stride, WM_MEM_HOST, p, res, multiscale_steps, &Ts[(size_t) r * 16],
+                                                   &sts[(size_t) r]);
         });
     for (auto &t : th) t.join();
     for (int r = 0; r < n; ++r)
         if (rcs[(size_t) r] < 0) return rcs[(size_t) r];
     if (stats) *stats = sts[0];
     if (rcs[0] == WM_OK) memcpy(T_out, Ts.data(), 16 * sizeof(double));
+    return rcs[0];
+}
+
+// ICPMatcher::estimateInfo() after a registration over the group (wm_multi_icp_match): every rank adds up
+// its own pairs, the sums are exchanged, every rank finishes the same 6x6 (wm_icp_info_sharded)
+int wm_multi_icp_info(wm_multi *m, int method, const double T_result[16], double lin_covar, double ang_covar,
+                      double max_corr, double info[36], int *degenerate) {
+    if (!m || !info) return WM_ERR_ARG;
+    const int n = (int) m->ctx.size();
+    if (n == 1) return wm_icp_info(m->ctx[0], method, T_result, lin_covar, ang_covar, max_corr, info, degenerate);
+    std::vector<int> rcs((size_t) n, WM_ERR_STATE), deg((size_t) n, 0);
+    std::vector<double> infos((size_t) n * 36, 0.0);
+    std::vector<std::thread> th;
+    for (int r = 0; r < n; ++r)
+        th.emplace_back([&, r] {
+            rcs[(size_t) r] = wm_icp_info_sharded(m->ctx[(size_t) r], m->comm[(size_t) r], method, T_result, lin_covar,
+                                                  ang_covar, max_corr, &infos[(size_t) r * 36], &deg[(size_t) r]);
+        });
+    for (auto &t : th) t.join();
+    for (int r = 0; r < n; ++r)
+        if (rcs[(size_t) r] < 0) return rcs[(size_t) r];
+    if (rcs[0] == WM_OK) {
+        memcpy(info, infos.data(), 36 * sizeof(double));
+        if (degenerate) *degenerate = deg[0];
+    }
     return rcs[0];
 }
 

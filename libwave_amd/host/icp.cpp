@@ -31,7 +31,7 @@ ICPMatcherParams::ICPMatcherParams(const std::string &config_path) {
 
 ICPMatcher::ICPMatcher(ICPMatcherParams params1)
     : params(params1), ctx(nullptr), multi(nullptr), device(shim::defaultDevice()), converged(false),
-      ref(shim::emptyCloud()), target(shim::emptyCloud()) {
+      lastMatch(kNone), ref(shim::emptyCloud()), target(shim::emptyCloud()) {
     resolution = params.res;
 }
 
@@ -39,7 +39,7 @@ ICPMatcher::ICPMatcher(ICPMatcherParams params1)
 // reference class, a context belongs to one object (and is created by the thread that uses it).
 ICPMatcher::ICPMatcher(const ICPMatcher &o)
     : Matcher<PCLPointCloudPtr>(o), params(o.params), ctx(nullptr), multi(nullptr), devices(o.devices),
-      device(o.device), converged(false), ref(o.ref), target(o.target) {}
+      device(o.device), converged(false), lastMatch(kNone), ref(o.ref), target(o.target) {}
 
 ICPMatcher &ICPMatcher::operator=(const ICPMatcher &o) {
     if (this == &o) return *this;
@@ -51,6 +51,7 @@ ICPMatcher &ICPMatcher::operator=(const ICPMatcher &o) {
     devices = o.devices;
     device = o.device;
     converged = false;
+    lastMatch = kNone;
     ref = o.ref;
     target = o.target;
     return *this;
@@ -64,6 +65,7 @@ ICPMatcher::~ICPMatcher() {
 void ICPMatcher::setDevices(const std::vector<int> &list) {
     if (multi) wm_multi_destroy(multi);
     multi = nullptr;
+    lastMatch = kNone;
     devices = list;
     if (devices.size() == 1) {  // a plain single-device matcher on that device
         if (devices[0] != device) shim::release(ctx);
@@ -80,6 +82,7 @@ void ICPMatcher::setTarget(const PCLPointCloudPtr &cloud) { target = cloud; }
 
 bool ICPMatcher::match() {
     converged = false;
+    lastMatch = kNone;
     wm_icp_params p;
     wm_icp_default_params(&p);
     p.max_corr = params.max_corr;  // setMaxCorrespondenceDistance,  icp.cpp:47
@@ -89,7 +92,7 @@ bool ICPMatcher::match() {
     p.carry_state = 1;             // one PCL object per matcher: its criteria remember the last MSE
     double T[16];
     wm_icp_stats stats;
-    if (devices.size() > 1 && !(params.res > 0)) {  // one registration over several GPUs (setDevices)
+    if (devices.size() > 1) {  // one registration over several GPUs (setDevices)
         if (!multi) {
             bool repeated = false;
             for (size_t a = 0; a < devices.size(); ++a)
@@ -101,13 +104,14 @@ bool ICPMatcher::match() {
                 return false;
             }
         }
-        const int rcm = wm_multi_icp_align(multi, cloudData(ref), cloudSize(ref), cloudData(target),
-                                           cloudSize(target), kCloudStride, &p, T, &stats);
-        if (!shim::succeeded(rcm, "wm_multi_icp_align", nullptr)) return false;
+        const int rcm = wm_multi_icp_match(multi, cloudData(ref), cloudSize(ref), cloudData(target), cloudSize(target),
+                                           kCloudStride, &p, params.res, params.multiscale_steps, T, &stats);
+        if (!shim::succeeded(rcm, "wm_multi_icp_match", nullptr)) return false;
         shim::toAffine(T, result);
-        return true;  // (converged stays false: no correspondences on one device for estimateInfo)
+        converged = true;
+        lastMatch = kOnMulti;
+        return true;
     }
-    if (devices.size() > 1) LOG_INFO("ICPMatcher: voxel-filtered matches run on one device; using device %d", device);
     if (!ensureContext()) return false;
     const int rc = wm_icp_match(ctx, cloudData(ref), cloudSize(ref), cloudData(target), cloudSize(target),
                                 kCloudStride, WM_MEM_HOST, &p, params.res, params.multiscale_steps, T,
@@ -116,6 +120,7 @@ bool ICPMatcher::match() {
     if (!shim::succeeded(rc, "wm_icp_match", ctx)) return false;
     shim::toAffine(T, result);
     converged = true;
+    lastMatch = kOnCtx;
     return true;
 }
 
@@ -143,7 +148,10 @@ bool ICPMatcher::batchable(const PCLPointCloudPtr &r, const PCLPointCloudPtr &t)
     // device (pairs that stay too large are registered one by one inside wm_icp_batch_match); raw scans
     // of up to 200 000 points are taken
     if (params.res > 0) return cloudSize(r) <= 200000 && cloudSize(t) <= 200000;
-    return cloudSize(t) <= maxBatchTargetPoints();
+    // (the source of a resident registration may be any size in principle, but a launch stages the sources
+    // of up to 256 pairs at once: a queue of dense scans against sparse key frames would cost gigabytes
+    // of staging per worker and run on one compute unit each -- those go one by one, on the whole device)
+    return cloudSize(t) <= maxBatchTargetPoints() && cloudSize(r) <= 200000;
 }
 
 bool ICPMatcher::matchBatch(const std::vector<std::pair<PCLPointCloudPtr, PCLPointCloudPtr>> &pairs,
@@ -186,6 +194,7 @@ bool ICPMatcher::matchBatch(const std::vector<std::pair<PCLPointCloudPtr, PCLPoi
         out[k].info = information;
     }
     converged = false;  // (no correspondences are kept on the device for a later estimateLUM / estimateCensi)
+    lastMatch = kNone;  // ... nor for estimateLUMold: the context may still hold an older match()'s
     return true;
 }
 
@@ -202,30 +211,40 @@ void ICPMatcher::estimateInfo() {
 
 
 void ICPMatcher::estimateLUM() {
-    if (!ctx || !converged) return;  // hasConverged() guard of icp_pcl_functions.cpp:190
+    if (lastMatch == kNone || !converged) return;  // hasConverged() guard of icp_pcl_functions.cpp:190
     double info[36];
     int degenerate = 0;
-    if (wm_icp_info(ctx, WM_INFO_LUM, nullptr, 0, 0, 0, info, &degenerate) != WM_OK) return;
+    const int rc = lastMatch == kOnMulti ? wm_multi_icp_info(multi, WM_INFO_LUM, nullptr, 0, 0, 0, info, &degenerate)
+                                         : wm_icp_info(ctx, WM_INFO_LUM, nullptr, 0, 0, 0, info, &degenerate);
+    if (rc != WM_OK) return;
     warnIfDegenerate(degenerate);
     storeInfo(info, information);
 }
 
 void ICPMatcher::estimateLUMold() {
-    if (!ctx) return;
+    // (the reference's estimateLUMold has no hasConverged() guard, but it works on the clouds of the last
+    // align of this matcher: after a failed match, a matchBatch() or before any match there are none here)
+    if (lastMatch == kNone) return;
     double info[36];
     int degenerate = 0;
-    if (wm_icp_info(ctx, WM_INFO_LUMOLD, nullptr, 0, 0, params.max_corr, info, &degenerate) != WM_OK) return;
+    const int rc = lastMatch == kOnMulti
+                       ? wm_multi_icp_info(multi, WM_INFO_LUMOLD, nullptr, 0, 0, params.max_corr, info, &degenerate)
+                       : wm_icp_info(ctx, WM_INFO_LUMOLD, nullptr, 0, 0, params.max_corr, info, &degenerate);
+    if (rc != WM_OK) return;
     warnIfDegenerate(degenerate);
     storeInfo(info, information);
 }
 
 void ICPMatcher::estimateCensi() {
-    if (!ctx || !converged) return;  // icp.cpp:174
+    if (lastMatch == kNone || !converged) return;  // icp.cpp:174
     double info[36], T[16];
     shim::fromAffine(result, T);
-    if (wm_icp_info(ctx, WM_INFO_CENSI, T, params.lidar_lin_covar, params.lidar_ang_covar, 0, info, nullptr) !=
-        WM_OK)
-        return;
+    const int rc = lastMatch == kOnMulti
+                       ? wm_multi_icp_info(multi, WM_INFO_CENSI, T, params.lidar_lin_covar, params.lidar_ang_covar, 0,
+                                           info, nullptr)
+                       : wm_icp_info(ctx, WM_INFO_CENSI, T, params.lidar_lin_covar, params.lidar_ang_covar, 0, info,
+                                     nullptr);
+    if (rc != WM_OK) return;
     storeInfo(info, information);
 }
 

@@ -304,6 +304,32 @@ AddCase c_icp_devices("ICPTest.setDevicesShardsOneRegistration", [] {
     EXPECT((many.getResult().matrix() - one.getResult().matrix()).norm() < 1e-12);
 });
 
+// ... with the reference's DEFAULT parameters (voxel filter + three coarser scales, icp.hpp:54,59) and
+// estimateInfo() after it, as MultiMatcher's worker loop calls it (impl/multi_matcher_impl.hpp:48)
+AddCase c_icp_devices_default("ICPTest.setDevicesDefaultParametersAndInfo", [] {
+    const auto ref = loadScan();
+    auto target = shifted(ref, translationX(0.2));
+    wave::ICPMatcherParams p;  // defaults: res 0.1, multiscale_steps 3, LUM
+    wave::ICPMatcher one(p), many(p);
+    one.setup(ref, target);
+    EXPECT(one.match());
+    one.estimateInfo();
+    many.setDevices({0, 0, 0});
+    many.setup(ref, target);
+    EXPECT(many.match());
+    EXPECT((many.getResult().matrix() - one.getResult().matrix()).norm() < 1e-6);
+    many.estimateInfo();
+    EXPECT(many.getInfo()(0, 0) > 0);
+    EXPECT((many.getInfo() - one.getInfo()).norm() < 1e-4 * one.getInfo().norm());
+    // a matchBatch() leaves nothing behind for the estimators: information keeps its value
+    many.setDevices({});
+    wave::ICPMatcher::BatchOutcomes out;
+    std::vector<std::pair<wave::PCLPointCloudPtr, wave::PCLPointCloudPtr>> pairs(2, std::make_pair(ref, target));
+    EXPECT(many.matchBatch(pairs, out));
+    many.estimateInfo();
+    EXPECT((many.getInfo() - out.back().info).norm() == 0);
+});
+
 // ---------------------------------------------------------------------- MultiMatcher
 wave::ICPMatcherParams singleScale() {
     wave::ICPMatcherParams p;

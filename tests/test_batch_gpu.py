@@ -290,3 +290,30 @@ def test_batched_matches_do_not_depend_on_where_the_clouds_live(wm, ctx, oracle,
         for x, y in zip(a, b):
             assert x["rc"] == y["rc"] == 0 and x["iterations"] == y["iterations"]
             assert np.array_equal(x["T"], y["T"]) and np.array_equal(x["info"], y["info"])
+
+
+@pytest.mark.parametrize("res,steps", [(-1.0, 0), (0.1, 0), (0.1, 3)])
+def test_batch_of_empty_pairs_only(wm, ctx, res, steps):
+    """The C API's contract is "WM_OK when the batch ran, one status per item": a batch whose items are
+    all empty ran (PCL: empty input -> "Not enough correspondences"), with or without a voxel filter."""
+    empty = np.zeros((0, 3), np.float32)
+    got = ctx.icp_batch_match([(empty, empty)] * 3, with_info=True, res=res, multiscale_steps=steps, max_corr=3.0)
+    assert len(got) == 3
+    for g in got:
+        assert g["rc"] == wm.WM_ERR_STATE and g["T"] is None and g["state"] == "NO_CORRESPONDENCES"
+
+
+def test_batch_fallback_pair_carries_the_mse_across_its_scales(wm, ctx):
+    """A pair too large for the resident kernel is registered inside the batch by the one-pair path; it
+    must stop where a fresh one-pair matcher stops (fresh criteria per pair, MSE carried across scales)."""
+    big_r, big_t, _ = synth.pair(150000, seed=61, mode="resample")
+    small_r, small_t, _ = synth.pair(9000, seed=62, mode="resample")
+    kw = dict(max_corr=3.0, max_iter=100)
+    got = ctx.icp_batch_match([(small_r, small_t), (big_r, big_t)], with_info=False, res=0.02, multiscale_steps=2, **kw)
+    c2 = wm.Context(0)
+    one = c2.icp_match(big_r, big_t, res=0.02, multiscale_steps=2, carry_state=1, **kw)
+    c2.close()
+    assert got[1]["rc"] == one["rc"] == 0
+    assert (got[1]["iterations"], got[1]["state"]) == (one["iterations"], one["state"])
+    dt, ang = pose_error(got[1]["T"], one["T"])
+    assert dt <= 1e-9 and ang <= 1e-10

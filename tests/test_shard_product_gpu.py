@@ -225,3 +225,33 @@ def test_bench_sharded_under_torch_distributed_run():
     assert sh["allreduce_us_isolated"] > 0 and sh["allreduce_ms"] > 0
     assert sh["plan_ms"] > 0 and sh["compact_ms"] > 0 and sh["index_ms"] > 0 and sh["iter_ms"] > 0
     assert d["config"]["final_translation_error_m"] < 2e-3
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("res,steps", [(-1.0, 0), (0.1, 0), (0.1, 3)])
+def test_multi_match_and_estimators_equal_one_device(wm, world, res, steps):
+    """ICPMatcher::match() over a group of devices -- full resolution, voxel-filtered, and the reference's
+    DEFAULT parameters (res 0.1, three coarser scales: icp.hpp:54,59, icp.cpp:77-104) -- and
+    estimateInfo() after it (icp.cpp:135-142 -> impl/multi_matcher_impl.hpp:48): same transform, same
+    stop, same three information matrices as one device."""
+    ref, tgt, _ = synth.pair(60000, seed=77, mode="resample")
+    kw = dict(max_corr=3.0, max_iter=100, nn_method=wm.WM_NN_GRID)
+    c = wm.Context(0)
+    one = c.icp_match(ref, tgt, res=res, multiscale_steps=steps, carry_state=0, **kw)
+    infos = {}
+    for name, method in (("lum", wm.WM_INFO_LUM), ("censi", wm.WM_INFO_CENSI), ("lumold", wm.WM_INFO_LUMOLD)):
+        infos[name] = c.icp_info(method, one["T"], max_corr=3.0)
+    c.close()
+    assert one["rc"] == 0
+    m = wm.Multi([0] * world, emulate=True)
+    got = m.icp_match(ref, tgt, res=res, multiscale_steps=steps, carry_state=0, **kw)
+    assert got["rc"] == 0 and got["owned_violations"] == 0
+    assert got["iterations"] == one["iterations"] and got["n_corr"] == one["n_corr"]
+    dt, ang = pose_error(got["T"], one["T"])
+    assert dt <= 1e-8 and ang <= 1e-9, (dt, ang)
+    for name, method in (("lum", wm.WM_INFO_LUM), ("censi", wm.WM_INFO_CENSI), ("lumold", wm.WM_INFO_LUMOLD)):
+        rc, info, deg = m.icp_info(method, got["T"], lin_covar=2.5e-4, ang_covar=7.78e-9, max_corr=3.0)
+        rc1, info1, deg1 = infos[name]
+        assert rc == rc1 == 0 and bool(deg) == bool(deg1)
+        assert np.allclose(info, info1, rtol=2e-5, atol=1e-9 * np.abs(info1).max()), (name, np.abs(info - info1).max())
+    m.close()
