@@ -171,7 +171,22 @@ static void r_derivative(const double x[6], const double Racc[9], double g[6]) {
  * line-search branch and move the stopping point by millimetres.  An order-independent sum is what
  * lets a parallel implementation (the HIP kernel adds in a strided tree order) make exactly the
  * decisions this sequential loop makes. */
+/* Summation of the objective's 13 sums: 0 = double-double (default: what the HIP path is held to bit
+ * for bit), 1 = PCL-LITERAL -- plain doubles added in index order, as Eigen does inside
+ * OptimizationFunctorWithIndices::fdf (`f += double(res.transpose() * temp)`, `g.head<3>() += temp`,
+ * `R += p_base_src * temp.transpose()`; PCL registration/impl/gicp.hpp).  The two differ in the last
+ * bit of f and the gradient; with PCL's BFGS tolerance of 1e-2 that can move the stopping point: the
+ * spread between the modes is what separates ANY faithful implementation from PCL itself
+ * (tests/test_gicp_gpu.py::test_gicp_spread_against_pcl_literal_summation). */
+static int g_gicp_summation = 0;
+void wmo_gicp_set_summation(int mode) { g_gicp_summation = mode ? 1 : 0; }
+int wmo_gicp_get_summation(void) { return g_gicp_summation; }
+
 static void dd_add(double *hi, double *lo, double x) {
+    if (g_gicp_summation) {  /* PCL-literal: one rounding per addition, in index order */
+        *hi += x;
+        return;
+    }
     const double s = *hi + x;
     const double bb = s - *hi;
     *lo += (*hi - (s - bb)) + (x - bb);

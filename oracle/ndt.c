@@ -15,6 +15,16 @@
  * Version switches:
  *   skip_line_search  PCL 1.8.x initialises `interval_converged` to true so the
  *                     More-Thuente loop never runs; default here = run it.
+ *                     With the reference's own test parameters (tests/config/ndt.yaml: step_size 3,
+ *                     max_iter 100, t_eps 1e-8) the 1.8-literal mode DOES reproduce the outcome of
+ *                     wave_matching/tests/ndt_tests.cpp:85-102 (green on the reference's CI with
+ *                     libpcl1.8): 102 iterations -- PCL's `nr_iterations_ > max_iterations_` rule,
+ *                     which is also what makes hasConverged() true --, final |T - T_gt|_F = 0.0099
+ *                     < 0.12.  The undamped Newton iteration leaves the basin after three steps
+ *                     (0.197 m, then 0.4-1.0 m for some eighty iterations) and returns to it near
+ *                     iteration 90; the trajectory is chaotic (pcl_d1_sign = 0 alone ends it 4.4 m
+ *                     away), so real PCL's digits cannot be promised, only the test's outcome
+ *                     (tests/test_oracle_cpu.py::test_ndt_pcl18_literal_mode_meets_the_reference_test).
  *   pcl_d1_sign       PCL's h_ang_d1 third component is +sy (thesis typo; the true
  *                     derivative is -sy); default = PCL's.
  * PARITY: unpinned (no PCL to run); pinned to the reference tests' assertions

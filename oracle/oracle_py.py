@@ -375,6 +375,12 @@ def gicp_covariances(xyz, k=10, eps=1e-3):
     return cov
 
 
+def gicp_set_summation(mode):
+    """0: double-double sums (default, what the HIP path reproduces bit for bit); 1: PCL-literal plain
+    doubles in index order (oracle/gicp.c).  Process-wide."""
+    lib().wmo_gicp_set_summation(int(mode))
+
+
 def gicp_align(src, tgt, params=None, **kw):
     src, tgt = _f32(src), _f32(tgt)
     p = params or gicp_params(**kw)

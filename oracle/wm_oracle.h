@@ -158,6 +158,9 @@ typedef struct {
     double f_final;
 } wmo_gicp_result;
 void wmo_gicp_default_params(wmo_gicp_params *p);
+/* summation of the objective's sums: 0 double-double (default), 1 PCL-literal plain doubles in index order */
+void wmo_gicp_set_summation(int mode);
+int wmo_gicp_get_summation(void);
 /* per-point covariances (n x 9 doubles, row-major 3x3) */
 int wmo_gicp_covariances(const float *xyz, int n, int k, double eps, double *cov);
 int wmo_gicp_align(const float *src, int n, const float *tgt, int m,

@@ -233,3 +233,26 @@ def test_unchanged_target_keeps_its_voxel_model(wm, ctx):
     assert c["model_builds"] == 2 and np.array_equal(a["T"], c["T"])
     d = ctx.ndt_align(res=2.0, step_size=0.1, max_iter=15)  # another resolution: another model
     assert d["model_builds"] == 3
+
+
+def test_ndt_pcl18_literal_mode_tracks_the_oracle(wm, ctx, oracle, testscan):
+    """The PCL-1.8-literal step rule (skip_line_search = 1) on the reference's smallDisplacement case
+    (ndt_tests.cpp:85-102): the HIP path follows the oracle's undamped Newton iteration step for step --
+    3 steps in: 0.0163 from the ground truth, 37 steps in: 0.4437, the same four digits on both sides --
+    and, like it, stops by PCL's iteration-count rule (102 iterations, hasConverged() true).  Where the
+    chaotic trajectory sits at step 102 is decided by the last bits of 100 sums (the oracle: 0.0099, inside
+    the reference test's 0.12; see tests/test_oracle_cpu.py): not asserted."""
+    P = np.eye(4)
+    P[0, 3] = 0.2
+    tgt = oracle.transform_cloud_d(testscan, P)
+    ctx.set_source(testscan)
+    ctx.set_target(tgt)
+    for max_iter in (1, 3, 35):
+        kw = dict(res=0.3, step_size=3.0, max_iter=max_iter, t_eps=1e-8, skip_line_search=1)
+        got = ctx.ndt_align(**kw)
+        want = oracle.ndt_align(testscan, tgt, **kw)
+        assert got["rc"] == 0 and got["iterations"] == want["iterations"] == max_iter + 2
+        dt, ang = pose_error(got["T"], want["T"])
+        assert dt < 1e-3 and ang < 1e-3, (max_iter, dt, ang)
+    got = ctx.ndt_align(res=0.3, step_size=3.0, max_iter=100, t_eps=1e-8, skip_line_search=1)
+    assert got["rc"] == 0 and got["converged"] and got["iterations"] == 102

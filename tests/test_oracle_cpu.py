@@ -206,3 +206,54 @@ def test_lum_normal_equations_match_numpy(oracle):
     # (Eigen::Vector3f operands, icp_pcl_functions.cpp:219-248) -> ~1e-7 relative
     np.testing.assert_allclose(r["MM"], MM, rtol=2e-6, atol=1e-4)
     np.testing.assert_allclose(r["MZ"], MZ, rtol=2e-6, atol=1e-4)
+
+
+def test_gicp_summation_modes_agree_at_the_millimetre_level(oracle):
+    """oracle/gicp.c sums the objective in double-double (default) or as PCL does (plain doubles in
+    index order): both are faithful restatements; on a noisy pair they may stop BFGS at slightly
+    different points (documented spread), both near the ground truth."""
+    from helpers import pose_error
+    from libwave_amd import synth
+    ref, tgt, T_gt = synth.pair(8000, seed=21)
+    a = oracle.gicp_align(ref, tgt)
+    assert oracle.lib().wmo_gicp_get_summation() == 0
+    oracle.gicp_set_summation(1)
+    try:
+        b = oracle.gicp_align(ref, tgt)
+        assert oracle.lib().wmo_gicp_get_summation() == 1
+    finally:
+        oracle.gicp_set_summation(0)
+    assert a["converged"] and b["converged"]
+    dt, ang = pose_error(a["T"], b["T"])
+    assert dt < 5e-3 and ang < 1e-3
+    for r in (a, b):
+        d, g = pose_error(r["T"], T_gt)
+        assert d < 2e-2 and g < 2e-3
+
+
+def test_ndt_pcl18_literal_mode_meets_the_reference_test(oracle, testscan):
+    """wave_matching/tests/ndt_tests.cpp:85-102 (smallDisplacement: res 0.3, +0.2 m in x, the
+    reference's ndt.yaml: step_size 3, max_iter 100, t_eps 1e-8) passes on the reference's CI with
+    libpcl1.8.  So does the oracle's PCL-1.8-literal mode (skip_line_search = 1: the 1.8.x
+    initialiser of `interval_converged` keeps the More-Thuente loop from ever running, every step is
+    the undamped Newton step clamped to step_size): it runs the 102 iterations PCL's
+    `nr_iterations_ > max_iterations_` rule allows -- which is also what sets hasConverged() --
+    and ends 0.0099 from the ground truth, inside the test's 0.12.  It gets there the hard way: the
+    iteration leaves the optimum's basin after three steps (0.197 m, then 0.4 ... 1.0 m for some
+    eighty iterations) and only returns to it near iteration 90.  That trajectory is chaotic -- the
+    sign of PCL's one mistaken Hessian entry alone ends it 4.4 m away -- so no restatement can
+    promise real PCL's digits here; what it reproduces is the reference test's outcome.  (Round 2
+    reported this mode as "wandering off": measured at the bench's max_iter = 35, where it does.)"""
+    P = np.eye(4)
+    P[0, 3] = 0.2
+    tgt = oracle.transform_cloud_d(testscan, P)
+    r = oracle.ndt_align(testscan, tgt, res=0.3, step_size=3.0, max_iter=100, t_eps=1e-8, skip_line_search=1)
+    assert r["converged"] and r["iterations"] == 102            # the iteration-count rule, not a small step
+    assert np.linalg.norm(r["T"] - P) < 0.12                     # ndt_tests.cpp:37,99-101
+    early = oracle.ndt_align(testscan, tgt, res=0.3, step_size=3.0, max_iter=1, t_eps=1e-8, skip_line_search=1)
+    assert abs(early["T"][0, 3] - 0.2) < 0.01                    # three undamped steps: already at 0.197
+    mid = oracle.ndt_align(testscan, tgt, res=0.3, step_size=3.0, max_iter=35, t_eps=1e-8, skip_line_search=1)
+    assert np.linalg.norm(mid["T"] - P) > 0.12                   # ... and far away again at the bench's 35
+    # the default (More-Thuente runs) converges properly, by the step-size rule
+    d = oracle.ndt_align(testscan, tgt, res=0.3, step_size=3.0, max_iter=100, t_eps=1e-8)
+    assert d["converged"] and d["iterations"] < 30 and np.linalg.norm(d["T"] - P) < 1e-3
