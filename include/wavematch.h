@@ -256,6 +256,9 @@ int wm_debug_cert_log(wm_ctx *ctx, int iterations, unsigned *out, int cap);
 /* developer (armed by wm_debug_cert_log with WM_CERT_PROF set): 64 words per launch -- 16 cycle stamps
  * of each of four sampled workgroups (see k_nn_cert) */
 int wm_debug_cert_prof(wm_ctx *ctx, unsigned long long *out, int cap);
+/* developer: the per-iteration records the solve kernels of the last align published for the host
+ * ([k], k >= 1: iteration : 16 | step size bfloat16 : 16 | changed matches : 16 | searched : 16) */
+int wm_debug_pub_log(wm_ctx *ctx, unsigned long long *out, int cap);
 /* Per-iteration device time (ms) of the correspondence kernel in the last
  * wm_icp_align call that ran with profile >= 1; returns the number written. */
 int wm_get_iteration_times(wm_ctx *ctx, float *nn_ms, int cap);

@@ -111,6 +111,7 @@ def lib():
         L.wm_debug_copy_bandwidth.argtypes = [C.c_void_p, C.c_size_t, C.c_int, _dp]
         L.wm_debug_cert_log.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint), C.c_int]
         L.wm_debug_cert_prof.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+        L.wm_debug_pub_log.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
         L.wm_cloud_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.wm_icp_default_params.argtypes = [C.POINTER(IcpParams)]
         L.wm_icp_default_params.restype = None
@@ -311,6 +312,19 @@ class Context:
         out = (C.c_uint * 4096)()
         k = lib().wm_debug_cert_log(self._h, 0, out, 4096)
         return [int(out[i]) for i in range(max(k, 0))]
+
+    def pub_log(self):
+        """[(iteration, step size m, fraction of matches changed, fraction searched by the certificate kernel)]"""
+        out = (C.c_uint64 * 1024)()
+        n = lib().wm_debug_pub_log(self._h, out, 1024)
+        rows = []
+        for k in range(1, max(n, 0)):
+            w = int(out[k])
+            if w == 0:
+                break
+            disp = np.array([((w >> 32) & 0xFFFF) << 16], np.uint32).view(np.float32)[0]
+            rows.append((w >> 48, float(disp), ((w >> 16) & 0xFFFF) / 65535.0, (w & 0xFFFF) / 65535.0))
+        return rows
 
     def cert_prof(self):
         out = (C.c_uint64 * (64 * 128))()

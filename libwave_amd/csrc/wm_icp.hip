@@ -256,6 +256,7 @@ __global__ void __launch_bounds__(THREADS)
             for (int k = 0; k < kAcc; ++k) a[k] = tot[k];
             double ex[kStatsLen];
             expand_stats(s_st.mode, a, ex);
+            s_st.local_handled = ex[kStatsLen - 1];
 #pragma unroll
             for (int k = 0; k < kStatsLen; ++k) s_st.stats[k] = ex[k];
             if (PHASES == 1 && stats_io) {  // the block the all-reduce works on
@@ -278,11 +279,17 @@ __global__ void __launch_bounds__(THREADS)
             // (pub[0]: the latest; pub[k]: iteration k's own record, so that what the host decides from
             // does not depend on when it looks)
             if (pub) {
-                const unsigned long long w = ((unsigned long long) (unsigned) s_st.iter << 32) |
-                                             (unsigned long long) __float_as_uint(s_st.step_disp);
+                // [iteration : 16 | step size as bfloat16 : 16 | changed matches : 16 | searched by the
+                //  certificate kernel : 16] -- fractions in 1 / 65535
+                const unsigned f_ch = (unsigned) (fminf(fmaxf(s_st.frac_changed, 0.f), 1.f) * 65535.f + 0.5f);
+                const unsigned f_un = (unsigned) (fminf(fmaxf(s_st.frac_unsettled, 0.f), 1.f) * 65535.f + 0.5f);
+                const unsigned long long w = ((unsigned long long) ((unsigned) s_st.iter & 0xFFFFu) << 48) |
+                                             ((unsigned long long) (__float_as_uint(s_st.step_disp) >> 16) << 32) |
+                                             ((unsigned long long) f_ch << 16) | (unsigned long long) f_un;
                 if (s_st.iter >= 1 && s_st.iter <= pub_slots)
                     __hip_atomic_store(pub + s_st.iter, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(pub, w | ((unsigned long long) (s_st.done ? 1u : 0u) << 63), __ATOMIC_RELAXED,
+                // ([0]: bit 0 = done)
+                __hip_atomic_store(pub, (unsigned long long) (s_st.done ? 1u : 0u), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
@@ -764,6 +771,14 @@ int wm_ctx_create(wm_ctx **out, int device) {
         const float v = (float) atof(e);
         if (v > 0) ctx->tune_cert_disp = v;
     }
+    if (const char *e = getenv("WM_TUNE_CERT_CHANGED")) {
+        const float v = (float) atof(e);
+        if (v > 0) ctx->tune_cert_changed = v;
+    }
+    if (const char *e = getenv("WM_TUNE_CERT_UNSETTLED")) {
+        const float v = (float) atof(e);
+        if (v > 0) ctx->tune_cert_unsettled = v;
+    }
     if (const char *e = getenv("WM_TUNE_CERT_PAD_MUL")) {
         const float v = (float) atof(e);
         if (v >= 0) ctx->tune_cert_pad_mul = v;
@@ -1006,19 +1021,26 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
     const bool slab = ctx->h_state->slab_on != 0;
     ctx->cert_launches = 0;
     std::vector<unsigned char> was_cert;
+    std::vector<unsigned char> kind((size_t) max_it, 0);  // which search kernel iteration k got (1: certificate, 2: its first launch)
     for (int it = 0; it < max_it; ++it) {
-        float seen_disp = -1.f;  // the step size iteration it - kLag published (its own record)
+        float seen_disp = -1.f;  // what iteration it - kLag recorded (its own record): step size, ...
+        float seen_changed = 1.f, seen_unsettled = 0.f;  // ... fraction of changed matches, of searched queries
+        auto parse = [&](unsigned long long w) {
+            seen_disp = __builtin_bit_cast(float, (unsigned) ((w >> 32) & 0xFFFFu) << 16);
+            seen_changed = (float) ((w >> 16) & 0xFFFFu) / 65535.f;
+            seen_unsettled = (float) (w & 0xFFFFu) / 65535.f;
+        };
         if (it >= kLag) {  // wait for it (3 stages as in wait_flag)
             const unsigned need = (unsigned) (it - kLag + 1);  // iterations finished by then
             const auto t0 = std::chrono::steady_clock::now();
             bool yielding = false;
             for (unsigned spins = 1;; ++spins) {
                 const unsigned long long w = pub[need];
-                if ((unsigned) (w >> 32) == need) {
-                    seen_disp = __builtin_bit_cast(float, (unsigned) w);
+                if ((unsigned) (w >> 48) == (need & 0xFFFFu) && w != 0ull) {
+                    parse(w);
                     break;
                 }
-                if ((pub[0] >> 63) != 0ull) {
+                if ((pub[0] & 1ull) != 0ull) {
                     seen_done = true;
                     break;
                 }
@@ -1033,7 +1055,7 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
                         // enqueued has run -- the record is there then, unless a kernel failed
                         WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
                         const unsigned long long w2 = pub[need];
-                        if ((unsigned) (w2 >> 32) == need) seen_disp = __builtin_bit_cast(float, (unsigned) w2);
+                        if ((unsigned) (w2 >> 48) == (need & 0xFFFFu) && w2 != 0ull) parse(w2);
                         else seen_done = true;
                         break;
                     }
@@ -1046,8 +1068,20 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
             if (ctx->tune_cert_from >= 0) {
                 cert_on = it >= ctx->tune_cert_from;
             } else if (seen_disp >= 0.f) {
-                if (!cert_on && seen_disp < cert_thr) cert_on = true;
-                else if (cert_on && seen_disp > 3.f * cert_thr) cert_on = false;
+                // certify once a step is small AND few matches still change (on a scan whose density varies
+                // by orders of magnitude the dense part keeps changing partners long after the step has
+                // become small against the grid cell); back to full searches when a certificate launch had
+                // to search a large share after all
+                // (the record of a certificate launch that had no bounds to go by -- the first after full
+                // searches -- says nothing: it searched everything)
+                const unsigned char rec = (size_t) (it - kLag) < kind.size() ? kind[(size_t) (it - kLag)] : 0;
+                if (!cert_on) {
+                    if (seen_disp < cert_thr && seen_changed < ctx->tune_cert_changed && rec == 0) cert_on = true;
+                } else if (rec == 1 && seen_unsettled > ctx->tune_cert_unsettled) {
+                    cert_on = false;
+                } else if (seen_disp > 3.f * cert_thr) {
+                    cert_on = false;
+                }
             }
         }
         hipEvent_t e0 = nullptr, e1 = nullptr, e1b = nullptr, e2 = nullptr, e3 = nullptr;
@@ -1076,6 +1110,7 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
                 WM_HIP(ctx, hipMemsetAsync(ctx->nn_bound.p, 0, ((size_t) ctx->n_src + 64) * sizeof(float4), ctx->stream));
             }
             WM_TRY(launch_nn_cert(ctx, thr, e0, e1, e1b, p->mode, &rows, bounds_valid || slab));
+            kind[(size_t) it] = bounds_valid ? 1 : 2;
             bounds_valid = true;
             ctx->cert_launches++;
             if (p->profile) {
@@ -1538,6 +1573,8 @@ int wm_set_option(wm_ctx *ctx, const char *name, double value) {
     else if (k == "cert_nb") ctx->tune_cert_nb = (int) value;
     else if (k == "cert_rc") ctx->tune_cert_rc = (int) value;
     else if (k == "cert_disp" && value > 0) ctx->tune_cert_disp = (float) value;
+    else if (k == "cert_changed" && value > 0) ctx->tune_cert_changed = (float) value;
+    else if (k == "cert_unsettled" && value > 0) ctx->tune_cert_unsettled = (float) value;
     else if (k == "cert_pad_mul" && value >= 0) ctx->tune_cert_pad_mul = (float) value;
     else if (k == "cert_pad_frac" && value >= 0) ctx->tune_cert_pad_frac = (float) value;
     else return WM_ERR_ARG;
@@ -1572,6 +1609,13 @@ int wm_debug_cert_log(wm_ctx *ctx, int iterations, unsigned *out, int cap) {
         for (int k = 0; k < 64; ++k) t += tmp[(size_t) i * 64 + k];
         out[i] = t;
     }
+    return n;
+}
+
+int wm_debug_pub_log(wm_ctx *ctx, unsigned long long *out, int cap) {
+    if (!ctx || !out || !ctx->h_pub) return WM_ERR_ARG;
+    const int n = ctx->h_pub_slots < cap ? ctx->h_pub_slots : cap;
+    for (int k = 0; k < n; ++k) out[k] = ctx->h_pub[k];
     return n;
 }
 

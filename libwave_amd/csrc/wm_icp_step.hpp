@@ -14,7 +14,10 @@ namespace wm {
 __device__ __host__ inline void expand_stats(int mode, const double *a, double *st) {
 #pragma unroll
     for (int k = 0; k < kStatsLen; ++k) st[k] = 0.0;
-    st[kStatsLen - 1] = a[17];  // source points handled (ownership check of the sharded path)
+    // source points handled (ownership check of the sharded path), and -- the fraction of a[17], in
+    // units of 2^-24 -- how many of them changed their match (a free slot of either layout)
+    st[kStatsLen - 1] = floor(a[17]);
+    st[kStatsLen - 3] = (a[17] - floor(a[17])) * 16777216.0;
     if (mode == WM_ICP_SVD) {
         st[kSvdN] = a[0];
         for (int k = 0; k < 3; ++k) st[kSvdSp + k] = a[1 + k];
@@ -72,6 +75,23 @@ __host__ __device__ inline void icp_apply_stats(IcpDevState *st, const double *s
     {
         const double expect = st->expect_owned < 0 ? stats[kStatsLen - 2] : st->expect_owned;
         if (st->expect_owned != 0 && stats[kStatsLen - 1] != expect) st->owned_violations += 1;
+    }
+    // what the host steers the choice of the next search kernel by
+    {
+        const double handled = stats[kStatsLen - 1];
+        unsigned uns = 0;
+        bool any = false;
+#pragma unroll 1
+        for (int k = 0; k < 64; ++k) {
+            uns += st->cert_unsettled[k];
+            any = any || st->cert_unsettled[k] != 0u;
+            st->cert_unsettled[k] = 0u;
+        }
+        // (sharded: `handled` is the all-reduced count, the searches counted are this rank's own)
+        const double mine = st->local_handled > 0 ? st->local_handled : handled;
+        st->frac_changed = handled > 0 ? (float) (stats[kStatsLen - 3] / handled) : 0.f;
+        st->frac_unsettled = mine > 0 ? (float) ((double) uns / mine) : 0.f;  // (0 after a full search: nothing counted)
+        (void) any;
     }
     // bookkeeping for the next iteration's queues
     st->deferred_total += st->queue_count[1];

@@ -115,10 +115,13 @@ struct IcpDevState {
     int svd_warm;      // warm-started SVD on (tune_fast_solve)
     double svd_v[10];  // V of the last iteration's SVD (+ a valid flag): the next one starts from it
     unsigned long long dbg[8];  // developer: cycle stamps of the last solve kernel (wm_debug_solve_cycles)
+    unsigned cert_unsettled[64];  // k_nn_cert: queries it had to search in this iteration (partial counts; zeroed by the solve)
+    double local_handled;  // queries THIS rank handled in the last search (sharded: before the all-reduce)
+    float frac_changed;    // fraction of the handled queries whose match changed in the last search
+    float frac_unsettled;  // fraction the last certificate launch had to search (0 after a full search)
     float step_disp;   // upper estimate of how far the last step moved the source points (metres)
     float src_radius;  // half diagonal of the source cloud's bounding box (for step_disp)
     float src_centre[3];
-    int pad_;
 };
 
 struct Bbox {
@@ -231,6 +234,8 @@ struct wm_ctx {
     int tune_nn_balanced = 1;    // search kernel: wave-pooled candidate trips (0: every lane walks its own)
     int tune_cert_from = -1;     // k_nn_cert from this iteration of an align on (-1: chosen from the step size, tune_cert_disp; -2: never)
     float tune_cert_disp = 0.15f;  // ... once a step moves the points by less than this many level-0 cells
+    float tune_cert_changed = 0.05f;   // ... AND fewer than this fraction of the matches changed in the last full search
+    float tune_cert_unsettled = 0.40f; // back to full searches when a certificate launch had to search more than this fraction
     float tune_cert_pad_mul = 8.f, tune_cert_pad_frac = 0.5f;  // runner-up room of a certified search (see k_nn_cert)
     int tune_cert_nb = 4;        // batches of 64 queries per workgroup of k_nn_cert (2, 4 or 8)
     int tune_cert_rc = 3;        // rows per step of its searches (3 or 6)

@@ -279,6 +279,28 @@ __device__ __forceinline__ unsigned long long scan_box(const GridDev &g, float q
     return best;
 }
 
+// scan_run with runner-up tracking: `second` = d2 bits of the closest point seen other than the best
+// (meeting the best again -- the seed, a point read past a run's end -- changes nothing)
+__device__ __forceinline__ unsigned long long scan_run_bound(const float4 *__restrict__ pts, unsigned s, unsigned e,
+                                                             float qx, float qy, float qz, unsigned long long best,
+                                                             unsigned &second) {
+    for (unsigned j = s; j < e; j += 4) {
+        const gp_f4 p = (gp_f4) pts + j;
+        const f4v t[4] = {p[0], p[1], p[2], p[3]};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long k = make_key(canon_d2v(qx, qy, qz, t[u]), __float_as_uint(t[u].w));
+            if (k < best) {
+                second = min(second, (unsigned) (best >> 32));
+                best = k;
+            } else if (k != best) {
+                second = min(second, (unsigned) (k >> 32));
+            }
+        }
+    }
+    return best;
+}
+
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -433,9 +455,13 @@ __device__ __forceinline__ void balanced_walk(BalLds &L, const unsigned (&rs)[RC
     if (T == 0u) return;  // (wave-uniform)
     if constexpr (COST) cost += t;
     if (T > (unsigned) kBalCap) {  // too much for the list: every lane for itself
+        if constexpr (BOUND) {
 #pragma unroll
-        for (int u = 0; u < RC; ++u) best = scan_run(pts, rs[u], re[u], qx, qy, qz, best);
-        if constexpr (BOUND) bnd->ok = false;  // (no runner-up tracked on this path)
+            for (int u = 0; u < RC; ++u) best = scan_run_bound(pts, rs[u], re[u], qx, qy, qz, best, bnd->second);
+        } else {
+#pragma unroll
+            for (int u = 0; u < RC; ++u) best = scan_run(pts, rs[u], re[u], qx, qy, qz, best);
+        }
         return;
     }
     unsigned off = incl - t;
@@ -699,10 +725,13 @@ __device__ __forceinline__ bool scan_box_rows(const GridDev &g, bool live, float
 // parallel (one memory round trip), then every row is streamed by all 64 lanes with
 // coalesced float4 loads.  Used for queries far from their neighbour, whose scans
 // would otherwise serialise thousands of dependent loads in one lane.
+// second_out != nullptr: also the d2 bits of the closest point seen other than the best (runner-up,
+// min'd into *second_out: wave-uniform like best)
 __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, float qx, float qy,
                                                             float qz, float r,
                                                             unsigned long long best, unsigned lane,
-                                                            float *margin) {
+                                                            float *margin, unsigned *second_out = nullptr,
+                                                            float pad = 0.f) {
     const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
     const float rc = r * g.inv_h + g.slack;
     const float big = 4.0e6f;
@@ -725,8 +754,10 @@ __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, fl
     const int wy = yb - ya + 1;
     const int nrows = wy * (zb - za + 1);
     const float bd2 = __uint_as_float((unsigned) (best >> 32));
-    const float Rb = __builtin_amdgcn_sqrtf(bd2) * g.inv_h * 1.00001f;  // best distance, in cells
+    // best distance (+ the room asked for above it, for the runner-up bound), in cells
+    const float Rb = (__builtin_amdgcn_sqrtf(bd2) + pad) * g.inv_h * 1.00001f;
     unsigned long long mine = best;
+    unsigned mine2 = 0x7F800000u;  // this lane's runner-up (second_out)
     for (int k0 = 0; k0 < nrows; k0 += 64) {
         // lanes resolve up to 64 rows at once
         const int k = k0 + (int) lane;
@@ -764,11 +795,28 @@ __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, fl
                 const unsigned long long a = make_key(canon_d2(qx, qy, qz, t0), __float_as_uint(t0.w));
                 const unsigned long long b = make_key(canon_d2(qx, qy, qz, t1), __float_as_uint(t1.w));
                 const unsigned long long m = a < b ? a : b;
+                if (second_out) {  // (wave-uniform branch)
+                    const unsigned long long hi = a < b ? b : a;
+                    if (m < mine) {
+                        mine2 = min(mine2, min((unsigned) (mine >> 32), hi != m ? (unsigned) (hi >> 32) : 0x7F800000u));
+                    } else {
+                        if (m != mine) mine2 = min(mine2, (unsigned) (m >> 32));
+                        if (hi != mine && hi != m) mine2 = min(mine2, (unsigned) (hi >> 32));
+                    }
+                }
                 mine = m < mine ? m : mine;
             }
         }
     }
-    return wave_min_u64(mine);
+    const unsigned long long all = wave_min_u64(mine);
+    if (second_out) {
+        // the wave's runner-up: the lanes' own runner-ups, and the bests of the lanes that do not hold the winner
+        unsigned v = mine != all ? min(mine2, (unsigned) (mine >> 32)) : mine2;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = min(v, (unsigned) __shfl_xor((int) v, off));
+        *second_out = min(*second_out, v);
+    }
+    return all;
 }
 
 // ------------------------------------------------- fused ICP statistics
@@ -780,13 +828,17 @@ __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, fl
 // (the wave reduction by recursive halving: wm_wave.hpp)
 
 // this lane's terms of the iteration's sums (same arithmetic as k_icp_stats, wm_icp.hip)
+// a[17] counts the queries this rank handled; its fraction (units of 2^-24: exact in a double for any
+// cloud a context can hold) counts those whose match CHANGED in this search -- what the host decides
+// by whether the next searches can be certified instead (wm_icp_align).
+constexpr double kChangedUnit = 1.0 / 16777216.0;
 template <int STATS>
 __device__ __forceinline__ void icp_terms(double (&a)[kAcc], bool mine, bool matched, float qx, float qy, float qz,
-                                          float bqx, float bqy, float bqz, float d2) {
+                                          float bqx, float bqy, float bqz, float d2, bool changed = false) {
 #pragma unroll
     for (int k = 0; k < kAcc; ++k) a[k] = 0.0;
     if (mine) {
-        a[17] = 1.0;
+        a[17] = changed ? 1.0 + kChangedUnit : 1.0;
         if (matched) {
             const double px = qx, py = qy, pz = qz, tx = bqx, ty = bqy, tz = bqz;
             a[0] = 1.0;
@@ -1061,7 +1113,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
     if constexpr (STATS >= 0) {
         double a[kAcc];
         icp_terms<STATS>(a, mine, (unsigned) best != kNoIdx, qx, qy, qz, bqx, bqy, bqz,
-                         __uint_as_float((unsigned) (best >> 32)));
+                         __uint_as_float((unsigned) (best >> 32)), (unsigned) best != (unsigned) seeded);
         acc_halve<kAcc, 32>(a, lane);
         const int comp = acc_comp_of_lane(lane);
         if (comp >= 0) st_f64(&partials[(size_t) row * kAcc + comp], a[0], nt);
@@ -1299,6 +1351,9 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
     for (int w = 0; w < kCertWaves; ++w) cum[w + 1] = cum[w] + s_cnt[w];
     unsigned U = cum[kCertWaves];
     if (uns_count && threadIdx.x == 0 && U) atomicAdd(&uns_count[blockIdx.x & 63u], U);  // developer statistics
+    // how many queries this launch had to search: the solve kernel hands it to the host (one atomic per
+    // workgroup, spread over 64 words)
+    if (threadIdx.x == 0 && U) atomicAdd(&st->cert_unsettled[blockIdx.x & 63u], U);
     if (dbg_skip == 1u && valid) U = 0;
     const unsigned nchunks = (U + 63u) / 64u;
     unsigned cost = 0;
@@ -1437,7 +1492,8 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
             }
         }
         if (c == wave) WM_STAMP(5);  // first chunk: pass loop done
-        // cooperative phase for radii beyond r_light (k_nn_grid's; no bound comes out of it)
+        // cooperative phase for radii beyond r_light (k_nn_grid's), with the runner-up tracked as well: the
+        // ball scanned is the query's whole search ball, so the bound is min(runner-up, margin of the last box)
         unsigned long long todo = __ballot(heavy);
         float seed = 0.f;
         while (todo) {
@@ -1447,13 +1503,17 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
             float ur = rl_f(r, sl);
             unsigned long long ub = ((unsigned long long) rl_u((unsigned) (best >> 32), sl) << 32) |
                                     rl_u((unsigned) best, sl);
+            unsigned usec = 0x7F800000u;
+            float umargin = 0.f;
+            const float upad = rl_f(pad, sl);
             if ((unsigned) ub == kNoIdx && seed > ur) ur = fminf(seed, rmax);
             for (int pass = 0; pass < 64; ++pass) {
                 int l = 0;
                 while (l < Ln - 1 && lv->g[l].h < coop_lf * ur) ++l;
                 const GridDev g = lv->g[l];
                 float margin;
-                ub = coop_scan_box(g, ux, uy, uz, ur, ub, lane, &margin);
+                ub = coop_scan_box(g, ux, uy, uz, ur, ub, lane, &margin, &usec, upad);
+                umargin = margin;
                 const float bd2 = __uint_as_float((unsigned) (ub >> 32));
                 if (margin > 0.f && (bd2 <= margin * margin || thr_d2 <= margin * margin)) break;
                 if (ur >= rmax) break;
@@ -1463,7 +1523,11 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
             seed = ((unsigned) ub != kNoIdx) ? 1.25f * sqrtf(__uint_as_float((unsigned) (ub >> 32))) : ur;
             if ((int) lane == sl) {
                 best = ub;
-                bnd.ok = false;
+                // (a scan cuts its rows to the chord of ball(q, best at its entry + pad): what it skipped is
+                // farther than that, hence farther than the final best + pad)
+                bnd.second = usec;
+                margin_last = umargin;
+                heavy = false;
             }
         }
         asm volatile("" ::: "memory");
@@ -1503,7 +1567,7 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
         if constexpr (STATS >= 0) {
             double a[kAcc];
             icp_terms<STATS>(a, mine, (unsigned) best != kNoIdx, qx, qy, qz, bqx, bqy, bqz,
-                             __uint_as_float((unsigned) (best >> 32)));
+                             __uint_as_float((unsigned) (best >> 32)), (unsigned) best != (unsigned) seeded);
             acc_halve<kAcc, 32>(a, lane);
             rowacc += comp >= 0 ? a[0] : 0.0;
         }
