@@ -1,0 +1,33 @@
+"""GICP 500k<->500k (BASELINE configs[2]): ms per registration, evaluations, result."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np
+import torch
+
+from libwave_amd import capi, synth
+
+n = int(os.environ.get("GICP_POINTS", "500000"))
+ref, tgt, T_gt = synth.pair(n, seed=42)
+d_ref, d_tgt = torch.from_numpy(ref).cuda(), torch.from_numpy(tgt).cuda()
+res = {}
+for posted in (0, 0):
+    ctx = capi.Context(0)
+
+    def run():
+        ctx.set_source(d_ref)
+        ctx.set_target(d_tgt)
+        return ctx.gicp_align()
+    run()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        r = run()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    print("run %d: %.3f ms/registration (min %.3f), %d outer / %d inner iterations, %d evaluations, f %.17g, |t - t_gt| %.2e" % (
+        posted, np.median(ts), min(ts), r["iterations"], r["inner_total"], r["evaluations"], r["f"],
+        np.linalg.norm(r["T"][:3, 3] - T_gt[:3, 3])), flush=True)
+    res.setdefault(posted, r)
+    ctx.close()

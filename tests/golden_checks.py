@@ -45,3 +45,15 @@ def check_ndt_derivatives(case, derivs):
         assert abs(D[4, 4] - want) <= 2e-4 * max(abs(want), 1e-9 * np.abs(HH).max()) + 1e-9 * np.abs(HH).max()
         D[4, 4] = 0
         assert np.abs(D).max() <= 1e-9 * np.abs(HH).max() and s1 == s and np.array_equal(g1, g)
+
+
+def noisy_filtered_pair(scan, case):
+    """The pair of GOLD["gicp"]["noisyFiltered"] (make_golden_gicp_ndt.py): the scan against a copy moved by
+    case["P"] and re-measured with Gaussian noise of a fixed seed -- regenerated here, checked against
+    the checksum the generator recorded."""
+    P = np.array(case["P"])
+    rng = np.random.Generator(np.random.PCG64(case["noise_seed"]))
+    moved = (scan.astype(np.float64) @ P[:3, :3].T + P[:3, 3]).astype(np.float32)
+    noisy = (moved.astype(np.float64) + rng.normal(0.0, case["noise_sigma"], scan.shape)).astype(np.float32)
+    assert abs(float(np.abs(noisy.astype(np.float64)).sum()) - case["target_checksum"]) <= 1e-9 * case["target_checksum"]
+    return noisy, P

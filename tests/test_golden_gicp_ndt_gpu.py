@@ -31,7 +31,7 @@ def test_hip_ndt_reaches_the_independent_optimum(wm, ctx, testscan, name):
     assert dt <= 1e-4 and ang <= 1e-4, (dt, ang)
 
 
-@pytest.mark.parametrize("name", sorted(GOLD["gicp"]))
+@pytest.mark.parametrize("name", [n for n in sorted(GOLD["gicp"]) if "probe" in GOLD["gicp"][n]])
 def test_hip_gicp_pieces_and_fixed_point(wm, ctx, testscan, name):
     c = GOLD["gicp"][name]
     target, P = G.shifted(testscan, c["tx"])
@@ -56,3 +56,26 @@ def test_hip_gicp_pieces_and_fixed_point(wm, ctx, testscan, name):
     assert got["rc"] == 0 and np.linalg.norm(got["T"] - P) < 0.1
     dt, ang = G.pose_err(got["T"], c["fixed_point_T"])
     assert dt <= 1e-4 and ang <= 1e-4, (dt, ang)
+
+
+def test_hip_gicp_on_the_noisy_filtered_pair(wm, ctx, testscan):
+    """As the oracle's test: wm_gicp_match with the voxel filter on the noisy pair, against the independent
+    fixed point at the documented millimetre spread of PCL's early-stopping BFGS."""
+    c = GOLD["gicp"]["noisyFiltered"]
+    noisy, P = G.noisy_filtered_pair(testscan, c)
+    got = ctx.gicp_match(testscan, noisy, res=c["res"])
+    assert got["rc"] == 0 and got["n_corr"] == c["n_ref"] and np.linalg.norm(got["T"] - P) < 0.1
+    dt, ang = G.pose_err(got["T"], c["fixed_point_T"])
+    assert dt <= 3e-3 and ang <= 1e-3, (dt, ang)
+
+
+def test_hip_ndt_pcl18_rule_takes_the_independent_newton_steps(wm, ctx, testscan):
+    c = GOLD["ndt"]["smallDisplacement"]
+    target, _ = G.shifted(testscan, c["tx"])
+    ctx.set_source(testscan)
+    ctx.set_target(target)
+    steps = c["pcl18_newton_steps"]
+    got = ctx.ndt_align(res=c["res"], step_size=3, max_iter=1, t_eps=1e-8, skip_line_search=1)
+    assert got["rc"] == 0 and got["iterations"] == 3
+    dt, ang = G.pose_err(got["T"], steps[2]["T"])
+    assert dt <= 2e-4 and ang <= 2e-4, (dt, ang)

@@ -91,3 +91,27 @@ def test_match_failure_leaves_result_untouched(wm, ctx):
     a = synth.scene(2000, seed=1)
     got = ctx.icp_match(a, a + np.float32(100.0), res=0.5, multiscale_steps=1)
     assert got["rc"] == wm.WM_TOO_FEW and got["T"] is None
+
+
+@pytest.mark.parametrize("case", ["smallDisplacement", "multiscale"])
+def test_information_matrices_after_match_against_golden(wm, ctx, oracle, testscan, case):
+    """match() + estimateLUM / estimateLUMold on the device against the independent numpy vectors
+    (tests/golden/icp_golden.json: info_lum / info_lumold, made by make_golden.py's lum_info) for the
+    voxel-filtered and the multiscale branch.  The residual s^2 of these exact-copy cases is pure
+    rounding noise (1e-9): the reference sums it as a sequential float, the kernel adds the same float
+    terms in double -- hence 1e-3 on the matrix, exact on its structure (M'M itself to 1e-9)."""
+    res, steps, tx = CASES[case]
+    with open(os.path.join(HERE, "golden", "icp_golden.json")) as f:
+        gold = json.load(f)["cases"][case]
+    perturb = np.eye(4)
+    perturb[0, 3] = tx
+    target = oracle.transform_cloud_d(testscan, perturb)
+    got = ctx.icp_match(testscan, target, res=res, multiscale_steps=steps)
+    assert got["rc"] == 0
+    for method, key in ((wm.WM_INFO_LUM, "info_lum"), (wm.WM_INFO_LUMOLD, "info_lumold")):
+        rc, info, deg = ctx.icp_info(method, got["T"], max_corr=3.0)
+        want = np.array(gold[key]["M"])
+        assert rc == 0 and not deg and info[0, 0] > 0
+        np.testing.assert_allclose(info, want, rtol=1e-3, atol=1e-9 * np.abs(want).max())
+        # s^2 cancels in the ratio of two entries: the normal equations themselves agree to 1e-9
+        np.testing.assert_allclose(info / info[0, 0], want / want[0, 0], rtol=1e-7, atol=1e-9)

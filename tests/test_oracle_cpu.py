@@ -257,3 +257,24 @@ def test_ndt_pcl18_literal_mode_meets_the_reference_test(oracle, testscan):
     # the default (More-Thuente runs) converges properly, by the step-size rule
     d = oracle.ndt_align(testscan, tgt, res=0.3, step_size=3.0, max_iter=100, t_eps=1e-8)
     assert d["converged"] and d["iterations"] < 30 and np.linalg.norm(d["T"] - P) < 1e-3
+
+
+@pytest.mark.parametrize("case", ["smallDisplacement", "fullResSmallDisplacement", "multiscale"])
+def test_information_matrices_match_golden(oracle, testscan, golden, case):
+    """estimateLUM / estimateLUMold after match() -- voxel-filtered, full-resolution and the multiscale
+    branch (icp.cpp:77-122, icp_pcl_functions.cpp:51-289) -- against the independent numpy restatement
+    (tests/golden/make_golden.py: lum_info): float pair averages and differences, double normal
+    equations, the residual as a sequential float sum."""
+    c = golden["cases"][case]
+    perturb = np.eye(4)
+    perturb[0, 3] = c["tx"]
+    target = oracle.transform_cloud_d(testscan, perturb)
+    m = oracle.IcpMatch(testscan, target, res=c["res"], multiscale_steps=c["multiscale_steps"], incremental_float=0)
+    assert m.ok
+    lum, rc1 = m.lum()
+    old, rc2 = m.lumold(3.0)
+    for got, key in ((lum, "info_lum"), (old, "info_lumold")):
+        want = np.array(c[key]["M"])
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12 * np.abs(want).max())
+        assert got[0, 0] > 0                                        # icp_tests.cpp:124
+    assert np.linalg.norm(old - lum) < 0.01 * np.linalg.norm(lum)   # icp_tests.cpp:192-194 (relative here)
