@@ -206,7 +206,11 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu):
          "roofline": {"bound": "hbm", "kernel": "wm::k_gicp_fdf (objective + gradient, one per BFGS evaluation)",
                       "achieved": bytes_eval / (us * 1e-6) / 1e9 if us > 0 else None, "peak": HBM_PEAK_GBS,
                       "unit": "GB/s", "frac": bytes_eval / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us > 0 else None,
-                      "algorithmic_bytes_per_launch": bytes_eval, "avg_launch_us": us, "launches_timed": ev}}
+                      "algorithmic_bytes_per_launch": bytes_eval, "avg_launch_us": us, "launches_timed": ev,
+                      # SURVEY 8(d)'s accounting of one objective evaluation: 12N + 4N + 12N (gather) + 24N = 52 B x n
+                      # (float upper-triangle matrices; this kernel reads 72-B double 3x3s and a 16-B packed match)
+                      "survey_bytes_per_launch": 52.0 * n,
+                      "frac_survey_bytes": 52.0 * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us > 0 else None}}
     if with_cpu:
         from oracle import oracle_py as O
         m = 20_000

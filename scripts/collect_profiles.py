@@ -35,7 +35,7 @@ for f in sorted(glob.glob(os.path.join(src, tag + "_detail", "*_per_dispatch.csv
         tabs.setdefault(int(r["iteration"]), {}).update({k: float(v) for k, v in r.items() if k != "iteration"})
 if tabs:
     cols = sorted(tabs[0].keys())
-    path = os.path.join(dst, tag + "_pmc_k_nn_grid_per_iteration.csv")
+    path = os.path.join(dst, tag + "_pmc_search_per_iteration.csv")
     with open(path, "w") as f:
         f.write("iteration," + ",".join(cols) + "\n")
         for i in sorted(tabs):

@@ -33,8 +33,11 @@ for name in ("sq1", "sq2", "sq3", "ta1", "ta2", "tcp1", "tcp2", "tlb"):
         print(name, "missing"); continue
     per = collections.OrderedDict()
     for row in csv.DictReader(open(path)):
-        if "k_nn_grid" not in row["Kernel_Name"]: continue
-        per.setdefault(int(row["Dispatch_Id"]), {})[row["Counter_Name"]] = float(row["Counter_Value"])
+        kn = row["Kernel_Name"]
+        if "k_nn_grid" not in kn and "k_nn_cert" not in kn: continue   # the two kernels of the correspondence step
+        d = per.setdefault(int(row["Dispatch_Id"]), {})
+        d[row["Counter_Name"]] = float(row["Counter_Value"])
+        d["is_cert"] = 1.0 if "k_nn_cert" in kn else 0.0
     ids = sorted(per)[-50:]  # the last registration
     names = sorted(per[ids[0]]) if ids else []
     with open(os.path.join(out, name + "_per_dispatch.csv"), "w") as f:
