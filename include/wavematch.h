@@ -321,6 +321,7 @@ typedef struct {
     int converged, iterations, n_corr, inner_total, evaluations;
     double f_final;
     float fdf_kernel_ms; /* summed device time of the objective/gradient kernel */
+    int served_evaluations; /* of `evaluations`: answered by the resident evaluator (no kernel launch each) */
 } wm_gicp_stats;
 
 void wm_gicp_default_params(wm_gicp_params *p);

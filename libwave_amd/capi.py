@@ -64,7 +64,7 @@ class GicpParams(C.Structure):
 class GicpStats(C.Structure):
     _fields_ = [("converged", C.c_int), ("iterations", C.c_int), ("n_corr", C.c_int),
                 ("inner_total", C.c_int), ("evaluations", C.c_int), ("f_final", C.c_double),
-                ("fdf_kernel_ms", C.c_float)]
+                ("fdf_kernel_ms", C.c_float), ("served_evaluations", C.c_int)]
 
 
 class NdtParams(C.Structure):
@@ -465,7 +465,8 @@ class Context:
     def _gicp_dict(rc, T, s):
         return dict(rc=rc, T=T if rc == WM_OK else None, converged=bool(s.converged),
                     iterations=s.iterations, n_corr=s.n_corr, inner_total=s.inner_total,
-                    evaluations=s.evaluations, f=s.f_final, fdf_kernel_ms=s.fdf_kernel_ms)
+                    evaluations=s.evaluations, f=s.f_final, fdf_kernel_ms=s.fdf_kernel_ms,
+                    served_evaluations=s.served_evaluations)
 
     def gicp_align(self, params=None, **kw):
         p = params or gicp_params(**kw)

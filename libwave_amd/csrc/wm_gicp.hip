@@ -14,9 +14,12 @@
 #include "wm_internal.hpp"
 
 #include <float.h>
+#include <stddef.h>
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
+#include <chrono>
 #include <vector>
 
 namespace wm {
@@ -308,11 +311,13 @@ __device__ __forceinline__ int dd_comp_of_lane(unsigned lane) {
 }
 
 // a[0] = sum r^T M r, a[1..3] = sum M r, a[4..12] = sum p_base (M r)^T; count separately.
-// partials: [block][kGicpAcc][2] = (hi, lo) pairs
-__global__ void __launch_bounds__(kBlock)
-    k_gicp_fdf(const float4 *__restrict__ src, unsigned n,
-               const unsigned long long *__restrict__ keys, const float4 *__restrict__ tgt,
-               const double *__restrict__ mahal, FdfArgs A, double *__restrict__ partials) {
+// partials: [block][kGicpAcc][2] = (hi, lo) pairs.  The workgroup's share of one evaluation
+// (all threads of the workgroup call it: it ends with a barrier and the row's store).
+template <bool COHERENT>
+__device__ __forceinline__ void gicp_fdf_block(const float4 *__restrict__ src, unsigned n,
+                                               const unsigned long long *__restrict__ keys,
+                                               const float4 *__restrict__ tgt, const double *__restrict__ mahal,
+                                               const FdfArgs &A, double *__restrict__ partials) {
     double hi[kGicpAcc], lo[kGicpAcc];
 #pragma unroll
     for (int k = 0; k < kGicpAcc; ++k) hi[k] = lo[k] = 0.0;
@@ -363,34 +368,209 @@ __global__ void __launch_bounds__(kBlock)
             dd_add(h, l, lds[w][threadIdx.x][0]);
             l += lds[w][threadIdx.x][1];
         }
-        partials[((size_t) blockIdx.x * kGicpAcc + threadIdx.x) * 2] = h;
-        partials[((size_t) blockIdx.x * kGicpAcc + threadIdx.x) * 2 + 1] = l;
+        double *row = partials + ((size_t) blockIdx.x * kGicpAcc + threadIdx.x) * 2;
+        if constexpr (COHERENT) {
+            // read by another workgroup of the SAME kernel: written through to where every XCD sees it
+            __hip_atomic_store(row, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(row + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            row[0] = h;
+            row[1] = l;
+        }
     }
 }
 
-// The block pairs -> kGicpAcc doubles in pinned memory: one wave per sum adds the rows' (hi, lo)
-// pairs in double-double, lane 0 rounds hi + lo once; then the fence + flag of fast_fetch.
-__global__ void __launch_bounds__(1024)
-    k_gicp_sum_fetch(double *dst, const double *__restrict__ src, unsigned rows, unsigned *flag, unsigned seq) {
-    const unsigned c = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    if (c < (unsigned) kGicpAcc) {
+__global__ void __launch_bounds__(kBlock)
+    k_gicp_fdf(const float4 *__restrict__ src, unsigned n,
+               const unsigned long long *__restrict__ keys, const float4 *__restrict__ tgt,
+               const double *__restrict__ mahal, FdfArgs A, double *__restrict__ partials) {
+    gicp_fdf_block<false>(src, n, keys, tgt, mahal, A, partials);
+}
+
+// The block rows -> the thirteen sums, by ONE workgroup of kBlock threads (the last workgroup of the
+// served evaluator, or k_gicp_sum_fetch behind a launched evaluation: the same code, the same order
+// of addition, the same bits).  The rows' (hi, lo) pairs are one contiguous array of rows x 13
+// 16-byte pairs; thread t < 247 = 19 x 13 adds pairs t, t + 247, t + 494, ... (component t % 13, rows
+// t / 13 + 19 m) in double-double -- consecutive lanes read consecutive pairs, a dozen cache lines per
+// wave instruction instead of 64 --, then thread c < 13 adds the 19 partial pairs of component c in
+// order and rounds hi + lo once.  Returns the sum in threads 0..12 (every thread must call).
+// COHERENT: the rows were written by other workgroups of the SAME kernel (write-through stores): they
+// are read at agent scope (sc1), past whatever stale lines this XCD's L2 may hold.
+constexpr int kGicpSumGroups = kBlock / kGicpAcc;  // 19
+typedef double gicp_d2v __attribute__((ext_vector_type(2)));
+template <bool COHERENT>
+__device__ __forceinline__ double gicp_sum_rows(const double *__restrict__ src, unsigned rows) {
+    __shared__ double s_h[kGicpSumGroups][kGicpAcc], s_l[kGicpSumGroups][kGicpAcc];
+    constexpr unsigned S = (unsigned) (kGicpSumGroups * kGicpAcc);
+    const unsigned t = threadIdx.x, total = rows * (unsigned) kGicpAcc;
+    if (t < S) {
         double h = 0, l = 0;
-        for (unsigned r = lane; r < rows; r += 64u) {
-            dd_add(h, l, src[((size_t) r * kGicpAcc + c) * 2]);
-            l += src[((size_t) r * kGicpAcc + c) * 2 + 1];
-        }
+        constexpr int U = 8;  // (the asm statement below is written for eight)
+        for (unsigned e0 = t; e0 < total; e0 += U * S) {
+            gicp_d2v v[U];
+            const gicp_d2v *p[U];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double h2 = __shfl_down(h, off), l2 = __shfl_down(l, off);
-            dd_add(h, l, h2);
-            l += l2;
+            for (int u = 0; u < U; ++u) {
+                const unsigned e = e0 + (unsigned) u * S;
+                p[u] = (const gicp_d2v *) src + (e < total ? e : 0u);
+            }
+            if constexpr (COHERENT) {
+                // (eight loads and the wait for them in ONE statement: the compiler must not touch the
+                // destination registers of an asynchronous load it knows nothing about before the wait)
+                asm volatile(
+                    "global_load_dwordx4 %0, %8, off sc1\n\t"
+                    "global_load_dwordx4 %1, %9, off sc1\n\t"
+                    "global_load_dwordx4 %2, %10, off sc1\n\t"
+                    "global_load_dwordx4 %3, %11, off sc1\n\t"
+                    "global_load_dwordx4 %4, %12, off sc1\n\t"
+                    "global_load_dwordx4 %5, %13, off sc1\n\t"
+                    "global_load_dwordx4 %6, %14, off sc1\n\t"
+                    "global_load_dwordx4 %7, %15, off sc1\n\t"
+                    "s_waitcnt vmcnt(0)"
+                    : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                    : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+                    : "memory");
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = *p[u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (e0 + (unsigned) u * S < total) {
+                    dd_add(h, l, v[u].x);
+                    l += v[u].y;
+                }
         }
-        if (lane == 0) dst[c] = h + l;
+        s_h[t / kGicpAcc][t % kGicpAcc] = h;
+        s_l[t / kGicpAcc][t % kGicpAcc] = l;
     }
     __syncthreads();
+    double out = 0.0;
+    if (t < (unsigned) kGicpAcc) {
+        double h = 0, l = 0;
+#pragma unroll
+        for (int g = 0; g < kGicpSumGroups; ++g) {
+            dd_add(h, l, s_h[g][t]);
+            l += s_l[g][t];
+        }
+        out = h + l;
+    }
+    __syncthreads();  // (the arrays may be used again by the next round)
+    return out;
+}
+
+// The block pairs -> kGicpAcc doubles in pinned memory, then the fence + flag of fast_fetch.
+__global__ void __launch_bounds__(kBlock)
+    k_gicp_sum_fetch(double *dst, const double *__restrict__ src, unsigned rows, unsigned *flag, unsigned seq) {
+    const double v = gicp_sum_rows<false>(src, rows);
+    if (threadIdx.x < (unsigned) kGicpAcc) dst[threadIdx.x] = v;
     if (threadIdx.x < 64) {
         __threadfence_system();
         if (threadIdx.x == 0) *(volatile unsigned *) flag = seq;
+    }
+}
+
+// ---- served evaluations.  One BFGS minimisation asks for ~20 evaluations of the objective, each at
+// a point that depends on the previous answer, and the optimiser stays on the host (its libm calls
+// are part of what has to match PCL bit for bit).  Launching a kernel pair per evaluation costs
+// ~15 us of launch + completion latency against ~14 us of work.  Instead ONE kernel stays resident
+// for the whole minimisation: its workgroups wait for the next trial point in a mailbox in DEVICE
+// memory, which the host writes straight through the PCIe BAR (a posted write: the kernel sees it
+// ~1 us later; polling costs the GPU nothing but its own memory), evaluate exactly as k_gicp_fdf
+// does, and the workgroup that finishes last adds the rows exactly as k_gicp_sum_fetch does and
+// writes the thirteen sums + flag into pinned host memory.  Same partial rows, same order of
+// addition: the same bits.  The kernel leaves when told to, or by itself when no command arrives
+// for kServeGuardTicks (a host that died or was descheduled: the host side then falls back to
+// launching, see gicp_fdf).
+struct GicpMailbox {
+    float T[12], B[12];   // FdfArgs of the evaluation
+    unsigned cmd;         // 1: evaluate, 2: leave
+    unsigned seq;         // command number (written last); the words above belong to it
+    unsigned abandoned;   // the kernel gave up waiting (set by the device)
+    unsigned pad[5];
+};
+struct alignas(16) GicpSlot {  // pinned host memory: one of the thirteen sums + the command it belongs to
+    double v;
+    unsigned long long seq;
+};
+constexpr unsigned long long kServeGuardTicks = 20000000ull;  // 0.2 s of the 100 MHz wall clock
+
+__device__ __forceinline__ unsigned ld_sys(const unsigned *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_gicp_fdf_served(const float4 *__restrict__ src, unsigned n, const unsigned long long *__restrict__ keys,
+                      const float4 *__restrict__ tgt, const double *__restrict__ mahal, GicpMailbox *mb,
+                      unsigned first_seq, double *__restrict__ partials, unsigned *ticket, GicpSlot *h_slots,
+                      unsigned long long *dbg) {
+    __shared__ float s_args[24];
+    __shared__ unsigned s_cmd, s_last;
+    for (unsigned seq = first_seq;; ++seq) {
+        if (threadIdx.x < 64) {
+            bool ok = true;
+            if (threadIdx.x == 0) {
+                const unsigned long long t0 = wall_clock64();
+                // (one look every ~0.5 us per workgroup: hundreds of workgroups looking as fast as they can
+                // keep the memory channel of that one line so busy that the stragglers of the evaluation
+                // under way, and the next command's arrival, are delayed by tens of microseconds)
+                while (ld_sys(&mb->seq) != seq) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (wall_clock64() - t0 > kServeGuardTicks) {
+                        ok = false;
+                        break;
+                    }
+                }
+                if (!ok) __hip_atomic_store(&mb->abandoned, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            ok = __builtin_amdgcn_readfirstlane((int) ok) != 0;
+            if (threadIdx.x < 24)
+                s_args[threadIdx.x] = __uint_as_float(ld_sys((const unsigned *) mb->T + threadIdx.x));  // (T and B are adjacent)
+            if (threadIdx.x == 24) s_cmd = ok ? ld_sys(&mb->cmd) : 2u;
+        }
+        __syncthreads();
+        if (s_cmd != 1u) return;  // (uniform)
+        const unsigned round = seq - first_seq;
+        if (dbg && blockIdx.x == 0 && threadIdx.x == 0 && round < 64u) dbg[round * 4 + 0] = wall_clock64();
+        FdfArgs A;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            A.T[k] = __uint_as_float((unsigned) __builtin_amdgcn_readfirstlane((int) __float_as_uint(s_args[k])));
+            A.B[k] = __uint_as_float((unsigned) __builtin_amdgcn_readfirstlane((int) __float_as_uint(s_args[12 + k])));
+        }
+        gicp_fdf_block<true>(src, n, keys, tgt, mahal, A, partials);
+        if (dbg && blockIdx.x == 0 && threadIdx.x == 0 && round < 64u) dbg[round * 4 + 1] = wall_clock64();
+        // The row is out (write-through stores): wait until they have been performed, then take a
+        // ticket; whoever draws the last one adds the rows up, reading them at agent scope.  No
+        // agent-scope FENCE on either side: a release fence writes the XCD's whole L2 back, and 32
+        // workgroups per XCD doing that one after the other took longer than the evaluation (17 us).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = t == gridDim.x - 1u ? 1u : 0u;
+        }
+        __syncthreads();
+        if (s_last) {
+            if (dbg && threadIdx.x == 0 && round < 64u) dbg[round * 4 + 2] = wall_clock64();
+            // (every workgroup has drawn its ticket: the counter can go back to 0 for the next round)
+            if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double v = gicp_sum_rows<true>(partials, gridDim.x);
+            if (threadIdx.x < (unsigned) kGicpAcc) {
+                // the sum and the number of the command it answers in ONE 16-byte store to pinned host
+                // memory: the host takes a slot once it carries the number it waits for -- no flag
+                // behind the data, hence no system-scope fence (an L2 write-back: ~5 us) before one.
+                // (written through at system scope -- sc0 sc1 --, as an atomic store would be; there is no
+                // 16-byte atomic store to ask the compiler for)
+                typedef unsigned u4v __attribute__((ext_vector_type(4)));
+                const unsigned long long vb = (unsigned long long) __double_as_longlong(v);
+                const u4v out = {(unsigned) vb, (unsigned) (vb >> 32), seq, 0u};
+                GicpSlot *dst = &h_slots[threadIdx.x];
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(out) : "memory");
+            }
+            if (dbg && threadIdx.x == 0 && round < 64u) dbg[round * 4 + 3] = wall_clock64();
+        }
     }
 }
 
@@ -488,7 +668,130 @@ struct GicpFn {
     int evals = 0;
     float kernel_ms = 0;
     int rc = WM_OK;
+    // served evaluations (k_gicp_fdf_served resident for the minimisation under way)
+    bool served = false;
+    unsigned served_evals = 0;
+    int served_total = 0, served_fallbacks = 0;
+    double host_us[64] = {0};
 };
+
+// one served evaluator per device and process at a time: two resident kernels that each hold part of
+// the GPU while waiting for their hosts would keep each other's remaining workgroups from starting
+static std::atomic<int> g_serving[64];
+
+static int gicp_blocks(const wm_ctx *ctx) {
+    int nb = (int) ((ctx->n_src + kBlock - 1) / kBlock);
+    if (nb > ctx->tune_gicp_blocks) nb = ctx->tune_gicp_blocks;
+    if (nb < 1) nb = 1;
+    return nb;
+}
+
+static void serve_post(wm_ctx *ctx, const FdfArgs *A, unsigned cmd) {
+    // plain stores into device memory through the BAR; the command number goes last, behind a store fence
+    // (16-byte stores: every store into this mapping is a PCIe write of its own, ~0.1 us each)
+    volatile GicpMailbox *mb = (volatile GicpMailbox *) ctx->gicp_mailbox.p;
+    typedef float v4f __attribute__((vector_size(16)));
+    if (A) {
+        static_assert(sizeof(FdfArgs) == 96 && offsetof(GicpMailbox, T) == 0 && offsetof(GicpMailbox, B) == 48, "layout");
+        v4f w[6];
+        memcpy(w, A, sizeof(w));
+        for (int k = 0; k < 6; ++k) ((volatile v4f *) mb)[k] = w[k];
+    }
+    mb->cmd = cmd;
+    __sync_synchronize();
+    mb->seq = ++ctx->gicp_serve_seq;
+    __sync_synchronize();
+}
+
+// start the resident evaluator for one minimisation (quietly not, when it cannot be used here)
+static void serve_begin(GicpFn &F) {
+    wm_ctx *ctx = F.ctx;
+    F.served = false;
+    if (!ctx->tune_gicp_served || ctx->gicp_profile || getenv("WM_GICP_TRACE")) return;
+    if (ctx->device < 0 || ctx->device >= 64) return;
+    if (ctx->gicp_serve_ok < 0) return;
+    if (ctx->gicp_serve_ok == 0) {  // first use: is device memory host-writable, and does the grid fit?
+        ctx->gicp_serve_ok = -1;
+        int large_bar = 0, cus = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->device) != hipSuccess || !large_bar) return;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) return;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gicp_fdf_served, kBlock, 0) != hipSuccess) return;
+        ctx->gicp_serve_capacity = cus * per_cu;
+        if (ctx->gicp_mailbox.reserve(4096) != hipSuccess) return;
+        if (hipMemsetAsync(ctx->gicp_mailbox.p, 0, 4096, ctx->stream) != hipSuccess) return;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return;
+        ctx->gicp_serve_seq = 0;
+        ctx->gicp_serve_ok = 1;
+    }
+    const int nb = gicp_blocks(ctx);
+    if (nb > ctx->gicp_serve_capacity) return;  // every workgroup has to be resident at once
+    if (!ctx->h_gicp && hipHostMalloc((void **) &ctx->h_gicp, sizeof(double) * 64, hipHostMallocDefault) != hipSuccess) return;
+    if (!ctx->h_gicp_slots) {
+        if (hipHostMalloc((void **) &ctx->h_gicp_slots, sizeof(GicpSlot) * 16, hipHostMallocDefault) != hipSuccess) return;
+        memset(ctx->h_gicp_slots, 0, sizeof(GicpSlot) * 16);
+    }
+    int expected = 0;
+    if (!g_serving[ctx->device].compare_exchange_strong(expected, 1)) return;
+    F.served_evals = 0;
+    unsigned *ticket = (unsigned *) ((char *) ctx->gicp_mailbox.p + sizeof(GicpMailbox));
+    hipLaunchKernelGGL(k_gicp_fdf_served, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->src_sorted.as<float4>(),
+                       (unsigned) ctx->n_src, ctx->keys.as<unsigned long long>(), ctx->match_pt.as<float4>(),
+                       ctx->gicp_mahal.as<double>(), (GicpMailbox *) ctx->gicp_mailbox.p, ctx->gicp_serve_seq + 1u,
+                       ctx->partials.as<double>(), ticket, (GicpSlot *) ctx->h_gicp_slots,
+                       getenv("WM_GICP_SERVE_DEBUG") ? (unsigned long long *) ((char *) ctx->gicp_mailbox.p + 256) : nullptr);
+    if (hipGetLastError() != hipSuccess) {
+        g_serving[ctx->device].store(0);
+        return;
+    }
+    F.served = true;
+}
+
+// tell the evaluator to leave and wait until it has (also after a failure: nothing of it may be
+// left on the stream when the next kernels are queued)
+static void serve_end(GicpFn &F) {
+    if (!F.served) return;
+    wm_ctx *ctx = F.ctx;
+    serve_post(ctx, nullptr, 2u);
+    (void) hipStreamSynchronize(ctx->stream);
+    if (getenv("WM_GICP_SERVE_DEBUG")) {  // developer: device-side stamps of the first rounds (100 MHz ticks)
+        unsigned long long d[64 * 4];
+        if (hipMemcpy(d, (char *) ctx->gicp_mailbox.p + 256, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess) {
+            for (unsigned r = 0; r < F.served_evals && r < 24; ++r)
+                fprintf(stderr, "  round %2u: seen->computed %6.2f us, computed->last arrives %6.2f us, sum+reply %6.2f us | since previous reply %6.2f us | host: post->answer %6.2f us\n",
+                        r, (d[r * 4 + 1] - d[r * 4]) * 0.01, ((long long) d[r * 4 + 2] - (long long) d[r * 4 + 1]) * 0.01,
+                        (d[r * 4 + 3] - d[r * 4 + 2]) * 0.01, r ? ((long long) d[r * 4] - (long long) d[(r - 1) * 4 + 3]) * 0.01 : 0.0,
+                        r < 64 ? F.host_us[r] : 0.0);
+        }
+    }
+    F.served = false;
+    g_serving[ctx->device].store(0);
+}
+
+// one served evaluation; false: no answer (the evaluator gave up or is stuck) -> it has been shut down
+static bool serve_eval(GicpFn &F, const FdfArgs &A) {
+    wm_ctx *ctx = F.ctx;
+    const auto t0 = std::chrono::steady_clock::now();
+    serve_post(ctx, &A, 1u);
+    const unsigned long long expect = ctx->gicp_serve_seq;
+    volatile GicpSlot *slots = (volatile GicpSlot *) ctx->h_gicp_slots;
+    int have = 0;  // slots 0 .. have - 1 carry this command's number
+    for (unsigned spins = 1; have < kGicpAcc; ++spins) {
+        while (have < kGicpAcc && slots[have].seq == expect) ++have;
+        if (have == kGicpAcc) break;
+        __builtin_ia32_pause();
+        if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(100)) {
+            serve_end(F);  // (waits for the kernel: it leaves on the command, or by its own guard)
+            F.served_fallbacks++;
+            return false;
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    for (int k = 0; k < kGicpAcc; ++k) ctx->h_gicp[k] = slots[k].v;
+    if (F.served_evals < 64) F.host_us[F.served_evals] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    F.served_evals++;
+    F.served_total++;
+    return true;
+}
 
 static double gicp_fdf(GicpFn &F, const double x[6], double g[6]) {
     wm_ctx *ctx = F.ctx;
@@ -500,9 +803,7 @@ static double gicp_fdf(GicpFn &F, const double x[6], double g[6]) {
         A.B[k] = (float) F.base[k];
     }
     const unsigned n = (unsigned) ctx->n_src;
-    int nb = (int) ((n + kBlock - 1) / kBlock);
-    if (nb > ctx->tune_gicp_blocks) nb = ctx->tune_gicp_blocks;
-    if (nb < 1) nb = 1;
+    const int nb = gicp_blocks(ctx);
     // The block partials stay in device memory; one workgroup adds them up and writes the
     // kGicpAcc sums into pinned memory (fast_fetch_sum): no copy engine, no pageable staging,
     // 104 bytes over PCIe -- this loop runs ~180 times per registration and is latency-bound.
@@ -513,17 +814,19 @@ static double gicp_fdf(GicpFn &F, const double x[6], double g[6]) {
         ctx->last_error = "gicp_fdf: hipHostMalloc failed";
         return 0;
     }
-    if (ctx->gicp_profile) (void) hipEventRecord(ctx->ev_a, ctx->stream);
-    hipLaunchKernelGGL(k_gicp_fdf, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->src_sorted.as<float4>(),
-                       n, ctx->keys.as<unsigned long long>(), ctx->match_pt.as<float4>(),
-                       ctx->gicp_mahal.as<double>(), A, ctx->partials.as<double>());
-    if (ctx->gicp_profile) (void) hipEventRecord(ctx->ev_b, ctx->stream);
-    if (fast_fetch_custom(ctx, [&](unsigned *flag, unsigned seq) {
-            hipLaunchKernelGGL(k_gicp_sum_fetch, dim3(1), dim3(1024), 0, ctx->stream, ctx->h_gicp,
-                               ctx->partials.as<double>(), (unsigned) nb, flag, seq);
-        }) != WM_OK) {
-        F.rc = WM_ERR_HIP;
-        return 0;
+    if (!(F.served && serve_eval(F, A))) {
+        if (ctx->gicp_profile) (void) hipEventRecord(ctx->ev_a, ctx->stream);
+        hipLaunchKernelGGL(k_gicp_fdf, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->src_sorted.as<float4>(),
+                           n, ctx->keys.as<unsigned long long>(), ctx->match_pt.as<float4>(),
+                           ctx->gicp_mahal.as<double>(), A, ctx->partials.as<double>());
+        if (ctx->gicp_profile) (void) hipEventRecord(ctx->ev_b, ctx->stream);
+        if (fast_fetch_custom(ctx, [&](unsigned *flag, unsigned seq) {
+                hipLaunchKernelGGL(k_gicp_sum_fetch, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->h_gicp,
+                                   ctx->partials.as<double>(), (unsigned) nb, flag, seq);
+            }) != WM_OK) {
+            F.rc = WM_ERR_HIP;
+            return 0;
+        }
     }
     if (ctx->gicp_profile) {
         float ms = 0;
@@ -942,7 +1245,26 @@ int wm_gicp_align(wm_ctx *ctx, const wm_gicp_params *prm, double T_out[16], wm_g
         double Td[16];
         for (int i = 0; i < 16; ++i) Td[i] = (double) T[i];
         // 1-NN of every transformed source point, d2 < max_corr^2 (strict)
-        WM_TRY(nn_pass(ctx, Td, thr, prm->max_corr, iter > 0));
+        // (the previous matches are worth starting from only if the last minimisation moved the cloud by
+        // less than about a grid cell: a seed farther away than that makes the search scan a ball of
+        // its radius, which costs more than finding the neighbour from scratch)
+        bool seeded = iter > 0;
+        if (seeded) {
+            double dt2 = 0, dr2 = 0, rad2 = 0;
+            for (int a = 0; a < 3; ++a) {
+                const double d = (double) T[a * 4 + 3] - (double) prevT[a * 4 + 3];
+                dt2 += d * d;
+                for (int b = 0; b < 3; ++b) {
+                    const double e = (double) T[a * 4 + b] - (double) prevT[a * 4 + b];
+                    dr2 += e * e;
+                }
+                const double ext = fmax(fabs((double) ctx->src_bbox.lo[a]), fabs((double) ctx->src_bbox.hi[a]));
+                rad2 += ext * ext;
+            }
+            const double cell = ctx->levels[0].built ? (double) ctx->levels[0].d.h : 0.0;
+            seeded = sqrt(dt2) + sqrt(dr2 * rad2) < 0.75 * cell;
+        }
+        WM_TRY(nn_pass(ctx, Td, thr, prm->max_corr, seeded));
         Mat3d R;
         for (int a = 0; a < 3; ++a)
             for (int b = 0; b < 3; ++b) R.m[a * 3 + b] = (double) T[a * 4 + b];
@@ -953,7 +1275,9 @@ int wm_gicp_align(wm_ctx *ctx, const wm_gicp_params *prm, double T_out[16], wm_g
         memcpy(prevT, T, sizeof(T));
         double x[6] = {T[3], T[7], T[11], atan2(T[9], T[10]), asin(-T[8]), atan2(T[4], T[0])};
         F.m = (int) cnt;
+        serve_begin(F);
         const int inner = bfgs_minimize(F, x, prm->max_inner, &f_last);
+        serve_end(F);
         if (F.rc != WM_OK) return F.rc;
         if (inner < 0) break;  // NotEnoughPointsException: loop breaks, converged_ stays false
         inner_total += inner;
@@ -981,6 +1305,7 @@ int wm_gicp_align(wm_ctx *ctx, const wm_gicp_params *prm, double T_out[16], wm_g
         stats->evaluations = F.evals;
         stats->f_final = f_last;
         stats->fdf_kernel_ms = F.kernel_ms;
+        stats->served_evaluations = F.served_total;
     }
     if (!converged) return cnt < 4 ? WM_TOO_FEW_CORRESPONDENCES : WM_NOT_CONVERGED;
     for (int i = 0; i < 16; ++i) T_out[i] = (double) prevT[i];

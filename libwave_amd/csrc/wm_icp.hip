@@ -247,6 +247,16 @@ __global__ void __launch_bounds__(THREADS)
     }
     __syncthreads();
     if (s_st.done) return;  // (uniform: every thread reads the staged copy)
+    // the certificate kernel's 64 partial counts of searched queries: added (and zeroed) by the first
+    // wave here, not one LDS round trip after the other by the lane that solves
+    __shared__ unsigned s_uns;
+    if (threadIdx.x < 64) {
+        unsigned v = s_st.cert_unsettled[threadIdx.x];
+        s_st.cert_unsettled[threadIdx.x] = 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += (unsigned) __shfl_xor((int) v, off);
+        if (threadIdx.x == 0) s_uns = v;
+    }
     if (threadIdx.x == 0) {
         s_st.dbg[0] = t_start;
         s_st.dbg[1] = clock64();  // state staged, rows added
@@ -273,7 +283,7 @@ __global__ void __launch_bounds__(THREADS)
 #pragma unroll
             for (int k = 0; k < kStatsLen; ++k) stats[k] = s_st.stats[k];
             s_st.dbg[2] = clock64();
-            icp_apply_stats(&s_st, stats);
+            icp_apply_stats(&s_st, stats, (long long) s_uns);
             // what the host steers by while it runs ahead of the device (wm_icp_align): one 8-byte word in
             // pinned memory -- done flag, iterations finished, the step's size -- in ONE system-scope store
             // (pub[0]: the latest; pub[k]: iteration k's own record, so that what the host decides from
@@ -808,6 +818,7 @@ int wm_ctx_create(wm_ctx **out, int device) {
         const float v = (float) atof(e);
         if (v > 0) ctx->tune_coop_lf = v;
     }
+    if (const char *e = getenv("WM_TUNE_GICP_SERVED")) ctx->tune_gicp_served = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("WM_TUNE_R0")) {
         const float v = (float) atof(e);
         if (v > 0) ctx->tune_r0 = v;
@@ -837,7 +848,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->src_sorted, &ctx->tgt_orig, &ctx->staging, &ctx->cell_of, &ctx->counts,
                       &ctx->block_sums, &ctx->bbox_buf, &ctx->cloud_bbox, &ctx->keys, &ctx->keys_bak, &ctx->match_pt, &ctx->match_pt_bak, &ctx->d_levels, &ctx->ndt_keys, &ctx->ndt_keys2,
                       &ctx->ndt_vox, &ctx->ndt_vkey, &ctx->ndt_hkeys, &ctx->ndt_hvals, &ctx->ndt_dense, &ctx->ndt_meanf, &ctx->src_orig,
-                      &ctx->gicp_c1, &ctx->gicp_c2, &ctx->gicp_mahal, &ctx->src_grid.pts,
+                      &ctx->gicp_c1, &ctx->gicp_c2, &ctx->gicp_mahal, &ctx->gicp_mailbox, &ctx->src_grid.pts,
                       &ctx->src_grid.cell_start, &ctx->vg_idx, &ctx->vg_idx2, &ctx->vg_perm,
                       &ctx->vg_perm2, &ctx->vg_tmp, &ctx->vg_seg, &ctx->io_a, &ctx->io_b, &ctx->ds_ref,
                       &ctx->ds_tgt, &ctx->match_ref, &ctx->match_tgt,
@@ -853,6 +864,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
     }
     if (ctx->h_state) (void) hipHostFree(ctx->h_state);
     if (ctx->h_gicp) (void) hipHostFree(ctx->h_gicp);
+    if (ctx->h_gicp_slots) (void) hipHostFree(ctx->h_gicp_slots);
     if (ctx->h_ndt) (void) hipHostFree(ctx->h_ndt);
     if (ctx->h_sig) (void) hipHostFree(ctx->h_sig);
     if (ctx->h_pub) (void) hipHostFree(ctx->h_pub);
@@ -1577,6 +1589,7 @@ int wm_set_option(wm_ctx *ctx, const char *name, double value) {
     else if (k == "cert_unsettled" && value > 0) ctx->tune_cert_unsettled = (float) value;
     else if (k == "cert_pad_mul" && value >= 0) ctx->tune_cert_pad_mul = (float) value;
     else if (k == "cert_pad_frac" && value >= 0) ctx->tune_cert_pad_frac = (float) value;
+    else if (k == "gicp_served") ctx->tune_gicp_served = value != 0 ? 1 : 0;
     else return WM_ERR_ARG;
     return WM_OK;
 }

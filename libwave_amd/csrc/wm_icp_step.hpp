@@ -58,7 +58,8 @@ __device__ __host__ inline void expand_stats(int mode, const double *a, double *
 // The solve + stopping rules of one ICP iteration, from the (all-reduced) statistics.
 // Runs as lane 0 of k_reduce_solve on the GPU and as plain host code in
 // wm_host_icp_apply (the sharded path's CPU tests drive exactly this function).
-__host__ __device__ inline void icp_apply_stats(IcpDevState *st, const double *stats_in) {
+// uns_total >= 0: the sum of st->cert_unsettled[] (already added up, and zeroed, by the caller's other lanes)
+__host__ __device__ inline void icp_apply_stats(IcpDevState *st, const double *stats_in, long long uns_total = -1) {
 
     // work on a register copy: every st-> access is a global round trip
     double stats[kStatsLen];
@@ -80,18 +81,19 @@ __host__ __device__ inline void icp_apply_stats(IcpDevState *st, const double *s
     {
         const double handled = stats[kStatsLen - 1];
         unsigned uns = 0;
-        bool any = false;
+        if (uns_total >= 0) {
+            uns = (unsigned) uns_total;
+        } else {
 #pragma unroll 1
-        for (int k = 0; k < 64; ++k) {
-            uns += st->cert_unsettled[k];
-            any = any || st->cert_unsettled[k] != 0u;
-            st->cert_unsettled[k] = 0u;
+            for (int k = 0; k < 64; ++k) {
+                uns += st->cert_unsettled[k];
+                st->cert_unsettled[k] = 0u;
+            }
         }
         // (sharded: `handled` is the all-reduced count, the searches counted are this rank's own)
         const double mine = st->local_handled > 0 ? st->local_handled : handled;
         st->frac_changed = handled > 0 ? (float) (stats[kStatsLen - 3] / handled) : 0.f;
         st->frac_unsettled = mine > 0 ? (float) ((double) uns / mine) : 0.f;  // (0 after a full search: nothing counted)
-        (void) any;
     }
     // bookkeeping for the next iteration's queues
     st->deferred_total += st->queue_count[1];

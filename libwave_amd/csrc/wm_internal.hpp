@@ -189,6 +189,12 @@ struct wm_ctx {
     size_t h_scratch_bytes = 0;
     unsigned *h_sig = nullptr;           // pinned: completion flag polled by fast_fetch
     unsigned sig_seq = 0;
+    // served GICP evaluations (wm_gicp.hip): the mailbox in device memory the host writes through the BAR
+    wm::DevBuf gicp_mailbox;
+    unsigned gicp_serve_seq = 0;
+    int gicp_serve_ok = 0, gicp_serve_capacity = 0;  // 0: not tried yet, 1: usable, -1: not on this system
+    int tune_gicp_served = 1;
+    void *h_gicp_slots = nullptr;         // pinned: the evaluator's answers, thirteen (sum, command number) pairs
     double *h_gicp = nullptr;            // pinned, device-visible: the GICP objective's partial sums land here
     int ndt_rank = 0, ndt_world = 1;     // wm_ndt_set_shard: this context's slice of the source
     int (*ndt_reduce)(double *, int, void *) = nullptr;
@@ -223,7 +229,7 @@ struct wm_ctx {
     int ndt_dense_lo[3] = {0, 0, 0}, ndt_dense_dim[3] = {0, 0, 0};
     int tune_ndt_dense = 1;
     float tune_knn_r0 = 0.f;     // first radius of the k-NN (covariance) scan in cells; 0 = by k (1.0 up to k = 12, else 1.5)
-    int tune_radix_min = 512 << 10;  // sorts of more items take rocPRIM's onesweep radix path (wm_sort.hpp)
+    int tune_radix_min = 256 << 10;  // sorts of more items take rocPRIM's onesweep radix path (wm_sort.hpp)
     int tune_xcd_chunk = 32;     // search kernel: XCDs take turns in chunks of this many workgroups (0: one eighth each)
     int tune_scan = 1;           // exclusive scans: rocPRIM look-back scan (1) or the three-kernel scan (0)
     int tune_nn_walk_filter = 1;  // balanced walk: LDS atomic only for trips that can improve the owner's best

@@ -209,10 +209,14 @@ def test_bench_sharded_under_torch_distributed_run():
     import os
     import subprocess
     import sys
+    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, WM_BENCH_FORCE_SHARDED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with socket.socket() as s:  # a port nobody holds right now
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-           "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(root, "bench.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
            "--gpus", "1", "--steps", "3", "--warmup", "1", "--points", "200000", "--no-cpu-baseline",
            "--no-other-configs"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -220,11 +224,11 @@ def test_bench_sharded_under_torch_distributed_run():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     sh = d["config"]["sharding"]
-    assert d["n_gpus"] == 1 and d["value"] > 0
-    assert sh["rccl_ranks"] == 1 and sh["owned_violations"] == 0 and sh["shard_attempts"] == 1
-    assert sh["allreduce_us_isolated"] > 0 and sh["allreduce_ms"] > 0
-    assert sh["plan_ms"] > 0 and sh["compact_ms"] > 0 and sh["index_ms"] > 0 and sh["iter_ms"] > 0
-    assert d["config"]["final_translation_error_m"] < 2e-3
+    assert d["n_gpus"] == 1 and d["value"] > 0, line
+    assert sh["rccl_ranks"] == 1 and sh["owned_violations"] == 0 and sh["shard_attempts"] == 1, sh
+    assert sh["allreduce_us_isolated"] > 0 and sh["allreduce_ms"] > 0, sh
+    assert sh["plan_ms"] > 0 and sh["compact_ms"] > 0 and sh["index_ms"] > 0 and sh["iter_ms"] > 0, sh
+    assert d["config"]["final_translation_error_m"] < 2e-3, line
 
 
 @pytest.mark.parametrize("world", [2, 4])
