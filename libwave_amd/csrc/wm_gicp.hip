@@ -313,15 +313,37 @@ __device__ __forceinline__ int dd_comp_of_lane(unsigned lane) {
 // a[0] = sum r^T M r, a[1..3] = sum M r, a[4..12] = sum p_base (M r)^T; count separately.
 // partials: [block][kGicpAcc][2] = (hi, lo) pairs.  The workgroup's share of one evaluation
 // (all threads of the workgroup call it: it ends with a barrier and the row's store).
-template <bool COHERENT>
-__device__ __forceinline__ void gicp_fdf_block(const float4 *__restrict__ src, unsigned n,
-                                               const unsigned long long *__restrict__ keys,
-                                               const float4 *__restrict__ tgt, const double *__restrict__ mahal,
-                                               const FdfArgs &A, double *__restrict__ partials) {
-    double hi[kGicpAcc], lo[kGicpAcc];
+// one matched pair's terms (p: the source point, q: its match, M: the pair's Mahalanobis matrix)
+__device__ __forceinline__ void gicp_fdf_point(double (&hi)[kGicpAcc], double (&lo)[kGicpAcc], const FdfArgs &A,
+                                               float px, float py, float pz, float qx, float qy, float qz,
+                                               const double (&M)[9]) {
+    const float ppx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.T[0], px), __fmul_rn(A.T[1], py)), __fmul_rn(A.T[2], pz)), A.T[3]);
+    const float ppy = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.T[4], px), __fmul_rn(A.T[5], py)), __fmul_rn(A.T[6], pz)), A.T[7]);
+    const float ppz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.T[8], px), __fmul_rn(A.T[9], py)), __fmul_rn(A.T[10], pz)), A.T[11]);
+    const double res[3] = {(double) __fsub_rn(ppx, qx), (double) __fsub_rn(ppy, qy), (double) __fsub_rn(ppz, qz)};
+    double temp[3];
 #pragma unroll
-    for (int k = 0; k < kGicpAcc; ++k) hi[k] = lo[k] = 0.0;
-    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    for (int r = 0; r < 3; ++r) temp[r] = M[r * 3] * res[0] + M[r * 3 + 1] * res[1] + M[r * 3 + 2] * res[2];
+    dd_add(hi[0], lo[0], res[0] * temp[0] + res[1] * temp[1] + res[2] * temp[2]);
+    const float pbx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.B[0], px), __fmul_rn(A.B[1], py)), __fmul_rn(A.B[2], pz)), A.B[3]);
+    const float pby = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.B[4], px), __fmul_rn(A.B[5], py)), __fmul_rn(A.B[6], pz)), A.B[7]);
+    const float pbz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.B[8], px), __fmul_rn(A.B[9], py)), __fmul_rn(A.B[10], pz)), A.B[11]);
+    const double pb[3] = {(double) pbx, (double) pby, (double) pbz};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        dd_add(hi[1 + r], lo[1 + r], temp[r]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dd_add(hi[4 + r * 3 + c], lo[4 + r * 3 + c], pb[r] * temp[c]);
+    }
+}
+
+// the pairs i0, i0 + stride, ... < n straight from HBM
+__device__ __forceinline__ void gicp_fdf_stream(double (&hi)[kGicpAcc], double (&lo)[kGicpAcc], unsigned i0,
+                                                unsigned stride, const float4 *__restrict__ src, unsigned n,
+                                                const unsigned long long *__restrict__ keys,
+                                                const float4 *__restrict__ tgt, const double *__restrict__ mahal,
+                                                const FdfArgs &A) {
+    for (unsigned i = i0; i < n; i += stride) {
         // everything this pair needs is loaded up front (one round trip); an unmatched point
         // (rare) wastes its loads
         const unsigned j = (unsigned) keys[i];
@@ -330,26 +352,14 @@ __device__ __forceinline__ void gicp_fdf_block(const float4 *__restrict__ src, u
 #pragma unroll
         for (int k = 0; k < 9; ++k) M[k] = mahal[(size_t) k * n + i];
         if (j == kNoIdx) continue;
-        const float ppx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.T[0], p.x), __fmul_rn(A.T[1], p.y)), __fmul_rn(A.T[2], p.z)), A.T[3]);
-        const float ppy = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.T[4], p.x), __fmul_rn(A.T[5], p.y)), __fmul_rn(A.T[6], p.z)), A.T[7]);
-        const float ppz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.T[8], p.x), __fmul_rn(A.T[9], p.y)), __fmul_rn(A.T[10], p.z)), A.T[11]);
-        const double res[3] = {(double) __fsub_rn(ppx, q.x), (double) __fsub_rn(ppy, q.y),
-                               (double) __fsub_rn(ppz, q.z)};
-        double temp[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) temp[r] = M[r * 3] * res[0] + M[r * 3 + 1] * res[1] + M[r * 3 + 2] * res[2];
-        dd_add(hi[0], lo[0], res[0] * temp[0] + res[1] * temp[1] + res[2] * temp[2]);
-        const float pbx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.B[0], p.x), __fmul_rn(A.B[1], p.y)), __fmul_rn(A.B[2], p.z)), A.B[3]);
-        const float pby = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.B[4], p.x), __fmul_rn(A.B[5], p.y)), __fmul_rn(A.B[6], p.z)), A.B[7]);
-        const float pbz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.B[8], p.x), __fmul_rn(A.B[9], p.y)), __fmul_rn(A.B[10], p.z)), A.B[11]);
-        const double pb[3] = {(double) pbx, (double) pby, (double) pbz};
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            dd_add(hi[1 + r], lo[1 + r], temp[r]);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) dd_add(hi[4 + r * 3 + c], lo[4 + r * 3 + c], pb[r] * temp[c]);
-        }
+        gicp_fdf_point(hi, lo, A, p.x, p.y, p.z, q.x, q.y, q.z, M);
     }
+}
+
+// the workgroup's threads' pairs -> its row of `partials` (ends with a barrier; every thread calls)
+template <bool COHERENT>
+__device__ __forceinline__ void gicp_fdf_finish(double (&hi)[kGicpAcc], double (&lo)[kGicpAcc],
+                                                double *__restrict__ partials) {
     // wave reduction by recursive halving (as the search kernel's statistics, wm_nn.hip): at the
     // step for lane bit M a lane keeps one half of its pairs and sends the other half to lane ^ M --
     // 7+4+2+1+1+1 = 16 pair exchanges instead of 13 x 6.  Component k ends in the lane dd_comp_of_lane names.
@@ -384,7 +394,11 @@ __global__ void __launch_bounds__(kBlock)
     k_gicp_fdf(const float4 *__restrict__ src, unsigned n,
                const unsigned long long *__restrict__ keys, const float4 *__restrict__ tgt,
                const double *__restrict__ mahal, FdfArgs A, double *__restrict__ partials) {
-    gicp_fdf_block<false>(src, n, keys, tgt, mahal, A, partials);
+    double hi[kGicpAcc], lo[kGicpAcc];
+#pragma unroll
+    for (int k = 0; k < kGicpAcc; ++k) hi[k] = lo[k] = 0.0;
+    gicp_fdf_stream(hi, lo, blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, src, n, keys, tgt, mahal, A);
+    gicp_fdf_finish<false>(hi, lo, partials);
 }
 
 // The block rows -> the thirteen sums, by ONE workgroup of kBlock threads (the last workgroup of the
@@ -493,12 +507,20 @@ struct alignas(16) GicpSlot {  // pinned host memory: one of the thirteen sums +
     double v;
     unsigned long long seq;
 };
+constexpr int kServeCached = 8;  // pairs per thread kept on chip by the cached variant
 constexpr unsigned long long kServeGuardTicks = 20000000ull;  // 0.2 s of the 100 MHz wall clock
 
 __device__ __forceinline__ unsigned ld_sys(const unsigned *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// PL: how many of a thread's pairs (i, i + stride, ...) stay ON CHIP for the whole minimisation -- the
+// coordinates in registers, the Mahalanobis matrices in LDS (72 B x PL x 256 threads: 147 KB of the CU's
+// 160 KB at PL = 8) --, loaded once when the kernel starts: a 500k pair on 256 workgroups is 7.6 pairs per
+// thread, so an evaluation reads nothing from HBM at all (11 us of streaming become ~3 us of LDS reads
+// and f64 arithmetic).  Pairs beyond PL per thread are streamed as before.  Same terms in the same
+// order either way.
+template <int PL>
 __global__ void __launch_bounds__(kBlock)
     k_gicp_fdf_served(const float4 *__restrict__ src, unsigned n, const unsigned long long *__restrict__ keys,
                       const float4 *__restrict__ tgt, const double *__restrict__ mahal, GicpMailbox *mb,
@@ -506,6 +528,27 @@ __global__ void __launch_bounds__(kBlock)
                       unsigned long long *dbg) {
     __shared__ float s_args[24];
     __shared__ unsigned s_cmd, s_last;
+    extern __shared__ double s_M[];  // [PL][9][kBlock]: column = thread (private to it: no barrier needed)
+    const unsigned stride = gridDim.x * kBlock, i_first = blockIdx.x * kBlock + threadIdx.x;
+    float cpx[PL > 0 ? PL : 1], cpy[PL > 0 ? PL : 1], cpz[PL > 0 ? PL : 1];
+    float cqx[PL > 0 ? PL : 1], cqy[PL > 0 ? PL : 1], cqz[PL > 0 ? PL : 1];
+    unsigned cvalid = 0;
+    if constexpr (PL > 0) {
+#pragma unroll
+        for (int k = 0; k < PL; ++k) {
+            const unsigned i = i_first + (unsigned) k * stride;
+            cpx[k] = cpy[k] = cpz[k] = cqx[k] = cqy[k] = cqz[k] = 0.f;
+            if (i < n) {
+                const unsigned j = (unsigned) keys[i];
+                const float4 p = src[i], q = tgt[i];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) s_M[(k * 9 + c) * kBlock + threadIdx.x] = mahal[(size_t) c * n + i];
+                cpx[k] = p.x, cpy[k] = p.y, cpz[k] = p.z;
+                cqx[k] = q.x, cqy[k] = q.y, cqz[k] = q.z;
+                if (j != kNoIdx) cvalid |= 1u << k;
+            }
+        }
+    }
     for (unsigned seq = first_seq;; ++seq) {
         if (threadIdx.x < 64) {
             bool ok = true;
@@ -514,12 +557,16 @@ __global__ void __launch_bounds__(kBlock)
                 // (one look every ~0.5 us per workgroup: hundreds of workgroups looking as fast as they can
                 // keep the memory channel of that one line so busy that the stragglers of the evaluation
                 // under way, and the next command's arrival, are delayed by tens of microseconds)
-                while (ld_sys(&mb->seq) != seq) {
-                    __builtin_amdgcn_s_sleep(16);
-                    if (wall_clock64() - t0 > kServeGuardTicks) {
+                for (;;) {
+                    const unsigned cur = ld_sys(&mb->seq);
+                    if (cur == seq) break;
+                    // a command PAST this workgroup's next one: it was not resident while the others worked
+                    // (the host has given up on the round by now): leave
+                    if ((int) (cur - seq) > 0 || wall_clock64() - t0 > kServeGuardTicks) {
                         ok = false;
                         break;
                     }
+                    __builtin_amdgcn_s_sleep(16);
                 }
                 if (!ok) __hip_atomic_store(&mb->abandoned, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
@@ -538,7 +585,21 @@ __global__ void __launch_bounds__(kBlock)
             A.T[k] = __uint_as_float((unsigned) __builtin_amdgcn_readfirstlane((int) __float_as_uint(s_args[k])));
             A.B[k] = __uint_as_float((unsigned) __builtin_amdgcn_readfirstlane((int) __float_as_uint(s_args[12 + k])));
         }
-        gicp_fdf_block<true>(src, n, keys, tgt, mahal, A, partials);
+        double hi[kGicpAcc], lo[kGicpAcc];
+#pragma unroll
+        for (int k = 0; k < kGicpAcc; ++k) hi[k] = lo[k] = 0.0;
+        if constexpr (PL > 0) {
+#pragma unroll
+            for (int k = 0; k < PL; ++k)
+                if ((cvalid >> k) & 1u) {
+                    double M[9];
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) M[c] = s_M[(k * 9 + c) * kBlock + threadIdx.x];
+                    gicp_fdf_point(hi, lo, A, cpx[k], cpy[k], cpz[k], cqx[k], cqy[k], cqz[k], M);
+                }
+        }
+        gicp_fdf_stream(hi, lo, i_first + (unsigned) PL * stride, stride, src, n, keys, tgt, mahal, A);
+        gicp_fdf_finish<true>(hi, lo, partials);
         if (dbg && blockIdx.x == 0 && threadIdx.x == 0 && round < 64u) dbg[round * 4 + 1] = wall_clock64();
         // The row is out (write-through stores): wait until they have been performed, then take a
         // ticket; whoever draws the last one adds the rows up, reading them at agent scope.  No
@@ -715,7 +776,18 @@ static void serve_begin(GicpFn &F) {
         int large_bar = 0, cus = 0, per_cu = 0;
         if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->device) != hipSuccess || !large_bar) return;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) return;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gicp_fdf_served, kBlock, 0) != hipSuccess) return;
+        // the variant that keeps eight pairs per thread on chip needs 147 KB of LDS per workgroup
+        constexpr size_t kCacheLds = (size_t) kServeCached * 9 * kBlock * sizeof(double);
+        ctx->gicp_serve_cached = 0;
+        if (hipFuncSetAttribute((const void *) k_gicp_fdf_served<kServeCached>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int) kCacheLds) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gicp_fdf_served<kServeCached>, kBlock, kCacheLds) == hipSuccess &&
+            per_cu >= 1) {
+            ctx->gicp_serve_cached = 1;
+        } else {
+            (void) hipGetLastError();
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gicp_fdf_served<0>, kBlock, 0) != hipSuccess) return;
+        }
         ctx->gicp_serve_capacity = cus * per_cu;
         if (ctx->gicp_mailbox.reserve(4096) != hipSuccess) return;
         if (hipMemsetAsync(ctx->gicp_mailbox.p, 0, 4096, ctx->stream) != hipSuccess) return;
@@ -734,11 +806,18 @@ static void serve_begin(GicpFn &F) {
     if (!g_serving[ctx->device].compare_exchange_strong(expected, 1)) return;
     F.served_evals = 0;
     unsigned *ticket = (unsigned *) ((char *) ctx->gicp_mailbox.p + sizeof(GicpMailbox));
-    hipLaunchKernelGGL(k_gicp_fdf_served, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->src_sorted.as<float4>(),
-                       (unsigned) ctx->n_src, ctx->keys.as<unsigned long long>(), ctx->match_pt.as<float4>(),
-                       ctx->gicp_mahal.as<double>(), (GicpMailbox *) ctx->gicp_mailbox.p, ctx->gicp_serve_seq + 1u,
-                       ctx->partials.as<double>(), ticket, (GicpSlot *) ctx->h_gicp_slots,
-                       getenv("WM_GICP_SERVE_DEBUG") ? (unsigned long long *) ((char *) ctx->gicp_mailbox.p + 256) : nullptr);
+    unsigned long long *dbg = getenv("WM_GICP_SERVE_DEBUG") ? (unsigned long long *) ((char *) ctx->gicp_mailbox.p + 256) : nullptr;
+    if (ctx->gicp_serve_cached && ctx->tune_gicp_served != 2)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gicp_fdf_served<kServeCached>), dim3(nb), dim3(kBlock),
+                           (size_t) kServeCached * 9 * kBlock * sizeof(double), ctx->stream, ctx->src_sorted.as<float4>(),
+                           (unsigned) ctx->n_src, ctx->keys.as<unsigned long long>(), ctx->match_pt.as<float4>(),
+                           ctx->gicp_mahal.as<double>(), (GicpMailbox *) ctx->gicp_mailbox.p, ctx->gicp_serve_seq + 1u,
+                           ctx->partials.as<double>(), ticket, (GicpSlot *) ctx->h_gicp_slots, dbg);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gicp_fdf_served<0>), dim3(nb), dim3(kBlock), 0, ctx->stream,
+                           ctx->src_sorted.as<float4>(), (unsigned) ctx->n_src, ctx->keys.as<unsigned long long>(),
+                           ctx->match_pt.as<float4>(), ctx->gicp_mahal.as<double>(), (GicpMailbox *) ctx->gicp_mailbox.p,
+                           ctx->gicp_serve_seq + 1u, ctx->partials.as<double>(), ticket, (GicpSlot *) ctx->h_gicp_slots, dbg);
     if (hipGetLastError() != hipSuccess) {
         g_serving[ctx->device].store(0);
         return;

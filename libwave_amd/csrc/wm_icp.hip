@@ -818,7 +818,7 @@ int wm_ctx_create(wm_ctx **out, int device) {
         const float v = (float) atof(e);
         if (v > 0) ctx->tune_coop_lf = v;
     }
-    if (const char *e = getenv("WM_TUNE_GICP_SERVED")) ctx->tune_gicp_served = atoi(e) != 0 ? 1 : 0;
+    if (const char *e = getenv("WM_TUNE_GICP_SERVED")) ctx->tune_gicp_served = atoi(e) == 2 ? 2 : (atoi(e) != 0 ? 1 : 0);
     if (const char *e = getenv("WM_TUNE_R0")) {
         const float v = (float) atof(e);
         if (v > 0) ctx->tune_r0 = v;
@@ -1589,7 +1589,7 @@ int wm_set_option(wm_ctx *ctx, const char *name, double value) {
     else if (k == "cert_unsettled" && value > 0) ctx->tune_cert_unsettled = (float) value;
     else if (k == "cert_pad_mul" && value >= 0) ctx->tune_cert_pad_mul = (float) value;
     else if (k == "cert_pad_frac" && value >= 0) ctx->tune_cert_pad_frac = (float) value;
-    else if (k == "gicp_served") ctx->tune_gicp_served = value != 0 ? 1 : 0;
+    else if (k == "gicp_served") ctx->tune_gicp_served = value == 2 ? 2 : (value != 0 ? 1 : 0);
     else return WM_ERR_ARG;
     return WM_OK;
 }

@@ -14,7 +14,7 @@ n = int(os.environ.get("GICP_POINTS", "500000"))
 ref, tgt, T_gt = synth.pair(n, seed=42)
 d_ref, d_tgt = torch.from_numpy(ref).cuda(), torch.from_numpy(tgt).cuda()
 res = {}
-for posted in (0, 1):
+for posted in (0, 2, 1):
     ctx = capi.Context(0)
     ctx.set_option("gicp_served", posted)
 
@@ -33,5 +33,6 @@ for posted in (0, 1):
         np.linalg.norm(r["T"][:3, 3] - T_gt[:3, 3])), flush=True)
     res.setdefault(posted, r)
     ctx.close()
-print("identical transform:", bool(np.array_equal(res[0]["T"], res[1]["T"])), "| identical objective:", res[0]["f"] == res[1]["f"],
-      "| same evaluations:", res[0]["evaluations"] == res[1]["evaluations"])
+for k in (1, 2):
+    print("served=%d vs launched: identical transform:" % k, bool(np.array_equal(res[0]["T"], res[k]["T"])), "| identical objective:", res[0]["f"] == res[k]["f"],
+          "| same evaluations:", res[0]["evaluations"] == res[k]["evaluations"])

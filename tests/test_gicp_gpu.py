@@ -176,3 +176,53 @@ def test_gicp_spread_against_pcl_literal_summation(wm, ctx, oracle):
     for r in rows:
         print("GICP %d pts seed %d: HIP vs PCL-literal oracle %.2e m / %.2e rad | vs ground truth: HIP %.2e m, "
               "literal %.2e m | inner iterations %d vs %d" % r)
+
+
+def _gicp_run(wm, ref, tgt, served, **kw):
+    c = wm.Context(0)
+    try:
+        c.set_option("gicp_served", served)
+        c.set_source(ref)
+        c.set_target(tgt)
+        return c.gicp_align(**kw)
+    finally:
+        c.close()
+
+
+def test_served_evaluations_give_the_launched_ones_bits(wm):
+    """The resident evaluator (k_gicp_fdf_served: trial points through a mailbox in device memory,
+    answers through pinned slots) and a kernel launch per evaluation run the same arithmetic in the
+    same order: same matrix, same objective, same number of evaluations -- on the reference-sized
+    case and on a noisy pair where a last-bit difference would move the BFGS stopping point."""
+    for n, seed, mode in ((20000, 3, "resample"), (40000, 9, "copy")):
+        ref, tgt, _ = synth.pair(n, seed=seed, mode=mode)
+        a = _gicp_run(wm, ref, tgt, 0)
+        b = _gicp_run(wm, ref, tgt, 1)
+        assert a["rc"] == b["rc"] == 0
+        assert a["served_evaluations"] == 0
+        assert b["served_evaluations"] == b["evaluations"] > 0, "the evaluator was not used (no large BAR here?)"
+        assert a["evaluations"] == b["evaluations"] and a["iterations"] == b["iterations"]
+        assert a["f"] == b["f"]
+        assert np.array_equal(a["T"], b["T"])
+
+
+def test_only_one_served_evaluator_per_device_at_a_time(wm):
+    """Two registrations running at once on one GPU (a MultiMatcher's workers): one of them is served,
+    the other falls back to launches while the evaluator is taken -- both get the same answer."""
+    import threading
+    ref, tgt, _ = synth.pair(30000, seed=21, mode="resample")
+    want = _gicp_run(wm, ref, tgt, 0)
+    out = [None, None]
+
+    def work(k):
+        for _ in range(3):
+            out[k] = _gicp_run(wm, ref, tgt, 1)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for r in out:
+        assert r is not None and r["rc"] == 0
+        assert np.array_equal(r["T"], want["T"]) and r["f"] == want["f"]
