@@ -1,9 +1,11 @@
 // wave::NDTMatcher on the MI355X back end.
 //
-// setTarget() marks the voxel model stale; match() uploads what changed (wm_set_source /
-// wm_set_target) and runs wm_ndt_align: per-voxel means and conditioned inverse covariances in a
-// device hash grid, then Newton iterations whose score / gradient / Hessian passes are device
-// reductions over (point, neighbouring voxel) pairs, with the More-Thuente step search of PCL.
+// setTarget() uploads the cloud and builds the voxel model at once (as ndt.cpp:53-56 ->
+// setInputTarget does: per-voxel means and conditioned inverse covariances in a device table); the
+// model is kept across match() calls until the next setTarget().  match() uploads the source and
+// runs wm_ndt_align: Newton iterations whose score / gradient / Hessian passes are device
+// reductions over (point, neighbouring voxel) pairs, with the More-Thuente step search PCL's code
+// contains (setPcl18StepRule(true): the undamped rule PCL 1.8 actually executes).
 //
 // Kept from the reference (wave_matching/include/wave/matching/ndt.hpp:33-85, src/ndt.cpp): the
 // parameter struct including the const `min_res` floor and the integer `step_size`, the clamp +
