@@ -20,6 +20,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 namespace wm {
@@ -849,6 +850,11 @@ static void serve_end(GicpFn &F) {
 // one served evaluation; false: no answer (the evaluator gave up or is stuck) -> it has been shut down
 static bool serve_eval(GicpFn &F, const FdfArgs &A) {
     wm_ctx *ctx = F.ctx;
+    if (ctx->gicp_serve_test_stall_ms > 0 && F.served_evals == 2) {
+        // test hook (wm_set_option "gicp_serve_test_stall_ms"): a host that goes away for longer than the
+        // evaluator's guard -- the kernel must have left by itself, and this call must recover by launching
+        std::this_thread::sleep_for(std::chrono::milliseconds(ctx->gicp_serve_test_stall_ms));
+    }
     const auto t0 = std::chrono::steady_clock::now();
     serve_post(ctx, &A, 1u);
     const unsigned long long expect = ctx->gicp_serve_seq;

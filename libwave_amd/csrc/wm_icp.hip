@@ -1590,6 +1590,7 @@ int wm_set_option(wm_ctx *ctx, const char *name, double value) {
     else if (k == "cert_pad_mul" && value >= 0) ctx->tune_cert_pad_mul = (float) value;
     else if (k == "cert_pad_frac" && value >= 0) ctx->tune_cert_pad_frac = (float) value;
     else if (k == "gicp_served") ctx->tune_gicp_served = value == 2 ? 2 : (value != 0 ? 1 : 0);
+    else if (k == "gicp_serve_test_stall_ms") ctx->gicp_serve_test_stall_ms = (int) value;
     else return WM_ERR_ARG;
     return WM_OK;
 }

@@ -194,6 +194,7 @@ struct wm_ctx {
     unsigned gicp_serve_seq = 0;
     int gicp_serve_ok = 0, gicp_serve_capacity = 0, gicp_serve_cached = 0;  // 0: not tried yet, 1: usable, -1: not on this system
     int tune_gicp_served = 1;             // 0: a kernel launch per evaluation; 1: resident evaluator; 2: ... without the on-chip copy of the pairs
+    int gicp_serve_test_stall_ms = 0;     // test hook: the host sleeps this long before its third served evaluation
     void *h_gicp_slots = nullptr;         // pinned: the evaluator's answers, thirteen (sum, command number) pairs
     double *h_gicp = nullptr;            // pinned, device-visible: the GICP objective's partial sums land here
     int ndt_rank = 0, ndt_world = 1;     // wm_ndt_set_shard: this context's slice of the source

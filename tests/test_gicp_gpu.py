@@ -226,3 +226,26 @@ def test_only_one_served_evaluator_per_device_at_a_time(wm):
     for r in out:
         assert r is not None and r["rc"] == 0
         assert np.array_equal(r["T"], want["T"]) and r["f"] == want["f"]
+
+
+def test_served_evaluator_gives_up_and_the_host_recovers(wm):
+    """A host that stalls for longer than the resident evaluator's guard (0.2 s without a command): the
+    kernel leaves by itself (it must never hold the GPU waiting for a dead host), the stalled call
+    notices, falls back to launching its evaluations -- and the registration's result is the same."""
+    ref, tgt, _ = synth.pair(20000, seed=3, mode="resample")
+    want = _gicp_run(wm, ref, tgt, 0)
+    c = wm.Context(0)
+    try:
+        c.set_option("gicp_served", 1)
+        c.set_option("gicp_serve_test_stall_ms", 350)
+        c.set_source(ref)
+        c.set_target(tgt)
+        got = c.gicp_align()
+        c.set_option("gicp_serve_test_stall_ms", 0)
+        again = c.gicp_align()   # the context is fully usable afterwards, served again
+    finally:
+        c.close()
+    assert got["rc"] == 0 and np.array_equal(got["T"], want["T"]) and got["f"] == want["f"]
+    assert 0 < got["served_evaluations"] < got["evaluations"]
+    assert again["rc"] == 0 and np.array_equal(again["T"], want["T"])
+    assert again["served_evaluations"] == again["evaluations"]
