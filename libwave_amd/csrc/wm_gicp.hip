@@ -1207,20 +1207,35 @@ static int launch_cov_k(wm_ctx *ctx, const GridDev &g, const float4 *q, size_t n
 static int compute_covariances(wm_ctx *ctx, int k, double eps) {
     if (k > 32) return WM_ERR_ARG;
     const bool same = ctx->gicp_cov_k == k && ctx->gicp_cov_eps == eps;
+    // both clouds new (the usual case): the target's pass runs on the side stream while this one
+    // builds the source's grid (a dozen small, host-bound launches) and starts the source's pass
+    hipStream_t main_stream = ctx->stream;
+    bool forked = false;
     if (!(ctx->gicp_cov_tgt_valid && same)) {
         // target: neighbours from the level-0 search grid
         if (!ctx->levels[0].built) WM_TRY(ensure_levels(ctx, -1.0));
         WM_HIP(ctx, ctx->gicp_c2.reserve((ctx->n_tgt_input > 0 ? ctx->n_tgt_input : 1) * 9 * sizeof(double)));
+        if (ctx->tune_two_streams && ctx->side_stream && !(ctx->gicp_cov_src_valid && same)) {
+            WM_HIP(ctx, hipEventRecord(ctx->ev_fork, main_stream));
+            WM_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+            ctx->stream = ctx->side_stream;
+            forked = true;
+        }
         const GridDev &g = ctx->levels[0].d;
         const float4 *orig = ctx->tgt_orig.as<float4>();
         // queries in the grid's own (cell-sorted) order -- a wave's 64 queries then scan the same
         // few rows of cells -- with the result stored under each point's caller index (.w).
         // Only finite points are in the grid; a cloud with non-finite ones takes caller order,
         // which also writes their (never read) placeholder covariances.
-        if (ctx->n_tgt == ctx->n_tgt_input)
-            WM_TRY(launch_cov_k(ctx, g, g.pts, ctx->n_tgt, orig, k, eps, ctx->gicp_c2.as<double>(), 1));
-        else
-            WM_TRY(launch_cov_k(ctx, g, orig, ctx->n_tgt_input, orig, k, eps, ctx->gicp_c2.as<double>(), 0));
+        const int rc = ctx->n_tgt == ctx->n_tgt_input
+                           ? launch_cov_k(ctx, g, g.pts, ctx->n_tgt, orig, k, eps, ctx->gicp_c2.as<double>(), 1)
+                           : launch_cov_k(ctx, g, orig, ctx->n_tgt_input, orig, k, eps, ctx->gicp_c2.as<double>(), 0);
+        if (forked) {  // (back on the main stream whatever happened)
+            const hipError_t e = hipEventRecord(ctx->ev_join, ctx->side_stream);
+            ctx->stream = main_stream;
+            WM_HIP(ctx, e);
+        }
+        WM_TRY(rc);
         ctx->gicp_cov_tgt_valid = true;
     }
     if (!(ctx->gicp_cov_src_valid && same)) {
@@ -1232,12 +1247,16 @@ static int compute_covariances(wm_ctx *ctx, int k, double eps) {
         // a source like the previous one (consecutive scans of one sensor): start from the cell
         // size that was tuned for it, which usually passes the occupancy check at once and saves
         // the second build (the level-0 grid of the target does the same)
+        bool trust = false;  // a cloud this close to the one the cell size was measured on: no occupancy check
+                             // (a device -> host round trip) -- but look again every 16th time, as build_level0 does
         if (ctx->tuned_src_h > 0 && ctx->tuned_src_n > 0) {
             const double rn = (double) ctx->n_src / (double) ctx->tuned_src_n, rv = vol / ctx->tuned_src_vol;
             if (rn > 0.8 && rn < 1.25 && rv > 0.6 && rv < 1.6) h = (float) ctx->tuned_src_h;
+            trust = rn > 0.9 && rn < 1.1 && rv > 0.8 && rv < 1.25 && ++ctx->tuned_src_uses < 16;
         }
+        if (!trust) ctx->tuned_src_uses = 0;
         WM_TRY(build_grid_level(ctx, ctx->src_orig.as<float4>(), ctx->n_src_input, ctx->src_bbox, h,
-                                &ctx->src_grid, &occ));
+                                &ctx->src_grid, trust ? nullptr : &occ));
         if (occ > 6.0 || (occ > 0 && occ < 1.5)) {
             h = (float) (h * sqrt(3.0 / occ));
             WM_TRY(build_grid_level(ctx, ctx->src_orig.as<float4>(), ctx->n_src_input, ctx->src_bbox, h,
@@ -1251,6 +1270,7 @@ static int compute_covariances(wm_ctx *ctx, int k, double eps) {
                             ctx->gicp_c1.as<double>(), 0));
         ctx->gicp_cov_src_valid = true;
     }
+    if (forked) WM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     ctx->gicp_cov_k = k;
     ctx->gicp_cov_eps = eps;
     return WM_OK;
@@ -1349,7 +1369,7 @@ int wm_gicp_align(wm_ctx *ctx, const wm_gicp_params *prm, double T_out[16], wm_g
             const double cell = ctx->levels[0].built ? (double) ctx->levels[0].d.h : 0.0;
             seeded = sqrt(dt2) + sqrt(dr2 * rad2) < 0.75 * cell;
         }
-        WM_TRY(nn_pass(ctx, Td, thr, prm->max_corr, seeded));
+        WM_TRY(nn_pass(ctx, Td, thr, prm->max_corr, seeded, false, 0.f, 0.f, /*wait=*/false));  // (count_matched below waits)
         Mat3d R;
         for (int a = 0; a < 3; ++a)
             for (int b = 0; b < 3; ++b) R.m[a * 3 + b] = (double) T[a * 4 + b];

@@ -632,7 +632,7 @@ static hipEvent_t get_event(wm_ctx *ctx, size_t k) {
 }
 
 int nn_pass(wm_ctx *ctx, const double T[16], float thr_d2, double max_corr, bool predict, bool slab, float slab_lo,
-            float slab_hi) {
+            float slab_hi, bool wait) {
     WM_TRY(finalize_clouds(ctx, max_corr, WM_NN_AUTO));
     WM_TRY(prepare_work(ctx));
     const bool brute = use_brute(ctx, WM_NN_AUTO) || ctx->n_tgt == 0;
@@ -652,7 +652,8 @@ int nn_pass(wm_ctx *ctx, const double T[16], float thr_d2, double max_corr, bool
         WM_TRY(launch_nn_brute(ctx, thr_d2, nullptr, nullptr));
     else
         WM_TRY(launch_nn_grid(ctx, thr_d2, nullptr, nullptr, nullptr));
-    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // (wait = false: the caller queues more work behind the search and waits for that)
+    if (wait) WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return WM_OK;
 }
 

@@ -164,6 +164,7 @@ struct wm_ctx {
     double tuned_h = 0, tuned_vol = 0;  // last auto-tuned level-0 cell size and its cloud
     size_t tuned_n = 0;
     double tuned_src_h = 0, tuned_src_vol = 0;  // the same for the source grid of the GICP covariances
+    unsigned tuned_src_uses = 0;               // builds that trusted it since the last occupancy check
     size_t tuned_src_n = 0;
 
     // scratch
@@ -388,6 +389,6 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, str
 // one correspondence pass with transform T; `predict` lets the search start from the
 // radii in the current keys
 int nn_pass(wm_ctx *ctx, const double T[16], float thr_d2, double max_corr, bool predict, bool slab = false,
-            float slab_lo = 0.f, float slab_hi = 0.f);
+            float slab_lo = 0.f, float slab_hi = 0.f, bool wait = true);
 
 }  // namespace wm
