@@ -252,6 +252,7 @@ struct wm_ctx {
     int tune_nn_nt_stores = 1;   // search kernels: non-temporal result stores (nothing left dirty in L2 at the kernel boundary)
     int tune_fast_solve = 1;     // experiment knob for the solve kernel
     int tune_spin_us = 80;       // wait_flag: busy-poll this long before polling with yields
+    int tune_ndt_spec_hessian = 1;  // form the Hessian along with the first extra line-search trial (wm_ndt.hip step_length_mt)
     int tune_ndt_blocks = 1024;  // workgroups (= partial rows) of one NDT derivative pass
     int tune_gicp_blocks = 256;  // workgroups (= partial rows) of one GICP objective evaluation (double-double sums: 512 / 256 / 128 / 64 -> 6.9 / 6.4 / 7.3 / 9.6 ms per 500k registration)
     bool ndt_built = false;

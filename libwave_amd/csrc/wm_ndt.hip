@@ -829,6 +829,7 @@ struct NdtEval {
     int evals = 0;
     float kernel_ms = 0;
     double host_launch_us = 0, host_wait_us = 0;  // WM_NDT_PROFILE=2: wall time inside the launch calls / the wait
+    int ls_hist[12] = {0};  // line searches by their number of extra trials (developer: WM_TRACE)
 };
 
 // score (+ gradient, + Hessian) at pose p; returns <0 on HIP error via *rc
@@ -1048,6 +1049,7 @@ static double step_length_mt(NdtEval &E, const double x[6], double dir[6], doubl
     }
     const int max_step_iterations = 10;
     int step_iterations = 0;
+    bool hess_at_xt = false;  // `hess` already holds the Hessian at the last trial point
     double a_l = 0, a_u = 0;
     double f_l = psi_mt(a_l, phi_0, phi_0, d_phi_0, mu), g_l = dpsi_mt(d_phi_0, d_phi_0, mu);
     double f_u = psi_mt(a_u, phi_0, phi_0, d_phi_0, mu), g_u = dpsi_mt(d_phi_0, d_phi_0, mu);
@@ -1066,7 +1068,17 @@ static double step_length_mt(NdtEval &E, const double x[6], double dir[6], doubl
                             : trial_value_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
         a_t = fmax(fmin(a_t, step_max), step_min);
         for (int a = 0; a < 6; ++a) x_t[a] = x[a] + dir[a] * a_t;
-        *score = ndt_eval(E, x_t, grad, nullptr, rc);
+        // PCL evaluates score + gradient here and, once the search has ended, the Hessian at the accepted
+        // point in a pass of its own (computeHessian).  Nearly every search that gets here ends with THIS
+        // trial, and a pass that forms the Hessian costs the same with or without the gradient (150 vs
+        // 153 us at 2M points, against 81 us for the gradient alone): so the Hessian is formed along with
+        // the FIRST extra trial, and the separate pass (+ its round trip) is dropped when that trial is
+        // accepted.  Same sums over the same terms as computeHessian's; a rejected trial wastes 72 us, and
+        // a search that rejects its first extra trial usually goes on for many (on the bench pair: 13
+        // searches without an extra trial, 9 with one, 1 with ten), so later trials are not speculated on.
+        const bool spec = E.ctx->tune_ndt_spec_hessian != 0 && step_iterations == 0;
+        *score = ndt_eval(E, x_t, grad, spec ? hess : nullptr, rc);
+        hess_at_xt = spec;
         if (*rc != WM_OK) return 0;
         phi_t = -(*score);
         d_phi_t = 0;
@@ -1085,7 +1097,8 @@ static double step_length_mt(NdtEval &E, const double x[6], double dir[6], doubl
                                  : update_interval_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
         ++step_iterations;
     }
-    if (step_iterations) {  // computeHessian at the accepted point
+    E.ls_hist[step_iterations < 11 ? step_iterations : 11]++;
+    if (step_iterations && !hess_at_xt) {  // computeHessian at the accepted point
         (void) ndt_eval(E, x_t, nullptr, hess, rc);
     }
     return a_t;
@@ -1201,6 +1214,10 @@ int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *prm, double T_out[16], wm_ndt
         if (ctx->trace)
             fprintf(stderr, "[wm] ndt: %d passes, host time in launches %.0f us, in waits %.0f us, kernels %.3f ms\n",
                     E.evals, E.host_launch_us, E.host_wait_us, E.kernel_ms);
+        if (ctx->trace)
+            fprintf(stderr, "[wm] ndt: line searches by extra trials 0..11+: %d %d %d %d %d %d %d %d %d %d %d %d\n", E.ls_hist[0],
+                    E.ls_hist[1], E.ls_hist[2], E.ls_hist[3], E.ls_hist[4], E.ls_hist[5], E.ls_hist[6], E.ls_hist[7],
+                    E.ls_hist[8], E.ls_hist[9], E.ls_hist[10], E.ls_hist[11]);
     }
     if (!converged) return WM_NOT_CONVERGED;
     float Tf[16];

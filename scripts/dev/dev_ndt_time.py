@@ -12,8 +12,9 @@ from libwave_amd import capi, synth
 n = int(os.environ.get("NDT_POINTS", "2000000"))
 ref, tgt, T_gt = synth.pair(n, seed=42, pattern="rings")
 d_ref, d_tgt = torch.from_numpy(ref).cuda(), torch.from_numpy(tgt).cuda()
-for blocks in [int(v) for v in os.environ.get("NDT_BLOCKS", "1024,512,768").split(",")]:
+for blocks, spec in ((1024, 0), (1024, 1)):
     os.environ["WM_TUNE_NDT_BLOCKS"] = str(blocks)
+    os.environ["WM_TUNE_NDT_SPEC_HESSIAN"] = str(spec)
     ctx = capi.Context(0)
 
     def run():
@@ -26,6 +27,7 @@ for blocks in [int(v) for v in os.environ.get("NDT_BLOCKS", "1024,512,768").spli
         t0 = time.perf_counter()
         r = run()
         ts.append((time.perf_counter() - t0) * 1e3)
-    print("blocks %d: %.3f ms/registration (min %.3f), %d iterations, %d passes, |t - t_gt| %.2e" % (
+    print(("blocks %d spec_hessian " + str(spec) + ": %.3f ms/registration (min %.3f), %d iterations, %d passes, |t - t_gt| %.2e") % (
         blocks, np.median(ts), min(ts), r["iterations"], r["evaluations"], np.linalg.norm(r["T"][:3, 3] - T_gt[:3, 3])), flush=True)
+    print('   T[:3,3] =', r['T'][:3, 3].tolist(), 'score', r.get('score'))
     ctx.close()
