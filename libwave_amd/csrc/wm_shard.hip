@@ -552,6 +552,7 @@ static int align_sharded_impl(wm_ctx *ctx, wm_comm *comm, const void *ref, size_
         WM_HIP(ctx, ctx->shard_stats.reserve(WM_STATS_LEN * sizeof(double)));
         double T[16];
         wm_icp_stats it_st;
+        memset(&it_st, 0, sizeof(it_st));  // (the loop ADDS its event times into the block)
         const int rc = icp_run_loop(ctx, p, brute, thr, comm, ctx->shard_stats.as<double>(), T, &it_st);
         const auto t_host2 = std::chrono::steady_clock::now();
         ctx->shard_active = false;
