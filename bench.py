@@ -164,7 +164,21 @@ def pmc_traffic_bytes(pmc, kernel="k_nn_grid"):
     return (2.0 * d["FETCH_SIZE_kb_per_dispatch"] + d["WRITE_SIZE_kb_per_dispatch"]) * 1024.0
 
 
-def other_configs(torch, dev, capi, synth, pmc, with_cpu):
+def counter_traffic(pmc, kernel, avg_launch_us, copy_peak_gbs):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_latest.json; FETCH_SIZE
+    doubled on gfx950 as for the search kernels, WRITE_SIZE as reported) and, with the launch time measured
+    in THIS run, the share of the measured copy rate they amount to."""
+    d = pmc.get(kernel, {})
+    if "FETCH_SIZE_kb_per_dispatch" not in d or "WRITE_SIZE_kb_per_dispatch" not in d:
+        return {"traffic": None}
+    t = (2.0 * d["FETCH_SIZE_kb_per_dispatch"] + d["WRITE_SIZE_kb_per_dispatch"]) * 1024.0
+    out = {"traffic": t, "traffic_source": "profiles/pmc_latest.json, %s" % d.get("traffic_source", pmc.get("tag"))}
+    if avg_launch_us and avg_launch_us > 0 and copy_peak_gbs:
+        out["hbm_util"] = t / (avg_launch_us * 1e-6) / 1e9 / copy_peak_gbs
+    return out
+
+
+def other_configs(torch, dev, capi, synth, pmc, with_cpu, copy_peak=None):
     """BASELINE configs[2] (GICP 500k<->500k) and configs[3] (NDT 2M, 0.5 m voxels): ms per
     registration (device-resident clouds), the dominant kernel against its roof, and the CPU oracle
     at a size it finishes in seconds."""
@@ -221,6 +235,7 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu):
                       # (float upper-triangle matrices; this kernel reads 72-B double 3x3s and a 16-B packed match)
                       "survey_bytes_per_launch": 52.0 * n,
                       "frac_survey_bytes": 52.0 * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us > 0 else None}}
+    e["roofline"].update(counter_traffic(pmc, "k_gicp_fdf", us, copy_peak))
     if with_cpu:
         from oracle import oracle_py as O
         m = 20_000
@@ -256,6 +271,7 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu):
     if fl and us > 0:
         roof["achieved"] = fl * n / (us * 1e-6) / 1e12
         roof["frac"] = roof["achieved"] / F64_VALU_PEAK_TFLOPS
+    roof.update(counter_traffic(pmc, "k_ndt_derivs", us, copy_peak))
     e["roofline"] = roof
     if with_cpu:
         from oracle import oracle_py as O
@@ -544,7 +560,7 @@ def main():
             out["value_h2d_inclusive_note"] = ("the same registration from pinned HOST clouds (both uploads inside the "
                                                "timed step); `value` is with the clouds already in HBM")
         if world == 1 and not a.no_other_configs:
-            out["other_configs"] = other_configs(torch, dev, capi, synth, pmc, not a.no_cpu_baseline)
+            out["other_configs"] = other_configs(torch, dev, capi, synth, pmc, not a.no_cpu_baseline, peak_copy)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ref, tgt, a.iters, a.max_corr, a.cpu_iters)
             out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

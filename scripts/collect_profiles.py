@@ -28,6 +28,8 @@ for name in ("fetch", "write", "sq", "tcc"):
     cp(os.path.join(src, tag + "_pmc", name + "_summary.csv"), "%s_pmc_%s_summary.csv" % (tag, name))
 for name in ("sq1", "sq2", "sq3", "f64"):
     cp(os.path.join(src, tag + "_ndt", name + "_summary.csv"), "%s_pmc_ndt_%s_summary.csv" % (tag, name))
+for name in ("fetch", "write"):
+    cp(os.path.join(src, tag + "_other", name + "_summary.csv"), "%s_pmc_gicp_ndt_%s_summary.csv" % (tag, name))
 cp(os.path.join(src, tag + "_pmc", "pmc_latest.json"), "pmc_latest.json")
 tabs = {}
 for f in sorted(glob.glob(os.path.join(src, tag + "_detail", "*_per_dispatch.csv"))):

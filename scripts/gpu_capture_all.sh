@@ -10,7 +10,8 @@ bash scripts/gpu_profile.sh ${TAG}_stats > /dev/null 2>&1
 bash scripts/gpu_pmc.sh ${TAG}_pmc > /dev/null 2>&1
 bash scripts/gpu_pmc_detail.sh ${TAG}_detail > /dev/null 2>&1
 bash scripts/gpu_pmc_ndt.sh ${TAG}_ndt > /dev/null 2>&1
-python scripts/pmc_to_json.py gpurun_out/${TAG}_pmc gpurun_out/${TAG}_pmc/pmc_latest.json gpurun_out/${TAG}_ndt > /dev/null
+bash scripts/gpu_pmc_other.sh ${TAG}_other > /dev/null 2>&1
+python scripts/pmc_to_json.py gpurun_out/${TAG}_pmc gpurun_out/${TAG}_pmc/pmc_latest.json gpurun_out/${TAG}_ndt gpurun_out/${TAG}_other > /dev/null
 python bench.py > gpurun_out/${TAG}_bench_line_noprof.json 2> /dev/null
 # the C++ wave::MultiMatcher pool: batched (deep queue) and stream-per-worker (queue of 2 x workers)
 ( cd libwave_amd/host

@@ -46,5 +46,26 @@ if len(sys.argv) > 3:
                                "active_lane_fraction": lanes,
                                "f64_flops_per_source_point": winst / disp * 64.0 * lanes / n_points,
                                "source": os.path.basename(os.path.normpath(nd))}
+# optional fourth argument: the GICP / NDT traffic directory (scripts/gpu_pmc_other.sh): FETCH / WRITE per
+# dispatch of k_gicp_fdf (launched evaluations) and of the k_ndt_derivs variants (dispatch-weighted)
+if len(sys.argv) > 4:
+    od = sys.argv[4]
+    acc = {}
+    for name in ("fetch", "write"):
+        path = os.path.join(od, name + "_summary.csv")
+        if not os.path.exists(path):
+            continue
+        for line in open(path).read().splitlines()[1:]:
+            kernel, dispatches, counter, total, _per = line.rsplit(",", 4)
+            k = kernel.replace("void ", "").replace("wm::", "").split("<")[0]
+            a = acc.setdefault(k, {}).setdefault(counter, [0.0, 0])
+            a[0] += float(total)
+            a[1] += int(dispatches)
+    for k, cs in acc.items():
+        d = out.setdefault(k, {})
+        for counter, (total, disp) in cs.items():
+            d[counter + "_kb_per_dispatch"] = total / max(disp, 1)
+            d.setdefault("dispatches_traffic", disp)
+        d["traffic_source"] = os.path.basename(os.path.normpath(od))
 json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
 print(json.dumps({k: out.get(k, {}) for k in ("k_nn_grid", "k_nn_cert")}, indent=1))
