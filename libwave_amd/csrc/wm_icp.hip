@@ -821,6 +821,7 @@ int wm_ctx_create(wm_ctx **out, int device) {
     }
     if (const char *e = getenv("WM_TUNE_GICP_SERVED")) ctx->tune_gicp_served = atoi(e) == 2 ? 2 : (atoi(e) != 0 ? 1 : 0);
     if (const char *e = getenv("WM_TUNE_NDT_SPEC_HESSIAN")) ctx->tune_ndt_spec_hessian = atoi(e);
+    if (const char *e = getenv("WM_TUNE_LAG")) ctx->tune_lag = atoi(e);
     if (const char *e = getenv("WM_TUNE_R0")) {
         const float v = (float) atof(e);
         if (v > 0) ctx->tune_r0 = v;
@@ -1014,7 +1015,7 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
     // timing and a registration stays bit-reproducible): the full search (k_nn_grid) while the clouds
     // still move, the certificate kernel (k_nn_cert) once a step is a small fraction of a grid cell.
     // The choice changes the work, never the correspondences.
-    constexpr int kLag = 4;
+    const int kLag = ctx->tune_lag >= 1 && ctx->tune_lag <= 16 ? ctx->tune_lag : 4;
     if (ctx->h_pub_slots < max_it + 1) {
         if (ctx->h_pub) (void) hipHostFree(ctx->h_pub);
         ctx->h_pub = nullptr;
