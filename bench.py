@@ -436,9 +436,10 @@ def main():
     step_ms = []
     for k in range(a.steps):
         # HIP events around every launch of the correspondence kernel cost a barrier packet
-        # each (~0.4 ms per registration), so they bracket the launches of ONE timed step in five
-        # (at least the last); the others run exactly as a caller's registration would
-        timed = (k % 5 == 4) or k == a.steps - 1
+        # each (~0.4 ms per registration), so they bracket the launches of ONE timed step in ten
+        # (at least the last: 50 launches, every iteration of one registration); the others run
+        # exactly as a caller's registration would
+        timed = (k % 10 == 9) or k == a.steps - 1
         t_step = time.perf_counter()
         r = step(1 if timed else 0)
         step_ms.append((time.perf_counter() - t_step) * 1e3)  # (align blocks: host time = step time)
