@@ -672,46 +672,53 @@ int finalize_clouds(wm_ctx *ctx, double max_corr, int nn_method) {
                               8 * sizeof(float) * ctx->tgt_bbox_blocks));
         }
     }
-    bool forked = false;
-    if (ctx->src_pending) {
+    // Both results are in: the target's grid ladder is enqueued FIRST (main stream), the source's Morton
+    // sort behind it on the side stream.  The preparation is bound by how fast the host can enqueue its
+    // ~55 small launches, not by the device: with the target's chain (the longer one on the device:
+    // ~250 us at 1M points) enqueued first, the device works through it while the host is still
+    // enqueueing the sort (sort first: the target's chain could not start before the sort's last launch
+    // had been issued -- ~100 us later).
+    const bool sort_src = ctx->src_pending;
+    size_t src_valid = 0;
+    if (sort_src) {
         ctx->src_pending = false;
         const float *res = (const float *) ctx->h_scratch;
-        size_t valid = 0;
-        finish_bbox(res, ctx->src_bbox_blocks, &ctx->src_bbox, &valid);
+        finish_bbox(res, ctx->src_bbox_blocks, &ctx->src_bbox, &src_valid);
         if (ctx->trace)
-            fprintf(stderr, "[wm] source: valid=%zu lo=(%g %g %g) hi=(%g %g %g)\n", valid, ctx->src_bbox.lo[0],
+            fprintf(stderr, "[wm] source: valid=%zu lo=(%g %g %g) hi=(%g %g %g)\n", src_valid, ctx->src_bbox.lo[0],
                     ctx->src_bbox.lo[1], ctx->src_bbox.lo[2], ctx->src_bbox.hi[0], ctx->src_bbox.hi[1],
                     ctx->src_bbox.hi[2]);
-        // the Morton sort of the source is independent of the target's grid build: side stream
-        hipStream_t main_stream = ctx->stream;
-        const bool side = ctx->tune_two_streams && ctx->side_stream && ctx->tgt_pending && max_corr > 0;
-        if (side) {
-            WM_HIP(ctx, hipEventRecord(ctx->ev_fork, main_stream));
-            WM_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
-            ctx->stream = ctx->side_stream;
-        }
-        const int rc = morton_sort(ctx, ctx->src_orig.as<float4>(), ctx->n_src_input, ctx->src_bbox, valid,
-                                   ctx->src_sorted.as<float4>());
-        ctx->stream = main_stream;
-        if (rc != WM_OK) return rc;
-        if (side) {
-            WM_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
-            forked = true;
-        }
-        ctx->n_src = valid;
-        WM_TRACE(ctx, "source: sorted");
     }
-    if (ctx->tgt_pending) {
+    const bool tgt_new = ctx->tgt_pending;
+    if (tgt_new) {
         ctx->tgt_pending = false;
         const float *res = (const float *) ctx->h_scratch + 8 * (size_t) kBboxBlocks;
         size_t valid = 0;
         finish_bbox(res, ctx->tgt_bbox_blocks, &ctx->tgt_bbox, &valid);
         ctx->n_tgt = valid;
     }
+    if (sort_src) ctx->n_src = src_valid;  // (the count of finite points: what the sort will leave in src_sorted)
+    hipStream_t main_stream = ctx->stream;
+    // the Morton sort of the source is independent of the target's grid build: side stream
+    const bool side = sort_src && ctx->tune_two_streams && ctx->side_stream && tgt_new && max_corr > 0;
+    if (side) {  // (the sort may start as soon as what is on the main stream NOW -- the packed clouds -- is done)
+        WM_HIP(ctx, hipEventRecord(ctx->ev_fork, main_stream));
+        WM_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+    }
     int rc = WM_OK;
-    if (max_corr > 0 && ctx->n_src > 0 && ctx->n_tgt > 0 && !use_brute(ctx, nn_method))
-        rc = ensure_levels(ctx, max_corr);
-    if (forked) WM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    if (max_corr > 0 && ctx->n_src > 0 && ctx->n_tgt > 0 && !use_brute(ctx, nn_method)) rc = ensure_levels(ctx, max_corr);
+    if (sort_src) {
+        if (side) ctx->stream = ctx->side_stream;
+        const int rc2 = morton_sort(ctx, ctx->src_orig.as<float4>(), ctx->n_src_input, ctx->src_bbox, src_valid,
+                                    ctx->src_sorted.as<float4>());
+        ctx->stream = main_stream;
+        if (rc2 != WM_OK) return rc2;
+        WM_TRACE(ctx, "source: sorted");
+        if (side) {
+            WM_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
+            WM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        }
+    }
     return rc;
 }
 
