@@ -213,10 +213,18 @@ __global__ void __launch_bounds__(kBlock) k_count(const float4 *pts, size_t n, K
     rank_of[i] = r;
 }
 
+// (thread 0 also writes the four NaN entries behind the last point: the search reads groups of four
+// entries and may run past the end of the last run -- see k_pad_tail, which does it for an empty level)
 __global__ void __launch_bounds__(kBlock) k_scatter(const float4 *pts, size_t n,
                                                      const unsigned *cell_of, const unsigned *rank_of,
-                                                     const unsigned *cell_start, float4 *out) {
+                                                     const unsigned *cell_start, float4 *out, size_t ncells) {
     size_t i = (size_t) blockIdx.x * kBlock + threadIdx.x;
+    if (i == 0) {
+        const unsigned end = cell_start[ncells];
+        const float nanv = __builtin_nanf("");
+#pragma unroll
+        for (int u = 0; u < 4; ++u) out[end + u] = make_float4(nanv, nanv, nanv, __uint_as_float(kNoIdx));
+    }
     if (i >= n) return;
     unsigned c = cell_of[i];
     if (c == kNoIdx) return;
@@ -302,12 +310,13 @@ __global__ void __launch_bounds__(kBlock) k_scan_add(unsigned *out, size_t n,
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *grand_total;
 }
 
-__global__ void k_scan_total(const unsigned *__restrict__ in, unsigned *out, size_t n) {
-    out[n] = out[n - 1] + in[n - 1];
-}
+struct ScanIn {  // in[i] for i < n, 0 at i = n (exclusive_scan below)
+    const unsigned *in;
+    size_t n;
+    __device__ unsigned operator()(size_t i) const { return i < n ? in[i] : 0u; }
+};
 
-// out must hold n+1 entries (out[n] = the total).  rocPRIM's single-pass look-back scan plus a
-// one-thread kernel for the total: 5 M cell counts in ~17 us against 41 us for the three-kernel
+// out must hold n+1 entries (out[n] = the total).  rocPRIM's single-pass look-back scan: 5 M cell counts in ~17 us against 41 us for the three-kernel
 // tiles / tile sums / add scan above (kept for `WM_TUNE_SCAN=0`).
 int exclusive_scan(wm_ctx *ctx, const unsigned *in, size_t n, unsigned *out) {
     if (n == 0) {
@@ -315,13 +324,15 @@ int exclusive_scan(wm_ctx *ctx, const unsigned *in, size_t n, unsigned *out) {
         return WM_OK;
     }
     if (ctx->tune_scan) {
+        // n + 1 items through an iterator that reads in[i] below n and 0 at n: out[n] comes out as the
+        // total, without a one-thread kernel behind the scan (a dependent launch of its own: ~5 us)
+        auto it = rocprim::make_transform_iterator(rocprim::counting_iterator<size_t>(0), ScanIn{in, n});
         size_t bytes = 0;
-        WM_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, n, rocprim::plus<unsigned>(),
+        WM_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, it, out, 0u, n + 1, rocprim::plus<unsigned>(),
                                             ctx->stream));
         WM_HIP(ctx, ctx->block_sums.reserve(bytes + 64));
-        WM_HIP(ctx, rocprim::exclusive_scan(ctx->block_sums.p, bytes, in, out, 0u, n,
+        WM_HIP(ctx, rocprim::exclusive_scan(ctx->block_sums.p, bytes, it, out, 0u, n + 1,
                                             rocprim::plus<unsigned>(), ctx->stream));
-        hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(1), 0, ctx->stream, in, out, n);
         WM_HIP(ctx, hipGetLastError());
         return WM_OK;
     }
@@ -352,7 +363,7 @@ static int counting_sort(wm_ctx *ctx, const float4 *pts, size_t n, KeyFn key, si
     WM_HIP(ctx, hipGetLastError());
     WM_TRY(exclusive_scan(ctx, counts, ncells, cell_start));
     hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, n, cell_of, rank_of,
-                       cell_start, out);
+                       cell_start, out, ncells);
     WM_HIP(ctx, hipGetLastError());
     return WM_OK;
 }
@@ -405,9 +416,9 @@ int build_grid_level(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, f
     } else {
         WM_HIP(ctx, hipMemsetAsync(lvl->cell_start.p, 0, (ncells + 1) * sizeof(unsigned),
                                    ctx->stream));
+        hipLaunchKernelGGL(k_pad_tail, dim3(1), dim3(64), 0, ctx->stream, lvl->cell_start.as<unsigned>(),
+                           (size_t) ncells, lvl->pts.as<float4>());
     }
-    hipLaunchKernelGGL(k_pad_tail, dim3(1), dim3(64), 0, ctx->stream, lvl->cell_start.as<unsigned>(),
-                       (size_t) ncells, lvl->pts.as<float4>());
     // float cell assignment can be off by the rounding of (p - origin) * inv_h:
     // keep a cell-unit margin in every geometric bound that relies on it.
     float extent = fmaxf(fmaxf(bb.hi[0] - bb.lo[0], bb.hi[1] - bb.lo[1]), bb.hi[2] - bb.lo[2]);
@@ -534,8 +545,14 @@ __global__ void __launch_bounds__(kBlock)
 __global__ void __launch_bounds__(kBlock)
     k_coarse_move(const unsigned *__restrict__ fs, const float4 *__restrict__ fpts, size_t fncells,
                   LinearKey key0, int shift, int fnx, int fny, int fnz, int cnx, int cny,
-                  const unsigned *__restrict__ cs, float4 *__restrict__ out) {
+                  const unsigned *__restrict__ cs, float4 *__restrict__ out, size_t cncells) {
     const unsigned j = blockIdx.x * kBlock + threadIdx.x;
+    if (j == 0) {  // the four NaN entries behind the last point (see k_scatter)
+        const unsigned end = cs[(size_t) cncells];
+        const float nanv = __builtin_nanf("");
+#pragma unroll
+        for (int u = 0; u < 4; ++u) out[end + u] = make_float4(nanv, nanv, nanv, __uint_as_float(kNoIdx));
+    }
     if (j >= fs[fncells]) return;
     const float4 p = fpts[j];
     int x = min(max((int) floorf((p.x - key0.ox) * key0.inv_h), 0), key0.nx - 1) >> shift;
@@ -573,10 +590,8 @@ static int derive_grid_level(wm_ctx *ctx, const GridLevel &fine, int fine_index,
         const unsigned pblocks = (unsigned) ((n + kBlock - 1) / kBlock);
         hipLaunchKernelGGL(k_coarse_move, dim3(pblocks), dim3(kBlock), 0, ctx->stream, f.cell_start,
                            f.pts, (size_t) fine.ncells, key0, fine_index, f.nx, f.ny, f.nz, nx, ny,
-                           lvl->cell_start.as<unsigned>(), lvl->pts.as<float4>());
+                           lvl->cell_start.as<unsigned>(), lvl->pts.as<float4>(), (size_t) ncells);
     }
-    hipLaunchKernelGGL(k_pad_tail, dim3(1), dim3(64), 0, ctx->stream, lvl->cell_start.as<unsigned>(),
-                       (size_t) ncells, lvl->pts.as<float4>());
     WM_HIP(ctx, hipGetLastError());
     lvl->d = f;
     lvl->d.h = 2.0f * f.h;  // exact in float
