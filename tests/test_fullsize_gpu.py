@@ -5,7 +5,9 @@ need the (far too slow) CPU oracle at that size:
               the FULL 1M target (bit-exact); 50 forced iterations land on the ground truth; a
               warm search at the final pose equals a cold one; an exact copy registers to 1e-6.
   configs[2]  GICP 500k<->500k recovers the ground-truth transform.
-  configs[3]  NDT 2M<->2M at 0.5 m voxels recovers the ground-truth transform.
+  configs[3]  NDT 2M<->2M at 0.5 m voxels recovers the ground-truth transform -- on the area-uniform
+              scene and on its 64-ring lidar sampling (KITTI-like: what bench.py times); ICP on that
+              sampling: grid = all-pairs on a sample, certified correspondences included.
   configs[4]  ICP 8M<->8M in 8 target slabs: one registration's statistics block, accumulated
               slab by slab on one GPU, equals the unsharded block (what the all-reduce would
               deliver), and every source point is owned by exactly one slab.
@@ -88,6 +90,44 @@ def test_ndt_2m_recovers_ground_truth(wm, ctx):
     assert r["rc"] == 0 and r["converged"] and r["n_voxels"] > 10000
     dt, ang = pose_error(r["T"], T_gt)
     assert dt < 1e-3 and ang < 1e-4, (dt, ang)
+
+
+def test_ndt_2m_64_ring_scan_recovers_ground_truth(wm, ctx):
+    """BASELINE configs[3] says KITTI-like: the 64-ring lidar sampling of the scene bench.py uses (dense
+    next to the sensor -- 1 700 points in the voxels there -- sparse far out), not the area-uniform one."""
+    ref, tgt, T_gt = synth.pair(2_000_000, seed=42, pattern="rings")
+    ctx.set_source(torch.from_numpy(ref).cuda())
+    ctx.set_target(torch.from_numpy(tgt).cuda())
+    r = ctx.ndt_align(res=0.5)
+    assert r["rc"] == 0 and r["converged"] and r["n_voxels"] > 10000
+    dt, ang = pose_error(r["T"], T_gt)
+    assert dt < 1e-3 and ang < 1e-4, (dt, ang)
+
+
+def test_icp_1m_64_ring_scan_grid_equals_all_pairs_on_a_sample(wm, ctx):
+    """Non-uniform density (hundreds of points of one scan line in a cell near the sensor, empty cells far
+    out): the grid search -- full and certified -- against the all-pairs search on a sample of the
+    queries, bit for bit; and the 50-iteration registration lands on ground truth."""
+    ref, tgt, T_gt = synth.pair(1_000_000, seed=42, pattern="rings")
+    d_tgt = torch.from_numpy(tgt).cuda()
+    sel = np.random.default_rng(5).choice(len(ref), 30000, replace=False)
+    ctx.set_source(ref[sel])
+    ctx.set_target(d_tgt)
+    gi, gd = ctx.nn_search(np.eye(4), max_corr=3.0, nn_method=wm.WM_NN_GRID)
+    bi, bd = ctx.nn_search(np.eye(4), max_corr=3.0, nn_method=wm.WM_NN_BRUTE)
+    assert np.array_equal(gi, bi) and np.array_equal(gd, bd)
+    ctx.set_source(torch.from_numpy(ref).cuda())
+    ctx.set_target(d_tgt)
+    r = ctx.icp_align(max_corr=3.0, force_iterations=50, nn_method=wm.WM_NN_GRID, carry_state=0)
+    assert r["rc"] == 0 and r["cert_launches"] > 0
+    dt, ang = pose_error(r["T"], T_gt)
+    assert dt < 1e-3 and ang < 1e-4, (dt, ang)
+    # the correspondences the certified iterations left = an all-pairs search of a sample under the final pose's predecessor
+    ci, cd = ctx.correspondences()
+    r49 = ctx.icp_align(max_corr=3.0, force_iterations=49, nn_method=wm.WM_NN_GRID, carry_state=0)
+    ctx.set_source(ref[sel])
+    bi, bd = ctx.nn_search(r49["T"], max_corr=3.0, nn_method=wm.WM_NN_BRUTE)
+    assert np.array_equal(ci[sel], bi)
 
 
 def test_icp_8m_slab_statistics_add_up(wm, ctx):
