@@ -733,13 +733,24 @@ struct GicpFn {
     // served evaluations (k_gicp_fdf_served resident for the minimisation under way)
     bool served = false;
     unsigned served_evals = 0;
+    int served_blocks = 0;  // this evaluator's share of the device's budget
     int served_total = 0, served_fallbacks = 0;
     double host_us[64] = {0};
 };
 
-// one served evaluator per device and process at a time: two resident kernels that each hold part of
-// the GPU while waiting for their hosts would keep each other's remaining workgroups from starting
-static std::atomic<int> g_serving[64];
+// Resident evaluators of one device and process share a budget of workgroups (what the device can keep
+// resident at once): two resident kernels that each hold part of the GPU while waiting for their
+// hosts must never keep each other's remaining workgroups from starting.  A 500k pair takes the whole
+// budget (256 workgroups); the matchers of a MultiMatcher pool working on 20k-point pairs (79
+// workgroups each) get three evaluators side by side, the others launch their evaluations meanwhile.
+static std::atomic<int> g_serving[64];  // workgroups of resident evaluators per device
+
+static bool serve_admit(int device, int nb, int capacity) {
+    int cur = g_serving[device].load();
+    while (cur + nb <= capacity)
+        if (g_serving[device].compare_exchange_weak(cur, cur + nb)) return true;
+    return false;
+}
 
 static int gicp_blocks(const wm_ctx *ctx) {
     int nb = (int) ((ctx->n_src + kBlock - 1) / kBlock);
@@ -803,8 +814,8 @@ static void serve_begin(GicpFn &F) {
         if (hipHostMalloc((void **) &ctx->h_gicp_slots, sizeof(GicpSlot) * 16, hipHostMallocDefault) != hipSuccess) return;
         memset(ctx->h_gicp_slots, 0, sizeof(GicpSlot) * 16);
     }
-    int expected = 0;
-    if (!g_serving[ctx->device].compare_exchange_strong(expected, 1)) return;
+    if (!serve_admit(ctx->device, nb, ctx->gicp_serve_capacity)) return;
+    F.served_blocks = nb;
     F.served_evals = 0;
     unsigned *ticket = (unsigned *) ((char *) ctx->gicp_mailbox.p + sizeof(GicpMailbox));
     unsigned long long *dbg = getenv("WM_GICP_SERVE_DEBUG") ? (unsigned long long *) ((char *) ctx->gicp_mailbox.p + 256) : nullptr;
@@ -820,7 +831,7 @@ static void serve_begin(GicpFn &F) {
                            ctx->match_pt.as<float4>(), ctx->gicp_mahal.as<double>(), (GicpMailbox *) ctx->gicp_mailbox.p,
                            ctx->gicp_serve_seq + 1u, ctx->partials.as<double>(), ticket, (GicpSlot *) ctx->h_gicp_slots, dbg);
     if (hipGetLastError() != hipSuccess) {
-        g_serving[ctx->device].store(0);
+        g_serving[ctx->device].fetch_sub(nb);
         return;
     }
     F.served = true;
@@ -844,7 +855,7 @@ static void serve_end(GicpFn &F) {
         }
     }
     F.served = false;
-    g_serving[ctx->device].store(0);
+    g_serving[ctx->device].fetch_sub(F.served_blocks);
 }
 
 // one served evaluation; false: no answer (the evaluator gave up or is stuck) -> it has been shut down

@@ -206,19 +206,20 @@ def test_served_evaluations_give_the_launched_ones_bits(wm):
         assert np.array_equal(a["T"], b["T"])
 
 
-def test_only_one_served_evaluator_per_device_at_a_time(wm):
-    """Two registrations running at once on one GPU (a MultiMatcher's workers): one of them is served,
-    the other falls back to launches while the evaluator is taken -- both get the same answer."""
+def test_concurrent_registrations_share_the_evaluator_budget(wm):
+    """Registrations running at once on one GPU (a MultiMatcher's workers): resident evaluators are admitted
+    while their workgroups fit the device together, the others launch their evaluations meanwhile --
+    every one of them gets the same answer."""
     import threading
     ref, tgt, _ = synth.pair(30000, seed=21, mode="resample")
     want = _gicp_run(wm, ref, tgt, 0)
-    out = [None, None]
+    out = [None] * 4
 
     def work(k):
         for _ in range(3):
             out[k] = _gicp_run(wm, ref, tgt, 1)
 
-    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
     for t in ts:
         t.start()
     for t in ts:
