@@ -1013,7 +1013,9 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
     const int nb = stat_blocks(ctx->n_src);
     ctx->iter_nn_ms.clear();
     WM_HIP(ctx, hipEventRecord(ctx->ev_a, ctx->stream));
-    // The host runs AHEAD of the device, never more than kLag iterations: every solve kernel publishes
+    // The host runs AHEAD of the device, never more than kLag iterations (2: one iteration in flight, one
+    // queued behind it -- 4 decided two iterations later when to certify, 3.72 vs 3.69 ms; 1 drains the
+    // queue between iterations, 4.04 ms): every solve kernel publishes
     // (done, iterations finished, the size of its step) in one word of pinned memory, and before
     // enqueueing iteration `it` the host waits until iteration it - kLag has been published.  The
     // device always has work queued (no pipeline drain, round 2: one every 8 iterations), iterations
@@ -1022,7 +1024,7 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
     // timing and a registration stays bit-reproducible): the full search (k_nn_grid) while the clouds
     // still move, the certificate kernel (k_nn_cert) once a step is a small fraction of a grid cell.
     // The choice changes the work, never the correspondences.
-    const int kLag = ctx->tune_lag >= 1 && ctx->tune_lag <= 16 ? ctx->tune_lag : 4;
+    const int kLag = ctx->tune_lag >= 1 && ctx->tune_lag <= 16 ? ctx->tune_lag : 2;
     if (ctx->h_pub_slots < max_it + 1) {
         if (ctx->h_pub) (void) hipHostFree(ctx->h_pub);
         ctx->h_pub = nullptr;

@@ -159,7 +159,7 @@ struct wm_ctx {
     bool trace = false;
     float tune_lane_lf = 0.2f;   // lane-serial scan: finest level with cell size >= this x radius
     float tune_coop_lf = 0.5f;   // cooperative scan: finest level with cell size >= this x radius
-    int tune_lag = 4;            // iterations the host may run ahead of the device (icp_run_loop)
+    int tune_lag = 2;            // iterations the host may run ahead of the device (icp_run_loop)
     float tune_r0 = 0.5f;        // first radius of an unseeded search, in level-0 cells
     float tune_r_light = 16.0f;  // lane-serial vs cooperative scan threshold, in level-0 cells (12-24 within 1 %)
     double tuned_h = 0, tuned_vol = 0;  // last auto-tuned level-0 cell size and its cloud
