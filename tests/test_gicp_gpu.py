@@ -250,3 +250,32 @@ def test_served_evaluator_gives_up_and_the_host_recovers(wm):
     assert 0 < got["served_evaluations"] < got["evaluations"]
     assert again["rc"] == 0 and np.array_equal(again["T"], want["T"])
     assert again["served_evaluations"] == again["evaluations"]
+
+
+@pytest.mark.parametrize("case", ["tiny", "partial-overlap", "beyond-the-on-chip-copy", "no-copy-variant"])
+def test_served_evaluations_corner_cases(wm, case):
+    """The resident evaluator against a launch per evaluation where its code paths differ: one
+    workgroup only; pairs without a match among the ones kept on chip; more than eight pairs per
+    thread (the ninth onwards streamed from HBM behind the on-chip ones); the variant that keeps
+    nothing on chip.  Identical matrix, objective and evaluation count every time."""
+    served = 1
+    kw = {}
+    if case == "tiny":
+        ref, tgt, _ = synth.pair(300, seed=31, mode="resample")
+    elif case == "partial-overlap":
+        ref, tgt, _ = synth.pair(30000, seed=32, mode="resample")
+        tgt = tgt[tgt[:, 0] < 10.0]          # a good part of the source has nothing within 5 m ... or barely
+        kw = dict(max_corr=1.0)
+    elif case == "beyond-the-on-chip-copy":
+        ref, tgt, _ = synth.pair(600000, seed=33)   # 256 workgroups x 256 threads x 8 pairs = 524 288 < 600 000
+    else:
+        ref, tgt, _ = synth.pair(50000, seed=34, mode="resample")
+        served = 2
+    a = _gicp_run(wm, ref, tgt, 0, **kw)
+    b = _gicp_run(wm, ref, tgt, served, **kw)
+    assert a["rc"] == b["rc"]
+    assert a["evaluations"] == b["evaluations"] and a["iterations"] == b["iterations"]
+    if a["rc"] == 0:
+        assert a["f"] == b["f"] and np.array_equal(a["T"], b["T"])
+    if b["evaluations"] > 0:
+        assert b["served_evaluations"] == b["evaluations"]
