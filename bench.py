@@ -32,6 +32,9 @@ import os
 # (cgroup cpu.stat: nr_throttled) -- seen as one 50-90 ms registration per run.
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ.setdefault(_v, "4")
+# multi-process GPU work on these hosts needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails otherwise); the
+# driver's environment exports it -- kept here too, for a launch line that does not
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import sys
 import threading
 import time
