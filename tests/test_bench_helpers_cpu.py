@@ -1,0 +1,26 @@
+"""bench.py's counter-traffic plumbing (no GPU): the committed PMC summary carries FETCH / WRITE for the
+kernels the line quotes, and the helper turns them into bytes per launch and a share of the copy rate."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_committed_pmc_summary_covers_the_quoted_kernels():
+    import bench
+    pmc = bench.pmc_summary()
+    assert pmc.get("tag"), "profiles/pmc_latest.json missing or without a tag"
+    for k in ("k_nn_grid", "k_nn_cert", "k_gicp_fdf", "k_ndt_derivs"):
+        assert "FETCH_SIZE_kb_per_dispatch" in pmc.get(k, {}), k
+        assert "WRITE_SIZE_kb_per_dispatch" in pmc.get(k, {}), k
+    assert pmc["k_ndt_derivs"].get("f64_flops_per_source_point", 0) > 100
+
+
+def test_counter_traffic_arithmetic():
+    import bench
+    pmc = {"tag": "t", "k": {"FETCH_SIZE_kb_per_dispatch": 1000.0, "WRITE_SIZE_kb_per_dispatch": 500.0}}
+    out = bench.counter_traffic(pmc, "k", avg_launch_us=10.0, copy_peak_gbs=5000.0)
+    assert out["traffic"] == (2 * 1000.0 + 500.0) * 1024.0          # FETCH doubled on gfx950, WRITE as reported
+    assert abs(out["hbm_util"] - out["traffic"] / 10e-6 / 1e9 / 5000.0) < 1e-12
+    assert bench.counter_traffic(pmc, "absent", 10.0, 5000.0) == {"traffic": None}
