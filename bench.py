@@ -9,7 +9,8 @@
            solve, all on device).  The same registration from HOST clouds (H2D inside the
            step, pageable and pinned) is reported beside it in config.host_clouds; it is
            never `value`.
-  N > 1  : one process per GPU.  The registration is sharded INSIDE the library
+  N > 1  : one process per GPU (launched plainly, `python bench.py --gpus N` re-executes itself under
+           torch.distributed.run on 127.0.0.1).  The registration is sharded INSIDE the library
            (wm_icp_align_sharded, libwave_amd/csrc/wm_shard.hip): slab planning on the
            device, the iteration loop in C++, one ncclAllReduce (RCCL over xGMI) of 32
            doubles per iteration on the context's stream.  torch.distributed only carries
@@ -148,14 +149,36 @@ def cpu_baseline(ref, tgt, iters_full, max_corr, cpu_iters):
     return out
 
 
+def csrc_sha256():
+    """sha256 over the kernel sources (libwave_amd/csrc/*.hip, *.hpp, in name order): what a committed counter
+    capture is stamped with (scripts/pmc_to_json.py) and checked against here."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "libwave_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
 def pmc_summary():
     """Committed PMC summary of this bench command (profiles/pmc_latest.json, written by
-    scripts/gpu_pmc.sh + scripts/pmc_to_json.py from separate rocprofv3 --pmc passes)."""
+    scripts/gpu_pmc.sh + scripts/pmc_to_json.py from separate rocprofv3 --pmc passes).  A capture whose
+    source stamp differs from the kernels in the tree is STALE: it is returned empty (every `traffic` /
+    `hbm_util` derived from it becomes null) with the reason under "stale"."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-            return json.load(f)
+            pmc = json.load(f)
     except Exception:
         return {}
+    stamp = pmc.get("csrc_sha256")
+    if stamp is not None and stamp != csrc_sha256():
+        return {"stale": "profiles/pmc_latest.json (tag %s) was captured from other kernel sources "
+                         "(csrc_sha256 %s..., tree %s...): traffic not reported" % (pmc.get("tag"), stamp[:12],
+                                                                                   csrc_sha256()[:12])}
+    return pmc
 
 
 def pmc_traffic_bytes(pmc, kernel="k_nn_grid"):
@@ -366,6 +389,22 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu, copy_peak=None):
     return out
 
 
+def relaunch(n):
+    """`python bench.py --gpus N` without a launcher: exec `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`."""
+    import socket
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    argv = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, argv)
+
+
 def main():
     a = parse()
     import torch
@@ -373,11 +412,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (a.gpus, a.gpus))
+        if world == 1 and a.gpus > 1 and "RANK" not in os.environ:
+            # launched plainly (`python bench.py --gpus N`): become the launcher -- one process per GPU under
+            # torch.distributed.run, exactly the line the driver uses, rendezvous on 127.0.0.1
+            relaunch(a.gpus)
         a.gpus = world
+    if os.environ.get("WM_BENCH_DRY_LAUNCH") == "1":
+        # launch-line check (tests/test_bench_launch_cpu.py, no GPU needed): the ranks exist, find each other
+        # and agree on the world -- everything up to the communicator's set-up -- and stop there
+        t = torch.tensor([rank], dtype=torch.int64)
+        if "RANK" in os.environ:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+            dist.all_reduce(t)
+            dist.destroy_process_group()
+        print("dry-launch rank %d of %d: ranks sum %d" % (rank, world, int(t.item())), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
+    if torch.cuda.device_count() < world and "LOCAL_RANK" in os.environ and local_rank >= torch.cuda.device_count():
+        raise SystemExit("--gpus %d: this node shows %d HIP devices" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     force_sharded = os.environ.get("WM_BENCH_FORCE_SHARDED") == "1"  # plumbing check at N=1
@@ -524,7 +578,8 @@ def main():
             "traffic": traffic,
             "hbm_util": (traffic / (nn_us * 1e-6) / 1e9 / peak_copy) if (traffic and peak_copy) else None,
             "traffic_source": ("profiles/pmc_latest.json, tag %s (separate rocprofv3 --pmc passes of this "
-                               "command; a committed measurement, not this run's)" % pmc.get("tag")) if pmc else None,
+                               "command; a committed measurement, not this run's; its csrc_sha256 stamp matches "
+                               "the kernels in the tree)" % pmc.get("tag")) if pmc.get("tag") else pmc.get("stale"),
             "peak_measured_copy": peak_copy,
             "peak_measured_copy_method": "float4 grid-stride copy kernel, 1 GiB in + 1 GiB out, 10 launches (wm_debug_copy_bandwidth)",
             "algorithmic_bytes_per_launch": alg_bytes,

@@ -818,6 +818,17 @@ static void serve_begin(GicpFn &F) {
     F.served_blocks = nb;
     F.served_evals = 0;
     unsigned *ticket = (unsigned *) ((char *) ctx->gicp_mailbox.p + sizeof(GicpMailbox));
+    // A round that ended in a fallback can leave the ticket counter above 0 (workgroups that left by their
+    // guard, or saw a command past their own, never drew one) and `abandoned` set: the next evaluator would
+    // then see its "last" ticket one workgroup early and add rows of the previous evaluation.  Both words
+    // (and the padding between them; NOT the command number) go back to 0 on the stream before every launch.
+    static_assert(offsetof(GicpMailbox, abandoned) + 6 * sizeof(unsigned) == sizeof(GicpMailbox), "layout");
+    if (hipMemsetAsync((char *) ctx->gicp_mailbox.p + offsetof(GicpMailbox, abandoned), 0,
+                       sizeof(GicpMailbox) - offsetof(GicpMailbox, abandoned) + sizeof(unsigned), ctx->stream) != hipSuccess) {
+        (void) hipGetLastError();
+        g_serving[ctx->device].fetch_sub(nb);
+        return;
+    }
     unsigned long long *dbg = getenv("WM_GICP_SERVE_DEBUG") ? (unsigned long long *) ((char *) ctx->gicp_mailbox.p + 256) : nullptr;
     if (ctx->gicp_serve_cached && ctx->tune_gicp_served != 2)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gicp_fdf_served<kServeCached>), dim3(nb), dim3(kBlock),
@@ -844,6 +855,12 @@ static void serve_end(GicpFn &F) {
     wm_ctx *ctx = F.ctx;
     serve_post(ctx, nullptr, 2u);
     (void) hipStreamSynchronize(ctx->stream);
+    if (F.served_fallbacks > 0) {
+        // (diagnostic, after a fallback only: a read through the BAR is a PCIe round trip) did workgroups leave by themselves?
+        const unsigned ab = ((volatile GicpMailbox *) ctx->gicp_mailbox.p)->abandoned;
+        if (ab && ctx->trace) fprintf(stderr, "[wm] gicp: resident evaluator abandoned a round (guard / late workgroups)\n");
+        ctx->gicp_serve_abandoned += ab ? 1 : 0;
+    }
     if (getenv("WM_GICP_SERVE_DEBUG")) {  // developer: device-side stamps of the first rounds (100 MHz ticks)
         unsigned long long d[64 * 4];
         if (hipMemcpy(d, (char *) ctx->gicp_mailbox.p + 256, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess) {

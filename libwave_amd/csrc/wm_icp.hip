@@ -174,7 +174,8 @@ __global__ void __launch_bounds__(kBlock)
 template <int PHASES, int THREADS>
 __global__ void __launch_bounds__(THREADS)
     k_reduce_solve(const double *__restrict__ partials, int nblocks, IcpDevState *st,
-                   double *stats_io, unsigned long long *pub, int pub_slots) {
+                   double *stats_io, unsigned long long *pub, int pub_slots, int blk_ext) {
+    // (blk_ext: stats_io is the sharded loop's kBlkLen block, not a caller's WM_STATS_LEN one)
     // The solve runs in ONE lane and touches two dozen fields of the state: read from HBM one
     // dependent access at a time that is most of this kernel's ~10 us.  So the whole state is
     // staged in LDS by all threads (one round trip), worked on there, and written back whole.
@@ -265,7 +266,7 @@ __global__ void __launch_bounds__(THREADS)
 #pragma unroll
             for (int k = 0; k < kAcc; ++k) a[k] = tot[k];
             double ex[kStatsLen];
-            expand_stats(s_st.mode, a, ex);
+            expand_stats(s_st.mode, a, ex, s_st.changed_mask);
             s_st.local_handled = ex[kStatsLen - 1];
 #pragma unroll
             for (int k = 0; k < kStatsLen; ++k) s_st.stats[k] = ex[k];
@@ -273,17 +274,25 @@ __global__ void __launch_bounds__(THREADS)
                 ex[kStatsLen - 2] = s_st.stripe_finite;  // (a free slot of either layout: summed, it is the cloud's count)
 #pragma unroll
                 for (int k = 0; k < kStatsLen; ++k) stats_io[k] = ex[k];
+                // (the searches this rank's certificate launch made: summed over the ranks, so that every
+                // rank's host steers by the same share and picks the same kernel)
+                if (blk_ext) {
+                    stats_io[kStatsLen] = (double) s_uns;
+                    stats_io[kStatsLen + 1] = 0.0;
+                }
             }
         } else if (stats_io) {  // PHASES == 2: the all-reduced block comes in
 #pragma unroll
             for (int k = 0; k < kStatsLen; ++k) s_st.stats[k] = stats_io[k];
+            s_st.uns_global = blk_ext ? 1 : 0;
         }
         if (PHASES & 2) {
             double stats[kStatsLen];
 #pragma unroll
             for (int k = 0; k < kStatsLen; ++k) stats[k] = s_st.stats[k];
             s_st.dbg[2] = clock64();
-            icp_apply_stats(&s_st, stats, (long long) s_uns);
+            const long long uns_total = (PHASES == 2 && stats_io && blk_ext) ? (long long) stats_io[kStatsLen] : (long long) s_uns;
+            icp_apply_stats(&s_st, stats, uns_total);
             // what the host steers by while it runs ahead of the device (wm_icp_align): one 8-byte word in
             // pinned memory -- done flag, iterations finished, the step's size -- in ONE system-scope store
             // (pub[0]: the latest; pub[k]: iteration k's own record, so that what the host decides from
@@ -299,8 +308,10 @@ __global__ void __launch_bounds__(THREADS)
                 if (s_st.iter >= 1 && s_st.iter <= pub_slots)
                     __hip_atomic_store(pub + s_st.iter, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 // ([0]: bit 0 = done)
-                __hip_atomic_store(pub, (unsigned long long) (s_st.done ? 1u : 0u), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_SYSTEM);
+                // ([0]: bit 0 = done, above it the number of iterations finished by then -- ONE word, so that a
+                // host that sees `done` before the last record knows whether that record is still to come)
+                __hip_atomic_store(pub, s_st.done ? (1ull | ((unsigned long long) (unsigned) s_st.iter << 1)) : 0ull,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
         s_st.dbg[3] = clock64();
@@ -373,7 +384,7 @@ static int launch_stats(wm_ctx *ctx, int mode) {
 // Sum `rows` partial rows (ctx->partials) and run the requested phases of the iteration's solve.
 template <int PHASES>
 static int launch_reduce_solve(wm_ctx *ctx, unsigned rows, double *stats_io, unsigned long long *pub = nullptr,
-                               int pub_slots = 0) {
+                               int pub_slots = 0, int blk_ext = 0) {
     IcpDevState *st = ctx->d_state.as<IcpDevState>();
     const double *part = ctx->partials.as<double>();
     if (rows > 2048u) {  // one workgroup cannot add that many rows quickly: 128 rows -> 1 first
@@ -386,10 +397,10 @@ static int launch_reduce_solve(wm_ctx *ctx, unsigned rows, double *stats_io, uns
     }
     if (rows > 512u)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<PHASES, 1024>), dim3(1), dim3(1024), 0, ctx->stream,
-                           part, (int) rows, st, stats_io, pub, pub_slots);
+                           part, (int) rows, st, stats_io, pub, pub_slots, blk_ext);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<PHASES, kBlock>), dim3(1), dim3(kBlock), 0, ctx->stream,
-                           part, (int) rows, st, stats_io, pub, pub_slots);
+                           part, (int) rows, st, stats_io, pub, pub_slots, blk_ext);
     WM_HIP(ctx, hipGetLastError());
     return WM_OK;
 }
@@ -434,6 +445,7 @@ static void init_state(IcpDevState *s, const double *T, const wm_icp_params *p, 
 }
 
 static int upload_state(wm_ctx *ctx) {
+    ctx->h_state->changed_mask = changed_mask_for((unsigned) ctx->n_src);
     WM_HIP(ctx, hipMemcpyAsync(ctx->d_state.p, ctx->h_state, sizeof(IcpDevState),
                                hipMemcpyHostToDevice, ctx->stream));
     return WM_OK;
@@ -1064,7 +1076,13 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
                     parse(w);
                     break;
                 }
-                if ((pub[0] & 1ull) != 0ull) {
+                // done -- and the record waited for is not one the device wrote before it stopped: nothing more
+                // will come.  (The last record and the done word are two relaxed stores of one kernel: seeing
+                // `done` first must not end the loop one iteration early -- in the sharded loop every enqueued
+                // iteration carries a collective, and all ranks have to issue the same number of them: exactly
+                // iterations-finished + kLag.)
+                const unsigned long long p0 = pub[0];
+                if ((p0 & 1ull) != 0ull && need > (unsigned) (p0 >> 1)) {
                     seen_done = true;
                     break;
                 }
@@ -1149,16 +1167,16 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
         if (blk) {
             // sharded: this rank's sums -> all-reduce of the block over the ranks (RCCL on this stream) ->
             // the same solve on every rank
-            WM_TRY(launch_reduce_solve<1>(ctx, rows, blk));
+            WM_TRY(launch_reduce_solve<1>(ctx, rows, blk, nullptr, 0, 1));
             hipEvent_t ea = nullptr, eb = nullptr;
             if (p->profile) {
                 ea = get_event(ctx, ev_ar++);
                 eb = get_event(ctx, ev_ar++);
                 WM_HIP(ctx, hipEventRecord(ea, ctx->stream));
             }
-            WM_TRY(comm_allreduce(ctx, comm, blk, WM_STATS_LEN));
+            WM_TRY(comm_allreduce(ctx, comm, blk, kBlkLen));
             if (eb) WM_HIP(ctx, hipEventRecord(eb, ctx->stream));
-            WM_TRY(launch_reduce_solve<2>(ctx, 0, blk, ctx->h_pub, ctx->h_pub_slots));
+            WM_TRY(launch_reduce_solve<2>(ctx, 0, blk, ctx->h_pub, ctx->h_pub_slots, 1));
         } else {
             WM_TRY(launch_reduce_solve<3>(ctx, rows, nullptr, ctx->h_pub, ctx->h_pub_slots));
         }

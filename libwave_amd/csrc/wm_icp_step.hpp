@@ -11,13 +11,21 @@
 namespace wm {
 
 // expand the 17 compact accumulators to the public 32-slot layout
-__device__ __host__ inline void expand_stats(int mode, const double *a, double *st) {
+// every (mask + 1)-th query reports whether its match changed: mask = 2^s - 1 with the smallest s for which
+// n >> s < 2^23 (0 for every cloud below 8.4M points)
+__device__ __host__ inline unsigned changed_mask_for(unsigned n) {
+    unsigned s = 0;
+    while ((n >> s) >= (1u << 23)) ++s;
+    return (1u << s) - 1u;
+}
+
+__device__ __host__ inline void expand_stats(int mode, const double *a, double *st, unsigned changed_mask = 0u) {
 #pragma unroll
     for (int k = 0; k < kStatsLen; ++k) st[k] = 0.0;
     // source points handled (ownership check of the sharded path), and -- the fraction of a[17], in
     // units of 2^-24 -- how many of them changed their match (a free slot of either layout)
     st[kStatsLen - 1] = floor(a[17]);
-    st[kStatsLen - 3] = (a[17] - floor(a[17])) * 16777216.0;
+    st[kStatsLen - 3] = (a[17] - floor(a[17])) * 16777216.0 * (double) (changed_mask + 1u);
     if (mode == WM_ICP_SVD) {
         st[kSvdN] = a[0];
         for (int k = 0; k < 3; ++k) st[kSvdSp + k] = a[1 + k];
@@ -91,7 +99,7 @@ __host__ __device__ inline void icp_apply_stats(IcpDevState *st, const double *s
             }
         }
         // (sharded: `handled` is the all-reduced count, the searches counted are this rank's own)
-        const double mine = st->local_handled > 0 ? st->local_handled : handled;
+        const double mine = (st->local_handled > 0 && !st->uns_global) ? st->local_handled : handled;
         st->frac_changed = handled > 0 ? (float) (stats[kStatsLen - 3] / handled) : 0.f;
         st->frac_unsettled = mine > 0 ? (float) ((double) uns / mine) : 0.f;  // (0 after a full search: nothing counted)
     }

@@ -17,6 +17,9 @@ namespace wm {
 constexpr int kMaxLevels = 6;
 constexpr int kBlock = 256;
 constexpr unsigned kNoIdx = 0xFFFFFFFFu;
+// all-reduced block of the sharded loop: the public WM_STATS_LEN slots + [kStatsLen]: queries the certificate
+// kernel searched on this rank (summed: every rank steers by the same share) + one spare
+constexpr int kBlkLen = 34;
 constexpr int kAcc = 18;  // ICP statistics per partial row: 17 sums + the number of source points this rank handled
 
 // ----------------------------------------------------------- error handling
@@ -122,6 +125,11 @@ struct IcpDevState {
     float step_disp;   // upper estimate of how far the last step moved the source points (metres)
     float src_radius;  // half diagonal of the source cloud's bounding box (for step_disp)
     float src_centre[3];
+    // the count of changed matches rides in the fraction of the handled-points sum (units of 2^-24, wm_nn.hip:
+    // icp_terms); beyond 2^23 queries per context only every (changed_mask + 1)-th query is counted, so
+    // that the fraction can never carry into the integer part, and the count is scaled back up here
+    unsigned changed_mask;
+    int uns_global;  // sharded: the count of searched queries came through the all-reduced block (all ranks steer alike)
 };
 
 struct Bbox {
@@ -194,6 +202,7 @@ struct wm_ctx {
     // served GICP evaluations (wm_gicp.hip): the mailbox in device memory the host writes through the BAR
     wm::DevBuf gicp_mailbox;
     unsigned gicp_serve_seq = 0;
+    unsigned gicp_serve_abandoned = 0;      // rounds after which the evaluator's `abandoned` word was found set (diagnostic)
     int gicp_serve_ok = 0, gicp_serve_capacity = 0, gicp_serve_cached = 0;  // 0: not tried yet, 1: usable, -1: not on this system
     int tune_gicp_served = 1;             // 0: a kernel launch per evaluation; 1: resident evaluator; 2: ... without the on-chip copy of the pairs
     int gicp_serve_test_stall_ms = 0;     // test hook: the host sleeps this long before its third served evaluation

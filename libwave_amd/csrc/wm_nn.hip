@@ -828,9 +828,11 @@ __device__ __forceinline__ unsigned long long coop_scan_box(const GridDev &g, fl
 // (the wave reduction by recursive halving: wm_wave.hpp)
 
 // this lane's terms of the iteration's sums (same arithmetic as k_icp_stats, wm_icp.hip)
-// a[17] counts the queries this rank handled; its fraction (units of 2^-24: exact in a double for any
-// cloud a context can hold) counts those whose match CHANGED in this search -- what the host decides
-// by whether the next searches can be certified instead (wm_icp_align).
+// a[17] counts the queries this rank handled; its fraction (units of 2^-24) counts those whose match
+// CHANGED in this search -- what the host decides by whether the next searches can be certified instead
+// (wm_icp_align).  Exact in a double, and never carrying into the integer part, because at most 2^23
+// queries report: beyond that size only every (IcpDevState::changed_mask + 1)-th does (changed_mask_for,
+// wm_icp_step.hpp) and the solve scales the count back up.
 constexpr double kChangedUnit = 1.0 / 16777216.0;
 template <int STATS>
 __device__ __forceinline__ void icp_terms(double (&a)[kAcc], bool mine, bool matched, float qx, float qy, float qz,
@@ -1113,7 +1115,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
     if constexpr (STATS >= 0) {
         double a[kAcc];
         icp_terms<STATS>(a, mine, (unsigned) best != kNoIdx, qx, qy, qz, bqx, bqy, bqz,
-                         __uint_as_float((unsigned) (best >> 32)), (unsigned) best != (unsigned) seeded);
+                         __uint_as_float((unsigned) (best >> 32)),
+                         (unsigned) best != (unsigned) seeded && (i_e & st->changed_mask) == 0u);
         acc_halve<kAcc, 32>(a, lane);
         const int comp = acc_comp_of_lane(lane);
         if (comp >= 0) st_f64(&partials[(size_t) row * kAcc + comp], a[0], nt);
@@ -1221,6 +1224,7 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
     // it stays consistent for the day it comes back)
     const bool slab_on = st->slab_on != 0;
     const float slab_lo = st->slab_lo, slab_hi = st->slab_hi;
+    const unsigned changed_mask = st->changed_mask;
     const int comp = acc_comp_of_lane(lane);
     double rowacc = 0.0;
     unsigned n_uns = 0;  // (wave-uniform)
@@ -1567,7 +1571,8 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
         if constexpr (STATS >= 0) {
             double a[kAcc];
             icp_terms<STATS>(a, mine, (unsigned) best != kNoIdx, qx, qy, qz, bqx, bqy, bqz,
-                             __uint_as_float((unsigned) (best >> 32)), (unsigned) best != (unsigned) seeded);
+                             __uint_as_float((unsigned) (best >> 32)),
+                             (unsigned) best != (unsigned) seeded && (i & changed_mask) == 0u);
             acc_halve<kAcc, 32>(a, lane);
             rowacc += comp >= 0 ? a[0] : 0.0;
         }

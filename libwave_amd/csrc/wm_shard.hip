@@ -549,7 +549,7 @@ static int align_sharded_impl(wm_ctx *ctx, wm_comm *comm, const void *ref, size_
         WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const auto t_host1 = std::chrono::steady_clock::now();
         // ---- the iteration loop: search + local sums -> all-reduce of the block -> solve (wm_icp.hip)
-        WM_HIP(ctx, ctx->shard_stats.reserve(WM_STATS_LEN * sizeof(double)));
+        WM_HIP(ctx, ctx->shard_stats.reserve(kBlkLen * sizeof(double)));
         double T[16];
         wm_icp_stats it_st;
         memset(&it_st, 0, sizeof(it_st));  // (the loop ADDS its event times into the block)

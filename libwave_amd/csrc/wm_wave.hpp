@@ -5,6 +5,12 @@
 
 #include "wm_internal.hpp"
 
+// v_permlane32_swap / v_permlane16_swap exist on gfx950 only, and this library is written for gfx950
+// only (CMakeLists.txt and the Makefile pin it): say so instead of failing inside a builtin.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "wavematch-hip targets gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+
 namespace wm {
 
 // Wave reduction of kAcc doubles by recursive halving: at the step for lane bit M a lane keeps one

@@ -20,6 +20,13 @@ for name in ("fetch", "write", "sq", "tcc"):
         unit = "_kb" if counter in ("FETCH_SIZE", "WRITE_SIZE") else ""
         d[counter + unit + "_per_dispatch"] = float(per)
 out["tag"] = os.path.basename(os.path.normpath(tag_dir))
+# the kernel sources this capture belongs to: bench.py drops the traffic figures when the tree differs
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+try:
+    import bench
+    out["csrc_sha256"] = bench.csrc_sha256()
+except Exception as e:  # (never lose a capture over the stamp)
+    print("no source stamp:", e)
 # optional third argument: the NDT counter directory (scripts/gpu_pmc_ndt.sh): f64 flops per source point
 # of the derivative kernel = (ADD + MUL + 2 FMA) wave-instructions x 64 lanes x the active-lane fraction
 if len(sys.argv) > 3:

@@ -8,9 +8,11 @@ sys.path.insert(0, ROOT)
 
 
 def test_committed_pmc_summary_covers_the_quoted_kernels():
-    import bench
-    pmc = bench.pmc_summary()
+    import json
+    with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+        pmc = json.load(f)
     assert pmc.get("tag"), "profiles/pmc_latest.json missing or without a tag"
+    assert len(pmc.get("csrc_sha256", "")) == 64, "capture not stamped with the kernel sources' hash"
     for k in ("k_nn_grid", "k_nn_cert", "k_gicp_fdf", "k_ndt_derivs"):
         assert "FETCH_SIZE_kb_per_dispatch" in pmc.get(k, {}), k
         assert "WRITE_SIZE_kb_per_dispatch" in pmc.get(k, {}), k
@@ -24,3 +26,27 @@ def test_counter_traffic_arithmetic():
     assert out["traffic"] == (2 * 1000.0 + 500.0) * 1024.0          # FETCH doubled on gfx950, WRITE as reported
     assert abs(out["hbm_util"] - out["traffic"] / 10e-6 / 1e9 / 5000.0) < 1e-12
     assert bench.counter_traffic(pmc, "absent", 10.0, 5000.0) == {"traffic": None}
+
+
+def test_stale_capture_reports_no_traffic(tmp_path, monkeypatch):
+    """A capture stamped with other kernel sources than the tree's must not be quoted."""
+    import json
+    import bench
+    fake = tmp_path / "profiles"
+    fake.mkdir()
+    (fake / "pmc_latest.json").write_text(json.dumps({
+        "tag": "old", "csrc_sha256": "0" * 64,
+        "k_nn_grid": {"FETCH_SIZE_kb_per_dispatch": 1.0, "WRITE_SIZE_kb_per_dispatch": 1.0}}))
+    real_root = bench.ROOT
+    real_hash = bench.csrc_sha256()
+    monkeypatch.setattr(bench, "csrc_sha256", lambda: real_hash)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    stale = bench.pmc_summary()
+    assert "stale" in stale and "tag" not in stale
+    assert bench.pmc_traffic_bytes(stale, "k_nn_grid") is None
+    assert bench.counter_traffic(stale, "k_nn_grid", 10.0, 5000.0) == {"traffic": None}
+    (fake / "pmc_latest.json").write_text(json.dumps({
+        "tag": "new", "csrc_sha256": real_hash,
+        "k_nn_grid": {"FETCH_SIZE_kb_per_dispatch": 1.0, "WRITE_SIZE_kb_per_dispatch": 1.0}}))
+    assert bench.pmc_summary().get("tag") == "new"
+    monkeypatch.setattr(bench, "ROOT", real_root)

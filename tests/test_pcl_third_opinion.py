@@ -14,7 +14,11 @@ import golden_checks as G
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOOL = os.path.join(ROOT, "oracle", "_ref", "pcl_third_opinion")
 
-pytestmark = pytest.mark.skipif(not os.path.exists(TOOL), reason="no system PCL: oracle/pcl_ref not built")
+pytestmark = pytest.mark.skipif(
+    not os.path.exists(TOOL),
+    reason="no system PCL: oracle/pcl_ref not built -- parity stays UNPINNED by the reference.  The one command "
+           "that flips it to pinned, on a box with network: `sudo apt-get install -y libpcl-dev pkg-config && "
+           "make -C oracle/pcl_ref && python -m pytest tests/test_pcl_third_opinion.py -q` (oracle/pcl_ref/README.md)")
 
 
 def _pcl(kind, ref, tgt, res=None):
