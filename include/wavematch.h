@@ -146,6 +146,11 @@ typedef struct {
     unsigned n_tgt_local, n_src_local; /* points this rank indexed / searched */
     int rccl_ranks;      /* ncclCommCount of the communicator (0: none or the in-process stand-in) */
     int shard_attempts;  /* 2 if the registration had to be redone with full source clouds */
+    /* the resident late-iteration kernel (k_nn_cert<.., LATE>: certificate, searches, sums, solve and
+       stopping rules of the late iterations in ONE launch; counted in cert_launches too) */
+    int late_iterations; /* iterations that ran inside it */
+    int late_launches;   /* its launches (1, unless its own policy sent it back to full searches in between) */
+    float late_ms;       /* their duration by HIP events (profile >= 1): search + sums + solve of those iterations */
 } wm_icp_stats;
 
 void wm_icp_default_params(wm_icp_params *p);

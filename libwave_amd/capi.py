@@ -48,7 +48,8 @@ class IcpStats(C.Structure):
                 ("owned_violations", C.c_int), ("cert_launches", C.c_int), ("nn_cert_ms", C.c_float),
                 ("plan_ms", C.c_float), ("compact_ms", C.c_float), ("index_ms", C.c_float), ("iter_ms", C.c_float),
                 ("allreduce_ms", C.c_float), ("n_tgt_local", C.c_uint), ("n_src_local", C.c_uint),
-                ("rccl_ranks", C.c_int), ("shard_attempts", C.c_int)]
+                ("rccl_ranks", C.c_int), ("shard_attempts", C.c_int),
+                ("late_iterations", C.c_int), ("late_launches", C.c_int), ("late_ms", C.c_float)]
 
 
 class BatchItem(C.Structure):
@@ -356,7 +357,8 @@ class Context:
                     solve_ms=s.solve_ms, nn_launches=s.nn_launches, nn_levels=s.nn_levels,
                     deferred=s.deferred, grid_cell=s.grid_cell,
                     owned_violations=s.owned_violations, cert_launches=s.cert_launches,
-                    nn_cert_ms=s.nn_cert_ms)
+                    nn_cert_ms=s.nn_cert_ms, late_iterations=s.late_iterations, late_launches=s.late_launches,
+                    late_ms=s.late_ms)
 
     def icp_match(self, ref, target, res=-1.0, multiscale_steps=0, params=None, **kw):
         """ICPMatcher::match() (icp.cpp:75-133) in one C-ABI call."""

@@ -733,7 +733,7 @@ struct GicpFn {
     // served evaluations (k_gicp_fdf_served resident for the minimisation under way)
     bool served = false;
     unsigned served_evals = 0;
-    int served_blocks = 0;  // this evaluator's share of the device's budget
+    int served_blocks = 0;  // this evaluator's share of the device's budget (1/1024ths)
     int served_total = 0, served_fallbacks = 0;
     double host_us[64] = {0};
 };
@@ -743,15 +743,7 @@ struct GicpFn {
 // hosts must never keep each other's remaining workgroups from starting.  A 500k pair takes the whole
 // budget (256 workgroups); the matchers of a MultiMatcher pool working on 20k-point pairs (79
 // workgroups each) get three evaluators side by side, the others launch their evaluations meanwhile.
-static std::atomic<int> g_serving[64];  // workgroups of resident evaluators per device
-
-static bool serve_admit(int device, int nb, int capacity) {
-    int cur = g_serving[device].load();
-    while (cur + nb <= capacity)
-        if (g_serving[device].compare_exchange_weak(cur, cur + nb)) return true;
-    return false;
-}
-
+// (the budget itself: resident_admit / resident_release, wm_nn.hip -- shared with the resident ICP kernel)
 static int gicp_blocks(const wm_ctx *ctx) {
     int nb = (int) ((ctx->n_src + kBlock - 1) / kBlock);
     if (nb > ctx->tune_gicp_blocks) nb = ctx->tune_gicp_blocks;
@@ -814,8 +806,9 @@ static void serve_begin(GicpFn &F) {
         if (hipHostMalloc((void **) &ctx->h_gicp_slots, sizeof(GicpSlot) * 16, hipHostMallocDefault) != hipSuccess) return;
         memset(ctx->h_gicp_slots, 0, sizeof(GicpSlot) * 16);
     }
-    if (!serve_admit(ctx->device, nb, ctx->gicp_serve_capacity)) return;
-    F.served_blocks = nb;
+    const int share = resident_admit(ctx->device, nb, ctx->gicp_serve_capacity);
+    if (share <= 0) return;
+    F.served_blocks = share;
     F.served_evals = 0;
     unsigned *ticket = (unsigned *) ((char *) ctx->gicp_mailbox.p + sizeof(GicpMailbox));
     // A round that ended in a fallback can leave the ticket counter above 0 (workgroups that left by their
@@ -826,7 +819,7 @@ static void serve_begin(GicpFn &F) {
     if (hipMemsetAsync((char *) ctx->gicp_mailbox.p + offsetof(GicpMailbox, abandoned), 0,
                        sizeof(GicpMailbox) - offsetof(GicpMailbox, abandoned) + sizeof(unsigned), ctx->stream) != hipSuccess) {
         (void) hipGetLastError();
-        g_serving[ctx->device].fetch_sub(nb);
+        resident_release(ctx->device, share);
         return;
     }
     unsigned long long *dbg = getenv("WM_GICP_SERVE_DEBUG") ? (unsigned long long *) ((char *) ctx->gicp_mailbox.p + 256) : nullptr;
@@ -842,7 +835,7 @@ static void serve_begin(GicpFn &F) {
                            ctx->match_pt.as<float4>(), ctx->gicp_mahal.as<double>(), (GicpMailbox *) ctx->gicp_mailbox.p,
                            ctx->gicp_serve_seq + 1u, ctx->partials.as<double>(), ticket, (GicpSlot *) ctx->h_gicp_slots, dbg);
     if (hipGetLastError() != hipSuccess) {
-        g_serving[ctx->device].fetch_sub(nb);
+        resident_release(ctx->device, share);
         return;
     }
     F.served = true;
@@ -872,7 +865,7 @@ static void serve_end(GicpFn &F) {
         }
     }
     F.served = false;
-    g_serving[ctx->device].fetch_sub(F.served_blocks);
+    resident_release(ctx->device, F.served_blocks);
 }
 
 // one served evaluation; false: no answer (the evaluator gave up or is stuck) -> it has been shut down

@@ -15,6 +15,7 @@
 #include "wm_internal.hpp"
 #include "wm_icp_step.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <thread>
 
@@ -841,6 +842,7 @@ int wm_ctx_create(wm_ctx **out, int device) {
     if (const char *e = getenv("WM_TUNE_GICP_SERVED")) ctx->tune_gicp_served = atoi(e) == 2 ? 2 : (atoi(e) != 0 ? 1 : 0);
     if (const char *e = getenv("WM_TUNE_NDT_SPEC_HESSIAN")) ctx->tune_ndt_spec_hessian = atoi(e);
     if (const char *e = getenv("WM_TUNE_LAG")) ctx->tune_lag = atoi(e);
+    if (const char *e = getenv("WM_TUNE_LATE")) ctx->tune_late = atoi(e);
     if (const char *e = getenv("WM_TUNE_R0")) {
         const float v = (float) atof(e);
         if (v > 0) ctx->tune_r0 = v;
@@ -874,7 +876,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
                       &ctx->src_grid.cell_start, &ctx->vg_idx, &ctx->vg_idx2, &ctx->vg_perm,
                       &ctx->vg_perm2, &ctx->vg_tmp, &ctx->vg_seg, &ctx->io_a, &ctx->io_b, &ctx->ds_ref,
                       &ctx->ds_tgt, &ctx->match_ref, &ctx->match_tgt,
-                      &ctx->partials, &ctx->partials2, &ctx->nn_bound, &ctx->cert_count, &ctx->cert_prof, &ctx->cost_log, &ctx->phase_log, &ctx->shard_ref, &ctx->shard_tgt,
+                      &ctx->partials, &ctx->partials2, &ctx->nn_bound, &ctx->late_ctl, &ctx->cert_count, &ctx->cert_prof, &ctx->cost_log, &ctx->phase_log, &ctx->shard_ref, &ctx->shard_tgt,
                       &ctx->shard_ref_band, &ctx->shard_tgt_band, &ctx->shard_misc, &ctx->shard_flags, &ctx->shard_pos_t,
                       &ctx->shard_pos_s, &ctx->shard_stats, &ctx->ndt_sum_dev, &ctx->corr_tmp_idx, &ctx->corr_tmp_d2, &ctx->d_state};
     for (DevBuf *b : bufs) b->release();
@@ -890,6 +892,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
     if (ctx->h_ndt) (void) hipHostFree(ctx->h_ndt);
     if (ctx->h_sig) (void) hipHostFree(ctx->h_sig);
     if (ctx->h_pub) (void) hipHostFree(ctx->h_pub);
+    if (ctx->h_late) (void) hipHostFree(ctx->h_late);
     if (ctx->h_scratch) (void) hipHostFree(ctx->h_scratch);
     for (hipEvent_t e : ctx->ev_pool) (void) hipEventDestroy(e);
     if (ctx->ev_a) (void) hipEventDestroy(ctx->ev_a);
@@ -1058,6 +1061,14 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
     ctx->cert_launches = 0;
     std::vector<unsigned char> was_cert;
     std::vector<unsigned char> kind((size_t) max_it, 0);  // which search kernel iteration k got (1: certificate, 2: its first launch)
+    std::vector<int> ev_slot((size_t) max_it, -1);        // profile: the iteration's first event in the pool
+    // the resident kernel (k_nn_cert<.., LATE>): once the certificate policy is on, the remaining iterations run
+    // inside ONE launch, the solve included, until the registration is done or the same policy says leave
+    bool late_ok = can_cert && ctx->tune_late && !blk && !slab && !ctx->cert_count.p && !ctx->cert_prof.p;
+    int cert_hold = 0;  // iterations for which the policy stays off after the resident kernel left by it
+    ctx->late_iters = ctx->late_launches = 0;
+    ctx->late_ms = 0.f;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> late_events;
     for (int it = 0; it < max_it; ++it) {
         float seen_disp = -1.f;  // what iteration it - kLag recorded (its own record): step size, ...
         float seen_changed = 1.f, seen_unsettled = 0.f;  // ... fraction of changed matches, of searched queries
@@ -1106,7 +1117,10 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
             }
             if (seen_done) break;
         }
-        if (can_cert) {
+        if (can_cert && cert_hold > 0) {
+            --cert_hold;
+            cert_on = false;
+        } else if (can_cert) {
             if (ctx->tune_cert_from >= 0) {
                 cert_on = it >= ctx->tune_cert_from;
             } else if (seen_disp >= 0.f) {
@@ -1126,8 +1140,116 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
                 }
             }
         }
+        unsigned late_blocks = 0;
+        if (cert_on && late_ok && late_possible(ctx, p->mode, &late_blocks)) {
+            const int share = resident_admit(ctx->device, (int) late_blocks, ctx->late_capacity);
+            if (share > 0) {
+                hipEvent_t l0 = nullptr, l1 = nullptr;
+                if (p->profile) {
+                    l0 = get_event(ctx, ev_used++);
+                    l1 = get_event(ctx, ev_used++);
+                    WM_HIP(ctx, hipEventRecord(l0, ctx->stream));
+                }
+                const unsigned seq = ++ctx->late_seq;
+                // (a forced choice -- tune_cert_from >= 0 -- stays inside whatever the searched share)
+                const bool forced_choice = ctx->tune_cert_from >= 0;
+                int rc = launch_nn_late(ctx, thr, p->mode, late_blocks, bounds_valid, seq,
+                                        forced_choice ? 2.f : ctx->tune_cert_unsettled, forced_choice ? 3.0e38f : 3.f * cert_thr,
+                                        max_it - it);
+                if (rc == WM_OK && l1) rc = hipEventRecord(l1, ctx->stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
+                if (rc == WM_OK) {  // the host has nothing to decide until it leaves: wait for its word
+                    volatile unsigned long long *hx = ctx->h_late;
+                    const auto t0 = std::chrono::steady_clock::now();
+                    bool yielding = false;
+                    for (unsigned spins = 1; (unsigned) (*hx >> 32) != seq; ++spins) {
+                        if (yielding) std::this_thread::yield();
+                        else __builtin_ia32_pause();
+                        if ((spins & 63u) == 0 || yielding) {
+                            const auto waited = std::chrono::steady_clock::now() - t0;
+                            if (waited > std::chrono::milliseconds(20)) {
+                                if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = WM_ERR_HIP;
+                                break;
+                            }
+                            yielding = waited > std::chrono::microseconds(ctx->tune_spin_us);
+                        }
+                    }
+                }
+                resident_release(ctx->device, share);
+                if (rc != WM_OK) {
+                    if (rc == WM_ERR_HIP) ctx->last_error = "resident ICP kernel: launch or wait failed";
+                    return rc;
+                }
+                const unsigned long long w = *ctx->h_late;
+                if ((unsigned) (w >> 32) != seq) {
+                    ctx->last_error = "resident ICP kernel: finished without its exit word";
+                    return WM_ERR_STATE;
+                }
+                const int reason = (int) ((w >> 24) & 0xFFu), inside = (int) (w & 0xFFFFFFu);
+                if (getenv("WM_LATE_DEBUG")) {  // developer: the solver's stamps (100 MHz wall clock)
+                    unsigned long long d[64 * 4];
+                    (void) hipStreamSynchronize(ctx->stream);
+                    if (hipMemcpy(d, (char *) ctx->late_ctl.p + late_ctl_bytes(), sizeof(d), hipMemcpyDeviceToHost) == hipSuccess) {
+                        fprintf(stderr, "[wm] late kernel: %d iterations, reason %d\n", inside, reason);
+                        for (int k = 0; k < inside && k < 64; ++k)
+                            fprintf(stderr, "  it %2d: workers (hand-out -> all rows in) %6.2f us | rows added %5.2f | solve %5.2f | hand-out %5.2f\n", k,
+                                    k ? ((long long) d[k * 4] - (long long) d[(k - 1) * 4 + 3]) * 0.01 : 0.0,
+                                    (d[k * 4 + 1] - d[k * 4]) * 0.01, (d[k * 4 + 2] - d[k * 4 + 1]) * 0.01,
+                                    (d[k * 4 + 3] - d[k * 4 + 2]) * 0.01);
+                        // the workers' stamps of iteration WM_LATE_DEBUG, relative to the solver's hand-out before it
+                        const int li = atoi(getenv("WM_LATE_DEBUG"));
+                        std::vector<unsigned long long> wst((size_t) late_blocks * 8);
+                        if (li >= 1 && li < inside && li < 64 && ctx->cert_prof.p &&
+                            hipMemcpy(wst.data(), ctx->cert_prof.p, wst.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                            const unsigned long long t0 = d[(li - 1) * 4 + 3];
+                            const char *names[6] = {"pose in", "phase 1 done", "wave 0 searched", "all searched + stored", "row stored", "ticket drawn"};
+                            for (int k = 0; k < 6; ++k) {
+                                double mx = 0, mn = 1e30;
+                                std::vector<double> v;
+                                for (unsigned b = 0; b < late_blocks; ++b) {
+                                    const double x = ((long long) wst[(size_t) b * 8 + k] - (long long) t0) * 0.01;
+                                    v.push_back(x);
+                                    mx = x > mx ? x : mx;
+                                    mn = x < mn ? x : mn;
+                                }
+                                std::sort(v.begin(), v.end());
+                                fprintf(stderr, "  it %d workers, %-22s: min %6.2f  median %6.2f  p90 %6.2f  p99 %6.2f  max %6.2f us after the hand-out\n", li,
+                                        names[k], mn, v[v.size() / 2], v[v.size() * 9 / 10], v[v.size() * 99 / 100], mx);
+                            }
+                            std::vector<std::pair<double, unsigned>> slow;
+                            for (unsigned b = 0; b < late_blocks; ++b)
+                                slow.emplace_back(((long long) wst[(size_t) b * 8 + 3] - (long long) wst[(size_t) b * 8 + 1]) * 0.01, (unsigned) wst[(size_t) b * 8 + 6]);
+                            std::sort(slow.begin(), slow.end());
+                            fprintf(stderr, "  searches (phase 1 done -> all stored), slowest five [us, searched]:");
+                            for (size_t k = slow.size() >= 5 ? slow.size() - 5 : 0; k < slow.size(); ++k) fprintf(stderr, " %.2f/%u", slow[k].first, slow[k].second);
+                            double su = 0;
+                            for (auto &x : slow) su += x.second;
+                            fprintf(stderr, "; median %.2f/%u; searched per workgroup: mean %.1f\n", slow[slow.size() / 2].first, slow[slow.size() / 2].second, su / slow.size());
+                        }
+                    }
+                }
+                if (l0) late_events.emplace_back(l0, l1);
+                ctx->late_launches++;
+                ctx->late_iters += inside;
+                ctx->cert_launches += inside;
+                for (int k = 0; k < inside && (size_t) (it + k) < kind.size(); ++k) kind[(size_t) (it + k)] = (k == 0 && !bounds_valid) ? 2 : 1;
+                if (inside > 0) bounds_valid = true;
+                if (reason == 3) late_ok = false;        // (a wait gave up: launched iterations from here on)
+                if (reason == 2) {                       // the policy: full searches again, and let the records catch up
+                    cert_on = false;
+                    cert_hold = kLag;
+                }
+                if (reason == 1) break;  // done (also: it was queued behind a `done` and ran nothing)
+                if (inside <= 0 && reason != 3) {  // (cannot happen: it left without a reason to)
+                    ctx->last_error = "resident ICP kernel: left without running an iteration";
+                    return WM_ERR_STATE;
+                }
+                it += inside - 1;  // (the loop's own ++it: on to the first iteration it did not run)
+                continue;
+            }
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr, e1b = nullptr, e2 = nullptr, e3 = nullptr;
         if (p->profile) {  // 5 pool slots per iteration; level 1 only fills the first two
+            ev_slot[(size_t) it] = (int) ev_used;
             e0 = get_event(ctx, ev_used++);
             e1 = get_event(ctx, ev_used++);
             if (p->profile >= 2) {
@@ -1205,14 +1327,25 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
         stats->grid_cell = brute ? 0.f : ctx->levels[0].d.h;
         stats->deferred = s.deferred_total;
         stats->cert_launches = ctx->cert_launches;
+        stats->late_iterations = ctx->late_iters;
+        stats->late_launches = ctx->late_launches;
+        for (auto &ev : late_events) {
+            float a = 0;
+            if (ev.first && ev.second && hipEventElapsedTime(&a, ev.first, ev.second) == hipSuccess) ctx->late_ms += a;
+        }
+        stats->late_ms = ctx->late_ms;
         stats->owned_violations = s.owned_violations;
         (void) hipEventElapsedTime(&stats->align_ms, ctx->ev_a, ctx->ev_b);
         if (p->profile) {
             // iterations that ran (the rest of the last batch were no-ops)
             const int ran = s.iter + (s.state == WM_CONV_NO_CORRESPONDENCES ? 1 : 0);
-            for (int it = 0; it < ran && (size_t) (5 * it + 4) < ev_used; ++it) {
+            for (int it = 0; it < ran && (size_t) it < ev_slot.size(); ++it) {
+                if (ev_slot[(size_t) it] < 0 || (size_t) (ev_slot[(size_t) it] + 4) >= ev_used) {
+                    ctx->iter_nn_ms.push_back(-1.f);  // (ran inside the resident kernel: no launch of its own)
+                    continue;
+                }
                 float a = 0, a2 = 0, b = 0, c = 0;
-                hipEvent_t *e = &ctx->ev_pool[5 * it];
+                hipEvent_t *e = &ctx->ev_pool[(size_t) ev_slot[(size_t) it]];
                 (void) hipEventElapsedTime(&a, e[0], e[1]);
                 if (p->profile >= 2) {
                     (void) hipEventElapsedTime(&a2, e[1], e[2]);
@@ -1619,6 +1752,7 @@ int wm_set_option(wm_ctx *ctx, const char *name, double value) {
     else if (k == "cert_unsettled" && value > 0) ctx->tune_cert_unsettled = (float) value;
     else if (k == "cert_pad_mul" && value >= 0) ctx->tune_cert_pad_mul = (float) value;
     else if (k == "cert_pad_frac" && value >= 0) ctx->tune_cert_pad_frac = (float) value;
+    else if (k == "late") ctx->tune_late = value != 0 ? 1 : 0;
     else if (k == "gicp_served") ctx->tune_gicp_served = value == 2 ? 2 : (value != 0 ? 1 : 0);
     else if (k == "gicp_serve_test_stall_ms") ctx->gicp_serve_test_stall_ms = (int) value;
     else return WM_ERR_ARG;

@@ -190,6 +190,19 @@ struct wm_ctx {
     wm::DevBuf cert_prof;                   // developer: phase cycle sums per launch of k_nn_cert ([launch][8][8])
     int cert_log_iter = 0, cert_log_cap = 0;
     int cert_launches = 0;                  // of the last align
+    // the resident late-iteration kernel (k_nn_cert<.., LATE>)
+    int late_capacity = 0;                  // workgroups of it the device holds at once (0: not asked yet, -1: unusable)
+    wm::DevBuf late_ctl;                    // LateCtl
+    unsigned long long *h_late = nullptr;   // pinned: its exit word
+    unsigned late_seq = 0;
+    int late_iters = 0, late_launches = 0;  // of the last align: iterations that ran inside it
+    float late_ms = 0.f;                    // ... and its event-timed duration (profile >= 1)
+    // 1: use it.  OFF by default: measured at 1M points (profiles/r04_experiments.md) an iteration inside costs
+    // 33-43 us against 32-37 us for a launched certificate iteration + its solve kernel -- the workers' certificate
+    // phase is bound by the vector ALU (~8 us chip-wide for the f64 sums of a million queries), the slowest
+    // workgroup's searches end 10 us after the median one's, and the solver's chain (rows 3.8, solve 4.4, hand-out
+    // 0.7 us) is serial behind them
+    int tune_late = 0;
     unsigned long long *h_pub = nullptr;    // pinned: [0] (done << 63 | iterations finished << 32 | step size bits) of the latest solve, [k] iteration k's own record
     int h_pub_slots = 0;
     wm::DevBuf vg_idx, vg_idx2, vg_perm, vg_perm2, vg_tmp, vg_seg, io_a, io_b, ds_ref, ds_tgt, match_ref, match_tgt;
@@ -358,6 +371,14 @@ int transform_cloud_dev(wm_ctx *ctx, const float4 *in, size_t n, const double T[
 int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2,
                    int stats_mode = -1, unsigned *rows_out = nullptr);
 int launch_nn_brute(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1);
+// the resident form of the certificate kernel (wm_nn.hip: k_nn_cert<.., LATE>): the late iterations in one launch
+bool late_possible(wm_ctx *ctx, int stats_mode, unsigned *blocks_out);
+size_t late_ctl_bytes();  // sizeof(LateCtl): the developer stamps sit behind it
+int launch_nn_late(wm_ctx *ctx, float thr_d2, int stats_mode, unsigned blocks, bool bounds_valid, unsigned exit_seq,
+                   float stop_unsettled, float stop_disp, int max_inside);
+// the device's budget of resident workgroups (per process), in 1/1024ths of the device: the share taken (0: refused)
+int resident_admit(int device, int nb, int capacity);
+void resident_release(int device, int share);
 int launch_fix_keys(wm_ctx *ctx, float thr_d2);  // after certified iterations: every key's distance brought up to date
 // the certificate kernel (late iterations): stats_mode as above; bounds_valid = the previous search of
 // this align was launch_nn_cert too (its per-query bounds are still in ctx->nn_bound)

@@ -19,7 +19,10 @@
 //               lane, large ones by the whole wavefront (see the kernel's comment).
 //   k_nn_brute  LDS-tiled all-pairs search (small clouds / cross-check).
 #include "wm_internal.hpp"
+#include "wm_icp_step.hpp"
 #include "wm_wave.hpp"
+
+#include <atomic>
 
 namespace wm {
 
@@ -1164,14 +1167,193 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
 // bounds_valid = 0: no usable bounds (the previous iteration was searched by k_nn_grid): every query
 // is searched and leaves its bound.
 constexpr int kCertWaves = 4;
-template <int STATS, int NB, int RC>
+
+// ---- the RESIDENT form of the certificate kernel (LATE = true): the late iterations of one registration
+// in ONE launch.  Every workgroup keeps its 4 x NB x 64 queries from iteration to iteration (their three
+// streams -- source point, match, position + bound -- are requested again while the solver works: L2 /
+// Infinity Cache hits that cost no time of their own), the
+// iteration's sums meet in device memory (one row per workgroup, written through; a ticket per workgroup),
+// and ONE extra workgroup -- the solver, a kernel of its own on a second stream -- adds the rows in a fixed order,
+// runs the solve and PCL's stopping rules (icp_apply_stats: what k_reduce_solve runs), publishes the
+// iteration's record to the host and hands the new pose to the workers through a 64-byte slot.  What a
+// launched certified iteration pays around its ~6 us of work -- two kernel boundaries, 48 MB of streams,
+// the dispatch of 4 000 waves -- is gone.  Every workgroup has to be resident at once (checked on the
+// host against the kernel's occupancy and the device's budget of resident workgroups); every wait gives
+// up after kLateGuardTicks and sets `abandoned`, after which everybody leaves and the host continues with
+// launched iterations from the state the solver wrote back.  No agent-scope fences anywhere (an XCD-wide
+// L2 write-back each): rows, pose and counters are written through / read at agent scope.
+// (every word that is polled or hammered sits in a 128-byte line of its own, and the word the thousand
+// workers wait on exists sixteen times: a worker that has delivered its row looks at copy (workgroup mod
+// 16) -- a thousand pollers of ONE line keep its memory channel so busy that the ticket atomics and row
+// stores of the workgroups still working queue up behind them)
+constexpr int kLateGenCopies = 16;
+struct LateCtl {            // device memory
+    unsigned ticket;        // rows delivered so far (monotonic over the iterations of one launch)
+    unsigned pad0[31];
+    unsigned abandoned;     // a wait timed out somewhere: everybody leaves
+    unsigned pad1[31];
+    float bc[2][16];        // by parity of the iteration: Tf[12], step size, flags (bit 0: stop), 2 spare
+    struct {
+        unsigned gen;       // iterations whose result the solver has handed out (0xFFFFFFFF: leave, a wait gave up)
+        unsigned pad[31];
+    } g[kLateGenCopies];
+};
+static_assert(sizeof(LateCtl) == 384 + 128 * kLateGenCopies, "layout");
+struct LateArgs {
+    LateCtl *ctl;
+    unsigned long long *pub;     // pinned: the iterations' records (as k_reduce_solve writes them)
+    int pub_slots;
+    unsigned long long *h_exit;  // pinned: [exit_seq : 32 | reason : 8 | iterations done inside : 24], written last
+    unsigned exit_seq;
+    float stop_unsettled;        // leave when an iteration had to search more than this share of the queries ...
+    float stop_disp;             // ... or a step moved the points by more than this (metres)
+    int max_inside;              // ... or after this many iterations
+    unsigned long long *dbg;     // developer (WM_LATE_DEBUG): 4 wall-clock stamps per iteration from the solver
+    unsigned long long *dbg_w;   // ... and 8 per WORKER for iteration dbg_li
+    unsigned dbg_li;
+};
+constexpr unsigned long long kLateGuardTicks = 20000000ull;  // 0.2 s of the 100 MHz wall clock
+constexpr int kLateRow = 20;  // doubles per workgroup row: the kAcc sums, the queries it searched, one spare
+enum { kLateDone = 1, kLatePolicy = 2, kLateAbandoned = 3, kLateBudget = 4 };
+
+__device__ __forceinline__ unsigned ld_agent_u32(const unsigned *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the solver workgroup of the resident kernel: see above
+struct LateSolverLds {
+    IcpDevState st;
+    double part[12][kLateRow];
+    double tot[kLateRow];
+    unsigned go, flags;
+};
+__global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_per_eu(4, 4)))
+    k_late_solver(const double *partials, unsigned workers, IcpDevState *st, LateArgs la) {
+    // (a kernel of its own, on a second stream beside the workers': its f64 solve and its 28 loads in flight per
+    // thread would otherwise set the register allocation of the search loop.  One workgroup, and no bigger than
+    // a worker's in threads / registers / LDS: it fits wherever a worker fits)
+    __shared__ LateSolverLds S;
+    LateCtl *ctl = la.ctl;
+    constexpr unsigned kWords = sizeof(IcpDevState) / 4;
+    for (unsigned w = threadIdx.x; w < kWords; w += 64u * kCertWaves)
+        reinterpret_cast<unsigned *>(&S.st)[w] = reinterpret_cast<const unsigned *>(st)[w];
+    __syncthreads();
+    unsigned reason = 0, inside = 0;
+    if (S.st.done) reason = kLateDone;  // (queued behind a `done`: nothing to do -- the workers have left too)
+    for (unsigned li = 0; reason == 0u; ++li) {
+        // ---- all rows of this iteration in?
+        if (threadIdx.x < 64u) {
+            const unsigned want = (li + 1u) * workers;
+            const unsigned long long t0 = wall_clock64();
+            bool ok = true;
+            for (;;) {
+                if ((int) (ld_agent_u32(&ctl->ticket) - want) >= 0) break;
+                if (ld_agent_u32(&ctl->abandoned) != 0u || wall_clock64() - t0 > kLateGuardTicks) {
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (threadIdx.x == 0) S.go = ok ? 1u : 0u;
+            if (threadIdx.x == 0 && la.dbg && li < 64u) la.dbg[li * 4u + 0u] = wall_clock64();  // all rows in
+        }
+        __syncthreads();
+        if (!S.go) {
+            if (threadIdx.x == 0) __hip_atomic_store(&ctl->abandoned, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            reason = kLateAbandoned;
+        } else {
+            // ---- the rows, in a fixed order: thread (r, c) adds rows r, r + 12, ... of column c (28 loads in
+            // flight per thread: three round trips for a thousand rows), one thread per column adds the 12
+            const unsigned c = threadIdx.x % (unsigned) kLateRow, r = threadIdx.x / (unsigned) kLateRow;
+            if (r < 12u) {
+                double acc = 0.0;
+                constexpr int U = 28;
+                for (unsigned b = r; b < workers; b += 12u * U) {
+                    double v[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const unsigned bb = b + 12u * (unsigned) u;
+                        v[u] = bb < workers ? __hip_atomic_load(partials + (size_t) bb * kLateRow + c, __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT)
+                                            : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc += v[u];
+                }
+                S.part[r][c] = acc;
+            }
+            __syncthreads();
+            if (threadIdx.x < (unsigned) kLateRow) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) t += S.part[k][threadIdx.x];
+                S.tot[threadIdx.x] = t;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                if (la.dbg && li < 64u) la.dbg[li * 4u + 1u] = wall_clock64();  // rows added
+                double a[kAcc], ex[kStatsLen];
+#pragma unroll
+                for (int k = 0; k < kAcc; ++k) a[k] = S.tot[k];
+                expand_stats(S.st.mode, a, ex, S.st.changed_mask);
+                S.st.local_handled = ex[kStatsLen - 1];
+#pragma unroll
+                for (int k = 0; k < kStatsLen; ++k) S.st.stats[k] = ex[k];
+                icp_apply_stats(&S.st, ex, (long long) S.tot[kAcc]);
+                unsigned fl = 0;
+                if (S.st.done) fl = kLateDone;
+                else if ((li > 0u || S.st.frac_unsettled < 0.999f) && S.st.frac_unsettled > la.stop_unsettled) fl = kLatePolicy;
+                else if (S.st.step_disp > la.stop_disp) fl = kLatePolicy;
+                else if ((int) (li + 1u) >= la.max_inside) fl = kLateBudget;
+                S.flags = fl;
+                if (la.dbg && li < 64u) la.dbg[li * 4u + 2u] = wall_clock64();  // solved
+                if (la.pub) {  // (the record k_reduce_solve publishes: same layout)
+                    const unsigned f_ch = (unsigned) (fminf(fmaxf(S.st.frac_changed, 0.f), 1.f) * 65535.f + 0.5f);
+                    const unsigned f_un = (unsigned) (fminf(fmaxf(S.st.frac_unsettled, 0.f), 1.f) * 65535.f + 0.5f);
+                    const unsigned long long w = ((unsigned long long) ((unsigned) S.st.iter & 0xFFFFu) << 48) |
+                                                 ((unsigned long long) (__float_as_uint(S.st.step_disp) >> 16) << 32) |
+                                                 ((unsigned long long) f_ch << 16) | (unsigned long long) f_un;
+                    if (S.st.iter >= 1 && S.st.iter <= la.pub_slots)
+                        __hip_atomic_store(la.pub + S.st.iter, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(la.pub, S.st.done ? (1ull | ((unsigned long long) (unsigned) S.st.iter << 1)) : 0ull,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            __syncthreads();
+            reason = S.flags;
+            inside = li + 1u;
+        }
+        // ---- the pose of the next iteration (or the word to leave) for the workers: data, wait, then the number
+        if (threadIdx.x < 16u) {
+            const unsigned t = threadIdx.x;
+            const float v = t < 12u ? S.st.Tf[t] : (t == 12u ? S.st.step_disp : (t == 13u ? __uint_as_float(reason) : 0.f));
+            __hip_atomic_store(&ctl->bc[(li + 1u) & 1u][t], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (threadIdx.x < (unsigned) kLateGenCopies)
+            __hip_atomic_store(&ctl->g[threadIdx.x].gen, reason == (unsigned) kLateAbandoned ? ~0u : li + 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0 && la.dbg && li < 64u) la.dbg[li * 4u + 3u] = wall_clock64();  // handed out
+    }
+    // ---- the state goes back to memory for the kernels behind this one; the host learns how it ended
+    __syncthreads();
+    for (unsigned w = threadIdx.x; w < kWords; w += 64u * kCertWaves)
+        reinterpret_cast<unsigned *>(st)[w] = reinterpret_cast<const unsigned *>(&S.st)[w];
+    if (threadIdx.x == 0 && la.h_exit)
+        __hip_atomic_store(la.h_exit, ((unsigned long long) la.exit_seq << 32) | ((unsigned long long) (reason & 0xFFu) << 24) |
+                                          (unsigned long long) (inside & 0xFFFFFFu),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <int STATS, int NB, int RC, bool LATE = false>
 __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_per_eu(4, 4)))
     k_nn_cert(const LevelsDev *__restrict__ lv, const float4 *__restrict__ src, unsigned n,
               IcpDevState *__restrict__ st, float thr_d2, unsigned long long *__restrict__ keys,
               float4 *__restrict__ match_pt, float4 *__restrict__ bound, const float4 *__restrict__ tgt_orig,
               float r_light_cells, float lane_lf, float coop_lf, float r0_cells, unsigned xflags,
               double *__restrict__ partials, int bounds_valid, float pad_mul, float pad_frac,
-              unsigned *__restrict__ uns_count, unsigned long long *__restrict__ prof_out) {
+              unsigned *__restrict__ uns_count, unsigned long long *__restrict__ prof_out, LateArgs la) {
     // (a wave's life is a chain of memory round trips: the phase's three streams are requested before
     // anything else is looked at -- their addresses need nothing but the block number)
     const unsigned lane = threadIdx.x & 63u;
@@ -1189,7 +1371,14 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
         mp[j] = match_pt[i];  // (meaningless before the first search, and then not looked at)
         rf[j] = bound[i];
     }
-    if (st->done) return;  // (uniform over the workgroup)
+    if (!LATE && st->done) return;  // (uniform over the workgroup)
+    // LATE: the three streams of the later iterations come through buffer loads the compiler cannot hoist out
+    // of the iteration loop (kept in registers across the searches they would be spilled to scratch: the
+    // searches need every register); the match and the bound at agent scope (sc1), past this compute unit's
+    // L1 -- the workgroup's own searches of the previous iteration rewrote some of them
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void *) src, 0, LATE ? n * 16u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_mp = __builtin_amdgcn_make_buffer_rsrc((void *) match_pt, 0, LATE ? n * 16u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_rf = __builtin_amdgcn_make_buffer_rsrc((void *) bound, 0, LATE ? n * 16u : 0u, 0x00020000);
     // developer (prof_out): shader-clock stamps of wave 0 of every 256th workgroup, 16 per sample
     // (the phases between them: scripts/dev/dev_cert_prof.py); nothing is recorded otherwise
     const bool stamp_on = prof_out != nullptr && (blockIdx.x & 255u) == 0u && wave == 0u;
@@ -1204,6 +1393,10 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
     __shared__ unsigned short s_list[kCertWaves][64 * NB];
     __shared__ unsigned s_cnt[kCertWaves];
     __shared__ double s_rows[kCertWaves][kAcc];
+    __shared__ float s_bc[20];  // LATE: this iteration's pose, step size, flags, [16] = a wait gave up
+    if constexpr (LATE) {
+        if (st->done) return;  // (a launch queued behind a `done`; the solver tells the host)
+    }
     BalLds &L = s_L[wave];
     s_win[wave][lane] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoIdx));  // (no winner recorded)
     const int Ln = lv->n;
@@ -1215,10 +1408,6 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
     const float rmax = sqrtf(thr_d2) * 1.0001f + 1e-6f;
     const float r_light = r_light_cells * h0;
     const bool have_prev = st->have_prev != 0;
-    const bool valid = bounds_valid != 0 && have_prev;
-    // room a search leaves above its result for the runner-up bound: a few of the last step's sizes
-    // (what the following steps will add up to while the registration converges)
-    const float pad_room = have_prev ? pad_mul * st->step_disp : 0.f;
     // sharded registration: this rank handles the queries whose transformed x lies in its slab (a query
     // it does not own is skipped: no test, no search, nothing stored -- whatever this rank knew about
     // it stays consistent for the day it comes back)
@@ -1226,9 +1415,68 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
     const float slab_lo = st->slab_lo, slab_hi = st->slab_hi;
     const unsigned changed_mask = st->changed_mask;
     const int comp = acc_comp_of_lane(lane);
-    double rowacc = 0.0;
-    unsigned n_uns = 0;  // (wave-uniform)
     WM_STAMP(1);  // state in
+    // (LATE: one trip per iteration of the registration; otherwise one trip)
+    for (unsigned li = 0;; ++li) {
+    // ---- this iteration's pose, step size, and whether bounds exist
+    if constexpr (LATE) {
+        if (li > 0u) {
+            // (requested BEFORE the wait for the solver: they arrive while it works)
+            typedef unsigned u4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const unsigned i = min(base + (unsigned) j * 64u + lane, n - 1u);
+                const u4v a = __builtin_amdgcn_raw_buffer_load_b128(rs_src, i * 16u, 0, 0);
+                const u4v b = __builtin_amdgcn_raw_buffer_load_b128(rs_mp, i * 16u, 0, 16);
+                const u4v c = __builtin_amdgcn_raw_buffer_load_b128(rs_rf, i * 16u, 0, 16);
+                p[j] = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+                mp[j] = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
+                rf[j] = make_float4(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z), __uint_as_float(c.w));
+            }
+            if (wave == 0u) {  // wave 0 waits for the solver's word (one request per look), then fetches the slot
+                // (the solver needs ~9 us from the last row to its word: a first long nap, then a look every ~0.5 us)
+                const unsigned *my_gen = &la.ctl->g[blockIdx.x & (unsigned) (kLateGenCopies - 1)].gen;
+                const unsigned long long t0 = wall_clock64();
+                bool ok = true;
+                __builtin_amdgcn_s_sleep(100);
+                for (;;) {
+                    const unsigned g = ld_agent_u32(my_gen);
+                    if (g == ~0u || wall_clock64() - t0 > kLateGuardTicks) {
+                        ok = false;
+                        break;
+                    }
+                    if ((int) (g - li) >= 0) break;
+                    __builtin_amdgcn_s_sleep(20);
+                }
+                if (lane < 16u)
+                    s_bc[lane] = __uint_as_float(ld_agent_u32(reinterpret_cast<const unsigned *>(&la.ctl->bc[li & 1u][lane])));
+                if (lane == 16u) s_bc[16] = ok ? 0.f : 1.f;
+                if (!ok && lane == 0u) __hip_atomic_store(&la.ctl->abandoned, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (threadIdx.x < 17u) {
+            s_bc[threadIdx.x] = threadIdx.x < 12u ? st->Tf[threadIdx.x] : (threadIdx.x == 12u ? st->step_disp : 0.f);
+        }
+        __syncthreads();
+        if (s_bc[16] != 0.f || __float_as_uint(s_bc[13]) != 0u) return;  // (uniform: gave up, or told to leave)
+    }
+#define WM_WSTAMP(k)                                                                                            \
+    do {                                                                                                        \
+        if constexpr (LATE)                                                                                     \
+            if (la.dbg_w && li == la.dbg_li && threadIdx.x == 0) la.dbg_w[(size_t) blockIdx.x * 8u + (k)] = wall_clock64(); \
+    } while (0)
+    WM_WSTAMP(0);  // pose in
+    float Tl[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+        Tl[k] = LATE ? __uint_as_float((unsigned) __builtin_amdgcn_readfirstlane((int) __float_as_uint(s_bc[k]))) : st->Tf[k];
+    const float step_now = LATE ? __uint_as_float((unsigned) __builtin_amdgcn_readfirstlane((int) __float_as_uint(s_bc[12])))
+                                : st->step_disp;
+    const bool valid = (LATE && li > 0u) || (bounds_valid != 0 && have_prev);
+    // room a search leaves above its result for the runner-up bound: a few of the last step's sizes
+    // (what the following steps will add up to while the registration converges)
+    const float pad_room = have_prev ? pad_mul * step_now : 0.f;
+    double rowacc = 0.0;
+    unsigned n_uns = 0;    // (wave-uniform)
     // ---- phase 1: the certificate
     {
         double acc[kAcc];
@@ -1246,7 +1494,7 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
             bool settled = false, owned = act;
             float qx = 0.f, qy = 0.f, qz = 0.f, d2 = 0.f;
             if (act) {
-                xform(st->Tf, p[j], qx, qy, qz);
+                xform(Tl, p[j], qx, qy, qz);
                 if (slab_on && !(qx >= slab_lo && qx < slab_hi)) owned = false;
             }
             if (owned && valid) {
@@ -1348,6 +1596,7 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
     if (lane == 0) s_cnt[wave] = n_uns;
     WM_STAMP(3);  // phase 1 done
     __syncthreads();
+    WM_WSTAMP(1);  // phase 1 done (all waves)
     // ---- phase 2: what is left in the workgroup, 64 queries at a time, chunk c by wave c mod 4
     unsigned cum[kCertWaves + 1];
     cum[0] = 0;
@@ -1357,7 +1606,8 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
     if (uns_count && threadIdx.x == 0 && U) atomicAdd(&uns_count[blockIdx.x & 63u], U);  // developer statistics
     // how many queries this launch had to search: the solve kernel hands it to the host (one atomic per
     // workgroup, spread over 64 words)
-    if (threadIdx.x == 0 && U) atomicAdd(&st->cert_unsettled[blockIdx.x & 63u], U);
+    if (!LATE && threadIdx.x == 0 && U) atomicAdd(&st->cert_unsettled[blockIdx.x & 63u], U);
+    const unsigned U_searched = U;
     if (dbg_skip == 1u && valid) U = 0;
     const unsigned nchunks = (U + 63u) / 64u;
     unsigned cost = 0;
@@ -1384,7 +1634,7 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
             } else {
                 const float4 p1 = src[gi];
                 if (have_prev) gtp = match_pt[gi];
-                xform(st->Tf, p1, gx, gy, gz);
+                xform(Tl, p1, gx, gy, gz);
             }
         }
         __syncthreads();
@@ -1426,7 +1676,7 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
         if (from_mem) {
             const float4 p1 = src[i];
             if (have_prev) tp = match_pt[i];
-            xform(st->Tf, p1, qx, qy, qz);
+            xform(Tl, p1, qx, qy, qz);
         }
         if (mine) {
             r = r0_cells * h0;
@@ -1580,7 +1830,33 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
         __builtin_amdgcn_wave_barrier();
     }
     WM_STAMP(10);
-    if constexpr (STATS >= 0) {
+    if constexpr (LATE) {
+        WM_WSTAMP(2);  // wave 0's searches done
+        // the four waves' sums in wave order -> the workgroup's row, written through; when the stores have
+        // been performed, the ticket.  (Every wave first waits for its own result stores: the next
+        // iteration's loads of the match and the bound, by other waves, come behind the barrier.)
+        if (comp >= 0) s_rows[wave][comp] = rowacc;
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        WM_WSTAMP(3);  // all waves' searches done, result stores performed
+        if (threadIdx.x == 0 && la.dbg_w && li == la.dbg_li) la.dbg_w[(size_t) blockIdx.x * 8u + 6u] = U_searched;
+        if (threadIdx.x < (unsigned) kAcc + 1u) {
+            double t;
+            if (threadIdx.x < (unsigned) kAcc) {
+                t = s_rows[0][threadIdx.x];
+#pragma unroll
+                for (int w = 1; w < kCertWaves; ++w) t += s_rows[w][threadIdx.x];
+            } else {
+                t = (double) U_searched;
+            }
+            __hip_atomic_store(partials + (size_t) row * kLateRow + threadIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        WM_WSTAMP(4);  // row stored
+        if (threadIdx.x == 0) (void) __hip_atomic_fetch_add(&la.ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        WM_WSTAMP(5);  // ticket drawn
+    } else if constexpr (STATS >= 0) {
         // the four waves' sums, added in wave order
         if (comp >= 0) s_rows[wave][comp] = rowacc;
         __syncthreads();
@@ -1598,6 +1874,9 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
         for (int k = 0; k < 12; ++k) o[k] = pt[k];
         o[12] = U;
     }
+    if constexpr (!LATE) break;
+    }  // (iterations)
+#undef WM_WSTAMP
 #undef WM_STAMP
 }
 
@@ -1759,7 +2038,7 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
 
 template <int STATS, int NB, int RC>
 static void launch_nn_cert_t(wm_ctx *ctx, unsigned blocks, float thr_d2, unsigned xcd_chunk, bool bounds_valid) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_cert<STATS, NB, RC>), dim3(blocks), dim3(64 * kCertWaves), 0, ctx->stream,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_cert<STATS, NB, RC, false>), dim3(blocks), dim3(64 * kCertWaves), 0, ctx->stream,
                        ctx->d_levels.as<LevelsDev>(), ctx->src_sorted.as<float4>(), (unsigned) ctx->n_src,
                        ctx->d_state.as<IcpDevState>(), thr_d2, ctx->keys.as<unsigned long long>(),
                        ctx->match_pt.as<float4>(), ctx->nn_bound.as<float4>(), ctx->tgt_orig.as<float4>(),
@@ -1769,7 +2048,8 @@ static void launch_nn_cert_t(wm_ctx *ctx, unsigned blocks, float thr_d2, unsigne
                        ctx->cert_count.p && ctx->cert_log_iter < ctx->cert_log_cap
                            ? ctx->cert_count.as<unsigned>() + 64 * (size_t) ctx->cert_log_iter : nullptr,
                        ctx->cert_prof.p && ctx->cert_log_iter < ctx->cert_log_cap
-                           ? ctx->cert_prof.as<unsigned long long>() + 64 * (size_t) ctx->cert_log_iter : nullptr);
+                           ? ctx->cert_prof.as<unsigned long long>() + 64 * (size_t) ctx->cert_log_iter : nullptr,
+                       LateArgs{});
 }
 
 template <int NB, int RC>
@@ -1802,6 +2082,115 @@ int launch_nn_cert(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
     if (ev1) WM_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     if (ev2) WM_HIP(ctx, hipEventRecord(ev2, ctx->stream));
     WM_HIP(ctx, hipGetLastError());
+    return WM_OK;
+}
+
+// ---- the resident form (k_nn_cert<.., LATE = true>)
+constexpr int kLateNB = 4;
+template <int STATS>
+static const void *late_kernel() {
+    return (const void *) k_nn_cert<STATS, kLateNB, 3, true>;
+}
+
+// workgroups of resident kernels (this one, GICP's evaluators) a device may hold at once, per process:
+// resident kernels that each hold part of the GPU while waiting must never keep each other's remaining
+// workgroups from starting
+// (in 1/1024ths of the device: a kernel of nb workgroups of which `capacity` fit at once takes
+// ceil(1024 nb / capacity) -- the kernels differ in what a workgroup occupies)
+static std::atomic<int> g_resident[64];
+int resident_admit(int device, int nb, int capacity) {
+    if (device < 0 || device >= 64 || capacity <= 0 || nb > capacity) return 0;
+    const int share = (int) (((long long) nb * 1024 + capacity - 1) / capacity);
+    int cur = g_resident[device].load();
+    while (cur + share <= 1024)
+        if (g_resident[device].compare_exchange_weak(cur, cur + share)) return share;
+    return 0;
+}
+void resident_release(int device, int share) {
+    if (device >= 0 && device < 64 && share > 0) g_resident[device].fetch_sub(share);
+}
+
+size_t late_ctl_bytes() { return sizeof(LateCtl); }
+
+// Can the late iterations of this align run in one resident launch?  (*blocks_out: its grid)
+bool late_possible(wm_ctx *ctx, int stats_mode, unsigned *blocks_out) {
+    const unsigned n = (unsigned) ctx->n_src;
+    if (n == 0 || (stats_mode != WM_ICP_SVD && stats_mode != WM_ICP_GN6)) return false;
+    if (ctx->late_capacity == 0) {  // first use: how many of its workgroups fit on the device at once?
+        ctx->late_capacity = -1;
+        int cus = 0, per_cu = 0, per_cu2 = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) return false;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, late_kernel<WM_ICP_SVD>(), 64 * kCertWaves, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, late_kernel<WM_ICP_GN6>(), 64 * kCertWaves, 0) != hipSuccess) {
+            (void) hipGetLastError();
+            return false;
+        }
+        ctx->late_capacity = cus * (per_cu < per_cu2 ? per_cu : per_cu2);
+    }
+    if (ctx->late_capacity <= 0) return false;
+    const unsigned per = 64u * (unsigned) kLateNB * (unsigned) kCertWaves;
+    unsigned workers = (n + per - 1u) / per;
+    workers = (workers + 7u) & ~7u;  // xcd_remap needs a multiple of 8
+    if ((int) workers + 1 > ctx->late_capacity) return false;  // (+ 1: the solver's workgroup)
+    if (blocks_out) *blocks_out = workers;
+    return true;
+}
+
+// Enqueue the resident kernel: iterations from the state's current one until done / the policy says leave
+// / max_inside.  The caller holds `blocks` of the device's resident budget until the kernel has finished.
+int launch_nn_late(wm_ctx *ctx, float thr_d2, int stats_mode, unsigned blocks, bool bounds_valid, unsigned exit_seq,
+                   float stop_unsettled, float stop_disp, int max_inside) {
+    const unsigned n = (unsigned) ctx->n_src;
+    const unsigned workers = blocks;
+    if (!ctx->side_stream || !ctx->ev_fork || !ctx->ev_join) return WM_ERR_STATE;
+    WM_HIP(ctx, ctx->nn_bound.reserve(((size_t) n + 64) * sizeof(float4)));
+    WM_HIP(ctx, ctx->partials.reserve((size_t) workers * kLateRow * sizeof(double)));
+    WM_HIP(ctx, ctx->late_ctl.reserve(sizeof(LateCtl) + 64 * 4 * sizeof(unsigned long long)));
+    if (!ctx->h_late) {
+        WM_HIP(ctx, hipHostMalloc((void **) &ctx->h_late, 64, hipHostMallocDefault));
+        *ctx->h_late = 0ull;
+    }
+    WM_HIP(ctx, hipMemsetAsync(ctx->late_ctl.p, 0, sizeof(LateCtl) + 64 * 4 * sizeof(unsigned long long), ctx->stream));
+    LateArgs la;
+    la.ctl = ctx->late_ctl.as<LateCtl>();
+    la.pub = ctx->h_pub;
+    la.pub_slots = ctx->h_pub_slots;
+    la.h_exit = ctx->h_late;
+    la.exit_seq = exit_seq;
+    la.stop_unsettled = stop_unsettled;
+    la.stop_disp = stop_disp;
+    la.max_inside = max_inside;
+    la.dbg = getenv("WM_LATE_DEBUG") ? (unsigned long long *) ((char *) ctx->late_ctl.p + sizeof(LateCtl)) : nullptr;
+    la.dbg_w = nullptr;
+    la.dbg_li = 0;
+    if (la.dbg) {
+        WM_HIP(ctx, ctx->cert_prof.reserve((size_t) workers * 8 * sizeof(unsigned long long)));
+        WM_HIP(ctx, hipMemsetAsync(ctx->cert_prof.p, 0, (size_t) workers * 8 * sizeof(unsigned long long), ctx->stream));
+        la.dbg_w = ctx->cert_prof.as<unsigned long long>();
+        la.dbg_li = (unsigned) atoi(getenv("WM_LATE_DEBUG"));
+    }
+    const unsigned xflags = (ctx->tune_nn_nt_stores ? 0x10000000u : 0u);
+    // the solver beside the workers, on the second stream: both start when what is on the main stream now is done
+    WM_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    WM_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+    hipLaunchKernelGGL(k_late_solver, dim3(1), dim3(64 * kCertWaves), 0, ctx->side_stream, ctx->partials.as<double>(),
+                       workers, ctx->d_state.as<IcpDevState>(), la);
+    WM_HIP(ctx, hipGetLastError());
+    WM_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
+#define WM_LATE_LAUNCH(MODE)                                                                                            \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_cert<MODE, kLateNB, 3, true>), dim3(blocks), dim3(64 * kCertWaves), 0,          \
+                       ctx->stream, ctx->d_levels.as<LevelsDev>(), ctx->src_sorted.as<float4>(), n,                       \
+                       ctx->d_state.as<IcpDevState>(), thr_d2, ctx->keys.as<unsigned long long>(),                        \
+                       ctx->match_pt.as<float4>(), ctx->nn_bound.as<float4>(), ctx->tgt_orig.as<float4>(),                \
+                       ctx->tune_r_light, ctx->tune_lane_lf, ctx->tune_coop_lf, ctx->tune_r0, xflags,                     \
+                       ctx->partials.as<double>(), bounds_valid ? 1 : 0, ctx->tune_cert_pad_mul, ctx->tune_cert_pad_frac, \
+                       (unsigned *) nullptr, (unsigned long long *) nullptr, la)
+    if (stats_mode == WM_ICP_SVD) WM_LATE_LAUNCH(WM_ICP_SVD);
+    else WM_LATE_LAUNCH(WM_ICP_GN6);
+#undef WM_LATE_LAUNCH
+    WM_HIP(ctx, hipGetLastError());
+    // (what follows on the main stream needs the state the solver writes back when it leaves)
+    WM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     return WM_OK;
 }
 

@@ -56,6 +56,9 @@ for cfg in sys.argv[1:] or ["-"]:
     it = ctx.iteration_times() * 1e3
     step(1)
     it = ctx.iteration_times() * 1e3
+    print('    late: %d iterations in %d launches, %.1f us per iteration inside' % (
+        r1.get("late_iterations", 0), r1.get("late_launches", 0),
+        r1.get("late_ms", 0.0) * 1e3 / max(r1.get("late_iterations", 0), 1)), flush=True)
     print('    cert launches %d; nn us by iteration:' % r.get("cert_launches", -1), ' '.join('%d:%.0f' % (k, it[k]) for k in range(len(it))), flush=True)
     c = ctx.solve_cycles()
     print('    solve kernel cycles: rows+stage %d, expand %d, pre-svd %d, svd %d, rest-of-apply %d' % (

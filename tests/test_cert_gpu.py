@@ -129,3 +129,48 @@ def test_certified_align_is_bit_reproducible(wm):
     assert a["cert_launches"] == b["cert_launches"] > 0
     assert np.array_equal(a["T"], b["T"])
     assert np.array_equal(a["corr"][1], b["corr"][1])
+
+
+# ---- the resident form (k_nn_cert<.., LATE> + k_late_solver, option "late"): the late iterations, their sums, the
+# solve and the stopping rules in ONE launch.  Off by default (it is not faster: profiles/r04_experiments.md);
+# it must give the launched path's correspondences and registration all the same.
+@pytest.mark.parametrize("name,ref,tgt,max_corr", _cases(), ids=[c[0] for c in _cases()])
+@pytest.mark.parametrize("cert_from", [1, 4, -1])
+def test_resident_kernel_leaves_the_kdtree_s_correspondences(wm, oracle, name, ref, tgt, max_corr, cert_from):
+    K = 14
+    a = _align(wm, ref, tgt, K - 1, cert_from, max_corr, late=1)
+    b = _align(wm, ref, tgt, K, cert_from, max_corr, late=1)
+    assert a["rc"] == 0 and b["rc"] == 0
+    if cert_from >= 0:
+        assert b["cert_launches"] == K - cert_from and b["late_iterations"] == K - cert_from
+    gi, gd = b["corr"]
+    want_i, want_d, keep = _oracle_corr(oracle, ref, tgt, a["T"], max_corr)
+    assert np.array_equal(gi, want_i), "%d of %d matches differ" % ((gi != want_i).sum(), len(gi))
+    assert np.array_equal(gd[keep], want_d[keep])
+
+
+def test_resident_kernel_registers_like_the_launched_path(wm, oracle):
+    ref, tgt, _ = synth.pair(60000, seed=11, mode="resample")
+    for kw in ({"force_iterations": 40}, {"max_iter": 60, "t_eps": 1e-12, "fit_eps": 1e-9}):
+        res = []
+        for late in (0, 1):
+            c = wm.Context(0)
+            c.set_option("late", late)
+            c.set_source(ref)
+            c.set_target(tgt)
+            r = c.icp_align(max_corr=3.0, nn_method=wm.WM_NN_GRID, carry_state=0, **kw)
+            r["corr"] = c.correspondences()
+            res.append(r)
+            c.close()
+        a, b = res
+        assert a["rc"] == 0 and b["rc"] == 0
+        assert b["late_iterations"] > 0 and a["late_iterations"] == 0
+        assert a["iterations"] == b["iterations"] and a["state"] == b["state"]
+        dt, da = pose_error(a["T"], b["T"])
+        assert dt < 1e-9 and da < 1e-10, (dt, da)   # the sums differ in order only
+        assert np.array_equal(a["corr"][0], b["corr"][0])
+    # bit-reproducible
+    x = _align(wm, ref, tgt, 30, -1, late=1)
+    y = _align(wm, ref, tgt, 30, -1, late=1)
+    assert x["late_iterations"] == y["late_iterations"] > 0
+    assert np.array_equal(x["T"], y["T"]) and np.array_equal(x["corr"][1], y["corr"][1])
