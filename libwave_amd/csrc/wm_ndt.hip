@@ -390,10 +390,8 @@ __device__ __forceinline__ double dot3d(const double *a, const double *b) {
 }
 
 // a[0] = score, a[1..6] = gradient, a[7..27] = upper triangle of the Hessian, row by row
-// (at least two waves per SIMD: the Hessian variants sit a couple of registers above the
-// 256-register line that would leave a single wave with nothing to hide its loads behind)
 template <bool GRAD, bool HESS>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2)))
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HESS ? 2 : 4, HESS ? 2 : 4)))
     k_ndt_derivs(const float4 *__restrict__ src, unsigned n, unsigned n_total, unsigned shard_rank,
                  unsigned shard_world, const NdtVoxel *__restrict__ vox,
                  const float4 *__restrict__ meanf, const unsigned long long *__restrict__ hkeys, const unsigned *__restrict__ hvals,
@@ -406,6 +404,19 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))
     // 72 M wave instructions that pair up.
 #pragma clang fp contract(fast)
     __shared__ unsigned s_near[27 * kBlock];  // per-lane lists, pass 1 -> pass 2 (lane-private)
+    // the 8 + 15 angle-derivative vectors: read once per point, after its voxels -- as kernel arguments they
+    // are 138 scalar registers the compiler spills lane by lane (171 spills); here they are LDS broadcasts
+    __shared__ double s_jh[23][3];
+    // (the reads must stay where they are used -- hoisted out of the point loop as loop invariants they would
+    // be 138 registers: the index carries a zero the compiler cannot see through, made once per point)
+    auto jh_dot = [&](const double (&x)[3], int k, int opaque0) -> double {
+        const double *v = &s_jh[k + opaque0][0];
+        return x[0] * v[0] + x[1] * v[1] + x[2] * v[2];
+    };
+    if (GRAD || HESS) {
+        if (threadIdx.x < 69u) (&s_jh[0][0])[threadIdx.x] = threadIdx.x < 24u ? (&A.j[0][0])[threadIdx.x] : (&A.h[0][0])[threadIdx.x - 24u];
+        __syncthreads();
+    }
     constexpr int NA = HESS ? kNdtAcc : kNdtAccGrad;  // a gradient pass carries (and ships) 7 sums, not 28
     double acc[NA];
 #pragma unroll
@@ -428,37 +439,6 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))
         const int ci = (int) floorf(__fmul_rn(xt0, A.inv_res));
         const int cj = (int) floorf(__fmul_rn(xt1, A.inv_res));
         const int ck = (int) floorf(__fmul_rn(xt2, A.inv_res));
-        const double x[3] = {(double) sp.x, (double) sp.y, (double) sp.z};
-        // point Jacobian (3x6) and second derivatives, computePointDerivatives
-        // Jc[c][b] = J(b, 3 + c); J(0, 3) = 0 and columns 0..2 are the identity
-        double Jc[3][3];
-        Jc[0][0] = 0.0;
-        Jc[0][1] = dot3d(x, A.j[0]);
-        Jc[0][2] = dot3d(x, A.j[1]);
-        Jc[1][0] = dot3d(x, A.j[2]);
-        Jc[1][1] = dot3d(x, A.j[3]);
-        Jc[1][2] = dot3d(x, A.j[4]);
-        Jc[2][0] = dot3d(x, A.j[5]);
-        Jc[2][1] = dot3d(x, A.j[6]);
-        Jc[2][2] = dot3d(x, A.j[7]);
-        double PH[6][3];  // a, b, c, d, e, f
-        if (HESS) {
-            PH[0][0] = 0.0;
-            PH[0][1] = dot3d(x, A.h[0]);
-            PH[0][2] = dot3d(x, A.h[1]);
-            PH[1][0] = 0.0;
-            PH[1][1] = dot3d(x, A.h[2]);
-            PH[1][2] = dot3d(x, A.h[3]);
-            PH[2][0] = 0.0;
-            PH[2][1] = dot3d(x, A.h[4]);
-            PH[2][2] = dot3d(x, A.h[5]);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                PH[3][r] = dot3d(x, A.h[6 + r]);
-                PH[4][r] = dot3d(x, A.h[9 + r]);
-                PH[5][r] = dot3d(x, A.h[12 + r]);
-            }
-        }
         // Pass 1: the 27 neighbouring cells -> this lane's own list of voxels within `res`
         // (slot numbers in LDS, column = lane).  Only about one neighbour in five passes, and
         // WHICH ones differs from lane to lane; evaluating inside the 27-trip loop would run the
@@ -534,23 +514,47 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))
         // the next voxel's record (mean + inverse covariance, 96 B) is requested before the
         // current one is evaluated: with two waves per SIMD a pass-2 trip would otherwise start
         // with a full memory round trip that nothing hides
+        // (PRE = false frees the 24 registers of the record in flight: the Hessian variants then fit three waves
+        // per SIMD instead of two -- measured equal, 6.30 vs 6.25 ms per 2M registration: lanes idling in this
+        // loop and the vector ALU bind, not latency)
+        constexpr bool PRE = true;
         NdtVoxel vn;
-        {
+        if (PRE) {
             const unsigned v0 = n_near > 0 ? s_near[threadIdx.x] : 0u;
 #pragma unroll
             for (int k = 0; k < 3; ++k) vn.mean[k] = vox[v0].mean[k];
 #pragma unroll
             for (int k = 0; k < 9; ++k) vn.icov[k] = vox[v0].icov[k];
         }
+        // Pass 2.  PCL adds, per (point, voxel) pair, w (-d2 (J_i^T cx)(cx^T J_j) + J_j^T C J_i + cx . h_ij) to
+        // Hessian entry (i, j) and w cx . J_i to gradient entry i (cx = C (x' - mean), C the voxel's inverse
+        // covariance, w = d1 d2 exp(-d2 q / 2)).  The point Jacobian J and the second derivatives h depend on
+        // the POINT only, so the pair loop gathers just
+        //     g3 = sum w cx,   P = sum w cx cx^T (symmetric),   Q = sum w C
+        // and the point's contribution follows once, after its voxels:
+        //     gradient = J^T g3,   Hessian = J^T S J + [g3 . h_ij],   S = -d2 P + Q^T
+        // -- ~35 fused multiply-adds and an exp per pair instead of ~170, the 6 x 6 algebra once per point instead
+        // of once per pair, and the 28 running sums out of the inner loop's registers.  Same terms, grouped
+        // by point: the sums differ from the pair-by-pair ones in rounding order only.
+        double g3[3] = {0.0, 0.0, 0.0}, P[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double Q[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        bool any = false;
 #pragma unroll 1
         for (int t = 0; t < n_near; ++t) {
-            const NdtVoxel v = vn;
-            {
+            NdtVoxel v;
+            if (PRE) {
+                v = vn;
                 const unsigned v1 = t + 1 < n_near ? s_near[(t + 1) * kBlock + threadIdx.x] : 0u;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) vn.mean[k] = vox[v1].mean[k];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) vn.icov[k] = vox[v1].icov[k];
+            } else {
+                const unsigned v1 = s_near[t * kBlock + threadIdx.x];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) v.mean[k] = vox[v1].mean[k];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) v.icov[k] = vox[v1].icov[k];
             }
             const double xx[3] = {(double) xt0 - v.mean[0], (double) xt1 - v.mean[1], (double) xt2 - v.mean[2]};
             double cx[3];
@@ -563,56 +567,93 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))
             acc[0] += -A.d1 * e;
             w *= A.d1;
             if (GRAD || HESS) {
-                // icov * J, column by column.  Columns 0..2 of the point Jacobian are the
-                // identity and J(0,3) is zero (computePointDerivatives), so those products are
-                // read off icov instead of being multiplied out against constants.
-                double cJ[6][3], xcJ[6];
+                any = true;
+                const double wc[3] = {w * cx[0], w * cx[1], w * cx[2]};
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        if (i < 3) {
-                            cJ[i][a] = v.icov[a * 3 + i];
-                        } else {
-                            double c = v.icov[a * 3 + 1] * Jc[i - 3][1] + v.icov[a * 3 + 2] * Jc[i - 3][2];
-                            if (i > 3) c += v.icov[a * 3] * Jc[i - 3][0];
-                            cJ[i][a] = c;
-                        }
-                    }
-                    // xx^T icov J_i through cx = icov xx (icov is symmetric up to rounding)
-                    if (i < 3) {
-                        xcJ[i] = cx[i];
-                    } else {
-                        xcJ[i] = cx[1] * Jc[i - 3][1] + cx[2] * Jc[i - 3][2];
-                        if (i > 3) xcJ[i] += cx[0] * Jc[i - 3][0];
-                    }
-                    if (GRAD) acc[1 + i] += xcJ[i] * w;
-                }
+                for (int a = 0; a < 3; ++a) g3[a] += wc[a];
                 if (HESS) {
+                    P[0] += wc[0] * cx[0];
+                    P[1] += wc[0] * cx[1];
+                    P[2] += wc[0] * cx[2];
+                    P[3] += wc[1] * cx[1];
+                    P[4] += wc[1] * cx[2];
+                    P[5] += wc[2] * cx[2];
 #pragma unroll
-                    for (int i = 0; i < 6; ++i)
-#pragma unroll
-                        for (int j = i; j < 6; ++j) {  // upper triangle; the host mirrors it
-                            double t2 = 0.0, t3;
-                            if (i >= 3 && j >= 3) {
-                                // block (i, j) of point_hessian_: a b c / b d e / c e f
-                                const int hi = i - 3, hj = j - 3;
-                                const int sel = (hi == 0 && hj == 0) ? 0 : ((hi + hj == 1) ? 1 : ((hi + hj == 2 && hi != hj) ? 2 : ((hi == 1 && hj == 1) ? 3 : ((hi + hj == 3) ? 4 : 5))));
-                                const double *hv = PH[sel];
-                                // xx^T icov h = cx . h; the a, b, c blocks have h.x = 0
-                                t2 = cx[1] * hv[1] + cx[2] * hv[2];
-                                if (sel >= 3) t2 += cx[0] * hv[0];
-                            }
-                            // column j of J against row i of icov * J
-                            if (j < 3) {
-                                t3 = cJ[i][j];
-                            } else {
-                                t3 = Jc[j - 3][1] * cJ[i][1] + Jc[j - 3][2] * cJ[i][2];
-                                if (j > 3) t3 += Jc[j - 3][0] * cJ[i][0];
-                            }
-                            acc[ndt_tri(i, j)] += w * (-A.d2 * xcJ[i] * xcJ[j] + t2 + t3);
-                        }
+                    for (int k = 0; k < 9; ++k) Q[k] += w * v.icov[k];
                 }
+            }
+        }
+        if ((GRAD || HESS) && any) {
+            // point Jacobian (3x6), computePointDerivatives: Jc[c][b] = J(b, 3 + c); J(0, 3) = 0 and columns 0..2
+            // are the identity
+            const double x[3] = {(double) sp.x, (double) sp.y, (double) sp.z};
+            int z0 = 0;
+            asm volatile("" : "+s"(z0));
+            double Jc[3][3];
+            Jc[0][0] = 0.0;
+            Jc[0][1] = jh_dot(x, 0, z0);
+            Jc[0][2] = jh_dot(x, 1, z0);
+            Jc[1][0] = jh_dot(x, 2, z0);
+            Jc[1][1] = jh_dot(x, 3, z0);
+            Jc[1][2] = jh_dot(x, 4, z0);
+            Jc[2][0] = jh_dot(x, 5, z0);
+            Jc[2][1] = jh_dot(x, 6, z0);
+            Jc[2][2] = jh_dot(x, 7, z0);
+            if (GRAD) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[1 + i] += g3[i];
+                acc[4] += Jc[0][1] * g3[1] + Jc[0][2] * g3[2];
+                acc[5] += dot3d(Jc[1], g3);
+                acc[6] += dot3d(Jc[2], g3);
+            }
+            if (HESS) {
+                // S = -d2 P + Q^T
+                const double md2 = -A.d2;
+                double S[3][3];
+                S[0][0] = md2 * P[0] + Q[0];
+                S[0][1] = md2 * P[1] + Q[3];
+                S[0][2] = md2 * P[2] + Q[6];
+                S[1][0] = md2 * P[1] + Q[1];
+                S[1][1] = md2 * P[3] + Q[4];
+                S[1][2] = md2 * P[4] + Q[7];
+                S[2][0] = md2 * P[2] + Q[2];
+                S[2][1] = md2 * P[4] + Q[5];
+                S[2][2] = md2 * P[5] + Q[8];
+                // rows 0..2: S itself (columns 0..2) and S J_c (columns 3..5)
+                double SJ[3][3];  // SJ[a][c] = sum_b S[a][b] Jc[c][b]
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    SJ[a][0] = S[a][1] * Jc[0][1] + S[a][2] * Jc[0][2];
+                    SJ[a][1] = S[a][0] * Jc[1][0] + S[a][1] * Jc[1][1] + S[a][2] * Jc[1][2];
+                    SJ[a][2] = S[a][0] * Jc[2][0] + S[a][1] * Jc[2][1] + S[a][2] * Jc[2][2];
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                    for (int j = i; j < 3; ++j) acc[ndt_tri(i, j)] += S[i][j];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) acc[ndt_tri(i, 3 + c)] += SJ[i][c];
+                }
+                // rows 3..5: J_ci^T S J_cj + g3 . h(ci, cj); the second derivatives a, b, c / b, d, e / c, e, f
+                // (computePointDerivatives; a, b, c have no x component) are formed where they are used: three
+                // values live at a time, not eighteen
+                // h vectors by block: a = (0, x.h0, x.h1), b = (0, x.h2, x.h3), c = (0, x.h4, x.h5),
+                // d = x.h[6..8], e = x.h[9..11], f = x.h[12..14]
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                    for (int cj = ci; cj < 3; ++cj) {
+                        const int sel = (ci == 0 && cj == 0) ? 0 : ((ci + cj == 1) ? 1 : ((ci + cj == 2 && ci != cj) ? 2 : ((ci == 1 && cj == 1) ? 3 : ((ci + cj == 3) ? 4 : 5))));
+                        double t = Jc[ci][1] * SJ[1][cj] + Jc[ci][2] * SJ[2][cj];
+                        if (ci > 0) t += Jc[ci][0] * SJ[0][cj];
+                        if (sel < 3) {
+                            t += g3[1] * jh_dot(x, 8 + 2 * sel, z0) + g3[2] * jh_dot(x, 8 + 2 * sel + 1, z0);
+                        } else {
+                            const int k0 = 8 + 6 + 3 * (sel - 3);
+                            t += g3[0] * jh_dot(x, k0, z0) + g3[1] * jh_dot(x, k0 + 1, z0) + g3[2] * jh_dot(x, k0 + 2, z0);
+                        }
+                        acc[ndt_tri(3 + ci, 3 + cj)] += t;
+                    }
             }
         }
     }
