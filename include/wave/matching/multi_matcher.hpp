@@ -9,8 +9,8 @@
 // on scans up to 200 000) takes
 // EVERYTHING that is queued -- up to 256 pairs, one compute unit each -- per trip: 80 000
 // registrations/s with one worker, 110 000-145 000 with two to four at 10 000 points, 19 000-37 000 at
-// 30 000 (libwave_amd/host/bench_multimatcher, BENCH_QUEUE=2048).  Queue depth is what feeds it: construct the pool with a
-// queue of a few hundred pairs rather than the reference's default of 10.
+// 30 000 (libwave_amd/host/bench_multimatcher).  A batch is gathered over several refills of the queue
+// (see work()): the reference's default queue of 10 feeds it as well as a deep one.
 //
 // Public surface as in the reference (wave_matching/include/wave/matching/multi_matcher.hpp:
 // 29-96): construct with (n_threads, queue_size, params); insert(id, ref, target) blocks while
@@ -21,6 +21,7 @@
 #define WAVE_MULTI_MATCHER_HPP
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <deque>
@@ -52,7 +53,7 @@ class MultiMatcher {
         const std::vector<int> devs = devices();
         for (int w = 0; w < crew; ++w) {
             const int dev = devs.empty() ? -1 : devs[(size_t) w % devs.size()];
-            workers_.emplace_back([this, dev] { work(dev); });
+            workers_.emplace_back([this, dev, w] { work(dev, w); });
         }
     }
 
@@ -62,6 +63,8 @@ class MultiMatcher {
             closing_ = true;
         }
         jobs_changed_.notify_all();
+        more_jobs_.notify_all();
+        space_free_.notify_all();
         for (auto &w : workers_) w.join();
     }
 
@@ -105,11 +108,15 @@ class MultiMatcher {
     /** Queues one pair; blocks while `queue_size` pairs are already waiting. */
     void insert(const int &id, const PCLPointCloudPtr &src, const PCLPointCloudPtr &target) {
         std::unique_lock<std::mutex> hold(lock_);
-        jobs_changed_.wait(hold, [this] { return jobs_.size() < capacity_; });
+        space_free_.wait(hold, [this] { return jobs_.size() < capacity_; });
         jobs_.push_back(Job{id, src, target});
         ++unfinished_;
+        const bool lingering = lingering_;
         hold.unlock();
-        jobs_changed_.notify_all();
+        // the worker that is gathering a batch if there is one (the usual case while pairs keep coming: ONE
+        // thread woken per pair, not the crew), else the idle workers
+        if (lingering) more_jobs_.notify_one();
+        else jobs_changed_.notify_all();  // (the workers' conditions differ -- batch workers, the bound: all look)
     }
 
     /** True once every inserted pair has been registered (successfully or not). */
@@ -156,6 +163,28 @@ class MultiMatcher {
     }
     template <typename M>
     static void takeBatch(M &, std::deque<Job> &, std::vector<Job> &, long) {}
+    // would the pair in front go down the batched path?
+    template <typename M>
+    static auto frontBatchable(M &matcher, const std::deque<Job> &jobs, int)
+        -> decltype(matcher.batchable(jobs.front().ref, jobs.front().target), bool()) {
+        return !jobs.empty() && matcher.batchable(jobs.front().ref, jobs.front().target);
+    }
+    template <typename M>
+    static bool frontBatchable(M &, const std::deque<Job> &, long) {
+        return false;
+    }
+    // Batches in flight at once (gathered, staged, launched, waited for -- each by its own worker): one batch
+    // fills the device, a second and third overlap their host-side staging and uploads with it; beyond that
+    // more only add threads copying at the same time (measured on an MI355X box with a 16-CPU quota, 10k-point
+    // pairs, queue of 10: 95 000 registrations/s with 4 workers, 74 000 with 8, 48 000 with 16 before this
+    // bound).  The other workers of a big crew stay asleep -- or register the pairs that do not batch.
+    static int maxBatchesInFlight() {
+        if (const char *e = std::getenv("WAVE_MATCHING_MAX_BATCHES")) {
+            const int v = std::atoi(e);
+            if (v > 0) return v;
+        }
+        return 4;
+    }
     template <typename M>
     auto runBatch(M &matcher, const std::vector<Job> &taken, int)
         -> decltype(matcher.matchBatch(std::declval<const std::vector<std::pair<PCLPointCloudPtr, PCLPointCloudPtr>> &>(),
@@ -205,7 +234,19 @@ class MultiMatcher {
     template <typename M>
     static void bindThread(int, long) {}
 
-    void work(int device) {
+    // How a batch forms.  The reference's default queue holds TEN pairs (multi_matcher.hpp:32-34), a launch of
+    // the batched path wants a couple of hundred (one compute unit each, ~3 ms whatever their number).  So
+    // the queue's capacity must not be the batch's: ONE worker at a time -- the gatherer -- takes what is
+    // queued, frees the slots, and keeps taking while the producer keeps delivering, until it holds kBatch
+    // pairs or nothing new has come for kLingerUs (a producer that paused: a lone pair is delayed by that
+    // much, against the milliseconds it takes to register); then the next worker gathers while this one
+    // stages and launches.  With a queue of 10 the pool now forms the same batches as with a queue of
+    // thousands, and more workers only add staging threads: throughput no longer falls with the crew.
+    static constexpr int kLingerUs = 30;
+    void work(int device, int index) {
+        // (pairs that batch go to the FIRST max_batches_ workers only: the same few contexts, with their staging
+        // buffers warm, instead of whichever of sixteen wakes up)
+        const bool batch_worker = index < max_batches_;
         if (device >= 0) bindThread<T>(device, 0);
         T matcher{R(config_)};
         std::vector<Job> taken;
@@ -214,23 +255,53 @@ class MultiMatcher {
             taken.clear();
             {
                 std::unique_lock<std::mutex> hold(lock_);
-                jobs_changed_.wait(hold, [this] { return closing_ || !jobs_.empty(); });
+                jobs_changed_.wait(hold, [this, &matcher, batch_worker] {
+                    return closing_ || (!jobs_.empty() && !gathering_ &&
+                                        (!frontBatchable(matcher, jobs_, 0) || (batch_worker && batches_in_flight_ < max_batches_)));
+                });
                 if (closing_) return;
+                gathering_ = true;
                 takeBatch(matcher, jobs_, taken, 0);
-                if (taken.size() < 2) {  // nothing to gain from a launch of one (or the matcher has no batch path)
-                    if (taken.empty()) {
-                        job = jobs_.front();
-                        jobs_.pop_front();
-                    } else {
+                if (taken.empty()) {  // the matcher has no batch path, or this pair does not fit it: one at a time
+                    job = jobs_.front();
+                    jobs_.pop_front();
+                } else {
+                    while (taken.size() < kBatch && !closing_) {
+                        if (jobs_.empty()) {
+                            space_free_.notify_one();  // (the producer may be waiting for the slots just freed)
+                            lingering_ = true;
+                            // (wait_until on the system clock = pthread_cond_timedwait; wait_for would be
+                            // pthread_cond_clockwait, which GCC 11's ThreadSanitizer does not know: it then
+                            // misses the unlock inside the wait and reports races that are not there)
+                            const bool more = more_jobs_.wait_until(hold, std::chrono::system_clock::now() + std::chrono::microseconds(kLingerUs),
+                                                                    [this] { return closing_ || !jobs_.empty(); });
+                            lingering_ = false;
+                            if (!more || closing_) break;
+                        }
+                        const size_t before = taken.size();
+                        takeBatch(matcher, jobs_, taken, 0);
+                        if (taken.size() == before) break;  // (the pair in front is for the one-at-a-time path)
+                    }
+                    if (taken.size() < 2) {  // nothing to gain from a launch of one
                         job = taken.front();
                         taken.clear();
+                    } else {
+                        ++batches_in_flight_;
                     }
                 }
+                gathering_ = false;
             }
-            jobs_changed_.notify_all();  // slots are free for insert()
+            space_free_.notify_one();    // slots are free for insert() ...
+            jobs_changed_.notify_all();  // ... and the next worker may gather
             if (!taken.empty()) {
-                if (runBatch(matcher, taken, 0)) continue;
-                for (const Job &j : taken) registerOne(matcher, j);  // (the device refused: one by one)
+                const bool ran = runBatch(matcher, taken, 0);
+                {
+                    std::lock_guard<std::mutex> hold(lock_);
+                    --batches_in_flight_;
+                }
+                jobs_changed_.notify_all();  // (a worker held back by the bound may gather now)
+                if (!ran)
+                    for (const Job &j : taken) registerOne(matcher, j);  // (the device refused: one by one)
                 continue;
             }
 
@@ -250,7 +321,12 @@ class MultiMatcher {
     const size_t capacity_;
     R config_;
     std::mutex lock_;
-    std::condition_variable jobs_changed_;
+    std::condition_variable jobs_changed_;  // idle workers: a pair is waiting and nobody is gathering
+    std::condition_variable more_jobs_;     // the gatherer, between the producer's deliveries
+    std::condition_variable space_free_;    // insert(): the queue has room
+    bool gathering_ = false, lingering_ = false;
+    int batches_in_flight_ = 0;
+    const int max_batches_ = maxBatchesInFlight();
     std::deque<Job> jobs_;
     std::deque<Outcome, Eigen::aligned_allocator<Outcome>> finished_;
     size_t unfinished_ = 0;

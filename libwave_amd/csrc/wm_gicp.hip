@@ -884,7 +884,7 @@ static bool serve_eval(GicpFn &F, const FdfArgs &A) {
     for (unsigned spins = 1; have < kGicpAcc; ++spins) {
         while (have < kGicpAcc && slots[have].seq == expect) ++have;
         if (have == kGicpAcc) break;
-        __builtin_ia32_pause();
+        cpu_relax();
         if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(100)) {
             serve_end(F);  // (waits for the kernel: it leaves on the command, or by its own guard)
             F.served_fallbacks++;

@@ -492,7 +492,7 @@ static int wait_flag(wm_ctx *ctx, unsigned seq) {
         if (yielding)
             std::this_thread::yield();
         else
-            __builtin_ia32_pause();
+            cpu_relax();
         if ((spins & 63u) == 0 || yielding) {
             const auto waited = std::chrono::steady_clock::now() - t0;
             if (waited > std::chrono::milliseconds(4)) {
@@ -605,6 +605,18 @@ int sum_to_device(wm_ctx *ctx, double *dst_dev, const double *src_dev, unsigned 
 
 static int download_state(wm_ctx *ctx) {
     return fast_fetch(ctx, ctx->h_state, ctx->d_state.p, sizeof(IcpDevState));
+}
+
+int sync_sleeping(wm_ctx *ctx) {
+    if (!ctx->ev_block && hipEventCreateWithFlags(&ctx->ev_block, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
+        (void) hipGetLastError();
+        ctx->ev_block = nullptr;
+        WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return WM_OK;
+    }
+    WM_HIP(ctx, hipEventRecord(ctx->ev_block, ctx->stream));
+    WM_HIP(ctx, hipEventSynchronize(ctx->ev_block));
+    return WM_OK;
 }
 
 int copy_to_caller(wm_ctx *ctx, void *dst, const void *src_dev, size_t bytes) {
@@ -893,6 +905,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
     if (ctx->h_sig) (void) hipHostFree(ctx->h_sig);
     if (ctx->h_pub) (void) hipHostFree(ctx->h_pub);
     if (ctx->h_late) (void) hipHostFree(ctx->h_late);
+    if (ctx->ev_block) (void) hipEventDestroy(ctx->ev_block);
     if (ctx->h_scratch) (void) hipHostFree(ctx->h_scratch);
     for (hipEvent_t e : ctx->ev_pool) (void) hipEventDestroy(e);
     if (ctx->ev_a) (void) hipEventDestroy(ctx->ev_a);
@@ -1100,7 +1113,7 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
                 if (yielding)
                     std::this_thread::yield();
                 else
-                    __builtin_ia32_pause();
+                    cpu_relax();
                 if ((spins & 63u) == 0 || yielding) {
                     const auto waited = std::chrono::steady_clock::now() - t0;
                     if (waited > std::chrono::milliseconds(20)) {
@@ -1163,7 +1176,7 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
                     bool yielding = false;
                     for (unsigned spins = 1; (unsigned) (*hx >> 32) != seq; ++spins) {
                         if (yielding) std::this_thread::yield();
-                        else __builtin_ia32_pause();
+                        else cpu_relax();
                         if ((spins & 63u) == 0 || yielding) {
                             const auto waited = std::chrono::steady_clock::now() - t0;
                             if (waited > std::chrono::milliseconds(20)) {

@@ -238,6 +238,7 @@ struct wm_ctx {
     // events for profile mode
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    hipEvent_t ev_block = nullptr;  // hipEventBlockingSync: waits of milliseconds sleep instead of spinning (sync_sleeping)
     std::vector<float> iter_nn_ms;
 
     // GICP: caller-order source, its own search grid, per-point covariances
@@ -379,6 +380,20 @@ int launch_nn_late(wm_ctx *ctx, float thr_d2, int stats_mode, unsigned blocks, b
 // the device's budget of resident workgroups (per process), in 1/1024ths of the device: the share taken (0: refused)
 int resident_admit(int device, int nb, int capacity);
 void resident_release(int device, int share);
+// one turn of a host-side busy-wait (the pause hint of the host's architecture; nothing where there is none)
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#endif
+}
+
+// Wait for everything enqueued on the context's stream WITHOUT burning a core: the batched paths wait
+// milliseconds per launch, and a crew of MultiMatcher workers that all spin through their waits
+// (hipStreamSynchronize busy-polls) exhausts a container's CPU quota -- the whole process is then
+// throttled, staging threads included.  The thread sleeps on a blocking event (wake-up ~0.1 ms).
+int sync_sleeping(wm_ctx *ctx);
 int launch_fix_keys(wm_ctx *ctx, float thr_d2);  // after certified iterations: every key's distance brought up to date
 // the certificate kernel (late iterations): stats_mode as above; bounds_valid = the previous search of
 // this align was launch_nn_cert too (its per-query bounds are still in ctx->nn_bound)
