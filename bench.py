@@ -181,13 +181,22 @@ def pmc_summary():
     return pmc
 
 
-def pmc_traffic_bytes(pmc, kernel="k_nn_grid"):
-    """HBM bytes per launch of a kernel: FETCH_SIZE doubled (MI355X_MICROARCH.md: gfx950 tallies
-    128-B requests at 64 B for wide coalesced reads) + WRITE_SIZE as reported."""
+def pmc_traffic_bytes(pmc, kernel="k_nn_grid", stream_bytes=None):
+    """HBM bytes per launch of a kernel from its FETCH_SIZE / WRITE_SIZE counters.  What FETCH_SIZE counts was
+    calibrated on this part with access patterns of known traffic (scripts/gpu_fetch_calib.sh ->
+    profiles/r04_fetch_size_calibration.json): a wide coalesced stream is tallied at HALF its bytes (2 GiB read =
+    1024 MiB counted: the guide's gfx950 note), a gather is tallied at what it moves -- 64 B per lone 16-byte
+    element, 128 B (the whole line) per run of four float4, the unit of the search's candidate walk.  So
+      stream_bytes = None : a streaming kernel, 2 x FETCH + WRITE;
+      stream_bytes = S    : a kernel that reads S bytes in coalesced streams and gathers the rest:
+                            (FETCH - S / 2) for the gathers + S for the streams = FETCH + S / 2, + WRITE."""
     d = pmc.get(kernel)
     if not d or "FETCH_SIZE_kb_per_dispatch" not in d:
         return None
-    return (2.0 * d["FETCH_SIZE_kb_per_dispatch"] + d["WRITE_SIZE_kb_per_dispatch"]) * 1024.0
+    fetch, write = d["FETCH_SIZE_kb_per_dispatch"] * 1024.0, d["WRITE_SIZE_kb_per_dispatch"] * 1024.0
+    if stream_bytes is None:
+        return 2.0 * fetch + write
+    return max(fetch + 0.5 * stream_bytes, stream_bytes) + write
 
 
 def counter_traffic(pmc, kernel, avg_launch_us, copy_peak_gbs):
@@ -267,9 +276,28 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu, copy_peak=None):
         m = 20_000
         rs, ts_, _ = synth.pair(m, seed=42)
         t0 = time.perf_counter()
-        O.gicp_align(rs, ts_)
+        want = O.gicp_align(rs, ts_)
         e["cpu_baseline"] = {"seconds_per_registration": time.perf_counter() - t0, "cores": 1, "kind": "port",
                              "sample": "the oracle's GICP on a %d<->%d pair of the same scene (the 500k pair takes minutes)" % (m, m)}
+        # parity where the oracle can be run: the SAME 20k pair through the HIP path.  (translation_error_m above
+        # is against the ground truth of a noisy re-sampled pair -- what GICP's loose BFGS stop leaves, for the
+        # oracle as for the kernels -- not a difference between the two.)
+        try:
+            ctx.set_source(rs)
+            ctx.set_target(ts_)
+            got = ctx.gicp_align()
+            if got["T"] is not None and want.get("T") is not None:
+                Tw = np.asarray(want["T"], dtype=np.float64)
+                dR = got["T"][:3, :3].T @ Tw[:3, :3]
+                e["parity_vs_oracle_20k"] = {
+                    "translation_difference_m": float(np.linalg.norm(got["T"][:3, 3] - Tw[:3, 3])),
+                    "rotation_difference_rad": float(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))),
+                    "identical_float_matrix": bool(np.array_equal(got["T"].astype(np.float32), Tw.astype(np.float32))),
+                    "outer_iterations": [got["iterations"], want.get("iterations")],
+                    "note": "the same 20k pair through the HIP path and the oracle; translation_error_m above is against "
+                            "the ground truth of the noisy 500k pair (what GICP's loose BFGS stop leaves), not a parity figure"}
+        except Exception as ex:  # (never lose the line over the extra check)
+            e["parity_vs_oracle_20k"] = {"error": str(ex)}
     out.append(e)
     del d_ref, d_tgt
 
@@ -561,11 +589,15 @@ def main():
             if launches <= 0:
                 continue
             us = ms / launches * 1e3
-            tr = pmc_traffic_bytes(pmc, key) if world == 1 else None
+            # coalesced streams of a launch: source points + previous keys + previous matches (k_nn_grid),
+            # source points + matches + positions-and-bounds (k_nn_cert); everything else it reads is gathered
+            streams = (16.0 + 8.0 + 16.0 if key == "k_nn_grid" else 48.0) * pts_per_launch
+            tr = pmc_traffic_bytes(pmc, key, streams) if world == 1 else None
+            tr_upper = pmc_traffic_bytes(pmc, key) if world == 1 else None
             kernels.append({"name": name, "launches_timed": launches, "avg_launch_us": us,
                             "share_of_search_time": ms / nn_ms if nn_ms > 0 else None,
                             "achieved": alg_bytes / (us * 1e-6) / 1e9, "frac": alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                            "traffic": tr,
+                            "traffic": tr, "traffic_if_all_streamed_x2": tr_upper,
                             "hbm_util": (tr / (us * 1e-6) / 1e9 / peak_copy) if (tr and peak_copy) else None})
         traffic = None
         if kernels and all(k["traffic"] for k in kernels):
@@ -579,7 +611,9 @@ def main():
             "hbm_util": (traffic / (nn_us * 1e-6) / 1e9 / peak_copy) if (traffic and peak_copy) else None,
             "traffic_source": ("profiles/pmc_latest.json, tag %s (separate rocprofv3 --pmc passes of this "
                                "command; a committed measurement, not this run's; its csrc_sha256 stamp matches "
-                               "the kernels in the tree)" % pmc.get("tag")) if pmc.get("tag") else pmc.get("stale"),
+                               "the kernels in the tree); FETCH_SIZE calibrated on this part: coalesced streams are "
+                               "tallied at half their bytes, gathers at what they move (profiles/r04_fetch_size_calibration.json)"
+                               % pmc.get("tag")) if pmc.get("tag") else pmc.get("stale"),
             "peak_measured_copy": peak_copy,
             "peak_measured_copy_method": "float4 grid-stride copy kernel, 1 GiB in + 1 GiB out, 10 launches (wm_debug_copy_bandwidth)",
             "algorithmic_bytes_per_launch": alg_bytes,

@@ -608,15 +608,23 @@ static int download_state(wm_ctx *ctx) {
 }
 
 int sync_sleeping(wm_ctx *ctx) {
-    if (!ctx->ev_block && hipEventCreateWithFlags(&ctx->ev_block, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
+    // an event behind what is queued, looked at every ~50 us between short sleeps: a few per cent of a core
+    // per waiting thread, and the wait ends within ~0.1 ms of the work (a BLOCKING event synchronise -- the
+    // runtime's interrupt path -- was seen to add up to a millisecond per wait: 59 000 -> 48 500 pairs/s for a
+    // single context's 256-pair batches)
+    if (!ctx->ev_block && hipEventCreateWithFlags(&ctx->ev_block, hipEventDisableTiming) != hipSuccess) {
         (void) hipGetLastError();
         ctx->ev_block = nullptr;
         WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return WM_OK;
     }
     WM_HIP(ctx, hipEventRecord(ctx->ev_block, ctx->stream));
-    WM_HIP(ctx, hipEventSynchronize(ctx->ev_block));
-    return WM_OK;
+    for (;;) {
+        const hipError_t e = hipEventQuery(ctx->ev_block);
+        if (e == hipSuccess) return WM_OK;
+        if (e != hipErrorNotReady) WM_HIP(ctx, e);
+        std::this_thread::sleep_for(std::chrono::microseconds(40));
+    }
 }
 
 int copy_to_caller(wm_ctx *ctx, void *dst, const void *src_dev, size_t bytes) {

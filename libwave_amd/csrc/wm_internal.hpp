@@ -238,7 +238,7 @@ struct wm_ctx {
     // events for profile mode
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    hipEvent_t ev_block = nullptr;  // hipEventBlockingSync: waits of milliseconds sleep instead of spinning (sync_sleeping)
+    hipEvent_t ev_block = nullptr;  // the event sync_sleeping polls between short sleeps
     std::vector<float> iter_nn_ms;
 
     // GICP: caller-order source, its own search grid, per-point covariances
@@ -392,7 +392,7 @@ static inline void cpu_relax() {
 // Wait for everything enqueued on the context's stream WITHOUT burning a core: the batched paths wait
 // milliseconds per launch, and a crew of MultiMatcher workers that all spin through their waits
 // (hipStreamSynchronize busy-polls) exhausts a container's CPU quota -- the whole process is then
-// throttled, staging threads included.  The thread sleeps on a blocking event (wake-up ~0.1 ms).
+// throttled, staging threads included.  The thread sleeps between looks at an event (wake-up ~0.1 ms).
 int sync_sleeping(wm_ctx *ctx);
 int launch_fix_keys(wm_ctx *ctx, float thr_d2);  // after certified iterations: every key's distance brought up to date
 // the certificate kernel (late iterations): stats_mode as above; bounds_valid = the previous search of

@@ -1465,10 +1465,14 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
             if (la.dbg_w && li == la.dbg_li && threadIdx.x == 0) la.dbg_w[(size_t) blockIdx.x * 8u + (k)] = wall_clock64(); \
     } while (0)
     WM_WSTAMP(0);  // pose in
-    float Tl[12];
+    // (one launch per iteration: the pose is read where it is used, as before; resident: from this iteration's slot)
+    float Tl_loc[12];
+    if constexpr (LATE) {
 #pragma unroll
-    for (int k = 0; k < 12; ++k)
-        Tl[k] = LATE ? __uint_as_float((unsigned) __builtin_amdgcn_readfirstlane((int) __float_as_uint(s_bc[k]))) : st->Tf[k];
+        for (int k = 0; k < 12; ++k)
+            Tl_loc[k] = __uint_as_float((unsigned) __builtin_amdgcn_readfirstlane((int) __float_as_uint(s_bc[k])));
+    }
+    const float *Tl = LATE ? Tl_loc : st->Tf;
     const float step_now = LATE ? __uint_as_float((unsigned) __builtin_amdgcn_readfirstlane((int) __float_as_uint(s_bc[12])))
                                 : st->step_disp;
     const bool valid = (LATE && li > 0u) || (bounds_valid != 0 && have_prev);

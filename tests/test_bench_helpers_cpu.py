@@ -50,3 +50,17 @@ def test_stale_capture_reports_no_traffic(tmp_path, monkeypatch):
         "k_nn_grid": {"FETCH_SIZE_kb_per_dispatch": 1.0, "WRITE_SIZE_kb_per_dispatch": 1.0}}))
     assert bench.pmc_summary().get("tag") == "new"
     monkeypatch.setattr(bench, "ROOT", real_root)
+
+
+def test_calibrated_gather_traffic():
+    """A kernel that streams S bytes and gathers the rest: FETCH_SIZE counts the streams at half (calibration:
+    profiles/r04_fetch_size_calibration.json), so bytes = FETCH + S / 2 + WRITE; never below the streams."""
+    import bench
+    pmc = {"k": {"FETCH_SIZE_kb_per_dispatch": 1000.0, "WRITE_SIZE_kb_per_dispatch": 100.0}}
+    assert bench.pmc_traffic_bytes(pmc, "k") == (2000.0 + 100.0) * 1024.0
+    assert bench.pmc_traffic_bytes(pmc, "k", stream_bytes=400.0 * 1024.0) == (1000.0 + 200.0 + 100.0) * 1024.0
+    assert bench.pmc_traffic_bytes(pmc, "k", stream_bytes=4000.0 * 1024.0) == (4000.0 + 100.0) * 1024.0
+    import json
+    cal = json.load(open(os.path.join(ROOT, "profiles", "r04_fetch_size_calibration.json")))
+    assert abs(cal[0]["factor_to_64B_sector_bytes"] - 2.0) < 0.05        # the stream: counted at half
+    assert abs(cal[3]["factor_to_128B_line_bytes"] - 1.0) < 0.05         # four float4 of one line: the whole line, once
