@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(kBlock)
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float4 q = qpts[i];
-    const unsigned slot = by_w ? __float_as_uint(q.w) : i;
+    const unsigned slot = (by_w & 1) ? __float_as_uint(q.w) : i;
     double *out = cov_out + (size_t) slot * 9;
     if (!(q.x == q.x)) {  // non-finite point: never matched; keep a defined value
 #pragma unroll
@@ -160,6 +160,13 @@ __global__ void __launch_bounds__(kBlock)
         return;
     }
     unsigned long long best[K];
+    // (developer timing experiment, WM_TUNE_COV_DBG -- WRONG results: 512 = no neighbour search, 256 = no SVD.
+    // Measured at 500k points: 329 us as is, 314 without the SVD, 49 without the search, 27 without both:
+    // the k-NN search is 85 % of this kernel)
+    if (by_w & 512) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) best[j] = (unsigned long long) min(i + (unsigned) j, n - 1u);
+    } else
     knn_search<K>(g, q.x, q.y, q.z, k, r0_cells, best, s_runs, threadIdx.x, kBlock);
     double mean[3] = {0, 0, 0}, c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -190,6 +197,11 @@ __global__ void __launch_bounds__(kBlock)
                 c[b * 3 + a] = c[a * 3 + b];
             }
     double U[9], S[3], V[9];
+    if (by_w & 256) {
+#pragma unroll
+        for (int a = 0; a < 9; ++a) out[a] = c[a];
+        return;
+    }
     svd3<false>(c, U, S, V);  // IEEE operations only: the oracle reproduces these matrices bit for bit
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -1205,7 +1217,7 @@ static int launch_cov(wm_ctx *ctx, const GridDev &g, const float4 *q, size_t n, 
                       int k, double eps, double *out, int by_w) {
     if (n == 0) return WM_OK;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gicp_cov<K>), dim3((unsigned) ((n + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, ctx->stream, g, q, (unsigned) n, orig, k, eps, out, by_w,
+                       dim3(kBlock), 0, ctx->stream, g, q, (unsigned) n, orig, k, eps, out, by_w | ctx->tune_cov_dbg,
                        ctx->tune_knn_r0 > 0 ? ctx->tune_knn_r0 : (k <= 12 ? 1.0f : 1.5f));
     WM_HIP(ctx, hipGetLastError());
     return WM_OK;

@@ -863,6 +863,7 @@ int wm_ctx_create(wm_ctx **out, int device) {
     if (const char *e = getenv("WM_TUNE_NDT_SPEC_HESSIAN")) ctx->tune_ndt_spec_hessian = atoi(e);
     if (const char *e = getenv("WM_TUNE_LAG")) ctx->tune_lag = atoi(e);
     if (const char *e = getenv("WM_TUNE_LATE")) ctx->tune_late = atoi(e);
+    if (const char *e = getenv("WM_TUNE_COV_DBG")) ctx->tune_cov_dbg = atoi(e) & 768;
     if (const char *e = getenv("WM_TUNE_R0")) {
         const float v = (float) atof(e);
         if (v > 0) ctx->tune_r0 = v;

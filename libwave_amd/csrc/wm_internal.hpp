@@ -203,6 +203,7 @@ struct wm_ctx {
     // workgroup's searches end 10 us after the median one's, and the solver's chain (rows 3.8, solve 4.4, hand-out
     // 0.7 us) is serial behind them
     int tune_late = 0;
+    int tune_cov_dbg = 0;                   // developer timing experiment in k_gicp_cov (wrong results): see there
     unsigned long long *h_pub = nullptr;    // pinned: [0] (done << 63 | iterations finished << 32 | step size bits) of the latest solve, [k] iteration k's own record
     int h_pub_slots = 0;
     wm::DevBuf vg_idx, vg_idx2, vg_perm, vg_perm2, vg_tmp, vg_seg, io_a, io_b, ds_ref, ds_tgt, match_ref, match_tgt;

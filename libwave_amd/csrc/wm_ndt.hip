@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(kBlock)
                            unsigned nvox, unsigned min_count, NdtLattice L, NdtVoxel *__restrict__ vox,
                            float4 *__restrict__ meanf, unsigned long long *__restrict__ vkey,
                            unsigned *__restrict__ n_valid) {
-    __shared__ float s_p[kBlock / 64][3][64];
+    __shared__ __attribute__((aligned(16))) float s_p[kBlock / 64][3][64];
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned waves_total = gridDim.x * (kBlock / 64);
     // lane 0..2: sum of p[lane] (times 1); lane 3..11: sum of p[a] * p[b]
@@ -302,20 +302,40 @@ __global__ void __launch_bounds__(kBlock)
         const unsigned i = heads[slot], j = heads[slot + 1];
         if (j - i < min_count) continue;  // (wave-uniform) a small voxel: the lane kernel's
         double acc = 0.0;
+        // (the NEXT 64 points are requested before this batch's 64 dependent additions start: the additions
+        // of a crowded voxel -- thousands of points next to the sensor of a ring scan, one batch after the
+        // other -- are the kernel's critical path, and two dependent gathers per batch were three quarters of it)
+        float4 pn = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i + lane < j) pn = pts[perm[i + lane]];
         for (unsigned t = i; t < j; t += 64) {
-            if (t + lane < j) {
-                const float4 p = pts[perm[t + lane]];
-                s_p[wave][0][lane] = p.x;
-                s_p[wave][1][lane] = p.y;
-                s_p[wave][2][lane] = p.z;
-            }
+            __builtin_amdgcn_wave_barrier();  // (the previous batch's reads are done: LDS operations of a wave execute in order)
+            s_p[wave][0][lane] = pn.x;
+            s_p[wave][1][lane] = pn.y;
+            s_p[wave][2][lane] = pn.z;
+            if (t + 64u + lane < j) pn = pts[perm[t + 64u + lane]];
             // (a wave's LDS traffic is in order: no barrier between its own write and read)
             if (lane < 12) {
                 const unsigned m = j - t < 64u ? j - t : 64u;
-                for (unsigned u = 0; u < m; ++u) {
+                unsigned u = 0;
+                // sixteen points at a time: their operands are read from LDS together (eight 16-byte reads), then
+                // the sixteen dependent additions follow -- one element per trip (read, wait, convert, add) was
+                // ~100 cycles per point, and a crowded voxel's thousands of points are the kernel's critical path
+                for (; u + 16u <= m; u += 16u) {
+                    float xs[16], ys[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 a = *reinterpret_cast<const float4 *>(&s_p[wave][ia][u + 4u * (unsigned) q]);
+                        const float4 b = *reinterpret_cast<const float4 *>(&s_p[wave][ib][u + 4u * (unsigned) q]);
+                        xs[4 * q] = a.x, xs[4 * q + 1] = a.y, xs[4 * q + 2] = a.z, xs[4 * q + 3] = a.w;
+                        ys[4 * q] = b.x, ys[4 * q + 1] = b.y, ys[4 * q + 2] = b.z, ys[4 * q + 3] = b.w;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc = fma((double) xs[q], product ? (double) ys[q] : 1.0, acc);  // y = 1: exactly acc + x
+                }
+                for (; u < m; ++u) {
                     const double x = (double) s_p[wave][ia][u];
                     const double y = product ? (double) s_p[wave][ib][u] : 1.0;
-                    acc = fma(x, y, acc);  // y = 1: exactly acc + x
+                    acc = fma(x, y, acc);
                 }
             }
         }
