@@ -811,14 +811,25 @@ static void serve_begin(GicpFn &F) {
         ctx->gicp_serve_seq = 0;
         ctx->gicp_serve_ok = 1;
     }
-    const int nb = gicp_blocks(ctx);
+    int nb = gicp_blocks(ctx);
     if (nb > ctx->gicp_serve_capacity) return;  // every workgroup has to be resident at once
     if (!ctx->h_gicp && hipHostMalloc((void **) &ctx->h_gicp, sizeof(double) * 64, hipHostMallocDefault) != hipSuccess) return;
     if (!ctx->h_gicp_slots) {
         if (hipHostMalloc((void **) &ctx->h_gicp_slots, sizeof(GicpSlot) * 16, hipHostMallocDefault) != hipSuccess) return;
         memset(ctx->h_gicp_slots, 0, sizeof(GicpSlot) * 16);
     }
-    const int share = resident_admit(ctx->device, nb, ctx->gicp_serve_capacity);
+    int share = resident_admit(ctx->device, nb, ctx->gicp_serve_capacity);
+    if (share <= 0 && ctx->gicp_serve_cached) {
+        // The device's budget is taken by other matchers' evaluators (a MultiMatcher pool of small pairs): come
+        // in COMPACT -- up to kServeCached pairs per thread instead of one, an eighth of the workgroups; an
+        // evaluation takes a microsecond or two longer, and eight times as many evaluators fit side by side.
+        // (The rows are added in double-double: the sums do not depend on how the pairs are dealt out.)
+        const int compact = (int) ((ctx->n_src + (size_t) kBlock * kServeCached - 1) / ((size_t) kBlock * kServeCached));
+        if (compact >= 1 && compact < nb) {
+            share = resident_admit(ctx->device, compact, ctx->gicp_serve_capacity);
+            if (share > 0) nb = compact;
+        }
+    }
     if (share <= 0) return;
     F.served_blocks = share;
     F.served_evals = 0;

@@ -31,16 +31,23 @@ __global__ void __launch_bounds__(kBlock) k_pack(const unsigned char *in, size_t
     out[i] = make_float4(x, y, z, __uint_as_float((unsigned) i));
 }
 
-int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, float4 *out) {
+int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, float4 *out, int slot) {
     if (n == 0) return WM_OK;
     const unsigned char *dptr = nullptr;
     if (mem == WM_MEM_HOST) {
-        // Caller memory is pageable: a blocking copy, after the stream has drained (the staging
-        // buffer may still feed the previous cloud's k_pack)
-        WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        WM_HIP(ctx, ctx->staging.reserve(n * stride));
-        WM_HIP(ctx, hipMemcpy(ctx->staging.p, pts, n * stride, hipMemcpyHostToDevice));
-        dptr = ctx->staging.as<unsigned char>();
+        // Caller memory is pageable: a blocking copy.  Slot 0 (the source, and every other caller): after the
+        // stream has drained -- the staging buffer may still feed the previous cloud's k_pack.  Slot 1 (the
+        // target, when the source of the same registration was uploaded just before): a staging buffer of
+        // its own and NO wait -- the source's bounding box, Morton sort and gather run on the stream while
+        // this cloud crosses PCIe (wm_set_target).
+        DevBuf &stage = slot == 1 ? ctx->staging2 : ctx->staging;
+        if (slot != 1) WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (stage.cap < n * stride) {  // (growing it frees the old one: nothing of ours may still read it)
+            WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            WM_HIP(ctx, stage.reserve(n * stride));
+        }
+        WM_HIP(ctx, hipMemcpy(stage.p, pts, n * stride, hipMemcpyHostToDevice));
+        dptr = stage.as<unsigned char>();
     } else {
         dptr = static_cast<const unsigned char *>(pts);
     }

@@ -863,6 +863,7 @@ int wm_ctx_create(wm_ctx **out, int device) {
     if (const char *e = getenv("WM_TUNE_NDT_SPEC_HESSIAN")) ctx->tune_ndt_spec_hessian = atoi(e);
     if (const char *e = getenv("WM_TUNE_LAG")) ctx->tune_lag = atoi(e);
     if (const char *e = getenv("WM_TUNE_LATE")) ctx->tune_late = atoi(e);
+    if (const char *e = getenv("WM_TUNE_EARLY_SOURCE")) ctx->tune_early_source = atoi(e);
     if (const char *e = getenv("WM_TUNE_COV_DBG")) ctx->tune_cov_dbg = atoi(e) & 768;
     if (const char *e = getenv("WM_TUNE_R0")) {
         const float v = (float) atof(e);
@@ -890,7 +891,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
     if (!ctx) return;
     (void) hipSetDevice(ctx->device);
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->src_sorted, &ctx->tgt_orig, &ctx->staging, &ctx->cell_of, &ctx->counts,
+    DevBuf *bufs[] = {&ctx->src_sorted, &ctx->tgt_orig, &ctx->staging, &ctx->staging2, &ctx->cell_of, &ctx->counts,
                       &ctx->block_sums, &ctx->bbox_buf, &ctx->cloud_bbox, &ctx->keys, &ctx->keys_bak, &ctx->match_pt, &ctx->match_pt_bak, &ctx->d_levels, &ctx->ndt_keys, &ctx->ndt_keys2,
                       &ctx->ndt_vox, &ctx->ndt_vkey, &ctx->ndt_hkeys, &ctx->ndt_hvals, &ctx->ndt_dense, &ctx->ndt_meanf, &ctx->src_orig,
                       &ctx->gicp_c1, &ctx->gicp_c2, &ctx->gicp_mahal, &ctx->gicp_mailbox, &ctx->src_grid.pts,
@@ -984,7 +985,24 @@ int wm_set_target(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem
     if (n == 0) return WM_OK;
     WM_HIP(ctx, ctx->tgt_orig.reserve(n * sizeof(float4)));
     WM_HIP(ctx, ctx->cloud_bbox.reserve(2 * 8 * sizeof(float) * kBboxBlocks));
-    WM_TRY(pack_cloud(ctx, pts, n, stride, mem, ctx->tgt_orig.as<float4>()));
+    int slot = 0;
+    if (mem == WM_MEM_HOST && ctx->src_pending && ctx->tune_early_source) {
+        // A HOST target right behind a new source: this cloud is about to spend ~0.25 ms per 16 MB on PCIe with
+        // the device idle.  Everything the source still needs -- its bounding box (one short round trip), its
+        // Morton sort and gather -- is put on the stream first and runs under the copy (own staging buffer, no
+        // drain of the stream: pack_cloud slot 1).
+        float *res = (float *) pinned_scratch(ctx, 2 * 8 * sizeof(float) * kBboxBlocks);
+        if (!res) return WM_ERR_HIP;
+        WM_TRY(fast_fetch(ctx, res, ctx->cloud_bbox.p, 8 * sizeof(float) * ctx->src_bbox_blocks));
+        size_t src_valid = 0;
+        finish_bbox(res, ctx->src_bbox_blocks, &ctx->src_bbox, &src_valid);
+        ctx->src_pending = false;
+        ctx->n_src = src_valid;
+        WM_TRY(morton_sort(ctx, ctx->src_orig.as<float4>(), ctx->n_src_input, ctx->src_bbox, src_valid,
+                           ctx->src_sorted.as<float4>()));
+        slot = 1;
+    }
+    WM_TRY(pack_cloud(ctx, pts, n, stride, mem, ctx->tgt_orig.as<float4>(), slot));
     WM_TRY(launch_bbox(ctx, ctx->tgt_orig.as<float4>(), n, ctx->cloud_bbox.as<float>() + 8 * kBboxBlocks,
                        &ctx->tgt_bbox_blocks));
     ctx->tgt_pending = true;

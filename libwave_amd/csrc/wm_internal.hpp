@@ -177,7 +177,7 @@ struct wm_ctx {
     size_t tuned_src_n = 0;
 
     // scratch
-    wm::DevBuf staging, cell_of, counts, block_sums, bbox_buf;
+    wm::DevBuf staging, staging2, cell_of, counts, block_sums, bbox_buf;
     wm::DevBuf match_pt, match_pt_bak;  // float4 per (sorted) source point: its match's xyz
     void *small_batch = nullptr;            // wm_small.hip: staging of the batched small registrations
     void *batch_voxel = nullptr;            // wm_batch.hip: buffers of the batched voxel filter
@@ -203,6 +203,7 @@ struct wm_ctx {
     // workgroup's searches end 10 us after the median one's, and the solver's chain (rows 3.8, solve 4.4, hand-out
     // 0.7 us) is serial behind them
     int tune_late = 0;
+    int tune_early_source = 1;              // a host target's upload overlaps the source's sort (wm_set_target)
     int tune_cov_dbg = 0;                   // developer timing experiment in k_gicp_cov (wrong results): see there
     unsigned long long *h_pub = nullptr;    // pinned: [0] (done << 63 | iterations finished << 32 | step size bits) of the latest solve, [k] iteration k's own record
     int h_pub_slots = 0;
@@ -299,7 +300,7 @@ struct wm_ctx {
 namespace wm {
 
 // ---- wm_grid.hip
-int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, float4 *out);
+int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, float4 *out, int slot = 0);
 int compute_bbox(wm_ctx *ctx, const float4 *pts, size_t n, Bbox *out, size_t *n_valid);
 // the two halves of compute_bbox: enqueue the reduction into `partials_dev` (kBboxBlocks * 8 floats),
 // and finish it on the host from the fetched partials

@@ -15,10 +15,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <string>
+#include <thread>
 #include <vector>
 
+#include "wave/matching/gicp.hpp"
 #include "wave/matching/icp.hpp"
 #include "wave/matching/multi_matcher.hpp"
+#include "wave/matching/ndt.hpp"
 
 namespace {
 
@@ -55,6 +59,48 @@ wave::PCLPointCloudPtr scene(int n, unsigned seed, float dx) {
 
 }  // namespace
 
+// the pool of one matcher type over the same synthetic pairs (BENCH_MATCHER = gicp | ndt: the reference's
+// MultiMatcher<T, R> is generic, multi_matcher.hpp:29)
+template <class M, class P>
+int run_pool(const char *name, const P &params, int n, int pairs, int argc, char **argv,
+             const std::vector<wave::PCLPointCloudPtr> &refs, const std::vector<wave::PCLPointCloudPtr> &targets) {
+    for (int a = 3; a < argc; ++a) {
+        const int workers = std::atoi(argv[a]);
+        wave::MultiMatcher<M, P>::setMaxWorkers(workers);
+        const char *qenv = std::getenv("BENCH_QUEUE");
+        const int queue = qenv && std::atoi(qenv) > 0 ? std::atoi(qenv) : 2 * workers;
+        wave::MultiMatcher<M, P> pool(workers, queue, params);
+        double shift_sum = 0;
+        auto drain = [&](int count) {
+            int got = 0, ok = 0;
+            shift_sum = 0;
+            for (int j = 0; j < count; ++j) pool.insert(j, refs[(size_t) j % 4], targets[(size_t) j % 4]);
+            while (got < count) {
+                int id;
+                Eigen::Affine3d T;
+                wave::Mat6 info;
+                if (pool.getResult(&id, &T, &info)) {
+                    ++got;
+                    ok += std::abs(T.translation()(0) - 0.15) < 0.05;
+                    shift_sum += T.translation()(0);
+                } else {
+                    std::this_thread::yield();
+                }
+            }
+            return ok;
+        };
+        drain(std::max(2 * workers, std::min(queue, pairs)));
+        const auto t0 = std::chrono::steady_clock::now();
+        const int ok = drain(pairs);
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("{\"bench\": \"wave::MultiMatcher<%s>\", \"points\": %d, \"workers\": %d, \"queue\": %d, \"pairs\": %d, "
+                    "\"seconds\": %.4f, \"registrations_per_s\": %.1f, \"recovered_shift\": %d, \"mean_shift_x\": %.4f}\n",
+                    name, n, pool.workers(), queue, pairs, s, pairs / s, ok, shift_sum / pairs);
+        std::fflush(stdout);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 4) {
         std::fprintf(stderr, "usage: %s <points> <pairs> <workers>...\n", argv[0]);
@@ -71,6 +117,20 @@ int main(int argc, char **argv) {
     for (int k = 0; k < 4; ++k) {  // four distinct pairs, reused round-robin
         refs.push_back(scene(n, 100u + (unsigned) k, 0.f));
         targets.push_back(scene(n, 200u + (unsigned) k, 0.15f));
+    }
+    if (const char *m = std::getenv("BENCH_MATCHER")) {
+        if (std::string(m) == "gicp") {
+            wave::GICPMatcherParams gp;
+            gp.res = -1;
+            if (const char *e = std::getenv("BENCH_RES")) gp.res = (float) std::atof(e);
+            return run_pool<wave::GICPMatcher, wave::GICPMatcherParams>("GICPMatcher", gp, n, pairs, argc, argv, refs, targets);
+        }
+        if (std::string(m) == "ndt") {
+            wave::NDTMatcherParams np;
+            np.res = 1.0f;
+            if (const char *e = std::getenv("BENCH_RES")) np.res = (float) std::atof(e);
+            return run_pool<wave::NDTMatcher, wave::NDTMatcherParams>("NDTMatcher", np, n, pairs, argc, argv, refs, targets);
+        }
     }
     for (int a = 3; a < argc; ++a) {
         const int workers = std::atoi(argv[a]);
