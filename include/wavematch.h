@@ -253,7 +253,11 @@ int wm_debug_copy_bandwidth(wm_ctx *ctx, size_t bytes, int reps, double *gb_per_
 /* Tuning knobs by name (tests, benchmarks; the defaults are the product's): "cert_from" (-1: the
  * certificate kernel takes over once an ICP step is small, -2: never, k >= 0: from iteration k of
  * every align), "cert_disp" (that step size, in level-0 grid cells), "cert_pad_mul",
- * "cert_pad_frac", "cert_nb".  None of them changes a result.  WM_ERR_ARG for an unknown name. */
+ * "cert_pad_frac", "cert_nb", "gicp_served" (0 / 1 / 2: GICP's objective evaluations launched / served by the
+ * resident evaluator / served without the on-chip pair cache), "late" (1: the late ICP iterations -- certificate,
+ * searches, sums, solve, stopping rules -- in ONE resident launch, k_nn_cert<.., LATE> + k_late_solver; 0, the
+ * default: a launch per iteration, which measures the same or faster).  None of them changes a result.
+ * WM_ERR_ARG for an unknown name. */
 int wm_set_option(wm_ctx *ctx, const char *name, double value);
 /* developer: out == NULL arms a log of `iterations` launches (0 disarms); otherwise writes, per
  * launch of the certificate kernel since, how many queries it had to search; returns the count */
