@@ -3,6 +3,7 @@
 // pool is exercised with a matcher that needs no device -- the same template, the same queueing,
 // producers and a consumer racing the workers -- under -fsanitize=thread (tests/test_pool_tsan_cpu.py).
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <set>
 #include <thread>
@@ -59,11 +60,16 @@ class FakeBatchMatcher : public FakeMatcher {
         }
         batches.fetch_add(1);
         batched_pairs.fetch_add((int) pairs.size());
+        int seen = largest.load();
+        while ((int) pairs.size() > seen && !largest.compare_exchange_weak(seen, (int) pairs.size())) {}
+        // (a launch of the real batched path takes milliseconds whatever its size: the pool's other workers
+        // gather the next batches meanwhile)
+        std::this_thread::sleep_for(std::chrono::microseconds(500));
         return true;
     }
-    static std::atomic<int> batches, batched_pairs;
+    static std::atomic<int> batches, batched_pairs, largest;
 };
-std::atomic<int> FakeBatchMatcher::batches{0}, FakeBatchMatcher::batched_pairs{0};
+std::atomic<int> FakeBatchMatcher::batches{0}, FakeBatchMatcher::batched_pairs{0}, FakeBatchMatcher::largest{0};
 
 template <class Pool>
 int drive(Pool &pool, int kJobs);
@@ -80,7 +86,34 @@ int main() {
         std::printf("FAILED: the batched branch never ran\n");
         return 1;
     }
-    return bad;
+    // The reference's DEFAULT queue of 10 (multi_matcher.hpp:32-34) must not cap a batch at 10: a batch is gathered
+    // over several refills of the queue.  All pairs batchable (even sizes), one fast producer.
+    FakeBatchMatcher::largest.store(0);
+    int bad2 = 0;
+    {
+        wave::MultiMatcher<FakeBatchMatcher, FakeParams> small_queue(6, 10, FakeParams());
+        const int kPairs = 3000;
+        std::thread producer([&] {
+            auto c = boost::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
+            c->points.resize(2);
+            for (int j = 0; j < kPairs; ++j) small_queue.insert(j, c, c);
+        });
+        int got = 0;
+        while (got < kPairs) {
+            int id;
+            Eigen::Affine3d T;
+            wave::Mat6 info;
+            if (small_queue.getResult(&id, &T, &info)) ++got;
+            else std::this_thread::yield();
+        }
+        producer.join();
+        std::printf("queue of 10: largest batch %d pairs\n", FakeBatchMatcher::largest.load());
+        if (FakeBatchMatcher::largest.load() <= 10 || !small_queue.done()) {
+            std::printf("FAILED: batches capped by the queue's capacity\n");
+            bad2 = 1;
+        }
+    }
+    return bad + bad2;
 }
 
 namespace {

@@ -23,3 +23,5 @@ def test_multimatcher_pool_is_race_free_under_tsan(tmp_path):
                          env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66"))
     assert "WARNING: ThreadSanitizer" not in run.stderr, run.stderr[-3000:]
     assert run.returncode == 0 and "OK" in run.stdout, (run.returncode, run.stdout, run.stderr[-1000:])
+    # the reference's default queue of 10 must not cap the batches (they are gathered over several refills)
+    assert "queue of 10: largest batch" in run.stdout and "capped by the queue" not in run.stdout, run.stdout
