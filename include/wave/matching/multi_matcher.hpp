@@ -268,7 +268,7 @@ class MultiMatcher {
                 } else {
                     while (taken.size() < kBatch && !closing_) {
                         if (jobs_.empty()) {
-                            space_free_.notify_one();  // (the producer may be waiting for the slots just freed)
+                            space_free_.notify_all();  // (the producer may be waiting for the slots just freed)
                             lingering_ = true;
                             // (wait_until on the system clock = pthread_cond_timedwait; wait_for would be
                             // pthread_cond_clockwait, which GCC 11's ThreadSanitizer does not know: it then
@@ -291,7 +291,7 @@ class MultiMatcher {
                 }
                 gathering_ = false;
             }
-            space_free_.notify_one();    // slots are free for insert() ...
+            space_free_.notify_all();    // slots are free for insert() ...
             jobs_changed_.notify_all();  // ... and the next worker may gather
             if (!taken.empty()) {
                 const bool ran = runBatch(matcher, taken, 0);
