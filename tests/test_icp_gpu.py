@@ -210,3 +210,38 @@ def test_empty_and_tiny_inputs(wm, ctx):
     r = ctx.icp_align()
     assert r["rc"] == 0
     assert np.linalg.norm(r["T"] - np.eye(4)) < 1e-6
+
+
+def test_host_clouds_early_source_path_equals_device_clouds(wm):
+    """wm_set_target with a HOST cloud right behind a new source runs the source's bounding box, Morton
+    sort and gather under the target's upload (own staging buffer, no drain of the stream).  Same
+    registration, bit for bit, as with that overlap off -- with
+    non-finite points in both clouds, strides 12 and 16, and clouds re-set in every order."""
+    import os
+    ref, tgt, _ = synth.pair(40000, seed=21, mode="resample")
+    ref = ref.copy()
+    tgt = tgt.copy()
+    ref[::977] = np.nan
+    tgt[5::1013, 1] = np.inf
+    out = []
+    for early in ("1", "0"):
+        os.environ["WM_TUNE_EARLY_SOURCE"] = early
+        c = wm.Context(0)
+        for _ in range(2):      # twice: the second registration re-uses both staging buffers
+            c.set_source(ref)
+            c.set_target(tgt)
+            r = c.icp_align(max_corr=3.0, force_iterations=15, nn_method=wm.WM_NN_GRID, carry_state=0)
+        # a target set twice in a row, and a new source behind a target
+        c.set_target(tgt)
+        c.set_source(ref[:, :3].copy())
+        c.set_target(tgt)
+        r2 = c.icp_align(max_corr=3.0, force_iterations=15, nn_method=wm.WM_NN_GRID, carry_state=0)
+        out.append((r, r2, c.correspondences()))
+        c.close()
+    del os.environ["WM_TUNE_EARLY_SOURCE"]
+    rd, _, cd = out[1]  # (the overlap off: the path every other host-cloud test has used since round 1)
+    for r, r2, corr in out:
+        assert r["rc"] == 0 and r2["rc"] == 0
+        assert np.array_equal(r["T"], rd["T"]) and np.array_equal(r2["T"], rd["T"])
+        assert r["n_corr"] == rd["n_corr"]
+        assert np.array_equal(corr[0], cd[0]) and np.array_equal(corr[1], cd[1])
