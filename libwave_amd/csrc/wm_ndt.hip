@@ -399,6 +399,7 @@ struct NdtArgs {
     float Tf[12];
     float inv_res;
     double res2, d1, d2;
+    float res2_f;  // the largest float d2 with (double) d2 < res2: the radius test in one float compare, same decisions
     // computeAngleDerivatives: 8 Jacobian and 15 Hessian 3-vectors
     double j[8][3];
     double h[15][3];
@@ -525,7 +526,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HES
             for (int u = 0; u < 4; ++u) {
                 const float fx = __fsub_rn(xt0, cm[u].x), fy = __fsub_rn(xt1, cm[u].y), fz = __fsub_rn(xt2, cm[u].z);
                 const float dd = __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz));
-                if (r + u < n_cand && (double) dd < A.res2) {
+                if (r + u < n_cand && dd <= A.res2_f) {  // <=> (double) dd < A.res2
                     s_near[n_near * kBlock + threadIdx.x] = cv[u];
                     ++n_near;
                 }
@@ -902,6 +903,7 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
     for (int k = 0; k < 12; ++k) A.Tf[k] = Tf[k];
     A.inv_res = 1.0f / (float) E.prm->res;
     A.res2 = E.prm->res * E.prm->res;
+    A.res2_f = threshold_d2_strict(E.prm->res);
     A.d1 = E.d1;
     A.d2 = E.d2;
     angle_derivatives(p, E.prm->pcl_d1_sign, &A);
