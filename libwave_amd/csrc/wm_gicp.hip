@@ -36,18 +36,34 @@ __device__ __forceinline__ float g_d2(float qx, float qy, float qz, const float4
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
-// sorted insertion into an ascending register-resident list (drops the largest)
+// sorted insertion into an ascending register-resident list (drops the largest).  The list is sorted, so
+// inserting is a shift: with c_j = (key < best[j]) -- false ... false true ... true --
+//     new best[j] = c_{j-1} ? best[j-1] : (c_j ? key : best[j]),
+// and for the distance word (the high one) alone that is the median of (best[j-1], key, best[j]).  One 64-bit
+// compare, one v_med3_u32 and two selects per slot, going down the list so that best[j-1] is still the old one
+// (the compare-and-swap chain this replaces compiled to two 64-bit compares, four selects and a move: 85
+// instructions per candidate for the whole wave at K = 10, now 45).
+__device__ __forceinline__ unsigned g_med3_u32(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 template <int K>
 __device__ __forceinline__ void knn_insert(unsigned long long (&best)[K], unsigned long long key) {
     if (key >= best[K - 1]) return;
-    unsigned long long cur = key;
+    const unsigned kh = (unsigned) (key >> 32), kl = (unsigned) key;
+    bool c[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        const bool sw = cur < best[j];
-        const unsigned long long t = best[j];
-        best[j] = sw ? cur : t;
-        cur = sw ? t : cur;
+    for (int j = 0; j < K; ++j) c[j] = key < best[j];
+#pragma unroll
+    for (int j = K - 1; j >= 1; --j) {
+        const unsigned ah = (unsigned) (best[j - 1] >> 32), al = (unsigned) best[j - 1];
+        const unsigned bh = (unsigned) (best[j] >> 32), bl = (unsigned) best[j];
+        const unsigned nh = g_med3_u32(ah, kh, bh);
+        const unsigned nl = c[j - 1] ? al : (c[j] ? kl : bl);
+        best[j] = ((unsigned long long) nh << 32) | nl;
     }
+    best[0] = c[0] ? key : best[0];
 }
 
 // k nearest neighbours of q among the cell-sorted points of grid g: scan the box of cells
@@ -84,24 +100,27 @@ __device__ void knn_search(const GridDev &g, float qx, float qy, float qz, int k
                 runs[n_runs * col_stride + lane_col] = make_uint2(rs[u], re[u]);
                 ++n_runs;
             }
+        if (n_runs == 0) return;
+        // (the next candidate is fetched before the current one goes through the insertion: the load's way to L2
+        // and back is as long as the insertion itself)
         int ri = 0;
-        unsigned j = 0, e = 0;
-        if (n_runs > 0) {
-            const uint2 r0 = runs[lane_col];
-            j = r0.x;
-            e = r0.y;
-        }
-        while (ri < n_runs) {
-            const float4 t = g.pts[j];
-            knn_insert<K>(best, g_make_key(g_d2(qx, qy, qz, t), __float_as_uint(t.w)));
+        const uint2 r0 = runs[lane_col];
+        unsigned j = r0.x, e = r0.y;
+        float4 t = g.pts[j];
+        for (;;) {
+            bool more = true;
             if (++j == e) {
-                ++ri;
-                if (ri < n_runs) {
+                more = ++ri < n_runs;
+                if (more) {
                     const uint2 rn = runs[ri * col_stride + lane_col];
                     j = rn.x;
                     e = rn.y;
                 }
             }
+            const float4 tn = g.pts[more ? j : r0.x];  // (a lane at its end reads a line it has had already)
+            knn_insert<K>(best, g_make_key(g_d2(qx, qy, qz, t), __float_as_uint(t.w)));
+            if (!more) break;
+            t = tn;
         }
     };
     int pxa = 1, pxb = 0, pya = 1, pyb = 0, pza = 1, pzb = 0;  // the box already scanned (clamped cells; none yet)
@@ -422,10 +441,9 @@ __device__ __forceinline__ void gicp_fdf_stream(double (&hi)[kGicpAcc], double (
     }
 }
 
-// the workgroup's threads' pairs -> its row of `partials` (ends with a barrier; every thread calls)
-template <bool COHERENT>
-__device__ __forceinline__ void gicp_fdf_finish(double (&hi)[kGicpAcc], double (&lo)[kGicpAcc],
-                                                double *__restrict__ partials) {
+// the workgroup's threads' pairs -> (h, l) of component threadIdx.x in threads 0..12 (contains a barrier; every
+// thread calls; a second call needs a barrier of the caller's in between: the LDS array is the same)
+__device__ __forceinline__ void gicp_block_reduce(double (&hi)[kGicpAcc], double (&lo)[kGicpAcc], double &h, double &l) {
     // wave reduction by recursive halving (as the search kernel's statistics, wm_nn.hip): at the
     // step for lane bit M a lane keeps one half of its pairs and sends the other half to lane ^ M --
     // 7+4+2+1+1+1 = 16 pair exchanges instead of 13 x 6.  Component k ends in the lane dd_comp_of_lane names.
@@ -438,21 +456,24 @@ __device__ __forceinline__ void gicp_fdf_finish(double (&hi)[kGicpAcc], double (
         lds[wave][comp][1] = lo[0];
     }
     __syncthreads();
+    h = l = 0;
     if (threadIdx.x < kGicpAcc) {
-        double h = 0, l = 0;
         for (int w = 0; w < kBlock / 64; ++w) {
             dd_add(h, l, lds[w][threadIdx.x][0]);
             l += lds[w][threadIdx.x][1];
         }
+    }
+}
+
+// ... -> the workgroup's row of `partials`
+__device__ __forceinline__ void gicp_fdf_finish(double (&hi)[kGicpAcc], double (&lo)[kGicpAcc],
+                                                double *__restrict__ partials) {
+    double h, l;
+    gicp_block_reduce(hi, lo, h, l);
+    if (threadIdx.x < kGicpAcc) {
         double *row = partials + ((size_t) blockIdx.x * kGicpAcc + threadIdx.x) * 2;
-        if constexpr (COHERENT) {
-            // read by another workgroup of the SAME kernel: written through to where every XCD sees it
-            __hip_atomic_store(row, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(row + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            row[0] = h;
-            row[1] = l;
-        }
+        row[0] = h;
+        row[1] = l;
     }
 }
 
@@ -464,28 +485,25 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
     for (int k = 0; k < kGicpAcc; ++k) hi[k] = lo[k] = 0.0;
     gicp_fdf_stream(hi, lo, blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, src, n, keys, tgt, mahal, A);
-    gicp_fdf_finish<false>(hi, lo, partials);
+    gicp_fdf_finish(hi, lo, partials);
 }
 
-// The block rows -> the thirteen sums, by ONE workgroup of kBlock threads (the last workgroup of the
-// served evaluator, or k_gicp_sum_fetch behind a launched evaluation: the same code, the same order
-// of addition, the same bits).  The rows' (hi, lo) pairs are one contiguous array of rows x 13
+// The block rows of a LAUNCHED evaluation -> the thirteen sums, by ONE workgroup of kBlock threads
+// (k_gicp_sum_fetch; the resident evaluator adds its rows in another order -- double-double sums: the same
+// value whatever the order).  The rows' (hi, lo) pairs are one contiguous array of rows x 13
 // 16-byte pairs; thread t < 247 = 19 x 13 adds pairs t, t + 247, t + 494, ... (component t % 13, rows
 // t / 13 + 19 m) in double-double -- consecutive lanes read consecutive pairs, a dozen cache lines per
 // wave instruction instead of 64 --, then thread c < 13 adds the 19 partial pairs of component c in
 // order and rounds hi + lo once.  Returns the sum in threads 0..12 (every thread must call).
-// COHERENT: the rows were written by other workgroups of the SAME kernel (write-through stores): they
-// are read at agent scope (sc1), past whatever stale lines this XCD's L2 may hold.
 constexpr int kGicpSumGroups = kBlock / kGicpAcc;  // 19
 typedef double gicp_d2v __attribute__((ext_vector_type(2)));
-template <bool COHERENT>
 __device__ __forceinline__ double gicp_sum_rows(const double *__restrict__ src, unsigned rows) {
     __shared__ double s_h[kGicpSumGroups][kGicpAcc], s_l[kGicpSumGroups][kGicpAcc];
     constexpr unsigned S = (unsigned) (kGicpSumGroups * kGicpAcc);
     const unsigned t = threadIdx.x, total = rows * (unsigned) kGicpAcc;
     if (t < S) {
         double h = 0, l = 0;
-        constexpr int U = 8;  // (the asm statement below is written for eight)
+        constexpr int U = 8;
         for (unsigned e0 = t; e0 < total; e0 += U * S) {
             gicp_d2v v[U];
             const gicp_d2v *p[U];
@@ -494,26 +512,8 @@ __device__ __forceinline__ double gicp_sum_rows(const double *__restrict__ src, 
                 const unsigned e = e0 + (unsigned) u * S;
                 p[u] = (const gicp_d2v *) src + (e < total ? e : 0u);
             }
-            if constexpr (COHERENT) {
-                // (eight loads and the wait for them in ONE statement: the compiler must not touch the
-                // destination registers of an asynchronous load it knows nothing about before the wait)
-                asm volatile(
-                    "global_load_dwordx4 %0, %8, off sc1\n\t"
-                    "global_load_dwordx4 %1, %9, off sc1\n\t"
-                    "global_load_dwordx4 %2, %10, off sc1\n\t"
-                    "global_load_dwordx4 %3, %11, off sc1\n\t"
-                    "global_load_dwordx4 %4, %12, off sc1\n\t"
-                    "global_load_dwordx4 %5, %13, off sc1\n\t"
-                    "global_load_dwordx4 %6, %14, off sc1\n\t"
-                    "global_load_dwordx4 %7, %15, off sc1\n\t"
-                    "s_waitcnt vmcnt(0)"
-                    : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-                    : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
-                    : "memory");
-            } else {
 #pragma unroll
-                for (int u = 0; u < U; ++u) v[u] = *p[u];
-            }
+            for (int u = 0; u < U; ++u) v[u] = *p[u];
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (e0 + (unsigned) u * S < total) {
@@ -542,7 +542,7 @@ __device__ __forceinline__ double gicp_sum_rows(const double *__restrict__ src, 
 // The block pairs -> kGicpAcc doubles in pinned memory, then the fence + flag of fast_fetch.
 __global__ void __launch_bounds__(kBlock)
     k_gicp_sum_fetch(double *dst, const double *__restrict__ src, unsigned rows, unsigned *flag, unsigned seq) {
-    const double v = gicp_sum_rows<false>(src, rows);
+    const double v = gicp_sum_rows(src, rows);
     if (threadIdx.x < (unsigned) kGicpAcc) dst[threadIdx.x] = v;
     if (threadIdx.x < 64) {
         __threadfence_system();
@@ -575,6 +575,7 @@ struct alignas(16) GicpSlot {  // pinned host memory: one of the thirteen sums +
 };
 constexpr int kServeCached = 8;  // pairs per thread kept on chip by the cached variant
 constexpr unsigned long long kServeGuardTicks = 20000000ull;  // 0.2 s of the 100 MHz wall clock
+constexpr size_t kServeRowsOffset = 4096, kServeRowsBytes = (size_t) kGicpBlocksMax * 2 * kGicpAcc * 16;  // (in the mailbox's allocation)
 
 __device__ __forceinline__ unsigned ld_sys(const unsigned *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -590,10 +591,10 @@ template <int PL>
 __global__ void __launch_bounds__(kBlock)
     k_gicp_fdf_served(const float4 *__restrict__ src, unsigned n, const unsigned long long *__restrict__ keys,
                       const float4 *__restrict__ tgt, const double *__restrict__ mahal, GicpMailbox *mb,
-                      unsigned first_seq, double *__restrict__ partials, unsigned *ticket, GicpSlot *h_slots,
+                      unsigned first_seq, unsigned __attribute__((ext_vector_type(4))) *rows, GicpSlot *h_slots,
                       unsigned long long *dbg) {
     __shared__ float s_args[24];
-    __shared__ unsigned s_cmd, s_last;
+    __shared__ unsigned s_cmd;
     extern __shared__ double s_M[];  // [PL][9][kBlock]: column = thread (private to it: no barrier needed)
     const unsigned stride = gridDim.x * kBlock, i_first = blockIdx.x * kBlock + threadIdx.x;
     float cpx[PL > 0 ? PL : 1], cpy[PL > 0 ? PL : 1], cpz[PL > 0 ? PL : 1];
@@ -665,36 +666,74 @@ __global__ void __launch_bounds__(kBlock)
                 }
         }
         gicp_fdf_stream(hi, lo, i_first + (unsigned) PL * stride, stride, src, n, keys, tgt, mahal, A);
-        gicp_fdf_finish<true>(hi, lo, partials);
+        double bh, bl;
+        gicp_block_reduce(hi, lo, bh, bl);
         if (dbg && blockIdx.x == 0 && threadIdx.x == 0 && round < 64u) dbg[round * 4 + 1] = wall_clock64();
-        // The row is out (write-through stores): wait until they have been performed, then take a
-        // ticket; whoever draws the last one adds the rows up, reading them at agent scope.  No
-        // agent-scope FENCE on either side: a release fence writes the XCD's whole L2 back, and 32
-        // workgroups per XCD doing that one after the other took longer than the evaluation (17 us).
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = t == gridDim.x - 1u ? 1u : 0u;
+        // The workgroup's row goes out as 26 16-byte slots {value, number of the round}, one store each, written
+        // through to where every XCD sees it (sc1); slot (c, row) lies at c * rows + row.  Workgroup 0 adds the rows
+        // up: its thread t reads row t -- 26 loads that are consecutive across the wave --, again until every slot
+        // carries this round's number, so the wait for the other workgroups IS the fetch of their rows.  (Rounds 2-3:
+        // rows, then a ticket drawn with an atomic per workgroup -- 256 atomics on one address retire one after the
+        // other, ~11 ns each --, then the last workgroup fetched the rows: two trips to memory and 3 us behind the
+        // last workgroup's last store.  No agent-scope FENCE anywhere: a release fence writes the XCD's whole L2 back.)
+        typedef unsigned u4v __attribute__((ext_vector_type(4)));
+        if (threadIdx.x < (unsigned) kGicpAcc) {
+            const unsigned long long hb = (unsigned long long) __double_as_longlong(bh), lb = (unsigned long long) __double_as_longlong(bl);
+            const u4v oh = {(unsigned) hb, (unsigned) (hb >> 32), seq, 0u}, ol = {(unsigned) lb, (unsigned) (lb >> 32), seq, 0u};
+            u4v *dh = rows + (size_t) (2u * threadIdx.x) * gridDim.x + blockIdx.x, *dl = dh + gridDim.x;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dh), "v"(oh) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dl), "v"(ol) : "memory");
         }
-        __syncthreads();
-        if (s_last) {
+        if (blockIdx.x == 0u) {  // (uniform)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *) rows, 0, gridDim.x * 2u * (unsigned) kGicpAcc * 16u, 0x00020000);
+            const unsigned long long t0 = wall_clock64();
+            double sh[kGicpAcc], sl[kGicpAcc];
+#pragma unroll
+            for (int k = 0; k < kGicpAcc; ++k) sh[k] = sl[k] = 0.0;
+            bool ok = true;
+            for (unsigned row = threadIdx.x; row < gridDim.x && ok; row += kBlock) {
+                u4v v[2 * kGicpAcc];
+                for (;;) {
+                    unsigned off = row * 16u;
+                    asm volatile("" : "+v"(off));  // (a fresh look every trip: nothing of it may be kept from the previous one)
+                    bool all = true;
+#pragma unroll
+                    for (int c = 0; c < 2 * kGicpAcc; ++c) {
+                        v[c] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, (unsigned) c * gridDim.x * 16u, 16);  // sc1
+                        all = all && v[c].z == seq;
+                    }
+                    if (all) break;
+                    if (wall_clock64() - t0 > kServeGuardTicks) {  // (a workgroup that never came: no answer; the host's own limit ends the round)
+                        ok = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (ok) {
+#pragma unroll
+                    for (int c = 0; c < kGicpAcc; ++c) {
+                        dd_add(sh[c], sl[c], __longlong_as_double((long long) (((unsigned long long) v[2 * c].y << 32) | v[2 * c].x)));
+                        sl[c] += __longlong_as_double((long long) (((unsigned long long) v[2 * c + 1].y << 32) | v[2 * c + 1].x));
+                    }
+                }
+            }
             if (dbg && threadIdx.x == 0 && round < 64u) dbg[round * 4 + 2] = wall_clock64();
-            // (every workgroup has drawn its ticket: the counter can go back to 0 for the next round)
-            if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const double v = gicp_sum_rows<true>(partials, gridDim.x);
-            if (threadIdx.x < (unsigned) kGicpAcc) {
-                // the sum and the number of the command it answers in ONE 16-byte store to pinned host
-                // memory: the host takes a slot once it carries the number it waits for -- no flag
-                // behind the data, hence no system-scope fence (an L2 write-back: ~5 us) before one.
-                // (written through at system scope -- sc0 sc1 --, as an atomic store would be; there is no
-                // 16-byte atomic store to ask the compiler for)
-                typedef unsigned u4v __attribute__((ext_vector_type(4)));
-                const unsigned long long vb = (unsigned long long) __double_as_longlong(v);
-                const u4v out = {(unsigned) vb, (unsigned) (vb >> 32), seq, 0u};
-                GicpSlot *dst = &h_slots[threadIdx.x];
-                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(out) : "memory");
+            // (the barrier the second use of the reduction's LDS array needs, and: did any thread give up?)
+            if (__syncthreads_and((int) ok)) {
+                double h, l;
+                gicp_block_reduce(sh, sl, h, l);
+                if (threadIdx.x < (unsigned) kGicpAcc) {
+                    // the sum and the number of the command it answers in ONE 16-byte store to pinned host
+                    // memory: the host takes a slot once it carries the number it waits for -- no flag
+                    // behind the data, hence no system-scope fence (an L2 write-back: ~5 us) before one.
+                    // (written through at system scope -- sc0 sc1 --, as an atomic store would be; there is no
+                    // 16-byte atomic store to ask the compiler for)
+                    const double v = h + l;
+                    const unsigned long long vb = (unsigned long long) __double_as_longlong(v);
+                    const u4v out = {(unsigned) vb, (unsigned) (vb >> 32), seq, 0u};
+                    GicpSlot *dst = &h_slots[threadIdx.x];
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(out) : "memory");
+                }
             }
             if (dbg && threadIdx.x == 0 && round < 64u) dbg[round * 4 + 3] = wall_clock64();
         }
@@ -858,8 +897,8 @@ static void serve_begin(GicpFn &F) {
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gicp_fdf_served<0>, kBlock, 0) != hipSuccess) return;
         }
         ctx->gicp_serve_capacity = cus * per_cu;
-        if (ctx->gicp_mailbox.reserve(4096) != hipSuccess) return;
-        if (hipMemsetAsync(ctx->gicp_mailbox.p, 0, 4096, ctx->stream) != hipSuccess) return;
+        if (ctx->gicp_mailbox.reserve(kServeRowsOffset + kServeRowsBytes) != hipSuccess) return;
+        if (hipMemsetAsync(ctx->gicp_mailbox.p, 0, kServeRowsOffset + kServeRowsBytes, ctx->stream) != hipSuccess) return;
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) return;
         ctx->gicp_serve_seq = 0;
         ctx->gicp_serve_ok = 1;
@@ -886,14 +925,12 @@ static void serve_begin(GicpFn &F) {
     if (share <= 0) return;
     F.served_blocks = share;
     F.served_evals = 0;
-    unsigned *ticket = (unsigned *) ((char *) ctx->gicp_mailbox.p + sizeof(GicpMailbox));
-    // A round that ended in a fallback can leave the ticket counter above 0 (workgroups that left by their
-    // guard, or saw a command past their own, never drew one) and `abandoned` set: the next evaluator would
-    // then see its "last" ticket one workgroup early and add rows of the previous evaluation.  Both words
-    // (and the padding between them; NOT the command number) go back to 0 on the stream before every launch.
-    static_assert(offsetof(GicpMailbox, abandoned) + 6 * sizeof(unsigned) == sizeof(GicpMailbox), "layout");
-    if (hipMemsetAsync((char *) ctx->gicp_mailbox.p + offsetof(GicpMailbox, abandoned), 0,
-                       sizeof(GicpMailbox) - offsetof(GicpMailbox, abandoned) + sizeof(unsigned), ctx->stream) != hipSuccess) {
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    u4v *rows = (u4v *) ((char *) ctx->gicp_mailbox.p + kServeRowsOffset);  // the workgroups' rows of the round under way ({value, round} slots)
+    // A round that ended in a fallback leaves `abandoned` set: it goes back to 0 on the stream before every
+    // launch (NOT the command number).  The rows need no reset: their slots carry numbers of rounds that are over,
+    // and no later round has one of those again.
+    if (hipMemsetAsync((char *) ctx->gicp_mailbox.p + offsetof(GicpMailbox, abandoned), 0, sizeof(unsigned), ctx->stream) != hipSuccess) {
         (void) hipGetLastError();
         resident_release(ctx->device, share);
         return;
@@ -904,12 +941,12 @@ static void serve_begin(GicpFn &F) {
                            (size_t) kServeCached * 9 * kBlock * sizeof(double), ctx->stream, ctx->src_sorted.as<float4>(),
                            (unsigned) ctx->n_src, ctx->keys.as<unsigned long long>(), ctx->match_pt.as<float4>(),
                            ctx->gicp_mahal.as<double>(), (GicpMailbox *) ctx->gicp_mailbox.p, ctx->gicp_serve_seq + 1u,
-                           ctx->partials.as<double>(), ticket, (GicpSlot *) ctx->h_gicp_slots, dbg);
+                           rows, (GicpSlot *) ctx->h_gicp_slots, dbg);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gicp_fdf_served<0>), dim3(nb), dim3(kBlock), 0, ctx->stream,
                            ctx->src_sorted.as<float4>(), (unsigned) ctx->n_src, ctx->keys.as<unsigned long long>(),
                            ctx->match_pt.as<float4>(), ctx->gicp_mahal.as<double>(), (GicpMailbox *) ctx->gicp_mailbox.p,
-                           ctx->gicp_serve_seq + 1u, ctx->partials.as<double>(), ticket, (GicpSlot *) ctx->h_gicp_slots, dbg);
+                           ctx->gicp_serve_seq + 1u, rows, (GicpSlot *) ctx->h_gicp_slots, dbg);
     if (hipGetLastError() != hipSuccess) {
         resident_release(ctx->device, share);
         return;
