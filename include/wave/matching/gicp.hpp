@@ -14,6 +14,8 @@
 #define WAVE_MATCHING_GICP_HPP
 
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "wave/matching/matcher.hpp"
 #include "wave/matching/pcl_common.hpp"
@@ -48,6 +50,23 @@ class GICPMatcher : public Matcher<PCLPointCloudPtr> {
     void setRef(const PCLPointCloudPtr &ref);
     void setTarget(const PCLPointCloudPtr &target);
     bool match();  // blocks until the registration is done; true when it converged
+
+    // Many pairs in ONE device launch (wm_gicp_batch_match: one registration per compute unit, the whole of
+    // align inside the kernel) -- what wave::MultiMatcher<GICPMatcher> hands its workers when several pairs are
+    // queued.  out[k] = {match() result, getResult(), getInfo()} as the worker loop would have read them after
+    // pair k: setup(ref, target) + match() + estimateInfo(); a failed match leaves the transform of the pair
+    // before it, and GICPMatcher has no information estimate (getInfo() stays what it was).
+    struct BatchOutcome {
+        EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+        bool matched;
+        Eigen::Affine3d transform;
+        Mat6 info;
+    };
+    typedef std::vector<BatchOutcome, Eigen::aligned_allocator<BatchOutcome>> BatchOutcomes;
+    // does the pair go down the batched path?  (clouds of at most 100 000 points as they are, 400 000 when they
+    // are voxel-filtered first; bigger ones are registered one at a time, on the whole device)
+    bool batchable(const PCLPointCloudPtr &ref, const PCLPointCloudPtr &target) const;
+    bool matchBatch(const std::vector<std::pair<PCLPointCloudPtr, PCLPointCloudPtr>> &pairs, BatchOutcomes &out);
 
  private:
     wm_ctx *ctx;

@@ -349,6 +349,22 @@ int wm_gicp_match(wm_ctx *ctx, const void *ref, size_t n_ref, const void *target
  * time of the call (a snapshot, as the reference's filtered copy is). */
 int wm_set_source_filtered(wm_ctx *ctx, const void *pts, size_t n, size_t stride_bytes, int mem, float leaf);
 int wm_set_target_filtered(wm_ctx *ctx, const void *pts, size_t n, size_t stride_bytes, int mem, float leaf);
+/* GICPMatcher::setRef + setTarget + match (wave_matching/src/gicp.cpp:37-64) for MANY pairs in one launch --
+ * what a wave::MultiMatcher<GICPMatcher> has waiting in its queue (multi_matcher.hpp:29-34): one registration per
+ * compute unit, the whole of align inside the kernel (grids, covariances, the outer loop with its 1-NN search,
+ * Mahalanobis matrices and the BFGS minimisation -- the optimiser's code runs on the device here).
+ *   res > 0: every cloud of the batch is voxel-filtered first (one pass of device-wide kernels), as
+ *            setRef / setTarget do; res <= 0: the clouds as given, at most WM_GICP_BATCH_MAX_POINTS points each
+ *            (beyond: WM_ERR_ARG).  A pair whose FILTERED cloud is larger is registered by wm_gicp_match.
+ * Per item k: status[k] as wm_gicp_match would return it (WM_OK / WM_NOT_CONVERGED / WM_TOO_FEW_CORRESPONDENCES;
+ * WM_ERR_STATE for an empty cloud), T_out + 16 k written when WM_OK, stats[k] (may be NULL).
+ * Same neighbours, covariances, objective terms and sums as wm_gicp_align; sin / cos / atan2 are the device
+ * library's instead of glibc's, so results agree with the one-pair path to ~1e-6 m, not bit for bit.
+ * kernel_ms (may be NULL): device time of the launch. */
+#define WM_GICP_BATCH_MAX_POINTS 100000
+int wm_gicp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, size_t stride_bytes, int mem,
+                        const wm_gicp_params *p, float res, double *T_out, wm_gicp_stats *stats, int *status,
+                        float *kernel_ms);
 /* OptimizationFunctorWithIndices::fdf once: pairs + Mahalanobis matrices formed with
  * T_pair as one outer iteration does, then f and gradient at x = (t, roll, pitch, yaw). */
 int wm_gicp_eval(wm_ctx *ctx, const wm_gicp_params *p, const double T_pair[16], const double x[6],

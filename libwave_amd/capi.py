@@ -123,6 +123,9 @@ def lib():
         L.wm_icp_batch_match.argtypes = [C.c_void_p, C.POINTER(BatchItem), C.c_int, C.c_size_t, C.c_int,
                                          C.POINTER(IcpParams), C.c_float, C.c_int, C.c_int, _dp, _dp,
                                          C.POINTER(IcpStats), C.POINTER(C.c_int)]
+        L.wm_gicp_batch_match.argtypes = [C.c_void_p, C.POINTER(BatchItem), C.c_int, C.c_size_t, C.c_int,
+                                          C.POINTER(GicpParams), C.c_float, _dp, C.POINTER(GicpStats),
+                                          C.POINTER(C.c_int), C.POINTER(C.c_float)]
         L.wm_voxel_downsample_batch.argtypes = [C.c_void_p, C.POINTER(BatchItem), C.c_int, C.c_size_t, C.c_int,
                                                 C.c_float, _fp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.wm_voxel_downsample.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
@@ -490,6 +493,35 @@ class Context:
                                              C.byref(s)), "wm_gicp_match")
         self.n_src, self.n_tgt = self.sizes()
         return self._gicp_dict(rc, T, s)
+
+    def gicp_batch_match(self, pairs, res=-1.0, params=None, **kw):
+        """GICPMatcher::match() of every pair in one launch (wm_gicp_batch_match), one registration per compute
+        unit.  pairs: [(ref, target), ...] -> list of dicts as gicp_align's (+ 'kernel_ms' of the launch)."""
+        p = params or gicp_params(**kw)
+        n = len(pairs)
+        items = (BatchItem * max(n, 1))()
+        keep = []
+        stride = mem = None
+        for k, (ref, tgt) in enumerate(pairs):
+            pr, nr, sr, mr, k1 = _cloud_arg(ref)
+            pt, nt, stt, mt, k2 = _cloud_arg(tgt)
+            assert sr == stt and mr == mt and (stride in (None, sr)) and (mem in (None, mr))
+            stride, mem = sr, mr
+            keep += [k1, k2]
+            items[k].src, items[k].n_src, items[k].target, items[k].n_target = pr, nr, pt, nt
+        T = np.zeros((max(n, 1), 4, 4), np.float64)
+        stats = (GicpStats * max(n, 1))()
+        status = (C.c_int * max(n, 1))()
+        ms = C.c_float(0)
+        self._check(lib().wm_gicp_batch_match(self._h, items, n, stride or 16, mem or WM_MEM_HOST, C.byref(p),
+                                              C.c_float(res), T.ctypes.data_as(_dp), stats, status, C.byref(ms)),
+                    "wm_gicp_batch_match")
+        out = []
+        for k in range(n):
+            d = self._gicp_dict(status[k], T[k].copy(), stats[k])
+            d["kernel_ms"] = ms.value
+            out.append(d)
+        return out
 
     def gicp_eval(self, T_pair, x, params=None, **kw):
         p = params or gicp_params(**kw)

@@ -580,6 +580,28 @@ static int scaled_sub_batch(wm_ctx *ctx, const wm_batch_item *items, const std::
     return WM_OK;
 }
 
+// pcl::VoxelGrid of every cloud of `idx`'s items (cloud 2 j = the ref of item idx[j], 2 j + 1 = its target) in one
+// pass: *filtered + off[c] = cloud c's centroids (float4, device memory of this context, valid until the next batched
+// filter), n_out[c] their number (0xFFFFFFFF: the leaf lattice overflows int32 -- PCL returns that cloud unfiltered).
+int batch_voxel_filter(wm_ctx *ctx, const wm_batch_item *items, const std::vector<int> &idx, size_t stride, int mem, float leaf,
+                       const float4 **filtered, std::vector<unsigned> &off, std::vector<unsigned> &n_out) {
+    off.assign(2 * idx.size(), 0u);
+    n_out.assign(2 * idx.size(), 0u);
+    *filtered = nullptr;
+    size_t total_pts = 0;
+    for (int k : idx) total_pts += items[k].n_src + items[k].n_target;
+    if (total_pts == 0) return WM_OK;
+    VoxelBatch vb;
+    WM_TRY(vb.setup(ctx, items, idx, stride, mem));
+    WM_TRY(vb.filter(leaf));
+    *filtered = vb.filtered;
+    for (unsigned c = 0; c < vb.n_clouds; ++c) {
+        off[c] = vb.cl[c].off;
+        n_out[c] = vb.n_out[c];
+    }
+    return WM_OK;
+}
+
 int batch_match_scaled(wm_ctx *ctx, const wm_batch_item *items, int n_items, size_t stride, int mem,
                        const wm_icp_params *p, float res, int multiscale_steps, int with_info, double *T_out,
                        double *info_out, wm_icp_stats *stats, int *status) {

@@ -12,6 +12,8 @@
 //                 Fletcher's line search), applyState, the outer delta test
 // [PCL registration/impl/gicp.hpp, registration/bfgs.h]
 #include "wm_internal.hpp"
+#include "wm_gicp_dev.hpp"
+#include "wm_bfgs.hpp"
 
 #include <float.h>
 #include <stddef.h>
@@ -25,193 +27,8 @@
 
 namespace wm {
 
-constexpr int kGicpAcc = 13;
 constexpr int kGicpBlocksMax = 4096;  // partial rows per objective evaluation (ctx->tune_gicp_blocks)
 
-__device__ __forceinline__ unsigned long long g_make_key(float d2, unsigned idx) {
-    return ((unsigned long long) __float_as_uint(d2) << 32) | idx;
-}
-__device__ __forceinline__ float g_d2(float qx, float qy, float qz, const float4 &t) {
-    const float dx = qx - t.x, dy = qy - t.y, dz = qz - t.z;
-    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-}
-
-// sorted insertion into an ascending register-resident list (drops the largest).  The list is sorted, so
-// inserting is a shift: with c_j = (key < best[j]) -- false ... false true ... true --
-//     new best[j] = c_{j-1} ? best[j-1] : (c_j ? key : best[j]),
-// and for the distance word (the high one) alone that is the median of (best[j-1], key, best[j]).  One 64-bit
-// compare, one v_med3_u32 and two selects per slot, going down the list so that best[j-1] is still the old one
-// (the compare-and-swap chain this replaces compiled to two 64-bit compares, four selects and a move: 85
-// instructions per candidate for the whole wave at K = 10, now 45).
-__device__ __forceinline__ unsigned g_med3_u32(unsigned a, unsigned b, unsigned c) {
-    unsigned r;
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-template <int K>
-__device__ __forceinline__ void knn_insert(unsigned long long (&best)[K], unsigned long long key) {
-    if (key >= best[K - 1]) return;
-    const unsigned kh = (unsigned) (key >> 32), kl = (unsigned) key;
-    bool c[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) c[j] = key < best[j];
-#pragma unroll
-    for (int j = K - 1; j >= 1; --j) {
-        const unsigned ah = (unsigned) (best[j - 1] >> 32), al = (unsigned) best[j - 1];
-        const unsigned bh = (unsigned) (best[j] >> 32), bl = (unsigned) best[j];
-        const unsigned nh = g_med3_u32(ah, kh, bh);
-        const unsigned nl = c[j - 1] ? al : (c[j] ? kl : bl);
-        best[j] = ((unsigned long long) nh << 32) | nl;
-    }
-    best[0] = c[0] ? key : best[0];
-}
-
-// k nearest neighbours of q among the cell-sorted points of grid g: scan the box of cells
-// covering ball(q, r); certified once the k-th distance is within the box margin.
-//
-// A pass resolves the box's rows (runs of x-adjacent cells = contiguous points) kKnnRows at a
-// time -- their cell_start look-ups are issued together, unconditionally (a row outside the box
-// reads row 0 and is given an empty run) -- pushes the non-empty runs into the lane's own column
-// of `runs` (LDS) and then walks them in ONE flat loop, a candidate per trip: a lane moves on to its
-// next run the moment its current one ends, so the wave makes max-over-lanes(candidates of a lane)
-// trips rather than sum-over-rows(max-over-lanes(row length)).  (Same structure, and for the same
-// reason, as the correspondence search's lane scan.)
-constexpr int kKnnRows = 8;
-// A later pass (the box had to grow: the k-th distance found exceeded the first box's margin, the usual case at
-// PCL's k = 10 on a grid of ~3 points per cell) does NOT start over: the list keeps what the smaller box gave, and
-// only the SHELL between the two boxes is scanned -- the x-extensions of the rows the old box had, whole rows
-// elsewhere, four rows (eight segments) per batch -- and of the shell only the rows the sphere of the k-th distance
-// found so far can reach.  (Re-scanning the whole bigger box was 75 candidates through the sorted insertion per
-// query instead of ~45; the insertion -- K compare-swaps for the whole wave per candidate -- is 85 % of k_gicp_cov.)
-template <int K>
-__device__ void knn_search(const GridDev &g, float qx, float qy, float qz, int k, float r0_cells,
-                           unsigned long long (&best)[K], uint2 *runs, unsigned lane_col, unsigned col_stride) {
-    const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
-    float r = r0_cells * g.h;
-    const float rmax = (float) (g.nx + g.ny + g.nz + 3) * g.h;  // covers the whole grid
-#pragma unroll
-    for (int j = 0; j < K; ++j) best[j] = ~0ull;
-    // the runs of one batch (s >= e: none) -> the lane's column of the LDS list -> ONE flat candidate loop
-    auto scan_slots = [&](const unsigned (&rs)[kKnnRows], const unsigned (&re)[kKnnRows]) {
-        int n_runs = 0;
-#pragma unroll
-        for (int u = 0; u < kKnnRows; ++u)
-            if (re[u] > rs[u]) {
-                runs[n_runs * col_stride + lane_col] = make_uint2(rs[u], re[u]);
-                ++n_runs;
-            }
-        if (n_runs == 0) return;
-        // (the next candidate is fetched before the current one goes through the insertion: the load's way to L2
-        // and back is as long as the insertion itself)
-        int ri = 0;
-        const uint2 r0 = runs[lane_col];
-        unsigned j = r0.x, e = r0.y;
-        float4 t = g.pts[j];
-        for (;;) {
-            bool more = true;
-            if (++j == e) {
-                more = ++ri < n_runs;
-                if (more) {
-                    const uint2 rn = runs[ri * col_stride + lane_col];
-                    j = rn.x;
-                    e = rn.y;
-                }
-            }
-            const float4 tn = g.pts[more ? j : r0.x];  // (a lane at its end reads a line it has had already)
-            knn_insert<K>(best, g_make_key(g_d2(qx, qy, qz, t), __float_as_uint(t.w)));
-            if (!more) break;
-            t = tn;
-        }
-    };
-    int pxa = 1, pxb = 0, pya = 1, pyb = 0, pza = 1, pzb = 0;  // the box already scanned (clamped cells; none yet)
-    for (int pass = 0; pass < 64; ++pass) {  // r at least x1.5 per pass: rmax is reached long before
-        const float rc = r * g.inv_h + g.slack;
-        const int x0 = (int) floorf(fx - rc), x1 = (int) floorf(fx + rc);
-        const int y0 = (int) floorf(fy - rc), y1 = (int) floorf(fy + rc);
-        const int z0 = (int) floorf(fz - rc), z1 = (int) floorf(fz + rc);
-        const float mx = fminf(fx - (float) x0, (float) (x1 + 1) - fx);
-        const float my = fminf(fy - (float) y0, (float) (y1 + 1) - fy);
-        const float mz = fminf(fz - (float) z0, (float) (z1 + 1) - fz);
-        const float margin = (fminf(mx, fminf(my, mz)) - g.slack) * g.h;
-        const int xa = max(x0, 0), xb = min(x1, g.nx - 1);
-        const int ya = max(y0, 0), yb = min(y1, g.ny - 1);
-        const int za = max(z0, 0), zb = min(z1, g.nz - 1);
-        const bool any = xa <= xb && ya <= yb && za <= zb;
-        const bool have_prev = pxa <= pxb && pya <= pyb && pza <= pzb;
-        int yy = ya, zz = any ? za : zb + 1;  // row cursor; zz > zb = past the last row
-        if (!have_prev) {
-            while (zz <= zb) {
-                unsigned rs[kKnnRows], re[kKnnRows];
-#pragma unroll
-                for (int u = 0; u < kKnnRows; ++u) {
-                    const bool live = zz <= zb;
-                    const size_t base = ((size_t) (live ? zz : za) * g.ny + (live ? yy : ya)) * g.nx;
-                    rs[u] = g.cell_start[base + xa];
-                    re[u] = live ? g.cell_start[base + xb + 1] : 0u;  // dead row: e <= s
-                    if (++yy > yb) {
-                        yy = ya;
-                        ++zz;
-                    }
-                }
-                scan_slots(rs, re);
-            }
-        } else {
-            // how far a point that still matters can be (cell units): the k-th distance found so far, if there is one
-            unsigned long long kth0 = ~0ull;
-#pragma unroll
-            for (int j = 0; j < K; ++j)
-                if (j == k - 1) kth0 = best[j];
-            const float reach = kth0 != ~0ull ? sqrtf(__uint_as_float((unsigned) (kth0 >> 32))) * g.inv_h * 1.0001f + g.slack
-                                              : 3.0e38f;
-            const float reach2 = reach < 1.0e18f ? reach * reach : 3.0e38f;
-            while (zz <= zb) {
-                unsigned rs[kKnnRows], re[kKnnRows];
-#pragma unroll
-                for (int u = 0; u < kKnnRows; u += 2) {
-                    const bool live = zz <= zb;
-                    const int ry_ = live ? yy : ya, rz_ = live ? zz : za;
-                    // the row's distance from the query in (y, z), cell units (0 inside the query's own row)
-                    const float dy = fmaxf(fmaxf((float) ry_ - fy, fy - (float) (ry_ + 1)), 0.f);
-                    const float dz = fmaxf(fmaxf((float) rz_ - fz, fz - (float) (rz_ + 1)), 0.f);
-                    const bool reachable = live && !(dy * dy + dz * dz > reach2);
-                    const bool old_row = ry_ >= pya && ry_ <= pyb && rz_ >= pza && rz_ <= pzb;
-                    const size_t base = ((size_t) rz_ * g.ny + ry_) * g.nx;
-                    // old row: [xa, pxa - 1] and [pxb + 1, xb]; new row: [xa, xb] and nothing
-                    const int a0 = xa, a1 = old_row ? pxa - 1 : xb;
-                    const int b0 = pxb + 1, b1 = xb;
-                    const bool sa = reachable && a0 <= a1, sb = reachable && old_row && b0 <= b1;
-                    rs[u] = sa ? g.cell_start[base + a0] : 0u;
-                    re[u] = sa ? g.cell_start[base + a1 + 1] : 0u;
-                    rs[u + 1] = sb ? g.cell_start[base + b0] : 0u;
-                    re[u + 1] = sb ? g.cell_start[base + b1 + 1] : 0u;
-                    if (++yy > yb) {
-                        yy = ya;
-                        ++zz;
-                    }
-                }
-                scan_slots(rs, re);
-            }
-        }
-        if (any) {
-            pxa = xa, pxb = xb, pya = ya, pyb = yb, pza = za, pzb = zb;
-        }
-        unsigned long long kth = ~0ull;
-#pragma unroll
-        for (int j = 0; j < K; ++j)
-            if (j == k - 1) kth = best[j];
-        const bool covers_all = x0 <= 0 && y0 <= 0 && z0 <= 0 && x1 >= g.nx - 1 && y1 >= g.ny - 1 &&
-                                z1 >= g.nz - 1;
-        if (covers_all) return;
-        if (kth != ~0ull && margin > 0.f) {
-            const float kd2 = __uint_as_float((unsigned) (kth >> 32));
-            if (kd2 <= margin * margin) return;
-            r = fmaxf(sqrtf(kd2) * 1.0001f + 1e-6f, 1.5f * r);  // one more pass certifies
-        } else {
-            r *= 2.0f;
-        }
-        r = fminf(r, rmax);
-    }
-}
 
 // computeCovariances for every point of `qpts` (any order); neighbours come from grid g
 // (built over the same cloud), coordinates are gathered from `orig` by caller index.
@@ -240,70 +57,9 @@ __global__ void __launch_bounds__(kBlock)
         for (int j = 0; j < K; ++j) best[j] = (unsigned long long) min(i + (unsigned) j, n - 1u);
     } else
     knn_search<K>(g, q.x, q.y, q.z, k, r0_cells, best, s_runs, threadIdx.x, kBlock);
-    double mean[3] = {0, 0, 0}, c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        if (j < k && best[j] != ~0ull) {
-            const float4 p = orig[(unsigned) best[j]];
-            mean[0] += p.x;
-            mean[1] += p.y;
-            mean[2] += p.z;
-            c[0] += __fmul_rn(p.x, p.x);  // float products, as `cov(0,0) += pt.x*pt.x`
-            c[3] += __fmul_rn(p.y, p.x);
-            c[4] += __fmul_rn(p.y, p.y);
-            c[6] += __fmul_rn(p.z, p.x);
-            c[7] += __fmul_rn(p.z, p.y);
-            c[8] += __fmul_rn(p.z, p.z);
-        }
-    }
-    const double kk = (double) k;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) mean[a] /= kk;
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-            if (b <= a) {
-                c[a * 3 + b] /= kk;
-                c[a * 3 + b] -= mean[a] * mean[b];
-                c[b * 3 + a] = c[a * 3 + b];
-            }
-    double U[9], S[3], V[9];
-    if (by_w & 256) {
-#pragma unroll
-        for (int a = 0; a < 9; ++a) out[a] = c[a];
-        return;
-    }
-    svd3<false>(c, U, S, V);  // IEEE operations only: the oracle reproduces these matrices bit for bit
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            double s = 0;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) s += (j == 2 ? eps : 1.0) * U[a * 3 + j] * U[b * 3 + j];
-            out[a * 3 + b] = s;
-        }
+    gicp_cov_of_list<K>(best, k, eps, [&](unsigned idx) { return orig[idx]; }, out, (by_w & 256) != 0);
 }
 
-struct Mat3d {
-    double m[9];
-};
-
-__device__ inline void inv3(const double *m, double *o) {
-    const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8],
-                 c02 = m[3] * m[7] - m[4] * m[6];
-    const double id = 1.0 / (m[0] * c00 + m[1] * c01 + m[2] * c02);
-    o[0] = c00 * id;
-    o[1] = (m[2] * m[7] - m[1] * m[8]) * id;
-    o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
-    o[3] = c01 * id;
-    o[4] = (m[0] * m[8] - m[2] * m[6]) * id;
-    o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
-    o[6] = c02 * id;
-    o[7] = (m[1] * m[6] - m[0] * m[7]) * id;
-    o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
-}
 
 // mahalanobis_[i] = (R C1_i R^T + C2_j)^-1 for matched i (sorted-source order)
 __global__ void __launch_bounds__(kBlock)
@@ -314,113 +70,14 @@ __global__ void __launch_bounds__(kBlock)
     if (i >= n) return;
     const unsigned j = (unsigned) keys[i];
     if (j == kNoIdx) return;
-    const double *c1 = C1 + (size_t) i * 9, *c2 = C2 + (size_t) j * 9;
-    double M[9], t[9];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            double s = 0;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) s += R.m[a * 3 + c] * c1[c * 3 + b];
-            M[a * 3 + b] = s;
-        }
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            double s = 0;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) s += M[a * 3 + c] * R.m[b * 3 + c];
-            t[a * 3 + b] = s + c2[a * 3 + b];
-        }
     double o[9];
-    inv3(t, o);
+    gicp_mahal_of(C1 + (size_t) i * 9, C2 + (size_t) j * 9, R.m, o);
     // component-major (nine arrays of n): the objective kernel, which reads these ~170 times per
     // registration, then gets fully coalesced 8-byte loads instead of a 72-byte stride per lane
 #pragma unroll
     for (int a = 0; a < 9; ++a) mahal[(size_t) a * n + i] = o[a];
 }
 
-struct FdfArgs {
-    float T[12];  // T(x) = applyState(base, x), float
-    float B[12];  // base_transformation_
-};
-
-// Double-double accumulation (error-free TwoSum of every term into a (hi, lo) pair): the thirteen
-// sums come out as the correctly rounded value of the EXACT sum of their terms (up to ~1e-26
-// relative), whatever the order they were added in.  Why it matters here and nowhere else: PCL's
-// BFGS stops at a gradient tolerance of 1e-2 on this objective, evaluated through a float-quantised
-// transform, so a last-bit difference in f or the gradient can flip a line-search branch and move the
-// stopping point by millimetres.  With order-independent sums the CPU oracle (sequential) and this
-// kernel (strided lanes, wave and block trees) agree bit for bit, and so does every decision after.
-__device__ __forceinline__ void dd_add(double &hi, double &lo, double x) {
-    const double s = hi + x;
-    const double bb = s - hi;
-    lo += (hi - (s - bb)) + (x - bb);
-    hi = s;
-}
-
-template <int C, int M>
-__device__ __forceinline__ void dd_halve(double (&hi)[kGicpAcc], double (&lo)[kGicpAcc], unsigned lane) {
-    constexpr int H = (C + 1) / 2;
-    const bool up = (lane & (unsigned) M) != 0u;
-#pragma unroll
-    for (int i = 0; i < H; ++i) {
-        const double h_lo = hi[i], l_lo = lo[i];
-        const double h_hi = (H + i < C) ? hi[H + i] : 0.0, l_hi = (H + i < C) ? lo[H + i] : 0.0;
-        const double sh = up ? h_lo : h_hi, sl = up ? l_lo : l_hi;  // the half this lane gives away
-        double kh = up ? h_hi : h_lo, kl = up ? l_hi : l_lo;        // the half it keeps
-        const double rh = __shfl_xor(sh, M), rl = __shfl_xor(sl, M);
-        dd_add(kh, kl, rh);
-        kl += rl;
-        hi[i] = kh;
-        lo[i] = kl;
-    }
-    if constexpr (M > 1) dd_halve<H, M / 2>(hi, lo, lane);
-}
-__device__ __forceinline__ int dd_comp_of_lane(unsigned lane) {
-    int c = kGicpAcc, base = 0, valid = kGicpAcc;
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) {
-        const int h = (c + 1) / 2;
-        if (lane & (unsigned) m) {
-            base += h;
-            valid -= h;
-        } else {
-            valid = valid < h ? valid : h;
-        }
-        c = h;
-    }
-    return valid >= 1 ? base : -1;
-}
-
-// a[0] = sum r^T M r, a[1..3] = sum M r, a[4..12] = sum p_base (M r)^T; count separately.
-// partials: [block][kGicpAcc][2] = (hi, lo) pairs.  The workgroup's share of one evaluation
-// (all threads of the workgroup call it: it ends with a barrier and the row's store).
-// one matched pair's terms (p: the source point, q: its match, M: the pair's Mahalanobis matrix)
-__device__ __forceinline__ void gicp_fdf_point(double (&hi)[kGicpAcc], double (&lo)[kGicpAcc], const FdfArgs &A,
-                                               float px, float py, float pz, float qx, float qy, float qz,
-                                               const double (&M)[9]) {
-    const float ppx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.T[0], px), __fmul_rn(A.T[1], py)), __fmul_rn(A.T[2], pz)), A.T[3]);
-    const float ppy = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.T[4], px), __fmul_rn(A.T[5], py)), __fmul_rn(A.T[6], pz)), A.T[7]);
-    const float ppz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.T[8], px), __fmul_rn(A.T[9], py)), __fmul_rn(A.T[10], pz)), A.T[11]);
-    const double res[3] = {(double) __fsub_rn(ppx, qx), (double) __fsub_rn(ppy, qy), (double) __fsub_rn(ppz, qz)};
-    double temp[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) temp[r] = M[r * 3] * res[0] + M[r * 3 + 1] * res[1] + M[r * 3 + 2] * res[2];
-    dd_add(hi[0], lo[0], res[0] * temp[0] + res[1] * temp[1] + res[2] * temp[2]);
-    const float pbx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.B[0], px), __fmul_rn(A.B[1], py)), __fmul_rn(A.B[2], pz)), A.B[3]);
-    const float pby = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.B[4], px), __fmul_rn(A.B[5], py)), __fmul_rn(A.B[6], pz)), A.B[7]);
-    const float pbz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(A.B[8], px), __fmul_rn(A.B[9], py)), __fmul_rn(A.B[10], pz)), A.B[11]);
-    const double pb[3] = {(double) pbx, (double) pby, (double) pbz};
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        dd_add(hi[1 + r], lo[1 + r], temp[r]);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) dd_add(hi[4 + r * 3 + c], lo[4 + r * 3 + c], pb[r] * temp[c]);
-    }
-}
 
 // the pairs i0, i0 + stride, ... < n straight from HBM
 __device__ __forceinline__ void gicp_fdf_stream(double (&hi)[kGicpAcc], double (&lo)[kGicpAcc], unsigned i0,
@@ -777,60 +434,14 @@ static int count_matched(wm_ctx *ctx, size_t n, unsigned *cnt) {
 }
 
 // ------------------------------------------------------------------ host
-static void state_to_matrix_f(const double base[16], const double x[6], float T[16]) {
-    const float cphi = cosf((float) x[3]), sphi = sinf((float) x[3]);
-    const float cth = cosf((float) x[4]), sth = sinf((float) x[4]);
-    const float cpsi = cosf((float) x[5]), spsi = sinf((float) x[5]);
-    float R[9], B[16], o[16];
-    R[0] = cpsi * cth;
-    R[1] = cpsi * sth * sphi - spsi * cphi;
-    R[2] = cpsi * sth * cphi + spsi * sphi;
-    R[3] = spsi * cth;
-    R[4] = spsi * sth * sphi + cpsi * cphi;
-    R[5] = spsi * sth * cphi - cpsi * sphi;
-    R[6] = -sth;
-    R[7] = cth * sphi;
-    R[8] = cth * cphi;
-    for (int i = 0; i < 16; ++i) B[i] = (float) base[i];
-    memcpy(o, B, sizeof(o));
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            float s = 0;
-            for (int k = 0; k < 3; ++k) s += R[i * 3 + k] * B[k * 4 + j];
-            o[i * 4 + j] = s;
-        }
-    o[3] = B[3] + (float) x[0];
-    o[7] = B[7] + (float) x[1];
-    o[11] = B[11] + (float) x[2];
-    memcpy(T, o, sizeof(o));
-}
-
-static void r_derivative(const double x[6], const double Racc[9], double g[6]) {
-    const double phi = x[3], theta = x[4], psi = x[5];
-    const double cphi = cos(phi), sphi = sin(phi), ctheta = cos(theta), stheta = sin(theta),
-                 cpsi = cos(psi), spsi = sin(psi);
-    const double dPhi[9] = {0, sphi * spsi + cphi * cpsi * stheta, cphi * spsi - cpsi * sphi * stheta,
-                            0, -cpsi * sphi + cphi * spsi * stheta, -cphi * cpsi - sphi * spsi * stheta,
-                            0, cphi * ctheta, -ctheta * sphi};
-    const double dTheta[9] = {-cpsi * stheta, cpsi * ctheta * sphi, cphi * cpsi * ctheta,
-                              -spsi * stheta, ctheta * sphi * spsi, cphi * ctheta * spsi,
-                              -ctheta, -sphi * stheta, -cphi * stheta};
-    const double dPsi[9] = {-ctheta * spsi, -cphi * cpsi - sphi * spsi * stheta, cpsi * sphi - cphi * spsi * stheta,
-                            cpsi * ctheta, -cphi * spsi + cpsi * sphi * stheta, sphi * spsi + cphi * cpsi * stheta,
-                            0, 0, 0};
-    g[3] = g[4] = g[5] = 0;
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {  // matricesInnerProd: sum mat1(j,i) * mat2(i,j)
-            g[3] += dPhi[j * 3 + i] * Racc[i * 3 + j];
-            g[4] += dTheta[j * 3 + i] * Racc[i * 3 + j];
-            g[5] += dPsi[j * 3 + i] * Racc[i * 3 + j];
-        }
-}
-
 struct GicpFn {
     wm_ctx *ctx;
     const double *base;
     int m = 0;  // matched pairs
+    // (what bfgs_minimize asks of its objective, wm_bfgs.hpp)
+    double fdf(const double x[6], double g[6]);
+    int pairs() const { return m; }
+    bool failed() const { return rc != WM_OK; }
     int evals = 0;
     float kernel_ms = 0;
     int rc = WM_OK;
@@ -1064,9 +675,9 @@ static double gicp_fdf(GicpFn &F, const double x[6], double g[6]) {
     if (const char *path = getenv("WM_GICP_TRACE")) {  // developer: every evaluation, in hex floats
         if (FILE *fp = fopen(path, "a")) {
             fprintf(fp, "%d", F.m);
-            for (int k = 0; k < 6; ++k) fprintf(fp, " %a", x[k]);
-            fprintf(fp, " | %a |", a[0] / m);
-            if (g) for (int k = 0; k < 6; ++k) fprintf(fp, " %a", g[k]);
+            for (int k = 0; k < 6; ++k) fprintf(fp, " %.17g", x[k]);
+            fprintf(fp, " | %.17g |", a[0] / m);
+            if (g) for (int k = 0; k < 6; ++k) fprintf(fp, " %.17g", g[k]);
             fprintf(fp, "\n");
             fclose(fp);
         }
@@ -1074,238 +685,7 @@ static double gicp_fdf(GicpFn &F, const double x[6], double g[6]) {
     return a[0] / m;
 }
 
-// ---- pcl::BFGS (GSL vector_bfgs2 + Fletcher line search)
-struct LineFn {
-    GicpFn *F;
-    double x0[6], p[6], f0, df0;
-    double x_a[6], g_a[6], alpha_c, f_c, df_c;
-    bool have_c = false;
-    void eval(double alpha) {
-        if (have_c && alpha == alpha_c) return;
-        for (int i = 0; i < 6; ++i) x_a[i] = x0[i] + alpha * p[i];
-        f_c = gicp_fdf(*F, x_a, g_a);
-        df_c = 0;
-        for (int i = 0; i < 6; ++i) df_c += g_a[i] * p[i];
-        alpha_c = alpha;
-        have_c = true;
-    }
-};
-
-static double cubic(double c0, double c1, double c2, double c3, double z) { return c0 + z * (c1 + z * (c2 + z * c3)); }
-static void check_extremum(double c0, double c1, double c2, double c3, double z, double *zmin, double *fmin) {
-    const double y = cubic(c0, c1, c2, c3, z);
-    if (y < *fmin) {
-        *zmin = z;
-        *fmin = y;
-    }
-}
-static int solve_quadratic(double a, double b, double c, double *x0, double *x1) {
-    if (a == 0) {
-        if (b == 0) return 0;
-        *x0 = -c / b;
-        return 1;
-    }
-    const double disc = b * b - 4 * a * c;
-    if (disc > 0) {
-        if (b == 0) {
-            const double r = sqrt(-c / a);
-            *x0 = -r;
-            *x1 = r;
-        } else {
-            const double sgnb = (b > 0 ? 1 : -1);
-            const double temp = -0.5 * (b + sgnb * sqrt(disc));
-            const double r1 = temp / a, r2 = c / temp;
-            *x0 = r1 < r2 ? r1 : r2;
-            *x1 = r1 < r2 ? r2 : r1;
-        }
-        return 2;
-    } else if (disc == 0) {
-        *x0 = *x1 = -0.5 * b / a;
-        return 2;
-    }
-    return 0;
-}
-static double interp_quad(double f0, double fp0, double f1, double zl, double zh) {
-    const double fl = f0 + zl * (fp0 + zl * (f1 - f0 - fp0));
-    const double fh = f0 + zh * (fp0 + zh * (f1 - f0 - fp0));
-    const double c = 2 * (f1 - f0 - fp0);
-    double zmin = zl, fmin = fl;
-    if (fh < fmin) {
-        zmin = zh;
-        fmin = fh;
-    }
-    if (c > 0) {
-        const double z = -fp0 / c;
-        if (z > zl && z < zh) {
-            const double f = f0 + z * (fp0 + z * (f1 - f0 - fp0));
-            if (f < fmin) {
-                zmin = z;
-                fmin = f;
-            }
-        }
-    }
-    return zmin;
-}
-static double interp_cubic(double f0, double fp0, double f1, double fp1, double zl, double zh) {
-    const double eta = 3 * (f1 - f0) - 2 * fp0 - fp1, xi = fp0 + fp1 - 2 * (f1 - f0);
-    const double c0 = f0, c1 = fp0, c2 = eta, c3 = xi;
-    double zmin = zl, fmin = cubic(c0, c1, c2, c3, zl), z0, z1;
-    check_extremum(c0, c1, c2, c3, zh, &zmin, &fmin);
-    const int n = solve_quadratic(3 * c3, 2 * c2, c1, &z0, &z1);
-    if (n == 2) {
-        if (z0 > zl && z0 < zh) check_extremum(c0, c1, c2, c3, z0, &zmin, &fmin);
-        if (z1 > zl && z1 < zh) check_extremum(c0, c1, c2, c3, z1, &zmin, &fmin);
-    } else if (n == 1) {
-        if (z0 > zl && z0 < zh) check_extremum(c0, c1, c2, c3, z0, &zmin, &fmin);
-    }
-    return zmin;
-}
-static double interpolate(double a, double fa, double fpa, double b, double fb, double fpb, double xmin,
-                          double xmax, int order) {
-    double ymin = (xmin - a) / (b - a), ymax = (xmax - a) / (b - a);
-    if (ymin > ymax) {
-        const double t = ymin;
-        ymin = ymax;
-        ymax = t;
-    }
-    const double y = (order > 2 && fpb == fpb) ? interp_cubic(fa, fpa * (b - a), fb, fpb * (b - a), ymin, ymax)
-                                               : interp_quad(fa, fpa * (b - a), fb, ymin, ymax);
-    return a + y * (b - a);
-}
-
-static bool line_search(LineFn &L, double rho, double sigma, double tau1, double tau2, double tau3,
-                        int order, double alpha1, double *alpha_new) {
-    const double f0 = L.f0, fp0 = L.df0;
-    double falpha, falpha_prev = f0, fpalpha, fpalpha_prev = fp0, delta, alpha_next;
-    double alpha = alpha1, alpha_prev = 0.0;
-    double a = 0.0, b = alpha, fa = f0, fb = 0.0, fpa = fp0, fpb = 0.0;
-    int i = 0;
-    while (i++ < 100) {
-        L.eval(alpha);
-        falpha = L.f_c;
-        if (falpha > f0 + alpha * rho * fp0 || falpha >= falpha_prev) {
-            a = alpha_prev; fa = falpha_prev; fpa = fpalpha_prev;
-            b = alpha; fb = falpha; fpb = NAN;
-            break;
-        }
-        fpalpha = L.df_c;
-        if (fabs(fpalpha) <= -sigma * fp0) {
-            *alpha_new = alpha;
-            return true;
-        }
-        if (fpalpha >= 0) {
-            a = alpha; fa = falpha; fpa = fpalpha;
-            b = alpha_prev; fb = falpha_prev; fpb = fpalpha_prev;
-            break;
-        }
-        delta = alpha - alpha_prev;
-        alpha_next = interpolate(alpha_prev, falpha_prev, fpalpha_prev, alpha, falpha, fpalpha,
-                                 alpha + delta, alpha + tau1 * delta, order);
-        alpha_prev = alpha; falpha_prev = falpha; fpalpha_prev = fpalpha;
-        alpha = alpha_next;
-    }
-    while (i++ < 100) {
-        delta = b - a;
-        alpha = interpolate(a, fa, fpa, b, fb, fpb, a + tau2 * delta, b - tau3 * delta, order);
-        L.eval(alpha);
-        falpha = L.f_c;
-        if ((a - alpha) * fpa <= DBL_EPSILON) return false;  // roundoff prevents progress
-        if (falpha > f0 + rho * alpha * fp0 || falpha >= fa) {
-            b = alpha; fb = falpha; fpb = NAN;
-        } else {
-            fpalpha = L.df_c;
-            if (fabs(fpalpha) <= -sigma * fp0) {
-                *alpha_new = alpha;
-                return true;
-            }
-            if (((b - a) >= 0 && fpalpha >= 0) || ((b - a) <= 0 && fpalpha <= 0)) {
-                b = a; fb = fa; fpb = fpa;
-                a = alpha; fa = falpha; fpa = fpalpha;
-            } else {
-                a = alpha; fa = falpha; fpa = fpalpha;
-            }
-        }
-    }
-    *alpha_new = alpha;
-    return true;
-}
-
-static double norm6(const double *v) {
-    double s = 0;
-    for (int i = 0; i < 6; ++i) s += v[i] * v[i];
-    return sqrt(s);
-}
-
-// estimateRigidTransformationBFGS; returns inner iterations, -1 if < 4 pairs
-static int bfgs_minimize(GicpFn &F, double x[6], int max_inner, double *f_out) {
-    const double rho = 0.01, sigma = 0.01, tau1 = 9, tau2 = 0.05, tau3 = 0.5, gradient_tol = 1e-2;
-    if (F.m < 4) return -1;
-    double g[6], x0[6], g0[6], p[6], dx0[6], dg0[6];
-    double f = gicp_fdf(F, x, g);
-    memcpy(x0, x, sizeof(x0));
-    memcpy(g0, g, sizeof(g0));
-    double g0norm = norm6(g0);
-    for (int i = 0; i < 6; ++i) p[i] = -g0[i] / g0norm;
-    double pnorm = norm6(p), fp0 = -g0norm, delta_f = 0;
-    int inner = 0;
-    do {
-        ++inner;
-        if (F.rc != WM_OK) break;
-        if (pnorm == 0.0 || g0norm == 0.0 || fp0 == 0 || pnorm != pnorm || g0norm != g0norm) break;
-        const double f_prev = f;
-        double alpha = 0, alpha1;
-        if (delta_f < 0) {
-            const double del = fmax(-delta_f, 10 * DBL_EPSILON * fabs(f_prev));
-            alpha1 = fmin(1.0, 2.0 * del / (-fp0));
-        } else {
-            alpha1 = 1.0;  // parameters.step_size
-        }
-        LineFn L;
-        L.F = &F;
-        memcpy(L.x0, x0, sizeof(x0));
-        memcpy(L.p, p, sizeof(p));
-        L.f0 = f_prev;
-        L.df0 = fp0;
-        if (!line_search(L, rho, sigma, tau1, tau2, tau3, 3, alpha1, &alpha)) break;
-        L.eval(alpha);
-        memcpy(x, L.x_a, sizeof(L.x_a));
-        memcpy(g, L.g_a, sizeof(L.g_a));
-        f = L.f_c;
-        delta_f = f - f_prev;
-        double dxg = 0, dgg = 0, dxdg = 0, A, B, pg = 0;
-        for (int i = 0; i < 6; ++i) {
-            dx0[i] = x[i] - x0[i];
-            dg0[i] = g[i] - g0[i];
-        }
-        for (int i = 0; i < 6; ++i) {
-            dxg += dx0[i] * g[i];
-            dgg += dg0[i] * g[i];
-            dxdg += dx0[i] * dg0[i];
-        }
-        const double dgnorm = norm6(dg0);
-        if (dxdg != 0) {
-            B = dxg / dxdg;
-            A = -(1.0 + dgnorm * dgnorm / dxdg) * B + dgg / dxdg;
-        } else {
-            B = 0;
-            A = 0;
-        }
-        for (int i = 0; i < 6; ++i) p[i] = g[i] - A * dx0[i] - B * dg0[i];
-        memcpy(g0, g, sizeof(g0));
-        memcpy(x0, x, sizeof(x0));
-        g0norm = norm6(g0);
-        pnorm = norm6(p);
-        for (int i = 0; i < 6; ++i) pg += p[i] * g0[i];
-        const double dir = (pg >= 0) ? -1.0 : +1.0;
-        for (int i = 0; i < 6; ++i) p[i] *= dir / pnorm;
-        pnorm = norm6(p);
-        fp0 = 0;
-        for (int i = 0; i < 6; ++i) fp0 += p[i] * g0[i];
-        if (norm6(g) < gradient_tol) break;
-    } while (inner < max_inner);
-    if (f_out) *f_out = f;
-    return inner;
-}
+double GicpFn::fdf(const double x[6], double g[6]) { return gicp_fdf(*this, x, g); }
 
 static float choose_cell(const Bbox &bb, size_t n) {
     double vol = 1;
@@ -1321,6 +701,15 @@ static int launch_cov(wm_ctx *ctx, const GridDev &g, const float4 *q, size_t n, 
                        dim3(kBlock), 0, ctx->stream, g, q, (unsigned) n, orig, k, eps, out, by_w | ctx->tune_cov_dbg,
                        ctx->tune_knn_r0 > 0 ? ctx->tune_knn_r0 : (k <= 12 ? 1.0f : 1.5f));
     WM_HIP(ctx, hipGetLastError());
+#ifdef WM_COV_COUNT
+    double c[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void) hipStreamSynchronize(ctx->stream);
+    (void) hipMemcpyFromSymbol(c, HIP_SYMBOL(g_knn_cnt), sizeof(c));
+    (void) hipMemcpyToSymbol(HIP_SYMBOL(g_knn_cnt), z, sizeof(z));
+    const double waves = (double) n / 64.0;
+    fprintf(stderr, "[knn] n %zu: candidates/query %.1f, wave trips/wave %.1f, batches/query %.2f, wave batches/wave %.2f, passes/query %.2f\n", n,
+            c[0] / n, c[1] / waves, c[2] / n, c[3] / waves, c[4] / n);
+#endif
     return WM_OK;
 }
 

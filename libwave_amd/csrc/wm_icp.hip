@@ -903,6 +903,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
                       &ctx->shard_pos_s, &ctx->shard_stats, &ctx->ndt_sum_dev, &ctx->corr_tmp_idx, &ctx->corr_tmp_d2, &ctx->d_state};
     for (DevBuf *b : bufs) b->release();
     small_batch_release(ctx);
+    gicp_small_release(ctx);
     batch_voxel_release(ctx);
     for (auto &l : ctx->levels) {
         l.pts.release();

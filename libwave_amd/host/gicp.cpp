@@ -99,4 +99,48 @@ bool GICPMatcher::match() {
     return true;
 }
 
+bool GICPMatcher::batchable(const PCLPointCloudPtr &r, const PCLPointCloudPtr &t) const {
+    if (!r || !t) return false;
+    const size_t cap = resolution > 0 ? (size_t) 4 * WM_GICP_BATCH_MAX_POINTS : (size_t) WM_GICP_BATCH_MAX_POINTS;
+    return cloudSize(r) <= cap && cloudSize(t) <= cap;
+}
+
+bool GICPMatcher::matchBatch(const std::vector<std::pair<PCLPointCloudPtr, PCLPointCloudPtr>> &pairs, BatchOutcomes &out) {
+    out.clear();
+    if (pairs.empty()) return true;
+    for (const auto &pr : pairs)
+        if (!batchable(pr.first, pr.second)) return false;
+    if (!ensureContext()) return false;
+    wm_gicp_params p;
+    wm_gicp_default_params(&p);
+    p.corr_rand = params.corr_rand;  // as match() sets them (gicp.cpp:31-33)
+    p.max_iter = params.max_iter;
+    p.r_eps = params.r_eps;
+    const size_t n = pairs.size();
+    std::vector<wm_batch_item> items(n);
+    for (size_t k = 0; k < n; ++k) {
+        items[k].src = cloudData(pairs[k].first);
+        items[k].n_src = cloudSize(pairs[k].first);
+        items[k].target = cloudData(pairs[k].second);
+        items[k].n_target = cloudSize(pairs[k].second);
+    }
+    std::vector<double> T(16 * n);
+    std::vector<int> status(n, WM_ERR_STATE);
+    const int rc = wm_gicp_batch_match(ctx, items.data(), (int) n, kCloudStride, WM_MEM_HOST, &p, resolution, T.data(), nullptr,
+                                       status.data(), nullptr);
+    if (!shim::succeeded(rc, "wm_gicp_batch_match", ctx)) return false;
+    out.resize(n);
+    for (size_t k = 0; k < n; ++k) {
+        ref = pairs[k].first;
+        target = pairs[k].second;
+        const bool ok = status[k] == WM_OK;
+        if (ok) shim::toAffine(&T[16 * k], result);  // anything else leaves `result` as it was (gicp.cpp:59-63)
+        out[k].matched = ok;
+        out[k].transform = result;
+        out[k].info = information;
+    }
+    ref_on_device = target_on_device = false;  // (the context holds no snapshot of the last pair's clouds)
+    return true;
+}
+
 }  // namespace wave

@@ -509,6 +509,66 @@ AddCase c_multi_devices("MultiTest.workersDealtOverDevices", [] {
     wave::ICPMatcher::setThreadDevice(-1);
 });
 
+// The batched path of GICPMatcher (matchBatch, wm_gicp_batch_match: one registration per compute unit, the whole of
+// align in the kernel).  Every pair must come out as a matcher used on that pair alone gives it.
+AddCase c_gicp_batch("GICPTest.matchBatchEqualsOneByOne", [] {
+    const auto scan = loadScan();
+    for (int variant = 0; variant < 2; ++variant) {
+        wave::GICPMatcherParams p;  // defaults: res 0.1
+        if (variant == 1) p.res = -1;
+        std::vector<std::pair<wave::PCLPointCloudPtr, wave::PCLPointCloudPtr>> pairs;
+        for (int k = 0; k < 4; ++k) pairs.emplace_back(subsample(scan, 6 + k, 0.f), subsample(scan, 5 + k, 0.05f * (float) k));
+        pairs.emplace_back(subsample(scan, 9, 0.f), subsample(scan, 9, 400.f));  // nothing within max_corr: match() fails
+        pairs.emplace_back(subsample(scan, 7, 0.f), subsample(scan, 6, 0.1f));
+        wave::GICPMatcher batch(p);
+        for (const auto &pr : pairs) EXPECT(batch.batchable(pr.first, pr.second));
+        wave::GICPMatcher::BatchOutcomes got;
+        EXPECT(batch.matchBatch(pairs, got));
+        EXPECT(got.size() == pairs.size());
+        wave::Affine3 last = wave::Affine3::Identity();
+        for (size_t k = 0; k < pairs.size() && k < got.size(); ++k) {
+            wave::GICPMatcher one(p);
+            one.setup(pairs[k].first, pairs[k].second);
+            const bool ok = one.match();
+            EXPECT(ok == got[k].matched);
+            EXPECT(ok == (k != 4));
+            if (ok) {
+                EXPECT(distanceTo(one.getResult(), got[k].transform) < 1e-6);
+                last = got[k].transform;
+            } else {
+                EXPECT(distanceTo(last, got[k].transform) == 0.0);  // `result` is left alone (gicp.cpp:59-63)
+            }
+        }
+    }
+});
+
+// ... under the pool, at the reference's default queue of ten (multi_matcher.hpp:32-34)
+AddCase c_gicp_pool("MultiTest.gicpPairsGoThroughTheBatchedPath", [] {
+    wave::GICPMatcherParams p;
+    p.res = -1;
+    wave::MultiMatcher<wave::GICPMatcher, wave::GICPMatcherParams> pool(4, 10, p);
+    const auto scan = loadScan();
+    std::vector<wave::PCLPointCloudPtr> refs, targets;
+    for (int k = 0; k < 24; ++k) {
+        refs.push_back(subsample(scan, 10 + (size_t) (k % 3), 0.f));
+        targets.push_back(subsample(scan, 9 + (size_t) (k % 3), 0.02f * (float) (k % 5)));
+    }
+    for (int k = 0; k < 24; ++k) pool.insert(k, refs[(size_t) k], targets[(size_t) k]);
+    while (!pool.done()) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+    std::set<int> seen;
+    int id = -1;
+    Eigen::Affine3d T;
+    wave::Mat6 info;
+    while (pool.getResult(&id, &T, &info)) {
+        seen.insert(id);
+        wave::GICPMatcher one(p);
+        one.setup(refs[(size_t) id], targets[(size_t) id]);
+        EXPECT(one.match());
+        EXPECT(distanceTo(one.getResult(), T) < 1e-6);
+    }
+    EXPECT(seen.size() == 24u);
+});
+
 }  // namespace
 
 int main(int argc, char **argv) {
