@@ -33,6 +33,22 @@ namespace wm {
 
 constexpr int kGsThreads = 1024;
 constexpr int kGsWaves = kGsThreads / 64;
+// An evaluation's data: per source slot the point (float4), its match (float4; x = NaN: none) and the pair's
+// Mahalanobis matrix (9 doubles) -- 104 bytes, read ~170 times per registration, from HBM every time (256
+// registrations at once: ~0.5 GB per round of evaluations).  Laid out in blocks of 64 slots = one wave's trip:
+// [64 x point | 64 x match | 9 x 64 x one matrix entry], 6656 contiguous bytes, every load of the wave a full
+// line.  (As eleven separate arrays per registration -- 2800 streams over the device -- the same bytes took 5 % longer
+// with 256 registrations running, 10 % with 16.)
+constexpr unsigned kGsEvBlock = 64u * (16u + 16u + 72u);
+__device__ __forceinline__ float4 *gs_ev_point(unsigned char *evb, unsigned i) {
+    return reinterpret_cast<float4 *>(evb + (size_t) (i >> 6) * kGsEvBlock) + (i & 63u);
+}
+__device__ __forceinline__ float4 *gs_ev_match(unsigned char *evb, unsigned i) {
+    return reinterpret_cast<float4 *>(evb + (size_t) (i >> 6) * kGsEvBlock + 1024u) + (i & 63u);
+}
+__device__ __forceinline__ double *gs_ev_mahal(unsigned char *evb, unsigned i) {  // entry c at [c * 64]
+    return reinterpret_cast<double *>(evb + (size_t) (i >> 6) * kGsEvBlock + 2048u) + (i & 63u);
+}
 constexpr unsigned kGsCells = 262144;  // cells of a cloud's grid at most (two arrays of that many words per cloud in the pair's scratch)
 
 struct GsPair {  // one registration of the batch (device table)
@@ -43,9 +59,8 @@ struct GsPair {  // one registration of the batch (device table)
     unsigned *s_cs, *t_cs;  // first slot of every cell (+ end)
     unsigned *run;          // the counting sort's histogram / running offsets
     double *c1, *c2;        // covariances, 9 per point, by the caller's index
-    double *mahal;          // 9 arrays of n_src (component-major), by the source's slot
+    unsigned char *evb;     // what an evaluation reads, in blocks of 64 source slots (kGsEvBlock bytes each, see gs_ev_*)
     unsigned *match;        // by the source's slot: the caller's index of its target match (kNoIdx none)
-    float4 *match_pt;       // ... and that point's coordinates (x = NaN: no match)
 };
 
 struct GsParams {
@@ -72,7 +87,7 @@ struct GsShared {
     float boxf[kGsWaves][8];
     unsigned wcnt[kGsWaves];
     unsigned scan[kGsWaves];
-    unsigned cmd;      // 1: evaluate at cmdT, 0: the minimisation is over
+    unsigned cmd;      // 1 / 2: evaluate at cmdT (2: walking the blocks backwards), 0: the minimisation is over
     float cmdT[12];
     double res[8];     // what wave 0's minimisation left: x (6), f, inner iterations
     int res_evals;
@@ -268,21 +283,23 @@ struct GsFn {
     __device__ int pairs() const { return m; }
     __device__ bool failed() const { return false; }
     // this wave's share of one evaluation -> its row of S->red
-    __device__ void share(const FdfArgs &A) {
+    __device__ void share(const FdfArgs &A, bool backwards) {
         double hi[kGicpAcc], lo[kGicpAcc];
 #pragma unroll
         for (int k = 0; k < kGicpAcc; ++k) hi[k] = lo[k] = 0.0;
         const unsigned tid = threadIdx.x;
-        // (six streams of 16 / 8 bytes per lane.  Measured: the point and its match as six float arrays -- 96 instead of
-        // 104 bytes per pair -- is SLOWER, 45.8 vs 40.6 Mcycles per registration with 256 of them running: what binds
-        // is the number of memory instructions and of concurrent streams, not the bytes)
-        const float4 *__restrict__ s_pts = pr->s_pts, *__restrict__ match_pt = pr->match_pt;
-        const double *__restrict__ mahal = pr->mahal;
-        for (unsigned i = tid; i < n; i += kGsThreads) {
-            const float4 p = s_pts[i], q = match_pt[i];
+        unsigned char *evb = pr->evb;
+        // Every other evaluation walks the blocks from the far end: what the last one read last -- about half of a
+        // 20 000-point registration's 2 MB, with 256 of them sharing the 256 MB memory-side cache -- is then read
+        // first, before the rest of the sweep has pushed it out.  (The sums are double-double: any order, same bits.)
+        const unsigned trips = n > tid ? (n - tid + kGsThreads - 1u) / kGsThreads : 0u;
+        for (unsigned t = 0; t < trips; ++t) {
+            const unsigned i = tid + (backwards ? trips - 1u - t : t) * kGsThreads;
+            const float4 p = *gs_ev_point(evb, i), q = *gs_ev_match(evb, i);
+            const double *m = gs_ev_mahal(evb, i);
             double M[9];
 #pragma unroll
-            for (int c = 0; c < 9; ++c) M[c] = mahal[(size_t) c * n + i];
+            for (int c = 0; c < 9; ++c) M[c] = m[c * 64];
             if (!(q.x == q.x)) continue;  // (no match)
             gicp_fdf_point(hi, lo, A, p.x, p.y, p.z, q.x, q.y, q.z, M);
         }
@@ -305,7 +322,7 @@ struct GsFn {
                 A.T[k] = S->cmdT[k];
                 A.B[k] = (k % 5 == 0) ? 1.f : 0.f;
             }
-            share(A);
+            share(A, S->cmd == 2u);
             __syncthreads();  // (the rows are in)
         }
     }
@@ -329,10 +346,10 @@ struct GsFn {
         if (lane == 0) {
 #pragma unroll
             for (int k = 0; k < 12; ++k) S->cmdT[k] = T[k];
-            S->cmd = 1u;
+            S->cmd = 1u + ((unsigned) evals & 1u);
         }
         __syncthreads();
-        share(A);
+        share(A, (evals & 1) != 0);
         __syncthreads();
         double v = 0;
         if (lane < (unsigned) kGicpAcc) {
@@ -400,9 +417,8 @@ __device__ __attribute__((noinline)) void gs_correspondences(GsShared &S, uint2 
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = S.T[i];
     const float4 *s_pts = S.pr.s_pts;
-    float4 *match_pt = S.pr.match_pt;
+    unsigned char *evb = S.pr.evb;
     unsigned *match = S.pr.match;
-    double *mahal = S.pr.mahal;
     const double *c1 = S.pr.c1, *c2 = S.pr.c2;
     const unsigned char *tgt = S.pr.tgt;
     unsigned mine = 0;
@@ -421,7 +437,8 @@ __device__ __attribute__((noinline)) void gs_correspondences(GsShared &S, uint2 
         if (j != kNoIdx) {
             float x, y, z;
             (void) gs_load(tgt, j, stride, x, y, z);
-            match_pt[i] = make_float4(x, y, z, 0.f);
+            *gs_ev_point(evb, i) = p;
+            *gs_ev_match(evb, i) = make_float4(x, y, z, 0.f);
             double R[9];
 #pragma unroll
             for (int a = 0; a < 3; ++a)
@@ -430,10 +447,10 @@ __device__ __attribute__((noinline)) void gs_correspondences(GsShared &S, uint2 
             double o[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
             if (!(debug & 2)) gicp_mahal_of(c1 + (size_t) __float_as_uint(p.w) * 9, c2 + (size_t) j * 9, R, o);
 #pragma unroll
-            for (int a = 0; a < 9; ++a) mahal[(size_t) a * n_s + i] = o[a];
+            for (int a = 0; a < 9; ++a) gs_ev_mahal(evb, i)[a * 64] = o[a];
             ++mine;
         } else {
-            match_pt[i] = make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
+            *gs_ev_match(evb, i) = make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
         }
     }
 #pragma unroll
@@ -641,7 +658,7 @@ static int gicp_small_run(wm_ctx *ctx, const GsJob *jobs, int n, size_t stride, 
     size_t cloud_bytes = 0, work_bytes = 0;
     auto work_need = [](size_t ns, size_t nt) {
         return up256((ns + 4) * 16) + up256((nt + 4) * 16) + 3 * up256(((size_t) kGsCells + 8) * 4) + up256(ns * 72) + up256(nt * 72) +
-               up256(ns * 72) + up256(ns * 4) + up256(ns * 16);
+               up256(((ns + 63) / 64) * (size_t) kGsEvBlock) + up256(ns * 4);
     };
     for (int k = 0; k < n; ++k) {
         if (jobs[k].n_src == 0 || jobs[k].n_tgt == 0 || jobs[k].n_src > (size_t) WM_GICP_BATCH_MAX_POINTS ||
@@ -693,9 +710,8 @@ static int gicp_small_run(wm_ctx *ctx, const GsJob *jobs, int n, size_t stride, 
         t.run = reinterpret_cast<unsigned *>(take(((size_t) kGsCells + 8) * 4));
         t.c1 = reinterpret_cast<double *>(take(it.n_src * 72));
         t.c2 = reinterpret_cast<double *>(take(it.n_tgt * 72));
-        t.mahal = reinterpret_cast<double *>(take(it.n_src * 72));
+        t.evb = take(((it.n_src + 63) / 64) * (size_t) kGsEvBlock);
         t.match = reinterpret_cast<unsigned *>(take(it.n_src * 4));
-        t.match_pt = reinterpret_cast<float4 *>(take(it.n_src * 16));
     }
     if (off > sent) WM_HIP(ctx, hipMemcpyAsync(d + sent, h + sent, off - sent, hipMemcpyHostToDevice, ctx->stream));
     WM_HIP(ctx, hipMemcpyAsync(d, h, table_bytes, hipMemcpyHostToDevice, ctx->stream));
