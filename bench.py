@@ -412,6 +412,36 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu, copy_peak=None):
         e["cpu_baseline"] = {"seconds_per_registration": time.perf_counter() - t0, "cores": 1, "kind": "port",
                              "sample": "the oracle's match() (4 scales) + estimateLUMold on one of the pairs"}
     out.append(e)
+
+    # ---- GICPMatcher pairs the MultiMatcher way: a queue of them, 256 per launch, one compute unit each with the
+    # whole of align inside the kernel (csrc/wm_gicp_small.hip); full-resolution 20k-point clouds
+    n, B = 20_000, 256
+    base = [synth.pair(n, seed=300 + k, mode="resample")[:2] for k in range(8)]
+    host_pairs = [base[k % 8] for k in range(B)]
+    dev_clouds = [(torch.from_numpy(r).to(dev), torch.from_numpy(t).to(dev)) for r, t in base]
+    dev_pairs = [dev_clouds[k % 8] for k in range(B)]
+    ms_h, got = median_ms(lambda: ctx.gicp_batch_match(host_pairs), reps=3)
+    ms_d, got = median_ms(lambda: ctx.gicp_batch_match(dev_pairs), reps=3)
+    ms_one, one = median_ms(lambda: ctx.gicp_match(base[0][0], base[0][1]))
+    e = {"config": "GICPMatcher 20k<->20k, %d queued pairs per launch (k = 10 covariances, PCL's default stopping rules)" % B,
+         "pairs_per_launch": B, "registrations_per_s": B / (ms_h * 1e-3), "ms_per_batch": ms_h,
+         "registrations_per_s_device_resident_clouds": B / (ms_d * 1e-3), "kernel_ms_per_batch": got[0]["kernel_ms"],
+         "outer_iterations_first_items": [g["iterations"] for g in got[:8]],
+         "objective_evaluations_first_items": [g["evaluations"] for g in got[:8]],
+         "all_converged": all(g["rc"] == 0 for g in got),
+         "one_pair_at_a_time_ms": ms_one,
+         "first_item_equals_the_one_pair_path_bit_for_bit": bool(np.array_equal(got[0]["T"], one["T"])) and got[0]["evaluations"] == one["evaluations"],
+         "roofline": {"bound": "hbm", "kernel": "wm::k_gicp_small<10>: the evaluations of the objective stream 104 bytes per pair of points",
+                      "algorithmic_bytes_per_launch": float(sum(g["evaluations"] for g in got) * n * 104),
+                      "achieved": sum(g["evaluations"] for g in got) * n * 104 / (got[0]["kernel_ms"] * 1e-3) / 1e9,
+                      "peak": 8000.0, "unit": "GB/s",
+                      "frac": sum(g["evaluations"] for g in got) * n * 104 / (got[0]["kernel_ms"] * 1e-3) / 1e9 / 8000.0,
+                      "note": "whole-kernel time (grids, covariances, searches included) against the evaluations' bytes alone; half "
+                              "of them are served by the memory-side cache (every other evaluation walks its blocks backwards)"},
+         "note": "host clouds: 2 x 320 kB per pair cross PCIe inside the timed call (one worker thread; "
+                 "libwave_amd/host/bench_multimatcher with BENCH_MATCHER=gicp runs the C++ wave::MultiMatcher pool on top of this)"}
+    out.append(e)
+    del dev_clouds, dev_pairs
     ctx.close()
     prof.close()
     return out
