@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libwavematch_hip.so")
 
 WM_OK, WM_NOT_CONVERGED, WM_TOO_FEW = 0, 1, 2
 WM_ERR_ARG, WM_ERR_HIP, WM_ERR_RCCL, WM_ERR_STATE, WM_ERR_NOMEM = -1, -2, -3, -4, -5
+WM_GICP_BATCH_MAX_POINTS = 100000  # wm_gicp_batch_match: a cloud of a batched GICP registration at most (after the voxel filter)
 WM_BATCH_LDS_TARGET_POINTS = 10000  # wm_icp_batch_match: targets up to this size live in one CU's LDS,
 WM_BATCH_MAX_TARGET_POINTS = 65535  # larger ones (up to this) in HBM scratch
 WM_MEM_HOST, WM_MEM_DEVICE = 0, 1

@@ -134,3 +134,20 @@ def test_more_pairs_than_compute_units(wm, ctx):
     first = [ctx.gicp_match(r, t) for r, t, _ in base]
     for k, g in enumerate(got):
         _same(g, first[k % 3])
+
+
+def test_batch_argument_checks(wm, ctx):
+    ref, tgt, _ = synth.pair(600, seed=9, mode="resample")
+    with pytest.raises(wm.WmError):
+        ctx.gicp_batch_match([(ref, tgt)], corr_rand=0)
+    with pytest.raises(wm.WmError):
+        ctx.gicp_batch_match([(ref, tgt)], corr_rand=33)
+    with pytest.raises(wm.WmError):
+        ctx.gicp_batch_match([(ref, tgt)], max_corr=0.0)
+    # a cloud beyond the resident kernel's size is refused at full resolution ...
+    big = np.zeros((wm.WM_GICP_BATCH_MAX_POINTS + 1, 3), np.float32)
+    with pytest.raises(wm.WmError):
+        ctx.gicp_batch_match([(big, tgt)])
+    # ... and the context is still usable afterwards
+    got = ctx.gicp_batch_match([(ref, tgt)])
+    assert got[0]["rc"] in (wm.WM_OK, wm.WM_NOT_CONVERGED)
