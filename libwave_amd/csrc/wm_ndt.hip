@@ -21,6 +21,8 @@
 
 #include "wm_internal.hpp"
 #include "wm_sort.hpp"
+#include "wm_ndt_dev.hpp"
+#include "wm_ndt_ctl.hpp"
 
 #include <chrono>
 #include <float.h>
@@ -28,19 +30,9 @@
 
 namespace wm {
 
-constexpr unsigned kNdtChunkLog2 = 12;  // sharded NDT: ranks take turns in chunks of 4096 source points
-constexpr int kNdtAcc = 28;  // score, 6 gradient entries, the 21 of the Hessian's upper triangle
-constexpr int kNdtAccGrad = 7;  // score + gradient (the line search's passes)
-__host__ __device__ constexpr int ndt_tri(int i, int j) {  // (i <= j) -> accumulator slot
-    return 7 + i * 6 - i * (i - 1) / 2 + (j - i);
-}
 constexpr int kNdtBlocks = 4096;  // upper bound; ctx->tune_ndt_blocks workgroups per pass
 constexpr unsigned long long kEmptyKey = ~0ull;
 
-struct NdtVoxel {
-    double mean[3];
-    double icov[9];
-};
 
 __host__ __device__ inline unsigned long long ndt_key(int i, int j, int k) {
     return ((unsigned long long) (unsigned) (i + (1 << 20)) << 42) |
@@ -102,86 +94,6 @@ __global__ void __launch_bounds__(kBlock)
     flags[i] = (k != invalid && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
 }
 
-// symmetric 3x3 eigen-decomposition (cyclic Jacobi), eigenvalues ascending
-__device__ inline void sym_eig3(const double *Ain, double *evals, double *V) {
-    double A[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        A[i] = Ain[i];
-        V[i] = (i % 4 == 0) ? 1.0 : 0.0;
-    }
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
-        const double diag = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
-        if (off <= 1e-32 * diag || off == 0.0) break;
-#pragma unroll
-        for (int pr = 0; pr < 3; ++pr) {
-            const int p = pr == 2 ? 1 : 0, q = pr == 0 ? 1 : 2;
-            const double apq = A[p * 3 + q];
-            if (fabs(apq) < 1e-300) continue;
-            const double theta = (A[q * 3 + q] - A[p * 3 + p]) / (2.0 * apq);
-            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double akp = A[k * 3 + p], akq = A[k * 3 + q];
-                A[k * 3 + p] = c * akp - s * akq;
-                A[k * 3 + q] = s * akp + c * akq;
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double apk = A[p * 3 + k], aqk = A[q * 3 + k];
-                A[p * 3 + k] = c * apk - s * aqk;
-                A[q * 3 + k] = s * apk + c * aqk;
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double vkp = V[k * 3 + p], vkq = V[k * 3 + q];
-                V[k * 3 + p] = c * vkp - s * vkq;
-                V[k * 3 + q] = s * vkp + c * vkq;
-            }
-        }
-    }
-    evals[0] = A[0];
-    evals[1] = A[4];
-    evals[2] = A[8];
-    // ascending sort with column swaps (static indices)
-#define SWAPCOL(a, b)                                  \
-    if (evals[b] < evals[a]) {                         \
-        double t = evals[a];                           \
-        evals[a] = evals[b];                           \
-        evals[b] = t;                                  \
-        _Pragma("unroll") for (int k = 0; k < 3; ++k) { \
-            t = V[k * 3 + a];                          \
-            V[k * 3 + a] = V[k * 3 + b];               \
-            V[k * 3 + b] = t;                          \
-        }                                              \
-    }
-    SWAPCOL(0, 1)
-    SWAPCOL(0, 2)
-    SWAPCOL(1, 2)
-#undef SWAPCOL
-}
-
-__device__ inline bool inverse3(const double *m, double *o) {
-    const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8],
-                 c02 = m[3] * m[7] - m[4] * m[6];
-    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
-    const double id = 1.0 / det;
-    o[0] = c00 * id;
-    o[1] = (m[2] * m[7] - m[1] * m[8]) * id;
-    o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
-    o[3] = c01 * id;
-    o[4] = (m[0] * m[8] - m[2] * m[6]) * id;
-    o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
-    o[6] = c02 * id;
-    o[7] = (m[1] * m[6] - m[0] * m[7]) * id;
-    o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) ok = ok && isfinite(o[k]);
-    return ok;
-}
 
 // heads[slot] = first sorted position of voxel `slot`; heads[n_voxels] = one past the last
 // finite point (seg[n] = n_voxels, the scan's total)
@@ -370,11 +282,6 @@ __global__ void __launch_bounds__(kBlock)
 // Dense alternative to the hash grid when the voxel lattice over the target's bounding box is
 // small (a few million cells): cell (i, j, k) -> voxel slot, -1 = empty / invalid.  A neighbour
 // look-up is then ONE 4-byte load instead of a hash and a probe sequence.
-struct NdtDense {
-    const int *table;  // nullptr: use the hash grid
-    int i0, j0, k0;    // lattice origin (cell indices)
-    int nx, ny, nz;
-};
 
 __global__ void __launch_bounds__(kBlock)
     k_ndt_dense_fill(const unsigned long long *__restrict__ vkey, unsigned nvox, NdtDense d, int *table) {
@@ -391,19 +298,6 @@ __global__ void __launch_bounds__(kBlock)
     table[((size_t) c * d.ny + b) * d.nx + a] = (int) s;
 }
 
-struct __attribute__((packed, aligned(4))) Int3 {  // three adjacent table cells, one 12-byte load
-    int a, b, c;
-};
-
-struct NdtArgs {
-    float Tf[12];
-    float inv_res;
-    double res2, d1, d2;
-    float res2_f;  // the largest float d2 with (double) d2 < res2: the radius test in one float compare, same decisions
-    // computeAngleDerivatives: 8 Jacobian and 15 Hessian 3-vectors
-    double j[8][3];
-    double h[15][3];
-};
 
 __device__ __forceinline__ double dot3d(const double *a, const double *b) {
 #pragma clang fp contract(fast)  // (used by k_ndt_derivs only: see there)
@@ -830,59 +724,6 @@ static int ndt_build(wm_ctx *ctx, double res) {
     return WM_OK;
 }
 
-static void pose_to_matrix_f(const double p[6], float T[16]) {
-    const float cx = cosf((float) p[3]), sx = sinf((float) p[3]);
-    const float cy = cosf((float) p[4]), sy = sinf((float) p[4]);
-    const float cz = cosf((float) p[5]), sz = sinf((float) p[5]);
-    T[0] = cy * cz;
-    T[1] = -cy * sz;
-    T[2] = sy;
-    T[4] = cx * sz + sx * sy * cz;
-    T[5] = cx * cz - sx * sy * sz;
-    T[6] = -sx * cy;
-    T[8] = sx * sz - cx * sy * cz;
-    T[9] = sx * cz + cx * sy * sz;
-    T[10] = cx * cy;
-    T[3] = (float) p[0];
-    T[7] = (float) p[1];
-    T[11] = (float) p[2];
-    T[12] = T[13] = T[14] = 0;
-    T[15] = 1;
-}
-
-static void angle_derivatives(const double p[6], int pcl_d1_sign, NdtArgs *A) {
-    double cx, cy, cz, sx, sy, sz;
-    if (fabs(p[3]) < 10e-5) { cx = 1.0; sx = 0.0; } else { cx = cos(p[3]); sx = sin(p[3]); }
-    if (fabs(p[4]) < 10e-5) { cy = 1.0; sy = 0.0; } else { cy = cos(p[4]); sy = sin(p[4]); }
-    if (fabs(p[5]) < 10e-5) { cz = 1.0; sz = 0.0; } else { cz = cos(p[5]); sz = sin(p[5]); }
-    const double j[8][3] = {
-        {-sx * sz + cx * sy * cz, -sx * cz - cx * sy * sz, -cx * cy},  // a
-        {cx * sz + sx * sy * cz, cx * cz - sx * sy * sz, -sx * cy},    // b
-        {-sy * cz, sy * sz, cy},                                       // c
-        {sx * cy * cz, -sx * cy * sz, sx * sy},                        // d
-        {-cx * cy * cz, cx * cy * sz, -cx * sy},                       // e
-        {-cy * sz, -cy * cz, 0},                                       // f
-        {cx * cz - sx * sy * sz, -cx * sz - sx * sy * cz, 0},          // g
-        {sx * cz + cx * sy * sz, cx * sy * cz - sx * sz, 0}};          // h
-    const double h[15][3] = {
-        {-cx * sz - sx * sy * cz, -cx * cz + sx * sy * sz, sx * cy},   // a2
-        {-sx * sz + cx * sy * cz, -cx * sy * sz - sx * cz, -cx * cy},  // a3
-        {cx * cy * cz, -cx * cy * sz, cx * sy},                        // b2
-        {sx * cy * cz, -sx * cy * sz, sx * sy},                        // b3
-        {-sx * cz - cx * sy * sz, sx * sz - cx * sy * cz, 0},          // c2
-        {cx * cz - sx * sy * sz, -sx * sy * cz - cx * sz, 0},          // c3
-        {-cy * cz, cy * sz, pcl_d1_sign ? sy : -sy},                   // d1
-        {-sx * sy * cz, sx * sy * sz, sx * cy},                        // d2
-        {cx * sy * cz, -cx * sy * sz, -cx * cy},                       // d3
-        {sy * sz, sy * cz, 0},                                         // e1
-        {-sx * cy * sz, -sx * cy * cz, 0},                             // e2
-        {cx * cy * sz, cx * cy * cz, 0},                               // e3
-        {-cy * cz, cy * sz, 0},                                        // f1
-        {-cx * sz - sx * sy * cz, -cx * cz + sx * sy * sz, 0},         // f2
-        {-sx * sz + cx * sy * cz, -cx * sy * sz - sx * cz, 0}};        // f3
-    memcpy(A->j, j, sizeof(j));
-    memcpy(A->h, h, sizeof(h));
-}
 
 struct NdtEval {
     wm_ctx *ctx;
@@ -892,6 +733,13 @@ struct NdtEval {
     float kernel_ms = 0;
     double host_launch_us = 0, host_wait_us = 0;  // WM_NDT_PROFILE=2: wall time inside the launch calls / the wait
     int ls_hist[12] = {0};  // line searches by their number of extra trials (developer: WM_TRACE)
+    int rc = WM_OK;
+    // (what ndt_align_loop / step_length_mt ask of an objective, wm_ndt_ctl.hpp)
+    double eval(const double p[6], double *grad, double *hess);
+    bool failed() const { return rc != WM_OK; }
+    bool skip_line_search() const { return prm->skip_line_search != 0; }
+    bool spec_hessian() const { return ctx->tune_ndt_spec_hessian != 0; }
+    void note_line_search(int trials) { ls_hist[trials < 11 ? trials : 11]++; }
 };
 
 // score (+ gradient, + Hessian) at pose p; returns <0 on HIP error via *rc
@@ -1003,169 +851,8 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
     return a[0];
 }
 
-// One-sided Jacobi SVD solve x = V S^+ U^T b for a 6x6 system (Eigen JacobiSVD::solve)
-static void svd_solve6(const double *A, const double *b, double *x) {
-    constexpr int N = 6;
-    double W[N * N], V[N * N];
-    memcpy(W, A, sizeof(W));
-    for (int i = 0; i < N; ++i)
-        for (int j = 0; j < N; ++j) V[i * N + j] = (i == j);
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        bool rotated = false;
-        for (int i = 0; i < N - 1; ++i)
-            for (int j = i + 1; j < N; ++j) {
-                double alpha = 0, beta = 0, gamma = 0;
-                for (int k = 0; k < N; ++k) {
-                    alpha += W[k * N + i] * W[k * N + i];
-                    beta += W[k * N + j] * W[k * N + j];
-                    gamma += W[k * N + i] * W[k * N + j];
-                }
-                if (fabs(gamma) <= 1e-300 || fabs(gamma) <= 2.3e-16 * sqrt(alpha * beta)) continue;
-                rotated = true;
-                const double zeta = (beta - alpha) / (2.0 * gamma);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-                for (int k = 0; k < N; ++k) {
-                    const double wi = W[k * N + i], wj = W[k * N + j];
-                    W[k * N + i] = c * wi - s * wj;
-                    W[k * N + j] = s * wi + c * wj;
-                    const double vi = V[k * N + i], vj = V[k * N + j];
-                    V[k * N + i] = c * vi - s * vj;
-                    V[k * N + j] = s * vi + c * vj;
-                }
-            }
-        if (!rotated) break;
-    }
-    double sv[N], smax = 0;
-    for (int j = 0; j < N; ++j) {
-        double s2 = 0;
-        for (int k = 0; k < N; ++k) s2 += W[k * N + j] * W[k * N + j];
-        sv[j] = sqrt(s2);
-        if (sv[j] > smax) smax = sv[j];
-    }
-    const double thr = smax * N * 2.220446049250313e-16;
-    double y[N];
-    for (int j = 0; j < N; ++j) {
-        double s = 0;
-        for (int k = 0; k < N; ++k) s += W[k * N + j] * b[k];  // (U S)_j . b
-        y[j] = (sv[j] > thr) ? s / (sv[j] * sv[j]) : 0.0;      // U_j . b / S_j
-    }
-    for (int i = 0; i < N; ++i) {
-        double s = 0;
-        for (int j = 0; j < N; ++j) s += V[i * N + j] * y[j];
-        x[i] = s;
-    }
-}
+double NdtEval::eval(const double p[6], double *grad, double *hess) { return ndt_eval(*this, p, grad, hess, &rc); }
 
-static double psi_mt(double a, double f_a, double f_0, double g_0, double mu) { return f_a - f_0 - mu * g_0 * a; }
-static double dpsi_mt(double g_a, double g_0, double mu) { return g_a - mu * g_0; }
-
-static bool update_interval_mt(double &a_l, double &f_l, double &g_l, double &a_u, double &f_u,
-                               double &g_u, double a_t, double f_t, double g_t) {
-    if (f_t > f_l) {
-        a_u = a_t; f_u = f_t; g_u = g_t;
-        return false;
-    } else if (g_t * (a_l - a_t) > 0) {
-        a_l = a_t; f_l = f_t; g_l = g_t;
-        return false;
-    } else if (g_t * (a_l - a_t) < 0) {
-        a_u = a_l; f_u = f_l; g_u = g_l;
-        a_l = a_t; f_l = f_t; g_l = g_t;
-        return false;
-    }
-    return true;
-}
-
-static double trial_value_mt(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u,
-                             double a_t, double f_t, double g_t) {
-    if (f_t > f_l) {
-        const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = sqrt(z * z - g_t * g_l);
-        const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
-        const double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
-        return fabs(a_c - a_l) < fabs(a_q - a_l) ? a_c : 0.5 * (a_q + a_c);
-    } else if (g_t * g_l < 0) {
-        const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = sqrt(z * z - g_t * g_l);
-        const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
-        const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
-        return fabs(a_c - a_t) >= fabs(a_s - a_t) ? a_c : a_s;
-    } else if (fabs(g_t) <= fabs(g_l)) {
-        const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = sqrt(z * z - g_t * g_l);
-        const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
-        const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
-        const double a_n = fabs(a_c - a_t) < fabs(a_s - a_t) ? a_c : a_s;
-        return a_t > a_l ? fmin(a_t + 0.66 * (a_u - a_t), a_n) : fmax(a_t + 0.66 * (a_u - a_t), a_n);
-    }
-    const double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u, w = sqrt(z * z - g_t * g_u);
-    return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
-}
-
-static double step_length_mt(NdtEval &E, const double x[6], double dir[6], double step_init,
-                             double step_max, double step_min, double *score, double grad[6],
-                             double hess[36], int *rc) {
-    const double phi_0 = -(*score), mu = 1.e-4, nu = 0.9;
-    double d_phi_0 = 0, x_t[6];
-    for (int a = 0; a < 6; ++a) d_phi_0 -= grad[a] * dir[a];
-    if (d_phi_0 >= 0) {
-        if (d_phi_0 == 0) return 0;
-        d_phi_0 *= -1;
-        for (int a = 0; a < 6; ++a) dir[a] *= -1;
-    }
-    const int max_step_iterations = 10;
-    int step_iterations = 0;
-    bool hess_at_xt = false;  // `hess` already holds the Hessian at the last trial point
-    double a_l = 0, a_u = 0;
-    double f_l = psi_mt(a_l, phi_0, phi_0, d_phi_0, mu), g_l = dpsi_mt(d_phi_0, d_phi_0, mu);
-    double f_u = psi_mt(a_u, phi_0, phi_0, d_phi_0, mu), g_u = dpsi_mt(d_phi_0, d_phi_0, mu);
-    bool interval_converged = E.prm->skip_line_search ? ((step_max - step_min) > 0) : ((step_max - step_min) < 0);
-    bool open_interval = true;
-    double a_t = fmax(fmin(step_init, step_max), step_min);
-    for (int a = 0; a < 6; ++a) x_t[a] = x[a] + dir[a] * a_t;
-    *score = ndt_eval(E, x_t, grad, hess, rc);
-    if (*rc != WM_OK) return 0;
-    double phi_t = -(*score), d_phi_t = 0;
-    for (int a = 0; a < 6; ++a) d_phi_t -= grad[a] * dir[a];
-    double psi_t = psi_mt(a_t, phi_t, phi_0, d_phi_0, mu), d_psi_t = dpsi_mt(d_phi_t, d_phi_0, mu);
-    while (!interval_converged && step_iterations < max_step_iterations &&
-           !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
-        a_t = open_interval ? trial_value_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t)
-                            : trial_value_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
-        a_t = fmax(fmin(a_t, step_max), step_min);
-        for (int a = 0; a < 6; ++a) x_t[a] = x[a] + dir[a] * a_t;
-        // PCL evaluates score + gradient here and, once the search has ended, the Hessian at the accepted
-        // point in a pass of its own (computeHessian).  Nearly every search that gets here ends with THIS
-        // trial, and a pass that forms the Hessian costs the same with or without the gradient (150 vs
-        // 153 us at 2M points, against 81 us for the gradient alone): so the Hessian is formed along with
-        // the FIRST extra trial, and the separate pass (+ its round trip) is dropped when that trial is
-        // accepted.  Same sums over the same terms as computeHessian's; a rejected trial wastes 72 us, and
-        // a search that rejects its first extra trial usually goes on for many (on the bench pair: 13
-        // searches without an extra trial, 9 with one, 1 with ten), so later trials are not speculated on.
-        const bool spec = E.ctx->tune_ndt_spec_hessian != 0 && step_iterations == 0;
-        *score = ndt_eval(E, x_t, grad, spec ? hess : nullptr, rc);
-        hess_at_xt = spec;
-        if (*rc != WM_OK) return 0;
-        phi_t = -(*score);
-        d_phi_t = 0;
-        for (int a = 0; a < 6; ++a) d_phi_t -= grad[a] * dir[a];
-        psi_t = psi_mt(a_t, phi_t, phi_0, d_phi_0, mu);
-        d_psi_t = dpsi_mt(d_phi_t, d_phi_0, mu);
-        if (open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
-            open_interval = false;
-            f_l = f_l + phi_0 - mu * d_phi_0 * a_l;
-            g_l = g_l + mu * d_phi_0;
-            f_u = f_u + phi_0 - mu * d_phi_0 * a_u;
-            g_u = g_u + mu * d_phi_0;
-        }
-        interval_converged = open_interval
-                                 ? update_interval_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t)
-                                 : update_interval_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
-        ++step_iterations;
-    }
-    E.ls_hist[step_iterations < 11 ? step_iterations : 11]++;
-    if (step_iterations && !hess_at_xt) {  // computeHessian at the accepted point
-        (void) ndt_eval(E, x_t, nullptr, hess, rc);
-    }
-    return a_t;
-}
 
 }  // namespace wm
 
@@ -1238,34 +925,13 @@ int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *prm, double T_out[16], wm_ndt
         E.d1 = -log(c1 + c2) - d3;
         E.d2 = -2.0 * log((-log(c1 * exp(-0.5) + c2) - d3) / E.d1);
     }
-    double p[6] = {0, 0, 0, 0, 0, 0}, grad[6], hess[36], delta[6];
-    int rc = WM_OK, iter = 0;
-    bool converged = false;
-    const int max_it = prm->force_iterations > 0 ? prm->force_iterations : prm->max_iter;
-    double score = ndt_eval(E, p, grad, hess, &rc);
-    if (rc != WM_OK) return rc;
-    while (!converged) {
-        double neg[6], norm = 0;
-        for (int a = 0; a < 6; ++a) neg[a] = -grad[a];
-        svd_solve6(hess, neg, delta);
-        for (int a = 0; a < 6; ++a) norm += delta[a] * delta[a];
-        norm = sqrt(norm);
-        if (norm == 0 || norm != norm) {
-            converged = (norm == norm);
-            break;
-        }
-        for (int a = 0; a < 6; ++a) delta[a] /= norm;
-        const double alpha = step_length_mt(E, p, delta, norm, prm->step_size, prm->t_eps / 2, &score,
-                                            grad, hess, &rc);
-        if (rc != WM_OK) return rc;
-        for (int a = 0; a < 6; ++a) p[a] += delta[a] * alpha;
-        if (prm->force_iterations > 0) {
-            if (iter + 1 >= max_it) converged = true;
-        } else if (iter > max_it || (iter && fabs(alpha) < prm->t_eps)) {
-            converged = true;
-        }
-        ++iter;
-    }
+    NdtLoopOut lo;
+    ndt_align_loop(E, prm->step_size, prm->t_eps, prm->max_iter, prm->force_iterations, &lo);
+    if (E.rc != WM_OK) return E.rc;
+    const double *p = lo.p;
+    const double score = lo.score;
+    const int iter = lo.iterations;
+    const bool converged = lo.converged;
     if (stats) {
         stats->converged = converged;
         stats->iterations = iter;
