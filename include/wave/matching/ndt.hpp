@@ -15,6 +15,9 @@
 
 #include <string>
 
+#include <utility>
+#include <vector>
+
 #include "wave/matching/matcher.hpp"
 #include "wave/matching/pcl_common.hpp"
 
@@ -48,6 +51,20 @@ class NDTMatcher : public Matcher<PCLPointCloudPtr> {
     void setRef(const PCLPointCloudPtr &ref);
     void setTarget(const PCLPointCloudPtr &target);
     bool match();  // blocks; true when the Newton iteration converged
+
+    // Many pairs in ONE device launch (wm_ndt_batch_match: one registration per compute unit, the target's voxel
+    // model and the whole of align inside the kernel) -- what wave::MultiMatcher<NDTMatcher> hands its workers when
+    // several pairs are queued.  out[k] = {match() result, getResult(), getInfo()} as the worker loop would have read
+    // them after pair k; a failed match leaves the transform of the pair before it.
+    struct BatchOutcome {
+        EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+        bool matched;
+        Eigen::Affine3d transform;
+        Mat6 info;
+    };
+    typedef std::vector<BatchOutcome, Eigen::aligned_allocator<BatchOutcome>> BatchOutcomes;
+    bool batchable(const PCLPointCloudPtr &ref, const PCLPointCloudPtr &target) const;  // clouds of at most 200 000 points
+    bool matchBatch(const std::vector<std::pair<PCLPointCloudPtr, PCLPointCloudPtr>> &pairs, BatchOutcomes &out);
 
     // PCL 1.8's NDT initialises its More-Thuente loop flag so that the loop body never runs (the step
     // is Newton's, its norm clamped to step_size); later PCL releases run the search.  The reference

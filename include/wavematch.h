@@ -403,6 +403,18 @@ int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *p, double T_out[16], wm_ndt_s
  * (wave_matching/src/ndt.cpp:55): the model of the current target at resolution `res`, now; later
  * wm_ndt_align calls with the same target and res reuse it. */
 int wm_ndt_build_model(wm_ctx *ctx, double res);
+/* NDTMatcher::setRef + setTarget + match (wave_matching/src/ndt.cpp:48-65) for MANY pairs in one launch -- what a
+ * wave::MultiMatcher<NDTMatcher> has waiting in its queue (multi_matcher.hpp:29-34): one registration per compute unit,
+ * the target's voxel model (pcl::VoxelGridCovariance), the Newton steps and the More-Thuente line search all inside the
+ * kernel.  Clouds of at most WM_NDT_BATCH_MAX_POINTS points (beyond: WM_ERR_ARG); a pair whose voxel lattice does not
+ * fit the kernel's table (262 144 cells) is registered by wm_ndt_align.
+ * Per item k: status[k] as wm_ndt_align would return it (WM_OK / WM_NOT_CONVERGED; WM_ERR_STATE for an empty cloud),
+ * T_out + 16 k written when WM_OK, stats[k] (may be NULL).  Same voxel membership, radius tests and terms as
+ * wm_ndt_align; a voxel's sums are formed in double-double instead of in point order and exp / log / sin / cos are the
+ * device library's: results agree with the one-pair path to ~1e-9, not bit for bit. */
+#define WM_NDT_BATCH_MAX_POINTS 200000
+int wm_ndt_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, size_t stride_bytes, int mem,
+                       const wm_ndt_params *p, double *T_out, wm_ndt_stats *stats, int *status, float *kernel_ms);
 /* computeDerivatives at pose (tx,ty,tz,rx,ry,rz): score, gradient(6), Hessian(36) */
 int wm_ndt_derivatives(wm_ctx *ctx, const wm_ndt_params *p, const double pose[6], double *score,
                        double grad[6], double hess[36], int *n_voxels);

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libwavematch_hip.so")
 
 WM_OK, WM_NOT_CONVERGED, WM_TOO_FEW = 0, 1, 2
 WM_ERR_ARG, WM_ERR_HIP, WM_ERR_RCCL, WM_ERR_STATE, WM_ERR_NOMEM = -1, -2, -3, -4, -5
+WM_NDT_BATCH_MAX_POINTS = 200000  # wm_ndt_batch_match: a cloud of a batched NDT registration at most
 WM_GICP_BATCH_MAX_POINTS = 100000  # wm_gicp_batch_match: a cloud of a batched GICP registration at most (after the voxel filter)
 WM_BATCH_LDS_TARGET_POINTS = 10000  # wm_icp_batch_match: targets up to this size live in one CU's LDS,
 WM_BATCH_MAX_TARGET_POINTS = 65535  # larger ones (up to this) in HBM scratch
@@ -127,6 +128,9 @@ def lib():
         L.wm_gicp_batch_match.argtypes = [C.c_void_p, C.POINTER(BatchItem), C.c_int, C.c_size_t, C.c_int,
                                           C.POINTER(GicpParams), C.c_float, _dp, C.POINTER(GicpStats),
                                           C.POINTER(C.c_int), C.POINTER(C.c_float)]
+        L.wm_ndt_batch_match.argtypes = [C.c_void_p, C.POINTER(BatchItem), C.c_int, C.c_size_t, C.c_int,
+                                         C.POINTER(NdtParams), _dp, C.POINTER(NdtStats), C.POINTER(C.c_int),
+                                         C.POINTER(C.c_float)]
         L.wm_voxel_downsample_batch.argtypes = [C.c_void_p, C.POINTER(BatchItem), C.c_int, C.c_size_t, C.c_int,
                                                 C.c_float, _fp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.wm_voxel_downsample.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
@@ -553,6 +557,35 @@ class Context:
         return dict(rc=rc, T=T if rc == WM_OK else None, converged=bool(s.converged),
                     iterations=s.iterations, n_voxels=s.n_voxels, evaluations=s.evaluations,
                     score=s.score, deriv_kernel_ms=s.deriv_kernel_ms, model_builds=s.model_builds)
+
+    def ndt_batch_match(self, pairs, params=None, **kw):
+        """NDTMatcher::match() of every pair in one launch (wm_ndt_batch_match), one registration per compute unit.
+        pairs: [(ref, target), ...] -> list of dicts as ndt_align's (+ 'kernel_ms' of the launch)."""
+        p = params or ndt_params(**kw)
+        n = len(pairs)
+        items = (BatchItem * max(n, 1))()
+        keep = []
+        stride = mem = None
+        for k, (ref, tgt) in enumerate(pairs):
+            pr, nr, sr, mr, k1 = _cloud_arg(ref)
+            pt, nt, stt, mt, k2 = _cloud_arg(tgt)
+            assert sr == stt and mr == mt and (stride in (None, sr)) and (mem in (None, mr))
+            stride, mem = sr, mr
+            keep += [k1, k2]
+            items[k].src, items[k].n_src, items[k].target, items[k].n_target = pr, nr, pt, nt
+        T = np.zeros((max(n, 1), 4, 4), np.float64)
+        stats = (NdtStats * max(n, 1))()
+        status = (C.c_int * max(n, 1))()
+        ms = C.c_float(0)
+        self._check(lib().wm_ndt_batch_match(self._h, items, n, stride or 16, mem or WM_MEM_HOST, C.byref(p),
+                                             T.ctypes.data_as(_dp), stats, status, C.byref(ms)), "wm_ndt_batch_match")
+        out = []
+        for k in range(n):
+            s = stats[k]
+            out.append(dict(rc=status[k], T=T[k].copy() if status[k] == WM_OK else None, converged=bool(s.converged),
+                            iterations=s.iterations, n_voxels=s.n_voxels, evaluations=s.evaluations, score=s.score,
+                            model_builds=s.model_builds, kernel_ms=ms.value))
+        return out
 
     def ndt_derivatives(self, pose, params=None, **kw):
         p = params or ndt_params(**kw)

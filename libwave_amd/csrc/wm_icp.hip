@@ -904,6 +904,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
     for (DevBuf *b : bufs) b->release();
     small_batch_release(ctx);
     gicp_small_release(ctx);
+    ndt_small_release(ctx);
     batch_voxel_release(ctx);
     for (auto &l : ctx->levels) {
         l.pts.release();

@@ -181,6 +181,7 @@ struct wm_ctx {
     wm::DevBuf match_pt, match_pt_bak;  // float4 per (sorted) source point: its match's xyz
     void *small_batch = nullptr;            // wm_small.hip: staging of the batched small registrations
     void *gicp_small_batch = nullptr;       // wm_gicp_small.hip: ... of the batched small GICP registrations
+    void *ndt_small_batch = nullptr;        // wm_ndt_small.hip: ... of the batched small NDT registrations
     void *batch_voxel = nullptr;            // wm_batch.hip: buffers of the batched voxel filter
     wm::DevBuf phase_log;                   // developer: per-iteration phase cycle sums of the search kernel
     wm::DevBuf cost_log;                    // developer: per-query search cost of every iteration (wm_debug_cost_log)
@@ -403,7 +404,8 @@ int launch_fix_keys(wm_ctx *ctx, float thr_d2);  // after certified iterations: 
 int launch_nn_cert(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2, int stats_mode,
                    unsigned *rows_out, bool bounds_valid);
 void small_batch_release(wm_ctx *ctx);
-void gicp_small_release(wm_ctx *ctx);  // wm_gicp_small.hip: the staging of the batched small GICP registrations
+void gicp_small_release(wm_ctx *ctx);
+void ndt_small_release(wm_ctx *ctx);   // wm_ndt_small.hip: ... of the batched small NDT registrations  // wm_gicp_small.hip: the staging of the batched small GICP registrations
 // wm_batch.hip: pcl::VoxelGrid of all the clouds of a batch in one pass (see there)
 int batch_voxel_filter(wm_ctx *ctx, const wm_batch_item *items, const std::vector<int> &idx, size_t stride, int mem, float leaf,
                        const float4 **filtered, std::vector<unsigned> &off, std::vector<unsigned> &n_out);

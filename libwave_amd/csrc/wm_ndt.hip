@@ -114,44 +114,8 @@ __device__ inline void ndt_voxel_finish(unsigned slot, unsigned long long cell, 
                                         NdtVoxel *__restrict__ vox,
                                         float4 *__restrict__ meanf, unsigned long long *__restrict__ vkey,
                                         unsigned *__restrict__ n_valid) {
-    const double nn = (double) count;
     NdtVoxel v;
-    bool valid = false;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) v.mean[a] = s[a] / nn;
-    if (count >= 6) {  // min_points_per_voxel_
-        double cov[9], evals[3], evecs[9];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b)
-                cov[a * 3 + b] = ((pp[a * 3 + b] - 2.0 * (s[a] * v.mean[b])) / nn + v.mean[a] * v.mean[b]) *
-                                 ((nn - 1.0) / nn);
-        sym_eig3(cov, evals, evecs);
-        if (!(evals[0] < 0 || evals[1] < 0 || evals[2] <= 0)) {
-            const double minv = 0.01 * evals[2];
-            if (evals[0] < minv) {
-                evals[0] = minv;
-                if (evals[1] < minv) evals[1] = minv;
-                double einv[9], t[9];
-                inverse3(evecs, einv);
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) t[a * 3 + b] = evecs[a * 3 + b] * evals[b];
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) {
-                        double acc = 0;
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) acc += t[a * 3 + k] * einv[k * 3 + b];
-                        cov[a * 3 + b] = acc;
-                    }
-            }
-            valid = inverse3(cov, v.icov);
-        }
-    }
+    const bool valid = ndt_voxel_record(count, s, pp, v);
     vox[slot] = v;
     // the radius test of the derivative passes runs on float means (PCL's kd-tree of centroids)
     meanf[slot] = make_float4((float) v.mean[0], (float) v.mean[1], (float) v.mean[2], 0.0f);

@@ -104,6 +104,50 @@ __device__ inline bool inverse3(const double *m, double *o) {
     return ok;
 }
 
+// mean, covariance, PCL's eigenvalue conditioning and the inverse of one voxel from its sums (s = sum p, pp = sum p p^T
+// over `count` points); false: the voxel takes no part (fewer than min_points_per_voxel_ = 6 points, or a covariance that
+// cannot be conditioned)
+__device__ inline bool ndt_voxel_record(unsigned count, const double *s, const double *pp, NdtVoxel &v) {
+    const double nn = (double) count;
+    bool valid = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) v.mean[a] = s[a] / nn;
+    if (count >= 6) {  // min_points_per_voxel_
+        double cov[9], evals[3], evecs[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                cov[a * 3 + b] = ((pp[a * 3 + b] - 2.0 * (s[a] * v.mean[b])) / nn + v.mean[a] * v.mean[b]) *
+                                 ((nn - 1.0) / nn);
+        sym_eig3(cov, evals, evecs);
+        if (!(evals[0] < 0 || evals[1] < 0 || evals[2] <= 0)) {
+            const double minv = 0.01 * evals[2];
+            if (evals[0] < minv) {
+                evals[0] = minv;
+                if (evals[1] < minv) evals[1] = minv;
+                double einv[9], t[9];
+                inverse3(evecs, einv);
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) t[a * 3 + b] = evecs[a * 3 + b] * evals[b];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        double acc = 0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) acc += t[a * 3 + k] * einv[k * 3 + b];
+                        cov[a * 3 + b] = acc;
+                    }
+            }
+            valid = inverse3(cov, v.icov);
+        }
+    }
+    return valid;
+}
+
 struct NdtDense {
     const int *table;  // nullptr: use the hash grid
     int i0, j0, k0;    // lattice origin (cell indices)

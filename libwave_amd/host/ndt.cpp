@@ -101,4 +101,47 @@ bool NDTMatcher::match() {
     return true;
 }
 
+bool NDTMatcher::batchable(const PCLPointCloudPtr &r, const PCLPointCloudPtr &t) const {
+    return r && t && cloudSize(r) <= (size_t) WM_NDT_BATCH_MAX_POINTS && cloudSize(t) <= (size_t) WM_NDT_BATCH_MAX_POINTS;
+}
+
+bool NDTMatcher::matchBatch(const std::vector<std::pair<PCLPointCloudPtr, PCLPointCloudPtr>> &pairs, BatchOutcomes &out) {
+    out.clear();
+    if (pairs.empty()) return true;
+    for (const auto &pr : pairs)
+        if (!batchable(pr.first, pr.second)) return false;
+    if (!ensureContext()) return false;
+    wm_ndt_params p;
+    wm_ndt_default_params(&p);
+    p.res = params.res;  // as match() sets them (ndt.cpp:30-33)
+    p.step_size = params.step_size;
+    p.t_eps = params.t_eps;
+    p.max_iter = params.max_iter;
+    p.skip_line_search = pcl18_step_rule ? 1 : 0;
+    const size_t n = pairs.size();
+    std::vector<wm_batch_item> items(n);
+    for (size_t k = 0; k < n; ++k) {
+        items[k].src = cloudData(pairs[k].first);
+        items[k].n_src = cloudSize(pairs[k].first);
+        items[k].target = cloudData(pairs[k].second);
+        items[k].n_target = cloudSize(pairs[k].second);
+    }
+    std::vector<double> T(16 * n);
+    std::vector<int> status(n, WM_ERR_STATE);
+    const int rc = wm_ndt_batch_match(ctx, items.data(), (int) n, kCloudStride, WM_MEM_HOST, &p, T.data(), nullptr, status.data(), nullptr);
+    if (!shim::succeeded(rc, "wm_ndt_batch_match", ctx)) return false;
+    out.resize(n);
+    for (size_t k = 0; k < n; ++k) {
+        ref = pairs[k].first;
+        target = pairs[k].second;
+        const bool ok = status[k] == WM_OK;
+        if (ok) shim::toAffine(&T[16 * k], result);  // anything else leaves `result` as it was (ndt.cpp:59-63)
+        out[k].matched = ok;
+        out[k].transform = result;
+        out[k].info = information;
+    }
+    target_on_device = false;  // (the context holds no model of the last pair's target)
+    return true;
+}
+
 }  // namespace wave
