@@ -569,6 +569,55 @@ AddCase c_gicp_pool("MultiTest.gicpPairsGoThroughTheBatchedPath", [] {
     EXPECT(seen.size() == 24u);
 });
 
+// The batched path of NDTMatcher (matchBatch, wm_ndt_batch_match: one registration per compute unit, voxel model and
+// align in the kernel) -- directly and under the pool at the reference's default queue of ten.
+AddCase c_ndt_batch("NDTTest.matchBatchEqualsOneByOne", [] {
+    const auto scan = loadScan();
+    wave::NDTMatcherParams p;
+    p.res = 2.0f;
+    std::vector<std::pair<wave::PCLPointCloudPtr, wave::PCLPointCloudPtr>> pairs;
+    for (int k = 0; k < 4; ++k) pairs.emplace_back(subsample(scan, 3 + k, 0.f), subsample(scan, 2 + k, 0.05f * (float) k));
+    pairs.emplace_back(subsample(scan, 5, 0.f), subsample(scan, 4, 0.1f));
+    wave::NDTMatcher batch(p);
+    for (const auto &pr : pairs) EXPECT(batch.batchable(pr.first, pr.second));
+    wave::NDTMatcher::BatchOutcomes got;
+    EXPECT(batch.matchBatch(pairs, got));
+    EXPECT(got.size() == pairs.size());
+    for (size_t k = 0; k < pairs.size() && k < got.size(); ++k) {
+        wave::NDTMatcher one(p);
+        one.setup(pairs[k].first, pairs[k].second);
+        const bool ok = one.match();
+        EXPECT(ok == got[k].matched);
+        if (ok) EXPECT(distanceTo(one.getResult(), got[k].transform) < 1e-6);
+    }
+});
+
+AddCase c_ndt_pool("MultiTest.ndtPairsGoThroughTheBatchedPath", [] {
+    wave::NDTMatcherParams p;
+    p.res = 2.0f;
+    wave::MultiMatcher<wave::NDTMatcher, wave::NDTMatcherParams> pool(4, 10, p);
+    const auto scan = loadScan();
+    std::vector<wave::PCLPointCloudPtr> refs, targets;
+    for (int k = 0; k < 24; ++k) {
+        refs.push_back(subsample(scan, 4 + (size_t) (k % 3), 0.f));
+        targets.push_back(subsample(scan, 3 + (size_t) (k % 3), 0.02f * (float) (k % 5)));
+    }
+    for (int k = 0; k < 24; ++k) pool.insert(k, refs[(size_t) k], targets[(size_t) k]);
+    while (!pool.done()) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+    std::set<int> seen;
+    int id = -1;
+    Eigen::Affine3d T;
+    wave::Mat6 info;
+    while (pool.getResult(&id, &T, &info)) {
+        seen.insert(id);
+        wave::NDTMatcher one(p);
+        one.setup(refs[(size_t) id], targets[(size_t) id]);
+        EXPECT(one.match());
+        EXPECT(distanceTo(one.getResult(), T) < 1e-6);
+    }
+    EXPECT(seen.size() == 24u);
+});
+
 }  // namespace
 
 int main(int argc, char **argv) {
