@@ -441,6 +441,28 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu, copy_peak=None):
          "note": "host clouds: 2 x 320 kB per pair cross PCIe inside the timed call (one worker thread; "
                  "libwave_amd/host/bench_multimatcher with BENCH_MATCHER=gicp runs the C++ wave::MultiMatcher pool on top of this)"}
     out.append(e)
+
+    # ---- NDTMatcher pairs the same way: voxel model + align inside one workgroup per pair (csrc/wm_ndt_small.hip);
+    # the same 20k-point clouds, 1 m voxels
+    ms_h, got = median_ms(lambda: ctx.ndt_batch_match(host_pairs, res=1.0), reps=3)
+    ms_d, got = median_ms(lambda: ctx.ndt_batch_match(dev_pairs, res=1.0), reps=3)
+
+    def ndt_one():
+        ctx.set_source(base[0][0])
+        ctx.set_target(base[0][1])
+        return ctx.ndt_align(res=1.0)
+    ms_one, one = median_ms(ndt_one)
+    e = {"config": "NDTMatcher 20k<->20k, 1 m voxels, %d queued pairs per launch (More-Thuente line search, PCL's defaults)" % B,
+         "pairs_per_launch": B, "registrations_per_s": B / (ms_h * 1e-3), "ms_per_batch": ms_h,
+         "registrations_per_s_device_resident_clouds": B / (ms_d * 1e-3), "kernel_ms_per_batch": got[0]["kernel_ms"],
+         "iterations_first_items": [g["iterations"] for g in got[:8]],
+         "derivative_passes_first_items": [g["evaluations"] for g in got[:8]],
+         "all_converged": all(g["rc"] == 0 for g in got),
+         "one_pair_at_a_time_ms": ms_one,
+         "first_item_vs_the_one_pair_path_max_abs_dT": float(np.abs(got[0]["T"] - one["T"]).max()),
+         "note": "a launch lasts as long as its slowest pair (30 to 140 passes on these pairs); the C++ pool keeps several launches in "
+                 "flight (libwave_amd/host/bench_multimatcher with BENCH_MATCHER=ndt)"}
+    out.append(e)
     del dev_clouds, dev_pairs
     ctx.close()
     prof.close()
