@@ -298,24 +298,48 @@ __device__ __attribute__((noinline)) void ns_share(NsShared &S, unsigned *s_near
             }
         }
         // kd-tree radius test in float on the float means; survivors compacted in place, in cell order
+        // (four candidates per trip so that four loads are in flight)
         int n_near = 0;
 #pragma unroll 1
-        for (int r = 0; r < n_cand; ++r) {
-            const unsigned cv = s_near[r * kNsThreads + tid];
-            const float4 cm = meanf[cv];
-            const float fx = __fsub_rn(xt0, cm.x), fy = __fsub_rn(xt1, cm.y), fz = __fsub_rn(xt2, cm.z);
-            const float dd = __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz));
-            if (dd <= res2_f) {  // <=> (double) dd < res^2
-                s_near[n_near * kNsThreads + tid] = cv;
-                ++n_near;
+        for (int r = 0; r < n_cand; r += 4) {
+            unsigned cv[4];
+            float4 cm[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cv[u] = s_near[min(r + u, n_cand - 1) * kNsThreads + tid];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cm[u] = meanf[cv[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float fx = __fsub_rn(xt0, cm[u].x), fy = __fsub_rn(xt1, cm[u].y), fz = __fsub_rn(xt2, cm[u].z);
+                const float dd = __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz));
+                if (r + u < n_cand && dd <= res2_f) {  // <=> (double) dd < res^2
+                    s_near[n_near * kNsThreads + tid] = cv[u];
+                    ++n_near;
+                }
             }
+        }
+        // the next voxel's record (96 B) is requested before the current one is evaluated
+        NdtVoxel vn;
+        {
+            const unsigned v0 = n_near > 0 ? s_near[tid] : 0u;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) vn.mean[k] = vox[v0].mean[k];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) vn.icov[k] = vox[v0].icov[k];
         }
         double g3[3] = {0.0, 0.0, 0.0}, P[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         double Q[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         bool any = false;
 #pragma unroll 1
         for (int t = 0; t < n_near; ++t) {
-            const NdtVoxel v = vox[s_near[t * kNsThreads + tid]];
+            const NdtVoxel v = vn;
+            {
+                const unsigned v1 = t + 1 < n_near ? s_near[(t + 1) * kNsThreads + tid] : 0u;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) vn.mean[k] = vox[v1].mean[k];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) vn.icov[k] = vox[v1].icov[k];
+            }
             const double xx[3] = {(double) xt0 - v.mean[0], (double) xt1 - v.mean[1], (double) xt2 - v.mean[2]};
             double cx[3];
 #pragma unroll
