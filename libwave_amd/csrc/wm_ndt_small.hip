@@ -43,7 +43,7 @@ struct NsPair {  // one registration of the batch (device table)
     int *table;        // cell -> voxel record (-1: none)
     NdtVoxel *vox;     // records: mean + inverse covariance
     float4 *meanf;     // float means (the radius test)
-    float4 *spts;      // the source's points as float4 (w = 0: not finite)
+    float4 *spts;      // the source's finite points in a spatial order
 };
 
 struct NsParams {
@@ -57,7 +57,7 @@ struct NsOut {
     double score;
     int converged, iterations, evaluations, n_voxels, status;
     int n_src_valid, n_tgt_valid;
-    unsigned long long cyc[2];  // developer: shader-clock cycles of the model build / the align
+    unsigned long long cyc[3];  // developer: shader-clock cycles of the model build / the align / the align's passes (the rest of the align: wave 0's control)
 };
 
 struct NsShared {
@@ -76,12 +76,50 @@ struct NsShared {
     int unsupported;  // the lattice does not fit kNsCells
     NdtLoopOut out;
     int evals;
+    unsigned long long pass_cyc;
 };
 
 __device__ __forceinline__ bool ns_load(const unsigned char *base, unsigned i, unsigned stride, float &x, float &y, float &z) {
     const float *p = reinterpret_cast<const float *>(base + (size_t) i * stride);
     x = p[0], y = p[1], z = p[2];
     return x - x == 0.f && y - y == 0.f && z - z == 0.f;  // finite
+}
+
+// exclusive scan of the counting sort's counts, four cells per thread at a time: run[c] = start[c] = first slot of cell
+// c (the counts were made by atomics, which live in L2: read there).  Every thread calls.
+__device__ __forceinline__ void ns_scan_counts(unsigned *run, unsigned *start, unsigned nc, NsShared &S) {
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    unsigned carry = 0;
+    for (unsigned c0 = 0; c0 < nc; c0 += 4u * kNsThreads) {
+        const unsigned c = c0 + 4u * tid;
+        unsigned v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = c + (unsigned) u < nc ? __hip_atomic_load(&run[c + (unsigned) u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const unsigned mine = v[0] + v[1] + v[2] + v[3];
+        unsigned incl = mine;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const unsigned up = __shfl_up(incl, m);
+            if ((int) lane >= m) incl += up;
+        }
+        if (lane == 63) S.scan[wave] = incl;
+        __syncthreads();
+        unsigned base = carry, all = 0;
+        for (unsigned w = 0; w < (unsigned) kNsWaves; ++w) {
+            if (w < wave) base += S.scan[w];
+            all += S.scan[w];
+        }
+        unsigned at = base + incl - mine;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c + (unsigned) u < nc) {
+                run[c + (unsigned) u] = at;
+                start[c + (unsigned) u] = at;
+                at += v[u];
+            }
+        carry += all;
+        __syncthreads();
+    }
 }
 
 // pcl::VoxelGridCovariance::filter of the target (setInputTarget, ndt.cpp:55): S.dense / S.n_valid
@@ -163,39 +201,7 @@ __device__ __attribute__((noinline)) void ns_build_model(NsShared &S) {
         if (ns_load(raw, i, stride, x, y, z)) atomicAdd(&run[cell_of(x, y, z)], 1u);
     }
     __syncthreads();
-    // exclusive scan of the counts, four cells per thread at a time (the counts were made by atomics, which live in
-    // L2: read there)
-    unsigned carry = 0;
-    for (unsigned c0 = 0; c0 < nc; c0 += 4u * kNsThreads) {
-        const unsigned c = c0 + 4u * tid;
-        unsigned v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = c + (unsigned) u < nc ? __hip_atomic_load(&run[c + (unsigned) u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        const unsigned mine = v[0] + v[1] + v[2] + v[3];
-        unsigned incl = mine;
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            const unsigned up = __shfl_up(incl, m);
-            if ((int) lane >= m) incl += up;
-        }
-        if (lane == 63) S.scan[wave] = incl;
-        __syncthreads();
-        unsigned base = carry, all = 0;
-        for (unsigned w = 0; w < (unsigned) kNsWaves; ++w) {
-            if (w < wave) base += S.scan[w];
-            all += S.scan[w];
-        }
-        unsigned at = base + incl - mine;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (c + (unsigned) u < nc) {
-                run[c + (unsigned) u] = at;
-                start[c + (unsigned) u] = at;
-                at += v[u];
-            }
-        carry += all;
-        __syncthreads();
-    }
+    ns_scan_counts(run, start, nc, S);
     if (tid == 0) start[nc] = cnt;
     __syncthreads();
     unsigned *order = S.pr.order;
@@ -240,6 +246,106 @@ __device__ __attribute__((noinline)) void ns_build_model(NsShared &S) {
     __syncthreads();
 }
 
+// The source in a spatial order (S.pr.spts, S.n_src_valid points): counting sort by the cell of a grid of its own
+// (~8 points per cell by volume), every cell's points in ascending caller index -- a fixed order, so that the passes'
+// sums are the same from run to run.  In caller order (arbitrary: a shuffled cloud) every lane of a wave looked up
+// another corner of the voxel table and another voxel record; 512 neighbours in space share them.
+__device__ __attribute__((noinline)) void ns_sort_source(NsShared &S) {
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned char *raw = S.pr.src;
+    const unsigned n = S.pr.n_src, stride = S.P.stride;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    unsigned cnt = 0;
+    for (unsigned i = tid; i < n; i += kNsThreads) {
+        float x, y, z;
+        if (ns_load(raw, i, stride, x, y, z)) {
+            lo[0] = fminf(lo[0], x), lo[1] = fminf(lo[1], y), lo[2] = fminf(lo[2], z);
+            hi[0] = fmaxf(hi[0], x), hi[1] = fmaxf(hi[1], y), hi[2] = fmaxf(hi[2], z);
+            ++cnt;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], m));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], m));
+        }
+        cnt += __shfl_xor(cnt, m);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) S.boxf[wave][d] = lo[d], S.boxf[wave][3 + d] = hi[d];
+        S.wcnt[wave] = cnt;
+    }
+    __syncthreads();
+    cnt = 0;
+    for (int w = 0; w < kNsWaves; ++w) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) lo[d] = fminf(lo[d], S.boxf[w][d]), hi[d] = fmaxf(hi[d], S.boxf[w][3 + d]);
+        cnt += S.wcnt[w];
+    }
+    __syncthreads();
+    if (tid == 0) S.n_src_valid = cnt;
+    if (cnt == 0) {
+        __syncthreads();
+        return;
+    }
+    double vol = 1;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) vol *= fmax((double) hi[d] - (double) lo[d], 1e-3);
+    float h = (float) fmax(cbrt(vol / (double) cnt) * 2.0, 1e-4);
+    int nx, ny, nz;
+    for (;;) {
+        nx = (int) floorf((hi[0] - lo[0]) / h) + 1, ny = (int) floorf((hi[1] - lo[1]) / h) + 1, nz = (int) floorf((hi[2] - lo[2]) / h) + 1;
+        if ((unsigned long long) nx * (unsigned long long) ny * (unsigned long long) nz <= (unsigned long long) kNsCells) break;
+        h *= 1.1f;
+    }
+    const float inv_h = 1.0f / h;
+    const unsigned nc = (unsigned) (nx * ny * nz);
+    auto cell_of = [&](float x, float y, float z) {
+        const int a = min(max((int) floorf((x - lo[0]) * inv_h), 0), nx - 1), b = min(max((int) floorf((y - lo[1]) * inv_h), 0), ny - 1),
+                  c = min(max((int) floorf((z - lo[2]) * inv_h), 0), nz - 1);
+        return (unsigned) ((c * ny + b) * nx + a);
+    };
+    unsigned *run = S.pr.run, *start = S.pr.start, *order = S.pr.order;
+    for (unsigned c = tid; c < nc; c += kNsThreads) run[c] = 0u;
+    __syncthreads();
+    for (unsigned i = tid; i < n; i += kNsThreads) {
+        float x, y, z;
+        if (ns_load(raw, i, stride, x, y, z)) atomicAdd(&run[cell_of(x, y, z)], 1u);
+    }
+    __syncthreads();
+    ns_scan_counts(run, start, nc, S);
+    if (tid == 0) start[nc] = cnt;
+    __syncthreads();
+    for (unsigned i = tid; i < n; i += kNsThreads) {
+        float x, y, z;
+        if (ns_load(raw, i, stride, x, y, z)) order[atomicAdd(&run[cell_of(x, y, z)], 1u)] = i;
+    }
+    __syncthreads();
+    // a thread per cell puts its points in ascending index (insertion sort: a cell holds a few dozen), then writes them out
+    float4 *spts = S.pr.spts;
+    for (unsigned c = tid; c < nc; c += kNsThreads) {
+        const unsigned s0 = start[c], s1 = start[c + 1];
+        for (unsigned a = s0 + 1; a < s1; ++a) {
+            const unsigned v = order[a];
+            unsigned b = a;
+            while (b > s0 && order[b - 1] > v) {
+                order[b] = order[b - 1];
+                --b;
+            }
+            order[b] = v;
+        }
+        for (unsigned a = s0; a < s1; ++a) {
+            float x, y, z;
+            (void) ns_load(raw, order[a], stride, x, y, z);
+            spts[a] = make_float4(x, y, z, 1.f);
+        }
+    }
+    __syncthreads();
+}
+
 // this thread's share of one derivative pass (the body of k_ndt_derivs, wm_ndt.hip: see there for why it is laid out
 // the way it is), then the workgroup's rows -> S.red
 template <bool GRAD, bool HESS>
@@ -250,7 +356,7 @@ __device__ __attribute__((noinline)) void ns_share(NsShared &S, unsigned *s_near
     const NdtDense dense = S.dense;
     const NdtVoxel *__restrict__ vox = S.pr.vox;
     const float4 *__restrict__ meanf = S.pr.meanf, *__restrict__ src = S.pr.spts;
-    const unsigned n = S.pr.n_src;
+    const unsigned n = S.n_src_valid;
     auto jh_dot = [&](const double (&x)[3], int k, int opaque0) -> double {
         const double *v = &s_jh[k + opaque0][0];
         return x[0] * v[0] + x[1] * v[1] + x[2] * v[2];
@@ -269,7 +375,6 @@ __device__ __attribute__((noinline)) void ns_share(NsShared &S, unsigned *s_near
     for (int k = 0; k < NA; ++k) acc[k] = 0.0;
     for (unsigned idx = tid; idx < n; idx += kNsThreads) {
         const float4 sp = src[idx];
-        if (sp.w == 0.f) continue;  // (not finite)
         const float xt0 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T0, sp.x), __fmul_rn(T1, sp.y)), __fmul_rn(T2, sp.z)), T3);
         const float xt1 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T4, sp.x), __fmul_rn(T5, sp.y)), __fmul_rn(T6, sp.z)), T7);
         const float xt2 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T8, sp.x), __fmul_rn(T9, sp.y)), __fmul_rn(T10, sp.z)), T11);
@@ -455,6 +560,7 @@ struct NsEval {
     double (*s_jh)[3];
     double d1, d2;
     int evals;
+    unsigned long long pass_cyc;
     __device__ bool failed() const { return false; }
     __device__ bool skip_line_search() const { return S->P.skip_line_search != 0; }
     __device__ bool spec_hessian() const { return S->P.spec_hessian != 0; }
@@ -474,9 +580,11 @@ struct NsEval {
             angle_derivatives(p, S->P.pcl_d1_sign, &A);
             S->cmd = cmd;
         }
+        const unsigned long long t0 = clock64();
         __syncthreads();
         ns_share_cmd(*S, cmd, s_near, s_jh);
         __syncthreads();
+        pass_cyc += clock64() - t0;
         const int n_acc = hess ? kNdtAcc : kNdtAccGrad;
         double v = 0;
         if ((int) lane < n_acc)
@@ -519,26 +627,7 @@ __global__ void __launch_bounds__(kNsThreads) k_ndt_small(const NsPair *__restri
     __syncthreads();
     unsigned long long t_mark = clock64();
     ns_build_model(S);
-    // the source as float4 in its own order (w = 1: finite)
-    {
-        unsigned cnt = 0;
-        for (unsigned i = tid; i < S.pr.n_src; i += kNsThreads) {
-            float x, y, z;
-            const bool ok = ns_load(S.pr.src, i, P.stride, x, y, z);
-            S.pr.spts[i] = make_float4(x, y, z, ok ? 1.f : 0.f);
-            cnt += ok ? 1u : 0u;
-        }
-#pragma unroll
-        for (int m = 32; m > 0; m >>= 1) cnt += __shfl_xor(cnt, m);
-        if ((tid & 63u) == 0) S.wcnt[tid >> 6] = cnt;
-        __syncthreads();
-        if (tid == 0) {
-            unsigned c = 0;
-            for (int w = 0; w < kNsWaves; ++w) c += S.wcnt[w];
-            S.n_src_valid = c;
-        }
-        __syncthreads();
-    }
+    ns_sort_source(S);
     if (tid == 0) {
         out.cyc[0] = clock64() - t_mark;
         out.n_src_valid = (int) S.n_src_valid;
@@ -558,6 +647,7 @@ __global__ void __launch_bounds__(kNsThreads) k_ndt_small(const NsPair *__restri
     E.s_near = s_near;
     E.s_jh = s_jh;
     E.evals = 0;
+    E.pass_cyc = 0;
     {
         const double c1 = 10.0 * (1.0 - P.outlier_ratio), c2 = P.outlier_ratio / pow(P.res, 3);
         const double d3 = -log(c2);
@@ -570,6 +660,7 @@ __global__ void __launch_bounds__(kNsThreads) k_ndt_small(const NsPair *__restri
         if (tid == 0) {
             S.out = lo;
             S.evals = E.evals;
+            S.pass_cyc = E.pass_cyc;
             S.cmd = 0u;
         }
         __syncthreads();  // (the waves in serve() see the end)
@@ -587,6 +678,7 @@ __global__ void __launch_bounds__(kNsThreads) k_ndt_small(const NsPair *__restri
         out.evaluations = S.evals;
         out.status = S.out.converged ? WM_OK : WM_NOT_CONVERGED;
         out.cyc[1] = clock64() - t_mark;
+        out.cyc[2] = S.pass_cyc;
     }
 }
 
@@ -645,7 +737,7 @@ static int ndt_small_run(wm_ctx *ctx, const NsJob *jobs, int n, size_t stride, i
     if (!B) return WM_ERR_NOMEM;
     size_t cloud_bytes = 0, work_bytes = 0;
     auto work_need = [](size_t ns, size_t nt) {
-        return 2 * ns_up256(((size_t) kNsCells + 8) * 4) + ns_up256(nt * 4 + 16) + ns_up256((size_t) kNsCells * 4) +
+        return 2 * ns_up256(((size_t) kNsCells + 8) * 4) + ns_up256((nt > ns ? nt : ns) * 4 + 16) + ns_up256((size_t) kNsCells * 4) +
                ns_up256((nt / 6 + 1) * sizeof(NdtVoxel)) + ns_up256((nt / 6 + 1) * sizeof(float4)) + ns_up256(ns * 16 + 16);
     };
     for (int k = 0; k < n; ++k) {
@@ -693,7 +785,7 @@ static int ndt_small_run(wm_ctx *ctx, const NsJob *jobs, int n, size_t stride, i
         };
         t.start = reinterpret_cast<unsigned *>(take(((size_t) kNsCells + 8) * 4));
         t.run = reinterpret_cast<unsigned *>(take(((size_t) kNsCells + 8) * 4));
-        t.order = reinterpret_cast<unsigned *>(take(it.n_tgt * 4 + 16));
+        t.order = reinterpret_cast<unsigned *>(take((it.n_tgt > it.n_src ? it.n_tgt : it.n_src) * 4 + 16));
         t.table = reinterpret_cast<int *>(take((size_t) kNsCells * 4));
         t.vox = reinterpret_cast<NdtVoxel *>(take((it.n_tgt / 6 + 1) * sizeof(NdtVoxel)));
         t.meanf = reinterpret_cast<float4 *>(take((it.n_tgt / 6 + 1) * sizeof(float4)));
@@ -775,8 +867,8 @@ int wm_ndt_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
             }
             if (r.status == WM_OK && T_out) memcpy(T_out + 16 * (size_t) k, r.T, sizeof(r.T));
             if (ctx->trace)
-                fprintf(stderr, "[wm] ndt batch: pair %d: %d + %d points, %d voxels, status %d, %d iterations, %d passes; kcycles: model %llu, align %llu\n",
-                        k, r.n_src_valid, r.n_tgt_valid, r.n_voxels, r.status, r.iterations, r.evaluations, r.cyc[0] / 1000, r.cyc[1] / 1000);
+                fprintf(stderr, "[wm] ndt batch: pair %d: %d + %d points, %d voxels, status %d, %d iterations, %d passes; kcycles: model %llu, align %llu (of it the passes %llu)\n",
+                        k, r.n_src_valid, r.n_tgt_valid, r.n_voxels, r.status, r.iterations, r.evaluations, r.cyc[0] / 1000, r.cyc[1] / 1000, r.cyc[2] / 1000);
         }
     }
     for (int k : one_by_one) {
