@@ -40,6 +40,19 @@ def test_no_cpu_fallback(wm):
         wm.Context(0)
 
 
+def test_batch_entry_points_refuse_bad_arguments_without_a_device(wm):
+    """wm_icp_batch_match / wm_gicp_batch_match / wm_ndt_batch_match check their arguments before they touch a device."""
+    L = wm.lib()
+    status = (ctypes.c_int * 1)()
+    items = (wm.BatchItem * 1)()
+    assert L.wm_gicp_batch_match(None, items, 1, 16, wm.WM_MEM_HOST, ctypes.byref(wm.gicp_params()), ctypes.c_float(-1.0), None, None,
+                                 status, None) == wm.WM_ERR_ARG
+    assert L.wm_ndt_batch_match(None, items, 1, 16, wm.WM_MEM_HOST, ctypes.byref(wm.ndt_params()), None, None, status, None) == wm.WM_ERR_ARG
+    assert L.wm_icp_batch_match(None, items, 1, 16, wm.WM_MEM_HOST, ctypes.byref(wm.icp_params()), ctypes.c_float(-1.0), 0, 1, None, None,
+                                None, status) == wm.WM_ERR_ARG
+    assert wm.WM_GICP_BATCH_MAX_POINTS == 100000 and wm.WM_NDT_BATCH_MAX_POINTS == 200000  # (include/wavematch.h)
+
+
 def test_strerror_and_default_params(wm):
     L = wm.lib()
     assert L.wm_strerror(0) == b"ok"
