@@ -629,18 +629,7 @@ void gicp_small_release(wm_ctx *ctx) {
     ctx->gicp_small_batch = nullptr;
 }
 
-static int gs_pinned(wm_ctx *ctx, void **p, size_t *cap, size_t bytes) {
-    if (bytes <= *cap) return WM_OK;
-    if (*p) (void) hipHostFree(*p);
-    *p = nullptr;
-    *cap = 0;
-    const size_t want = bytes + bytes / 4 + 4096;
-    WM_HIP(ctx, hipHostMalloc(p, want, hipHostMallocDefault));
-    *cap = want;
-    return WM_OK;
-}
 
-static size_t up256(size_t v) { return (v + 255) & ~(size_t) 255; }
 
 struct GsJob {
     const void *src;
@@ -657,23 +646,23 @@ static int gicp_small_run(wm_ctx *ctx, const GsJob *jobs, int n, size_t stride, 
     if (!B) return WM_ERR_NOMEM;
     size_t cloud_bytes = 0, work_bytes = 0;
     auto work_need = [](size_t ns, size_t nt) {
-        return up256((ns + 4) * 16) + up256((nt + 4) * 16) + 3 * up256(((size_t) kGsCells + 8) * 4) + up256(ns * 72) + up256(nt * 72) +
-               up256(((ns + 63) / 64) * (size_t) kGsEvBlock) + up256(ns * 4);
+        return align_up256((ns + 4) * 16) + align_up256((nt + 4) * 16) + 3 * align_up256(((size_t) kGsCells + 8) * 4) + align_up256(ns * 72) + align_up256(nt * 72) +
+               align_up256(((ns + 63) / 64) * (size_t) kGsEvBlock) + align_up256(ns * 4);
     };
     for (int k = 0; k < n; ++k) {
         if (jobs[k].n_src == 0 || jobs[k].n_tgt == 0 || jobs[k].n_src > (size_t) WM_GICP_BATCH_MAX_POINTS ||
             jobs[k].n_tgt > (size_t) WM_GICP_BATCH_MAX_POINTS)
             return WM_ERR_ARG;
-        cloud_bytes += up256(jobs[k].n_src * stride) + up256(jobs[k].n_tgt * stride);
+        cloud_bytes += align_up256(jobs[k].n_src * stride) + align_up256(jobs[k].n_tgt * stride);
         work_bytes += work_need(jobs[k].n_src, jobs[k].n_tgt);
     }
-    const size_t table_bytes = up256((size_t) n * sizeof(GsPair));
+    const size_t table_bytes = align_up256((size_t) n * sizeof(GsPair));
     const size_t up_bytes = table_bytes + (mem == WM_MEM_HOST ? cloud_bytes : 0);
     WM_HIP(ctx, B->d_stage.reserve(up_bytes));
     WM_HIP(ctx, B->d_work.reserve(work_bytes));
     WM_HIP(ctx, B->d_out.reserve((size_t) n * sizeof(GsOut)));
-    WM_TRY(gs_pinned(ctx, &B->h_stage, &B->h_stage_cap, up_bytes));
-    WM_TRY(gs_pinned(ctx, &B->h_out, &B->h_out_cap, (size_t) n * sizeof(GsOut)));
+    WM_TRY(pinned_reserve(ctx, &B->h_stage, &B->h_stage_cap, up_bytes));
+    WM_TRY(pinned_reserve(ctx, &B->h_out, &B->h_out_cap, (size_t) n * sizeof(GsOut)));
     WM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (the stream may still be reading the staging buffer for the previous batch)
     unsigned char *h = static_cast<unsigned char *>(B->h_stage), *d = B->d_stage.as<unsigned char>(), *w = B->d_work.as<unsigned char>();
     GsPair *table = reinterpret_cast<GsPair *>(h);
@@ -686,10 +675,10 @@ static int gicp_small_run(wm_ctx *ctx, const GsJob *jobs, int n, size_t stride, 
         if (mem == WM_MEM_HOST) {
             memcpy(h + off, it.src, it.n_src * stride);
             t.src = d + off;
-            off += up256(it.n_src * stride);
+            off += align_up256(it.n_src * stride);
             memcpy(h + off, it.tgt, it.n_tgt * stride);
             t.tgt = d + off;
-            off += up256(it.n_tgt * stride);
+            off += align_up256(it.n_tgt * stride);
             if (off - sent >= ((size_t) 2 << 20)) {  // (each slice's DMA runs under the next slices' copies)
                 WM_HIP(ctx, hipMemcpyAsync(d + sent, h + sent, off - sent, hipMemcpyHostToDevice, ctx->stream));
                 sent = off;
@@ -700,7 +689,7 @@ static int gicp_small_run(wm_ctx *ctx, const GsJob *jobs, int n, size_t stride, 
         }
         auto take = [&](size_t bytes) {
             unsigned char *p = w;
-            w += up256(bytes);
+            w += align_up256(bytes);
             return p;
         };
         t.s_pts = reinterpret_cast<float4 *>(take((it.n_src + 4) * 16));

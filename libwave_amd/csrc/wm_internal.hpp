@@ -403,6 +403,18 @@ int launch_fix_keys(wm_ctx *ctx, float thr_d2);  // after certified iterations: 
 // this align was launch_nn_cert too (its per-query bounds are still in ctx->nn_bound)
 int launch_nn_cert(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2, int stats_mode,
                    unsigned *rows_out, bool bounds_valid);
+// pinned host staging of the batched paths (wm_small.hip, wm_gicp_small.hip, wm_ndt_small.hip): grows, never shrinks
+inline int pinned_reserve(wm_ctx *ctx, void **p, size_t *cap, size_t bytes) {
+    if (bytes <= *cap) return WM_OK;
+    if (*p) (void) hipHostFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    WM_HIP(ctx, hipHostMalloc(p, want, hipHostMallocDefault));
+    *cap = want;
+    return WM_OK;
+}
+inline size_t align_up256(size_t v) { return (v + 255) & ~(size_t) 255; }
 void small_batch_release(wm_ctx *ctx);
 void gicp_small_release(wm_ctx *ctx);
 void ndt_small_release(wm_ctx *ctx);   // wm_ndt_small.hip: ... of the batched small NDT registrations  // wm_gicp_small.hip: the staging of the batched small GICP registrations

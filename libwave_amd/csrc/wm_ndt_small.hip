@@ -710,18 +710,7 @@ void ndt_small_release(wm_ctx *ctx) {
     ctx->ndt_small_batch = nullptr;
 }
 
-static int ns_pinned(wm_ctx *ctx, void **p, size_t *cap, size_t bytes) {
-    if (bytes <= *cap) return WM_OK;
-    if (*p) (void) hipHostFree(*p);
-    *p = nullptr;
-    *cap = 0;
-    const size_t want = bytes + bytes / 4 + 4096;
-    WM_HIP(ctx, hipHostMalloc(p, want, hipHostMallocDefault));
-    *cap = want;
-    return WM_OK;
-}
 
-static size_t ns_up256(size_t v) { return (v + 255) & ~(size_t) 255; }
 
 struct NsJob {
     const void *src;
@@ -737,23 +726,23 @@ static int ndt_small_run(wm_ctx *ctx, const NsJob *jobs, int n, size_t stride, i
     if (!B) return WM_ERR_NOMEM;
     size_t cloud_bytes = 0, work_bytes = 0;
     auto work_need = [](size_t ns, size_t nt) {
-        return 2 * ns_up256(((size_t) kNsCells + 8) * 4) + ns_up256((nt > ns ? nt : ns) * 4 + 16) + ns_up256((size_t) kNsCells * 4) +
-               ns_up256((nt / 6 + 1) * sizeof(NdtVoxel)) + ns_up256((nt / 6 + 1) * sizeof(float4)) + ns_up256(ns * 16 + 16);
+        return 2 * align_up256(((size_t) kNsCells + 8) * 4) + align_up256((nt > ns ? nt : ns) * 4 + 16) + align_up256((size_t) kNsCells * 4) +
+               align_up256((nt / 6 + 1) * sizeof(NdtVoxel)) + align_up256((nt / 6 + 1) * sizeof(float4)) + align_up256(ns * 16 + 16);
     };
     for (int k = 0; k < n; ++k) {
         if (jobs[k].n_src == 0 || jobs[k].n_tgt == 0 || jobs[k].n_src > (size_t) WM_NDT_BATCH_MAX_POINTS ||
             jobs[k].n_tgt > (size_t) WM_NDT_BATCH_MAX_POINTS)
             return WM_ERR_ARG;
-        cloud_bytes += ns_up256(jobs[k].n_src * stride) + ns_up256(jobs[k].n_tgt * stride);
+        cloud_bytes += align_up256(jobs[k].n_src * stride) + align_up256(jobs[k].n_tgt * stride);
         work_bytes += work_need(jobs[k].n_src, jobs[k].n_tgt);
     }
-    const size_t table_bytes = ns_up256((size_t) n * sizeof(NsPair));
+    const size_t table_bytes = align_up256((size_t) n * sizeof(NsPair));
     const size_t up_bytes = table_bytes + (mem == WM_MEM_HOST ? cloud_bytes : 0);
     WM_HIP(ctx, B->d_stage.reserve(up_bytes));
     WM_HIP(ctx, B->d_work.reserve(work_bytes));
     WM_HIP(ctx, B->d_out.reserve((size_t) n * sizeof(NsOut)));
-    WM_TRY(ns_pinned(ctx, &B->h_stage, &B->h_stage_cap, up_bytes));
-    WM_TRY(ns_pinned(ctx, &B->h_out, &B->h_out_cap, (size_t) n * sizeof(NsOut)));
+    WM_TRY(pinned_reserve(ctx, &B->h_stage, &B->h_stage_cap, up_bytes));
+    WM_TRY(pinned_reserve(ctx, &B->h_out, &B->h_out_cap, (size_t) n * sizeof(NsOut)));
     WM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (the stream may still be reading the staging buffer for the previous batch)
     unsigned char *h = static_cast<unsigned char *>(B->h_stage), *d = B->d_stage.as<unsigned char>(), *w = B->d_work.as<unsigned char>();
     NsPair *table = reinterpret_cast<NsPair *>(h);
@@ -766,10 +755,10 @@ static int ndt_small_run(wm_ctx *ctx, const NsJob *jobs, int n, size_t stride, i
         if (mem == WM_MEM_HOST) {
             memcpy(h + off, it.src, it.n_src * stride);
             t.src = d + off;
-            off += ns_up256(it.n_src * stride);
+            off += align_up256(it.n_src * stride);
             memcpy(h + off, it.tgt, it.n_tgt * stride);
             t.tgt = d + off;
-            off += ns_up256(it.n_tgt * stride);
+            off += align_up256(it.n_tgt * stride);
             if (off - sent >= ((size_t) 2 << 20)) {
                 WM_HIP(ctx, hipMemcpyAsync(d + sent, h + sent, off - sent, hipMemcpyHostToDevice, ctx->stream));
                 sent = off;
@@ -780,7 +769,7 @@ static int ndt_small_run(wm_ctx *ctx, const NsJob *jobs, int n, size_t stride, i
         }
         auto take = [&](size_t bytes) {
             unsigned char *p = w;
-            w += ns_up256(bytes);
+            w += align_up256(bytes);
             return p;
         };
         t.start = reinterpret_cast<unsigned *>(take(((size_t) kNsCells + 8) * 4));

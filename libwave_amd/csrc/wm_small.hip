@@ -884,16 +884,6 @@ void small_batch_release(wm_ctx *ctx) {
     ctx->small_batch = nullptr;
 }
 
-static int pinned_reserve(wm_ctx *ctx, void **p, size_t *cap, size_t bytes) {
-    if (bytes <= *cap) return WM_OK;
-    if (*p) (void) hipHostFree(*p);
-    *p = nullptr;
-    *cap = 0;
-    const size_t want = bytes + bytes / 4 + 4096;
-    WM_HIP(ctx, hipHostMalloc(p, want, hipHostMallocDefault));
-    *cap = want;
-    return WM_OK;
-}
 
 }  // namespace wm
 
