@@ -108,3 +108,15 @@ def test_batch_device_clouds_and_many_pairs(wm, ctx):
     for k, g in enumerate(got):
         _close(g, first[k % 3])
         assert np.array_equal(g["T"], got[k % 3]["T"])
+
+
+@pytest.mark.parametrize("kw", [dict(pcl_d1_sign=0), dict(force_iterations=6), dict(outlier_ratio=0.3), dict(step_size=0.05, max_iter=8)])
+def test_batch_follows_the_parameters(wm, ctx, kw):
+    """the true second derivative instead of PCL's sign slip, forced iterations (the bench mode), another outlier ratio,
+    a registration cut short by max_iter: the same as the one-pair path each time"""
+    pairs = [synth.pair(n, seed=1100 + k, mode="resample") for k, n in enumerate((14000, 9000))]
+    got = ctx.ndt_batch_match([(r, t) for r, t, _ in pairs], res=1.5, **kw)
+    for (r, t, _), g in zip(pairs, got):
+        _close(g, _one(ctx, r, t, res=1.5, **kw))
+    if "force_iterations" in kw:
+        assert all(g["iterations"] == 6 for g in got)
