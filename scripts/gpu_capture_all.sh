@@ -26,14 +26,15 @@ python bench.py > gpurun_out/${TAG}_bench_line_noprof.json 2> /dev/null
   BENCH_QUEUE=10 BENCH_RES=0.1 BENCH_MULTISCALE=3 timeout 200 ./bench_multimatcher 55000 3000 1 4 16
   BENCH_QUEUE=512 BENCH_RES=0.1 BENCH_MULTISCALE=3 timeout 200 ./bench_multimatcher 55000 3000 1 2 4
   BENCH_QUEUE=10 BENCH_RES=0.1 BENCH_MULTISCALE=0 timeout 200 ./bench_multimatcher 55000 3000 1 4
+  # (steady state: 16 000 / 40 000 pairs -- a launch of 256 lasts 25 / 12 ms, a run of 4 000 pairs is warm-up and tail)
   # MultiMatcher<GICPMatcher>: the batched small GICP (one registration per compute unit), full resolution and the
   # matcher's default voxel filter; MultiMatcher<NDTMatcher>: the batched small NDT, 1 m voxels and the matcher's default 5 m
-  BENCH_MATCHER=gicp BENCH_QUEUE=10 timeout 200 ./bench_multimatcher 20000 4000 1 2 4 8 16
-  BENCH_MATCHER=gicp BENCH_QUEUE=2048 timeout 200 ./bench_multimatcher 20000 4000 1 2 4 16
+  BENCH_MATCHER=gicp BENCH_QUEUE=10 timeout 200 ./bench_multimatcher 20000 16000 1 2 4 8 16
+  BENCH_MATCHER=gicp BENCH_QUEUE=2048 timeout 200 ./bench_multimatcher 20000 16000 1 2 4 16
   BENCH_MATCHER=gicp BENCH_QUEUE=10 timeout 200 ./bench_multimatcher 10000 6000 4 16
   BENCH_MATCHER=gicp BENCH_QUEUE=10 BENCH_RES=0.1 timeout 200 ./bench_multimatcher 55000 1500 4 16
-  BENCH_MATCHER=ndt BENCH_QUEUE=10 timeout 200 ./bench_multimatcher 20000 4000 1 2 4 8 16
-  BENCH_MATCHER=ndt BENCH_QUEUE=2048 timeout 200 ./bench_multimatcher 20000 4000 1 2 4 16
+  BENCH_MATCHER=ndt BENCH_QUEUE=10 timeout 200 ./bench_multimatcher 20000 40000 1 2 4 8 16
+  BENCH_MATCHER=ndt BENCH_QUEUE=2048 timeout 200 ./bench_multimatcher 20000 40000 1 2 4 16
   BENCH_MATCHER=ndt BENCH_QUEUE=10 BENCH_RES=5 timeout 200 ./bench_multimatcher 55000 2000 4 16 ) > gpurun_out/${TAG}_multimatcher_cpp.jsonl 2> /dev/null
 python scripts/dev/dev_batch_scaled.py 128 > gpurun_out/${TAG}_batch_scaled_testscan.txt 2> /dev/null
 ls gpurun_out/${TAG}_*
