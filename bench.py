@@ -149,6 +149,14 @@ def cpu_baseline(ref, tgt, iters_full, max_corr, cpu_iters):
     return out
 
 
+def rotation_angle(R_a, R_b):
+    """Angle [rad] of R_a^T R_b through |R - I|_F = 2 sqrt(2) |sin(theta / 2)|: well conditioned near zero, where
+    arccos((trace - 1) / 2) turns the 1e-7 non-orthonormality of a float matrix into 3e-4 rad (tests/helpers.py:
+    pose_error is the same formula)."""
+    R = np.asarray(R_a, dtype=np.float64).T @ np.asarray(R_b, dtype=np.float64)
+    return float(2.0 * np.arcsin(min(1.0, np.linalg.norm(R - np.eye(3)) / (2.0 * np.sqrt(2.0)))))
+
+
 def csrc_sha256():
     """sha256 over the kernel sources (libwave_amd/csrc/*.hip, *.hpp, in name order): what a committed counter
     capture is stamped with (scripts/pmc_to_json.py) and checked against here."""
@@ -174,7 +182,9 @@ def pmc_summary():
     except Exception:
         return {}
     stamp = pmc.get("csrc_sha256")
-    if stamp is not None and stamp != csrc_sha256():
+    if stamp is None:  # (an unstamped capture cannot be tied to the kernels in the tree: treated as stale too)
+        return {"stale": "profiles/pmc_latest.json (tag %s) carries no csrc_sha256 stamp: traffic not reported" % pmc.get("tag")}
+    if stamp != csrc_sha256():
         return {"stale": "profiles/pmc_latest.json (tag %s) was captured from other kernel sources "
                          "(csrc_sha256 %s..., tree %s...): traffic not reported" % (pmc.get("tag"), stamp[:12],
                                                                                    csrc_sha256()[:12])}
@@ -288,10 +298,9 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu, copy_peak=None):
             got = ctx.gicp_align()
             if got["T"] is not None and want.get("T") is not None:
                 Tw = np.asarray(want["T"], dtype=np.float64)
-                dR = got["T"][:3, :3].T @ Tw[:3, :3]
                 e["parity_vs_oracle_20k"] = {
                     "translation_difference_m": float(np.linalg.norm(got["T"][:3, 3] - Tw[:3, 3])),
-                    "rotation_difference_rad": float(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))),
+                    "rotation_difference_rad": rotation_angle(got["T"][:3, :3], Tw[:3, :3]),
                     "identical_float_matrix": bool(np.array_equal(got["T"].astype(np.float32), Tw.astype(np.float32))),
                     "outer_iterations": [got["iterations"], want.get("iterations")],
                     "note": "the same 20k pair through the HIP path and the oracle; translation_error_m above is against "
@@ -351,8 +360,8 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu, copy_peak=None):
     ctx.set_source(base[0][0])
     ctx.set_target(base[0][1])
     ms_one, one = median_ms(lambda: ctx.icp_match(base[0][0], base[0][1], res=-1.0, max_corr=3.0, max_iter=100, carry_state=0))
-    e = {"config": "ICPMatcher 10k<->10k (BASELINE configs[0]), %d queued pairs per launch: match() + estimateInfo() each, "
-                   "PCL's default stopping rules" % B,
+    e = {"config": "ICPMatcher 10k<->10k (BASELINE configs[0]), %d queued pairs per launch (8 distinct pairs, each 32 times): "
+                   "match() + estimateInfo() each, PCL's default stopping rules" % B,
          "pairs_per_launch": B,
          "registrations_per_s": B / (ms_h * 1e-3), "ms_per_batch": ms_h,
          "registrations_per_s_device_resident_clouds": B / (ms_d * 1e-3),
@@ -415,15 +424,17 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu, copy_peak=None):
 
     # ---- GICPMatcher pairs the MultiMatcher way: a queue of them, 256 per launch, one compute unit each with the
     # whole of align inside the kernel (csrc/wm_gicp_small.hip); full-resolution 20k-point clouds
+    # (256 DISTINCT pairs: a launch lasts as long as its slowest pair, so repeating a handful of pairs would
+    # understate the spread of their durations)
     n, B = 20_000, 256
-    base = [synth.pair(n, seed=300 + k, mode="resample")[:2] for k in range(8)]
-    host_pairs = [base[k % 8] for k in range(B)]
+    base = [synth.pair(n, seed=300 + k, mode="resample")[:2] for k in range(B)]
+    host_pairs = base
     dev_clouds = [(torch.from_numpy(r).to(dev), torch.from_numpy(t).to(dev)) for r, t in base]
-    dev_pairs = [dev_clouds[k % 8] for k in range(B)]
+    dev_pairs = dev_clouds
     ms_h, got = median_ms(lambda: ctx.gicp_batch_match(host_pairs), reps=3)
     ms_d, got = median_ms(lambda: ctx.gicp_batch_match(dev_pairs), reps=3)
     ms_one, one = median_ms(lambda: ctx.gicp_match(base[0][0], base[0][1]))
-    e = {"config": "GICPMatcher 20k<->20k, %d queued pairs per launch (k = 10 covariances, PCL's default stopping rules)" % B,
+    e = {"config": "GICPMatcher 20k<->20k, %d distinct queued pairs per launch (k = 10 covariances, PCL's default stopping rules)" % B,
          "pairs_per_launch": B, "registrations_per_s": B / (ms_h * 1e-3), "ms_per_batch": ms_h,
          "registrations_per_s_device_resident_clouds": B / (ms_d * 1e-3), "kernel_ms_per_batch": got[0]["kernel_ms"],
          "outer_iterations_first_items": [g["iterations"] for g in got[:8]],
@@ -452,7 +463,7 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu, copy_peak=None):
         ctx.set_target(base[0][1])
         return ctx.ndt_align(res=1.0)
     ms_one, one = median_ms(ndt_one)
-    e = {"config": "NDTMatcher 20k<->20k, 1 m voxels, %d queued pairs per launch (More-Thuente line search, PCL's defaults)" % B,
+    e = {"config": "NDTMatcher 20k<->20k, 1 m voxels, %d distinct queued pairs per launch (More-Thuente line search, PCL's defaults)" % B,
          "pairs_per_launch": B, "registrations_per_s": B / (ms_h * 1e-3), "ms_per_batch": ms_h,
          "registrations_per_s_device_resident_clouds": B / (ms_d * 1e-3), "kernel_ms_per_batch": got[0]["kernel_ms"],
          "iterations_first_items": [g["iterations"] for g in got[:8]],
@@ -700,6 +711,12 @@ def main():
                 hc[name] = {"ms_per_registration": float(np.median(ts)), "registrations_per_s": 1e3 / float(np.median(ts))}
             hc["note"] = "wm_set_source / wm_set_target with WM_MEM_HOST: 2 x 16 MB cross PCIe inside the step"
             out["config"]["host_clouds"] = hc
+            # SURVEY 8(d) / BASELINE.md section 3 define a registration as INCLUDING the upload of both clouds.  Scalar
+            # keys of `config` (the driver's record keeps those; it drops nested objects and extra top-level keys):
+            out["config"]["registrations_per_s_h2d_inclusive"] = hc["pinned"]["registrations_per_s"]
+            out["config"]["ms_per_registration_h2d_inclusive"] = hc["pinned"]["ms_per_registration"]
+            out["config"]["registrations_per_s_h2d_inclusive_pageable"] = hc["pageable"]["registrations_per_s"]
+            out["config"]["ms_per_registration_device_resident"] = elapsed / a.steps * 1e3
             # SURVEY 8(d) counts the upload of both clouds as part of a registration: that rate, first class
             out["value_h2d_inclusive"] = hc["pinned"]["registrations_per_s"]
             out["value_h2d_inclusive_note"] = ("the same registration from pinned HOST clouds (both uploads inside the "

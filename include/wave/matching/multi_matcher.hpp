@@ -15,8 +15,10 @@
 // Public surface as in the reference (wave_matching/include/wave/matching/multi_matcher.hpp:
 // 29-96): construct with (n_threads, queue_size, params); insert(id, ref, target) blocks while
 // the job queue is full; done() tells whether every inserted pair has been registered;
-// getResult(&id, &T, &info) -- declared there but never defined -- pops one finished job.
-// The machinery underneath is this file's own: one mutex, two condition variables, plain structs.
+// getResult(&id, &T, &info) -- declared there (multi_matcher.hpp:64-77) but never defined -- pops one
+// finished job, BLOCKING while none is finished but pairs are still pending, as its comment there says.
+// The machinery underneath is this file's own: one mutex, four condition variables (idle workers, the
+// gatherer, insert(), getResult()), a gather protocol for batches, plain structs.
 #ifndef WAVE_MULTI_MATCHER_HPP
 #define WAVE_MULTI_MATCHER_HPP
 
@@ -35,6 +37,17 @@
 #include "wave/matching/pcl_common.hpp"
 #include "wave/utils/math.hpp"
 
+#if defined(__SANITIZE_THREAD__)
+#define WAVE_MATCHING_TSAN 1
+#elif defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+#define WAVE_MATCHING_TSAN 1
+#endif
+#endif
+#ifndef WAVE_MATCHING_TSAN
+#define WAVE_MATCHING_TSAN 0
+#endif
+
 namespace wave {
 
 template <typename T, typename R>
@@ -51,9 +64,17 @@ class MultiMatcher {
         const int crew = std::max(1, std::min(n_threads > 0 ? n_threads : 1, maxWorkers()));
         workers_.reserve(crew);
         const std::vector<int> devs = devices();
+        // workers are dealt onto the device SLOTS round robin; the batched path's bookkeeping (which workers
+        // gather batches, how many batches are in flight) is per slot, so that every listed GPU gets batches
+        const size_t slots = devs.empty() ? 1 : devs.size();
+        batches_in_flight_.assign(slots, 0);
+        idle_batch_workers_.assign(slots, 0);
+        batches_run_.assign(slots, 0);
         for (int w = 0; w < crew; ++w) {
-            const int dev = devs.empty() ? -1 : devs[(size_t) w % devs.size()];
-            workers_.emplace_back([this, dev, w] { work(dev, w); });
+            const int slot = (int) ((size_t) w % slots);
+            const int dev = devs.empty() ? -1 : devs[(size_t) slot];
+            const int rank = (int) ((size_t) w / slots);  // this worker's number among its slot's workers
+            workers_.emplace_back([this, dev, slot, rank] { work(dev, slot, rank); });
         }
     }
 
@@ -65,6 +86,7 @@ class MultiMatcher {
         jobs_changed_.notify_all();
         more_jobs_.notify_all();
         space_free_.notify_all();
+        results_changed_.notify_all();
         for (auto &w : workers_) w.join();
     }
 
@@ -101,6 +123,12 @@ class MultiMatcher {
     }
     /** Number of worker threads of this pool. */
     int workers() const { return static_cast<int>(workers_.size()); }
+    /** Batched launches run so far by the workers of each device slot (slot k = the k-th entry of devices(); one
+     *  slot without a device list).  Diagnostic: tells whether every GPU of the list is being fed batches. */
+    std::vector<int> batchesPerSlot() {
+        std::lock_guard<std::mutex> hold(lock_);
+        return batches_run_;
+    }
 
     MultiMatcher(const MultiMatcher &) = delete;
     MultiMatcher &operator=(const MultiMatcher &) = delete;
@@ -125,9 +153,13 @@ class MultiMatcher {
         return unfinished_ == 0;
     }
 
-    /** Pops the oldest finished registration; false when none is waiting. */
+    /** Pops the oldest finished registration.  Blocks until one is ready while the output is empty but
+     *  inserted pairs are still pending; returns false only when the output is empty AND nothing is pending
+     *  (the contract the reference documents, multi_matcher.hpp:64-77): `insert` N pairs, then
+     *  `while (getResult(...))` collects exactly N. */
     bool getResult(int *id, Eigen::Affine3d *transform, Mat6 *info) {
-        std::lock_guard<std::mutex> hold(lock_);
+        std::unique_lock<std::mutex> hold(lock_);
+        results_changed_.wait(hold, [this] { return !finished_.empty() || unfinished_ == 0 || closing_; });
         if (finished_.empty()) return false;
         const Outcome &o = finished_.front();
         if (id) *id = o.id;
@@ -195,15 +227,18 @@ class MultiMatcher {
         for (const Job &j : taken) pairs.emplace_back(j.ref, j.target);
         typename M::BatchOutcomes got;
         if (!matcher.matchBatch(pairs, got) || got.size() != taken.size()) return false;
-        std::lock_guard<std::mutex> hold(lock_);
-        for (size_t k = 0; k < taken.size(); ++k) {
-            Outcome out;
-            out.id = taken[k].id;
-            out.transform = got[k].transform;
-            out.info = got[k].info;
-            finished_.push_back(out);
-            --unfinished_;
+        {
+            std::lock_guard<std::mutex> hold(lock_);
+            for (size_t k = 0; k < taken.size(); ++k) {
+                Outcome out;
+                out.id = taken[k].id;
+                out.transform = got[k].transform;
+                out.info = got[k].info;
+                finished_.push_back(out);
+                --unfinished_;
+            }
         }
+        results_changed_.notify_all();
         return true;
     }
     template <typename M>
@@ -220,9 +255,12 @@ class MultiMatcher {
         out.id = job.id;
         out.transform = matcher.getResult();
         out.info = matcher.getInfo();
-        std::lock_guard<std::mutex> hold(lock_);
-        finished_.push_back(out);
-        --unfinished_;
+        {
+            std::lock_guard<std::mutex> hold(lock_);
+            finished_.push_back(out);
+            --unfinished_;
+        }
+        results_changed_.notify_all();  // (all: the last result also releases every getResult() that must return false)
     }
 
     // worker body: the matcher lives on this thread's stack, so its device context is created
@@ -243,10 +281,19 @@ class MultiMatcher {
     // stages and launches.  With a queue of 10 the pool now forms the same batches as with a queue of
     // thousands, and more workers only add staging threads: throughput no longer falls with the crew.
     static constexpr int kLingerUs = 30;
-    void work(int device, int index) {
-        // (pairs that batch go to the FIRST max_batches_ workers only: the same few contexts, with their staging
-        // buffers warm, instead of whichever of sixteen wakes up)
-        const bool batch_worker = index < max_batches_;
+    // may a worker of device slot `slot` take the (batchable) pair in front?  Batches are gathered by the first
+    // max_batches_ workers OF EACH SLOT (the same few contexts per GPU, their staging buffers warm), at most
+    // max_batches_ in flight per slot.  Another worker steps in only when no batch worker anywhere could take
+    // the pair (they are all busy registering pairs one at a time): no head-of-line blocking behind them.
+    bool mayGather(int slot, bool batch_worker) const {
+        if (batches_in_flight_[(size_t) slot] >= max_batches_) return false;
+        if (batch_worker) return true;
+        for (size_t s = 0; s < idle_batch_workers_.size(); ++s)
+            if (idle_batch_workers_[s] > 0 && batches_in_flight_[s] < max_batches_) return false;
+        return true;
+    }
+    void work(int device, int slot, int rank) {
+        const bool batch_worker = rank < max_batches_;
         if (device >= 0) bindThread<T>(device, 0);
         T matcher{R(config_)};
         std::vector<Job> taken;
@@ -255,10 +302,12 @@ class MultiMatcher {
             taken.clear();
             {
                 std::unique_lock<std::mutex> hold(lock_);
-                jobs_changed_.wait(hold, [this, &matcher, batch_worker] {
+                if (batch_worker) ++idle_batch_workers_[(size_t) slot];
+                jobs_changed_.wait(hold, [this, &matcher, batch_worker, slot] {
                     return closing_ || (!jobs_.empty() && !gathering_ &&
-                                        (!frontBatchable(matcher, jobs_, 0) || (batch_worker && batches_in_flight_ < max_batches_)));
+                                        (!frontBatchable(matcher, jobs_, 0) || mayGather(slot, batch_worker)));
                 });
+                if (batch_worker) --idle_batch_workers_[(size_t) slot];
                 if (closing_) return;
                 gathering_ = true;
                 takeBatch(matcher, jobs_, taken, 0);
@@ -270,11 +319,17 @@ class MultiMatcher {
                         if (jobs_.empty()) {
                             space_free_.notify_all();  // (the producer may be waiting for the slots just freed)
                             lingering_ = true;
-                            // (wait_until on the system clock = pthread_cond_timedwait; wait_for would be
-                            // pthread_cond_clockwait, which GCC 11's ThreadSanitizer does not know: it then
-                            // misses the unlock inside the wait and reports races that are not there)
+                            // The monotonic clock: a wall-clock step backwards must not stretch the linger (the
+                            // gatherer holds `gathering_` meanwhile).  Under ThreadSanitizer only, the system clock:
+                            // wait_for is pthread_cond_clockwait, which GCC 11's TSan does not know -- it misses the
+                            // unlock inside the wait and reports races that are not there.
+#if WAVE_MATCHING_TSAN
                             const bool more = more_jobs_.wait_until(hold, std::chrono::system_clock::now() + std::chrono::microseconds(kLingerUs),
                                                                     [this] { return closing_ || !jobs_.empty(); });
+#else
+                            const bool more = more_jobs_.wait_for(hold, std::chrono::microseconds(kLingerUs),
+                                                                  [this] { return closing_ || !jobs_.empty(); });
+#endif
                             lingering_ = false;
                             if (!more || closing_) break;
                         }
@@ -286,7 +341,8 @@ class MultiMatcher {
                         job = taken.front();
                         taken.clear();
                     } else {
-                        ++batches_in_flight_;
+                        ++batches_in_flight_[(size_t) slot];
+                        ++batches_run_[(size_t) slot];
                     }
                 }
                 gathering_ = false;
@@ -297,7 +353,7 @@ class MultiMatcher {
                 const bool ran = runBatch(matcher, taken, 0);
                 {
                     std::lock_guard<std::mutex> hold(lock_);
-                    --batches_in_flight_;
+                    --batches_in_flight_[(size_t) slot];
                 }
                 jobs_changed_.notify_all();  // (a worker held back by the bound may gather now)
                 if (!ran)
@@ -324,8 +380,11 @@ class MultiMatcher {
     std::condition_variable jobs_changed_;  // idle workers: a pair is waiting and nobody is gathering
     std::condition_variable more_jobs_;     // the gatherer, between the producer's deliveries
     std::condition_variable space_free_;    // insert(): the queue has room
+    std::condition_variable results_changed_;  // getResult(): a registration finished (or nothing is pending any more)
     bool gathering_ = false, lingering_ = false;
-    int batches_in_flight_ = 0;
+    std::vector<int> batches_in_flight_;    // per device slot
+    std::vector<int> idle_batch_workers_;   // per device slot: batch workers waiting for work
+    std::vector<int> batches_run_;          // per device slot: batches launched so far (batchesPerSlot)
     const int max_batches_ = maxBatchesInFlight();
     std::deque<Job> jobs_;
     std::deque<Outcome, Eigen::aligned_allocator<Outcome>> finished_;

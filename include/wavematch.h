@@ -358,8 +358,13 @@ int wm_set_target_filtered(wm_ctx *ctx, const void *pts, size_t n, size_t stride
  *            (beyond: WM_ERR_ARG).  A pair whose FILTERED cloud is larger is registered by wm_gicp_match.
  * Per item k: status[k] as wm_gicp_match would return it (WM_OK / WM_NOT_CONVERGED / WM_TOO_FEW_CORRESPONDENCES;
  * WM_ERR_STATE for an empty cloud), T_out + 16 k written when WM_OK, stats[k] (may be NULL).
- * Same neighbours, covariances, objective terms and sums as wm_gicp_align; sin / cos / atan2 are the device
- * library's instead of glibc's, so results agree with the one-pair path to ~1e-6 m, not bit for bit.
+ * Same neighbours, covariances, objective terms and (double-double) sums as wm_gicp_align, and the float
+ * sinf / cosf / atan2f / asinf PCL's transform goes through are glibc's algorithms restated (wm_bfgs.hpp), so on
+ * every pair tested the transform, objective value and iteration / evaluation counts EQUAL the one-pair path's and
+ * the oracle's -- which is what tests/test_gicp_batch_gpu.py asserts (np.array_equal).  What is GUARANTEED is
+ * 1e-6 m / 1e-6 rad: the double sin / cos of the gradient's rotation part are the device library's, and a
+ * last-bit difference there can, after hundreds of evaluations of a registration that does not converge, take a
+ * line-search branch the other way.
  * kernel_ms (may be NULL): device time of the launch. */
 #define WM_GICP_BATCH_MAX_POINTS 100000
 int wm_gicp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, size_t stride_bytes, int mem,
@@ -408,7 +413,8 @@ int wm_ndt_build_model(wm_ctx *ctx, double res);
  * the target's voxel model (pcl::VoxelGridCovariance), the Newton steps and the More-Thuente line search all inside the
  * kernel.  Clouds of at most WM_NDT_BATCH_MAX_POINTS points (beyond: WM_ERR_ARG); a pair whose voxel lattice does not
  * fit the kernel's table (262 144 cells) is registered by wm_ndt_align.
- * Per item k: status[k] as wm_ndt_align would return it (WM_OK / WM_NOT_CONVERGED; WM_ERR_STATE for an empty cloud),
+ * Per item k: status[k] as wm_ndt_align would return it (WM_OK / WM_NOT_CONVERGED; WM_ERR_STATE for an empty cloud;
+ * WM_ERR_ARG for a target spanning more than 2^20 voxels along an axis -- e.g. one far-away garbage return),
  * T_out + 16 k written when WM_OK, stats[k] (may be NULL).  Same voxel membership, radius tests and terms as
  * wm_ndt_align; a voxel's sums are formed in double-double instead of in point order and exp / log / sin / cos are the
  * device library's: results agree with the one-pair path to ~1e-9, not bit for bit. */

@@ -4,6 +4,16 @@
 // the device (one registration per workgroup: every thread runs it, the objective is a workgroup-wide sum,
 // wm_gicp_small.hip).  Fn: double fdf(const double x[6], double g[6]); int pairs(); bool failed().
 // [PCL registration/bfgs.h, registration/impl/gicp.hpp]
+//
+// THIRD-PARTY PROVENANCE (none of it is in /root/reference; all restated from published algorithms, no source copied):
+//   * bfgs_minimize / the line search: PCL 1.8's BFGS (BSD-3), itself a C++ rendering of GSL's vector_bfgs2 and
+//     Fletcher's line search (GNU Scientific Library, multimin/vector_bfgs2.c, linear_minimize.c);
+//   * libm_sincosf: the sinf / cosf of glibc >= 2.28, i.e. ARM's "optimized-routines" single-precision algorithm
+//     (MIT / LGPL; constants = its published minimax coefficients);
+//   * libm_atanf / libm_atan2f / libm_asinf: fdlibm's float functions (Sun Microsystems, "Freely distributable"
+//     notice; s_atanf.c, e_atan2f.c, e_asinf.c as glibc 2.35 ships them).
+// Why they are here at all: so that the batched path and the one-pair path (host libm) take the same branches
+// (section 4.5 of DESIGN.md) -- a self-consistency measure of this repo, not a parity requirement of the reference.
 #pragma once
 #include <float.h>
 #include <math.h>

@@ -165,15 +165,24 @@ __device__ __attribute__((noinline)) void ns_build_model(NsShared &S) {
     NdtDense d{S.pr.table, 0, 0, 0, 1, 1, 1};
     long long cells = 1;
     if (cnt > 0) {
-        int l3[3], d3[3];
+        int l3[3] = {0, 0, 0}, d3[3] = {1, 1, 1};
+        bool fits = true;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            l3[a] = (int) floorf(lo[a] * inv) - 2;
-            d3[a] = (int) floorf(hi[a] * inv) - l3[a] + 3;
-            cells *= d3[a] > 0 ? d3[a] : 1;
-            if (d3[a] > (1 << 20)) cells = (long long) kNsCells + 1;
+            // (in double: a finite outlier with |coordinate / res| >= 2^31 -- a garbage lidar return, res down to 0.05 --
+            // saturates an int cast, and the - 2 / + 3 then overflow; wm_ndt.hip does this sum in long long)
+            const double fl = floor((double) (lo[a] * inv)), fh = floor((double) (hi[a] * inv));
+            const double dd = fh - fl + 5.0;
+            if (!(fabs(fl) < 1073741824.0) || !(fabs(fh) < 1073741824.0) || !(dd >= 1.0) || dd > 1048576.0) {
+                fits = false;
+            } else {
+                l3[a] = (int) fl - 2;
+                d3[a] = (int) dd;
+                cells *= d3[a];
+            }
         }
-        d = NdtDense{S.pr.table, l3[0], l3[1], l3[2], d3[0], d3[1], d3[2]};
+        if (!fits) cells = (long long) kNsCells + 1;  // -> unsupported: registered by wm_ndt_align inside the same call
+        else d = NdtDense{S.pr.table, l3[0], l3[1], l3[2], d3[0], d3[1], d3[2]};
     }
     if (tid == 0) {
         S.dense = d;
@@ -866,7 +875,9 @@ int wm_ndt_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, siz
         int rc = wm_set_source(ctx, items[k].src, items[k].n_src, stride, mem);
         if (rc == WM_OK) rc = wm_set_target(ctx, items[k].target, items[k].n_target, stride, mem);
         if (rc == WM_OK) rc = wm_ndt_align(ctx, p, T, &s);
-        if (rc < 0 && rc != WM_ERR_STATE) return rc;
+        // (WM_ERR_ARG here is about THIS pair's data -- a lattice beyond 2^20 voxels along an axis: one garbage
+        // return must not fail the whole batch; device errors do)
+        if (rc < 0 && rc != WM_ERR_STATE && rc != WM_ERR_ARG) return rc;
         status[k] = rc;
         if (stats) stats[k] = s;
         if (rc == WM_OK && T_out) memcpy(T_out + 16 * (size_t) k, T, sizeof(T));

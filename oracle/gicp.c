@@ -12,6 +12,9 @@
  *        estimateRigidTransformationBFGS, OptimizationFunctorWithIndices::{(),df,fdf},
  *        computeRDerivative, applyState)
  *   registration/bfgs.h         (a port of GSL's vector_bfgs2 + Fletcher line search)
+ * THIRD-PARTY PROVENANCE: PCL 1.8 (BSD-3) is restated from its published algorithm, not copied; its BFGS is
+ * in turn GSL's vector_bfgs2 + Fletcher's line search (GNU Scientific Library).  Nothing here comes from
+ * /root/reference, which only calls into PCL.
  * PARITY: unpinned (no PCL to run); pinned to the reference tests' assertions
  * (wave_matching/tests/gicp_tests.cpp:43-100) and a finite-difference gradient check.
  */

@@ -379,6 +379,36 @@ wave::PCLPointCloudPtr subsample(const wave::PCLPointCloudPtr &c, size_t every, 
     return out;
 }
 
+// getResult() as the reference DOCUMENTS it (multi_matcher.hpp:64-77; it declares the method and never defines it):
+// "Will block until a result is ready if the output buffer is empty but there are matches pending ... false if the
+// output queue is empty and there are no matches pending".  Insert N pairs, then `while (getResult(...))` collects
+// exactly N -- without polling done(), and with pairs of both kinds (batched launches and one-by-one registrations).
+AddCase c_multi_blocking("MultiTest.getResultBlocksWhilePairsArePending", [] {
+    wave::ICPMatcherParams p;
+    p.res = -1;
+    p.multiscale_steps = 0;
+    wave::MultiMatcher<wave::ICPMatcher, wave::ICPMatcherParams> pool(3, 10, p);
+    const auto scan = loadScan();
+    std::vector<wave::PCLPointCloudPtr> small;  // (these batch: full resolution, a few thousand points)
+    for (int k = 0; k < 4; ++k) small.push_back(subsample(scan, 9 + (size_t) k, 0.f));
+    const int kPairs = 24;
+    for (int k = 0; k < kPairs; ++k) {
+        if (k % 6 == 5) pool.insert(k, scan, scan);  // (55k points: beyond the batched path, one by one)
+        else pool.insert(k, small[(size_t) k % 4], small[(size_t) k % 4]);
+    }
+    std::set<int> seen;
+    int id = -1;
+    Eigen::Affine3d T;
+    wave::Mat6 info;
+    while (pool.getResult(&id, &T, &info)) {
+        seen.insert(id);
+        EXPECT(distanceTo(wave::Affine3::Identity(), T) < 1e-6);
+    }
+    EXPECT(seen.size() == (size_t) kPairs);
+    EXPECT(pool.done());
+    EXPECT(!pool.getResult(&id, &T, &info));  // nothing pending, nothing waiting: false at once
+});
+
 AddCase c_batch_direct("ICPTest.matchBatchEqualsOneByOne", [] {
     const auto scan = loadScan();
     wave::ICPMatcherParams p;

@@ -5,6 +5,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <set>
 #include <thread>
 
@@ -113,7 +114,87 @@ int main() {
             bad2 = 1;
         }
     }
-    return bad + bad2;
+    // The reference's documented getResult() (multi_matcher.hpp:64-77): "Will block until a result is ready if the
+    // output buffer is empty but there are matches pending ... false if the output queue is empty and there are no
+    // matches pending".  Insert N, then `while (getResult)` must collect exactly N -- no done() polling, no yield.
+    int bad3 = 0;
+    {
+        wave::MultiMatcher<FakeBatchMatcher, FakeParams> pool(5, 10, FakeParams());
+        const int kPairs = 700;
+        for (int j = 0; j < kPairs; ++j) {
+            auto c = boost::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
+            c->points.resize((size_t) (j % 50 + 1));  // odd sizes go one by one, even ones in batches
+            pool.insert(j, c, c);
+        }
+        int id, got = 0;
+        Eigen::Affine3d T;
+        wave::Mat6 info;
+        std::set<int> ids;
+        while (pool.getResult(&id, &T, &info)) {
+            ids.insert(id);
+            ++got;
+        }
+        // two more consumers blocked in getResult() while the last pairs finish must both be released with `false`
+        for (int j = 0; j < 6; ++j) {
+            auto c = boost::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
+            c->points.resize(3);
+            pool.insert(kPairs + j, c, c);
+        }
+        std::atomic<int> late{0};
+        std::thread extra[2];
+        for (auto &t : extra)
+            t = std::thread([&] {
+                int i2;
+                Eigen::Affine3d T2;
+                wave::Mat6 info2;
+                while (pool.getResult(&i2, &T2, &info2)) late.fetch_add(1);
+            });
+        for (auto &t : extra) t.join();
+        std::printf("blocking getResult: %d of %d collected, %d late\n", got, kPairs, late.load());
+        if (got != kPairs || (int) ids.size() != kPairs || late.load() != 6 || !pool.done()) {
+            std::printf("FAILED: blocking getResult lost results\n");
+            bad3 = 1;
+        }
+    }
+    // Batches must reach the workers of EVERY device slot (round 4's advisor finding: with eight devices only the
+    // first four workers -- GPUs 0-3 -- gathered batches).  Eight slots naming no real device (the fake matcher has
+    // no setThreadDevice), one batch in flight per slot, long launches: the gatherers of a busy slot are held back,
+    // so the others must step in.
+    int bad4 = 0;
+    {
+        typedef wave::MultiMatcher<FakeBatchMatcher, FakeParams> Pool;
+        Pool::setDevices({0, 0, 0, 0, 0, 0, 0, 0});
+        setenv("WAVE_MATCHING_MAX_BATCHES", "1", 1);
+        {
+            Pool pool(16, 10, FakeParams());
+            const int kPairs = 6000;
+            std::thread producer([&] {
+                auto c = boost::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
+                c->points.resize(2);
+                for (int j = 0; j < kPairs; ++j) pool.insert(j, c, c);
+            });
+            producer.join();
+            int id, got = 0;
+            Eigen::Affine3d T;
+            wave::Mat6 info;
+            while (pool.getResult(&id, &T, &info)) ++got;
+            const std::vector<int> per = pool.batchesPerSlot();
+            std::printf("device slots: batches per slot");
+            int empty_slots = 0;
+            for (int v : per) {
+                std::printf(" %d", v);
+                empty_slots += v == 0;
+            }
+            std::printf("\n");
+            if (got != kPairs || per.size() != 8u || empty_slots != 0) {
+                std::printf("FAILED: a device slot got no batches\n");
+                bad4 = 1;
+            }
+        }
+        unsetenv("WAVE_MATCHING_MAX_BATCHES");
+        Pool::setDevices({});
+    }
+    return bad + bad2 + bad3 + bad4;
 }
 
 namespace {

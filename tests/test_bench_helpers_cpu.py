@@ -49,7 +49,24 @@ def test_stale_capture_reports_no_traffic(tmp_path, monkeypatch):
         "tag": "new", "csrc_sha256": real_hash,
         "k_nn_grid": {"FETCH_SIZE_kb_per_dispatch": 1.0, "WRITE_SIZE_kb_per_dispatch": 1.0}}))
     assert bench.pmc_summary().get("tag") == "new"
+    # a capture WITHOUT a stamp cannot be tied to the kernels in the tree: stale as well
+    (fake / "pmc_latest.json").write_text(json.dumps({
+        "tag": "unstamped", "k_nn_grid": {"FETCH_SIZE_kb_per_dispatch": 1.0, "WRITE_SIZE_kb_per_dispatch": 1.0}}))
+    unstamped = bench.pmc_summary()
+    assert "stale" in unstamped and "tag" not in unstamped
     monkeypatch.setattr(bench, "ROOT", real_root)
+
+
+def test_rotation_angle_of_identical_float_matrices_is_tiny():
+    """The parity figure of the bench line: two identical float rotations must read ~1e-7 rad, not the 3e-4 that
+    arccos((trace - 1) / 2) makes of their non-orthonormality."""
+    import numpy as np
+    import bench
+    c, s_ = np.float32(np.cos(0.3)), np.float32(np.sin(0.3))
+    R = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], dtype=np.float32).astype(np.float64)
+    assert bench.rotation_angle(R, R) < 1e-6
+    R2 = np.array([[np.cos(0.3001), -np.sin(0.3001), 0], [np.sin(0.3001), np.cos(0.3001), 0], [0, 0, 1]])
+    assert abs(bench.rotation_angle(R, R2) - 1e-4) < 2e-6
 
 
 def test_calibrated_gather_traffic():

@@ -87,6 +87,19 @@ def test_batch_edge_cases(wm, ctx):
     again = ctx.ndt_batch_match([pairs[3], pairs[0]], res=1.0)
     assert np.array_equal(again[0]["T"], got[3]["T"]) and np.array_equal(again[1]["T"], got[0]["T"])
     assert ctx.ndt_batch_match([], res=1.0) == []
+    # one far-away FINITE outlier (a garbage lidar return): |coordinate / res| >= 2^31 must not overflow the lattice
+    # arithmetic of the batched kernel (round 4's advisor finding) -- the item is handed to the one-pair path, which
+    # refuses a lattice of more than 2^20 voxels along an axis; its neighbours in the batch are registered as ever
+    out_tgt = tgt.copy()
+    out_tgt[5] = (np.float32(3.0e9), np.float32(-2.5e9), np.float32(1.0))
+    out_ref = ref.copy()
+    out_ref[9, 0] = np.float32(-4.0e9)
+    got2 = ctx.ndt_batch_match([(ref, out_tgt), (ref, tgt), (out_ref, tgt)], res=1.0)
+    with pytest.raises(wm.WmError):  # (the one-pair call raises for its WM_ERR_ARG)
+        _one(ctx, ref, out_tgt, res=1.0)
+    assert got2[0]["rc"] == wm.WM_ERR_ARG and got2[0]["T"] is None
+    assert np.array_equal(got2[1]["T"], got[0]["T"])
+    _close(got2[2], _one(ctx, out_ref, tgt, res=1.0))
     with pytest.raises(wm.WmError):
         ctx.ndt_batch_match([(ref, tgt)], res=0.0)
 

@@ -25,3 +25,8 @@ def test_multimatcher_pool_is_race_free_under_tsan(tmp_path):
     assert run.returncode == 0 and "OK" in run.stdout, (run.returncode, run.stdout, run.stderr[-1000:])
     # the reference's default queue of 10 must not cap the batches (they are gathered over several refills)
     assert "queue of 10: largest batch" in run.stdout and "capped by the queue" not in run.stdout, run.stdout
+    # getResult() blocks while pairs are pending and returns false once all have been handed out
+    # (wave_matching/include/wave/matching/multi_matcher.hpp:64-77)
+    assert "blocking getResult: 700 of 700 collected, 6 late" in run.stdout, run.stdout
+    # every device slot of an eight-device list is fed batches
+    assert "device slots: batches per slot" in run.stdout and "got no batches" not in run.stdout, run.stdout
