@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--max-corr", type=float, default=3.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-in-flight", action="store_true", help="skip the several-registrations-in-flight measurement")
     ap.add_argument("--cpu-iters", type=int, default=20, help="oracle iterations timed for the baseline")
     return ap.parse_args()
 
@@ -480,6 +481,52 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu, copy_peak=None):
     return out
 
 
+def in_flight_throughput(torch, capi, d_ref, d_tgt, h_ref, h_tgt, a, crews=(1, 2, 4), regs_per_worker=6):
+    """BASELINE configs[1] the way the reference gets THROUGHPUT: wave::MultiMatcher's pattern (multi_matcher.hpp:32,
+    impl/multi_matcher_impl.hpp:30-64) -- one matcher per worker thread, every worker registering its own pairs --
+    with 1M<->1M pairs at full resolution and 50 forced iterations.  Here a worker is a host thread with its own
+    wm_ctx (own HIP stream, own device buffers); the registrations of different workers overlap on the one GPU: one
+    worker's single-workgroup tails and cloud preparation run under another's searches.  Clouds: device-resident
+    (as `value`) and pinned host memory (H2D inside the step).  ctypes releases the GIL inside the C-ABI calls."""
+    out = []
+    for mode, (r_, t_) in (("device-resident clouds", (d_ref, d_tgt)), ("pinned host clouds (H2D inside)", (h_ref, h_tgt))):
+        rows = []
+        for crew in crews:
+            ctxs = [capi.Context(0) for _ in range(crew)]
+
+            def reg(c):
+                c.set_source(r_)
+                c.set_target(t_)
+                return c.icp_align(max_corr=a.max_corr, force_iterations=a.iters, nn_method=capi.WM_NN_GRID, profile=0,
+                                   carry_state=0)
+            for c in ctxs:  # warm-up: allocations, the tuned cell size
+                reg(c)
+                reg(c)
+            torch.cuda.synchronize()
+            errs = []
+            start = threading.Barrier(crew + 1)
+
+            def worker(c):
+                start.wait()
+                for _ in range(regs_per_worker):
+                    r = reg(c)
+                    if r["rc"] != 0:
+                        errs.append(r["rc"])
+            th = [threading.Thread(target=worker, args=(c,)) for c in ctxs]
+            [t.start() for t in th]
+            start.wait()
+            t0 = time.perf_counter()
+            [t.join() for t in th]
+            wall = time.perf_counter() - t0
+            for c in ctxs:
+                c.close()
+            rows.append({"workers": crew, "registrations": crew * regs_per_worker, "seconds": wall,
+                         "registrations_per_s": crew * regs_per_worker / wall, "failed": len(errs)})
+        out.append({"clouds": mode, "rows": rows,
+                    "speedup_2_in_flight": rows[1]["registrations_per_s"] / rows[0]["registrations_per_s"] if len(rows) > 1 else None})
+    return out
+
+
 def relaunch(n):
     """`python bench.py --gpus N` without a launcher: exec `python -m torch.distributed.run --nnodes=1
     --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`."""
@@ -721,6 +768,19 @@ def main():
             out["value_h2d_inclusive"] = hc["pinned"]["registrations_per_s"]
             out["value_h2d_inclusive_note"] = ("the same registration from pinned HOST clouds (both uploads inside the "
                                                "timed step); `value` is with the clouds already in HBM")
+        if world == 1 and dist is None and not a.no_in_flight:
+            # configs[1] with MORE THAN ONE registration in flight (the headline `value` stays one at a time)
+            try:
+                pin_r, pin_t = torch.from_numpy(ref).pin_memory().numpy(), torch.from_numpy(tgt).pin_memory().numpy()
+                fl = in_flight_throughput(torch, capi, d_ref, d_tgt, pin_r, pin_t, a)
+                out["in_flight"] = {"config": "ICPMatcher 1M<->1M, %d forced iterations (BASELINE configs[1]), the MultiMatcher "
+                                              "pattern: one matcher (wm_ctx + stream) per worker thread on ONE GPU" % a.iters,
+                                    "results": fl}
+                for blk, suffix in ((fl[0], ""), (fl[1], "_h2d_inclusive")):
+                    for row in blk["rows"]:
+                        out["config"]["registrations_per_s_%d_in_flight%s" % (row["workers"], suffix)] = row["registrations_per_s"]
+            except Exception as ex:  # (never lose the line over the extra measurement)
+                out["in_flight"] = {"error": str(ex)}
         if world == 1 and not a.no_other_configs:
             out["other_configs"] = other_configs(torch, dev, capi, synth, pmc, not a.no_cpu_baseline, peak_copy)
         if world == 1 and not a.no_cpu_baseline:

@@ -71,6 +71,11 @@ class ICPMatcher : public Matcher<PCLPointCloudPtr> {
     // ... and for the matchers the CALLING THREAD constructs from now on (wave::MultiMatcher spreads its
     // workers over the devices of a node with it); a negative ordinal returns to the default
     static void setThreadDevice(int device);
+    // BENCH ONLY (no reference counterpart): matchers run exactly `n` iterations per align, PCL's stopping rules
+    // switched off -- SURVEY 8(d) C2's "force_iterations = 50", without which fit_eps = 1e-2 (a relative MSE test)
+    // stops a 1M pair after a dozen iterations.  n <= 0 (the default): PCL's rules.  Env
+    // WAVE_ICP_BENCH_FORCE_ITERATIONS does the same.
+    static void setBenchForceIterations(int n);
 
     // Spread ONE registration over several GPUs of the node (no reference counterpart): the target is
     // cut into equal-count x-slabs, one per device, every device searches the source points that fall

@@ -4,12 +4,33 @@
 // dispatch :135-142) and src/icp_pcl_functions.cpp (LUM / LUMold).
 #include "wave/matching/icp.hpp"
 
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+
 #include "shim.hpp"
 
 namespace wave {
 
 void ICPMatcher::setDefaultDevice(int device) { shim::setDefaultDevice(device); }
 void ICPMatcher::setThreadDevice(int device) { shim::setThreadDevice(device); }
+
+namespace {
+std::atomic<int> &benchForceSetting() {
+    static std::atomic<int> n{-1};  // -1: not set (the environment decides)
+    return n;
+}
+int benchForceIterations() {
+    const int n = benchForceSetting().load();
+    if (n >= 0) return n;
+    static const int from_env = [] {
+        const char *e = std::getenv("WAVE_ICP_BENCH_FORCE_ITERATIONS");
+        return e ? std::max(0, std::atoi(e)) : 0;
+    }();
+    return from_env;
+}
+}  // namespace
+void ICPMatcher::setBenchForceIterations(int n) { benchForceSetting().store(n > 0 ? n : 0); }
 
 ICPMatcherParams::ICPMatcherParams(const std::string &config_path) {
     int estimator = 0;
@@ -90,6 +111,10 @@ bool ICPMatcher::match() {
     p.t_eps = params.t_eps;        // setTransformationEpsilon,      icp.cpp:49
     p.fit_eps = params.fit_eps;    // setEuclideanFitnessEpsilon,    icp.cpp:50
     p.carry_state = 1;             // one PCL object per matcher: its criteria remember the last MSE
+    if (const int forced = benchForceIterations()) {  // (bench only: see setBenchForceIterations)
+        p.force_iterations = forced;
+        p.max_iter = std::max(p.max_iter, forced);
+    }
     double T[16];
     wm_icp_stats stats;
     if (devices.size() > 1) {  // one registration over several GPUs (setDevices)

@@ -113,9 +113,34 @@ int main(int argc, char **argv) {
     if (const char *e = std::getenv("BENCH_RES")) params.res = (float) std::atof(e);
     if (const char *e = std::getenv("BENCH_MULTISCALE")) params.multiscale_steps = std::atoi(e);
     std::vector<wave::PCLPointCloudPtr> refs, targets;
+    // BENCH_PAIR = resample (default: the target is an independent re-sampling of the scene, shifted by 0.15 m) or
+    // copy (the target is the ref cloud shifted by 0.15 m + N(0, 1 cm) per coordinate -- what the reference's own tests
+    // register, tests/icp_tests.cpp:31: with it PCL's relative-MSE stop, fit_eps 1e-2, lets sparse 10k-point pairs
+    // converge, and `recovered_shift` counts them; a 10k re-sampling of a 40 x 30 m scene has its points 0.35 m apart,
+    // the MSE barely moves and every pair stops half-way)
+    const char *pair_env = std::getenv("BENCH_PAIR");
+    const bool copy_pairs = pair_env && std::string(pair_env) == "copy";
     for (int k = 0; k < 4; ++k) {  // four distinct pairs, reused round-robin
         refs.push_back(scene(n, 100u + (unsigned) k, 0.f));
-        targets.push_back(scene(n, 200u + (unsigned) k, 0.15f));
+        if (copy_pairs) {
+            auto t = boost::make_shared<pcl::PointCloud<pcl::PointXYZ>>(*refs.back());
+            std::mt19937 rng(300u + (unsigned) k);
+            std::normal_distribution<float> noise(0.f, 0.01f);
+            for (auto &q : t->points) {
+                q.x += 0.15f + noise(rng);
+                q.y += noise(rng);
+                q.z += noise(rng);
+            }
+            targets.push_back(t);
+        } else {
+            targets.push_back(scene(n, 200u + (unsigned) k, 0.15f));
+        }
+    }
+    if (const char *e = std::getenv("BENCH_ESTIMATOR")) {  // LUM (default: LUM + Censi + LUMold run, icp.cpp:135-142) | CENSI | LUM_OLD
+        const std::string v(e);
+        params.covar_estimator = v == "LUM_OLD" ? wave::ICPMatcherParams::covar_method::LUMold
+                                 : v == "CENSI" ? wave::ICPMatcherParams::covar_method::CENSI
+                                                : wave::ICPMatcherParams::covar_method::LUM;
     }
     if (const char *m = std::getenv("BENCH_MATCHER")) {
         if (std::string(m) == "gicp") {
@@ -159,9 +184,10 @@ int main(int argc, char **argv) {
         const auto t0 = std::chrono::steady_clock::now();
         const int ok = drain(pairs);
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        std::printf("{\"bench\": \"wave::MultiMatcher<ICPMatcher>\", \"res\": %g, \"multiscale_steps\": %d, \"points\": %d, \"workers\": %d, \"queue\": %d, "
+        std::printf("{\"bench\": \"wave::MultiMatcher<ICPMatcher>\", \"pair\": \"%s\", \"forced_iterations\": %d, \"res\": %g, \"multiscale_steps\": %d, \"points\": %d, \"workers\": %d, \"queue\": %d, "
                     "\"pairs\": %d, \"seconds\": %.4f, \"registrations_per_s\": %.1f, \"recovered_shift\": %d, "
                     "\"mean_shift_x\": %.4f}\n",
+                    copy_pairs ? "copy + 1 cm noise" : "resample", std::getenv("WAVE_ICP_BENCH_FORCE_ITERATIONS") ? std::atoi(std::getenv("WAVE_ICP_BENCH_FORCE_ITERATIONS")) : 0,
                     (double) params.res, params.multiscale_steps, n, pool.workers(), queue, pairs, s, pairs / s, ok, shift_sum / pairs);
         std::fflush(stdout);
     }
