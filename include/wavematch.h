@@ -324,7 +324,23 @@ typedef struct {
     double gicp_epsilon;  /* PCL default 1e-3 */
     int max_inner;        /* PCL default 20 BFGS iterations per outer iteration */
     int force_iterations; /* >0: exactly this many outer iterations (bench) */
+    int objective;        /* how estimateRigidTransformationBFGS's objective is evaluated: WM_GICP_OBJECTIVE_* below */
+    int reserved;
 } wm_gicp_params;
+/* WM_GICP_OBJECTIVE_STATISTICS (0, the default): between two correspondence searches the pairs and their Mahalanobis
+ * matrices are fixed and the residual is affine in the transform's entries, so the objective PCL sums pair by pair at
+ * every trial point of the line search (OptimizationFunctorWithIndices::fdf, ~170 passes over the pairs per
+ * registration) is formed ONCE per outer iteration as 74 sufficient statistics around the pairing transform; every
+ * evaluation is then scalar work (libwave_amd/csrc/wm_gicp_quad.hpp).  The statistics' base point is PCL's float
+ * residual; away from it the per-point float rounding of PCL's transform (a relative ~4e-7 of f) is absent.  PCL's
+ * BFGS stops at a gradient tolerance of 1e-2 wherever its line search lands, so registrations of noisy pairs end
+ * 1e-5 .. 1e-3 m apart between the two objectives -- the spread PCL's own result has against its summation order --
+ * and pairs that register sharply (the reference's test cases) within 1e-4 m / 1e-5 rad; neither is systematically
+ * closer to ground truth (tests/test_gicp_quad_gpu.py, tests/test_oracle_cpu.py).  Bit for bit the same as the
+ * oracle's restatement of this objective (oracle/gicp.c, objective mode 1), on the one-pair and the batched path.
+ * WM_GICP_OBJECTIVE_PCL_SUMS (1): PCL's per-pair float path, bit for bit the oracle's default mode. */
+#define WM_GICP_OBJECTIVE_STATISTICS 0
+#define WM_GICP_OBJECTIVE_PCL_SUMS 1
 
 typedef struct {
     int converged, iterations, n_corr, inner_total, evaluations;

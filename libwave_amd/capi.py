@@ -61,7 +61,11 @@ class BatchItem(C.Structure):
 class GicpParams(C.Structure):
     _fields_ = [("corr_rand", C.c_int), ("max_iter", C.c_int), ("r_eps", C.c_double),
                 ("t_eps", C.c_double), ("max_corr", C.c_double), ("gicp_epsilon", C.c_double),
-                ("max_inner", C.c_int), ("force_iterations", C.c_int)]
+                ("max_inner", C.c_int), ("force_iterations", C.c_int), ("objective", C.c_int), ("reserved", C.c_int)]
+
+
+WM_GICP_OBJECTIVE_STATISTICS = 0   # the default: 74 sufficient statistics per outer iteration (csrc/wm_gicp_quad.hpp)
+WM_GICP_OBJECTIVE_PCL_SUMS = 1     # PCL's per-pair sums through the float transform
 
 
 class GicpStats(C.Structure):

@@ -8,12 +8,17 @@
 //   k_gicp_mahal  M_i = (C2_j + R C1_i R^T)^-1 for every matched pair
 //   k_gicp_fdf    OptimizationFunctorWithIndices::fdf: f, sum M r (3), sum p (M r)^T (9)
 //                 -> 13 doubles per evaluation; the only thing the optimiser sees
+//   k_gicp_quad   (the default, wm_gicp_params::objective = WM_GICP_OBJECTIVE_STATISTICS) the same objective as 74
+//                 sufficient statistics of the pairs, formed ONCE per outer iteration: the ~40 evaluations of a
+//                 minimisation are then scalar work on the host, no pass over the pairs (wm_gicp_quad.hpp);
+//                 k_gicp_mahal / k_gicp_fdf / the resident evaluator serve WM_GICP_OBJECTIVE_PCL_SUMS
 //   host          estimateRigidTransformationBFGS: pcl::BFGS (GSL vector_bfgs2 with
 //                 Fletcher's line search), applyState, the outer delta test
 // [PCL registration/impl/gicp.hpp, registration/bfgs.h]
 #include "wm_internal.hpp"
 #include "wm_gicp_dev.hpp"
 #include "wm_bfgs.hpp"
+#include "wm_gicp_quad.hpp"
 
 #include <float.h>
 #include <stddef.h>
@@ -204,6 +209,102 @@ __global__ void __launch_bounds__(kBlock)
     if (threadIdx.x < 64) {
         __threadfence_system();
         if (threadIdx.x == 0) *(volatile unsigned *) flag = seq;
+    }
+}
+
+// ---- the objective as sufficient statistics (wm_gicp_quad.hpp).  One pass per outer iteration: every matched
+// pair's Mahalanobis matrix is formed (never stored) and its 74 terms go into double-double sums.  A thread keeps
+// HALF of the accumulators (37 (hi, lo) pairs: all 74 would be 300 registers); blockIdx.y says which half, both
+// halves read the same pairs (the second reading comes from L2).  Rows: [gridDim.x][74] (hi, lo) pairs.
+constexpr int kQuadHalf = kQuadN / 2;
+static_assert(kQuadHalf * 2 == kQuadN, "two equal halves");
+struct QuadT0 {
+    float m[12];
+};
+template <int PART>
+__device__ __forceinline__ void gicp_quad_part(const float4 *__restrict__ src, unsigned n,
+                                               const unsigned long long *__restrict__ keys,
+                                               const float4 *__restrict__ match, const double *__restrict__ C1,
+                                               const double *__restrict__ C2, const QuadT0 &T0,
+                                               double *__restrict__ rows) {
+    double hi[kQuadHalf], lo[kQuadHalf];
+#pragma unroll
+    for (int k = 0; k < kQuadHalf; ++k) hi[k] = lo[k] = 0.0;
+    double R[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) R[a * 3 + b] = (double) T0.m[a * 4 + b];
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const unsigned j = (unsigned) keys[i];
+        const float4 p = src[i], q = match[i];
+        if (j == kNoIdx) continue;
+        double M[9];
+        gicp_mahal_of(C1 + (size_t) i * 9, C2 + (size_t) j * 9, R, M);
+        gicp_quad_terms(T0.m, p.x, p.y, p.z, q.x, q.y, q.z, M, [&](int idx, double term) {
+            if (idx >= PART * kQuadHalf && idx < (PART + 1) * kQuadHalf) ddn_add(hi[idx - PART * kQuadHalf], lo[idx - PART * kQuadHalf], term);
+        });
+    }
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    ddn_halve<kQuadHalf, kQuadHalf, 32>(hi, lo, lane);
+    __shared__ double lds[kBlock / 64][kQuadHalf][2];
+    const int comp = ddn_comp_of_lane<kQuadHalf>(lane);
+    if (comp >= 0) {
+        lds[wave][comp][0] = hi[0];
+        lds[wave][comp][1] = lo[0];
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned) kQuadHalf) {
+        double h = 0, l = 0;
+        for (int w = 0; w < kBlock / 64; ++w) {
+            ddn_add(h, l, lds[w][threadIdx.x][0]);
+            l += lds[w][threadIdx.x][1];
+        }
+        double *row = rows + ((size_t) blockIdx.x * kQuadN + PART * kQuadHalf + threadIdx.x) * 2;
+        row[0] = h;
+        row[1] = l;
+    }
+}
+__global__ void __launch_bounds__(kBlock)
+    k_gicp_quad(const float4 *__restrict__ src, unsigned n, const unsigned long long *__restrict__ keys,
+                const float4 *__restrict__ match, const double *__restrict__ C1, const double *__restrict__ C2,
+                QuadT0 T0, double *__restrict__ rows) {
+    if (blockIdx.y == 0) gicp_quad_part<0>(src, n, keys, match, C1, C2, T0, rows);
+    else gicp_quad_part<1>(src, n, keys, match, C1, C2, T0, rows);
+}
+// the rows -> the 74 sums (each hi + lo rounded once), in pinned memory, then the fence + flag of fast_fetch.
+// One workgroup of 1024: thread t < 962 = 13 x 74 adds the rows t / 74, t / 74 + 13, ... of column t % 74
+// (consecutive lanes read consecutive pairs), wave 0 adds the thirteen partial pairs of every column in order.
+__global__ void __launch_bounds__(1024)
+    k_gicp_quad_fetch(double *dst, const double *__restrict__ rows, unsigned nrows, unsigned *flag, unsigned seq) {
+    constexpr unsigned kGroups = 1024u / (unsigned) kQuadN;  // 13
+    __shared__ double part[kGroups][kQuadN][2];
+    const unsigned t = threadIdx.x;
+    if (t < kGroups * (unsigned) kQuadN) {
+        const unsigned c = t % (unsigned) kQuadN, g = t / (unsigned) kQuadN;
+        double h = 0, l = 0;
+        for (unsigned r = g; r < nrows; r += kGroups) {
+            const double *e = rows + ((size_t) r * kQuadN + c) * 2;
+            ddn_add(h, l, e[0]);
+            l += e[1];
+        }
+        part[g][c][0] = h;
+        part[g][c][1] = l;
+    }
+    __syncthreads();
+    if (t < 64u) {
+        for (unsigned c = t; c < (unsigned) kQuadN; c += 64u) {
+            double h = 0, l = 0;
+            for (unsigned g = 0; g < kGroups; ++g) {
+                ddn_add(h, l, part[g][c][0]);
+                l += part[g][c][1];
+            }
+            dst[c] = h + l;
+        }
+        if (flag) {
+            __threadfence_system();
+            if (t == 0) *(volatile unsigned *) flag = seq;
+        }
     }
 }
 
@@ -638,7 +739,7 @@ static double gicp_fdf(GicpFn &F, const double x[6], double g[6]) {
     // kGicpAcc sums into pinned memory (fast_fetch_sum): no copy engine, no pageable staging,
     // 104 bytes over PCIe -- this loop runs ~180 times per registration and is latency-bound.
     if (!ctx->h_gicp &&
-        hipHostMalloc((void **) &ctx->h_gicp, sizeof(double) * 64,
+        hipHostMalloc((void **) &ctx->h_gicp, sizeof(double) * 128,
                       hipHostMallocDefault) != hipSuccess) {
         F.rc = WM_ERR_HIP;
         ctx->last_error = "gicp_fdf: hipHostMalloc failed";
@@ -686,6 +787,60 @@ static double gicp_fdf(GicpFn &F, const double x[6], double g[6]) {
 }
 
 double GicpFn::fdf(const double x[6], double g[6]) { return gicp_fdf(*this, x, g); }
+
+// ---- the statistics objective on the host: what bfgs_minimize asks of its objective (wm_bfgs.hpp), answered from
+// the 74 sums of the pairs (no device work per evaluation)
+struct GicpQuadFn {
+    double Q[kQuadN];
+    float T0[12];
+    const double *base;
+    int m = 0;
+    int evals = 0;
+    int pairs() const { return m; }
+    bool failed() const { return false; }
+    double fdf(const double x[6], double g[6]) {
+        ++evals;
+        const double f = gicp_quad_eval(Q, T0, base, x, g);
+        if (const char *path = getenv("WM_GICP_TRACE")) {  // developer: every evaluation (as gicp_fdf prints them)
+            if (FILE *fp = fopen(path, "a")) {
+                fprintf(fp, "%d", m);
+                for (int k = 0; k < 6; ++k) fprintf(fp, " %.17g", x[k]);
+                fprintf(fp, " | %.17g |", f);
+                if (g) for (int k = 0; k < 6; ++k) fprintf(fp, " %.17g", g[k]);
+                fprintf(fp, "\n");
+                fclose(fp);
+            }
+        }
+        return f;
+    }
+};
+// the 74 sums of the pairs the last search left (keys / match_pt), found under the float transform T -> F
+static int gicp_quad_statistics(wm_ctx *ctx, const float T[16], GicpQuadFn &F, float *kernel_ms) {
+    const unsigned n = (unsigned) ctx->n_src;
+    const int nb = gicp_blocks(ctx);
+    WM_HIP(ctx, ctx->partials.reserve((size_t) kGicpBlocksMax * kQuadN * 2 * sizeof(double) + 64));
+    if (!ctx->h_gicp) WM_HIP(ctx, hipHostMalloc((void **) &ctx->h_gicp, sizeof(double) * 128, hipHostMallocDefault));
+    QuadT0 T0;
+    for (int k = 0; k < 12; ++k) T0.m[k] = F.T0[k] = T[k];
+    if (ctx->gicp_profile) (void) hipEventRecord(ctx->ev_a, ctx->stream);
+    hipLaunchKernelGGL(k_gicp_quad, dim3((unsigned) nb, 2), dim3(kBlock), 0, ctx->stream, ctx->src_sorted.as<float4>(), n,
+                       ctx->keys.as<unsigned long long>(), ctx->match_pt.as<float4>(), ctx->gicp_c1.as<double>(),
+                       ctx->gicp_c2.as<double>(), T0, ctx->partials.as<double>());
+    WM_HIP(ctx, hipGetLastError());
+    if (ctx->gicp_profile) (void) hipEventRecord(ctx->ev_b, ctx->stream);
+    WM_TRY(fast_fetch_custom(ctx, [&](unsigned *flag, unsigned seq) {
+        hipLaunchKernelGGL(k_gicp_quad_fetch, dim3(1), dim3(1024), 0, ctx->stream, ctx->h_gicp, ctx->partials.as<double>(),
+                           (unsigned) nb, flag, seq);
+    }));
+    if (ctx->gicp_profile && kernel_ms) {
+        float ms = 0;
+        (void) hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b);
+        *kernel_ms += ms;
+    }
+    for (int k = 0; k < kQuadN; ++k) F.Q[k] = ctx->h_gicp[k];
+    F.m = (int) F.Q[kQuadOffCount];
+    return WM_OK;
+}
 
 static float choose_cell(const Bbox &bb, size_t n) {
     double vol = 1;
@@ -853,8 +1008,8 @@ int wm_gicp_align(wm_ctx *ctx, const wm_gicp_params *prm, double T_out[16], wm_g
     if ((size_t) prm->corr_rand > ctx->n_src || (size_t) prm->corr_rand > ctx->n_tgt) return WM_NOT_CONVERGED;
     WM_TRY(compute_covariances(ctx, prm->corr_rand, prm->gicp_epsilon));
     const size_t n = ctx->n_src;
-    WM_HIP(ctx, ctx->gicp_mahal.reserve(n * 9 * sizeof(double)));
-    WM_HIP(ctx, ctx->partials.reserve((size_t) kGicpBlocksMax * kGicpAcc * 2 * sizeof(double) + 64));
+    if (prm->objective == WM_GICP_OBJECTIVE_PCL_SUMS) WM_HIP(ctx, ctx->gicp_mahal.reserve(n * 9 * sizeof(double)));
+    WM_HIP(ctx, ctx->partials.reserve((size_t) kGicpBlocksMax * kQuadN * 2 * sizeof(double) + 64));
     const float thr = threshold_d2_strict(prm->max_corr);
     double base[16];
     mat4_identity(base);
@@ -863,6 +1018,9 @@ int wm_gicp_align(wm_ctx *ctx, const wm_gicp_params *prm, double T_out[16], wm_g
     GicpFn F;
     F.ctx = ctx;
     F.base = base;
+    const bool statistics = prm->objective != WM_GICP_OBJECTIVE_PCL_SUMS;
+    GicpQuadFn Q;
+    Q.base = base;
     const int max_it = prm->force_iterations > 0 ? prm->force_iterations : prm->max_iter;
     int iter = 0, inner_total = 0;
     bool converged = false;
@@ -892,21 +1050,31 @@ int wm_gicp_align(wm_ctx *ctx, const wm_gicp_params *prm, double T_out[16], wm_g
             const double cell = ctx->levels[0].built ? (double) ctx->levels[0].d.h : 0.0;
             seeded = sqrt(dt2) + sqrt(dr2 * rad2) < 0.75 * cell;
         }
-        WM_TRY(nn_pass(ctx, Td, thr, prm->max_corr, seeded, false, 0.f, 0.f, /*wait=*/false));  // (count_matched below waits)
-        Mat3d R;
-        for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) R.m[a * 3 + b] = (double) T[a * 4 + b];
-        hipLaunchKernelGGL(k_gicp_mahal, dim3(blocks), dim3(kBlock), 0, ctx->stream, (unsigned) n,
-                           ctx->keys.as<unsigned long long>(), ctx->gicp_c1.as<double>(),
-                           ctx->gicp_c2.as<double>(), R, ctx->gicp_mahal.as<double>());
-        WM_TRY(count_matched(ctx, n, &cnt));
-        memcpy(prevT, T, sizeof(T));
+        WM_TRY(nn_pass(ctx, Td, thr, prm->max_corr, seeded, false, 0.f, 0.f, /*wait=*/false));  // (the fetch below waits)
+        int inner;
         double x[6] = {T[3], T[7], T[11], atan2(T[9], T[10]), asin(-T[8]), atan2(T[4], T[0])};
-        F.m = (int) cnt;
-        serve_begin(F);
-        const int inner = bfgs_minimize(F, x, prm->max_inner, &f_last);
-        serve_end(F);
-        if (F.rc != WM_OK) return F.rc;
+        if (statistics) {
+            // ONE pass over the pairs: Mahalanobis matrices formed on the fly, 74 sums out; the minimisation's
+            // evaluations are then scalar work here (wm_gicp_quad.hpp)
+            WM_TRY(gicp_quad_statistics(ctx, T, Q, &F.kernel_ms));
+            cnt = (unsigned) Q.m;
+            memcpy(prevT, T, sizeof(T));
+            inner = bfgs_minimize(Q, x, prm->max_inner, &f_last);
+        } else {
+            Mat3d R;
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) R.m[a * 3 + b] = (double) T[a * 4 + b];
+            hipLaunchKernelGGL(k_gicp_mahal, dim3(blocks), dim3(kBlock), 0, ctx->stream, (unsigned) n,
+                               ctx->keys.as<unsigned long long>(), ctx->gicp_c1.as<double>(),
+                               ctx->gicp_c2.as<double>(), R, ctx->gicp_mahal.as<double>());
+            WM_TRY(count_matched(ctx, n, &cnt));
+            memcpy(prevT, T, sizeof(T));
+            F.m = (int) cnt;
+            serve_begin(F);
+            inner = bfgs_minimize(F, x, prm->max_inner, &f_last);
+            serve_end(F);
+            if (F.rc != WM_OK) return F.rc;
+        }
         if (inner < 0) break;  // NotEnoughPointsException: loop breaks, converged_ stays false
         inner_total += inner;
         state_to_matrix_f(base, x, T);
@@ -930,7 +1098,7 @@ int wm_gicp_align(wm_ctx *ctx, const wm_gicp_params *prm, double T_out[16], wm_g
         stats->iterations = iter;
         stats->n_corr = (int) cnt;
         stats->inner_total = inner_total;
-        stats->evaluations = F.evals;
+        stats->evaluations = F.evals + Q.evals;
         stats->f_final = f_last;
         stats->fdf_kernel_ms = F.kernel_ms;
         stats->served_evaluations = F.served_total;
@@ -953,13 +1121,30 @@ int wm_gicp_eval(wm_ctx *ctx, const wm_gicp_params *prm, const double T_pair[16]
     WM_TRY(compute_covariances(ctx, prm->corr_rand, prm->gicp_epsilon));
     const size_t n = ctx->n_src;
     WM_HIP(ctx, ctx->gicp_mahal.reserve(n * 9 * sizeof(double)));
-    WM_HIP(ctx, ctx->partials.reserve((size_t) kGicpBlocksMax * kGicpAcc * 2 * sizeof(double) + 64));
+    WM_HIP(ctx, ctx->partials.reserve((size_t) kGicpBlocksMax * kQuadN * 2 * sizeof(double) + 64));
     double Td[16];
     Mat3d R;
     for (int i = 0; i < 16; ++i) Td[i] = (double) (float) T_pair[i];
     for (int a = 0; a < 3; ++a)
         for (int b = 0; b < 3; ++b) R.m[a * 3 + b] = Td[a * 4 + b];
     WM_TRY(nn_pass(ctx, Td, threshold_d2_strict(prm->max_corr), prm->max_corr, false));
+    if (prm->objective != WM_GICP_OBJECTIVE_PCL_SUMS) {  // the statistics objective: the 74 sums under T_pair, evaluated at x
+        double base[16];
+        mat4_identity(base);
+        GicpQuadFn Q;
+        Q.base = base;
+        float Tf[16];
+        for (int i = 0; i < 16; ++i) Tf[i] = (float) T_pair[i];
+        WM_TRY(gicp_quad_statistics(ctx, Tf, Q, nullptr));
+        ctx->have_corr = true;
+        ctx->last_align_valid = false;
+        if (n_pairs) *n_pairs = Q.m;
+        if (Q.m == 0) return WM_TOO_FEW_CORRESPONDENCES;
+        double gg[6];
+        *f = Q.fdf(x, gg);
+        if (g) memcpy(g, gg, sizeof(gg));
+        return WM_OK;
+    }
     const unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
     unsigned cnt = 0;
     hipLaunchKernelGGL(k_gicp_mahal, dim3(blocks), dim3(kBlock), 0, ctx->stream, (unsigned) n,

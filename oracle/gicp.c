@@ -233,6 +233,108 @@ double wmo_gicp_fdf(const float *src, const float *tgt, const int *src_idx, cons
     return f / m;
 }
 
+/* ------------------------------------------------------------------ the objective as sufficient statistics
+ * Objective mode 1 (wmo_gicp_set_objective): NOT PCL's arithmetic but the HIP path's default
+ * (libwave_amd/csrc/wm_gicp_quad.hpp -- read its header for the algebra): between two correspondence searches the
+ * pairs and their Mahalanobis matrices are fixed and the residual is affine in the transform's entries, so
+ *     sum r^T M r = C0 + sum_aj D_aj (B0_aj + G_aj),   G_aj = B0_aj + sum_ck D_ck A_(ac)(jk),   D = T(x) - T0,
+ * with 74 sums over the pairs formed once per outer iteration (A: 60, B0: 12, C0, the count) around T0, the
+ * transform the pairs were found under.  r0 = T0 p - q is PCL's float residual; away from T0 the per-point float
+ * rounding of PCL's transform (a relative ~4e-7 of f) is absent.  The oracle restates it so that the HIP path can
+ * be held to it bit for bit (same terms, double-double sums, same evaluation order), while mode 0 -- PCL's per-pair
+ * sums -- says how far this objective's registrations are from PCL's (tests/test_gicp_quad_gpu.py, test_oracle_cpu.py). */
+static int g_gicp_objective = 0;
+void wmo_gicp_set_objective(int mode) { g_gicp_objective = mode ? 1 : 0; }
+int wmo_gicp_get_objective(void) { return g_gicp_objective; }
+
+enum { QUAD_N = 74, QUAD_OFF_B = 60, QUAD_OFF_C = 72, QUAD_OFF_COUNT = 73 };
+static int quad_s6(int a, int c) {
+    const int lo = a < c ? a : c, hi = a < c ? c : a;
+    return lo == 0 ? hi : (lo == 1 ? 2 + hi : 5);
+}
+static int quad_s10(int j, int k) {
+    const int lo = j < k ? j : k, hi = j < k ? k : j;
+    return lo == 0 ? hi : (lo == 1 ? 3 + hi : (lo == 2 ? 5 + hi : 9));
+}
+/* the 74 sums of the pairs (si, ti, mahal) found under the float transform T0 (always double-double: one rounding) */
+static void quad_statistics(const float *src, const float *tgt, const int *src_idx, const int *tgt_idx,
+                            const double *mahal, int m, const float T0[16], double Q[QUAD_N]) {
+    double hi[QUAD_N] = {0}, lo[QUAD_N] = {0};
+    const int keep = g_gicp_summation;
+    int i, a, j, k, s, t;
+    g_gicp_summation = 0;
+    for (i = 0; i < m; ++i) {
+        const float *ps = src + 3 * src_idx[i], *pt = tgt + 3 * tgt_idx[i];
+        const double *M = mahal + 9 * src_idx[i];
+        float pp[3];
+        double r0[3], Ms[6], z[4], zz[10], t0[3];
+        mul_pt_f(T0, ps, pp);
+        r0[0] = pp[0] - pt[0]; /* float subtraction, then widened */
+        r0[1] = pp[1] - pt[1];
+        r0[2] = pp[2] - pt[2];
+        Ms[0] = M[0];
+        Ms[1] = 0.5 * (M[1] + M[3]);
+        Ms[2] = 0.5 * (M[2] + M[6]);
+        Ms[3] = M[4];
+        Ms[4] = 0.5 * (M[5] + M[7]);
+        Ms[5] = M[8];
+        z[0] = ps[0];
+        z[1] = ps[1];
+        z[2] = ps[2];
+        z[3] = 1.0;
+        for (j = 0; j < 4; ++j)
+            for (k = j; k < 4; ++k) zz[quad_s10(j, k)] = z[j] * z[k];
+        for (s = 0; s < 6; ++s)
+            for (t = 0; t < 10; ++t) dd_add(&hi[s * 10 + t], &lo[s * 10 + t], Ms[s] * zz[t]);
+        for (a = 0; a < 3; ++a) t0[a] = (Ms[quad_s6(a, 0)] * r0[0] + Ms[quad_s6(a, 1)] * r0[1]) + Ms[quad_s6(a, 2)] * r0[2];
+        for (a = 0; a < 3; ++a)
+            for (j = 0; j < 4; ++j) dd_add(&hi[QUAD_OFF_B + a * 4 + j], &lo[QUAD_OFF_B + a * 4 + j], t0[a] * z[j]);
+        dd_add(&hi[QUAD_OFF_C], &lo[QUAD_OFF_C], (r0[0] * t0[0] + r0[1] * t0[1]) + r0[2] * t0[2]);
+        dd_add(&hi[QUAD_OFF_COUNT], &lo[QUAD_OFF_COUNT], 1.0);
+    }
+    g_gicp_summation = keep;
+    for (i = 0; i < QUAD_N; ++i) Q[i] = hi[i] + lo[i];
+}
+/* f and gradient at x from the statistics (gicp_quad_eval of wm_gicp_quad.hpp, operation for operation) */
+static double quad_eval(const double Q[QUAD_N], const float T0[16], const double base[16], const double x[6], double g[6]) {
+    float T[16];
+    double D[12], G[12], fm, m;
+    int a, b, c, j, k;
+    state_to_matrix_f(base, x, T);
+    for (k = 0; k < 12; ++k) D[k] = (double) T[k] - (double) T0[k];
+    for (a = 0; a < 3; ++a)
+        for (j = 0; j < 4; ++j) {
+            double s = Q[QUAD_OFF_B + a * 4 + j];
+            for (c = 0; c < 3; ++c)
+                for (k = 0; k < 4; ++k) s += D[c * 4 + k] * Q[quad_s6(a, c) * 10 + quad_s10(j, k)];
+            G[a * 4 + j] = s;
+        }
+    fm = Q[QUAD_OFF_C];
+    for (k = 0; k < 12; ++k) fm += D[k] * (Q[QUAD_OFF_B + k] + G[k]);
+    m = Q[QUAD_OFF_COUNT];
+    if (g) {
+        double Racc[9];
+        for (a = 0; a < 3; ++a) g[a] = G[a * 4 + 3] * 2.0 / m;
+        for (a = 0; a < 3; ++a)
+            for (b = 0; b < 3; ++b) {
+                double s = 0.0;
+                for (j = 0; j < 4; ++j) s += base[a * 4 + j] * G[b * 4 + j];
+                Racc[a * 3 + b] = s * 2.0 / m;
+            }
+        r_derivative(x, Racc, g);
+    }
+    return fm / m;
+}
+/* test hook: the statistics objective evaluated once (pairs found under T0, state x) */
+double wmo_gicp_fdf_statistics(const float *src, const float *tgt, const int *src_idx, const int *tgt_idx,
+                               const double *mahal, int m, const double base[16], const float T0[16],
+                               const double x[6], double g[6], double Q_out[74]) {
+    double Q[QUAD_N];
+    quad_statistics(src, tgt, src_idx, tgt_idx, mahal, m, T0, Q);
+    if (Q_out) memcpy(Q_out, Q, sizeof(Q));
+    return quad_eval(Q, T0, base, x, g);
+}
+
 /* ------------------------------------------------------------------ BFGS
  * pcl::BFGS (registration/bfgs.h), itself GSL's vector_bfgs2: a memoryless BFGS
  * direction update with Fletcher's bracketing / sectioning line search. */
@@ -243,13 +345,17 @@ typedef struct {
     int m;
     const double *base;
     int evals;
+    int quad;            /* objective mode 1: evaluate from Q */
+    double Q[QUAD_N];
+    float T0[16];
 } gicp_fn;
 
 static double fn_fdf(gicp_fn *F, const double x[6], double g[6]) {
     double f;
     const char *path = getenv("WMO_GICP_TRACE"); /* developer: every evaluation, in hex floats */
     F->evals++;
-    f = wmo_gicp_fdf(F->src, F->tgt, F->si, F->ti, F->mahal, F->m, F->base, x, g);
+    f = F->quad ? quad_eval(F->Q, F->T0, F->base, x, g)
+                : wmo_gicp_fdf(F->src, F->tgt, F->si, F->ti, F->mahal, F->m, F->base, x, g);
     if (path) {
         FILE *fp = fopen(path, "a");
         if (fp) {
@@ -574,7 +680,7 @@ int wmo_gicp_align(const float *src, int n, const float *tgt, int m, const wmo_g
     wmo_kdtree *tree;
     float T[16], prevT[16];
     double base[16], f_last = 0;
-    int iter = 0, converged = 0, i, a, b, c, cnt = 0, inner_total = 0, rc = 1;
+    int iter = 0, converged = 0, i, a, b, c, cnt = 0, inner_total = 0, rc = 1, evals_total = 0;
     const double dist_thr = prm->max_corr * prm->max_corr;
     const int max_it = prm->force_iterations > 0 ? prm->force_iterations : prm->max_iter;
     for (i = 0; i < 16; ++i) T[i] = (i % 5 == 0);
@@ -636,7 +742,13 @@ int wmo_gicp_align(const float *src, int n, const float *tgt, int m, const wmo_g
         F.m = cnt;
         F.base = base;
         F.evals = 0;
+        F.quad = g_gicp_objective;
+        if (F.quad && cnt > 0) {
+            memcpy(F.T0, T, sizeof(T));
+            quad_statistics(src, tgt, si, ti, mahal, cnt, F.T0, F.Q);
+        }
         inner = bfgs_minimize(&F, x, prm->max_inner, &f_last);
+        evals_total += F.evals;
         if (inner < 0) break; /* exception -> the loop breaks, converged_ stays false */
         inner_total += inner;
         state_to_matrix_f(base, x, T); /* transformation_matrix.setIdentity(); applyState */
@@ -668,6 +780,8 @@ done:
         res->n_corr = cnt;
         res->inner_total = inner_total;
         res->f_final = f_last;
+        res->evaluations = evals_total;
+        res->reserved = 0;
     }
     free(C1);
     free(C2);

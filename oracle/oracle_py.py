@@ -51,7 +51,8 @@ class GicpParams(C.Structure):
 
 class GicpResult(C.Structure):
     _fields_ = [("converged", C.c_int), ("iterations", C.c_int), ("n_corr", C.c_int),
-                ("inner_total", C.c_int), ("f_final", C.c_double)]
+                ("inner_total", C.c_int), ("f_final", C.c_double), ("evaluations", C.c_int),
+                ("reserved", C.c_int)]
 
 
 class NdtParams(C.Structure):
@@ -389,7 +390,31 @@ def gicp_align(src, tgt, params=None, **kw):
     rc = lib().wmo_gicp_align(_p(src, _fp), len(src), _p(tgt, _fp), len(tgt), C.byref(p),
                               _p(T, _dp), C.byref(r))
     return dict(rc=rc, T=T, converged=bool(r.converged), iterations=r.iterations,
-                n_corr=r.n_corr, inner_total=r.inner_total, f=r.f_final)
+                n_corr=r.n_corr, inner_total=r.inner_total, f=r.f_final, evaluations=r.evaluations)
+
+
+def gicp_set_objective(mode):
+    """0: PCL's per-pair sums through the float transform (default); 1: the same objective as 74 sufficient
+    statistics formed once per outer iteration -- the HIP path's default (oracle/gicp.c).  Process-wide."""
+    lib().wmo_gicp_set_objective(int(mode))
+
+
+def gicp_fdf_statistics(src, tgt, src_idx, tgt_idx, mahal, base, T0, x):
+    """(f, g, Q): the statistics objective evaluated once (pairs found under the float transform T0)."""
+    src, tgt = _f32(src), _f32(tgt)
+    si = np.ascontiguousarray(src_idx, np.int32)
+    ti = np.ascontiguousarray(tgt_idx, np.int32)
+    M = np.ascontiguousarray(mahal, np.float64)
+    base = np.ascontiguousarray(base, np.float64)
+    T0 = np.ascontiguousarray(T0, np.float32)
+    x = np.ascontiguousarray(x, np.float64)
+    g, Q = np.zeros(6), np.zeros(74)
+    L = lib()
+    L.wmo_gicp_fdf_statistics.restype = C.c_double
+    L.wmo_gicp_fdf_statistics.argtypes = [_fp, _fp, _ip, _ip, _dp, C.c_int, _dp, _fp, _dp, _dp, _dp]
+    f = L.wmo_gicp_fdf_statistics(_p(src, _fp), _p(tgt, _fp), _p(si, _ip), _p(ti, _ip), _p(M, _dp), len(si),
+                                  _p(base, _dp), _p(T0, _fp), _p(x, _dp), _p(g, _dp), _p(Q, _dp))
+    return f, g, Q
 
 
 def gicp_fdf(src, tgt, src_idx, tgt_idx, mahal, base, x):

@@ -156,11 +156,23 @@ typedef struct {
 typedef struct {
     int converged, iterations, n_corr, inner_total;
     double f_final;
+    int evaluations;       /* objective evaluations of all minimisations */
+    int reserved;
 } wmo_gicp_result;
 void wmo_gicp_default_params(wmo_gicp_params *p);
 /* summation of the objective's sums: 0 double-double (default), 1 PCL-literal plain doubles in index order */
 void wmo_gicp_set_summation(int mode);
 int wmo_gicp_get_summation(void);
+/* the objective the minimisations evaluate: 0 (default) PCL's per-pair sums through the float transform
+ * (OptimizationFunctorWithIndices::fdf); 1 the same objective as 74 sufficient statistics formed once per outer
+ * iteration around the pairing transform -- the HIP path's default (libwave_amd/csrc/wm_gicp_quad.hpp) */
+void wmo_gicp_set_objective(int mode);
+int wmo_gicp_get_objective(void);
+/* the statistics objective once: pairs found under the float transform T0 (row-major 4x4), evaluated at state x
+ * on `base`; Q_out (may be NULL) receives the 74 sums */
+double wmo_gicp_fdf_statistics(const float *src, const float *tgt, const int *src_idx, const int *tgt_idx,
+                               const double *mahal, int n_pairs, const double base[16], const float T0[16],
+                               const double x[6], double g[6], double Q_out[74]);
 /* per-point covariances (n x 9 doubles, row-major 3x3) */
 int wmo_gicp_covariances(const float *xyz, int n, int k, double eps, double *cov);
 int wmo_gicp_align(const float *src, int n, const float *tgt, int m,

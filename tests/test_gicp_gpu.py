@@ -9,6 +9,20 @@ from libwave_amd import synth
 
 pytestmark = pytest.mark.gpu
 
+# The objective of the minimisations comes in two forms (include/wavematch.h: wm_gicp_params::objective): the default,
+# 74 sufficient statistics formed once per outer iteration (csrc/wm_gicp_quad.hpp), and PCL's per-pair sums through the
+# float transform.  The oracle restates both (oracle/gicp.c: wmo_gicp_set_objective); the HIP path is held to each
+# BIT FOR BIT.  How far the two objectives' registrations are apart: tests/test_gicp_quad_gpu.py.
+OBJECTIVES = [("statistics", 0, 1), ("pcl_sums", 1, 0)]   # (name, wm_gicp_params::objective, oracle objective mode)
+
+
+@pytest.fixture(params=OBJECTIVES, ids=[o[0] for o in OBJECTIVES])
+def objective(request, oracle):
+    name, hip, orc = request.param
+    oracle.gicp_set_objective(orc)
+    yield hip
+    oracle.gicp_set_objective(0)
+
 
 # one value per neighbour-list instantiation of k_gicp_cov (8, 10, 12, 16, 20, 24, 32) + edges
 @pytest.mark.parametrize("k", [3, 8, 10, 11, 16, 20, 23, 32])
@@ -54,11 +68,11 @@ CASES = [("fullResNullMatch", -1.0, 0.0), ("nullDisplacement", 0.05, 0.0),
 
 
 @pytest.mark.parametrize("name,res,tx", CASES)
-def test_reference_gicp_cases(wm, ctx, oracle, testscan, name, res, tx):
+def test_reference_gicp_cases(wm, ctx, oracle, testscan, objective, name, res, tx):
     P = np.eye(4)
     P[0, 3] = tx
     target = oracle.transform_cloud_d(testscan, P)
-    got = ctx.gicp_match(testscan, target, res=res)     # GICPMatcherParams defaults
+    got = ctx.gicp_match(testscan, target, res=res, objective=objective)     # GICPMatcherParams defaults
     a = testscan if res < 0 else oracle.voxel_grid(testscan, res)
     b = target if res < 0 else oracle.voxel_grid(target, res)
     want = oracle.gicp_align(a, b)
@@ -78,7 +92,7 @@ def test_gicp_objective_and_gradient_match_oracle(wm, ctx, oracle):
     ctx.set_target(tgt)
     T_pair = synth.make_T((0.1, -0.05, 0.02), (0.004, -0.01, 0.015)).astype(np.float32).astype(np.float64)
     x = np.array([0.12, -0.06, 0.03, 0.005, -0.012, 0.017])
-    f, g, m = ctx.gicp_eval(T_pair, x)
+    f, g, m = ctx.gicp_eval(T_pair, x, objective=wm.WM_GICP_OBJECTIVE_PCL_SUMS)
     gi, gd = ctx.correspondences()
     moved = oracle.transform_cloud_f(ref, T_pair.astype(np.float32))
     oi, od = oracle.KdTree(tgt).nn(moved)
@@ -93,9 +107,25 @@ def test_gicp_objective_and_gradient_match_oracle(wm, ctx, oracle):
     of, og = oracle.gicp_fdf(ref, tgt, si, oi[si], M, np.eye(4), x)
     assert abs(f - of) <= 1e-12 * abs(of)   # (M through numpy's inverse here: last-bit differences in the terms)
     np.testing.assert_allclose(g, og, rtol=1e-10, atol=1e-10 * np.abs(og).max())
+    # ... and the statistics objective (the default): the 74 sums of the same pairs, found under T_pair, evaluated at x
+    f2, g2, m2 = ctx.gicp_eval(T_pair, x)
+    qf, qg, Q = oracle.gicp_fdf_statistics(ref, tgt, si, oi[si], M, np.eye(4), T_pair.astype(np.float32), x)
+    assert m2 == m and Q[73] == m
+    assert abs(f2 - qf) <= 1e-12 * abs(qf)
+    np.testing.assert_allclose(g2, qg, rtol=1e-10, atol=1e-10 * np.abs(qg).max())
+    # the two objectives are the same function up to the float rounding of PCL's per-point transform (away from the
+    # pairing transform): a relative 1e-6 of f at most on 30 000 pairs
+    assert abs(f2 - f) <= 3e-6 * abs(f)
+    np.testing.assert_allclose(g2, g, rtol=0, atol=3e-5 * np.abs(g).max())
+    # at the pairing transform itself the statistics' constant term IS PCL's sum
+    x0 = np.array([T_pair[0, 3], T_pair[1, 3], T_pair[2, 3], np.arctan2(np.float32(T_pair[2, 1]), np.float32(T_pair[2, 2])),
+                   np.arcsin(-np.float32(T_pair[2, 0])), np.arctan2(np.float32(T_pair[1, 0]), np.float32(T_pair[0, 0]))])
+    fa, _, _ = ctx.gicp_eval(T_pair, x0, objective=wm.WM_GICP_OBJECTIVE_PCL_SUMS)
+    fb, _, _ = ctx.gicp_eval(T_pair, x0)
+    assert abs(fa - fb) <= 2e-5 * abs(fa)   # (x0 -> float matrix reproduces T_pair to an ulp or two of its entries)
 
 
-def test_gicp_on_noisy_synthetic_pair(wm, ctx, oracle):
+def test_gicp_on_noisy_synthetic_pair(wm, ctx, oracle, objective):
     """BASELINE config 3 shape (resample pair with noise), small enough for the oracle.
     PCL's inner optimiser (BFGS, gradient tolerance 1e-2, objective evaluated through a
     float-quantised transform) stops wherever its line search lands, so a last-bit difference in f
@@ -108,11 +138,12 @@ def test_gicp_on_noisy_synthetic_pair(wm, ctx, oracle):
         ref, tgt, T_gt = synth.pair(n, seed=seed)
         ctx.set_source(ref)
         ctx.set_target(tgt)
-        got = ctx.gicp_align()
+        got = ctx.gicp_align(objective=objective)
         want = oracle.gicp_align(ref, tgt)
         assert got["rc"] == 0 and got["converged"] and want["converged"]
         assert got["n_corr"] == want["n_corr"]
         assert got["iterations"] == want["iterations"] and got["inner_total"] == want["inner_total"]
+        assert got["evaluations"] == want["evaluations"]
         assert got["f"] == want["f"]
         assert np.array_equal(got["T"], want["T"])
         dt, ang = pose_error(got["T"], T_gt)
@@ -136,7 +167,7 @@ def test_reference_gicp_cases_against_pcl_literal_summation(wm, ctx, oracle, tes
     P = np.eye(4)
     P[0, 3] = tx
     target = oracle.transform_cloud_d(testscan, P)
-    got = ctx.gicp_match(testscan, target, res=res)
+    got = ctx.gicp_match(testscan, target, res=res, objective=wm.WM_GICP_OBJECTIVE_PCL_SUMS)
     a = testscan if res < 0 else oracle.voxel_grid(testscan, res)
     b = target if res < 0 else oracle.voxel_grid(target, res)
     oracle.gicp_set_summation(1)
@@ -160,7 +191,7 @@ def test_gicp_spread_against_pcl_literal_summation(wm, ctx, oracle):
         ref, tgt, T_gt = synth.pair(n, seed=seed)
         ctx.set_source(ref)
         ctx.set_target(tgt)
-        got = ctx.gicp_align()
+        got = ctx.gicp_align(objective=wm.WM_GICP_OBJECTIVE_PCL_SUMS)
         oracle.gicp_set_summation(1)
         try:
             lit = oracle.gicp_align(ref, tgt)
@@ -179,6 +210,8 @@ def test_gicp_spread_against_pcl_literal_summation(wm, ctx, oracle):
 
 
 def _gicp_run(wm, ref, tgt, served, **kw):
+    # (the resident evaluator serves the PER-PAIR objective; the default -- sufficient statistics -- needs none)
+    kw.setdefault("objective", wm.WM_GICP_OBJECTIVE_PCL_SUMS)
     c = wm.Context(0)
     try:
         c.set_option("gicp_served", served)
@@ -241,9 +274,9 @@ def test_served_evaluator_gives_up_and_the_host_recovers(wm):
         c.set_option("gicp_serve_test_stall_ms", 350)
         c.set_source(ref)
         c.set_target(tgt)
-        got = c.gicp_align()
+        got = c.gicp_align(objective=wm.WM_GICP_OBJECTIVE_PCL_SUMS)
         c.set_option("gicp_serve_test_stall_ms", 0)
-        again = c.gicp_align()   # the context is fully usable afterwards, served again
+        again = c.gicp_align(objective=wm.WM_GICP_OBJECTIVE_PCL_SUMS)   # the context is fully usable afterwards, served again
     finally:
         c.close()
     assert got["rc"] == 0 and np.array_equal(got["T"], want["T"]) and got["f"] == want["f"]

@@ -231,6 +231,65 @@ def test_gicp_summation_modes_agree_at_the_millimetre_level(oracle):
         assert d < 2e-2 and g < 2e-3
 
 
+def test_gicp_statistics_objective_is_the_same_function_as_the_per_pair_sums(oracle):
+    """oracle/gicp.c objective mode 1 -- the HIP path's default, libwave_amd/csrc/wm_gicp_quad.hpp: the 74 sufficient
+    statistics of the pairs, formed once around the pairing transform -- against mode 0, PCL's per-pair sums through the
+    float transform (OptimizationFunctorWithIndices::fdf).  (i) At a given state the two are the same f and gradient up
+    to the float rounding of PCL's per-point transform; a double-precision numpy evaluation of r^T M r sits between
+    them.  (ii) Registrations: identical on a copy pair at the identity, within the documented spread on a noisy pair
+    (PCL's BFGS stops at |g| < 1e-2 wherever its line search lands)."""
+    from helpers import pose_error
+    from libwave_amd import synth
+    ref, tgt, T_gt = synth.pair(6000, seed=33)
+    T0 = synth.make_T((0.15, -0.08, 0.03), (0.006, -0.015, 0.02)).astype(np.float32)
+    moved = oracle.transform_cloud_f(ref, T0)
+    oi, od = oracle.KdTree(tgt).nn(moved)
+    keep = od.astype(np.float64) < 25.0
+    si = np.nonzero(keep)[0].astype(np.int32)
+    C1, C2 = oracle.gicp_covariances(ref), oracle.gicp_covariances(tgt)
+    R = T0[:3, :3].astype(np.float64)
+    M = np.zeros((len(ref), 3, 3))
+    M[si] = np.linalg.inv(C2[oi[si]] + R @ C1[si] @ R.T)
+    for x in (np.array([0.15, -0.08, 0.03, 0.006, -0.015, 0.02]), np.array([0.2, -0.1, 0.05, 0.01, -0.02, 0.03]),
+              np.array([0.1, -0.05, 0.0, 0.0, -0.01, 0.015])):
+        f0, g0 = oracle.gicp_fdf(ref, tgt, si, oi[si], M, np.eye(4), x)
+        f1, g1, Q = oracle.gicp_fdf_statistics(ref, tgt, si, oi[si], M, np.eye(4), T0, x)
+        assert Q[73] == len(si)
+        assert abs(f1 - f0) <= 3e-6 * abs(f0), (f0, f1)
+        np.testing.assert_allclose(g1, g0, rtol=0, atol=3e-5 * np.abs(g0).max())
+        # the smooth function both approximate: double-precision transform of every point
+        # PCL's applyState builds the matrix in FLOAT: do the same, then apply it in double
+        Tf = np.eye(4, dtype=np.float32)
+        cphi, sphi, cth, sth, cpsi, spsi = (np.float32(np.cos(np.float32(x[3]))), np.float32(np.sin(np.float32(x[3]))),
+                                            np.float32(np.cos(np.float32(x[4]))), np.float32(np.sin(np.float32(x[4]))),
+                                            np.float32(np.cos(np.float32(x[5]))), np.float32(np.sin(np.float32(x[5]))))
+        Tf[:3, :3] = np.array([[cpsi * cth, cpsi * sth * sphi - spsi * cphi, cpsi * sth * cphi + spsi * sphi],
+                               [spsi * cth, spsi * sth * sphi + cpsi * cphi, spsi * sth * cphi - cpsi * sphi],
+                               [-sth, cth * sphi, cth * cphi]], dtype=np.float32)
+        Tf[:3, 3] = x[:3].astype(np.float32)
+        W = Tf.astype(np.float64)
+        r = ref[si].astype(np.float64) @ W[:3, :3].T + W[:3, 3] - tgt[oi[si]].astype(np.float64)
+        Ms = 0.5 * (M[si] + np.transpose(M[si], (0, 2, 1)))
+        f_smooth = np.einsum("ni,nij,nj->", r, Ms, r) / len(si)
+        assert abs(f1 - f_smooth) <= 3e-6 * f_smooth and abs(f0 - f_smooth) <= 3e-6 * f_smooth
+    # registrations
+    a = oracle.gicp_align(ref, tgt)
+    oracle.gicp_set_objective(1)
+    try:
+        assert oracle.lib().wmo_gicp_get_objective() == 1
+        b = oracle.gicp_align(ref, tgt)
+        same = oracle.gicp_align(ref, ref.copy())
+    finally:
+        oracle.gicp_set_objective(0)
+    assert a["converged"] and b["converged"] and same["converged"]
+    assert np.array_equal(same["T"], np.eye(4)) and same["evaluations"] == 1
+    dt, ang = pose_error(a["T"], b["T"])
+    assert dt < 5e-3 and ang < 1e-3
+    for r_ in (a, b):
+        d, g = pose_error(r_["T"], T_gt)
+        assert d < 2e-2 and g < 2e-3
+
+
 def test_ndt_pcl18_literal_mode_meets_the_reference_test(oracle, testscan):
     """wave_matching/tests/ndt_tests.cpp:85-102 (smallDisplacement: res 0.3, +0.2 m in x, the
     reference's ndt.yaml: step_size 3, max_iter 100, t_eps 1e-8) passes on the reference's CI with
