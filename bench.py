@@ -250,46 +250,70 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu, copy_peak=None):
     ref, tgt, T_gt = synth.pair(n, seed=42)
     d_ref, d_tgt = torch.from_numpy(ref).to(dev), torch.from_numpy(tgt).to(dev)
 
-    def gicp(c):
+    def gicp(c, **kw):
         c.set_source(d_ref)
         c.set_target(d_tgt)
-        return c.gicp_align()
+        return c.gicp_align(**kw)
+    # the default: the objective as 74 sufficient statistics per outer iteration (csrc/wm_gicp_quad.hpp) ...
     ms, r = median_ms(lambda: gicp(ctx))
     rp = gicp(prof)
+    # ... and PCL's per-pair sums (one pass over the pairs per evaluation; served by the resident evaluator / launched)
+    PCL = capi.WM_GICP_OBJECTIVE_PCL_SUMS
+    ms_pcl, r_pcl = median_ms(lambda: gicp(ctx, objective=PCL))
+    rp_pcl = gicp(prof, objective=PCL)
     launched = capi.Context(0)
     launched.set_option("gicp_served", 0)
-    ms_launched, _ = median_ms(lambda: gicp(launched))
+    ms_launched, _ = median_ms(lambda: gicp(launched, objective=PCL))
     launched.close()
-    ev = max(rp["evaluations"], 1)
-    us = rp["fdf_kernel_ms"] / ev * 1e3
+    passes = max(rp["iterations"], 1)
+    us = rp["fdf_kernel_ms"] / passes * 1e3
+    bytes_pass = 184.0 * n  # 16 source point + 8 key + 16 match + 72 source covariance + 72 target covariance (gathered)
+    ev = max(rp_pcl["evaluations"], 1)
+    us_fdf = rp_pcl["fdf_kernel_ms"] / ev * 1e3
     bytes_eval = 112.0 * n  # 16 source + 16 match + 8 key + 72 Mahalanobis per pair
     e = {"config": "GICPMatcher 500k<->500k, k = 10 covariances (BASELINE configs[2])",
          "ms_per_registration": ms, "registrations_per_s": 1e3 / ms, "outer_iterations": r["iterations"],
          "objective_evaluations": r["evaluations"],
-         # of those: answered by the resident evaluator (k_gicp_fdf_served: trial points through a mailbox
-         # in device memory the host writes over the PCIe BAR; no kernel launch per evaluation)
-         "served_evaluations": r.get("served_evaluations"),
-         "ms_per_registration_launched": ms_launched,  # the same registration with a kernel launch per evaluation
+         "objective": "sufficient statistics: 74 sums per outer iteration, every evaluation scalar work on the host "
+                      "(wm_gicp_params::objective = WM_GICP_OBJECTIVE_STATISTICS, the default)",
          "translation_error_m": float(np.linalg.norm(r["T"][:3, 3] - T_gt[:3, 3])) if r["T"] is not None else None,
-         "roofline": {"bound": "hbm", "kernel": "wm::k_gicp_fdf (objective + gradient, one per BFGS evaluation; timed as "
-                                                "launched kernels -- the profiling context does not use the resident evaluator, "
-                                                "whose workgroups run the same code)",
-                      "achieved": bytes_eval / (us * 1e-6) / 1e9 if us > 0 else None, "peak": HBM_PEAK_GBS,
-                      "unit": "GB/s", "frac": bytes_eval / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us > 0 else None,
-                      "algorithmic_bytes_per_launch": bytes_eval, "avg_launch_us": us, "launches_timed": ev,
-                      # SURVEY 8(d)'s accounting of one objective evaluation: 12N + 4N + 12N (gather) + 24N = 52 B x n
-                      # (float upper-triangle matrices; this kernel reads 72-B double 3x3s and a 16-B packed match)
-                      "survey_bytes_per_launch": 52.0 * n,
-                      "frac_survey_bytes": 52.0 * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us > 0 else None}}
-    e["roofline"].update(counter_traffic(pmc, "k_gicp_fdf", us, copy_peak))
+         # the same registration with PCL's per-pair objective (WM_GICP_OBJECTIVE_PCL_SUMS): evaluations answered by the
+         # resident evaluator (k_gicp_fdf_served, trial points through a mailbox the host writes over the PCIe BAR) ...
+         "pcl_sums": {"ms_per_registration": ms_pcl, "outer_iterations": r_pcl["iterations"],
+                      "objective_evaluations": r_pcl["evaluations"], "served_evaluations": r_pcl.get("served_evaluations"),
+                      "ms_per_registration_launched": ms_launched,  # ... or with a kernel launch per evaluation
+                      "translation_error_m": float(np.linalg.norm(r_pcl["T"][:3, 3] - T_gt[:3, 3])) if r_pcl["T"] is not None else None,
+                      "difference_to_the_statistics_objective_m": (float(np.linalg.norm(r["T"][:3, 3] - r_pcl["T"][:3, 3]))
+                                                                   if r["T"] is not None and r_pcl["T"] is not None else None),
+                      "roofline": {"bound": "hbm", "kernel": "wm::k_gicp_fdf (one per BFGS evaluation, timed as launched kernels)",
+                                   "achieved": bytes_eval / (us_fdf * 1e-6) / 1e9 if us_fdf > 0 else None, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": bytes_eval / (us_fdf * 1e-6) / 1e9 / HBM_PEAK_GBS if us_fdf > 0 else None,
+                                   "algorithmic_bytes_per_launch": bytes_eval, "avg_launch_us": us_fdf, "launches_timed": ev,
+                                   # SURVEY 8(d)'s accounting of one objective evaluation: 52 B x n
+                                   "survey_bytes_per_launch": 52.0 * n,
+                                   "frac_survey_bytes": 52.0 * n / (us_fdf * 1e-6) / 1e9 / HBM_PEAK_GBS if us_fdf > 0 else None}},
+         "roofline": {"bound": "hbm", "kernel": "wm::k_gicp_quad (ONE pass over the pairs per outer iteration: Mahalanobis matrices "
+                                                "formed on the fly, 74 double-double sums; both halves of the sums read the pairs)",
+                      "achieved": bytes_pass / (us * 1e-6) / 1e9 if us > 0 else None, "peak": HBM_PEAK_GBS,
+                      "unit": "GB/s", "frac": bytes_pass / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us > 0 else None,
+                      "algorithmic_bytes_per_launch": bytes_pass, "avg_launch_us": us, "launches_timed": passes,
+                      "note": "of a registration's time the objective is now %.0f %%: what is left are the two k-NN covariance "
+                              "passes, the correspondence searches and the index builds" % (100.0 * rp["fdf_kernel_ms"] / ms if ms > 0 else 0.0)}}
+    e["pcl_sums"]["roofline"].update(counter_traffic(pmc, "k_gicp_fdf", us_fdf, copy_peak))
     if with_cpu:
         from oracle import oracle_py as O
         m = 20_000
         rs, ts_, _ = synth.pair(m, seed=42)
         t0 = time.perf_counter()
-        want = O.gicp_align(rs, ts_)
+        want_pcl = O.gicp_align(rs, ts_)
         e["cpu_baseline"] = {"seconds_per_registration": time.perf_counter() - t0, "cores": 1, "kind": "port",
-                             "sample": "the oracle's GICP on a %d<->%d pair of the same scene (the 500k pair takes minutes)" % (m, m)}
+                             "sample": "the oracle's GICP (PCL's per-pair objective) on a %d<->%d pair of the same scene "
+                                       "(the 500k pair takes minutes)" % (m, m)}
+        O.gicp_set_objective(1)   # (the oracle's restatement of the statistics objective: what the default is held to)
+        try:
+            want = O.gicp_align(rs, ts_)
+        finally:
+            O.gicp_set_objective(0)
         # parity where the oracle can be run: the SAME 20k pair through the HIP path.  (translation_error_m above
         # is against the ground truth of a noisy re-sampled pair -- what GICP's loose BFGS stop leaves, for the
         # oracle as for the kernels -- not a difference between the two.)
@@ -304,8 +328,18 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu, copy_peak=None):
                     "rotation_difference_rad": rotation_angle(got["T"][:3, :3], Tw[:3, :3]),
                     "identical_float_matrix": bool(np.array_equal(got["T"].astype(np.float32), Tw.astype(np.float32))),
                     "outer_iterations": [got["iterations"], want.get("iterations")],
-                    "note": "the same 20k pair through the HIP path and the oracle; translation_error_m above is against "
-                            "the ground truth of the noisy 500k pair (what GICP's loose BFGS stop leaves), not a parity figure"}
+                    "note": "the same 20k pair through the HIP path (default objective: sufficient statistics) and the oracle's "
+                            "restatement of that objective; translation_error_m above is against the ground truth of the "
+                            "noisy 500k pair, not a parity figure"}
+                got_p = ctx.gicp_align(objective=PCL)
+                Tp = np.asarray(want_pcl["T"], dtype=np.float64)
+                e["parity_vs_oracle_20k"]["pcl_sums"] = {
+                    "identical_float_matrix": bool(got_p["T"] is not None and np.array_equal(got_p["T"].astype(np.float32), Tp.astype(np.float32))),
+                    "statistics_vs_pcl_sums_translation_difference_m": float(np.linalg.norm(got["T"][:3, 3] - Tp[:3, 3])),
+                    "statistics_vs_pcl_sums_rotation_difference_rad": rotation_angle(got["T"][:3, :3], Tp[:3, :3]),
+                    "note": "PCL's per-pair objective: the HIP path against the oracle's default mode, and how far the two "
+                            "objectives' registrations of this noisy pair are apart (PCL's BFGS stops at |g| < 1e-2 wherever "
+                            "its line search lands: tests/test_gicp_quad_gpu.py)"}
         except Exception as ex:  # (never lose the line over the extra check)
             e["parity_vs_oracle_20k"] = {"error": str(ex)}
     out.append(e)
@@ -435,6 +469,14 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu, copy_peak=None):
     ms_h, got = median_ms(lambda: ctx.gicp_batch_match(host_pairs), reps=3)
     ms_d, got = median_ms(lambda: ctx.gicp_batch_match(dev_pairs), reps=3)
     ms_one, one = median_ms(lambda: ctx.gicp_match(base[0][0], base[0][1]))
+    # ... and with PCL's per-pair objective: every evaluation streams 104 bytes per pair of points (HBM-bound)
+    ms_dp, got_p = median_ms(lambda: ctx.gicp_batch_match(dev_pairs, objective=capi.WM_GICP_OBJECTIVE_PCL_SUMS), reps=2)
+    ev_bytes = float(sum(g["evaluations"] for g in got_p) * n * 104)
+    pcl_entry = {"registrations_per_s_device_resident_clouds": B / (ms_dp * 1e-3), "kernel_ms_per_batch": got_p[0]["kernel_ms"],
+                 "roofline": {"bound": "hbm", "kernel": "wm::k_gicp_small<10>, per-pair objective: the evaluations stream 104 bytes per pair of points",
+                              "algorithmic_bytes_per_launch": ev_bytes, "achieved": ev_bytes / (got_p[0]["kernel_ms"] * 1e-3) / 1e9,
+                              "peak": 8000.0, "unit": "GB/s", "frac": ev_bytes / (got_p[0]["kernel_ms"] * 1e-3) / 1e9 / 8000.0,
+                              "note": "whole-kernel time (grids, covariances, searches included) against the evaluations' bytes alone"}}
     e = {"config": "GICPMatcher 20k<->20k, %d distinct queued pairs per launch (k = 10 covariances, PCL's default stopping rules)" % B,
          "pairs_per_launch": B, "registrations_per_s": B / (ms_h * 1e-3), "ms_per_batch": ms_h,
          "registrations_per_s_device_resident_clouds": B / (ms_d * 1e-3), "kernel_ms_per_batch": got[0]["kernel_ms"],
@@ -443,13 +485,9 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu, copy_peak=None):
          "all_converged": all(g["rc"] == 0 for g in got),
          "one_pair_at_a_time_ms": ms_one,
          "first_item_equals_the_one_pair_path_bit_for_bit": bool(np.array_equal(got[0]["T"], one["T"])) and got[0]["evaluations"] == one["evaluations"],
-         "roofline": {"bound": "hbm", "kernel": "wm::k_gicp_small<10>: the evaluations of the objective stream 104 bytes per pair of points",
-                      "algorithmic_bytes_per_launch": float(sum(g["evaluations"] for g in got) * n * 104),
-                      "achieved": sum(g["evaluations"] for g in got) * n * 104 / (got[0]["kernel_ms"] * 1e-3) / 1e9,
-                      "peak": 8000.0, "unit": "GB/s",
-                      "frac": sum(g["evaluations"] for g in got) * n * 104 / (got[0]["kernel_ms"] * 1e-3) / 1e9 / 8000.0,
-                      "note": "whole-kernel time (grids, covariances, searches included) against the evaluations' bytes alone; half "
-                              "of them are served by the memory-side cache (every other evaluation walks its blocks backwards)"},
+         "objective": "sufficient statistics (the default): a pair's 74 sums are formed in the correspondence phase, wave 0's "
+                      "optimiser evaluates them as scalar work; nothing is streamed per evaluation",
+         "pcl_sums": pcl_entry,
          "note": "host clouds: 2 x 320 kB per pair cross PCIe inside the timed call (one worker thread; "
                  "libwave_amd/host/bench_multimatcher with BENCH_MATCHER=gicp runs the C++ wave::MultiMatcher pool on top of this)"}
     out.append(e)

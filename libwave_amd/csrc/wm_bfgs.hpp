@@ -395,6 +395,15 @@ WM_HD int bfgs_minimize(Fn &F, double x[6], int max_inner, double *f_out) {
     for (int i_ = 0; i_ < 6; ++i_) x0[i_] = x[i_];
     for (int i_ = 0; i_ < 6; ++i_) g0[i_] = g[i_];
     double g0norm = norm6(g0);
+    // F.test_at_start() (the statistics objective only, wm_gicp_quad.hpp): the minimiser's own success test is made at
+    // the starting point too.  pcl::BFGS tests only AFTER a step; with PCL's per-pair objective a step from an already
+    // converged point dies in the float dust of the objective (NoProgress: x unchanged, the outer loop stops).  The
+    // statistics have no dust: the step succeeds, moves x by ~1e-6, the float transform changes in its last bit, and
+    // the outer loop (libwave's r_eps = 1e-8) re-pairs and crawls on for dozens of iterations that change nothing.
+    if (F.test_at_start() && g0norm < 1e-2) {
+        if (f_out) *f_out = f;
+        return 0;
+    }
     for (int i = 0; i < 6; ++i) p[i] = -g0[i] / g0norm;
     double pnorm = norm6(p), fp0 = -g0norm, delta_f = 0;
     int inner = 0;

@@ -543,6 +543,7 @@ struct GicpFn {
     double fdf(const double x[6], double g[6]);
     int pairs() const { return m; }
     bool failed() const { return rc != WM_OK; }
+    bool test_at_start() const { return false; }  // (PCL's per-pair objective: pcl::BFGS as it is)
     int evals = 0;
     float kernel_ms = 0;
     int rc = WM_OK;
@@ -798,6 +799,7 @@ struct GicpQuadFn {
     int evals = 0;
     int pairs() const { return m; }
     bool failed() const { return false; }
+    bool test_at_start() const { return true; }  // (see bfgs_minimize)
     double fdf(const double x[6], double g[6]) {
         ++evals;
         const double f = gicp_quad_eval(Q, T0, base, x, g);

@@ -23,6 +23,7 @@
 #include "wm_internal.hpp"
 #include "wm_gicp_dev.hpp"
 #include "wm_bfgs.hpp"
+#include "wm_gicp_quad.hpp"
 
 #include <float.h>
 #include <math.h>
@@ -74,6 +75,7 @@ struct GsParams {
     int max_iter, max_inner, forced;
     double r_eps, t_eps;
     int debug;  // developer (WM_GICP_SMALL_TRACE): pair 0 prints every evaluation, as WM_GICP_TRACE does on the one-pair path
+    int objective;  // wm_gicp_params::objective (WM_GICP_OBJECTIVE_STATISTICS: no evaluation blocks, 74 sums per outer iteration)
 };
 
 struct GsOut {
@@ -104,7 +106,48 @@ struct GsShared {
     float T[16];
     unsigned cnt;  // matched pairs of the last search
     int evals;
+    double Q[kQuadN];  // the statistics objective: the 74 sums of the last search's pairs (wm_gicp_quad.hpp)
 };
+
+// The statistics objective inside the workgroup.  A trip of gs_correspondences gives every thread one pair; what the
+// pair's 74 terms are made of -- the symmetric part of its Mahalanobis matrix, the source point, PCL's float residual
+// at the pairing transform -- goes into LDS (structure of arrays: 72 bytes per pair), and after a barrier WAVE w adds
+// the terms of components w, w + 16, ... (five at most) of all 1024 pairs, sixteen pairs per lane, in double-double:
+// a component is wave-uniform, so its formula is scalar control flow, and a thread keeps five (hi, lo) pairs instead
+// of seventy-four.  Same terms, same double-double sums as k_gicp_quad (wm_gicp.hip): the same 74 numbers, bit for bit.
+struct GsQuadLds {
+    double Ms[6][kGsThreads];
+    float z[3][kGsThreads];
+    float r0[3][kGsThreads];
+    unsigned ok[kGsThreads];
+};
+constexpr int kGsQuadPerWave = (kQuadN + kGsWaves - 1) / kGsWaves;  // 5
+// component c's term of the pair in slot e (the expressions of gicp_quad_terms, operation for operation)
+__device__ __forceinline__ double gs_quad_term(const GsQuadLds &G, int c, unsigned e) {
+    if (c < kQuadOffB) {
+        const int sidx = c / 10, t = c - sidx * 10;
+        // t -> (j, k), j <= k, in quad_s10's order
+        const int j = t < 4 ? 0 : (t < 7 ? 1 : (t < 9 ? 2 : 3));
+        const int k = t < 4 ? t : (t < 7 ? t - 3 : (t < 9 ? t - 5 : 3));
+        const double zj = j < 3 ? (double) G.z[j][e] : 1.0, zk = k < 3 ? (double) G.z[k][e] : 1.0;
+        return G.Ms[sidx][e] * (zj * zk);
+    }
+    const double r0[3] = {(double) G.r0[0][e], (double) G.r0[1][e], (double) G.r0[2][e]};
+    if (c < kQuadOffC) {
+        const int a = (c - kQuadOffB) >> 2, j = (c - kQuadOffB) & 3;
+        const double t0 = (G.Ms[quad_s6(a, 0)][e] * r0[0] + G.Ms[quad_s6(a, 1)][e] * r0[1]) + G.Ms[quad_s6(a, 2)][e] * r0[2];
+        return t0 * (j < 3 ? (double) G.z[j][e] : 1.0);
+    }
+    if (c == kQuadOffC) {
+        double t0[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            t0[a] = (G.Ms[quad_s6(a, 0)][e] * r0[0] + G.Ms[quad_s6(a, 1)][e] * r0[1]) + G.Ms[quad_s6(a, 2)][e] * r0[2];
+        return (r0[0] * t0[0] + r0[1] * t0[1]) + r0[2] * t0[2];
+    }
+    return 1.0;
+}
+
 
 __device__ __forceinline__ bool gs_load(const unsigned char *base, unsigned i, unsigned stride, float &x, float &y, float &z) {
     const float *p = reinterpret_cast<const float *>(base + (size_t) i * stride);
@@ -285,6 +328,7 @@ struct GsFn {
     int debug;
     __device__ int pairs() const { return m; }
     __device__ bool failed() const { return false; }
+    __device__ bool test_at_start() const { return false; }
     // this wave's share of one evaluation -> its row of S->red
     __device__ void share(const FdfArgs &A, bool backwards) {
         double hi[kGicpAcc], lo[kGicpAcc];
@@ -409,7 +453,23 @@ __device__ __attribute__((noinline)) void gs_covariances(GsShared &S, uint2 *run
 
 // one outer iteration's correspondences: 1-NN of every transformed source point, d2 < max_corr^2, and the
 // Mahalanobis matrix of every pair; S.cnt = the number of pairs
-__device__ __attribute__((noinline)) void gs_correspondences(GsShared &S, uint2 *runs) {
+// one trip's pairs -> this wave's components (a function of its own: its registers are not the search loop's)
+__device__ __attribute__((noinline)) void gs_quad_accumulate(const GsQuadLds &G, unsigned wave, unsigned lane, double *qh, double *ql) {
+#pragma unroll
+    for (int u = 0; u < kGsQuadPerWave; ++u) {
+        const int c = (int) wave + u * kGsWaves;  // (wave-uniform)
+        if (c < kQuadN) {
+            double h = qh[u], l = ql[u];
+            for (unsigned e = lane; e < (unsigned) kGsThreads; e += 64u)
+                if (G.ok[e]) ddn_add(h, l, gs_quad_term(G, c, e));
+            qh[u] = h;
+            ql[u] = l;
+        }
+    }
+}
+
+template <bool STATS>
+__device__ __attribute__((noinline)) void gs_correspondences(GsShared &S, uint2 *runs, GsQuadLds *G) {
     const unsigned tid = threadIdx.x;
     const GridDev gt = S.gt;
     const unsigned n_s = S.n_s, n_t = S.n_t, stride = S.P.stride;
@@ -425,7 +485,15 @@ __device__ __attribute__((noinline)) void gs_correspondences(GsShared &S, uint2 
     const double *c1 = S.pr.c1, *c2 = S.pr.c2;
     const unsigned char *tgt = S.pr.tgt;
     unsigned mine = 0;
-    for (unsigned i = tid; i < n_s; i += kGsThreads) {
+    // (statistics: this wave's components of the 74 sums, sixteen pairs per lane and trip)
+    const unsigned lane = tid & 63u, wave = tid >> 6;
+    double qh[kGsQuadPerWave], ql[kGsQuadPerWave];
+#pragma unroll
+    for (int u = 0; u < kGsQuadPerWave; ++u) qh[u] = ql[u] = 0.0;
+    for (unsigned i0 = 0; i0 < n_s; i0 += kGsThreads) {
+        const unsigned i = i0 + tid;
+        if constexpr (STATS) G->ok[tid] = 0u;
+        if (i < n_s) {
         const float4 p = s_pts[i];
         // PCL's float transform of a source point: ((m00*x + m01*y) + m02*z) + m03
         const float qx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[0], p.x), __fmul_rn(T[1], p.y)), __fmul_rn(T[2], p.z)), T[3]);
@@ -440,8 +508,6 @@ __device__ __attribute__((noinline)) void gs_correspondences(GsShared &S, uint2 
         if (j != kNoIdx) {
             float x, y, z;
             (void) gs_load(tgt, j, stride, x, y, z);
-            *gs_ev_point(evb, i) = p;
-            *gs_ev_match(evb, i) = make_float4(x, y, z, 0.f);
             double R[9];
 #pragma unroll
             for (int a = 0; a < 3; ++a)
@@ -449,11 +515,48 @@ __device__ __attribute__((noinline)) void gs_correspondences(GsShared &S, uint2 
                 for (int b = 0; b < 3; ++b) R[a * 3 + b] = (double) T[a * 4 + b];
             double o[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
             if (!(debug & 2)) gicp_mahal_of(c1 + (size_t) __float_as_uint(p.w) * 9, c2 + (size_t) j * 9, R, o);
+            if constexpr (STATS) {
+                // what the pair's 74 terms are made of (gicp_quad_terms, wm_gicp_quad.hpp): the symmetric part of M,
+                // the point, PCL's float residual under the pairing transform
+                G->Ms[0][tid] = o[0];
+                G->Ms[1][tid] = 0.5 * (o[1] + o[3]);
+                G->Ms[2][tid] = 0.5 * (o[2] + o[6]);
+                G->Ms[3][tid] = o[4];
+                G->Ms[4][tid] = 0.5 * (o[5] + o[7]);
+                G->Ms[5][tid] = o[8];
+                G->z[0][tid] = p.x, G->z[1][tid] = p.y, G->z[2][tid] = p.z;
+                G->r0[0][tid] = __fsub_rn(qx, x), G->r0[1][tid] = __fsub_rn(qy, y), G->r0[2][tid] = __fsub_rn(qz, z);
+                G->ok[tid] = 1u;
+            } else {
+                *gs_ev_point(evb, i) = p;
+                *gs_ev_match(evb, i) = make_float4(x, y, z, 0.f);
 #pragma unroll
-            for (int a = 0; a < 9; ++a) gs_ev_mahal(evb, i)[a * 64] = o[a];
+                for (int a = 0; a < 9; ++a) gs_ev_mahal(evb, i)[a * 64] = o[a];
+            }
             ++mine;
-        } else {
+        } else if constexpr (!STATS) {
             *gs_ev_match(evb, i) = make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
+        }
+        }  // (i < n_s)
+        if constexpr (STATS) {
+            __syncthreads();  // (the trip's pairs are in LDS)
+            gs_quad_accumulate(*G, wave, lane, qh, ql);
+            __syncthreads();  // (... and read, before the next trip overwrites them)
+        }
+    }
+    if constexpr (STATS) {
+        // the lanes' double-double sums of a component -> one (hi, lo) -> rounded once (any order: the same value)
+#pragma unroll
+        for (int u = 0; u < kGsQuadPerWave; ++u) {
+            const int c = (int) wave + u * kGsWaves;
+            double h = qh[u], l = ql[u];
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) {
+                const double oh = __shfl_xor(h, m), ol = __shfl_xor(l, m);
+                ddn_add(h, l, oh);
+                l += ol;
+            }
+            if (lane == 0 && c < kQuadN) S.Q[c] = h + l;
         }
     }
 #pragma unroll
@@ -498,9 +601,54 @@ __device__ __attribute__((noinline)) void gs_minimise(GsShared &S) {
     __syncthreads();
 }
 
+// ... with the statistics objective: the 74 sums are in S.Q (gs_correspondences<true>), wave 0 runs the optimiser
+// and every evaluation it asks for is scalar work (gicp_quad_eval); the other waves have nothing to serve
+struct GsQuadFn {
+    const GsShared *S;  // (the 74 sums are read where they are: in LDS)
+    float T0[12];
+    double base[16];
+    int m, evals, debug;
+    __device__ int pairs() const { return m; }
+    __device__ bool failed() const { return false; }
+    __device__ bool test_at_start() const { return true; }
+    __device__ double fdf(const double x[6], double g[6]) {
+        ++evals;
+        const double f = gicp_quad_eval(S->Q, T0, base, x, g);
+        if ((debug & 1) && blockIdx.x == 0 && (threadIdx.x & 63u) == 0)
+            printf("%d %.17g %.17g %.17g %.17g %.17g %.17g | %.17g | %.17g %.17g %.17g %.17g %.17g %.17g\n", m, x[0], x[1], x[2], x[3], x[4], x[5], f,
+                   g ? g[0] : 0.0, g ? g[1] : 0.0, g ? g[2] : 0.0, g ? g[3] : 0.0, g ? g[4] : 0.0, g ? g[5] : 0.0);
+        return f;
+    }
+};
+__device__ __attribute__((noinline)) void gs_minimise_stats(GsShared &S) {
+    const unsigned tid = threadIdx.x;
+    if (tid < 64u) {
+        GsQuadFn F;
+        F.S = &S;
+        for (int k = 0; k < 12; ++k) F.T0[k] = S.T[k];
+        mat4_identity(F.base);
+        F.m = (int) S.cnt;
+        F.evals = 0;
+        F.debug = S.P.debug;
+        double x[6] = {(double) S.T[3], (double) S.T[7], (double) S.T[11], (double) libm_atan2f(S.T[9], S.T[10]),
+                       (double) libm_asinf(-S.T[8]), (double) libm_atan2f(S.T[4], S.T[0])};
+        double fl = 0;
+        const int in0 = bfgs_minimize(F, x, S.P.max_inner, &fl);
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) S.res[k] = x[k];
+            S.res[6] = fl;
+            S.res[7] = (double) in0;
+            S.evals += F.evals;
+        }
+    }
+    __syncthreads();
+}
+
 template <int K>
 __global__ void __launch_bounds__(kGsThreads) k_gicp_small(const GsPair *__restrict__ table, GsParams P, GsOut *__restrict__ outs) {
     __shared__ uint2 runs[kKnnRows * kGsThreads];  // the k-NN search's run lists (64 KB)
+    __shared__ GsQuadLds quad;                     // the statistics objective's per-trip pair data (76 KB)
     __shared__ GsShared S;
     GsOut &out = outs[blockIdx.x];
     const unsigned tid = threadIdx.x;
@@ -543,6 +691,7 @@ __global__ void __launch_bounds__(kGsThreads) k_gicp_small(const GsPair *__restr
     if (tid < 16) S.T[tid] = (tid % 5 == 0) ? 1.f : 0.f;
     __syncthreads();
     const int max_it = P.forced > 0 ? P.forced : P.max_iter;
+    const bool statistics = P.objective != WM_GICP_OBJECTIVE_PCL_SUMS;
     int iter = 0, inner_total = 0, status = WM_NOT_CONVERGED;
     bool converged = false;
     double f_last = 0;
@@ -550,13 +699,15 @@ __global__ void __launch_bounds__(kGsThreads) k_gicp_small(const GsPair *__restr
     unsigned long long cyc_search = 0, cyc_min = 0;
     while (!converged) {
         t_mark = clock64();
-        gs_correspondences(S, runs);
+        if (statistics) gs_correspondences<true>(S, runs, &quad);
+        else gs_correspondences<false>(S, runs, nullptr);
         cnt = S.cnt;
         cyc_search += clock64() - t_mark;
         t_mark = clock64();
 #pragma unroll
         for (int i = 0; i < 16; ++i) prevT[i] = S.T[i];
-        gs_minimise(S);
+        if (statistics) gs_minimise_stats(S);
+        else gs_minimise(S);
         cyc_min += clock64() - t_mark;
         const int inner = (int) S.res[7];
         if (inner < 0) break;  // NotEnoughPointsException: the loop breaks, converged_ stays false
@@ -718,6 +869,7 @@ static int gicp_small_run(wm_ctx *ctx, const GsJob *jobs, int n, size_t stride, 
     P.forced = prm->force_iterations;
     P.r_eps = prm->r_eps;
     P.t_eps = prm->t_eps;
+    P.objective = prm->objective;
     // 1: trace.  Bits 2 / 4 are timing experiments that give WRONG registrations (no Mahalanobis matrices / no
     // search): they exist only in a developer build (-DWM_GICP_SMALL_EXPERIMENTS); a stray environment variable
     // must not be able to switch them on in the production library

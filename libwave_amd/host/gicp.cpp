@@ -2,6 +2,9 @@
 // wave_matching/src/gicp.cpp:6-64).
 #include "wave/matching/gicp.hpp"
 
+#include <cstdlib>
+#include <string>
+
 #include "shim.hpp"
 
 namespace wave {
@@ -66,10 +69,24 @@ void GICPMatcher::setTarget(const PCLPointCloudPtr &cloud) {
                                            "wm_set_target_filtered", ctx);
 }
 
+namespace {
+// how the minimisations' objective is evaluated (include/wavematch.h: wm_gicp_params::objective).  The default is the
+// library's: 74 sufficient statistics per outer iteration; env WAVE_GICP_OBJECTIVE=pcl_sums selects PCL's per-pair
+// sums through the float transform (slower: ~170 passes over the pairs per registration).
+int gicpObjective() {
+    static const int v = [] {
+        const char *e = std::getenv("WAVE_GICP_OBJECTIVE");
+        return e && std::string(e) == "pcl_sums" ? WM_GICP_OBJECTIVE_PCL_SUMS : WM_GICP_OBJECTIVE_STATISTICS;
+    }();
+    return v;
+}
+}  // namespace
+
 bool GICPMatcher::match() {
     if (!ensureContext()) return false;
     wm_gicp_params p;
     wm_gicp_default_params(&p);
+    p.objective = gicpObjective();
     p.corr_rand = params.corr_rand;  // setCorrespondenceRandomness, gicp.cpp:31
     p.max_iter = params.max_iter;    // setMaximumIterations,        gicp.cpp:32
     p.r_eps = params.r_eps;          // setRotationEpsilon,          gicp.cpp:33
@@ -113,6 +130,7 @@ bool GICPMatcher::matchBatch(const std::vector<std::pair<PCLPointCloudPtr, PCLPo
     if (!ensureContext()) return false;
     wm_gicp_params p;
     wm_gicp_default_params(&p);
+    p.objective = gicpObjective();
     p.corr_rand = params.corr_rand;  // as match() sets them (gicp.cpp:31-33)
     p.max_iter = params.max_iter;
     p.r_eps = params.r_eps;

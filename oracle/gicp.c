@@ -586,6 +586,16 @@ static int bfgs_minimize(gicp_fn *F, double x[6], int max_inner, double *f_out) 
     memcpy(x0, x, sizeof(x0));
     memcpy(g0, g, sizeof(g0));
     g0norm = norm6(g0);
+    /* Objective mode 1 only (the statistics objective, wm_bfgs.hpp does the same for it): the minimiser's own
+     * success test, |g| < gradient_tol, is made at the starting point too.  pcl::BFGS (GSL's vector_bfgs2) tests
+     * only AFTER a step; with PCL's per-pair objective a step from an already converged point dies in the float
+     * dust of the objective (NoProgress: x unchanged, the outer loop sees no change and stops).  The statistics
+     * objective has no dust: the step succeeds, moves x by ~1e-6, the float transform changes in its last bit, and
+     * the outer loop (r_eps = 1e-8) re-pairs and crawls on for dozens of iterations that change nothing. */
+    if (F->quad && g0norm < gradient_tol) {
+        if (f_out) *f_out = f;
+        return 0;
+    }
     for (i = 0; i < 6; ++i) p[i] = -g0[i] / g0norm;
     pnorm = norm6(p);
     fp0 = -g0norm;

@@ -19,6 +19,18 @@ pytestmark = pytest.mark.gpu
 
 KEYS = ("rc", "converged", "iterations", "inner_total", "evaluations", "n_corr")
 
+# both forms of the objective (include/wavematch.h: wm_gicp_params::objective), each against the oracle's restatement
+# of it (oracle/gicp.c: wmo_gicp_set_objective) and against the one-pair path in the same form
+OBJECTIVES = [("statistics", 0, 1), ("pcl_sums", 1, 0)]   # (name, wm_gicp_params::objective, oracle objective mode)
+
+
+@pytest.fixture(params=OBJECTIVES, ids=[o[0] for o in OBJECTIVES])
+def objective(request, oracle):
+    name, hip, orc = request.param
+    oracle.gicp_set_objective(orc)
+    yield hip
+    oracle.gicp_set_objective(0)
+
 
 def _pairs(sizes, seed0=100, mode="resample"):
     return [synth.pair(n, seed=seed0 + k, mode=mode) for k, n in enumerate(sizes)]
@@ -33,12 +45,12 @@ def _same(a, b):
     assert a["f"] == b["f"]
 
 
-def test_batch_items_equal_the_oracle_and_the_one_pair_path(wm, ctx, oracle):
+def test_batch_items_equal_the_oracle_and_the_one_pair_path(wm, ctx, oracle, objective):
     pairs = _pairs([3000, 1200, 5000, 400, 2999, 8000])
-    got = ctx.gicp_batch_match([(r, t) for r, t, _ in pairs])
+    got = ctx.gicp_batch_match([(r, t) for r, t, _ in pairs], objective=objective)
     assert len(got) == len(pairs)
     for (ref, tgt, T_gt), g in zip(pairs, got):
-        one = ctx.gicp_match(ref, tgt)
+        one = ctx.gicp_match(ref, tgt, objective=objective)
         _same(g, one)
         assert g["rc"] == 0
         if len(ref) >= 5000:  # (sparser samplings of this 100 x 60 m scene do not pin the pose)
@@ -53,7 +65,7 @@ def test_batch_items_equal_the_oracle_and_the_one_pair_path(wm, ctx, oracle):
 CASES = [("fullResNullMatch", -1.0, 0.0), ("nullDisplacement", 0.05, 0.0), ("smallDisplacement", 0.05, 0.2)]
 
 
-def test_reference_gicp_cases_through_the_batch(wm, ctx, oracle, testscan):
+def test_reference_gicp_cases_through_the_batch(wm, ctx, oracle, testscan, objective):
     """wave_matching/tests/gicp_tests.cpp's three cases on testscan.pcd, queued together (the voxel-filtered two in
     one call: res is the matcher's parameter, not the pair's)."""
     def target_of(tx):
@@ -63,19 +75,19 @@ def test_reference_gicp_cases_through_the_batch(wm, ctx, oracle, testscan):
     for res in (-1.0, 0.05):
         cases = [c for c in CASES if c[1] == res]
         pairs = [(testscan, target_of(tx)[0]) for _, _, tx in cases]
-        got = ctx.gicp_batch_match(pairs, res=res)
+        got = ctx.gicp_batch_match(pairs, res=res, objective=objective)
         for (name, _, tx), (ref, tgt), g in zip(cases, pairs, got):
             P = target_of(tx)[1]
             assert g["rc"] == 0 and g["converged"], name
             assert np.linalg.norm(g["T"] - P) < 0.1  # gicp_tests.cpp:36 threshold
-            _same(g, ctx.gicp_match(ref, tgt, res=res))
+            _same(g, ctx.gicp_match(ref, tgt, res=res, objective=objective))
             a = ref if res < 0 else oracle.voxel_grid(ref, res)
             b = tgt if res < 0 else oracle.voxel_grid(tgt, res)
             want = oracle.gicp_align(a, b)
             assert np.array_equal(g["T"], want["T"]) and g["n_corr"] == want["n_corr"], name
 
 
-def test_batch_edge_cases(wm, ctx):
+def test_batch_edge_cases(wm, ctx, objective):
     ref, tgt, _ = synth.pair(2000, seed=7, mode="resample")
     empty = np.zeros((0, 3), np.float32)
     nan_ref = ref.copy()
@@ -85,16 +97,16 @@ def test_batch_edge_cases(wm, ctx):
     far = tgt + np.float32(500.0)  # nothing within max_corr = 5 m
     pairs = [(ref, tgt), (empty, tgt), (ref, empty), (ref[:5], tgt), (ref, tgt[:9]), (nan_ref, nan_tgt), (ref, far), (ref[:10], tgt[:10]),
              (empty, empty)]
-    got = ctx.gicp_batch_match(pairs)
+    got = ctx.gicp_batch_match(pairs, objective=objective)
     assert [g["rc"] for g in got[1:5]] == [wm.WM_ERR_STATE, wm.WM_ERR_STATE, wm.WM_NOT_CONVERGED, wm.WM_NOT_CONVERGED]
     assert got[6]["rc"] == wm.WM_TOO_FEW and got[6]["T"] is None and got[6]["n_corr"] == 0
     assert got[8]["rc"] == wm.WM_ERR_STATE
     for k in (0, 5, 7):
-        _same(got[k], ctx.gicp_match(*pairs[k]))
-    one_far = ctx.gicp_match(ref, far)
+        _same(got[k], ctx.gicp_match(*pairs[k], objective=objective))
+    one_far = ctx.gicp_match(ref, far, objective=objective)
     assert one_far["rc"] == got[6]["rc"]
     # an item's result does not depend on its neighbours in the batch, nor on the order
-    again = ctx.gicp_batch_match([pairs[5], pairs[0]])
+    again = ctx.gicp_batch_match([pairs[5], pairs[0]], objective=objective)
     _same(again[0], got[5])
     _same(again[1], got[0])
     assert ctx.gicp_batch_match([]) == []
