@@ -565,6 +565,104 @@ def in_flight_throughput(torch, capi, d_ref, d_tgt, h_ref, h_tgt, a, crews=(1, 2
     return out
 
 
+def assemble_line(a, world, r, T_gt, elapsed, step_ms, nn_ms, nn_launches, cert_ms, cert_launches, parallelism,
+                  pmc=None, peak_copy=None, sharded=False, ar_us=None):
+    """The bench line of rank 0 from one run's measurements -- `r`: the last timed step's result dict (capi's
+    icp_align / icp_align_sharded), the event-timed search totals, the wall time of the `a.steps` timed steps.  A function
+    of its own so that the N > 1 line (config.sharding from the sharded result's keys) is exercised without GPUs
+    (tests/test_bench_helpers_cpu.py): the first real multi-GPU run must not end in a KeyError."""
+    pmc = pmc or {}
+    n_total = a.points * world
+    T = r["T"]
+    err_t = float(np.linalg.norm(T[:3, 3] - T_gt[:3, 3]))
+    # whole-job throughput in 1M-point registration equivalents (weak scaling: the
+    # N-GPU job registers an N x 1M-point pair, i.e. N units of the metric's size)
+    regs_per_s_raw = a.steps / elapsed
+    value = regs_per_s_raw * (n_total / 1_000_000.0)
+    nn_us = nn_ms / max(nn_launches, 1) * 1e3
+    pts_per_launch = a.points  # queries handled by one rank's launch
+    alg_bytes = 32.0 * pts_per_launch  # SURVEY 8(d): 12N + 12M + 8N with N = M
+    achieved = alg_bytes / (nn_us * 1e-6) / 1e9 if nn_us > 0 else 0.0
+    out = {
+        "metric": "point-cloud registrations/sec (1M<->1M pts, ICP)",
+        "value": value, "unit": "registrations/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "ICPMatcher %d<->%d synthetic XYZ clouds (BASELINE configs[%d]), DEVICE-RESIDENT "
+                        "(both clouds in HBM before the timed region), %d forced iterations, max_corr=%g, "
+                        "res=-1; step = set_source + set_target (index build) + align" % (
+                            n_total, n_total, 1 if world == 1 else 4, a.iters, a.max_corr),
+            "arithmetic": "f32 points and distances, f64 reductions and solve",
+            "scene": "base scene x%d tiled along x at constant density; T_gt rotation / %d" % (world, world),
+            "points_per_cloud_total": n_total, "points_per_gpu": a.points,
+            "iterations": a.iters, "parallelism": parallelism,
+            "registrations_per_s_raw": regs_per_s_raw,
+            "icp_iterations_per_s": regs_per_s_raw * a.iters,
+            "final_translation_error_m": err_t, "grid_cell_m": r.get("grid_cell"),
+            "cert_launches_per_registration": r.get("cert_launches"),
+            "ms_each_step_rank0": [round(t, 3) for t in step_ms],
+        },
+        "roofline": None,
+    }
+    # The correspondence step of an iteration is ONE launch of one of two kernels: the full search
+    # (k_nn_grid) while the clouds still move, the certificate kernel (k_nn_cert: previous match proved
+    # still nearest, search only where the proof fails) once a step is small.  Both leave the same keys
+    # and carry the iteration's statistics; SURVEY 8(d)'s 32 B x n is the algorithmic traffic of either.
+    grid_launches = nn_launches - cert_launches
+    kernels = []
+    for name, key, ms, launches in (("wm::k_nn_grid", "k_nn_grid", nn_ms - cert_ms, grid_launches),
+                                    ("wm::k_nn_cert", "k_nn_cert", cert_ms, cert_launches)):
+        if launches <= 0:
+            continue
+        us = ms / launches * 1e3
+        # coalesced streams of a launch: source points + previous keys + previous matches (k_nn_grid),
+        # source points + matches + positions-and-bounds (k_nn_cert); everything else it reads is gathered
+        streams = (16.0 + 8.0 + 16.0 if key == "k_nn_grid" else 48.0) * pts_per_launch
+        tr = pmc_traffic_bytes(pmc, key, streams) if world == 1 else None
+        tr_upper = pmc_traffic_bytes(pmc, key) if world == 1 else None
+        kernels.append({"name": name, "launches_timed": launches, "avg_launch_us": us,
+                        "share_of_search_time": ms / nn_ms if nn_ms > 0 else None,
+                        "achieved": alg_bytes / (us * 1e-6) / 1e9, "frac": alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": tr, "traffic_if_all_streamed_x2": tr_upper,
+                        "hbm_util": (tr / (us * 1e-6) / 1e9 / peak_copy) if (tr and peak_copy) else None})
+    traffic = None
+    if kernels and all(k["traffic"] for k in kernels):
+        traffic = sum(k["traffic"] * k["launches_timed"] for k in kernels) / max(nn_launches, 1)
+    out["roofline"] = {
+        "bound": "hbm",
+        "kernel": "the correspondence step of an ICP iteration: one launch of wm::k_nn_grid or wm::k_nn_cert "
+                  "(search + the iteration's statistics); launch-weighted over both, per kernel in `kernels`",
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic,
+        "hbm_util": (traffic / (nn_us * 1e-6) / 1e9 / peak_copy) if (traffic and peak_copy) else None,
+        "traffic_source": ("profiles/pmc_latest.json, tag %s (separate rocprofv3 --pmc passes of this "
+                           "command; a committed measurement, not this run's; its csrc_sha256 stamp matches "
+                           "the kernels in the tree); FETCH_SIZE calibrated on this part: coalesced streams are "
+                           "tallied at half their bytes, gathers at what they move (profiles/r04_fetch_size_calibration.json)"
+                           % pmc.get("tag")) if pmc.get("tag") else pmc.get("stale"),
+        "peak_measured_copy": peak_copy,
+        "peak_measured_copy_method": "float4 grid-stride copy kernel, 1 GiB in + 1 GiB out, 10 launches (wm_debug_copy_bandwidth)",
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "avg_launch_us": nn_us, "launches_timed": nn_launches, "kernels": kernels,
+        "note": "an exact gather search: what binds is the vector ALU and the L1 address path of the candidate "
+                "walk (k_nn_grid) and instruction issue + workgroup dispatch (k_nn_cert), not HBM (DESIGN.md "
+                "sections 4.1 / 5)",
+    }
+    if sharded:
+        # where rank 0's time went in the last (event-bracketed) step, and what an all-reduce costs alone
+        out["config"]["sharding"] = {
+            k: r.get(k) for k in ("plan_ms", "compact_ms", "index_ms", "iter_ms", "allreduce_ms", "n_tgt_local",
+                                  "n_src_local", "rccl_ranks", "shard_attempts", "owned_violations", "align_ms")}
+        out["config"]["sharding"]["allreduce_us_isolated"] = ar_us
+        out["config"]["sharding"]["note"] = (
+            "rank 0, last timed step: plan/compact = device time of slab planning and band selection; index = host "
+            "wall time of building the local clouds' order and grid; iter = host wall time of the 50 iterations; "
+            "allreduce = sum of the 50 ncclAllReduce(32 f64) by HIP events; isolated = back-to-back all-reduces alone")
+    return out
+
+
 def relaunch(n):
     """`python bench.py --gpus N` without a launcher: exec `python -m torch.distributed.run --nnodes=1
     --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`."""
@@ -691,95 +789,11 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        T = r["T"]
-        err_t = float(np.linalg.norm(T[:3, 3] - T_gt[:3, 3]))
-        # whole-job throughput in 1M-point registration equivalents (weak scaling: the
-        # N-GPU job registers an N x 1M-point pair, i.e. N units of the metric's size)
-        regs_per_s_raw = a.steps / elapsed
-        value = regs_per_s_raw * (n_total / 1_000_000.0)
-        nn_us = nn_ms / max(nn_launches, 1) * 1e3
-        pts_per_launch = a.points  # queries handled by one rank's launch
-        alg_bytes = 32.0 * pts_per_launch  # 12N + 12M + 8N with N = M
-        achieved = alg_bytes / (nn_us * 1e-6) / 1e9 if nn_us > 0 else 0.0
         pmc = pmc_summary() if world == 1 else {}
-        out = {
-            "metric": "point-cloud registrations/sec (1M<->1M pts, ICP)",
-            "value": value, "unit": "registrations/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {
-                "workload": "ICPMatcher %d<->%d synthetic XYZ clouds (BASELINE configs[%d]), DEVICE-RESIDENT "
-                            "(both clouds in HBM before the timed region), %d forced iterations, max_corr=%g, "
-                            "res=-1; step = set_source + set_target (index build) + align" % (
-                                n_total, n_total, 1 if world == 1 else 4, a.iters, a.max_corr),
-                "arithmetic": "f32 points and distances, f64 reductions and solve",
-                "scene": "base scene x%d tiled along x at constant density; T_gt rotation / %d" % (world, world),
-                "points_per_cloud_total": n_total, "points_per_gpu": a.points,
-                "iterations": a.iters, "parallelism": parallelism,
-                "registrations_per_s_raw": regs_per_s_raw,
-                "icp_iterations_per_s": regs_per_s_raw * a.iters,
-                "final_translation_error_m": err_t, "grid_cell_m": r.get("grid_cell"),
-                "cert_launches_per_registration": r.get("cert_launches"),
-                "ms_each_step_rank0": [round(t, 3) for t in step_ms],
-            },
-            "roofline": None,
-        }
-        # The correspondence step of an iteration is ONE launch of one of two kernels: the full search
-        # (k_nn_grid) while the clouds still move, the certificate kernel (k_nn_cert: previous match proved
-        # still nearest, search only where the proof fails) once a step is small.  Both leave the same keys
-        # and carry the iteration's statistics; SURVEY 8(d)'s 32 B x n is the algorithmic traffic of either.
         peak_copy = ctx.copy_bandwidth() if world == 1 else None
-        grid_launches = nn_launches - cert_launches
-        kernels = []
-        for name, key, ms, launches in (("wm::k_nn_grid", "k_nn_grid", nn_ms - cert_ms, grid_launches),
-                                        ("wm::k_nn_cert", "k_nn_cert", cert_ms, cert_launches)):
-            if launches <= 0:
-                continue
-            us = ms / launches * 1e3
-            # coalesced streams of a launch: source points + previous keys + previous matches (k_nn_grid),
-            # source points + matches + positions-and-bounds (k_nn_cert); everything else it reads is gathered
-            streams = (16.0 + 8.0 + 16.0 if key == "k_nn_grid" else 48.0) * pts_per_launch
-            tr = pmc_traffic_bytes(pmc, key, streams) if world == 1 else None
-            tr_upper = pmc_traffic_bytes(pmc, key) if world == 1 else None
-            kernels.append({"name": name, "launches_timed": launches, "avg_launch_us": us,
-                            "share_of_search_time": ms / nn_ms if nn_ms > 0 else None,
-                            "achieved": alg_bytes / (us * 1e-6) / 1e9, "frac": alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                            "traffic": tr, "traffic_if_all_streamed_x2": tr_upper,
-                            "hbm_util": (tr / (us * 1e-6) / 1e9 / peak_copy) if (tr and peak_copy) else None})
-        traffic = None
-        if kernels and all(k["traffic"] for k in kernels):
-            traffic = sum(k["traffic"] * k["launches_timed"] for k in kernels) / max(nn_launches, 1)
-        out["roofline"] = {
-            "bound": "hbm",
-            "kernel": "the correspondence step of an ICP iteration: one launch of wm::k_nn_grid or wm::k_nn_cert "
-                      "(search + the iteration's statistics); launch-weighted over both, per kernel in `kernels`",
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "hbm_util": (traffic / (nn_us * 1e-6) / 1e9 / peak_copy) if (traffic and peak_copy) else None,
-            "traffic_source": ("profiles/pmc_latest.json, tag %s (separate rocprofv3 --pmc passes of this "
-                               "command; a committed measurement, not this run's; its csrc_sha256 stamp matches "
-                               "the kernels in the tree); FETCH_SIZE calibrated on this part: coalesced streams are "
-                               "tallied at half their bytes, gathers at what they move (profiles/r04_fetch_size_calibration.json)"
-                               % pmc.get("tag")) if pmc.get("tag") else pmc.get("stale"),
-            "peak_measured_copy": peak_copy,
-            "peak_measured_copy_method": "float4 grid-stride copy kernel, 1 GiB in + 1 GiB out, 10 launches (wm_debug_copy_bandwidth)",
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "avg_launch_us": nn_us, "launches_timed": nn_launches, "kernels": kernels,
-            "note": "an exact gather search: what binds is the vector ALU and the L1 address path of the candidate "
-                    "walk (k_nn_grid) and instruction issue + workgroup dispatch (k_nn_cert), not HBM (DESIGN.md "
-                    "sections 4.1 / 5)",
-        }
-        if comm is not None:
-            # where rank 0's time went in the last (event-bracketed) step, and what an all-reduce costs alone
-            out["config"]["sharding"] = {
-                k: r.get(k) for k in ("plan_ms", "compact_ms", "index_ms", "iter_ms", "allreduce_ms", "n_tgt_local",
-                                      "n_src_local", "rccl_ranks", "shard_attempts", "owned_violations", "align_ms")}
-            out["config"]["sharding"]["allreduce_us_isolated"] = ar_us
-            out["config"]["sharding"]["note"] = (
-                "rank 0, last timed step: plan/compact = device time of slab planning and band selection; index = host "
-                "wall time of building the local clouds' order and grid; iter = host wall time of the 50 iterations; "
-                "allreduce = sum of the 50 ncclAllReduce(32 f64) by HIP events; isolated = back-to-back all-reduces alone")
+        out = assemble_line(a, world, r, T_gt, elapsed, step_ms, nn_ms, nn_launches, cert_ms, cert_launches, parallelism,
+                            pmc=pmc, peak_copy=peak_copy, sharded=comm is not None, ar_us=ar_us)
+        value = out["value"]
         if world == 1 and dist is None:
             # the same registration from HOST clouds: H2D of both clouds inside the step
             hc = {}

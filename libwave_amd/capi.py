@@ -651,7 +651,12 @@ class Context:
                                                     C.c_void_p(rp), rn, C.c_void_p(tp), tn, rs, rm,
                                                     C.byref(p), T.ctypes.data_as(_dp), C.byref(s)),
                          "wm_icp_align_sharded")
-        d = self._stats_dict(rc, T, s)
+        return self._sharded_dict(rc, T, s)
+
+    @staticmethod
+    def _sharded_dict(rc, T, s):
+        """_stats_dict + what a sharded registration says about itself (wm_icp_stats' planning / exchange fields)"""
+        d = Context._stats_dict(rc, T, s)
         d["owned_violations"] = s.owned_violations
         for k in ("plan_ms", "compact_ms", "index_ms", "iter_ms", "allreduce_ms", "n_tgt_local", "n_src_local",
                   "rccl_ranks", "shard_attempts"):

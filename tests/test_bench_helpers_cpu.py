@@ -81,3 +81,42 @@ def test_calibrated_gather_traffic():
     cal = json.load(open(os.path.join(ROOT, "profiles", "r04_fetch_size_calibration.json")))
     assert abs(cal[0]["factor_to_64B_sector_bytes"] - 2.0) < 0.05        # the stream: counted at half
     assert abs(cal[3]["factor_to_128B_line_bytes"] - 1.0) < 0.05         # four float4 of one line: the whole line, once
+
+
+def test_multi_gpu_bench_line_assembles_from_the_sharded_result_keys():
+    """`bench.py --gpus N` has never run on more than one physical GPU in the build container: what CAN be checked
+    without GPUs is that rank 0's line is assembled from exactly the keys the C-ABI wrapper produces for a sharded
+    registration (capi.Context._sharded_dict over wm_icp_stats) -- no KeyError on the first real 8-GPU run, the
+    contract's fields present, `config.sharding` carrying the per-phase budget, JSON-serialisable."""
+    import argparse
+    import json
+    import numpy as np
+    import bench
+    from libwave_amd import capi
+    st = capi.IcpStats()
+    st.iterations, st.n_corr, st.nn_ms, st.nn_launches, st.cert_launches, st.nn_cert_ms = 50, 8_000_000, 3.1, 50, 25, 0.7
+    st.plan_ms, st.compact_ms, st.index_ms, st.iter_ms, st.allreduce_ms = 0.4, 0.2, 0.5, 3.6, 0.6
+    st.n_tgt_local, st.n_src_local, st.rccl_ranks, st.shard_attempts, st.grid_cell = 1_050_000, 1_020_000, 8, 1, 0.183
+    r = capi.Context._sharded_dict(0, np.eye(4), st)
+    a = argparse.Namespace(points=1_000_000, steps=20, warmup=5, iters=50, max_corr=3.0)
+    for world in (2, 8):
+        out = bench.assemble_line(a, world, r, np.eye(4), elapsed=0.1, step_ms=[5.0] * 20, nn_ms=3.1, nn_launches=50,
+                                  cert_ms=0.7, cert_launches=25, parallelism="target x-slabs x%d" % world,
+                                  sharded=True, ar_us=11.0)
+        line = json.loads(json.dumps(out))
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in line, k
+        assert line["n_gpus"] == world and line["scaling"] == "weak" and line["vs_baseline"] is None
+        # whole-job throughput in 1M-point registration equivalents: N x the raw rate
+        assert abs(line["value"] - world * 20 / 0.1) < 1e-6
+        sh = line["config"]["sharding"]
+        for k in ("plan_ms", "compact_ms", "index_ms", "iter_ms", "allreduce_ms", "n_tgt_local", "n_src_local",
+                  "rccl_ranks", "shard_attempts", "owned_violations", "allreduce_us_isolated"):
+            assert k in sh, k
+        assert sh["rccl_ranks"] == 8 and sh["allreduce_us_isolated"] == 11.0
+        assert line["roofline"]["traffic"] is None and line["roofline"]["frac"] > 0
+    # ... and the one-GPU line (no sharding block)
+    one = bench.assemble_line(a, 1, capi.Context._stats_dict(0, np.eye(4), st), np.eye(4), 0.075, [3.75] * 20, 3.1, 50, 0.7, 25,
+                              "single", pmc={}, peak_copy=5800.0)
+    assert "sharding" not in one["config"] and one["n_gpus"] == 1 and json.dumps(one)
