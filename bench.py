@@ -300,6 +300,7 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu, copy_peak=None):
                       "note": "of a registration's time the objective is now %.0f %%: what is left are the two k-NN covariance "
                               "passes, the correspondence searches and the index builds" % (100.0 * rp["fdf_kernel_ms"] / ms if ms > 0 else 0.0)}}
     e["pcl_sums"]["roofline"].update(counter_traffic(pmc, "k_gicp_fdf", us_fdf, copy_peak))
+    e["roofline"].update(counter_traffic(pmc, "k_gicp_quad", us, copy_peak))
     if with_cpu:
         from oracle import oracle_py as O
         m = 20_000

@@ -13,7 +13,7 @@ def test_committed_pmc_summary_covers_the_quoted_kernels():
         pmc = json.load(f)
     assert pmc.get("tag"), "profiles/pmc_latest.json missing or without a tag"
     assert len(pmc.get("csrc_sha256", "")) == 64, "capture not stamped with the kernel sources' hash"
-    for k in ("k_nn_grid", "k_nn_cert", "k_gicp_fdf", "k_ndt_derivs"):
+    for k in ("k_nn_grid", "k_nn_cert", "k_gicp_fdf", "k_gicp_quad", "k_ndt_derivs"):
         assert "FETCH_SIZE_kb_per_dispatch" in pmc.get(k, {}), k
         assert "WRITE_SIZE_kb_per_dispatch" in pmc.get(k, {}), k
     assert pmc["k_ndt_derivs"].get("f64_flops_per_source_point", 0) > 100

@@ -84,3 +84,30 @@ def test_statistics_objective_needs_no_pass_per_evaluation(wm, ctx):
     print("objective kernels: statistics %.3f ms for %d evaluations (%d outer iterations); per-pair sums %.3f ms for %d"
           % (a["fdf_kernel_ms"], a["evaluations"], a["iterations"], b["fdf_kernel_ms"], b["evaluations"]))
     assert a["fdf_kernel_ms"] < 0.5 * b["fdf_kernel_ms"]
+
+
+def test_both_objectives_against_the_independent_fixed_point(wm, ctx, testscan):
+    """tests/golden/gicp_ndt_golden.json (make_golden_gicp_ndt.py: numpy / scipy, written without either path in
+    view) holds the FIXED POINT of pair -> minimise (scipy BFGS to 1e-12, double-precision transform) -> re-pair for the
+    reference's cases and a noisy voxel-filtered pair: where a GICP that converged fully would land.  Both objectives
+    are held to it at the golden tests' bars; the statistics objective -- the same smooth function scipy minimised -- is
+    never farther from it than PCL's per-pair objective is (plus the float quantum of the result)."""
+    import golden_checks as G
+    GOLD = G.golden()["gicp"]
+    for name in ("smallDisplacement", "fullResSmallDisplacement", "noisyFiltered"):
+        c = GOLD[name]
+        if name == "noisyFiltered":
+            target, P = G.noisy_filtered_pair(testscan, c)
+            bar = (3e-3, 1e-3)
+        else:
+            target, P = G.shifted(testscan, c["tx"])
+            bar = (1e-4, 1e-4)
+        a = ctx.gicp_match(testscan, target, res=c["res"])
+        b = ctx.gicp_match(testscan, target, res=c["res"], objective=wm.WM_GICP_OBJECTIVE_PCL_SUMS)
+        assert a["rc"] == 0 and b["rc"] == 0
+        da, ra = pose_error(a["T"], np.array(c["fixed_point_T"]))
+        db, rb = pose_error(b["T"], np.array(c["fixed_point_T"]))
+        print("GICP %s vs the independent fixed point: statistics %.2e m / %.2e rad, per-pair sums %.2e m / %.2e rad"
+              % (name, da, ra, db, rb))
+        assert da <= bar[0] and ra <= bar[1] and db <= bar[0] and rb <= bar[1]
+        assert da <= db + 2e-5
