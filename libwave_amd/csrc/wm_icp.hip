@@ -893,7 +893,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->src_sorted, &ctx->tgt_orig, &ctx->staging, &ctx->staging2, &ctx->cell_of, &ctx->counts,
                       &ctx->block_sums, &ctx->bbox_buf, &ctx->cloud_bbox, &ctx->keys, &ctx->keys_bak, &ctx->match_pt, &ctx->match_pt_bak, &ctx->d_levels, &ctx->ndt_keys, &ctx->ndt_keys2,
-                      &ctx->ndt_vox, &ctx->ndt_vkey, &ctx->ndt_hkeys, &ctx->ndt_hvals, &ctx->ndt_dense, &ctx->ndt_meanf, &ctx->ndt_cache_ref, &ctx->ndt_cache_ids, &ctx->ndt_cache_hits, &ctx->src_orig,
+                      &ctx->ndt_vox, &ctx->ndt_vkey, &ctx->ndt_hkeys, &ctx->ndt_hvals, &ctx->ndt_dense, &ctx->ndt_meanf, &ctx->src_orig,
                       &ctx->gicp_c1, &ctx->gicp_c2, &ctx->gicp_mahal, &ctx->gicp_mailbox, &ctx->src_grid.pts,
                       &ctx->src_grid.cell_start, &ctx->vg_idx, &ctx->vg_idx2, &ctx->vg_perm,
                       &ctx->vg_perm2, &ctx->vg_tmp, &ctx->vg_seg, &ctx->io_a, &ctx->io_b, &ctx->ds_ref,
@@ -1796,7 +1796,6 @@ int wm_set_option(wm_ctx *ctx, const char *name, double value) {
     else if (k == "cert_pad_frac" && value >= 0) ctx->tune_cert_pad_frac = (float) value;
     else if (k == "late") ctx->tune_late = value != 0 ? 1 : 0;
     else if (k == "gicp_served") ctx->tune_gicp_served = value == 2 ? 2 : (value != 0 ? 1 : 0);
-    else if (k == "ndt_cache") ctx->tune_ndt_cache = value != 0 ? 1 : 0;
     else if (k == "gicp_serve_test_stall_ms") ctx->gicp_serve_test_stall_ms = (int) value;
     else return WM_ERR_ARG;
     return WM_OK;

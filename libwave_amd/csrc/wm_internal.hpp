@@ -255,9 +255,6 @@ struct wm_ctx {
 
     // NDT voxel model of the target
     wm::DevBuf ndt_keys, ndt_keys2, ndt_vox, ndt_vkey, ndt_hkeys, ndt_hvals, ndt_dense, ndt_meanf;
-    wm::DevBuf ndt_cache_ref, ndt_cache_ids;  // the derivative passes' neighbour-list certificate (wm_ndt.hip: NdtCache)
-    wm::DevBuf ndt_cache_hits;                // developer: points that took their cached list, per pass (WM_TRACE)
-    int tune_ndt_cache = 1;                   // 0: every pass searches every point's voxels
     bool ndt_dense_on = false;  // dense cell -> voxel-slot table built (small lattices)
     int ndt_dense_lo[3] = {0, 0, 0}, ndt_dense_dim[3] = {0, 0, 0};
     int tune_ndt_dense = 1;

@@ -263,25 +263,6 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 
-// ---- the neighbour-list certificate (round 5).  Half of a derivative pass is FINDING a point's voxels: the nine rows of
-// its 3 x 3 x 3 block of cells, a float mean per occupied cell, the radius test (PCL's radiusSearch over the voxel
-// centroids).  A registration makes ~44 passes, and from one to the next a point moves by millimetres while the
-// nearest decision boundary -- a centroid's distance from `res` -- is centimetres away.  So a full search leaves, per
-// point, its list (up to kNdtCacheMax voxel slots), where the point was, and the smallest |distance - res| over ALL the
-// candidates it tested; a later pass that finds the point in the same cell (same block of cells: the same candidates)
-// and closer to that position than the margin takes the list as it is -- one 16-byte read and the slots, no table
-// rows, no means, no tests.  Same voxels in the same order as the search would have found: the pass's sums are the
-// same bits (tests/test_ndt_gpu.py: cached == uncached).  mode 0: off; 1: try, and refresh on a miss; 2: search and
-// store (the first pass of an align: whatever the arrays held belongs to another registration).
-constexpr int kNdtCacheMax = 8;
-struct NdtCache {
-    float4 *ref;       // [n]: position at the last search, w = margin (low 4 mantissa bits: the list's length; < 0: no list)
-    unsigned *ids;     // [kNdtCacheMax][n]
-    unsigned stride;   // n
-    int mode;
-    unsigned *hits;    // developer: points that took their list (nullptr: not counted)
-};
-
 __device__ __forceinline__ double dot3d(const double *a, const double *b) {
 #pragma clang fp contract(fast)  // (used by k_ndt_derivs only: see there)
     return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
@@ -293,7 +274,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HES
     k_ndt_derivs(const float4 *__restrict__ src, unsigned n, unsigned n_total, unsigned shard_rank,
                  unsigned shard_world, const NdtVoxel *__restrict__ vox,
                  const float4 *__restrict__ meanf, const unsigned long long *__restrict__ hkeys, const unsigned *__restrict__ hvals,
-                 unsigned mask, NdtDense dense, NdtArgs A, double *__restrict__ partials, NdtCache C) {
+                 unsigned mask, NdtDense dense, NdtArgs A, double *__restrict__ partials) {
     // The double-precision algebra of this kernel may fuse a multiply with the add that follows it
     // (the library is built with -ffp-contract=off for the FLOAT arithmetic that has to reproduce PCL's
     // bits: the point transform and the radius test below, written with explicit _rn intrinsics, are not
@@ -348,30 +329,6 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HES
         // [1, n-2] reads in bounds and any other has no neighbours.  All nine row loads (three
         // adjacent cells each) are issued together.
         int n_cand = 0;
-        int n_near = 0;
-        bool hit = false;
-        if (C.mode == 1) {  // (uniform)
-            const float4 cr = C.ref[idx];
-            const unsigned wb = __float_as_uint(cr.w);
-            const float margin = __uint_as_float(wb & ~0xFu);
-            const int rci = (int) floorf(__fmul_rn(cr.x, A.inv_res)), rcj = (int) floorf(__fmul_rn(cr.y, A.inv_res)),
-                      rck = (int) floorf(__fmul_rn(cr.z, A.inv_res));
-            const float ex = xt0 - cr.x, ey = xt1 - cr.y, ez = xt2 - cr.z;
-            const float disp = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez);
-            // (cushions: the approximate square roots, the float rounding of the transform and of the test's own
-            // arithmetic -- ~1e-5 m on 100 m coordinates -- against margins of centimetres)
-            hit = margin > 0.f && rci == ci && rcj == cj && rck == ck && disp * 1.0001f + 1e-4f < margin;
-            if (hit) {
-                n_near = (int) (wb & 0xFu);
-                for (int t = 0; t < n_near; ++t) s_near[t * kBlock + threadIdx.x] = C.ids[(size_t) t * C.stride + idx];
-            }
-            if (C.hits) {
-                const unsigned long long hm = __ballot(hit);
-                if ((threadIdx.x & 63u) == 0u && hm) atomicAdd(C.hits, (unsigned) __popcll(hm));
-            }
-        }
-        float near_margin = 3.0e38f;  // smallest |distance - res| over the candidates tested (the certificate's margin)
-        if (!hit) {
         if (dense.table) {  // uniform
             const int ta = ci - dense.i0, tb = cj - dense.j0, tc = ck - dense.k0;
             if (ta >= 1 && tb >= 1 && tc >= 1 && ta <= dense.nx - 2 && tb <= dense.ny - 2 && tc <= dense.nz - 2) {
@@ -414,6 +371,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HES
         // 1b: kd-tree radius test in float on the float means (one 16-byte load each), four
         // candidates per trip so that four loads are in flight; survivors are compacted in place
         // (the write index never passes the read index), still in cell order
+        int n_near = 0;
 #pragma unroll 1
         for (int r = 0; r < n_cand; r += 4) {
             unsigned cv[4];
@@ -426,25 +384,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HES
             for (int u = 0; u < 4; ++u) {
                 const float fx = __fsub_rn(xt0, cm[u].x), fy = __fsub_rn(xt1, cm[u].y), fz = __fsub_rn(xt2, cm[u].z);
                 const float dd = __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz));
-                if (r + u < n_cand) {
-                    if (C.mode != 0) near_margin = fminf(near_margin, fabsf(__builtin_amdgcn_sqrtf(dd) - A.res_f));
-                    if (dd <= A.res2_f) {  // <=> (double) dd < A.res2
-                        s_near[n_near * kBlock + threadIdx.x] = cv[u];
-                        ++n_near;
-                    }
+                if (r + u < n_cand && dd <= A.res2_f) {  // <=> (double) dd < A.res2
+                    s_near[n_near * kBlock + threadIdx.x] = cv[u];
+                    ++n_near;
                 }
             }
         }
-        if (C.mode != 0) {  // leave the list for the next passes
-            const bool fits = n_near <= kNdtCacheMax;
-            if (fits)
-                for (int t = 0; t < n_near; ++t) C.ids[(size_t) t * C.stride + idx] = s_near[t * kBlock + threadIdx.x];
-            // the margin, rounded DOWN into a float whose low four mantissa bits carry the list's length
-            const float m = near_margin * 0.9999f - 1e-6f;
-            const unsigned wb = fits && m > 0.f ? ((__float_as_uint(fminf(m, 1.0e30f)) & ~0xFu) | (unsigned) n_near) : 0x80000000u;
-            C.ref[idx] = make_float4(xt0, xt1, xt2, __uint_as_float(wb));
-        }
-        }  // (!hit)
         // the next voxel's record (mean + inverse covariance, 96 B) is requested before the
         // current one is evaluated: with two waves per SIMD a pass-2 trip would otherwise start
         // with a full memory round trip that nothing hides
@@ -753,10 +698,6 @@ struct NdtEval {
     double host_launch_us = 0, host_wait_us = 0;  // WM_NDT_PROFILE=2: wall time inside the launch calls / the wait
     int ls_hist[12] = {0};  // line searches by their number of extra trials (developer: WM_TRACE)
     int rc = WM_OK;
-    // the neighbour-list certificate (NdtCache): off for a lone evaluation; in an align the first pass stores, the rest try
-    bool cache = false;
-    int cache_passes = 0;
-    unsigned long long cache_hits = 0;  // developer (WM_TRACE)
     // (what ndt_align_loop / step_length_mt ask of an objective, wm_ndt_ctl.hpp)
     double eval(const double p[6], double *grad, double *hess);
     bool failed() const { return rc != WM_OK; }
@@ -775,7 +716,6 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
     A.inv_res = 1.0f / (float) E.prm->res;
     A.res2 = E.prm->res * E.prm->res;
     A.res2_f = threshold_d2_strict(E.prm->res);
-    A.res_f = sqrtf(A.res2_f);
     A.d1 = E.d1;
     A.d2 = E.d2;
     angle_derivatives(p, E.prm->pcl_d1_sign, &A);
@@ -804,41 +744,23 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
         dense = NdtDense{ctx->ndt_dense.as<int>(), ctx->ndt_dense_lo[0], ctx->ndt_dense_lo[1],
                          ctx->ndt_dense_lo[2], ctx->ndt_dense_dim[0], ctx->ndt_dense_dim[1],
                          ctx->ndt_dense_dim[2]};
-    NdtCache C{nullptr, nullptr, 0u, 0, nullptr};
-    if (E.cache && ctx->tune_ndt_cache && n_total > 0) {
-        if (ctx->ndt_cache_ref.reserve((size_t) n_total * sizeof(float4)) != hipSuccess ||
-            ctx->ndt_cache_ids.reserve((size_t) n_total * kNdtCacheMax * sizeof(unsigned)) != hipSuccess) {
-            ctx->last_error = "ndt_eval: out of memory (neighbour lists)";
-            *rc = WM_ERR_NOMEM;
-            return 0;
-        }
-        C.ref = ctx->ndt_cache_ref.as<float4>();
-        C.ids = ctx->ndt_cache_ids.as<unsigned>();
-        C.stride = n_total;
-        C.mode = E.cache_passes == 0 ? 2 : 1;
-        if (ctx->trace && ctx->ndt_cache_hits.reserve(256 * sizeof(unsigned)) == hipSuccess) {
-            if (E.cache_passes == 0) (void) hipMemsetAsync(ctx->ndt_cache_hits.p, 0, 256 * sizeof(unsigned), ctx->stream);
-            C.hits = ctx->ndt_cache_hits.as<unsigned>() + (E.cache_passes < 255 ? E.cache_passes : 255);
-        }
-        E.cache_passes++;
-    }
     const auto t_launch0 = std::chrono::steady_clock::now();
     if (ctx->ndt_profile) (void) hipEventRecord(ctx->ev_a, ctx->stream);
     if (hess && grad)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<true, true>), dim3(nb), dim3(kBlock), 0,
                            ctx->stream, src, n, n_total, s_rank, s_world, vox, ctx->ndt_meanf.as<float4>(), hk,
                            hv, ctx->ndt_hmask, dense, A,
-                           partials, C);
+                           partials);
     else if (grad)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<true, false>), dim3(nb), dim3(kBlock), 0,
                            ctx->stream, src, n, n_total, s_rank, s_world, vox, ctx->ndt_meanf.as<float4>(), hk,
                            hv, ctx->ndt_hmask, dense, A,
-                           partials, C);
+                           partials);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<false, true>), dim3(nb), dim3(kBlock), 0,
                            ctx->stream, src, n, n_total, s_rank, s_world, vox, ctx->ndt_meanf.as<float4>(), hk,
                            hv, ctx->ndt_hmask, dense, A,
-                           partials, C);
+                           partials);
     if (ctx->ndt_profile) (void) hipEventRecord(ctx->ev_b, ctx->stream);
     if (!ctx->h_ndt && hipHostMalloc((void **) &ctx->h_ndt, 64 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
         ctx->last_error = "ndt_eval: pinned allocation failed";
@@ -967,18 +889,9 @@ int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *prm, double T_out[16], wm_ndt
         E.d1 = -log(c1 + c2) - d3;
         E.d2 = -2.0 * log((-log(c1 * exp(-0.5) + c2) - d3) / E.d1);
     }
-    E.cache = true;
     NdtLoopOut lo;
     ndt_align_loop(E, prm->step_size, prm->t_eps, prm->max_iter, prm->force_iterations, &lo);
     if (E.rc != WM_OK) return E.rc;
-    if (ctx->trace && E.cache_passes > 0 && ctx->ndt_cache_hits.p) {  // developer: how many points took their list, pass by pass
-        std::vector<unsigned> h(256);
-        if (copy_to_caller(ctx, h.data(), ctx->ndt_cache_hits.p, 256 * sizeof(unsigned)) == WM_OK) {
-            fprintf(stderr, "[wm] ndt: points that took their cached neighbour list, per pass (of %zu):", ctx->n_src);
-            for (int k = 0; k < E.cache_passes && k < 256; ++k) fprintf(stderr, " %u", h[(size_t) k]);
-            fprintf(stderr, "\n");
-        }
-    }
     const double *p = lo.p;
     const double score = lo.score;
     const int iter = lo.iterations;

@@ -163,7 +163,6 @@ struct NdtArgs {
     float inv_res;
     double res2, d1, d2;
     float res2_f;  // the largest float d2 with (double) d2 < res2: the radius test in one float compare, same decisions
-    float res_f;   // sqrt(res2_f): where the radius test's decision changes, as a distance (the neighbour-list certificate)
     // computeAngleDerivatives: 8 Jacobian and 15 Hessian 3-vectors
     double j[8][3];
     double h[15][3];

@@ -630,7 +630,6 @@ __global__ void __launch_bounds__(kNsThreads) k_ndt_small(const NsPair *__restri
         S.pr = table[blockIdx.x];
         S.P = P;
         S.A.res2_f = res2_f;
-        S.A.res_f = sqrtf(res2_f);
         S.cmd = 0u;
         S.evals = 0;
     }

@@ -256,51 +256,3 @@ def test_ndt_pcl18_literal_mode_tracks_the_oracle(wm, ctx, oracle, testscan):
         assert dt < 1e-3 and ang < 1e-3, (max_iter, dt, ang)
     got = ctx.ndt_align(res=0.3, step_size=3.0, max_iter=100, t_eps=1e-8, skip_line_search=1)
     assert got["rc"] == 0 and got["converged"] and got["iterations"] == 102
-
-
-def _ndt_with_cache(wm, cache, ref, tgt, **kw):
-    c = wm.Context(0)
-    try:
-        c.set_option("ndt_cache", cache)
-        c.set_source(ref)
-        c.set_target(tgt)
-        return c.ndt_align(**kw)
-    finally:
-        c.close()
-
-
-@pytest.mark.parametrize("case", ["testscan-0.3", "testscan-5", "rings-0.5", "uniform-1-literal", "hash-grid"])
-def test_neighbour_list_certificate_changes_nothing(wm, oracle, testscan, case):
-    """Half of a derivative pass is finding every point's voxels (PCL's radiusSearch over the centroids); from one pass
-    of a registration to the next a point moves by far less than the distance of the nearest decision boundary, and
-    then its list of the last search is taken as it is (csrc/wm_ndt.hip: NdtCache).  Same voxels in the same order as
-    a search would have found: the SAME BITS -- transform, score, Newton iterations, passes -- with and without, on
-    the reference's cases, a ring scan, PCL-1.8's undamped steps (large moves between passes: the certificate must
-    fail and refresh there) and the hash-grid look-up."""
-    kw = {}
-    if case.startswith("testscan"):
-        res = float(case.split("-")[1])
-        P = np.eye(4)
-        P[0, 3] = 0.2
-        ref, tgt = testscan, oracle.transform_cloud_d(testscan, P)
-        kw = dict(res=res, step_size=3, max_iter=100, t_eps=1e-8)
-    elif case == "rings-0.5":
-        ref, tgt, _ = synth.pair(200_000, seed=42, pattern="rings")
-        kw = dict(res=0.5)
-    elif case == "uniform-1-literal":
-        ref, tgt, _ = synth.pair(60_000, seed=8)
-        kw = dict(res=1.0, skip_line_search=1, max_iter=30)
-    else:
-        ref, tgt, _ = synth.pair(40_000, seed=9)
-        ref = ref.copy()
-        tgt = tgt.copy()
-        tgt[0] = (9000.0, -7000.0, 30.0)   # a lattice too large for the dense table: the hash look-up
-        kw = dict(res=0.25)
-    a = _ndt_with_cache(wm, 1, ref, tgt, **kw)
-    b = _ndt_with_cache(wm, 0, ref, tgt, **kw)
-    assert a["rc"] == b["rc"] and (a["iterations"], a["evaluations"], a["n_voxels"]) == (b["iterations"], b["evaluations"], b["n_voxels"])
-    assert a["score"] == b["score"]
-    if a["T"] is None:
-        assert b["T"] is None
-    else:
-        assert np.array_equal(a["T"], b["T"])
