@@ -30,7 +30,7 @@ for name in ("fetch", "write"):
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter(); seen = set()
     for row in csv.DictReader(open(path)):
         k = row["Kernel_Name"].split("(")[0]
-        if not any(t in k for t in ("k_gicp_fdf", "k_ndt_derivs", "k_gicp_cov", "k_gicp_mahal")): continue
+        if not any(t in k for t in ("k_gicp_fdf", "k_gicp_quad", "k_ndt_derivs", "k_gicp_cov", "k_gicp_mahal")): continue
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
         key = (k, row["Dispatch_Id"])
         if key not in seen:
