@@ -299,6 +299,10 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu, copy_peak=None):
                       "algorithmic_bytes_per_launch": bytes_pass, "avg_launch_us": us, "launches_timed": passes,
                       "note": "of a registration's time the objective is now %.0f %%: what is left are the two k-NN covariance "
                               "passes, the correspondence searches and the index builds" % (100.0 * rp["fdf_kernel_ms"] / ms if ms > 0 else 0.0)}}
+    try:
+        e["in_flight"] = two_in_flight(torch, capi, gicp)
+    except Exception as ex:
+        e["in_flight"] = {"error": str(ex)}
     e["pcl_sums"]["roofline"].update(counter_traffic(pmc, "k_gicp_fdf", us_fdf, copy_peak))
     e["roofline"].update(counter_traffic(pmc, "k_gicp_quad", us, copy_peak))
     if with_cpu:
@@ -372,6 +376,10 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu, copy_peak=None):
         roof["frac"] = roof["achieved"] / F64_VALU_PEAK_TFLOPS
     roof.update(counter_traffic(pmc, "k_ndt_derivs", us, copy_peak))
     e["roofline"] = roof
+    try:
+        e["in_flight"] = two_in_flight(torch, capi, ndt)
+    except Exception as ex:
+        e["in_flight"] = {"error": str(ex)}
     if with_cpu:
         from oracle import oracle_py as O
         m = 100_000
@@ -564,6 +572,34 @@ def in_flight_throughput(torch, capi, d_ref, d_tgt, h_ref, h_tgt, a, crews=(1, 2
         out.append({"clouds": mode, "rows": rows,
                     "speedup_2_in_flight": rows[1]["registrations_per_s"] / rows[0]["registrations_per_s"] if len(rows) > 1 else None})
     return out
+
+
+def two_in_flight(torch, capi, reg, regs_per_worker=5):
+    """registrations/s of `reg(ctx)` with one and with two worker threads, each with its own context (the MultiMatcher
+    pattern on one GPU, as in_flight_throughput): what the host round trips of a GICP / NDT registration leave idle."""
+    rows = {}
+    for crew in (1, 2):
+        ctxs = [capi.Context(0) for _ in range(crew)]
+        for c in ctxs:
+            reg(c)
+            reg(c)
+        torch.cuda.synchronize()
+        start = threading.Barrier(crew + 1)
+
+        def worker(c):
+            start.wait()
+            for _ in range(regs_per_worker):
+                reg(c)
+        th = [threading.Thread(target=worker, args=(c,)) for c in ctxs]
+        [t.start() for t in th]
+        start.wait()
+        t0 = time.perf_counter()
+        [t.join() for t in th]
+        rows[crew] = crew * regs_per_worker / (time.perf_counter() - t0)
+        for c in ctxs:
+            c.close()
+    return {"registrations_per_s_1_in_flight": rows[1], "registrations_per_s_2_in_flight": rows[2],
+            "speedup_2_in_flight": rows[2] / rows[1]}
 
 
 def assemble_line(a, world, r, T_gt, elapsed, step_ms, nn_ms, nn_launches, cert_ms, cert_launches, parallelism,
