@@ -1108,7 +1108,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
             bqy = c.y;
             bqz = c.z;
         }
-        st_f4(&match_pt[i_e], bqx, bqy, bqz, __uint_as_float((unsigned) best), nt);  // (.w: the match's index, for k_nn_cert)
+        // (.w: the match's index, for k_nn_cert.)  A query that KEPT its match -- the seed's key, formed from match_pt[i]
+        // itself under this pose, is still the best -- finds match_pt[i] already holding these very coordinates and
+        // this index: no store (16 of the 24 result bytes of most queries once the clouds are close)
+        if (!(best == seeded && (unsigned) best != kNoIdx))
+            st_f4(&match_pt[i_e], bqx, bqy, bqz, __uint_as_float((unsigned) best), nt);
     }
     if (lane == 0 && n_heavy) atomicAdd(&st->queue_count[1], n_heavy);  // stats only
     const unsigned long long prof_store = COST ? clock64() : 0ull;
