@@ -796,8 +796,8 @@ def main():
     ar_us = ctx.allreduce_probe(comm) if comm is not None else None
     if dist:
         dist.barrier()
-    # (no collector pauses inside the timed region: one generation-2 collection over the interpreter's heap -- the
-    # synthetic clouds, the ctypes wrappers -- was seen as a lone 7 ms step among 3.75 ms ones)
+    # (no collector pauses inside the timed region: a capture of this command showed a lone 7 ms step among 3.75 ms
+    # ones, profiles/r05m_bench_line_noprof.json; the interpreter's collector is the one pause this script can rule out)
     import gc
     gc.collect()
     gc.disable()
