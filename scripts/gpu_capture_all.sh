@@ -29,8 +29,8 @@ python bench.py > gpurun_out/${TAG}_bench_line_noprof.json 2> /dev/null
   # (steady state: 16 000 / 40 000 pairs -- a launch of 256 lasts 25 / 12 ms, a run of 4 000 pairs is warm-up and tail)
   # MultiMatcher<GICPMatcher>: the batched small GICP (one registration per compute unit), full resolution and the
   # matcher's default voxel filter; MultiMatcher<NDTMatcher>: the batched small NDT, 1 m voxels and the matcher's default 5 m
-  BENCH_MATCHER=gicp BENCH_QUEUE=10 timeout 200 ./bench_multimatcher 20000 16000 1 2 4 8 16
-  BENCH_MATCHER=gicp BENCH_QUEUE=2048 timeout 200 ./bench_multimatcher 20000 16000 1 2 4 16
+  BENCH_MATCHER=gicp BENCH_QUEUE=10 timeout 200 ./bench_multimatcher 20000 20000 1 2 4 8 16
+  BENCH_MATCHER=gicp BENCH_QUEUE=2048 timeout 200 ./bench_multimatcher 20000 20000 1 2 4 16
   BENCH_MATCHER=gicp BENCH_QUEUE=10 timeout 200 ./bench_multimatcher 10000 6000 4 16
   BENCH_MATCHER=gicp BENCH_QUEUE=10 BENCH_RES=0.1 timeout 200 ./bench_multimatcher 55000 1500 4 16
   BENCH_MATCHER=ndt BENCH_QUEUE=10 timeout 200 ./bench_multimatcher 20000 40000 1 2 4 8 16
