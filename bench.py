@@ -12,8 +12,9 @@
   N > 1  : one process per GPU (launched plainly, `python bench.py --gpus N` re-executes itself under
            torch.distributed.run on 127.0.0.1).  The registration is sharded INSIDE the library
            (wm_icp_align_sharded, libwave_amd/csrc/wm_shard.hip): slab planning on the
-           device, the iteration loop in C++, one ncclAllReduce (RCCL over xGMI) of 32
-           doubles per iteration on the context's stream.  torch.distributed only carries
+           device, the iteration loop in C++, one exchange of 34 doubles per iteration (the
+           ranks' mailboxes over xGMI, summed inside the solve kernel; ncclAllReduce on the
+           context's stream where mailboxes cannot be set up).  torch.distributed only carries
            the 128-byte RCCL id to the ranks and the barriers around the timed region.
            Weak scaling: N x 1M points per cloud.
 
@@ -691,12 +692,18 @@ def assemble_line(a, world, r, T_gt, elapsed, step_ms, nn_ms, nn_launches, cert_
         # where rank 0's time went in the last (event-bracketed) step, and what an all-reduce costs alone
         out["config"]["sharding"] = {
             k: r.get(k) for k in ("plan_ms", "compact_ms", "index_ms", "iter_ms", "allreduce_ms", "n_tgt_local",
-                                  "n_src_local", "rccl_ranks", "shard_attempts", "owned_violations", "align_ms")}
+                                  "n_src_local", "rccl_ranks", "shard_attempts", "owned_violations", "align_ms",
+                                  "exchange_in_kernel")}
         out["config"]["sharding"]["allreduce_us_isolated"] = ar_us
+        out["config"]["sharding"]["exchange"] = (
+            "mailboxes: every rank's 34-double block stored into every peer's mailbox over xGMI and summed in rank "
+            "order INSIDE the solve kernel (wm_xchg.hpp)" if r.get("exchange_in_kernel") else
+            "ncclAllReduce(34 f64) on the context's stream between a rank's sums and its solve")
         out["config"]["sharding"]["note"] = (
             "rank 0, last timed step: plan/compact = device time of slab planning and band selection; index = host "
-            "wall time of building the local clouds' order and grid; iter = host wall time of the 50 iterations; "
-            "allreduce = sum of the 50 ncclAllReduce(32 f64) by HIP events; isolated = back-to-back all-reduces alone")
+            "wall time of enqueueing the local clouds' order and grid; iter = host wall time of the 50 iterations; "
+            "allreduce = sum of the 50 ncclAllReduce by HIP events (0 when the exchange runs inside the solve kernel); "
+            "isolated = one exchange alone, back to back (a kernel of its own there)")
     return out
 
 
@@ -788,19 +795,22 @@ def main():
         def step(profile):
             return ctx.icp_align_sharded(comm, d_ref, d_tgt, max_corr=a.max_corr, force_iterations=a.iters,
                                          nn_method=capi.WM_NN_GRID, profile=profile, carry_state=0)
-        parallelism = "target x-slabs x%d + ncclAllReduce(32 f64)/iteration inside the library" % world
+        parallelism = ("target x-slabs x%d + one exchange of 34 f64 per iteration inside the library (mailboxes over "
+                       "xGMI inside the solve kernel; ncclAllReduce where they cannot be set up)" % world)
 
+    # (no collector pauses inside the timed region: a capture of this command showed a lone 7 ms step among 3.75 ms
+    # ones, profiles/r05m_bench_line_noprof.json; the interpreter's collector is the one pause this script can rule
+    # out.  Collected BEFORE the warm-up: a collection between warm-up and timing leaves the GPU idle for tens of
+    # milliseconds and the first timed step 0.3 ms slower, gpurun_out/r05n_jitter)
+    import gc
+    gc.collect()
+    gc.disable()
     for _ in range(a.warmup):
         r = step(1)
     torch.cuda.synchronize()
     ar_us = ctx.allreduce_probe(comm) if comm is not None else None
     if dist:
         dist.barrier()
-    # (no collector pauses inside the timed region: a capture of this command showed a lone 7 ms step among 3.75 ms
-    # ones, profiles/r05m_bench_line_noprof.json; the interpreter's collector is the one pause this script can rule out)
-    import gc
-    gc.collect()
-    gc.disable()
     t0 = time.perf_counter()
     nn_ms = 0.0
     nn_launches = 0
@@ -809,10 +819,10 @@ def main():
     step_ms = []
     for k in range(a.steps):
         # HIP events around every launch of the correspondence kernel cost a barrier packet
-        # each (~0.4 ms per registration), so they bracket the launches of ONE timed step in ten
-        # (at least the last: 50 launches, every iteration of one registration); the others run
-        # exactly as a caller's registration would
-        timed = (k % 10 == 9) or k == a.steps - 1
+        # each (~0.35 ms per registration), so they bracket the launches of ONE step per twenty
+        # (at least the last: 50 launches, every iteration of one registration -- each step runs
+        # the same 50); the others run exactly as a caller's registration would
+        timed = (k % 20 == 19) or k == a.steps - 1
         t_step = time.perf_counter()
         r = step(1 if timed else 0)
         step_ms.append((time.perf_counter() - t_step) * 1e3)  # (align blocks: host time = step time)

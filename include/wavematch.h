@@ -151,6 +151,8 @@ typedef struct {
     int late_iterations; /* iterations that ran inside it */
     int late_launches;   /* its launches (1, unless its own policy sent it back to full searches in between) */
     float late_ms;       /* their duration by HIP events (profile >= 1): search + sums + solve of those iterations */
+    int exchange_in_kernel; /* sharded: 1 if the iterations' blocks were exchanged through the ranks' mailboxes inside
+                               the solve kernel (one launch per iteration's tail), 0 if by ncclAllReduce between two */
 } wm_icp_stats;
 
 void wm_icp_default_params(wm_icp_params *p);
@@ -486,16 +488,25 @@ typedef int (*wm_allreduce_fn)(double *vals, int n, void *user);
 int wm_ndt_set_shard(wm_ctx *ctx, int rank, int world, wm_allreduce_fn reduce, void *user);
 
 /* ------------------------------------------ sharded registration, driven from C (RCCL inside)
- * A wm_comm is one rank's handle on a group of `world` ranks, one GPU each, whose exchange step is
- * an RCCL all-reduce over xGMI on the calling context's stream (librccl is linked into this
- * library).  No reference counterpart: libwave's only parallelism is one matcher per thread
+ * A wm_comm is one rank's handle on a group of `world` ranks, one GPU each (librccl is linked into this
+ * library).  The ICP loop's exchange step -- 34 doubles per rank and iteration -- goes through MAILBOXES where
+ * they can be set up: fine-grained device memory of every rank, mapped into its peers (IPC handles all-gathered
+ * over the communicator between processes, peer access inside one), into which the solve kernel of every rank
+ * stores its block over xGMI and out of which it adds all blocks in rank order (csrc/wm_xchg.hpp: no launch
+ * between a rank's sums and its solve).  A probe exchange at creation and an all-reduced verdict decide, alike
+ * on every rank, whether they are used; otherwise, and with WM_COMM_P2P=0, the step is an RCCL all-reduce on the
+ * calling context's stream.  A peer whose block does not arrive within WM_COMM_P2P_TIMEOUT_MS (default 5000)
+ * fails the registration with WM_ERR_RCCL instead of hanging.  wm_icp_stats.exchange_in_kernel says which ran.
+ * No reference counterpart: libwave's only parallelism is one matcher per thread
  * (wave_matching/include/wave/matching/multi_matcher.hpp:32).
  *   wm_comm_get_unique_id + wm_comm_init_rank   one rank per process (or thread): rank 0 creates the
  *        128-byte id, the launcher hands it to every rank (bench.py: torch.distributed broadcast;
  *        MPI_Bcast; a file), every rank calls init_rank on its device.   = ncclCommInitRank
  *   wm_comm_init_all     all ranks in one process, `devices[r]` for rank r.  = ncclCommInitAll
  *   wm_comm_init_local   test stand-in: `n` ranks on ONE device whose all-reduce is a host-side sum
- *        in rank order at a barrier (each rank must run on its own thread). */
+ *        in rank order at a barrier (each rank must run on its own thread).  WM_COMM_P2P_LOCAL=1 gives these
+ *        ranks mailboxes too (tests of the protocol; on one GPU a rank's first-call allocations wait for the
+ *        other rank's polling kernel, so contexts must have registered once before). */
 typedef struct wm_comm wm_comm;
 #define WM_COMM_ID_BYTES 128
 int wm_comm_get_unique_id(void *id_out /* WM_COMM_ID_BYTES */);
@@ -503,7 +514,8 @@ int wm_comm_init_rank(wm_comm **out, int device, const void *id, int rank, int w
 int wm_comm_init_all(wm_comm **comms /* [n] */, const int *devices, int n);
 int wm_comm_init_local(wm_comm **comms /* [n] */, int n, int device);
 void wm_comm_destroy(wm_comm *comm);
-/* us per all-reduce of WM_STATS_LEN doubles, `reps` back to back on the context's stream (collective) */
+/* us per exchange of the loop's block (the mailbox exchange in a kernel of its own, or ncclAllReduce), `reps` back
+ * to back on the context's stream (collective) */
 int wm_comm_allreduce_probe(wm_ctx *ctx, wm_comm *comm, int reps, double *us_out);
 int wm_comm_rank(const wm_comm *comm);
 int wm_comm_world(const wm_comm *comm);

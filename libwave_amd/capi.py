@@ -51,7 +51,8 @@ class IcpStats(C.Structure):
                 ("plan_ms", C.c_float), ("compact_ms", C.c_float), ("index_ms", C.c_float), ("iter_ms", C.c_float),
                 ("allreduce_ms", C.c_float), ("n_tgt_local", C.c_uint), ("n_src_local", C.c_uint),
                 ("rccl_ranks", C.c_int), ("shard_attempts", C.c_int),
-                ("late_iterations", C.c_int), ("late_launches", C.c_int), ("late_ms", C.c_float)]
+                ("late_iterations", C.c_int), ("late_launches", C.c_int), ("late_ms", C.c_float),
+                ("exchange_in_kernel", C.c_int)]
 
 
 class BatchItem(C.Structure):
@@ -659,7 +660,7 @@ class Context:
         d = Context._stats_dict(rc, T, s)
         d["owned_violations"] = s.owned_violations
         for k in ("plan_ms", "compact_ms", "index_ms", "iter_ms", "allreduce_ms", "n_tgt_local", "n_src_local",
-                  "rccl_ranks", "shard_attempts"):
+                  "rccl_ranks", "shard_attempts", "exchange_in_kernel"):
             d[k] = getattr(s, k)
         return d
 

@@ -14,6 +14,7 @@
 //      the RCCL all-reduce carries between (2) and (3).
 #include "wm_internal.hpp"
 #include "wm_icp_step.hpp"
+#include "wm_xchg.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -167,15 +168,36 @@ __global__ void __launch_bounds__(kBlock)
     }
 }
 
+// What the host steers by while it runs ahead of the device (wm_icp_align): one 8-byte word in pinned memory -- done
+// flag, iterations finished, the step's size -- in ONE system-scope store (pub[0]: the latest; pub[k]: iteration k's
+// own record, so that what the host decides from does not depend on when it looks).
+__device__ __forceinline__ void publish_step(const IcpDevState *s, unsigned long long *pub, int pub_slots) {
+    if (!pub) return;
+    // [iteration : 16 | step size as bfloat16 : 16 | changed matches : 16 | searched by the certificate kernel : 16]
+    // -- fractions in 1 / 65535
+    const unsigned f_ch = (unsigned) (fminf(fmaxf(s->frac_changed, 0.f), 1.f) * 65535.f + 0.5f);
+    const unsigned f_un = (unsigned) (fminf(fmaxf(s->frac_unsettled, 0.f), 1.f) * 65535.f + 0.5f);
+    const unsigned long long w = ((unsigned long long) ((unsigned) s->iter & 0xFFFFu) << 48) |
+                                 ((unsigned long long) (__float_as_uint(s->step_disp) >> 16) << 32) |
+                                 ((unsigned long long) f_ch << 16) | (unsigned long long) f_un;
+    if (s->iter >= 1 && s->iter <= pub_slots) __hip_atomic_store(pub + s->iter, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // ([0]: bit 0 = done, above it the number of iterations finished by then -- ONE word, so that a host that sees
+    // `done` before the last record knows whether that record is still to come)
+    __hip_atomic_store(pub, s->done ? (1ull | ((unsigned long long) (unsigned) s->iter << 1)) : 0ull, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // PHASE 1: sum partials -> st->stats.   PHASE 2: solve + criteria from st->stats.
 // Single GPU launches <1|2>; the sharded path launches <1>, all-reduces
 // st->stats over RCCL, then launches <2>.
 // THREADS = 256 for the few rows of k_icp_stats, 1024 for the thousands of rows the fused search
 // kernel leaves (one row per workgroup).
+// PHASES == 7 (sharded loop, mailboxes available): 1, then the exchange of the block with the other ranks INSIDE this
+// kernel (wm_xchg.hpp), then 2 -- one launch per iteration where <1>, ncclAllReduce, <2> are three.
 template <int PHASES, int THREADS>
 __global__ void __launch_bounds__(THREADS)
     k_reduce_solve(const double *__restrict__ partials, int nblocks, IcpDevState *st,
-                   double *stats_io, unsigned long long *pub, int pub_slots, int blk_ext) {
+                   double *stats_io, unsigned long long *pub, int pub_slots, int blk_ext, XchgDev xd) {
     // (blk_ext: stats_io is the sharded loop's kBlkLen block, not a caller's WM_STATS_LEN one)
     // The solve runs in ONE lane and touches two dozen fields of the state: read from HBM one
     // dependent access at a time that is most of this kernel's ~10 us.  So the whole state is
@@ -259,7 +281,48 @@ __global__ void __launch_bounds__(THREADS)
         for (int off = 32; off > 0; off >>= 1) v += (unsigned) __shfl_xor((int) v, off);
         if (threadIdx.x == 0) s_uns = v;
     }
-    if (threadIdx.x == 0) {
+    if constexpr (PHASES == 7) {
+        // this rank's block -> every rank's mailbox; every rank's block -> the sum, in rank order (all threads)
+        __shared__ double s_blk[kBlkLen], s_sum[kBlkLen];
+        __shared__ unsigned s_half[kXMaxWorld * kXWords], s_ctl[2];
+        if (threadIdx.x == 0) {
+            double a[kAcc];
+#pragma unroll
+            for (int k = 0; k < kAcc; ++k) a[k] = tot[k];
+            double ex[kStatsLen];
+            expand_stats(s_st.mode, a, ex, s_st.changed_mask);
+            s_st.local_handled = ex[kStatsLen - 1];
+            ex[kStatsLen - 2] = s_st.stripe_finite;  // (as in <1>: summed, it is the cloud's count)
+#pragma unroll
+            for (int k = 0; k < kStatsLen; ++k) s_blk[k] = ex[k];
+            s_blk[kStatsLen] = (double) s_uns;
+            s_blk[kStatsLen + 1] = 0.0;
+        }
+        __syncthreads();
+        const bool arrived = xchg_allreduce<THREADS>(xd, s_blk, s_sum, s_half, s_ctl);
+        if (threadIdx.x == 0) {
+            s_st.dbg[0] = t_start;
+            s_st.dbg[1] = clock64();
+            if (!arrived) {  // a peer never delivered: the registration ends here, on this rank, with an error
+                s_st.xchg_failed = 1;
+                s_st.done = 1;
+                s_st.converged = 0;
+                if (pub) __hip_atomic_store(pub, 1ull | ((unsigned long long) (unsigned) s_st.iter << 1), __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                double stats[kStatsLen];
+#pragma unroll
+                for (int k = 0; k < kStatsLen; ++k) stats[k] = s_st.stats[k] = s_sum[k];
+                s_st.uns_global = 1;
+                s_st.dbg[2] = clock64();
+                icp_apply_stats(&s_st, stats, (long long) s_sum[kStatsLen]);
+                if (stats_io)  // (the reduced block, for a caller that looks: wm_icp_shard_* / tests)
+                    for (int k = 0; k < kBlkLen; ++k) stats_io[k] = s_sum[k];
+                publish_step(&s_st, pub, pub_slots);
+            }
+            s_st.dbg[3] = clock64();
+        }
+    } else if (threadIdx.x == 0) {
         s_st.dbg[0] = t_start;
         s_st.dbg[1] = clock64();  // state staged, rows added
         if (PHASES & 1) {
@@ -298,22 +361,7 @@ __global__ void __launch_bounds__(THREADS)
             // pinned memory -- done flag, iterations finished, the step's size -- in ONE system-scope store
             // (pub[0]: the latest; pub[k]: iteration k's own record, so that what the host decides from
             // does not depend on when it looks)
-            if (pub) {
-                // [iteration : 16 | step size as bfloat16 : 16 | changed matches : 16 | searched by the
-                //  certificate kernel : 16] -- fractions in 1 / 65535
-                const unsigned f_ch = (unsigned) (fminf(fmaxf(s_st.frac_changed, 0.f), 1.f) * 65535.f + 0.5f);
-                const unsigned f_un = (unsigned) (fminf(fmaxf(s_st.frac_unsettled, 0.f), 1.f) * 65535.f + 0.5f);
-                const unsigned long long w = ((unsigned long long) ((unsigned) s_st.iter & 0xFFFFu) << 48) |
-                                             ((unsigned long long) (__float_as_uint(s_st.step_disp) >> 16) << 32) |
-                                             ((unsigned long long) f_ch << 16) | (unsigned long long) f_un;
-                if (s_st.iter >= 1 && s_st.iter <= pub_slots)
-                    __hip_atomic_store(pub + s_st.iter, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                // ([0]: bit 0 = done)
-                // ([0]: bit 0 = done, above it the number of iterations finished by then -- ONE word, so that a
-                // host that sees `done` before the last record knows whether that record is still to come)
-                __hip_atomic_store(pub, s_st.done ? (1ull | ((unsigned long long) (unsigned) s_st.iter << 1)) : 0ull,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+            publish_step(&s_st, pub, pub_slots);
         }
         s_st.dbg[3] = clock64();
     }
@@ -385,7 +433,8 @@ static int launch_stats(wm_ctx *ctx, int mode) {
 // Sum `rows` partial rows (ctx->partials) and run the requested phases of the iteration's solve.
 template <int PHASES>
 static int launch_reduce_solve(wm_ctx *ctx, unsigned rows, double *stats_io, unsigned long long *pub = nullptr,
-                               int pub_slots = 0, int blk_ext = 0) {
+                               int pub_slots = 0, int blk_ext = 0, const XchgDev *xchg = nullptr) {
+    const XchgDev xd = xchg ? *xchg : XchgDev{nullptr, nullptr, 0, 0, 0u};
     IcpDevState *st = ctx->d_state.as<IcpDevState>();
     const double *part = ctx->partials.as<double>();
     if (rows > 2048u) {  // one workgroup cannot add that many rows quickly: 128 rows -> 1 first
@@ -398,10 +447,10 @@ static int launch_reduce_solve(wm_ctx *ctx, unsigned rows, double *stats_io, uns
     }
     if (rows > 512u)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<PHASES, 1024>), dim3(1), dim3(1024), 0, ctx->stream,
-                           part, (int) rows, st, stats_io, pub, pub_slots, blk_ext);
+                           part, (int) rows, st, stats_io, pub, pub_slots, blk_ext, xd);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<PHASES, kBlock>), dim3(1), dim3(kBlock), 0, ctx->stream,
-                           part, (int) rows, st, stats_io, pub, pub_slots, blk_ext);
+                           part, (int) rows, st, stats_io, pub, pub_slots, blk_ext, xd);
     WM_HIP(ctx, hipGetLastError());
     return WM_OK;
 }
@@ -1100,6 +1149,8 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
     size_t ev_used = 0;
     size_t ev_ar = (size_t) 5 * (size_t) max_it;  // the all-reduce's event pairs sit behind the iterations' slots
     const bool slab = ctx->h_state->slab_on != 0;
+    XchgDev xchg{nullptr, nullptr, 0, 0, 0u};
+    const bool in_kernel_exchange = blk && comm_exchange_args(comm, &xchg) == WM_OK;
     ctx->cert_launches = 0;
     std::vector<unsigned char> was_cert;
     std::vector<unsigned char> kind((size_t) max_it, 0);  // which search kernel iteration k got (1: certificate, 2: its first launch)
@@ -1328,7 +1379,11 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
             bounds_valid = false;
         }
         if (e2) WM_HIP(ctx, hipEventRecord(e2, ctx->stream));
-        if (blk) {
+        if (blk && in_kernel_exchange) {
+            // sharded, mailboxes: this rank's sums, their exchange with the other ranks over xGMI and the same
+            // solve on every rank in ONE launch
+            WM_TRY(launch_reduce_solve<7>(ctx, rows, blk, ctx->h_pub, ctx->h_pub_slots, 1, &xchg));
+        } else if (blk) {
             // sharded: this rank's sums -> all-reduce of the block over the ranks (RCCL on this stream) ->
             // the same solve on every rank
             WM_TRY(launch_reduce_solve<1>(ctx, rows, blk, nullptr, 0, 1));
@@ -1352,6 +1407,11 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
     WM_HIP(ctx, hipEventRecord(ctx->ev_b, ctx->stream));
     WM_HIP(ctx, hipEventSynchronize(ctx->ev_b));
     const IcpDevState &s = *ctx->h_state;
+    if (s.xchg_failed) {
+        ctx->last_error = "sharded registration: a rank's block did not arrive in this rank's mailbox in time "
+                          "(a peer failed or fell behind by more than the exchange's time limit)";
+        return WM_ERR_RCCL;
+    }
     ctx->prev_mse = s.prev_mse;
     ctx->have_corr = true;
     ctx->last_align_valid = true;
@@ -1376,6 +1436,7 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
             if (ev.first && ev.second && hipEventElapsedTime(&a, ev.first, ev.second) == hipSuccess) ctx->late_ms += a;
         }
         stats->late_ms = ctx->late_ms;
+        stats->exchange_in_kernel = in_kernel_exchange ? 1 : 0;
         stats->owned_violations = s.owned_violations;
         (void) hipEventElapsedTime(&stats->align_ms, ctx->ev_a, ctx->ev_b);
         if (p->profile) {

@@ -130,6 +130,8 @@ struct IcpDevState {
     // that the fraction can never carry into the integer part, and the count is scaled back up here
     unsigned changed_mask;
     int uns_global;  // sharded: the count of searched queries came through the all-reduced block (all ranks steer alike)
+    int xchg_failed;  // sharded, in-kernel exchange (wm_xchg.hpp): a peer's block never arrived; the registration ended there
+    int pad_;
 };
 
 struct Bbox {
@@ -289,7 +291,7 @@ struct wm_ctx {
     unsigned ndt_nvox = 0, ndt_nvalid = 0, ndt_hmask = 0;
 
     // sharded (multi-GPU) stepping
-    wm::DevBuf shard_ref, shard_tgt, shard_ref_band, shard_tgt_band, shard_misc, shard_flags, shard_pos_t,
+    wm::DevBuf shard_ref, shard_tgt, shard_ref_band, shard_tgt_band, shard_misc, shard_flags, shard_flags2, shard_pos_t,
         shard_pos_s, shard_stats, ndt_sum_dev;
     float shard_lo = 0, shard_hi = 0;
     struct wm_comm *ndt_comm = nullptr;    // wm_ndt_set_comm: the derivative passes' sums are all-reduced on the device
@@ -339,6 +341,9 @@ inline int fast_fetch_custom(wm_ctx *ctx, Launch launch) {
 int sum_to_device(wm_ctx *ctx, double *dst_dev, const double *src_dev, unsigned rows, unsigned k);
 // ---- wm_shard.hip: sum `n` doubles in device memory over the ranks of `comm`, on the context's stream
 int comm_allreduce(wm_ctx *ctx, struct wm_comm *comm, double *dev, int n);
+struct XchgDev;
+// WM_OK (and *out filled) when the communicator has mailboxes for the in-kernel exchange of the sharded loop's block
+int comm_exchange_args(struct wm_comm *comm, XchgDev *out);
 // developer tracing (env WM_TRACE=1): drain the stream and print a marker, so that a GPU fault can
 // be pinned to the stage that was running
 #define WM_TRACE(ctx, what)                                                     \

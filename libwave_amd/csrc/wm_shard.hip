@@ -21,6 +21,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "wm_internal.hpp"
+#include "wm_xchg.hpp"
 
 #include <rccl/rccl.h>
 
@@ -52,9 +53,109 @@ struct wm_comm {
     ncclComm_t nccl = nullptr;
     wm_local_group *local = nullptr;  // shared by the ranks of an emulated group; freed by rank 0's destroy
     std::string last_error;
+    // mailboxes for the in-kernel exchange of the ICP loop's block (wm_xchg.hpp); ncclAllReduce where they are absent
+    unsigned long long *mail = nullptr;        // this rank's mailbox: fine-grained device memory
+    unsigned long long **peer_dev = nullptr;   // [world] in device memory: every rank's mailbox as this device sees it
+    std::vector<void *> ipc_opened;            // peers' mailboxes mapped through IPC handles (other processes)
+    bool p2p = false;
+    unsigned p2p_timeout_ms = 5000;
 };
 
 namespace wm {
+
+// ---------------------------------------------------------------- mailboxes
+// (default on; WM_COMM_P2P=0 keeps ncclAllReduce as the loop's exchange)
+static bool mailboxes_wanted() {
+    const char *e = getenv("WM_COMM_P2P");
+    return !(e && atoi(e) == 0);
+}
+
+static int mailbox_alloc(wm_comm *c) {
+    if (c->world > kXMaxWorld) return WM_ERR_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return WM_ERR_HIP;
+    const size_t bytes = xchg_mailbox_words(c->world) * sizeof(unsigned long long);
+    void *p = nullptr;
+    // remote stores must be seen by a kernel that is already polling: uncached (or at least fine-grained) memory
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess || !p) {
+        (void) hipGetLastError();
+        p = nullptr;
+        if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess || !p) {
+            (void) hipGetLastError();
+            return WM_ERR_NOMEM;
+        }
+    }
+    if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void) hipFree(p);
+        return WM_ERR_HIP;
+    }
+    c->mail = static_cast<unsigned long long *>(p);
+    if (const char *e = getenv("WM_COMM_P2P_TIMEOUT_MS")) {
+        const int v = atoi(e);
+        if (v > 0) c->p2p_timeout_ms = (unsigned) v;
+    }
+    return WM_OK;
+}
+
+static int mailbox_set_peers(wm_comm *c, const std::vector<unsigned long long *> &peers) {
+    if (hipSetDevice(c->device) != hipSuccess) return WM_ERR_HIP;
+    void *d = nullptr;
+    if (hipMalloc(&d, peers.size() * sizeof(void *)) != hipSuccess) return WM_ERR_NOMEM;
+    if (hipMemcpy(d, peers.data(), peers.size() * sizeof(void *), hipMemcpyHostToDevice) != hipSuccess) {
+        (void) hipFree(d);
+        return WM_ERR_HIP;
+    }
+    c->peer_dev = static_cast<unsigned long long **>(d);
+    return WM_OK;
+}
+
+static void mailbox_free(wm_comm *c) {
+    if (!c) return;
+    (void) hipSetDevice(c->device);
+    for (void *q : c->ipc_opened) (void) hipIpcCloseMemHandle(q);
+    c->ipc_opened.clear();
+    if (c->peer_dev) (void) hipFree(c->peer_dev);
+    if (c->mail) (void) hipFree(c->mail);
+    c->peer_dev = nullptr;
+    c->mail = nullptr;
+    c->p2p = false;
+}
+
+static XchgDev mailbox_args(const wm_comm *c, unsigned timeout_ms) {
+    return XchgDev{c->peer_dev, c->mail, c->world, c->rank, timeout_ms};
+}
+
+// one exchange on its own: block[k] = (k + 1) * (rank + 1) in, the sum over the ranks out; ok = it arrived
+__global__ void __launch_bounds__(256) k_xchg_probe(XchgDev x, double *out, int *ok) {
+    __shared__ double s_in[kBlkLen], s_out[kBlkLen];
+    __shared__ unsigned s_half[kXMaxWorld * kXWords], s_ctl[2];
+    if (threadIdx.x < kBlkLen) s_in[threadIdx.x] = (double) (threadIdx.x + 1) * (double) (x.rank + 1);
+    __syncthreads();
+    const bool arrived = xchg_allreduce<256>(x, s_in, s_out, s_half, s_ctl);
+    if (threadIdx.x < kBlkLen && out) out[threadIdx.x] = s_out[threadIdx.x];
+    if (threadIdx.x == 0 && ok) *ok = arrived ? 1 : 0;
+}
+
+// launch one probe exchange on `stream` (every rank of the group must, at about the same time)
+static int mailbox_probe_launch(wm_comm *c, hipStream_t stream, double *out_dev, int *ok_dev, unsigned timeout_ms) {
+    if (hipSetDevice(c->device) != hipSuccess) return WM_ERR_HIP;
+    hipLaunchKernelGGL(k_xchg_probe, dim3(1), dim3(256), 0, stream, mailbox_args(c, timeout_ms), out_dev, ok_dev);
+    return hipGetLastError() == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
+
+// did the probe deliver the sum it must?  (host side, after the stream has been synchronised)
+static bool mailbox_probe_good(const wm_comm *c, const double *out_host, int ok_host) {
+    if (!ok_host) return false;
+    const double ranks = 0.5 * (double) c->world * (double) (c->world + 1);  // sum of (rank + 1)
+    for (int k = 0; k < kBlkLen; ++k)
+        if (out_host[k] != (double) (k + 1) * ranks) return false;
+    return true;
+}
+
+int comm_exchange_args(wm_comm *comm, XchgDev *out) {
+    if (!comm || !comm->p2p || !comm->mail || !comm->peer_dev || !out) return WM_ERR_STATE;
+    *out = mailbox_args(comm, comm->p2p_timeout_ms);
+    return WM_OK;
+}
 
 int comm_allreduce(wm_ctx *ctx, wm_comm *comm, double *dev, int n) {
     if (!comm) return WM_OK;
@@ -113,197 +214,469 @@ int comm_allreduce(wm_ctx *ctx, wm_comm *comm, double *dev, int n) {
 //     is counted per rank over its 1 / world stripe of the source and summed by the all-reduce that
 //     runs anyway (a spare slot of the block).
 constexpr int kHistBins = 1 << 16;
-constexpr int kRangeBlocks = 256;
 
 __device__ __forceinline__ float raw_x(const unsigned char *raw, size_t stride, size_t i) {
     return *reinterpret_cast<const float *>(raw + i * stride);
 }
 
-// per-block min / max of the finite x of the sub-sample (points 0, step, 2 step, ...)
+// The sub-sample the slab edges are planned from: kPlanSamples points at a fixed stride through the target (the same
+// points on every rank), their x gathered into one compact array (NaN for a non-finite point) with per-block min / max.
+// (Round 2-4 histogrammed every world-th point into 64 Ki bins in HBM: 1M global atomics and a one-workgroup scan of
+// the table, 110 us of the 130 a plan took.  Sixteen thousand samples place a quantile to 0.4 % of the cloud.)
+constexpr unsigned kPlanSamples = 16384;
+constexpr int kSampleBlocks = kPlanSamples / kBlock;
 __global__ void __launch_bounds__(kBlock)
-    k_xrange(const unsigned char *__restrict__ raw, size_t stride, unsigned n, unsigned step, float *__restrict__ part) {
-    float lo = INFINITY, hi = -INFINITY;
-    const unsigned m = (n + step - 1) / step;
-    for (unsigned k = blockIdx.x * kBlock + threadIdx.x; k < m; k += gridDim.x * kBlock) {
-        const float x = raw_x(raw, stride, (size_t) k * step);
-        if (x - x == 0.f) {  // finite
-            lo = fminf(lo, x);
-            hi = fmaxf(hi, x);
-        }
-    }
-    __shared__ float s_lo[kBlock], s_hi[kBlock];
-    s_lo[threadIdx.x] = lo;
-    s_hi[threadIdx.x] = hi;
-    __syncthreads();
-    for (int w = kBlock / 2; w > 0; w >>= 1) {
-        if ((int) threadIdx.x < w) {
-            s_lo[threadIdx.x] = fminf(s_lo[threadIdx.x], s_lo[threadIdx.x + w]);
-            s_hi[threadIdx.x] = fmaxf(s_hi[threadIdx.x], s_hi[threadIdx.x + w]);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        part[2 * blockIdx.x] = s_lo[0];
-        part[2 * blockIdx.x + 1] = s_hi[0];
-    }
-}
-
-// (lo, bin width) of the histogram from the range partials: every block of the kernels below forms
-// them again from the kRangeBlocks partials -- cheaper than a launch and a round trip for two numbers
-__device__ __forceinline__ void range_of(const float *__restrict__ part, float *lo_out, float *w_out) {
-    __shared__ float r_lo[kBlock], r_hi[kBlock];
-    float lo = INFINITY, hi = -INFINITY;
-    for (int k = threadIdx.x; k < kRangeBlocks; k += kBlock) {
-        lo = fminf(lo, part[2 * k]);
-        hi = fmaxf(hi, part[2 * k + 1]);
-    }
-    r_lo[threadIdx.x] = lo;
-    r_hi[threadIdx.x] = hi;
-    __syncthreads();
-    for (int w = kBlock / 2; w > 0; w >>= 1) {
-        if ((int) threadIdx.x < w) {
-            r_lo[threadIdx.x] = fminf(r_lo[threadIdx.x], r_lo[threadIdx.x + w]);
-            r_hi[threadIdx.x] = fmaxf(r_hi[threadIdx.x], r_hi[threadIdx.x + w]);
-        }
-        __syncthreads();
-    }
-    lo = r_lo[0];
-    hi = r_hi[0];
-    if (!(lo <= hi)) lo = hi = 0.f;  // no finite point at all
-    *lo_out = lo;
-    *w_out = fmaxf((hi - lo) / (float) kHistBins, 1e-30f);
-}
-
-// histogram of the sub-sample's finite x (LDS is too small for 64 Ki bins, and a cloud's points
-// arrive in no particular x order, so the atomics spread over the whole table)
-__global__ void __launch_bounds__(kBlock)
-    k_xhist(const unsigned char *__restrict__ raw, size_t stride, unsigned n, unsigned step,
-            const float *__restrict__ part, unsigned *__restrict__ hist) {
-    float lo, w;
-    range_of(part, &lo, &w);
-    const float inv_w = 1.0f / w;
-    const unsigned m = (n + step - 1) / step;
+    k_xsample(const unsigned char *__restrict__ raw, size_t stride, unsigned n, unsigned step, float *__restrict__ xs,
+              float *__restrict__ part) {
     const unsigned k = blockIdx.x * kBlock + threadIdx.x;
-    if (k >= m) return;
-    const float x = raw_x(raw, stride, (size_t) k * step);
-    if (!(x - x == 0.f)) return;
-    int b = (int) ((x - lo) * inv_w);
-    b = min(max(b, 0), kHistBins - 1);
-    atomicAdd(&hist[b], 1u);
+    const unsigned m = (n + step - 1) / step;
+    float x = NAN;
+    if (k < m) x = raw_x(raw, stride, (size_t) k * step);
+    if (!(x - x == 0.f)) x = NAN;
+    xs[k] = x;
+    float lo = x == x ? x : INFINITY, hi = x == x ? x : -INFINITY;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, off));
+        hi = fmaxf(hi, __shfl_xor(hi, off));
+    }
+    __shared__ float s_lo[kBlock / 64], s_hi[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) {
+        s_lo[threadIdx.x >> 6] = lo;
+        s_hi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) {
+            lo = fminf(lo, s_lo[w]);
+            hi = fmaxf(hi, s_hi[w]);
+        }
+        part[2 * blockIdx.x] = lo;
+        part[2 * blockIdx.x + 1] = hi;
+    }
 }
 
-// edges[0] = -inf, edges[world] = +inf, edges[k] = upper boundary of the first bin at which the
-// running count reaches k / world of the points (one workgroup; 64 Ki bins = 256 per thread)
-__global__ void __launch_bounds__(kBlock)
-    k_plan_edges(const unsigned *__restrict__ hist, const float *__restrict__ part, int world, float *__restrict__ edges) {
-    float lo, w;
-    range_of(part, &lo, &w);
-    __shared__ unsigned long long s_pre[kBlock + 1];
-    constexpr int kPer = kHistBins / kBlock;
-    unsigned long long mine = 0;
-    for (int k = 0; k < kPer; ++k) mine += hist[threadIdx.x * kPer + k];
-    s_pre[threadIdx.x + 1] = mine;
-    if (threadIdx.x == 0) s_pre[0] = 0;
+// edges[0] = -inf, edges[world] = +inf, edges[k] = upper boundary of the first of kHistBins equal bins of the samples'
+// x range at which the running count reaches k / world of the finite samples.  ONE workgroup, the whole histogram in
+// LDS: two 16-bit counters per word (a bin holds at most kPlanSamples < 65 536 samples).
+constexpr int kPlanThreads = 1024;
+// where word W of the histogram lives: a thread owns 32 consecutive words, and 64 threads reading their k-th word at
+// once would all hit one LDS bank (64 waves-cycles per read, 16 waves: most of this kernel's time) -- rotated by the
+// owner's number within its 32 words, they spread over the banks
+__device__ __forceinline__ unsigned plan_word(unsigned W) { return (W & ~31u) | ((W + (W >> 5)) & 31u); }
+__global__ void __launch_bounds__(kPlanThreads)
+    k_plan_edges(const float *__restrict__ xs, const float *__restrict__ part, int world, float *__restrict__ edges) {
+    __shared__ unsigned s_hist[kHistBins / 2];  // 128 KB
+    __shared__ float s_lo[kPlanThreads / 64], s_hi[kPlanThreads / 64];
+    __shared__ unsigned s_wave[kPlanThreads / 64];
+    const unsigned t = threadIdx.x;
+    for (unsigned w = t; w < kHistBins / 2; w += kPlanThreads) s_hist[w] = 0u;
+    float lo = INFINITY, hi = -INFINITY;
+    if (t < (unsigned) kSampleBlocks) {
+        lo = part[2 * t];
+        hi = part[2 * t + 1];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, off));
+        hi = fmaxf(hi, __shfl_xor(hi, off));
+    }
+    if ((t & 63u) == 0u) {
+        s_lo[t >> 6] = lo;
+        s_hi[t >> 6] = hi;
+    }
     __syncthreads();
-    if (threadIdx.x == 0)
-        for (int t = 1; t <= kBlock; ++t) s_pre[t] += s_pre[t - 1];
+    lo = s_lo[0];
+    hi = s_hi[0];
+    for (int w = 1; w < kSampleBlocks / 64 + (kSampleBlocks % 64 ? 1 : 0); ++w) {
+        lo = fminf(lo, s_lo[w]);
+        hi = fmaxf(hi, s_hi[w]);
+    }
+    if (!(lo <= hi)) lo = hi = 0.f;  // no finite sample at all
+    const float width = fmaxf((hi - lo) / (float) kHistBins, 1e-30f);
+    const float inv_w = 1.0f / width;
+    for (unsigned k = t; k < kPlanSamples; k += kPlanThreads) {
+        const float x = xs[k];
+        if (x == x) {
+            int b = (int) ((x - lo) * inv_w);
+            b = min(max(b, 0), kHistBins - 1);
+            atomicAdd(&s_hist[plan_word((unsigned) b >> 1)], (b & 1) ? 0x10000u : 1u);
+        }
+    }
     __syncthreads();
-    const unsigned long long total = s_pre[kBlock];
-    if (threadIdx.x == 0) {
+    // thread t owns bins [t kPer, (t + 1) kPer)
+    constexpr int kPer = kHistBins / kPlanThreads;  // 64 bins = 32 words
+    unsigned mine = 0;
+#pragma unroll 8
+    for (int w = 0; w < kPer / 2; ++w) {
+        const unsigned v = s_hist[plan_word(t * (kPer / 2) + w)];
+        mine += (v & 0xFFFFu) + (v >> 16);
+    }
+    unsigned incl = mine;  // inclusive scan across the workgroup: in the wave, then over the waves' totals
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned up = (unsigned) __shfl_up((int) incl, off);
+        if ((int) (t & 63u) >= off) incl += up;
+    }
+    if ((t & 63u) == 63u) s_wave[t >> 6] = incl;
+    __syncthreads();
+    unsigned before = incl - mine, total = 0;
+    for (unsigned w = 0; w < kPlanThreads / 64; ++w) {
+        const unsigned v = s_wave[w];
+        if (w < (t >> 6)) before += v;
+        total += v;
+    }
+    if (t == 0) {
         edges[0] = -INFINITY;
         edges[world] = INFINITY;
+        if (total == 0u)
+            for (int e = 1; e < world; ++e) edges[e] = INFINITY;
     }
-    // thread t owns bins [t kPer, (t + 1) kPer): it emits every edge whose target count falls there
-    unsigned long long run = s_pre[threadIdx.x];
+    if (total == 0u || mine == 0u) return;
+    // the edges whose target count falls among this thread's bins (counts are small: 32-bit products do not overflow
+    // below 262 144 ranks)
+    unsigned run = before;
     for (int k = 0; k < kPer; ++k) {
-        const unsigned long long before = run;
-        run += hist[threadIdx.x * kPer + k];
+        const unsigned v = s_hist[plan_word(t * (kPer / 2) + (k >> 1))];
+        const unsigned c = (k & 1) ? (v >> 16) : (v & 0xFFFFu);
+        if (c == 0u) continue;
+        const unsigned prev = run;
+        run += c;
         for (int e = 1; e < world; ++e) {
-            const unsigned long long want = (total * (unsigned long long) e + (unsigned long long) world - 1ull) /
-                                            (unsigned long long) world;  // ceil(total e / world)
-            if (want > before && want <= run) edges[e] = lo + (float) (threadIdx.x * kPer + k + 1) * w;
+            const unsigned want = (unsigned) (((unsigned long long) total * (unsigned) e + (unsigned) world - 1u) / (unsigned) world);
+            if (want > prev && want <= run) edges[e] = lo + (float) (t * kPer + k + 1) * width;
         }
     }
-    if (total == 0ull && threadIdx.x == 0)
-        for (int e = 1; e < world; ++e) edges[e] = INFINITY;
 }
-
-// finite points of the stripe [i0, i1) of a raw cloud, one partial count per block
-__global__ void __launch_bounds__(kBlock)
-    k_count_finite(const unsigned char *__restrict__ raw, size_t stride, unsigned i0, unsigned i1,
-                   unsigned *__restrict__ part) {
-    unsigned c = 0;
-    for (unsigned i = i0 + blockIdx.x * kBlock + threadIdx.x; i < i1; i += gridDim.x * kBlock) {
-        const float *q = reinterpret_cast<const float *>(raw + (size_t) i * stride);
-        const float x = q[0], y = q[1], z = q[2];
-        c += (x - x == 0.f && y - y == 0.f && z - z == 0.f) ? 1u : 0u;
-    }
-    __shared__ unsigned s_c[kBlock];
-    s_c[threadIdx.x] = c;
-    __syncthreads();
-    for (int w = kBlock / 2; w > 0; w >>= 1) {
-        if ((int) threadIdx.x < w) s_c[threadIdx.x] += s_c[threadIdx.x + w];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) part[blockIdx.x] = s_c[0];
-}
-
-// a raw cloud as a sequence of float4 (x, y, z, index bits), and the band test on it
-struct RawLoad {
-    const unsigned char *raw;
-    size_t stride;
-    __device__ float4 operator()(unsigned i) const {
-        const float *q = reinterpret_cast<const float *>(raw + (size_t) i * stride);
-        return make_float4(q[0], q[1], q[2], __uint_as_float(i));
-    }
-};
-struct InBand {  // x within [edges[rank] - widen, edges[rank + 1] + widen] (a NaN never passes)
-    const float *edges;
-    int rank;
-    float widen;
-    __device__ bool operator()(const float4 &p) const {
-        return p.x >= edges[rank] - widen && p.x <= edges[rank + 1] + widen;
-    }
-};
 
 struct ShardPlan {
     float edges[2];      // this rank's [lo, hi)
     unsigned n_tgt_local, n_src_local, stripe_finite, pad;
 };
-__global__ void k_plan_pack(const float *__restrict__ edges, int rank, const unsigned *__restrict__ n_t,
-                            const unsigned *__restrict__ n_s, const unsigned *__restrict__ fin_part, unsigned fin_blocks,
-                            ShardPlan *out) {
-    if (threadIdx.x != 0) return;
-    out->edges[0] = edges[rank];
-    out->edges[1] = edges[rank + 1];
-    out->n_tgt_local = *n_t;
-    out->n_src_local = n_s ? *n_s : 0u;
-    unsigned c = 0;
-    for (unsigned b = 0; b < fin_blocks; ++b) c += fin_part[b];
-    out->stripe_finite = c;
-    out->pad = 0;
+
+// ---- this rank's bands of both clouds, selected in input order (a STABLE compaction: the local clouds' order, and
+// with it every later tie-break and summation order, is a function of the clouds alone).  Three launches for both
+// clouds together: per-block counts -> one workgroup's scan of them (+ the plan, packed for the host's one fetch) ->
+// the write.  (Rounds 2-4: rocprim::select per cloud -- a memset, a look-back initialisation, the partition and a
+// count kernel each, 83 us for the two at 1M points; and a separate pass over the source for its finite count.)
+constexpr unsigned kBandRows = 4;
+constexpr unsigned kBandPoints = kBandRows * kBlock;  // points per workgroup
+struct BandArgs {
+    const unsigned char *raw_t, *raw_s;
+    size_t stride;
+    unsigned nt, ns, blocks_t, blocks_s;
+    const float *edges;
+    int rank;
+    float widen_t, widen_s;  // (INFINITY: everything finite in x passes)
+    int all_s;               // the source unselected (second attempt: every rank takes the whole source)
+    unsigned s0, s1;         // the stripe of the source whose finite points this rank counts
+};
+
+__device__ __forceinline__ bool band_test(const BandArgs &a, bool source, unsigned i, float *xyz) {
+    const unsigned char *raw = source ? a.raw_s : a.raw_t;
+    const float *q = reinterpret_cast<const float *>(raw + (size_t) i * a.stride);
+    xyz[0] = q[0];
+    xyz[1] = q[1];
+    xyz[2] = q[2];
+    const int r = (source && a.all_s) ? 0 : a.rank;
+    const float w = source ? (a.all_s ? INFINITY : a.widen_s) : a.widen_t;
+    return xyz[0] >= a.edges[r] - w && xyz[0] <= a.edges[r + 1] + w;  // (a NaN never passes)
 }
 
-// stable selection of a raw cloud's points inside the rank's band: out <- (x, y, z, index), *count <- how many
-static int select_band(wm_ctx *ctx, const unsigned char *raw, size_t stride, unsigned n, const float *edges_dev,
-                       int rank, float widen, float4 *out, unsigned *count_dev) {
-    if (n == 0) {
-        WM_HIP(ctx, hipMemsetAsync(count_dev, 0, sizeof(unsigned), ctx->stream));
-        return WM_OK;
+__global__ void __launch_bounds__(kBlock) k_band_count(BandArgs a, unsigned *__restrict__ blk_cnt, unsigned *__restrict__ blk_fin) {
+    const bool source = blockIdx.x >= a.blocks_t;
+    const unsigned blk = source ? blockIdx.x - a.blocks_t : blockIdx.x;
+    const unsigned n = source ? a.ns : a.nt;
+    unsigned cnt = 0, fin = 0;
+#pragma unroll
+    for (unsigned j = 0; j < kBandRows; ++j) {
+        const unsigned i = blk * kBandPoints + j * kBlock + threadIdx.x;
+        float v[3];
+        bool in = false;
+        if (i < n) {
+            in = band_test(a, source, i, v);
+            if (source && i >= a.s0 && i < a.s1) fin += (v[0] - v[0] == 0.f && v[1] - v[1] == 0.f && v[2] - v[2] == 0.f) ? 1u : 0u;
+        }
+        cnt += in ? 1u : 0u;
     }
-    using In = rocprim::transform_iterator<rocprim::counting_iterator<unsigned>, RawLoad, float4>;
-    const In in(rocprim::counting_iterator<unsigned>(0u), RawLoad{raw, stride});
-    const InBand pred{edges_dev, rank, widen};
-    size_t bytes = 0;
-    WM_HIP(ctx, rocprim::select(nullptr, bytes, in, out, count_dev, (size_t) n, pred, ctx->stream));
-    WM_HIP(ctx, ctx->shard_flags.reserve(bytes + 64));
-    WM_HIP(ctx, rocprim::select(ctx->shard_flags.p, bytes, in, out, count_dev, (size_t) n, pred, ctx->stream));
-    return WM_OK;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += (unsigned) __shfl_xor((int) cnt, off);
+        fin += (unsigned) __shfl_xor((int) fin, off);
+    }
+    __shared__ unsigned s_c[kBlock / 64], s_f[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) {
+        s_c[threadIdx.x >> 6] = cnt;
+        s_f[threadIdx.x >> 6] = fin;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned c = 0, f = 0;
+        for (int w = 0; w < kBlock / 64; ++w) {
+            c += s_c[w];
+            f += s_f[w];
+        }
+        blk_cnt[blockIdx.x] = c;
+        if (source) blk_fin[blk] = f;
+    }
+}
+
+// exclusive scan of cnt[0, n) in place by ONE workgroup; returns the total (to every thread)
+template <int THREADS>
+__device__ unsigned scan_in_place(unsigned *__restrict__ cnt, unsigned n, unsigned *s_wave /* [THREADS / 64 + 1] */) {
+    const unsigned t = threadIdx.x;
+    const unsigned per = (n + THREADS - 1) / THREADS;
+    const unsigned b0 = min(t * per, n), b1 = min(b0 + per, n);
+    unsigned mine = 0;
+    for (unsigned b = b0; b < b1; ++b) mine += cnt[b];
+    unsigned incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned up = (unsigned) __shfl_up((int) incl, off);
+        if ((int) (t & 63u) >= off) incl += up;
+    }
+    __syncthreads();  // (s_wave may still be read from an earlier call)
+    if ((t & 63u) == 63u) s_wave[t >> 6] = incl;
+    __syncthreads();
+    unsigned before = incl - mine, total = 0;
+    for (unsigned w = 0; w < THREADS / 64; ++w) {
+        const unsigned v = s_wave[w];
+        if (w < (t >> 6)) before += v;
+        total += v;
+    }
+    unsigned run = before;
+    for (unsigned b = b0; b < b1; ++b) {
+        const unsigned c = cnt[b];
+        cnt[b] = run;
+        run += c;
+    }
+    return total;
+}
+
+__global__ void __launch_bounds__(1024)
+    k_band_scan(unsigned *__restrict__ blk_cnt, const unsigned *__restrict__ blk_fin, unsigned blocks_t, unsigned blocks_s,
+                const float *__restrict__ edges, int rank, ShardPlan *__restrict__ out) {
+    __shared__ unsigned s_wave[1024 / 64 + 1];
+    const unsigned n_t = scan_in_place<1024>(blk_cnt, blocks_t, s_wave);
+    const unsigned n_s = scan_in_place<1024>(blk_cnt + blocks_t, blocks_s, s_wave);
+    unsigned f = 0;
+    for (unsigned b = threadIdx.x; b < blocks_s; b += 1024) f += blk_fin[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) f += (unsigned) __shfl_xor((int) f, off);
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0u) s_wave[threadIdx.x >> 6] = f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned fin = 0;
+        for (int w = 0; w < 1024 / 64; ++w) fin += s_wave[w];
+        out->edges[0] = edges[rank];
+        out->edges[1] = edges[rank + 1];
+        out->n_tgt_local = n_t;
+        out->n_src_local = n_s;
+        out->stripe_finite = fin;
+        out->pad = 0;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_band_write(BandArgs a, const unsigned *__restrict__ blk_off, float4 *__restrict__ out_t, float4 *__restrict__ out_s) {
+    const bool source = blockIdx.x >= a.blocks_t;
+    const unsigned blk = source ? blockIdx.x - a.blocks_t : blockIdx.x;
+    const unsigned n = source ? a.ns : a.nt;
+    float4 *out = source ? out_s : out_t;
+    __shared__ unsigned s_cnt[kBandRows][kBlock / 64];
+    float v[kBandRows][3];
+    bool in[kBandRows];
+    unsigned below[kBandRows];  // passing points of this wave's row before this lane
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (unsigned j = 0; j < kBandRows; ++j) {
+        const unsigned i = blk * kBandPoints + j * kBlock + threadIdx.x;
+        in[j] = i < n && band_test(a, source, i, v[j]);
+        const unsigned long long m = __ballot(in[j]);
+        below[j] = (unsigned) __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_cnt[j][wave] = (unsigned) __popcll(m);
+    }
+    __syncthreads();
+    unsigned base = blk_off[blockIdx.x];
+#pragma unroll
+    for (unsigned j = 0; j < kBandRows; ++j) {
+#pragma unroll
+        for (unsigned w = 0; w < kBlock / 64; ++w) {
+            const unsigned c = s_cnt[j][w];
+            if (w == wave && in[j]) {
+                const unsigned i = blk * kBandPoints + j * kBlock + threadIdx.x;
+                out[base + below[j]] = make_float4(v[j][0], v[j][1], v[j][2], __uint_as_float(i));
+            }
+            base += c;
+        }
+    }
 }
 
 }  // namespace wm
 
 using namespace wm;
+
+// One rank per process (or thread) under RCCL: mailboxes reach the other ranks as IPC handles, all-gathered over the
+// communicator itself; a probe exchange over them and an all-reduced verdict decide, alike on every rank, whether the
+// loop uses them.  Returns an error only when a COLLECTIVE failed (the communicator is unusable then).
+static int setup_mailboxes_rccl(wm_comm *c) {
+    struct Record {
+        int ok, pad[15];
+        hipIpcMemHandle_t h;
+    };
+    static_assert(sizeof(Record) == 128, "one 128-byte record per rank");
+    const int world = c->world;
+    bool ok = mailboxes_wanted() && world <= kXMaxWorld && mailbox_alloc(c) == WM_OK;
+    if (world == 1) {
+        if (ok) ok = mailbox_set_peers(c, {c->mail}) == WM_OK;
+    }
+    hipStream_t stream = nullptr;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess)
+        return WM_ERR_HIP;
+    void *scratch = nullptr;  // [world] records | probe sums | ok word | verdict
+    const size_t rec_bytes = (size_t) world * sizeof(Record);
+    int rc = WM_OK;
+    if (hipMalloc(&scratch, rec_bytes + 512) != hipSuccess) {
+        (void) hipStreamDestroy(stream);
+        return WM_ERR_NOMEM;
+    }
+    double *probe_out = reinterpret_cast<double *>(static_cast<char *>(scratch) + rec_bytes);
+    int *probe_ok = reinterpret_cast<int *>(probe_out + kBlkLen + 2);
+    int *verdict = probe_ok + 2;
+    std::vector<Record> recs((size_t) world);
+    if (world > 1) {
+        Record mine;
+        memset(&mine, 0, sizeof(mine));
+        if (ok) ok = hipIpcGetMemHandle(&mine.h, c->mail) == hipSuccess;
+        if (!ok) (void) hipGetLastError();
+        mine.ok = ok ? 1 : 0;
+        if (hipMemcpy(static_cast<Record *>(scratch) + c->rank, &mine, sizeof(mine), hipMemcpyHostToDevice) != hipSuccess)
+            rc = WM_ERR_HIP;
+        if (rc == WM_OK && ncclAllGather(static_cast<Record *>(scratch) + c->rank, scratch, sizeof(Record), ncclUint8, c->nccl,
+                                         stream) != ncclSuccess)
+            rc = WM_ERR_RCCL;
+        if (rc == WM_OK && hipStreamSynchronize(stream) != hipSuccess) rc = WM_ERR_HIP;
+        if (rc == WM_OK && hipMemcpy(recs.data(), scratch, rec_bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = WM_ERR_HIP;
+        bool all = rc == WM_OK;
+        for (int r = 0; r < world && all; ++r) all = recs[(size_t) r].ok != 0;
+        if (rc == WM_OK && all) {  // (every rank sees the same records: the same branch everywhere)
+            std::vector<unsigned long long *> peers((size_t) world, nullptr);
+            bool opened = true;
+            for (int r = 0; r < world && opened; ++r) {
+                if (r == c->rank) {
+                    peers[(size_t) r] = c->mail;
+                    continue;
+                }
+                void *q = nullptr;
+                if (hipIpcOpenMemHandle(&q, recs[(size_t) r].h, hipIpcMemLazyEnablePeerAccess) != hipSuccess || !q) {
+                    (void) hipGetLastError();
+                    opened = false;
+                    break;
+                }
+                c->ipc_opened.push_back(q);
+                peers[(size_t) r] = static_cast<unsigned long long *>(q);
+            }
+            if (opened) opened = mailbox_set_peers(c, peers) == WM_OK;
+            // the probe: a rank that could not map its peers skips it -- the others' probes then run into their
+            // time limit, and the verdict below is "no" everywhere
+            int good = 0;
+            if (opened && hipMemset(probe_ok, 0, 16) == hipSuccess &&
+                mailbox_probe_launch(c, stream, probe_out, probe_ok, 2000u) == WM_OK && hipStreamSynchronize(stream) == hipSuccess) {
+                double out_h[kBlkLen];
+                int ok_h = 0;
+                if (hipMemcpy(out_h, probe_out, sizeof(out_h), hipMemcpyDeviceToHost) == hipSuccess &&
+                    hipMemcpy(&ok_h, probe_ok, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess)
+                    good = mailbox_probe_good(c, out_h, ok_h) ? 1 : 0;
+            }
+            (void) hipGetLastError();
+            if (hipMemcpy(verdict, &good, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) rc = WM_ERR_HIP;
+            if (rc == WM_OK && ncclAllReduce(verdict, verdict, 1, ncclInt32, ncclMin, c->nccl, stream) != ncclSuccess)
+                rc = WM_ERR_RCCL;
+            if (rc == WM_OK && hipStreamSynchronize(stream) != hipSuccess) rc = WM_ERR_HIP;
+            int all_good = 0;
+            if (rc == WM_OK && hipMemcpy(&all_good, verdict, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = WM_ERR_HIP;
+            ok = rc == WM_OK && all_good == 1;
+        } else {
+            ok = false;
+        }
+    } else if (ok) {  // a group of one: its own mailbox, checked the same way
+        int good = 0;
+        if (hipMemset(probe_ok, 0, 16) == hipSuccess && mailbox_probe_launch(c, stream, probe_out, probe_ok, 2000u) == WM_OK &&
+            hipStreamSynchronize(stream) == hipSuccess) {
+            double out_h[kBlkLen];
+            int ok_h = 0;
+            if (hipMemcpy(out_h, probe_out, sizeof(out_h), hipMemcpyDeviceToHost) == hipSuccess &&
+                hipMemcpy(&ok_h, probe_ok, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess)
+                good = mailbox_probe_good(c, out_h, ok_h) ? 1 : 0;
+        }
+        (void) hipGetLastError();
+        ok = good == 1;
+    }
+    (void) hipFree(scratch);
+    (void) hipStreamDestroy(stream);
+    if (rc != WM_OK) return rc;
+    if (ok)
+        c->p2p = true;
+    else
+        mailbox_free(c);
+    return WM_OK;
+}
+
+// All ranks in this process (ncclCommInitAll, or the one-GPU stand-in): mailboxes are plain device pointers, with peer
+// access enabled between the devices.  Best effort: on any failure every rank keeps the collective exchange.
+static void setup_mailboxes_in_process(wm_comm **comms, int n, bool probe) {
+    if (!mailboxes_wanted() || n > kXMaxWorld) return;
+    bool ok = true;
+    for (int r = 0; r < n && ok; ++r) ok = mailbox_alloc(comms[r]) == WM_OK;
+    for (int r = 0; r < n && ok; ++r)
+        for (int q = 0; q < n && ok; ++q) {
+            if (comms[r]->device == comms[q]->device) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, comms[r]->device, comms[q]->device) != hipSuccess || !can) ok = false;
+            if (ok && hipSetDevice(comms[r]->device) == hipSuccess) {
+                const hipError_t e = hipDeviceEnablePeerAccess(comms[q]->device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = false;
+                (void) hipGetLastError();
+            }
+        }
+    std::vector<unsigned long long *> peers((size_t) n, nullptr);
+    for (int r = 0; r < n && ok; ++r) peers[(size_t) r] = comms[r]->mail;
+    for (int r = 0; r < n && ok; ++r) ok = mailbox_set_peers(comms[r], peers) == WM_OK;
+    if (ok && probe) {  // one exchange, all ranks at once (one stream per device), before anything relies on it
+        std::vector<hipStream_t> st((size_t) n, nullptr);
+        std::vector<void *> buf((size_t) n, nullptr);
+        for (int r = 0; r < n && ok; ++r) {
+            ok = hipSetDevice(comms[r]->device) == hipSuccess &&
+                 hipStreamCreateWithFlags(&st[(size_t) r], hipStreamNonBlocking) == hipSuccess &&
+                 hipMalloc(&buf[(size_t) r], 512) == hipSuccess && hipMemset(buf[(size_t) r], 0, 512) == hipSuccess;
+        }
+        for (int r = 0; r < n && ok; ++r)
+            ok = mailbox_probe_launch(comms[r], st[(size_t) r], static_cast<double *>(buf[(size_t) r]),
+                                      reinterpret_cast<int *>(static_cast<double *>(buf[(size_t) r]) + kBlkLen + 2), 2000u) == WM_OK;
+        for (int r = 0; r < n; ++r) {
+            if (!st[(size_t) r]) continue;
+            (void) hipSetDevice(comms[r]->device);
+            if (hipStreamSynchronize(st[(size_t) r]) != hipSuccess) ok = false;
+            if (ok && buf[(size_t) r]) {
+                double out_h[kBlkLen + 3];
+                if (hipMemcpy(out_h, buf[(size_t) r], sizeof(out_h), hipMemcpyDeviceToHost) != hipSuccess)
+                    ok = false;
+                else
+                    ok = mailbox_probe_good(comms[r], out_h, *reinterpret_cast<const int *>(out_h + kBlkLen + 2));
+            }
+            (void) hipStreamDestroy(st[(size_t) r]);
+            if (buf[(size_t) r]) (void) hipFree(buf[(size_t) r]);
+        }
+        (void) hipGetLastError();
+    }
+    for (int r = 0; r < n; ++r) {
+        if (ok)
+            comms[r]->p2p = true;
+        else
+            mailbox_free(comms[r]);
+    }
+}
 
 extern "C" {
 
@@ -332,6 +705,13 @@ int wm_comm_init_rank(wm_comm **out, int device, const void *id_bytes, int rank,
         delete c;
         return WM_ERR_RCCL;
     }
+    // mailboxes: best effort, and the SAME verdict on every rank (a rank that failed any step says so through the
+    // collectives every rank runs regardless) -- ncclAllReduce stays the exchange if they cannot be had
+    const int rc_mail = setup_mailboxes_rccl(c);
+    if (rc_mail != WM_OK) {
+        wm_comm_destroy(c);
+        return rc_mail;
+    }
     *out = c;
     return WM_OK;
 }
@@ -357,6 +737,7 @@ int wm_comm_init_all(wm_comm **comms, const int *devices, int n) {
         c->nccl = nc[(size_t) r];
         comms[r] = c;
     }
+    setup_mailboxes_in_process(comms, n, true);
     return WM_OK;
 }
 
@@ -384,11 +765,17 @@ int wm_comm_init_local(wm_comm **comms, int n, int device) {
         c->local = g;
         comms[r] = c;
     }
+    // the stand-in's ranks share ONE GPU: their solve kernels would poll each other's mailboxes while queued behind
+    // one another on the same hardware queues, so the host-side sum stays the default here; WM_COMM_P2P_LOCAL=1
+    // runs the mailbox protocol anyway (tests: two ranks, two streams)
+    if (const char *e = getenv("WM_COMM_P2P_LOCAL"))
+        if (atoi(e) == 1) setup_mailboxes_in_process(comms, n, false);
     return WM_OK;
 }
 
 void wm_comm_destroy(wm_comm *c) {
     if (!c) return;
+    mailbox_free(c);
     if (c->nccl) (void) ncclCommDestroy(c->nccl);
     if (c->local && c->rank == 0) delete c->local;
     delete c;
@@ -399,12 +786,20 @@ void wm_comm_destroy(wm_comm *c) {
 int wm_comm_allreduce_probe(wm_ctx *ctx, wm_comm *comm, int reps, double *us_out) {
     if (!ctx || !comm || !us_out || reps < 1) return WM_ERR_ARG;
     WM_HIP(ctx, hipSetDevice(ctx->device));
-    WM_HIP(ctx, ctx->shard_stats.reserve(WM_STATS_LEN * sizeof(double)));
+    WM_HIP(ctx, ctx->shard_stats.reserve(kBlkLen * sizeof(double)));
     double *blk = ctx->shard_stats.as<double>();
     WM_HIP(ctx, hipMemsetAsync(blk, 0, WM_STATS_LEN * sizeof(double), ctx->stream));
-    for (int r = 0; r < 3; ++r) WM_TRY(wm::comm_allreduce(ctx, comm, blk, WM_STATS_LEN));
+    // (with mailboxes: the exchange as the loop runs it, in a kernel of its own here)
+    auto once = [&]() -> int {
+        if (!comm->p2p) return wm::comm_allreduce(ctx, comm, blk, WM_STATS_LEN);
+        hipLaunchKernelGGL(k_xchg_probe, dim3(1), dim3(256), 0, ctx->stream, mailbox_args(comm, comm->p2p_timeout_ms), blk,
+                           (int *) nullptr);
+        WM_HIP(ctx, hipGetLastError());
+        return WM_OK;
+    };
+    for (int r = 0; r < 3; ++r) WM_TRY(once());
     WM_HIP(ctx, hipEventRecord(ctx->ev_a, ctx->stream));
-    for (int r = 0; r < reps; ++r) WM_TRY(wm::comm_allreduce(ctx, comm, blk, WM_STATS_LEN));
+    for (int r = 0; r < reps; ++r) WM_TRY(once());
     WM_HIP(ctx, hipEventRecord(ctx->ev_b, ctx->stream));
     WM_HIP(ctx, hipEventSynchronize(ctx->ev_b));
     float ms = 0;
@@ -480,40 +875,47 @@ static int align_sharded_impl(wm_ctx *ctx, wm_comm *comm, const void *ref, size_
     // ---- the plan (see "slab planning" above): all on the device, one fetch of 24 bytes at the end
     WM_HIP(ctx, ctx->shard_ref_band.reserve((size_t) nr * sizeof(float4)));
     WM_HIP(ctx, ctx->shard_tgt_band.reserve((size_t) nt * sizeof(float4)));
-    WM_HIP(ctx, ctx->shard_misc.reserve((size_t) kHistBins * 4 + 16384));
-    unsigned *hist = ctx->shard_misc.as<unsigned>();
-    float *edges = reinterpret_cast<float *>(hist + kHistBins);               // [world + 1] (<= 501)
-    float *range_part = edges + 512;                                          // [kRangeBlocks][2]
-    unsigned *fin_part = reinterpret_cast<unsigned *>(range_part + 2 * kRangeBlocks);  // [256]
-    unsigned *counts = fin_part + 256;                                        // [0] target band, [1] source band
-    ShardPlan *plan_dev = reinterpret_cast<ShardPlan *>(counts + 8);
-    const unsigned step = (unsigned) world;  // the sub-sample every rank histograms
-    const unsigned m_sub = (nt + step - 1) / step;
-    WM_HIP(ctx, hipMemsetAsync(hist, 0, (size_t) kHistBins * 4, ctx->stream));
-    hipLaunchKernelGGL(k_xrange, dim3(kRangeBlocks), dim3(kBlock), 0, ctx->stream, raw_tgt, stride, nt, step, range_part);
-    hipLaunchKernelGGL(k_xhist, dim3((m_sub + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, raw_tgt, stride, nt,
-                       step, range_part, hist);
-    hipLaunchKernelGGL(k_plan_edges, dim3(1), dim3(kBlock), 0, ctx->stream, hist, range_part, world, edges);
-    // finite source points of this rank's stripe
-    const unsigned s0 = (unsigned) ((unsigned long long) nr * (unsigned) rank / (unsigned) world);
-    const unsigned s1 = (unsigned) ((unsigned long long) nr * (unsigned) (rank + 1) / (unsigned) world);
-    hipLaunchKernelGGL(k_count_finite, dim3(256), dim3(kBlock), 0, ctx->stream, raw_ref, stride, s0, s1, fin_part);
+    WM_HIP(ctx, ctx->shard_misc.reserve((size_t) kPlanSamples * 4 + 16384));
+    float *xs = ctx->shard_misc.as<float>();                                  // [kPlanSamples]
+    float *edges = xs + kPlanSamples;                                         // [world + 1] (<= 501)
+    float *range_part = edges + 512;                                          // [kSampleBlocks][2]
+    ShardPlan *plan_dev = reinterpret_cast<ShardPlan *>(range_part + 512);
+    // the sub-sample every rank plans from: kPlanSamples points at a fixed stride through the target
+    const unsigned step = nt > kPlanSamples ? (nt + kPlanSamples - 1) / kPlanSamples : 1u;
+    hipLaunchKernelGGL(k_xsample, dim3(kSampleBlocks), dim3(kBlock), 0, ctx->stream, raw_tgt, stride, nt, step, xs, range_part);
+    hipLaunchKernelGGL(k_plan_edges, dim3(1), dim3(kPlanThreads), 0, ctx->stream, xs, range_part, world, edges);
     WM_HIP(ctx, hipGetLastError());
     WM_HIP(ctx, hipEventRecord(e_b, ctx->stream));
     // this rank's target slab + halo (a float32-safe halo: max_corr plus a hair for the rounding of x)
     // and source band (points that start within max_corr of the slab)
-    const float halo = (float) (p->max_corr * (1.0 + 1e-6) + 1e-4);
-    const float pad = (float) p->max_corr;
+    BandArgs ba;
+    ba.raw_t = raw_tgt;
+    ba.raw_s = raw_ref;
+    ba.stride = stride;
+    ba.nt = nt;
+    ba.ns = nr;
+    ba.blocks_t = (nt + kBandPoints - 1) / kBandPoints;
+    ba.blocks_s = (nr + kBandPoints - 1) / kBandPoints;
+    ba.edges = edges;
+    ba.rank = rank;
+    ba.widen_t = (float) (p->max_corr * (1.0 + 1e-6) + 1e-4);
+    ba.widen_s = (float) p->max_corr;
+    ba.all_s = 0;
+    // (the finite source points of this rank's 1 / world stripe: counted by the same pass)
+    ba.s0 = (unsigned) ((unsigned long long) nr * (unsigned) rank / (unsigned) world);
+    ba.s1 = (unsigned) ((unsigned long long) nr * (unsigned) (rank + 1) / (unsigned) world);
+    const unsigned band_blocks = ba.blocks_t + ba.blocks_s;
+    WM_HIP(ctx, ctx->shard_flags.reserve(((size_t) band_blocks + ba.blocks_s + 64) * sizeof(unsigned)));
+    unsigned *blk_cnt = ctx->shard_flags.as<unsigned>(), *blk_fin = blk_cnt + band_blocks;
     hipEvent_t e_c = nullptr;
     for (int attempt = 0; attempt < 2; ++attempt) {
         const bool full_source = attempt == 1;
-        WM_TRY(select_band(ctx, raw_tgt, stride, nt, edges, rank, halo, ctx->shard_tgt_band.as<float4>(), counts));
-        if (full_source)
-            WM_TRY(select_band(ctx, raw_ref, stride, nr, edges, 0, INFINITY, ctx->shard_ref_band.as<float4>(), counts + 1));
-        else
-            WM_TRY(select_band(ctx, raw_ref, stride, nr, edges, rank, pad, ctx->shard_ref_band.as<float4>(), counts + 1));
-        hipLaunchKernelGGL(k_plan_pack, dim3(1), dim3(64), 0, ctx->stream, edges, rank, counts, counts + 1, fin_part, 256u,
-                           plan_dev);
+        ba.all_s = full_source ? 1 : 0;
+        hipLaunchKernelGGL(k_band_count, dim3(band_blocks), dim3(kBlock), 0, ctx->stream, ba, blk_cnt, blk_fin);
+        hipLaunchKernelGGL(k_band_scan, dim3(1), dim3(1024), 0, ctx->stream, blk_cnt, blk_fin, ba.blocks_t, ba.blocks_s, edges,
+                           rank, plan_dev);
+        hipLaunchKernelGGL(k_band_write, dim3(band_blocks), dim3(kBlock), 0, ctx->stream, ba, blk_cnt,
+                           ctx->shard_tgt_band.as<float4>(), ctx->shard_ref_band.as<float4>());
         WM_HIP(ctx, hipGetLastError());
         if (!e_c) {
             while (ctx->ev_pool.size() < 1) {
@@ -546,7 +948,7 @@ static int align_sharded_impl(wm_ctx *ctx, wm_comm *comm, const void *ref, size_
         float thr = 0.f;
         WM_TRY(shard_begin(ctx, p, (double) pl.edges[0], (double) pl.edges[1], -1.0, (double) pl.stripe_finite, &brute, &thr,
                            (p->carry_state && ctx->prev_mse >= 0) ? ctx->prev_mse : DBL_MAX));
-        WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        // (no synchronisation here: the loop's first launches queue up behind the index build, as in wm_icp_align)
         const auto t_host1 = std::chrono::steady_clock::now();
         // ---- the iteration loop: search + local sums -> all-reduce of the block -> solve (wm_icp.hip)
         WM_HIP(ctx, ctx->shard_stats.reserve(kBlkLen * sizeof(double)));

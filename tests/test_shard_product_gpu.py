@@ -87,6 +87,65 @@ def test_one_rank_rccl_group_runs_the_allreduce(wm, monkeypatch):
     assert got["rc"] == 0
     dt, ang = pose_error(got["T"], want["T"])
     assert dt <= 1e-9 and ang <= 1e-9
+    # the loop's exchange ran through the rank's mailbox, inside the solve kernel (wm_xchg.hpp)
+    assert got["exchange_in_kernel"] == 1 and got["rccl_ranks"] == 1
+
+
+def test_one_rank_rccl_group_collective_exchange_gives_the_same_bits(wm, monkeypatch):
+    """WM_COMM_P2P=0: ncclAllReduce between a rank's sums and its solve (three launches per iteration's tail)
+    and the in-kernel exchange (one) are the same arithmetic: identical transforms."""
+    monkeypatch.setenv("WM_SHARD_FORCE", "1")
+    ref, tgt, _ = synth.pair(30000, seed=3)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("WM_COMM_P2P", mode)
+        comm = wm.Comm.init_rank(0, wm.Comm.unique_id(), 0, 1)
+        c = wm.Context(0)
+        outs[mode] = c.icp_align_sharded(comm, ref, tgt, max_corr=3.0, max_iter=40, nn_method=wm.WM_NN_GRID)
+        c.close()
+        comm.close()
+    assert outs["1"]["rc"] == outs["0"]["rc"] == 0
+    assert outs["1"]["exchange_in_kernel"] == 1 and outs["0"]["exchange_in_kernel"] == 0
+    assert outs["1"]["iterations"] == outs["0"]["iterations"]
+    assert np.array_equal(outs["1"]["T"], outs["0"]["T"])
+
+
+def test_two_ranks_exchange_through_mailboxes(wm, monkeypatch):
+    """The mailbox protocol between two ranks that really run side by side (two threads, two streams, one GPU:
+    WM_COMM_P2P_LOCAL=1): each solve kernel writes its block into both mailboxes and polls its own for both --
+    the same transform, bit for bit, on both ranks and as the host-side stand-in's; a time limit turns a stall
+    into an error instead of a hang."""
+    ref, tgt, _ = synth.pair(40000, seed=17)
+    world = 2
+    # (the SAME two contexts for both runs: the first run leaves every buffer allocated.  On one GPU a rank's first-call
+    # hipMalloc / hipFree waits for the whole device -- for the other rank's solve kernel, which polls for this rank's
+    # block: a stall that ranks on GPUs of their own cannot have, and that the exchange's time limit turns into an error)
+    ctxs = [wm.Context(0) for _ in range(world)]
+
+    def run_group():
+        comms = wm.Comm.init_local(world, 0)
+        outs = [None] * world
+
+        def run(r):
+            outs[r] = ctxs[r].icp_align_sharded(comms[r], ref, tgt, max_corr=3.0, force_iterations=15,
+                                                nn_method=wm.WM_NN_GRID)
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        for c in reversed(comms):
+            c.close()
+        return outs
+    want = run_group()
+    monkeypatch.setenv("WM_COMM_P2P_LOCAL", "1")
+    monkeypatch.setenv("WM_COMM_P2P_TIMEOUT_MS", "3000")
+    got = run_group()
+    for c in ctxs:
+        c.close()
+    assert all(o is not None and o["rc"] == 0 for o in want + got)
+    assert all(o["exchange_in_kernel"] == 0 for o in want) and all(o["exchange_in_kernel"] == 1 for o in got)
+    assert np.array_equal(got[0]["T"], got[1]["T"])
+    assert np.array_equal(got[0]["T"], want[0]["T"])
+    assert got[0]["owned_violations"] == 0 and got[0]["n_corr"] == want[0]["n_corr"]
 
 
 def test_icp_8m_in_8_slabs_full_registration(wm):
@@ -230,7 +289,8 @@ def test_bench_sharded_under_torch_distributed_run():
     sh = d["config"]["sharding"]
     assert d["n_gpus"] == 1 and d["value"] > 0, line
     assert sh["rccl_ranks"] == 1 and sh["owned_violations"] == 0 and sh["shard_attempts"] == 1, sh
-    assert sh["allreduce_us_isolated"] > 0 and sh["allreduce_ms"] > 0, sh
+    # the exchange ran inside the solve kernel (the rank's mailbox): no collective launches to time
+    assert sh["allreduce_us_isolated"] > 0 and sh["exchange_in_kernel"] == 1 and sh["allreduce_ms"] == 0, sh
     assert sh["plan_ms"] > 0 and sh["compact_ms"] > 0 and sh["index_ms"] > 0 and sh["iter_ms"] > 0, sh
     assert d["config"]["final_translation_error_m"] < 2e-3, line
 
