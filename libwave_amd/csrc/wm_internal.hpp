@@ -259,7 +259,9 @@ struct wm_ctx {
     wm::DevBuf ndt_keys, ndt_keys2, ndt_vox, ndt_vkey, ndt_hkeys, ndt_hvals, ndt_dense, ndt_meanf;
     bool ndt_dense_on = false;  // dense cell -> voxel-slot table built (small lattices)
     int ndt_dense_lo[3] = {0, 0, 0}, ndt_dense_dim[3] = {0, 0, 0};
-    int tune_ndt_dense = 1;
+    int tune_ndt_dense = 2;  // 0: hash grid; 1: dense cell -> slot table; 2: + the float4 cell lattice (wm_ndt.hip)
+    bool ndt_cells4_on = false;
+    wm::DevBuf ndt_cells4;
     float tune_knn_r0 = 0.f;     // first radius of the k-NN (covariance) scan in cells; 0 = by k (1.0 up to k = 12, else 1.5)
     int tune_radix_min = 256 << 10;  // sorts of more items take rocPRIM's onesweep radix path (wm_sort.hpp)
     int tune_xcd_chunk = 32;     // search kernel: XCDs take turns in chunks of this many workgroups (0: one eighth each)
@@ -283,6 +285,8 @@ struct wm_ctx {
     int tune_fast_solve = 1;     // experiment knob for the solve kernel
     int tune_spin_us = 80;       // wait_flag: busy-poll this long before polling with yields
     int tune_ndt_spec_hessian = 1;  // form the Hessian along with the first extra line-search trial (wm_ndt.hip step_length_mt)
+    int tune_ndt_group = 1;  // NDT: the source regrouped by how many voxels each point meets (wm_ndt.hip: ndt_regroup)
+    wm::DevBuf ndt_grp, ndt_cnt[2], ndt_grp_tmp;
     int tune_ndt_blocks = 1024;  // workgroups (= partial rows) of one NDT derivative pass
     int tune_gicp_blocks = 256;  // workgroups (= partial rows) of one GICP objective evaluation (double-double sums: 512 / 256 / 128 / 64 -> 6.9 / 6.4 / 7.3 / 9.6 ms per 500k registration)
     bool ndt_built = false;

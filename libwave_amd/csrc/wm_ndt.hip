@@ -248,7 +248,8 @@ __global__ void __launch_bounds__(kBlock)
 // look-up is then ONE 4-byte load instead of a hash and a probe sequence.
 
 __global__ void __launch_bounds__(kBlock)
-    k_ndt_dense_fill(const unsigned long long *__restrict__ vkey, unsigned nvox, NdtDense d, int *table) {
+    k_ndt_dense_fill(const unsigned long long *__restrict__ vkey, unsigned nvox, NdtDense d, int *table,
+                     const float4 *__restrict__ meanf, float4 *__restrict__ cells4) {
     const unsigned s = blockIdx.x * kBlock + threadIdx.x;
     if (s >= nvox) return;
     const unsigned long long key = vkey[s];
@@ -260,6 +261,10 @@ __global__ void __launch_bounds__(kBlock)
     const int a = i - d.i0, b = j - d.j0, c = k - d.k0;
     if (a < 0 || b < 0 || c < 0 || a >= d.nx || b >= d.ny || c >= d.nz) return;
     table[((size_t) c * d.ny + b) * d.nx + a] = (int) s;
+    if (cells4) {
+        const float4 m = meanf[s];
+        cells4[((size_t) c * d.ny + b) * d.nx + a] = make_float4(m.x, m.y, m.z, __uint_as_float(s));
+    }
 }
 
 
@@ -274,7 +279,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HES
     k_ndt_derivs(const float4 *__restrict__ src, unsigned n, unsigned n_total, unsigned shard_rank,
                  unsigned shard_world, const NdtVoxel *__restrict__ vox,
                  const float4 *__restrict__ meanf, const unsigned long long *__restrict__ hkeys, const unsigned *__restrict__ hvals,
-                 unsigned mask, NdtDense dense, NdtArgs A, double *__restrict__ partials) {
+                 unsigned mask, NdtDense dense, const float4 *__restrict__ cells4, NdtArgs A, double *__restrict__ partials,
+                 unsigned char *__restrict__ cnt_out) {
     // The double-precision algebra of this kernel may fuse a multiply with the add that follows it
     // (the library is built with -ffp-contract=off for the FLOAT arithmetic that has to reproduce PCL's
     // bits: the point transform and the radius test below, written with explicit _rn intrinsics, are not
@@ -329,7 +335,39 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HES
         // [1, n-2] reads in bounds and any other has no neighbours.  All nine row loads (three
         // adjacent cells each) are issued together.
         int n_cand = 0;
-        if (dense.table) {  // uniform
+        int n_near = 0;
+        if (cells4) {  // uniform
+            // The lattice as float4 cells (the voxel's float mean + its slot; an empty cell's "mean" is 3.4e38, which
+            // no point is near): the 27 cells ARE the 27 radius tests -- one memory round trip per plane of nine and no
+            // candidate list between finding a voxel and testing it, where the slot table + the means' gather are three
+            // to four dependent trips (the passes run at the two waves per SIMD the f64 algebra leaves room for, which
+            // hide little).  Same float arithmetic on the same float means in the same cell order: the same lists.
+            // (Measured and dropped: the wave staging the 5 x 5 x 5 cells around its first point's cell in LDS and the
+            // lanes reading their 27 from there -- 136 against 109 us per pass, profiles/r05_experiments.md.)
+            const int ta = ci - dense.i0, tb = cj - dense.j0, tc = ck - dense.k0;
+            if (ta >= 1 && tb >= 1 && tc >= 1 && ta <= dense.nx - 2 && tb <= dense.ny - 2 && tc <= dense.nz - 2) {
+#pragma unroll
+                for (int dk = -1; dk <= 1; ++dk) {
+                    float4 c9[9];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const float4 *row = cells4 + (((size_t) (tc + dk) * dense.ny + (tb + r - 1)) * dense.nx + (ta - 1));
+                        c9[r * 3 + 0] = row[0];
+                        c9[r * 3 + 1] = row[1];
+                        c9[r * 3 + 2] = row[2];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 9; ++u) {
+                        const float fx = __fsub_rn(xt0, c9[u].x), fy = __fsub_rn(xt1, c9[u].y), fz = __fsub_rn(xt2, c9[u].z);
+                        const float dd = __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz));
+                        if (dd <= A.res2_f) {
+                            s_near[n_near * kBlock + threadIdx.x] = __float_as_uint(c9[u].w);
+                            ++n_near;
+                        }
+                    }
+                }
+            }
+        } else if (dense.table) {  // uniform
             const int ta = ci - dense.i0, tb = cj - dense.j0, tc = ck - dense.k0;
             if (ta >= 1 && tb >= 1 && tc >= 1 && ta <= dense.nx - 2 && tb <= dense.ny - 2 && tc <= dense.nz - 2) {
                 Int3 rows[9];
@@ -371,7 +409,6 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HES
         // 1b: kd-tree radius test in float on the float means (one 16-byte load each), four
         // candidates per trip so that four loads are in flight; survivors are compacted in place
         // (the write index never passes the read index), still in cell order
-        int n_near = 0;
 #pragma unroll 1
         for (int r = 0; r < n_cand; r += 4) {
             unsigned cv[4];
@@ -390,6 +427,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HES
                 }
             }
         }
+        // (how many voxels this point met, as a sort key that puts the busiest points first: ndt_regroup)
+        if (cnt_out) cnt_out[idx] = (unsigned char) (15 - min(n_near, 15));
         // the next voxel's record (mean + inverse covariance, 96 B) is requested before the
         // current one is evaluated: with two waves per SIMD a pass-2 trip would otherwise start
         // with a full memory round trip that nothing hides
@@ -670,9 +709,19 @@ static int ndt_build(wm_ctx *ctx, double res) {
             WM_HIP(ctx, ctx->ndt_dense.reserve((size_t) cells * 4));
             WM_HIP(ctx, hipMemsetAsync(ctx->ndt_dense.p, 0xFF, (size_t) cells * 4, ctx->stream));
             const NdtDense d{ctx->ndt_dense.as<int>(), lo[0], lo[1], lo[2], dim[0], dim[1], dim[2]};
+            // ... and, while that lattice is at most 4 M cells (64 MB), the same with the voxel's float mean in the cell
+            // (k_ndt_derivs: the cells are the radius tests); every byte 0x7f = a "mean" of 3.4e38 in an empty cell
+            ctx->ndt_cells4_on = false;
+            float4 *cells4 = nullptr;
+            if (cells <= (int64_t) 4 << 20 && ctx->tune_ndt_dense >= 2) {
+                WM_HIP(ctx, ctx->ndt_cells4.reserve((size_t) cells * sizeof(float4)));
+                WM_HIP(ctx, hipMemsetAsync(ctx->ndt_cells4.p, 0x7F, (size_t) cells * sizeof(float4), ctx->stream));
+                cells4 = ctx->ndt_cells4.as<float4>();
+                ctx->ndt_cells4_on = true;
+            }
             hipLaunchKernelGGL(k_ndt_dense_fill, dim3((nvox + kBlock - 1) / kBlock), dim3(kBlock), 0,
                                ctx->stream, ctx->ndt_vkey.as<unsigned long long>(), nvox, d,
-                               ctx->ndt_dense.as<int>());
+                               ctx->ndt_dense.as<int>(), ctx->ndt_meanf.as<float4>(), cells4);
             WM_HIP(ctx, hipGetLastError());
             for (int k = 0; k < 3; ++k) {
                 ctx->ndt_dense_lo[k] = lo[k];
@@ -693,6 +742,8 @@ struct NdtEval {
     wm_ctx *ctx;
     const wm_ndt_params *prm;
     double d1, d2;
+    // the source regrouped by voxel count (ndt_eval): on for wm_ndt_align's passes only
+    bool group = false, have_counts = false, grouped = false;
     int evals = 0;
     float kernel_ms = 0;
     double host_launch_us = 0, host_wait_us = 0;  // WM_NDT_PROFILE=2: wall time inside the launch calls / the wait
@@ -705,6 +756,18 @@ struct NdtEval {
     bool spec_hessian() const { return ctx->tune_ndt_spec_hessian != 0; }
     void note_line_search(int trials) { ls_hist[trials < 11 ? trials : 11]++; }
 };
+
+// out <- the points of `in` in the order of their keys (15 - voxel count of the last pass), stable
+static int ndt_regroup(wm_ctx *ctx, const float4 *in, unsigned char *keys, float4 *out, unsigned n) {
+    size_t bytes = 0;
+    unsigned char *keys_out = ctx->ndt_cnt[1].as<unsigned char>();
+    WM_HIP(ctx, sort_pairs_low_bits(nullptr, bytes, keys, keys_out, const_cast<float4 *>(in), out, (size_t) n, 4u, ctx->stream,
+                                    (size_t) 0));
+    WM_HIP(ctx, ctx->ndt_grp_tmp.reserve(bytes + 64));
+    WM_HIP(ctx, sort_pairs_low_bits(ctx->ndt_grp_tmp.p, bytes, keys, keys_out, const_cast<float4 *>(in), out, (size_t) n, 4u,
+                                    ctx->stream, (size_t) 0));
+    return WM_OK;
+}
 
 // score (+ gradient, + Hessian) at pose p; returns <0 on HIP error via *rc
 static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess, int *rc) {
@@ -738,29 +801,51 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
     const NdtVoxel *vox = ctx->ndt_vox.as<NdtVoxel>();
     const unsigned long long *hk = ctx->ndt_hkeys.as<unsigned long long>();
     const unsigned *hv = ctx->ndt_hvals.as<unsigned>();
+    // The pair loop of a pass runs, per wave, as long as its busiest lane: in Morton order a wave's 64 points meet 0..12
+    // voxels each (3.0 on average, 4.1 for the busiest: 74 % of the lanes at work on the ring scan).  So from the
+    // second pass on the passes read the source REGROUPED by the count each point had in the first (a stable one-pass
+    // radix sort of the points themselves on a 4-bit key, busiest first: within a class the order stays Morton's) and a
+    // wave's lanes run about the same number of trips.  Same terms, another summation order.  (Once per registration:
+    // regrouping again as the pose moves costs more than the passes gain, profiles/r05_experiments.md.)
     const float4 *src = ctx->src_sorted.as<float4>();
+    unsigned char *cnt_out = nullptr;
+    if (E.group && !sharded) {
+        if (E.have_counts && !E.grouped) {
+            if (ndt_regroup(ctx, src, ctx->ndt_cnt[0].as<unsigned char>(), ctx->ndt_grp.as<float4>(), n_total) != WM_OK) {
+                *rc = WM_ERR_HIP;
+                return 0;
+            }
+            E.grouped = true;
+        }
+        if (E.grouped)
+            src = ctx->ndt_grp.as<float4>();
+        else
+            cnt_out = ctx->ndt_cnt[0].as<unsigned char>();  // (the first pass leaves the counts)
+        E.have_counts = true;
+    }
     NdtDense dense{nullptr, 0, 0, 0, 0, 0, 0};
     if (ctx->ndt_dense_on && ctx->tune_ndt_dense)
         dense = NdtDense{ctx->ndt_dense.as<int>(), ctx->ndt_dense_lo[0], ctx->ndt_dense_lo[1],
                          ctx->ndt_dense_lo[2], ctx->ndt_dense_dim[0], ctx->ndt_dense_dim[1],
                          ctx->ndt_dense_dim[2]};
+    const float4 *cells4 = (dense.table && ctx->ndt_cells4_on && ctx->tune_ndt_dense >= 2) ? ctx->ndt_cells4.as<float4>() : nullptr;
     const auto t_launch0 = std::chrono::steady_clock::now();
     if (ctx->ndt_profile) (void) hipEventRecord(ctx->ev_a, ctx->stream);
     if (hess && grad)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<true, true>), dim3(nb), dim3(kBlock), 0,
                            ctx->stream, src, n, n_total, s_rank, s_world, vox, ctx->ndt_meanf.as<float4>(), hk,
-                           hv, ctx->ndt_hmask, dense, A,
-                           partials);
+                           hv, ctx->ndt_hmask, dense, cells4, A,
+                           partials, cnt_out);
     else if (grad)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<true, false>), dim3(nb), dim3(kBlock), 0,
                            ctx->stream, src, n, n_total, s_rank, s_world, vox, ctx->ndt_meanf.as<float4>(), hk,
-                           hv, ctx->ndt_hmask, dense, A,
-                           partials);
+                           hv, ctx->ndt_hmask, dense, cells4, A,
+                           partials, cnt_out);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<false, true>), dim3(nb), dim3(kBlock), 0,
                            ctx->stream, src, n, n_total, s_rank, s_world, vox, ctx->ndt_meanf.as<float4>(), hk,
-                           hv, ctx->ndt_hmask, dense, A,
-                           partials);
+                           hv, ctx->ndt_hmask, dense, cells4, A,
+                           partials, cnt_out);
     if (ctx->ndt_profile) (void) hipEventRecord(ctx->ev_b, ctx->stream);
     if (!ctx->h_ndt && hipHostMalloc((void **) &ctx->h_ndt, 64 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
         ctx->last_error = "ndt_eval: pinned allocation failed";
@@ -889,6 +974,13 @@ int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *prm, double T_out[16], wm_ndt
         E.d1 = -log(c1 + c2) - d3;
         E.d2 = -2.0 * log((-log(c1 * exp(-0.5) + c2) - d3) / E.d1);
     }
+    if (ctx->tune_ndt_group > 0 && ctx->n_src >= 65536 && !(ctx->ndt_world > 1 && (ctx->ndt_reduce || ctx->ndt_comm))) {
+        const size_t n = ctx->n_src;
+        WM_HIP(ctx, ctx->ndt_grp.reserve(n * sizeof(float4)));
+        WM_HIP(ctx, ctx->ndt_cnt[0].reserve(n + 64));
+        WM_HIP(ctx, ctx->ndt_cnt[1].reserve(n + 64));
+        E.group = true;
+    }
     NdtLoopOut lo;
     ndt_align_loop(E, prm->step_size, prm->t_eps, prm->max_iter, prm->force_iterations, &lo);
     if (E.rc != WM_OK) return E.rc;
@@ -905,8 +997,8 @@ int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *prm, double T_out[16], wm_ndt
         stats->score = ctx->n_src > 0 ? score / (double) ctx->n_src_input : 0;
         stats->deriv_kernel_ms = E.kernel_ms;
         if (ctx->trace)
-            fprintf(stderr, "[wm] ndt: %d passes, host time in launches %.0f us, in waits %.0f us, kernels %.3f ms\n",
-                    E.evals, E.host_launch_us, E.host_wait_us, E.kernel_ms);
+            fprintf(stderr, "[wm] ndt: %d passes (source regrouped: %d), host time in launches %.0f us, in waits %.0f us, kernels %.3f ms\n",
+                    E.evals, (int) E.grouped, E.host_launch_us, E.host_wait_us, E.kernel_ms);
         if (ctx->trace)
             fprintf(stderr, "[wm] ndt: line searches by extra trials 0..11+: %d %d %d %d %d %d %d %d %d %d %d %d\n", E.ls_hist[0],
                     E.ls_hist[1], E.ls_hist[2], E.ls_hist[3], E.ls_hist[4], E.ls_hist[5], E.ls_hist[6], E.ls_hist[7],

@@ -110,42 +110,55 @@ def test_one_rank_rccl_group_collective_exchange_gives_the_same_bits(wm, monkeyp
     assert np.array_equal(outs["1"]["T"], outs["0"]["T"])
 
 
-def test_two_ranks_exchange_through_mailboxes(wm, monkeypatch):
+_MAILBOX_PAIR = r"""
+import os, sys, threading
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from libwave_amd import capi as wm, synth
+ref, tgt, _ = synth.pair(40000, seed=17)
+world = 2
+# the SAME two contexts for both runs: the first leaves every buffer allocated (on one GPU a rank's first-call
+# hipMalloc / hipFree waits for the whole device -- for the other rank's solve kernel, which polls for this rank's block)
+ctxs = [wm.Context(0) for _ in range(world)]
+def run_group():
+    comms = wm.Comm.init_local(world, 0)
+    outs = [None] * world
+    def run(r):
+        outs[r] = ctxs[r].icp_align_sharded(comms[r], ref, tgt, max_corr=3.0, force_iterations=15, nn_method=wm.WM_NN_GRID)
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for c in reversed(comms):
+        c.close()
+    return outs
+want = run_group()
+os.environ["WM_COMM_P2P_LOCAL"] = "1"
+os.environ["WM_COMM_P2P_TIMEOUT_MS"] = "3000"
+got = run_group()
+assert all(o is not None and o["rc"] == 0 for o in want + got)
+assert all(o["exchange_in_kernel"] == 0 for o in want) and all(o["exchange_in_kernel"] == 1 for o in got)
+assert np.array_equal(got[0]["T"], got[1]["T"])
+assert np.array_equal(got[0]["T"], want[0]["T"])
+assert got[0]["owned_violations"] == 0 and got[0]["n_corr"] == want[0]["n_corr"]
+print("MAILBOX PAIR OK")
+"""
+
+
+def test_two_ranks_exchange_through_mailboxes():
     """The mailbox protocol between two ranks that really run side by side (two threads, two streams, one GPU:
     WM_COMM_P2P_LOCAL=1): each solve kernel writes its block into both mailboxes and polls its own for both --
     the same transform, bit for bit, on both ranks and as the host-side stand-in's; a time limit turns a stall
-    into an error instead of a hang."""
-    ref, tgt, _ = synth.pair(40000, seed=17)
-    world = 2
-    # (the SAME two contexts for both runs: the first run leaves every buffer allocated.  On one GPU a rank's first-call
-    # hipMalloc / hipFree waits for the whole device -- for the other rank's solve kernel, which polls for this rank's
-    # block: a stall that ranks on GPUs of their own cannot have, and that the exchange's time limit turns into an error)
-    ctxs = [wm.Context(0) for _ in range(world)]
-
-    def run_group():
-        comms = wm.Comm.init_local(world, 0)
-        outs = [None] * world
-
-        def run(r):
-            outs[r] = ctxs[r].icp_align_sharded(comms[r], ref, tgt, max_corr=3.0, force_iterations=15,
-                                                nn_method=wm.WM_NN_GRID)
-        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
-        [t.start() for t in th]
-        [t.join() for t in th]
-        for c in reversed(comms):
-            c.close()
-        return outs
-    want = run_group()
-    monkeypatch.setenv("WM_COMM_P2P_LOCAL", "1")
-    monkeypatch.setenv("WM_COMM_P2P_TIMEOUT_MS", "3000")
-    got = run_group()
-    for c in ctxs:
-        c.close()
-    assert all(o is not None and o["rc"] == 0 for o in want + got)
-    assert all(o["exchange_in_kernel"] == 0 for o in want) and all(o["exchange_in_kernel"] == 1 for o in got)
-    assert np.array_equal(got[0]["T"], got[1]["T"])
-    assert np.array_equal(got[0]["T"], want[0]["T"])
-    assert got[0]["owned_violations"] == 0 and got[0]["n_corr"] == want[0]["n_corr"]
+    into an error instead of a hang.  In a process of its own with a hardware queue per stream: two ranks on ONE
+    GPU whose streams share a hardware queue would queue one rank's kernels behind the other's polling solve kernel
+    (ranks on GPUs of their own cannot meet that)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    env.pop("WM_COMM_P2P_LOCAL", None)
+    out = subprocess.run([sys.executable, "-c", _MAILBOX_PAIR, root], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "MAILBOX PAIR OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
 
 
 def test_icp_8m_in_8_slabs_full_registration(wm):
