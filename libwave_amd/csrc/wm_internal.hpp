@@ -285,9 +285,8 @@ struct wm_ctx {
     int tune_fast_solve = 1;     // experiment knob for the solve kernel
     int tune_spin_us = 80;       // wait_flag: busy-poll this long before polling with yields
     int tune_ndt_spec_hessian = 1;  // form the Hessian along with the first extra line-search trial (wm_ndt.hip step_length_mt)
-    int tune_ndt_group = 1;  // NDT: the source regrouped by how many voxels each point meets (wm_ndt.hip: ndt_regroup)
-    wm::DevBuf ndt_grp, ndt_cnt[2], ndt_grp_tmp;
-    int tune_ndt_blocks = 1024;  // workgroups (= partial rows) of one NDT derivative pass
+    int tune_ndt_blocks = 0;  // workgroups (= partial rows) of one NDT derivative pass; 0: one resident round (wm_ndt.hip)
+    int ndt_cus = 0;
     int tune_gicp_blocks = 256;  // workgroups (= partial rows) of one GICP objective evaluation (double-double sums: 512 / 256 / 128 / 64 -> 6.9 / 6.4 / 7.3 / 9.6 ms per 500k registration)
     bool ndt_built = false;
     int ndt_model_builds = 0;    // voxel models built so far (wm_ndt_stats.model_builds)

@@ -275,12 +275,11 @@ __device__ __forceinline__ double dot3d(const double *a, const double *b) {
 
 // a[0] = score, a[1..6] = gradient, a[7..27] = upper triangle of the Hessian, row by row
 template <bool GRAD, bool HESS>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HESS ? 2 : 4, HESS ? 2 : 4)))
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HESS ? 3 : 4, HESS ? 3 : 4)))
     k_ndt_derivs(const float4 *__restrict__ src, unsigned n, unsigned n_total, unsigned shard_rank,
                  unsigned shard_world, const NdtVoxel *__restrict__ vox,
                  const float4 *__restrict__ meanf, const unsigned long long *__restrict__ hkeys, const unsigned *__restrict__ hvals,
-                 unsigned mask, NdtDense dense, const float4 *__restrict__ cells4, NdtArgs A, double *__restrict__ partials,
-                 unsigned char *__restrict__ cnt_out) {
+                 unsigned mask, NdtDense dense, const float4 *__restrict__ cells4, NdtArgs A, double *__restrict__ partials) {
     // The double-precision algebra of this kernel may fuse a multiply with the add that follows it
     // (the library is built with -ffp-contract=off for the FLOAT arithmetic that has to reproduce PCL's
     // bits: the point transform and the radius test below, written with explicit _rn intrinsics, are not
@@ -346,24 +345,28 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HES
             // lanes reading their 27 from there -- 136 against 109 us per pass, profiles/r05_experiments.md.)
             const int ta = ci - dense.i0, tb = cj - dense.j0, tc = ck - dense.k0;
             if (ta >= 1 && tb >= 1 && tc >= 1 && ta <= dense.nx - 2 && tb <= dense.ny - 2 && tc <= dense.nz - 2) {
+                // (a plane of nine cells at a time: all 27 in flight cost the registers of the third wave per SIMD)
+                constexpr int kBatch = 9;
 #pragma unroll
-                for (int dk = -1; dk <= 1; ++dk) {
-                    float4 c9[9];
+                for (int b0 = 0; b0 < 27; b0 += kBatch) {
+                    float4 cb[kBatch];
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        const float4 *row = cells4 + (((size_t) (tc + dk) * dense.ny + (tb + r - 1)) * dense.nx + (ta - 1));
-                        c9[r * 3 + 0] = row[0];
-                        c9[r * 3 + 1] = row[1];
-                        c9[r * 3 + 2] = row[2];
+                    for (int r = 0; r < kBatch / 3; ++r) {
+                        const int row_id = b0 / 3 + r;
+                        const float4 *row =
+                            cells4 + (((size_t) (tc + row_id / 3 - 1) * dense.ny + (tb + row_id % 3 - 1)) * dense.nx + (ta - 1));
+                        cb[r * 3 + 0] = row[0];
+                        cb[r * 3 + 1] = row[1];
+                        cb[r * 3 + 2] = row[2];
                     }
 #pragma unroll
-                    for (int u = 0; u < 9; ++u) {
-                        const float fx = __fsub_rn(xt0, c9[u].x), fy = __fsub_rn(xt1, c9[u].y), fz = __fsub_rn(xt2, c9[u].z);
+                    for (int u = 0; u < kBatch; ++u) {
+                        const float fx = __fsub_rn(xt0, cb[u].x), fy = __fsub_rn(xt1, cb[u].y), fz = __fsub_rn(xt2, cb[u].z);
                         const float dd = __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz));
-                        if (dd <= A.res2_f) {
-                            s_near[n_near * kBlock + threadIdx.x] = __float_as_uint(c9[u].w);
-                            ++n_near;
-                        }
+                        // (stored whether it passes or not, kept only if it does: no branch, no exec mask to set
+                        // up and restore per cell -- the next store lands on a slot that did not pass)
+                        s_near[n_near * kBlock + threadIdx.x] = __float_as_uint(cb[u].w);
+                        n_near += dd <= A.res2_f ? 1 : 0;
                     }
                 }
             }
@@ -427,15 +430,13 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HES
                 }
             }
         }
-        // (how many voxels this point met, as a sort key that puts the busiest points first: ndt_regroup)
-        if (cnt_out) cnt_out[idx] = (unsigned char) (15 - min(n_near, 15));
         // the next voxel's record (mean + inverse covariance, 96 B) is requested before the
         // current one is evaluated: with two waves per SIMD a pass-2 trip would otherwise start
         // with a full memory round trip that nothing hides
         // (PRE = false frees the 24 registers of the record in flight: the Hessian variants then fit three waves
-        // per SIMD instead of two -- measured equal, 6.30 vs 6.25 ms per 2M registration: lanes idling in this
-        // loop and the vector ALU bind, not latency)
-        constexpr bool PRE = true;
+        // per SIMD instead of two.  Round 4 measured that equal -- with 1024 workgroups, a round and a third of
+        // the 768 that are resident at three waves; with a grid of exactly one round it is 87 against 100 us per pass)
+        constexpr bool PRE = !HESS;
         NdtVoxel vn;
         if (PRE) {
             const unsigned v0 = n_near > 0 ? s_near[threadIdx.x] : 0u;
@@ -742,8 +743,6 @@ struct NdtEval {
     wm_ctx *ctx;
     const wm_ndt_params *prm;
     double d1, d2;
-    // the source regrouped by voxel count (ndt_eval): on for wm_ndt_align's passes only
-    bool group = false, have_counts = false, grouped = false;
     int evals = 0;
     float kernel_ms = 0;
     double host_launch_us = 0, host_wait_us = 0;  // WM_NDT_PROFILE=2: wall time inside the launch calls / the wait
@@ -756,18 +755,6 @@ struct NdtEval {
     bool spec_hessian() const { return ctx->tune_ndt_spec_hessian != 0; }
     void note_line_search(int trials) { ls_hist[trials < 11 ? trials : 11]++; }
 };
-
-// out <- the points of `in` in the order of their keys (15 - voxel count of the last pass), stable
-static int ndt_regroup(wm_ctx *ctx, const float4 *in, unsigned char *keys, float4 *out, unsigned n) {
-    size_t bytes = 0;
-    unsigned char *keys_out = ctx->ndt_cnt[1].as<unsigned char>();
-    WM_HIP(ctx, sort_pairs_low_bits(nullptr, bytes, keys, keys_out, const_cast<float4 *>(in), out, (size_t) n, 4u, ctx->stream,
-                                    (size_t) 0));
-    WM_HIP(ctx, ctx->ndt_grp_tmp.reserve(bytes + 64));
-    WM_HIP(ctx, sort_pairs_low_bits(ctx->ndt_grp_tmp.p, bytes, keys, keys_out, const_cast<float4 *>(in), out, (size_t) n, 4u,
-                                    ctx->stream, (size_t) 0));
-    return WM_OK;
-}
 
 // score (+ gradient, + Hessian) at pose p; returns <0 on HIP error via *rc
 static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess, int *rc) {
@@ -795,34 +782,22 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
         n = mine << kNdtChunkLog2;
     }
     int nb = (int) ((n + kBlock - 1) / kBlock);
-    if (nb > ctx->tune_ndt_blocks) nb = ctx->tune_ndt_blocks;
+    // one full round of resident workgroups: the Hessian variants run three waves per SIMD (three workgroups per compute
+    // unit), the gradient variant four -- 768 / 1024 on the 256 compute units of an MI355X (1024 for all, round 4, made
+    // the Hessian passes a round and a third: 102 against 87 us)
+    if (ctx->ndt_cus == 0) {
+        int cus = 0;
+        ctx->ndt_cus = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && cus > 0) ? cus : 256;
+    }
+    const int nb_cap = ctx->tune_ndt_blocks > 0 ? ctx->tune_ndt_blocks : ctx->ndt_cus * (hess ? 3 : 4);
+    if (nb > nb_cap) nb = nb_cap;
+    if (nb > kNdtBlocks) nb = kNdtBlocks;
     if (nb < 1) nb = 1;
     double *partials = ctx->partials.as<double>();
     const NdtVoxel *vox = ctx->ndt_vox.as<NdtVoxel>();
     const unsigned long long *hk = ctx->ndt_hkeys.as<unsigned long long>();
     const unsigned *hv = ctx->ndt_hvals.as<unsigned>();
-    // The pair loop of a pass runs, per wave, as long as its busiest lane: in Morton order a wave's 64 points meet 0..12
-    // voxels each (3.0 on average, 4.1 for the busiest: 74 % of the lanes at work on the ring scan).  So from the
-    // second pass on the passes read the source REGROUPED by the count each point had in the first (a stable one-pass
-    // radix sort of the points themselves on a 4-bit key, busiest first: within a class the order stays Morton's) and a
-    // wave's lanes run about the same number of trips.  Same terms, another summation order.  (Once per registration:
-    // regrouping again as the pose moves costs more than the passes gain, profiles/r05_experiments.md.)
     const float4 *src = ctx->src_sorted.as<float4>();
-    unsigned char *cnt_out = nullptr;
-    if (E.group && !sharded) {
-        if (E.have_counts && !E.grouped) {
-            if (ndt_regroup(ctx, src, ctx->ndt_cnt[0].as<unsigned char>(), ctx->ndt_grp.as<float4>(), n_total) != WM_OK) {
-                *rc = WM_ERR_HIP;
-                return 0;
-            }
-            E.grouped = true;
-        }
-        if (E.grouped)
-            src = ctx->ndt_grp.as<float4>();
-        else
-            cnt_out = ctx->ndt_cnt[0].as<unsigned char>();  // (the first pass leaves the counts)
-        E.have_counts = true;
-    }
     NdtDense dense{nullptr, 0, 0, 0, 0, 0, 0};
     if (ctx->ndt_dense_on && ctx->tune_ndt_dense)
         dense = NdtDense{ctx->ndt_dense.as<int>(), ctx->ndt_dense_lo[0], ctx->ndt_dense_lo[1],
@@ -835,17 +810,17 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<true, true>), dim3(nb), dim3(kBlock), 0,
                            ctx->stream, src, n, n_total, s_rank, s_world, vox, ctx->ndt_meanf.as<float4>(), hk,
                            hv, ctx->ndt_hmask, dense, cells4, A,
-                           partials, cnt_out);
+                           partials);
     else if (grad)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<true, false>), dim3(nb), dim3(kBlock), 0,
                            ctx->stream, src, n, n_total, s_rank, s_world, vox, ctx->ndt_meanf.as<float4>(), hk,
                            hv, ctx->ndt_hmask, dense, cells4, A,
-                           partials, cnt_out);
+                           partials);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<false, true>), dim3(nb), dim3(kBlock), 0,
                            ctx->stream, src, n, n_total, s_rank, s_world, vox, ctx->ndt_meanf.as<float4>(), hk,
                            hv, ctx->ndt_hmask, dense, cells4, A,
-                           partials, cnt_out);
+                           partials);
     if (ctx->ndt_profile) (void) hipEventRecord(ctx->ev_b, ctx->stream);
     if (!ctx->h_ndt && hipHostMalloc((void **) &ctx->h_ndt, 64 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
         ctx->last_error = "ndt_eval: pinned allocation failed";
@@ -974,13 +949,6 @@ int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *prm, double T_out[16], wm_ndt
         E.d1 = -log(c1 + c2) - d3;
         E.d2 = -2.0 * log((-log(c1 * exp(-0.5) + c2) - d3) / E.d1);
     }
-    if (ctx->tune_ndt_group > 0 && ctx->n_src >= 65536 && !(ctx->ndt_world > 1 && (ctx->ndt_reduce || ctx->ndt_comm))) {
-        const size_t n = ctx->n_src;
-        WM_HIP(ctx, ctx->ndt_grp.reserve(n * sizeof(float4)));
-        WM_HIP(ctx, ctx->ndt_cnt[0].reserve(n + 64));
-        WM_HIP(ctx, ctx->ndt_cnt[1].reserve(n + 64));
-        E.group = true;
-    }
     NdtLoopOut lo;
     ndt_align_loop(E, prm->step_size, prm->t_eps, prm->max_iter, prm->force_iterations, &lo);
     if (E.rc != WM_OK) return E.rc;
@@ -997,8 +965,8 @@ int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *prm, double T_out[16], wm_ndt
         stats->score = ctx->n_src > 0 ? score / (double) ctx->n_src_input : 0;
         stats->deriv_kernel_ms = E.kernel_ms;
         if (ctx->trace)
-            fprintf(stderr, "[wm] ndt: %d passes (source regrouped: %d), host time in launches %.0f us, in waits %.0f us, kernels %.3f ms\n",
-                    E.evals, (int) E.grouped, E.host_launch_us, E.host_wait_us, E.kernel_ms);
+            fprintf(stderr, "[wm] ndt: %d passes, host time in launches %.0f us, in waits %.0f us, kernels %.3f ms\n",
+                    E.evals, E.host_launch_us, E.host_wait_us, E.kernel_ms);
         if (ctx->trace)
             fprintf(stderr, "[wm] ndt: line searches by extra trials 0..11+: %d %d %d %d %d %d %d %d %d %d %d %d\n", E.ls_hist[0],
                     E.ls_hist[1], E.ls_hist[2], E.ls_hist[3], E.ls_hist[4], E.ls_hist[5], E.ls_hist[6], E.ls_hist[7],

@@ -1,5 +1,6 @@
-"""NDT 2M-point 64-ring pair, 0.5 m voxels (BASELINE configs[3]): the source regrouped by voxel count
-(WM_TUNE_NDT_GROUP = pose change in thousandths of the resolution after which it is redone; 0 = off)."""
+"""NDT 2M-point 64-ring pair, 0.5 m voxels (BASELINE configs[3]): ms per registration and us per derivative pass by
+the number of workgroups of a pass (WM_TUNE_NDT_BLOCKS; 0 = one resident round, the default).
+NDT_PATTERN= NDT_POINTS=1000000 NDT_RES=1.0 for the uniform scene."""
 import os
 import sys
 import time
@@ -15,8 +16,8 @@ pattern = os.environ.get("NDT_PATTERN", "rings")
 ref, tgt, T_gt = synth.pair(n, seed=42, pattern=pattern) if pattern else synth.pair(n, seed=42)
 d_ref, d_tgt = torch.from_numpy(ref).cuda(), torch.from_numpy(tgt).cuda()
 os.environ["WM_TRACE"] = os.environ.get("WM_TRACE", "0")
-for group in [int(x) for x in os.environ.get("NDT_GROUPS", "0,150,50,300,1000,100000").split(",")]:
-    os.environ["WM_TUNE_NDT_GROUP"] = str(group)
+for group in [int(x) for x in os.environ.get("NDT_BLOCKS", "0,512,768,1024,1536").split(",")]:
+    os.environ["WM_TUNE_NDT_BLOCKS"] = str(group)
     ctx = capi.Context(0)
     os.environ["WM_NDT_PROFILE"] = "1"
     prof = capi.Context(0)
@@ -34,7 +35,7 @@ for group in [int(x) for x in os.environ.get("NDT_GROUPS", "0,150,50,300,1000,10
         ts.append((time.perf_counter() - t0) * 1e3)
     run(prof)
     rp = run(prof)
-    print("group %6d: %.3f ms/registration (min %.3f), %d iterations, %d passes, kernel %.1f us/pass, |t - t_gt| %.3e, T[0,3] %.9f" % (
+    print("blocks %5d: %.3f ms/registration (min %.3f), %d iterations, %d passes, kernel %.1f us/pass, |t - t_gt| %.3e, T[0,3] %.9f" % (
         group, np.median(ts), min(ts), r["iterations"], r["evaluations"], rp.get("deriv_kernel_ms", 0) / max(rp["evaluations"], 1) * 1e3,
         np.linalg.norm(r["T"][:3, 3] - T_gt[:3, 3]), r["T"][0, 3]), flush=True)
     ctx.close(); prof.close()
