@@ -37,6 +37,25 @@ def test_multi_emulated_equals_unsharded(wm, world):
     assert dt <= 1e-9 and ang <= 1e-9, (dt, ang)  # differs only by summation order
 
 
+def test_multi_redoes_with_full_source_when_points_leave_their_bands(wm):
+    """A source 2 m off along the slab axis: the registration pulls points out of the bands their ranks were given
+    (max_corr wide), the all-reduced count of handled points says so, and every rank redoes the registration with the
+    whole source (wm_icp_stats.shard_attempts = 2: the second selection of k_band_count / k_band_write) -- to the
+    unsharded result."""
+    ref, tgt, _ = synth.pair(60000, seed=21)
+    ref = ref.copy()
+    ref[:, 0] -= 2.0
+    want = _unsharded(wm, ref, tgt, max_corr=3.0, force_iterations=30)
+    m = wm.Multi([0] * 4, emulate=True)
+    got = m.icp_align(ref, tgt, max_corr=3.0, force_iterations=30, nn_method=wm.WM_NN_GRID)
+    m.close()
+    assert got["rc"] == want["rc"] == 0 and got["shard_attempts"] == 2 and got["owned_violations"] == 0
+    assert got["n_corr"] == want["n_corr"]
+    dt, ang = pose_error(got["T"], want["T"])
+    assert dt <= 1e-9 and ang <= 1e-9, (dt, ang)
+    assert abs(want["T"][0, 3]) > 1.5  # (the cloud did move by most of the offset)
+
+
 def test_multi_free_running_same_stop(wm):
     """PCL's stopping rules, applied to the all-reduced block on every rank: same iteration count
     and state as the unsharded registration."""
