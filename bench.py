@@ -529,7 +529,7 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu, copy_peak=None):
     return out
 
 
-def in_flight_throughput(torch, capi, d_ref, d_tgt, h_ref, h_tgt, a, crews=(1, 2, 4), regs_per_worker=6):
+def in_flight_throughput(torch, capi, d_ref, d_tgt, h_ref, h_tgt, a, crews=(1, 2, 4), regs_per_worker=24):
     """BASELINE configs[1] the way the reference gets THROUGHPUT: wave::MultiMatcher's pattern (multi_matcher.hpp:32,
     impl/multi_matcher_impl.hpp:30-64) -- one matcher per worker thread, every worker registering its own pairs --
     with 1M<->1M pairs at full resolution and 50 forced iterations.  Here a worker is a host thread with its own
@@ -575,7 +575,7 @@ def in_flight_throughput(torch, capi, d_ref, d_tgt, h_ref, h_tgt, a, crews=(1, 2
     return out
 
 
-def two_in_flight(torch, capi, reg, regs_per_worker=5):
+def two_in_flight(torch, capi, reg, regs_per_worker=16):
     """registrations/s of `reg(ctx)` with one and with two worker threads, each with its own context (the MultiMatcher
     pattern on one GPU, as in_flight_throughput): what the host round trips of a GICP / NDT registration leave idle."""
     rows = {}
