@@ -4,9 +4,10 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
 import torch
 from libwave_amd import capi, synth
-ref, tgt, T_gt = synth.pair(1_000_000, seed=42)
+pattern = os.environ.get("PATTERN", "")  # "rings": the 64-ring scan
+ref, tgt, T_gt = synth.pair(1_000_000, seed=42, pattern=pattern) if pattern else synth.pair(1_000_000, seed=42)
 d_ref, d_tgt = torch.from_numpy(ref).cuda(), torch.from_numpy(tgt).cuda()
-for h in (0.0, 0.09, 0.11, 0.13, 0.15, 0.183, 0.22, 0.27):
+for h in [float(x) for x in os.environ.get("CELLS", "0.0,0.09,0.11,0.13,0.15,0.183,0.22,0.27").split(",")]:
     ctx = capi.Context(0)
     if h > 0:
         ctx.set_grid_cell(h)
