@@ -910,6 +910,7 @@ int wm_ctx_create(wm_ctx **out, int device) {
     }
     if (const char *e = getenv("WM_TUNE_GICP_SERVED")) ctx->tune_gicp_served = atoi(e) == 2 ? 2 : (atoi(e) != 0 ? 1 : 0);
     if (const char *e = getenv("WM_TUNE_NDT_SPEC_HESSIAN")) ctx->tune_ndt_spec_hessian = atoi(e);
+    if (const char *e = getenv("WM_TUNE_NDT_FUSED_FETCH")) ctx->tune_ndt_fused_fetch = atoi(e);
     if (const char *e = getenv("WM_TUNE_LAG")) ctx->tune_lag = atoi(e);
     if (const char *e = getenv("WM_TUNE_LATE")) ctx->tune_late = atoi(e);
     if (const char *e = getenv("WM_TUNE_EARLY_SOURCE")) ctx->tune_early_source = atoi(e);

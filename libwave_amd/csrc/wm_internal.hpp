@@ -287,6 +287,9 @@ struct wm_ctx {
     int tune_ndt_spec_hessian = 1;  // form the Hessian along with the first extra line-search trial (wm_ndt.hip step_length_mt)
     int tune_ndt_blocks = 0;  // workgroups (= partial rows) of one NDT derivative pass; 0: one resident round (wm_ndt.hip)
     int ndt_cus = 0;
+    int tune_ndt_fused_fetch = 1;  // a pass's last workgroup adds the rows and hands the sums to the host (wm_ndt.hip)
+    wm::DevBuf ndt_ticket;
+    unsigned ndt_seq = 0;
     int tune_gicp_blocks = 256;  // workgroups (= partial rows) of one GICP objective evaluation (double-double sums: 512 / 256 / 128 / 64 -> 6.9 / 6.4 / 7.3 / 9.6 ms per 500k registration)
     bool ndt_built = false;
     int ndt_model_builds = 0;    // voxel models built so far (wm_ndt_stats.model_builds)

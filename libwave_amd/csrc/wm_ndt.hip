@@ -25,6 +25,7 @@
 #include "wm_ndt_ctl.hpp"
 
 #include <chrono>
+#include <thread>
 #include <float.h>
 #include <math.h>
 
@@ -273,13 +274,23 @@ __device__ __forceinline__ double dot3d(const double *a, const double *b) {
     return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
 }
 
+// where the last workgroup of a pass leaves the sums for the host (ticket == nullptr: it does not; k_sum_fetch does)
+constexpr unsigned kFetchGroup = 16;    // workgroups whose rows one of them adds
+constexpr unsigned kFetchRowsMax = 64;  // rows one add_rows call takes at most: kFetchGroup, and the groups of a pass
+struct NdtFetch {
+    unsigned *ticket;  // device words, zero between passes: [0] the groups', [1 + g] group g's workgroups'
+    void *dst;         // pinned host memory: 16-byte slots {double value, unsigned number of the pass, 0}
+    unsigned seq;      // this pass's number (never 0)
+};
+
 // a[0] = score, a[1..6] = gradient, a[7..27] = upper triangle of the Hessian, row by row
 template <bool GRAD, bool HESS>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HESS ? 3 : 4, HESS ? 3 : 4)))
     k_ndt_derivs(const float4 *__restrict__ src, unsigned n, unsigned n_total, unsigned shard_rank,
                  unsigned shard_world, const NdtVoxel *__restrict__ vox,
                  const float4 *__restrict__ meanf, const unsigned long long *__restrict__ hkeys, const unsigned *__restrict__ hvals,
-                 unsigned mask, NdtDense dense, const float4 *__restrict__ cells4, NdtArgs A, double *__restrict__ partials) {
+                 unsigned mask, NdtDense dense, const float4 *__restrict__ cells4, NdtArgs A, double *__restrict__ partials,
+                 NdtFetch F) {
     // The double-precision algebra of this kernel may fuse a multiply with the add that follows it
     // (the library is built with -ffp-contract=off for the FLOAT arithmetic that has to reproduce PCL's
     // bits: the point transform and the radius test below, written with explicit _rn intrinsics, are not
@@ -590,7 +601,76 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HES
     if (threadIdx.x < NA) {
         double s = 0;
         for (int w = 0; w < kBlock / 64; ++w) s += lds[w][threadIdx.x];
-        partials[(size_t) blockIdx.x * NA + threadIdx.x] = s;
+        // (written through to where every XCD sees it -- an agent-scope store --, for the workgroup that adds the rows)
+        __hip_atomic_store(&partials[(size_t) blockIdx.x * NA + threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!F.ticket) return;  // (the rows are added by a launch of their own: the sharded passes)
+    // The workgroups add the rows themselves and the LAST one hands the sums to the host -- what k_sum_fetch did in a
+    // launch of its own: a dependent launch (~6 us of dispatch) and 5 us of one workgroup behind every pass.  Two levels
+    // (one workgroup adding all 768 rows is a chain of dependent L2 round trips): the last of every kFetchGroup
+    // consecutive workgroups adds that group's rows into one, the last of those adds the groups' rows.  Groups and
+    // orders are fixed by the workgroup numbers, not by who finishes when: the sums do not depend on it.
+    // No fence anywhere (an agent-scope release writes the XCD's whole L2 back, a system-scope one too: with
+    // __threadfence() around the tickets a pass took 157 us instead of 89): rows are stored write-through, a workgroup
+    // waits for its own stores (s_waitcnt), draws its ticket with a relaxed atomic, the last one reads the rows at
+    // agent scope, and the sums reach the host as 16-byte slots {value, number of the pass} in ONE store each --
+    // the host takes a slot once it carries the number it waits for (the recipe of the GICP evaluator, wm_gicp.hip).
+    constexpr unsigned kLanes = (unsigned) kBlock / (unsigned) NA;  // row-lanes of NA columns
+    __shared__ double s1[kLanes][NA];
+    __shared__ unsigned s_last;
+    const unsigned t = threadIdx.x, c = t % (unsigned) NA, g = t / (unsigned) NA;
+    const unsigned ngroups = (gridDim.x + kFetchGroup - 1u) / kFetchGroup, grp = blockIdx.x / kFetchGroup;
+    const unsigned members = min(kFetchGroup, gridDim.x - grp * kFetchGroup);
+    double *grows = partials + (size_t) gridDim.x * NA;  // the groups' rows, behind the workgroups'
+    if (t < 64u) {  // (the row's writers are lanes of wave 0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t == 0) s_last = __hip_atomic_fetch_add(F.ticket + 1u + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    auto add_rows = [&](const double *rows, unsigned n) -> double {  // (thread t < NA returns rows[0][t] + rows[1][t] + ...; fixed order)
+        if (g < kLanes) {
+            double v[(kFetchRowsMax + kLanes - 1u) / kLanes];
+#pragma unroll
+            for (unsigned u = 0; u < (kFetchRowsMax + kLanes - 1u) / kLanes; ++u) {
+                const unsigned r = g + u * kLanes;
+                v[u] = r < n ? __hip_atomic_load(&rows[(size_t) r * NA + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            }
+            double a = 0.0;
+#pragma unroll
+            for (unsigned u = 0; u < (kFetchRowsMax + kLanes - 1u) / kLanes; ++u) a += v[u];
+            s1[g][c] = a;
+        }
+        __syncthreads();
+        double r = 0.0;
+        if (t < (unsigned) NA)
+            for (unsigned gg = 0; gg < kLanes; ++gg) r += s1[gg][t];
+        return r;
+    };
+    {
+        const double r = add_rows(partials + (size_t) grp * kFetchGroup * NA, members);
+        if (t < (unsigned) NA) __hip_atomic_store(&grows[(size_t) grp * NA + t], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();  // (s1 is used again below; and wave 0 draws the next ticket behind its own stores)
+    if (t < 64u) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t == 0) {
+            __hip_atomic_store(F.ticket + 1u + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next pass)
+            s_last = __hip_atomic_fetch_add(F.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1u ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    {
+        const double r = add_rows(grows, ngroups);
+        if (t < (unsigned) NA) {
+            typedef unsigned u4v __attribute__((ext_vector_type(4)));
+            const unsigned long long rb = (unsigned long long) __double_as_longlong(r);
+            const u4v out = {(unsigned) rb, (unsigned) (rb >> 32), F.seq, 0u};
+            u4v *dst = reinterpret_cast<u4v *>(F.dst) + t;
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(out) : "memory");
+        }
+        if (t == 0) __hip_atomic_store(F.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -756,6 +836,38 @@ struct NdtEval {
     void note_line_search(int trials) { ls_hist[trials < 11 ? trials : 11]++; }
 };
 
+// wait until the n 16-byte slots {value, number} at `slots` (pinned memory) all carry `seq` (wait_flag's three stages:
+// spin, poll with yields, and after 4 ms let the runtime block -- which is also what reports a failed kernel)
+static int wait_slots(wm_ctx *ctx, const double *slots, int n, unsigned seq) {
+    const volatile unsigned *w = reinterpret_cast<const volatile unsigned *>(slots);
+    auto all_there = [&]() {
+        for (int k = n - 1; k >= 0; --k)
+            if (w[4 * k + 2] != seq) return false;
+        return true;
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    bool yielding = false;
+    for (unsigned spins = 1; !all_there(); ++spins) {
+        if (yielding)
+            std::this_thread::yield();
+        else
+            cpu_relax();
+        if ((spins & 63u) == 0 || yielding) {
+            const auto waited = std::chrono::steady_clock::now() - t0;
+            if (waited > std::chrono::milliseconds(4)) {
+                WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (!all_there()) {
+                    ctx->last_error = "ndt_eval: the pass ended without delivering its sums";
+                    return WM_ERR_HIP;
+                }
+                break;
+            }
+            yielding = waited > std::chrono::microseconds(ctx->tune_spin_us);
+        }
+    }
+    return WM_OK;
+}
+
 // score (+ gradient, + Hessian) at pose p; returns <0 on HIP error via *rc
 static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess, int *rc) {
     wm_ctx *ctx = E.ctx;
@@ -804,29 +916,44 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
                          ctx->ndt_dense_lo[2], ctx->ndt_dense_dim[0], ctx->ndt_dense_dim[1],
                          ctx->ndt_dense_dim[2]};
     const float4 *cells4 = (dense.table && ctx->ndt_cells4_on && ctx->tune_ndt_dense >= 2) ? ctx->ndt_cells4.as<float4>() : nullptr;
+    // the sums come back from the pass's own last workgroup (not when the ranks' sums are all-reduced on the device first)
+    NdtFetch F{nullptr, nullptr, 0u};
+    const bool fused_fetch = !(sharded && ctx->ndt_comm) && ctx->tune_ndt_fused_fetch &&
+                             (unsigned) nb <= kFetchGroup * kFetchRowsMax;  // (two levels of at most 16 and 64 rows)
+    if (!ctx->h_ndt && hipHostMalloc((void **) &ctx->h_ndt, 64 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+        ctx->last_error = "ndt_eval: pinned allocation failed";
+        *rc = WM_ERR_HIP;
+        return 0;
+    }
+    if (fused_fetch) {
+        if (!ctx->ndt_ticket.p) {
+            memset(ctx->h_ndt, 0, 64 * sizeof(double));
+            if (ctx->ndt_ticket.reserve(4096) != hipSuccess || hipMemsetAsync(ctx->ndt_ticket.p, 0, 4096, ctx->stream) != hipSuccess) {
+                *rc = WM_ERR_HIP;
+                return 0;
+            }
+        }
+        if (++ctx->ndt_seq == 0u) ctx->ndt_seq = 1u;
+        F = NdtFetch{ctx->ndt_ticket.as<unsigned>(), ctx->h_ndt, ctx->ndt_seq};
+    }
     const auto t_launch0 = std::chrono::steady_clock::now();
     if (ctx->ndt_profile) (void) hipEventRecord(ctx->ev_a, ctx->stream);
     if (hess && grad)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<true, true>), dim3(nb), dim3(kBlock), 0,
                            ctx->stream, src, n, n_total, s_rank, s_world, vox, ctx->ndt_meanf.as<float4>(), hk,
                            hv, ctx->ndt_hmask, dense, cells4, A,
-                           partials);
+                           partials, F);
     else if (grad)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<true, false>), dim3(nb), dim3(kBlock), 0,
                            ctx->stream, src, n, n_total, s_rank, s_world, vox, ctx->ndt_meanf.as<float4>(), hk,
                            hv, ctx->ndt_hmask, dense, cells4, A,
-                           partials);
+                           partials, F);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_derivs<false, true>), dim3(nb), dim3(kBlock), 0,
                            ctx->stream, src, n, n_total, s_rank, s_world, vox, ctx->ndt_meanf.as<float4>(), hk,
                            hv, ctx->ndt_hmask, dense, cells4, A,
-                           partials);
+                           partials, F);
     if (ctx->ndt_profile) (void) hipEventRecord(ctx->ev_b, ctx->stream);
-    if (!ctx->h_ndt && hipHostMalloc((void **) &ctx->h_ndt, 64 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
-        ctx->last_error = "ndt_eval: pinned allocation failed";
-        *rc = WM_ERR_HIP;
-        return 0;
-    }
     const auto t_launch1 = std::chrono::steady_clock::now();
     // sums over blocks, formed on the device (fixed order); 224 bytes come back
     const int n_acc = hess ? kNdtAcc : kNdtAccGrad;
@@ -840,7 +967,8 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
             *rc = WM_ERR_HIP;
             return 0;
         }
-    } else if (fast_fetch_sum(ctx, ctx->h_ndt, partials, (unsigned) nb, (unsigned) n_acc) != WM_OK) {
+    } else if ((fused_fetch ? wait_slots(ctx, ctx->h_ndt, n_acc, F.seq)
+                            : fast_fetch_sum(ctx, ctx->h_ndt, partials, (unsigned) nb, (unsigned) n_acc)) != WM_OK) {
         ctx->last_error = "ndt_eval: HIP error";
         *rc = WM_ERR_HIP;
         return 0;
@@ -856,7 +984,7 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
     E.kernel_ms += ms;
     E.evals += 1;
     double a[kNdtAcc] = {0};
-    for (int k = 0; k < n_acc; ++k) a[k] = ctx->h_ndt[k];
+    for (int k = 0; k < n_acc; ++k) a[k] = fused_fetch ? ctx->h_ndt[2 * k] : ctx->h_ndt[k];  // (slots of 16 bytes: the value first)
     if (sharded && !ctx->ndt_comm && ctx->ndt_reduce(a, n_acc, ctx->ndt_reduce_user) != 0) {
         ctx->last_error = "ndt_eval: the all-reduce callback failed";
         *rc = WM_ERR_STATE;
@@ -935,7 +1063,7 @@ int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *prm, double T_out[16], wm_ndt
     if (ctx->n_src_input == 0 || ctx->n_tgt_input == 0) return WM_ERR_STATE;
     WM_HIP(ctx, hipSetDevice(ctx->device));
     WM_TRY(finalize_clouds(ctx));
-    WM_HIP(ctx, ctx->partials.reserve((size_t) kNdtBlocks * kNdtAcc * sizeof(double)));
+    WM_HIP(ctx, ctx->partials.reserve((size_t) (kNdtBlocks + 256) * kNdtAcc * sizeof(double)));
     if (!ctx->ndt_built || ctx->ndt_res != prm->res) {
         WM_TRY(ndt_build(ctx, prm->res));
         ctx->ndt_model_builds++;
@@ -986,7 +1114,7 @@ int wm_ndt_derivatives(wm_ctx *ctx, const wm_ndt_params *prm, const double pose[
     if (ctx->n_src_input == 0 || ctx->n_tgt_input == 0) return WM_ERR_STATE;
     WM_HIP(ctx, hipSetDevice(ctx->device));
     WM_TRY(finalize_clouds(ctx));
-    WM_HIP(ctx, ctx->partials.reserve((size_t) kNdtBlocks * kNdtAcc * sizeof(double)));
+    WM_HIP(ctx, ctx->partials.reserve((size_t) (kNdtBlocks + 256) * kNdtAcc * sizeof(double)));
     if (!ctx->ndt_built || ctx->ndt_res != prm->res) {
         WM_TRY(ndt_build(ctx, prm->res));
         ctx->ndt_model_builds++;
