@@ -920,21 +920,22 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
     NdtFetch F{nullptr, nullptr, 0u};
     const bool fused_fetch = !(sharded && ctx->ndt_comm) && ctx->tune_ndt_fused_fetch &&
                              (unsigned) nb <= kFetchGroup * kFetchRowsMax;  // (two levels of at most 16 and 64 rows)
-    if (!ctx->h_ndt && hipHostMalloc((void **) &ctx->h_ndt, 64 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+    // (pinned: [0, 64) the sums as k_sum_fetch leaves them; [64, 128) the fused hand-over's 16-byte slots, zeroed once)
+    if (!ctx->h_ndt && (hipHostMalloc((void **) &ctx->h_ndt, 128 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+                        !memset(ctx->h_ndt, 0, 128 * sizeof(double)))) {
         ctx->last_error = "ndt_eval: pinned allocation failed";
         *rc = WM_ERR_HIP;
         return 0;
     }
     if (fused_fetch) {
         if (!ctx->ndt_ticket.p) {
-            memset(ctx->h_ndt, 0, 64 * sizeof(double));
             if (ctx->ndt_ticket.reserve(4096) != hipSuccess || hipMemsetAsync(ctx->ndt_ticket.p, 0, 4096, ctx->stream) != hipSuccess) {
                 *rc = WM_ERR_HIP;
                 return 0;
             }
         }
         if (++ctx->ndt_seq == 0u) ctx->ndt_seq = 1u;
-        F = NdtFetch{ctx->ndt_ticket.as<unsigned>(), ctx->h_ndt, ctx->ndt_seq};
+        F = NdtFetch{ctx->ndt_ticket.as<unsigned>(), ctx->h_ndt + 64, ctx->ndt_seq};
     }
     const auto t_launch0 = std::chrono::steady_clock::now();
     if (ctx->ndt_profile) (void) hipEventRecord(ctx->ev_a, ctx->stream);
@@ -967,7 +968,7 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
             *rc = WM_ERR_HIP;
             return 0;
         }
-    } else if ((fused_fetch ? wait_slots(ctx, ctx->h_ndt, n_acc, F.seq)
+    } else if ((fused_fetch ? wait_slots(ctx, ctx->h_ndt + 64, n_acc, F.seq)
                             : fast_fetch_sum(ctx, ctx->h_ndt, partials, (unsigned) nb, (unsigned) n_acc)) != WM_OK) {
         ctx->last_error = "ndt_eval: HIP error";
         *rc = WM_ERR_HIP;
@@ -984,7 +985,7 @@ static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess
     E.kernel_ms += ms;
     E.evals += 1;
     double a[kNdtAcc] = {0};
-    for (int k = 0; k < n_acc; ++k) a[k] = fused_fetch ? ctx->h_ndt[2 * k] : ctx->h_ndt[k];  // (slots of 16 bytes: the value first)
+    for (int k = 0; k < n_acc; ++k) a[k] = fused_fetch ? ctx->h_ndt[64 + 2 * k] : ctx->h_ndt[k];  // (slots of 16 bytes: the value first)
     if (sharded && !ctx->ndt_comm && ctx->ndt_reduce(a, n_acc, ctx->ndt_reduce_user) != 0) {
         ctx->last_error = "ndt_eval: the all-reduce callback failed";
         *rc = WM_ERR_STATE;
