@@ -77,16 +77,17 @@ def test_ndt_rebuilds_model_when_target_or_res_changes(wm, ctx, oracle, testscan
 
 
 def test_ndt_hash_grid_and_dense_table_agree_bit_for_bit(wm, testscan, oracle):
-    """The dense cell -> voxel table (small lattices) and the open-addressing hash (the fallback
-    for lattices over 32 M cells) are two look-ups of the same voxels in the same neighbour order,
-    so every accumulated double must be identical; the hash path has no other coverage."""
+    """The lattice of float4 cells (the default up to 4 M cells: a cell is its radius test), the dense cell -> voxel
+    table (up to 32 M cells) and the open-addressing hash (the fallback beyond) are three look-ups of the same
+    voxels in the same neighbour order, so every accumulated double must be identical; the table and the hash
+    path have no other coverage."""
     import os
     P = np.eye(4)
     P[0, 3] = 0.2
     target = oracle.transform_cloud_d(testscan, P)
     pose = np.array([0.05, -0.02, 0.01, 0.004, -0.003, 0.006])
     out = {}
-    for mode in ("1", "0"):
+    for mode in ("2", "1", "0"):
         os.environ["WM_TUNE_NDT_DENSE"] = mode
         try:
             c = wm.Context(0)   # the knob is read when a context is created
@@ -96,11 +97,44 @@ def test_ndt_hash_grid_and_dense_table_agree_bit_for_bit(wm, testscan, oracle):
         c.set_target(target)
         out[mode] = (c.ndt_derivatives(pose, res=0.5), c.ndt_align(res=0.5))
     (s1, g1, H1, n1), a1 = out["1"]
+    for other in ("2", "0"):
+        (s0, g0, H0, n0), a0 = out[other]
+        assert n1 == n0 and s1 == s0, other
+        assert np.array_equal(g1, g0) and np.array_equal(H1, H0), other
+        assert a1["rc"] == a0["rc"] == 0 and np.array_equal(a1["T"], a0["T"]), other
+        assert a1["iterations"] == a0["iterations"] and a1["evaluations"] == a0["evaluations"], other
+
+
+def test_ndt_sums_added_inside_the_pass_or_by_a_launch_behind_it(wm, testscan, oracle):
+    """A pass's rows are added by its own last-finishing workgroups and handed to the host as 16-byte slots (the
+    default), or by k_sum_fetch in a launch of its own (WM_TUNE_NDT_FUSED_FETCH=0): the same terms in another
+    order -- derivatives to 1e-12, registrations to 1e-8 m."""
+    import os
+    P = np.eye(4)
+    P[0, 3] = 0.2
+    target = oracle.transform_cloud_d(testscan, P)
+    pose = np.array([0.05, -0.02, 0.01, 0.004, -0.003, 0.006])
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["WM_TUNE_NDT_FUSED_FETCH"] = mode
+        try:
+            c = wm.Context(0)
+        finally:
+            del os.environ["WM_TUNE_NDT_FUSED_FETCH"]
+        c.set_source(testscan)
+        c.set_target(target)
+        first = c.ndt_derivatives(pose, res=0.5)
+        again = c.ndt_derivatives(pose, res=0.5)  # (the tickets were left at zero: the second pass is the first's twin)
+        assert first[0] == again[0] and np.array_equal(first[1], again[1]) and np.array_equal(first[2], again[2])
+        out[mode] = (first, c.ndt_align(res=0.5))
+    (s1, g1, H1, n1), a1 = out["1"]
     (s0, g0, H0, n0), a0 = out["0"]
-    assert n1 == n0 and s1 == s0
-    assert np.array_equal(g1, g0) and np.array_equal(H1, H0)
-    assert a1["rc"] == a0["rc"] == 0 and np.array_equal(a1["T"], a0["T"])
-    assert a1["iterations"] == a0["iterations"]
+    assert n1 == n0 and abs(s1 - s0) <= 1e-12 * abs(s0)
+    np.testing.assert_allclose(g1, g0, rtol=1e-12, atol=1e-12 * np.abs(g0).max())
+    np.testing.assert_allclose(H1, H0, rtol=1e-12, atol=1e-12 * np.abs(H0).max())
+    assert a1["rc"] == a0["rc"] == 0
+    dt, ang = pose_error(a1["T"], a0["T"])
+    assert dt <= 1e-8 and ang <= 1e-8, (dt, ang)
 
 
 def test_ndt_queries_around_and_outside_the_voxel_lattice(wm, oracle):
@@ -127,7 +161,7 @@ def test_ndt_queries_around_and_outside_the_voxel_lattice(wm, oracle):
     oprm = oracle.ndt_params(res=res)
     finite = np.isfinite(src).all(1)
     out = {}
-    for mode in ("1", "0"):
+    for mode in ("2", "1", "0"):
         os.environ["WM_TUNE_NDT_DENSE"] = mode
         try:
             c = wm.Context(0)
@@ -143,8 +177,9 @@ def test_ndt_queries_around_and_outside_the_voxel_lattice(wm, oracle):
             np.testing.assert_allclose(g, og, rtol=1e-8, atol=1e-8 * np.abs(og).max())
             np.testing.assert_allclose(H, oH, rtol=1e-8, atol=1e-8 * np.abs(oH).max())
             out.setdefault(mode, []).append((s, g, H))
-    for (s1, g1, H1), (s0, g0, H0) in zip(out["1"], out["0"]):
-        assert s1 == s0 and np.array_equal(g1, g0) and np.array_equal(H1, H0)
+    for other in ("2", "0"):
+        for (s1, g1, H1), (s0, g0, H0) in zip(out["1"], out[other]):
+            assert s1 == s0 and np.array_equal(g1, g0) and np.array_equal(H1, H0), other
 
 
 @pytest.mark.parametrize("world", [2, 3])
