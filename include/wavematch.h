@@ -523,11 +523,12 @@ int wm_comm_world(const wm_comm *comm);
 /* pcl::IterativeClosestPoint::align (wave_matching/src/icp.cpp:126-129) as ONE registration over
  * all ranks of `comm`.  Collective: every rank calls it with the same two (full) clouds and
  * parameters, on its own context (`mem` = where the clouds live for THIS rank).  Inside the call:
- * equal-count x-slabs of the target from a histogram of a fixed sub-sample (identical on all ranks,
- * no communication), this rank's slab + max_corr halo of the target and its band of the source
- * selected out of the clouds as the caller laid them out (one pass each), the index over them, then
- * per iteration search + local sums -> ncclAllReduce of WM_STATS_LEN doubles -> solve, all enqueued
- * on the context's stream.  Host clouds: with an RCCL communicator rank 0 uploads, the others receive
+ * equal-count x-slabs of the target from a histogram of a fixed sub-sample of 16 384 points (identical on
+ * all ranks, no communication), this rank's slab + max_corr halo of the target and its band of the source
+ * selected out of the clouds as the caller laid them out (one stable compaction of both), the index over
+ * them, then per iteration search + local sums -> exchange of 34 doubles (the ranks' mailboxes inside the
+ * solve kernel, or ncclAllReduce: see wm_comm above) -> solve, all enqueued on the context's stream.  A peer
+ * whose block does not arrive in time fails this rank's call with WM_ERR_RCCL.  Host clouds: with an RCCL communicator rank 0 uploads, the others receive
  * over xGMI (ncclBroadcast).  Every rank returns the same transform and status; `stats` carries the
  * rank's per-phase budget.  A rank that fails with a HIP / RCCL error aborts the communicator (its
  * peers' pending collectives fail instead of waiting for ever); the communicator is finished then.
