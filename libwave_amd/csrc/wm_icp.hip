@@ -739,7 +739,15 @@ int nn_pass(wm_ctx *ctx, const double T[16], float thr_d2, double max_corr, bool
     return WM_OK;
 }
 
-int finalize_clouds(wm_ctx *ctx, double max_corr, int nn_method) {
+int join_source_sort(wm_ctx *ctx) {
+    if (!ctx->sort_join_pending) return WM_OK;
+    ctx->sort_join_pending = false;
+    WM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    return WM_OK;
+}
+
+int finalize_clouds(wm_ctx *ctx, double max_corr, int nn_method, bool sort_aside) {
+    WM_TRY(join_source_sort(ctx));  // (left behind by a call that failed before its own join)
     if (ctx->src_pending || ctx->tgt_pending) {
         // ONE round trip for both clouds' partials (they sit in one device buffer)
         float *res = (float *) pinned_scratch(ctx, 2 * 8 * sizeof(float) * kBboxBlocks);
@@ -782,7 +790,8 @@ int finalize_clouds(wm_ctx *ctx, double max_corr, int nn_method) {
     if (sort_src) ctx->n_src = src_valid;  // (the count of finite points: what the sort will leave in src_sorted)
     hipStream_t main_stream = ctx->stream;
     // the Morton sort of the source is independent of the target's grid build: side stream
-    const bool side = sort_src && ctx->tune_two_streams && ctx->side_stream && tgt_new && max_corr > 0;
+    const bool aside = sort_aside && sort_src && ctx->tune_two_streams && ctx->side_stream != nullptr;
+    const bool side = aside || (sort_src && ctx->tune_two_streams && ctx->side_stream && tgt_new && max_corr > 0);
     if (side) {  // (the sort may start as soon as what is on the main stream NOW -- the packed clouds -- is done)
         WM_HIP(ctx, hipEventRecord(ctx->ev_fork, main_stream));
         WM_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
@@ -798,7 +807,10 @@ int finalize_clouds(wm_ctx *ctx, double max_corr, int nn_method) {
         WM_TRACE(ctx, "source: sorted");
         if (side) {
             WM_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
-            WM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+            if (aside)
+                ctx->sort_join_pending = true;
+            else
+                WM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         }
     }
     return rc;

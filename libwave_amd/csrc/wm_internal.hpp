@@ -289,6 +289,8 @@ struct wm_ctx {
     int ndt_cus = 0;
     int tune_ndt_fused_fetch = 1;  // a pass's last workgroup adds the rows and hands the sums to the host (wm_ndt.hip)
     wm::DevBuf ndt_ticket;
+    wm::DevBuf ndt_perm, ndt_perm2, ndt_flags, ndt_seg, ndt_tmp;  // ndt_build's scratch (its own: see there)
+    bool sort_join_pending = false;  // the source's Morton sort runs on the side stream, ev_join recorded, nobody waits yet
     unsigned ndt_seq = 0;
     int tune_gicp_blocks = 256;  // workgroups (= partial rows) of one GICP objective evaluation (double-double sums: 512 / 256 / 128 / 64 -> 6.9 / 6.4 / 7.3 / 9.6 ms per 500k registration)
     bool ndt_built = false;
@@ -320,7 +322,10 @@ void finish_bbox(const float *partials_host, unsigned blocks, Bbox *out, size_t 
 // Fetch what wm_set_source / wm_set_target left pending (bounding boxes, finite-point counts), then
 // Morton-sort the source on the side stream while -- when max_corr > 0 and the search will use the
 // grid -- the target's level ladder is built on the main stream; both are joined before returning.
-int finalize_clouds(wm_ctx *ctx, double max_corr = -1.0, int nn_method = 0);
+// sort_aside: the source's Morton sort goes to the side stream and the call does NOT wait for it (ctx->sort_join_pending;
+// join_source_sort makes the context's stream wait) -- for a caller with work of its own to enqueue meanwhile
+int finalize_clouds(wm_ctx *ctx, double max_corr = -1.0, int nn_method = 0, bool sort_aside = false);
+int join_source_sort(wm_ctx *ctx);
 int build_grid_level(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, float h,
                      GridLevel *lvl, double *avg_occupancy);
 int morton_sort(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, size_t n_valid,

@@ -687,13 +687,15 @@ static int ndt_build(wm_ctx *ctx, double res) {
     const unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
     WM_HIP(ctx, ctx->ndt_keys.reserve(n * 8));
     WM_HIP(ctx, ctx->ndt_keys2.reserve(n * 8));
-    WM_HIP(ctx, ctx->vg_perm.reserve((n + 1) * 4));  // later: the voxels' head positions (+ end)
-    WM_HIP(ctx, ctx->vg_perm2.reserve(n * 4));
-    WM_HIP(ctx, ctx->vg_idx.reserve(n * 4));
-    WM_HIP(ctx, ctx->vg_seg.reserve((n + 1) * 4));
+    // (scratch of its own, not the voxel filter's / the Morton sort's vg_*: the source's sort may be running on the
+    // side stream while this model is built, wm_ndt_align)
+    WM_HIP(ctx, ctx->ndt_perm.reserve((n + 1) * 4));  // later: the voxels' head positions (+ end)
+    WM_HIP(ctx, ctx->ndt_perm2.reserve(n * 4));
+    WM_HIP(ctx, ctx->ndt_flags.reserve(n * 4));
+    WM_HIP(ctx, ctx->ndt_seg.reserve((n + 1) * 4));
     unsigned long long *k1 = ctx->ndt_keys.as<unsigned long long>(), *k2 = ctx->ndt_keys2.as<unsigned long long>();
-    unsigned *p1 = ctx->vg_perm.as<unsigned>(), *p2 = ctx->vg_perm2.as<unsigned>();
-    unsigned *flags = ctx->vg_idx.as<unsigned>(), *seg = ctx->vg_seg.as<unsigned>();
+    unsigned *p1 = ctx->ndt_perm.as<unsigned>(), *p2 = ctx->ndt_perm2.as<unsigned>();
+    unsigned *flags = ctx->ndt_flags.as<unsigned>(), *seg = ctx->ndt_seg.as<unsigned>();
     // the lattice of voxels over the target's bounding box (cell numbers from the same float
     // product as the keys)
     NdtLattice L{};
@@ -721,8 +723,8 @@ static int ndt_build(wm_ctx *ctx, double res) {
     size_t tmp = 0;
     WM_HIP(ctx, sort_pairs_low_bits(nullptr, tmp, k1, k2, p1, p2, n, key_bits, ctx->stream,
                                     (size_t) ctx->tune_radix_min));
-    WM_HIP(ctx, ctx->vg_tmp.reserve(tmp));
-    WM_HIP(ctx, sort_pairs_low_bits(ctx->vg_tmp.p, tmp, k1, k2, p1, p2, n, key_bits, ctx->stream,
+    WM_HIP(ctx, ctx->ndt_tmp.reserve(tmp));
+    WM_HIP(ctx, sort_pairs_low_bits(ctx->ndt_tmp.p, tmp, k1, k2, p1, p2, n, key_bits, ctx->stream,
                                     (size_t) ctx->tune_radix_min));
     hipLaunchKernelGGL(k_ndt_flags, dim3(blocks), dim3(kBlock), 0, ctx->stream, k2, (unsigned) n, L.cells,
                        flags);
@@ -1063,12 +1065,17 @@ int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *prm, double T_out[16], wm_ndt
     if (stats) memset(stats, 0, sizeof(*stats));
     if (ctx->n_src_input == 0 || ctx->n_tgt_input == 0) return WM_ERR_STATE;
     WM_HIP(ctx, hipSetDevice(ctx->device));
-    WM_TRY(finalize_clouds(ctx));
+    // a new source's Morton sort and a new target's voxel model are independent chains of small launches (230 + 410 us
+    // at 2M points, one behind the other on one stream in rounds 1-4): the sort goes to the side stream, the model is
+    // built on this one meanwhile, and the passes wait for both
+    const bool will_build = !ctx->ndt_built || ctx->ndt_res != prm->res;
+    WM_TRY(finalize_clouds(ctx, -1.0, 0, will_build));
     WM_HIP(ctx, ctx->partials.reserve((size_t) (kNdtBlocks + 256) * kNdtAcc * sizeof(double)));
     if (!ctx->ndt_built || ctx->ndt_res != prm->res) {
         WM_TRY(ndt_build(ctx, prm->res));
         ctx->ndt_model_builds++;
     }
+    WM_TRY(join_source_sort(ctx));
     NdtEval E;
     E.ctx = ctx;
     E.prm = prm;
