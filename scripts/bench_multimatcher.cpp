@@ -92,9 +92,13 @@ int run_pool(const char *name, const P &params, int n, int pairs, int argc, char
         const auto t0 = std::chrono::steady_clock::now();
         const int ok = drain(pairs);
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        int launches = 0;
+        for (int b : pool.batchesPerSlot()) launches += b;
         std::printf("{\"bench\": \"wave::MultiMatcher<%s>\", \"points\": %d, \"workers\": %d, \"queue\": %d, \"pairs\": %d, "
-                    "\"seconds\": %.4f, \"registrations_per_s\": %.1f, \"recovered_shift\": %d, \"mean_shift_x\": %.4f}\n",
-                    name, n, pool.workers(), queue, pairs, s, pairs / s, ok, shift_sum / pairs);
+                    "\"seconds\": %.4f, \"registrations_per_s\": %.1f, \"recovered_shift\": %d, \"mean_shift_x\": %.4f, "
+                    "\"batches\": %d, \"pairs_per_batch\": %.1f}\n",
+                    name, n, pool.workers(), queue, pairs, s, pairs / s, ok, shift_sum / pairs, launches,
+                    launches ? (double) (pairs + std::max(2 * workers, std::min(queue, pairs))) / launches : 0.0);
         std::fflush(stdout);
     }
     return 0;
