@@ -65,6 +65,28 @@ def parse():
     return ap.parse_args()
 
 
+def first_step_with_fallback(step, rebuild, all_ranks_ok, error_type):
+    """The first sharded registration of a run, on every rank: if it fails on ANY rank (`all_ranks_ok` is a collective
+    AND over the ranks), every rank calls `rebuild` (collective) and the registration is tried once more; a second
+    failure is raised.  Returns True when the fallback was taken."""
+    err = None
+    try:
+        step()
+    except error_type as e:
+        err = e
+    if all_ranks_ok(err is None):
+        return False
+    rebuild()
+    err2 = None
+    try:
+        step()
+    except error_type as e:
+        err2 = e
+    if not all_ranks_ok(err2 is None):
+        raise RuntimeError("sharded registration failed with the collective exchange too: %s (first: %s)" % (err2, err))
+    return True
+
+
 def usable_cpus():
     """CPUs this process may really use: the affinity mask, cut by the container's CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -779,6 +801,7 @@ def main():
     comm = None
     torch.cuda.synchronize()
 
+    exchange_fallback = False
     if dist is None:
         def step(profile, r_=d_ref, t_=d_tgt):
             ctx.set_source(r_)
@@ -787,14 +810,39 @@ def main():
                                  nn_method=capi.WM_NN_GRID, profile=profile, carry_state=0)
         parallelism = "single"
     else:
-        # the RCCL id: made by rank 0, handed to every rank (the one thing torch.distributed carries)
-        uid = [capi.Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        comm = capi.Comm.init_rank(local_rank, uid[0], rank, world)
+        def make_comm():
+            # the RCCL id: made by rank 0, handed to every rank (the one thing torch.distributed carries)
+            uid = [capi.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            return capi.Comm.init_rank(local_rank, uid[0], rank, world)
+
+        def all_ranks_ok(ok):
+            t = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+        box = {"ctx": ctx, "comm": make_comm()}
+
+        def one(profile):
+            return box["ctx"].icp_align_sharded(box["comm"], d_ref, d_tgt, max_corr=a.max_corr, force_iterations=a.iters,
+                                                nn_method=capi.WM_NN_GRID, profile=profile, carry_state=0)
+
+        def rebuild_collective():
+            # (the exchange through the ranks' mailboxes has never run over xGMI in the builder's container: if the
+            # very first registration fails on ANY rank, every rank drops its communicator and context and starts
+            # over with the collective exchange -- ncclAllReduce between a rank's sums and its solve)
+            os.environ["WM_COMM_P2P"] = "0"
+            for k in ("comm", "ctx"):
+                try:
+                    box[k].close()
+                except Exception:
+                    pass
+            box["ctx"] = capi.Context(local_rank)
+            box["comm"] = make_comm()
+        exchange_fallback = first_step_with_fallback(lambda: one(1), rebuild_collective, all_ranks_ok, capi.WmError)
+        ctx, comm = box["ctx"], box["comm"]
 
         def step(profile):
-            return ctx.icp_align_sharded(comm, d_ref, d_tgt, max_corr=a.max_corr, force_iterations=a.iters,
-                                         nn_method=capi.WM_NN_GRID, profile=profile, carry_state=0)
+            return one(profile)
         parallelism = ("target x-slabs x%d + one exchange of 34 f64 per iteration inside the library (mailboxes over "
                        "xGMI inside the solve kernel; ncclAllReduce where they cannot be set up)" % world)
 
@@ -846,6 +894,8 @@ def main():
         peak_copy = ctx.copy_bandwidth() if world == 1 else None
         out = assemble_line(a, world, r, T_gt, elapsed, step_ms, nn_ms, nn_launches, cert_ms, cert_launches, parallelism,
                             pmc=pmc, peak_copy=peak_copy, sharded=comm is not None, ar_us=ar_us)
+        if comm is not None:
+            out["config"]["sharding"]["exchange_fell_back_to_collective"] = bool(exchange_fallback)
         value = out["value"]
         if world == 1 and dist is None:
             # the same registration from HOST clouds: H2D of both clouds inside the step

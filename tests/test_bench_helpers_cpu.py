@@ -3,6 +3,8 @@ kernels the line quotes, and the helper turns them into bytes per launch and a s
 import os
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -120,3 +122,46 @@ def test_multi_gpu_bench_line_assembles_from_the_sharded_result_keys():
     one = bench.assemble_line(a, 1, capi.Context._stats_dict(0, np.eye(4), st), np.eye(4), 0.075, [3.75] * 20, 3.1, 50, 0.7, 25,
                               "single", pmc={}, peak_copy=5800.0)
     assert "sharding" not in one["config"] and one["n_gpus"] == 1 and json.dumps(one)
+
+
+def test_first_sharded_step_falls_back_once_and_only_together():
+    """bench.py --gpus N: the first sharded registration decides, for all ranks alike, whether the run keeps the
+    mailbox exchange; a failure anywhere rebuilds everywhere, a second failure is an error."""
+    import bench
+
+    class Boom(RuntimeError):
+        pass
+    calls = {"step": 0, "rebuild": 0, "votes": []}
+
+    def votes(ok):  # (one rank here: the AND over the ranks is its own vote; a peer's failure is injected below)
+        calls["votes"].append(ok)
+        return ok
+
+    def good():
+        calls["step"] += 1
+    assert bench.first_step_with_fallback(good, lambda: calls.__setitem__("rebuild", calls["rebuild"] + 1), votes, Boom) is False
+    assert calls == {"step": 1, "rebuild": 0, "votes": [True]}
+
+    # this rank succeeds, a peer does not: this rank rebuilds too and registers again
+    calls.update(step=0, rebuild=0, votes=[])
+    peer = iter([False, True])
+    assert bench.first_step_with_fallback(good, lambda: calls.__setitem__("rebuild", calls["rebuild"] + 1),
+                                          lambda ok: votes(ok) and next(peer), Boom) is True
+    assert calls["step"] == 2 and calls["rebuild"] == 1
+
+    # this rank fails once (the mailbox exchange timed out), then the collective exchange works
+    state = {"n": 0}
+
+    def flaky():
+        state["n"] += 1
+        if state["n"] == 1:
+            raise Boom("a peer's block did not arrive")
+    calls.update(step=0, rebuild=0, votes=[])
+    assert bench.first_step_with_fallback(flaky, lambda: calls.__setitem__("rebuild", calls["rebuild"] + 1), votes, Boom) is True
+    assert calls["rebuild"] == 1 and calls["votes"] == [False, True]
+
+    # failing twice is fatal
+    def bad():
+        raise Boom("no")
+    with pytest.raises(RuntimeError):
+        bench.first_step_with_fallback(bad, lambda: None, votes, Boom)
