@@ -859,7 +859,7 @@ class Multi:
                  n_corr=s.n_corr, mse=s.mse, align_ms=s.align_ms, owned_violations=s.owned_violations,
                  cert_launches=s.cert_launches)
         for k in ("plan_ms", "compact_ms", "index_ms", "iter_ms", "allreduce_ms", "n_tgt_local", "n_src_local",
-                  "rccl_ranks", "shard_attempts"):
+                  "rccl_ranks", "shard_attempts", "exchange_in_kernel"):
             d[k] = getattr(s, k)   # (rank 0's)
         return d
 

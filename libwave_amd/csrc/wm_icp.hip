@@ -1421,6 +1421,7 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
     WM_HIP(ctx, hipEventSynchronize(ctx->ev_b));
     const IcpDevState &s = *ctx->h_state;
     if (s.xchg_failed) {
+        ctx->xchg_timed_out = true;
         ctx->last_error = "sharded registration: a rank's block did not arrive in this rank's mailbox in time "
                           "(a peer failed or fell behind by more than the exchange's time limit)";
         return WM_ERR_RCCL;

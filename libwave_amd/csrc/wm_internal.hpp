@@ -290,6 +290,7 @@ struct wm_ctx {
     int tune_ndt_fused_fetch = 1;  // a pass's last workgroup adds the rows and hands the sums to the host (wm_ndt.hip)
     wm::DevBuf ndt_ticket;
     wm::DevBuf ndt_perm, ndt_perm2, ndt_flags, ndt_seg, ndt_tmp;  // ndt_build's scratch (its own: see there)
+    bool xchg_timed_out = false;  // the last sharded loop ended because a peer's block did not arrive (wm_shard.hip)
     bool sort_join_pending = false;  // the source's Morton sort runs on the side stream, ev_join recorded, nobody waits yet
     unsigned ndt_seq = 0;
     int tune_gicp_blocks = 256;  // workgroups (= partial rows) of one GICP objective evaluation (double-double sums: 512 / 256 / 128 / 64 -> 6.9 / 6.4 / 7.3 / 9.6 ms per 500k registration)

@@ -91,7 +91,7 @@ static int mailbox_alloc(wm_comm *c) {
     c->mail = static_cast<unsigned long long *>(p);
     if (const char *e = getenv("WM_COMM_P2P_TIMEOUT_MS")) {
         const int v = atoi(e);
-        if (v > 0) c->p2p_timeout_ms = (unsigned) v;
+        if (v >= 0) c->p2p_timeout_ms = (unsigned) v;  // (0: a block that is not there within 64 looks is "late" -- tests)
     }
     return WM_OK;
 }
@@ -986,6 +986,14 @@ int wm_icp_align_sharded(wm_ctx *ctx, wm_comm *comm, const void *ref, size_t n_r
     // would leave its peers waiting in ncclAllReduce for ever: abort the communicator, which fails the
     // peers' pending collectives too.  The communicator is finished after that; argument errors are
     // returned before anything collective has started and abort nothing.
+    if (ctx && ctx->xchg_timed_out) {
+        // ... except when what failed is the exchange through the mailboxes (a peer's block did not arrive): the
+        // communicator itself is intact, and this rank stops using its mailboxes -- its next registration exchanges
+        // by ncclAllReduce (all ranks of a group whose exchange failed time out alike; wm_multi_icp_match retries)
+        ctx->xchg_timed_out = false;
+        if (comm) comm->p2p = false;
+        return rc;
+    }
     if ((rc == WM_ERR_HIP || rc == WM_ERR_RCCL || rc == WM_ERR_NOMEM) && comm && comm->nccl && comm->world > 1) {
         (void) ncclCommAbort(comm->nccl);
         comm->nccl = nullptr;
@@ -1108,6 +1116,7 @@ int wm_multi_icp_match(wm_multi *m, const void *ref, size_t n_ref, const void *t
     std::vector<int> rcs((size_t) n, WM_ERR_STATE);
     std::vector<wm_icp_stats> sts((size_t) n);
     std::vector<double> Ts((size_t) n * 16, 0.0);
+    auto run_all = [&]() -> int {
     std::vector<std::thread> th;
     for (int r = 0; r < n; ++r)
         th.emplace_back([&, r] {
@@ -1116,6 +1125,23 @@ int wm_multi_icp_match(wm_multi *m, const void *ref, size_t n_ref, const void *t
                                                    &sts[(size_t) r]);
         });
     for (auto &t : th) t.join();
+    return WM_OK;
+    };
+    bool had_mailboxes = false;
+    for (int r = 0; r < n; ++r) had_mailboxes = had_mailboxes || (m->comm[(size_t) r] && m->comm[(size_t) r]->p2p);
+    run_all();
+    bool rccl_error = false;
+    for (int r = 0; r < n; ++r) rccl_error = rccl_error || rcs[(size_t) r] == WM_ERR_RCCL;
+    if (rccl_error && had_mailboxes) {
+        // the exchange through the mailboxes failed somewhere (it has never run over xGMI in the builder's container):
+        // every rank of this group goes back to the collective exchange, and the registration is run once more
+        bool usable = true;
+        for (int r = 0; r < n; ++r) {
+            if (m->comm[(size_t) r]) m->comm[(size_t) r]->p2p = false;
+            usable = usable && m->comm[(size_t) r] && (m->comm[(size_t) r]->nccl || m->comm[(size_t) r]->local);
+        }
+        if (usable) run_all();
+    }
     for (int r = 0; r < n; ++r)
         if (rcs[(size_t) r] < 0) return rcs[(size_t) r];
     if (stats) *stats = sts[0];

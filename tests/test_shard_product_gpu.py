@@ -180,6 +180,40 @@ def test_two_ranks_exchange_through_mailboxes():
     assert out.returncode == 0 and "MAILBOX PAIR OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
 
 
+_MAILBOX_FALLBACK = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+os.environ["WM_COMM_P2P_LOCAL"] = "1"
+os.environ["WM_COMM_P2P_TIMEOUT_MS"] = "0"   # a peer's block that is not there at once counts as never coming
+from libwave_amd import capi as wm, synth
+ref, tgt, _ = synth.pair(40000, seed=17)
+c = wm.Context(0); c.set_source(ref); c.set_target(tgt)
+want = c.icp_align(max_corr=3.0, force_iterations=15, nn_method=wm.WM_NN_GRID); c.close()
+m = wm.Multi([0, 0, 0], emulate=True)   # fresh contexts: on ONE GPU their first-call allocations stall the mailbox exchange
+got = m.icp_align(ref, tgt, max_corr=3.0, force_iterations=15, nn_method=wm.WM_NN_GRID)
+again = m.icp_align(ref, tgt, max_corr=3.0, force_iterations=15, nn_method=wm.WM_NN_GRID)
+m.close()
+assert got["rc"] == 0 and again["rc"] == 0, (got["rc"], again["rc"])
+assert np.abs(got["T"] - want["T"]).max() <= 1e-9 and np.array_equal(got["T"], again["T"])
+assert got["exchange_in_kernel"] == 0 and again["exchange_in_kernel"] == 0   # (the mailboxes were dropped for good)
+print("FALLBACK OK")
+"""
+
+
+def test_multi_goes_back_to_the_collective_exchange_when_the_mailboxes_fail():
+    """wm_multi_icp_match: a mailbox exchange that fails (here: three ranks on one GPU and a time limit of zero -- a
+    peer's block that is not in the mailbox at once counts as never coming) does not fail the registration: every rank drops its mailboxes, the communicators stay, and the
+    registration is run once more with the group's other exchange -- the unsharded result either way."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    out = subprocess.run([sys.executable, "-c", _MAILBOX_FALLBACK, root], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "FALLBACK OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
 def test_icp_8m_in_8_slabs_full_registration(wm):
     """BASELINE configs[4]: ICP 8M<->8M as ONE registration in 8 slabs, all 50 iterations, equal to
     the unsharded registration of the same pair."""
