@@ -496,7 +496,10 @@ int wm_ndt_set_shard(wm_ctx *ctx, int rank, int world, wm_allreduce_fn reduce, v
  * between a rank's sums and its solve).  A probe exchange at creation and an all-reduced verdict decide, alike
  * on every rank, whether they are used; otherwise, and with WM_COMM_P2P=0, the step is an RCCL all-reduce on the
  * calling context's stream.  A peer whose block does not arrive within WM_COMM_P2P_TIMEOUT_MS (default 5000)
- * fails the registration with WM_ERR_RCCL instead of hanging.  wm_icp_stats.exchange_in_kernel says which ran.
+ * fails the registration with WM_ERR_RCCL instead of hanging -- and that rank's communicator then goes back to the
+ * collective exchange for good (wm_multi_* run the failed registration once more by themselves; bench.py --gpus N
+ * rebuilds its communicators without mailboxes if its first registration fails on any rank).
+ * wm_icp_stats.exchange_in_kernel says which exchange ran.
  * No reference counterpart: libwave's only parallelism is one matcher per thread
  * (wave_matching/include/wave/matching/multi_matcher.hpp:32).
  *   wm_comm_get_unique_id + wm_comm_init_rank   one rank per process (or thread): rank 0 creates the
