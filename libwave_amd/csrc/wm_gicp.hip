@@ -618,7 +618,8 @@ static void serve_begin(GicpFn &F) {
     }
     int nb = gicp_blocks(ctx);
     if (nb > ctx->gicp_serve_capacity) return;  // every workgroup has to be resident at once
-    if (!ctx->h_gicp && hipHostMalloc((void **) &ctx->h_gicp, sizeof(double) * 64, hipHostMallocDefault) != hipSuccess) return;
+    // (128 doubles wherever it is allocated: the statistics objective fetches 74 into it)
+    if (!ctx->h_gicp && hipHostMalloc((void **) &ctx->h_gicp, sizeof(double) * 128, hipHostMallocDefault) != hipSuccess) return;
     if (!ctx->h_gicp_slots) {
         if (hipHostMalloc((void **) &ctx->h_gicp_slots, sizeof(GicpSlot) * 16, hipHostMallocDefault) != hipSuccess) return;
         memset(ctx->h_gicp_slots, 0, sizeof(GicpSlot) * 16);

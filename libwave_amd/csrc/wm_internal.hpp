@@ -341,6 +341,9 @@ int fast_fetch_sum(wm_ctx *ctx, double *dst_pinned, const double *src_dev, unsig
 // flag's address and the sequence number to write); waits for it
 int fast_fetch_begin(wm_ctx *ctx, unsigned **flag, unsigned *seq);
 int fast_fetch_wait(wm_ctx *ctx, unsigned seq);
+// results that a kernel hands over as 16-byte slots {double value, unsigned number, 0} in pinned memory, one store each
+// (no flag behind the data, hence no system-scope fence): wait until all n slots carry `seq`
+int wait_slots(wm_ctx *ctx, const double *slots, int n, unsigned seq);
 template <class Launch>
 inline int fast_fetch_custom(wm_ctx *ctx, Launch launch) {
     unsigned *flag = nullptr, seq = 0;

@@ -838,38 +838,6 @@ struct NdtEval {
     void note_line_search(int trials) { ls_hist[trials < 11 ? trials : 11]++; }
 };
 
-// wait until the n 16-byte slots {value, number} at `slots` (pinned memory) all carry `seq` (wait_flag's three stages:
-// spin, poll with yields, and after 4 ms let the runtime block -- which is also what reports a failed kernel)
-static int wait_slots(wm_ctx *ctx, const double *slots, int n, unsigned seq) {
-    const volatile unsigned *w = reinterpret_cast<const volatile unsigned *>(slots);
-    auto all_there = [&]() {
-        for (int k = n - 1; k >= 0; --k)
-            if (w[4 * k + 2] != seq) return false;
-        return true;
-    };
-    const auto t0 = std::chrono::steady_clock::now();
-    bool yielding = false;
-    for (unsigned spins = 1; !all_there(); ++spins) {
-        if (yielding)
-            std::this_thread::yield();
-        else
-            cpu_relax();
-        if ((spins & 63u) == 0 || yielding) {
-            const auto waited = std::chrono::steady_clock::now() - t0;
-            if (waited > std::chrono::milliseconds(4)) {
-                WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                if (!all_there()) {
-                    ctx->last_error = "ndt_eval: the pass ended without delivering its sums";
-                    return WM_ERR_HIP;
-                }
-                break;
-            }
-            yielding = waited > std::chrono::microseconds(ctx->tune_spin_us);
-        }
-    }
-    return WM_OK;
-}
-
 // score (+ gradient, + Hessian) at pose p; returns <0 on HIP error via *rc
 static double ndt_eval(NdtEval &E, const double p[6], double *grad, double *hess, int *rc) {
     wm_ctx *ctx = E.ctx;

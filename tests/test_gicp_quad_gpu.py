@@ -111,3 +111,26 @@ def test_both_objectives_against_the_independent_fixed_point(wm, ctx, testscan):
               % (name, da, ra, db, rb))
         assert da <= bar[0] and ra <= bar[1] and db <= bar[0] and rb <= bar[1]
         assert da <= db + 2e-5
+
+
+def test_one_context_alternating_between_the_objectives(wm):
+    """A context that ran PCL's per-pair objective first (its resident evaluator allocates the pinned answer buffer)
+    and then the statistics objective (which fetches 74 sums into the same buffer), and back: each result is the one
+    a fresh context gives for that objective."""
+    ref, tgt, _ = synth.pair(20000, seed=5, mode="resample")
+    fresh = {}
+    for obj in (wm.WM_GICP_OBJECTIVE_PCL_SUMS, wm.WM_GICP_OBJECTIVE_STATISTICS):
+        c = wm.Context(0)
+        c.set_source(ref)
+        c.set_target(tgt)
+        fresh[obj] = c.gicp_align(objective=obj)
+        c.close()
+    c = wm.Context(0)
+    c.set_source(ref)
+    c.set_target(tgt)
+    for obj in (wm.WM_GICP_OBJECTIVE_PCL_SUMS, wm.WM_GICP_OBJECTIVE_STATISTICS, wm.WM_GICP_OBJECTIVE_PCL_SUMS,
+                wm.WM_GICP_OBJECTIVE_STATISTICS):
+        got = c.gicp_align(objective=obj)
+        assert got["rc"] == fresh[obj]["rc"] == 0
+        assert np.array_equal(got["T"], fresh[obj]["T"]) and got["iterations"] == fresh[obj]["iterations"]
+    c.close()
