@@ -51,6 +51,16 @@ class GICPMatcher : public Matcher<PCLPointCloudPtr> {
     void setTarget(const PCLPointCloudPtr &target);
     bool match();  // blocks until the registration is done; true when it converged
 
+    // NOT in the reference: how the BFGS minimisations' objective is evaluated.  PclSums (the default) is the
+    // reference's algorithm -- PCL's OptimizationFunctorWithIndices summed pair by pair through the float transform at
+    // every trial point.  Statistics forms the same objective once per outer iteration as 74 sufficient statistics
+    // (2.4x faster at 500k points); its result is NOT PCL's bit for bit: 0 .. 3e-5 m apart on pairs that register
+    // sharply, up to 1e-3 m on noisy pairs (the spread PCL's own result has against its summation order).  A matcher
+    // that was never told takes env WAVE_GICP_OBJECTIVE=statistics, else PclSums.
+    enum class Objective { PclSums, Statistics };
+    void setObjective(Objective o);
+    Objective getObjective() const;
+
     // Many pairs in ONE device launch (wm_gicp_batch_match: one registration per compute unit, the whole of
     // align inside the kernel) -- what wave::MultiMatcher<GICPMatcher> hands its workers when several pairs are
     // queued.  out[k] = {match() result, getResult(), getInfo()} as the worker loop would have read them after
@@ -74,6 +84,7 @@ class GICPMatcher : public Matcher<PCLPointCloudPtr> {
     PCLPointCloudPtr ref, target;
     GICPMatcherParams params;
     bool ref_on_device, target_on_device;  // res > 0: the filtered snapshot already sits in the context
+    int objective;                         // wm_gicp_params::objective, or -1: not told (environment, else PCL's)
     bool ensureContext();
 };
 

@@ -329,8 +329,11 @@ typedef struct {
     int objective;        /* how estimateRigidTransformationBFGS's objective is evaluated: WM_GICP_OBJECTIVE_* below */
     int reserved;
 } wm_gicp_params;
-/* WM_GICP_OBJECTIVE_STATISTICS (0, the default): between two correspondence searches the pairs and their Mahalanobis
- * matrices are fixed and the residual is affine in the transform's entries, so the objective PCL sums pair by pair at
+/* WM_GICP_OBJECTIVE_PCL_SUMS (0, the default -- what the reference runs, wave_matching/src/gicp.cpp:58): PCL's per-pair
+ * float path (OptimizationFunctorWithIndices::fdf summed pair by pair at every trial point), bit for bit the oracle's
+ * default mode (oracle/gicp.c, objective mode 0).
+ * WM_GICP_OBJECTIVE_STATISTICS (1, an explicit opt-in: NOT PCL's arithmetic): between two correspondence searches the
+ * pairs and their Mahalanobis matrices are fixed and the residual is affine in the transform's entries, so the objective PCL sums pair by pair at
  * every trial point of the line search (OptimizationFunctorWithIndices::fdf, ~170 passes over the pairs per
  * registration) is formed ONCE per outer iteration as 74 sufficient statistics around the pairing transform; every
  * evaluation is then scalar work (libwave_amd/csrc/wm_gicp_quad.hpp).  The statistics' base point is PCL's float
@@ -338,11 +341,12 @@ typedef struct {
  * BFGS stops at a gradient tolerance of 1e-2 wherever its line search lands, so registrations of noisy pairs end
  * 1e-5 .. 1e-3 m apart between the two objectives -- the spread PCL's own result has against its summation order --
  * and pairs that register sharply (the reference's test cases) within 1e-4 m / 1e-5 rad; neither is systematically
- * closer to ground truth (tests/test_gicp_quad_gpu.py, tests/test_oracle_cpu.py).  Bit for bit the same as the
- * oracle's restatement of this objective (oracle/gicp.c, objective mode 1), on the one-pair and the batched path.
- * WM_GICP_OBJECTIVE_PCL_SUMS (1): PCL's per-pair float path, bit for bit the oracle's default mode. */
-#define WM_GICP_OBJECTIVE_STATISTICS 0
-#define WM_GICP_OBJECTIVE_PCL_SUMS 1
+ * closer to ground truth (tests/test_gicp_quad_gpu.py, tests/test_oracle_cpu.py).  That spread is ABOVE north_star's
+ * 1e-4 m on noisy pairs, which is why this form is not the default.  Held bit for bit to the oracle's restatement of the
+ * builder's reformulation (oracle/gicp.c, objective mode 1 -- a restatement check, not reference parity), on the
+ * one-pair and the batched path.  The numbers equal the oracle's objective modes. */
+#define WM_GICP_OBJECTIVE_PCL_SUMS 0
+#define WM_GICP_OBJECTIVE_STATISTICS 1
 
 typedef struct {
     int converged, iterations, n_corr, inner_total, evaluations;

@@ -65,8 +65,8 @@ class GicpParams(C.Structure):
                 ("max_inner", C.c_int), ("force_iterations", C.c_int), ("objective", C.c_int), ("reserved", C.c_int)]
 
 
-WM_GICP_OBJECTIVE_STATISTICS = 0   # the default: 74 sufficient statistics per outer iteration (csrc/wm_gicp_quad.hpp)
-WM_GICP_OBJECTIVE_PCL_SUMS = 1     # PCL's per-pair sums through the float transform
+WM_GICP_OBJECTIVE_PCL_SUMS = 0     # the default (the reference's algorithm): PCL's per-pair sums through the float transform
+WM_GICP_OBJECTIVE_STATISTICS = 1   # opt-in: 74 sufficient statistics per outer iteration (csrc/wm_gicp_quad.hpp)
 
 
 class GicpStats(C.Structure):

@@ -8,7 +8,7 @@
 //   k_gicp_mahal  M_i = (C2_j + R C1_i R^T)^-1 for every matched pair
 //   k_gicp_fdf    OptimizationFunctorWithIndices::fdf: f, sum M r (3), sum p (M r)^T (9)
 //                 -> 13 doubles per evaluation; the only thing the optimiser sees
-//   k_gicp_quad   (the default, wm_gicp_params::objective = WM_GICP_OBJECTIVE_STATISTICS) the same objective as 74
+//   k_gicp_quad   (opt-in, wm_gicp_params::objective = WM_GICP_OBJECTIVE_STATISTICS) the same objective as 74
 //                 sufficient statistics of the pairs, formed ONCE per outer iteration: the ~40 evaluations of a
 //                 minimisation are then scalar work on the host, no pass over the pairs (wm_gicp_quad.hpp);
 //                 k_gicp_mahal / k_gicp_fdf / the resident evaluator serve WM_GICP_OBJECTIVE_PCL_SUMS
@@ -1003,6 +1003,7 @@ int wm_gicp_covariances(wm_ctx *ctx, int k, double eps, double *cov_source, doub
 int wm_gicp_align(wm_ctx *ctx, const wm_gicp_params *prm, double T_out[16], wm_gicp_stats *stats) {
     if (!ctx || !prm || !T_out || prm->corr_rand < 1 || prm->corr_rand > 32 || !(prm->max_corr > 0))
         return WM_ERR_ARG;
+    if (prm->objective != WM_GICP_OBJECTIVE_PCL_SUMS && prm->objective != WM_GICP_OBJECTIVE_STATISTICS) return WM_ERR_ARG;
     if (stats) memset(stats, 0, sizeof(*stats));
     if (ctx->n_src_input == 0 || ctx->n_tgt_input == 0) return WM_ERR_STATE;
     WM_HIP(ctx, hipSetDevice(ctx->device));

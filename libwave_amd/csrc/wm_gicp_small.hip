@@ -913,6 +913,7 @@ int wm_gicp_batch_match(wm_ctx *ctx, const wm_batch_item *items, int n_items, si
                         float res, double *T_out, wm_gicp_stats *stats, int *status, float *kernel_ms) {
     if (!ctx || !p || !status || n_items < 0 || (n_items > 0 && !items) || stride < 12 || (stride & 3)) return WM_ERR_ARG;
     if (p->corr_rand < 1 || p->corr_rand > 32 || !(p->max_corr > 0)) return WM_ERR_ARG;
+    if (p->objective != WM_GICP_OBJECTIVE_PCL_SUMS && p->objective != WM_GICP_OBJECTIVE_STATISTICS) return WM_ERR_ARG;
     if (p->force_iterations <= 0 && p->max_iter <= 0) return WM_ERR_ARG;
     if (kernel_ms) *kernel_ms = 0;
     if (n_items == 0) return WM_OK;

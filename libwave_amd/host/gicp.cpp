@@ -25,7 +25,7 @@ void GICPMatcher::setThreadDevice(int device) { shim::setThreadDevice(device); }
 
 GICPMatcher::GICPMatcher(GICPMatcherParams params1)
     : ctx(nullptr), device(shim::defaultDevice()), ref(shim::emptyCloud()), target(shim::emptyCloud()),
-      params(params1), ref_on_device(false), target_on_device(false) {
+      params(params1), ref_on_device(false), target_on_device(false), objective(-1) {
     resolution = params.res > 0 ? params.res : -1.0f;
 }
 
@@ -33,7 +33,7 @@ GICPMatcher::GICPMatcher(GICPMatcherParams params1)
 // original's context is re-made from the handle the next time the copy matches).
 GICPMatcher::GICPMatcher(const GICPMatcher &o)
     : Matcher<PCLPointCloudPtr>(o), ctx(nullptr), device(o.device), ref(o.ref), target(o.target),
-      params(o.params), ref_on_device(false), target_on_device(false) {}
+      params(o.params), ref_on_device(false), target_on_device(false), objective(o.objective) {}
 
 GICPMatcher &GICPMatcher::operator=(const GICPMatcher &o) {
     if (this == &o) return *this;
@@ -43,6 +43,7 @@ GICPMatcher &GICPMatcher::operator=(const GICPMatcher &o) {
     ref = o.ref;
     target = o.target;
     params = o.params;
+    objective = o.objective;
     ref_on_device = target_on_device = false;
     return *this;
 }
@@ -71,22 +72,33 @@ void GICPMatcher::setTarget(const PCLPointCloudPtr &cloud) {
 
 namespace {
 // how the minimisations' objective is evaluated (include/wavematch.h: wm_gicp_params::objective).  The default is the
-// library's: 74 sufficient statistics per outer iteration; env WAVE_GICP_OBJECTIVE=pcl_sums selects PCL's per-pair
-// sums through the float transform (slower: ~170 passes over the pairs per registration).
-int gicpObjective() {
+// REFERENCE's: PCL's per-pair sums through the float transform (gicp.cpp:58 -> pcl::GeneralizedIterativeClosestPoint).
+// The 74-sufficient-statistics form (2.4x faster at 500k points, not PCL's arithmetic: its registrations of noisy
+// pairs end up to 1e-3 m from PCL's) is an explicit opt-in: GICPMatcher::setObjective(GICPMatcher::Objective::
+// Statistics) on the matcher, or env WAVE_GICP_OBJECTIVE=statistics for matchers that were not told.
+int envObjective() {
     static const int v = [] {
         const char *e = std::getenv("WAVE_GICP_OBJECTIVE");
-        return e && std::string(e) == "pcl_sums" ? WM_GICP_OBJECTIVE_PCL_SUMS : WM_GICP_OBJECTIVE_STATISTICS;
+        return e && std::string(e) == "statistics" ? WM_GICP_OBJECTIVE_STATISTICS : WM_GICP_OBJECTIVE_PCL_SUMS;
     }();
     return v;
 }
 }  // namespace
 
+void GICPMatcher::setObjective(Objective o) {
+    objective = o == Objective::Statistics ? WM_GICP_OBJECTIVE_STATISTICS : WM_GICP_OBJECTIVE_PCL_SUMS;
+}
+
+GICPMatcher::Objective GICPMatcher::getObjective() const {
+    const int o = objective >= 0 ? objective : envObjective();
+    return o == WM_GICP_OBJECTIVE_STATISTICS ? Objective::Statistics : Objective::PclSums;
+}
+
 bool GICPMatcher::match() {
     if (!ensureContext()) return false;
     wm_gicp_params p;
     wm_gicp_default_params(&p);
-    p.objective = gicpObjective();
+    p.objective = objective >= 0 ? objective : envObjective();
     p.corr_rand = params.corr_rand;  // setCorrespondenceRandomness, gicp.cpp:31
     p.max_iter = params.max_iter;    // setMaximumIterations,        gicp.cpp:32
     p.r_eps = params.r_eps;          // setRotationEpsilon,          gicp.cpp:33
@@ -130,7 +142,7 @@ bool GICPMatcher::matchBatch(const std::vector<std::pair<PCLPointCloudPtr, PCLPo
     if (!ensureContext()) return false;
     wm_gicp_params p;
     wm_gicp_default_params(&p);
-    p.objective = gicpObjective();
+    p.objective = objective >= 0 ? objective : envObjective();
     p.corr_rand = params.corr_rand;  // as match() sets them (gicp.cpp:31-33)
     p.max_iter = params.max_iter;
     p.r_eps = params.r_eps;

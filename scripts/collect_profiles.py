@@ -20,6 +20,7 @@ def cp(a, b):
 
 
 cp(os.path.join(src, tag + "_stats", "kernel_stats.csv"), tag + "_bench_kernel_stats.csv")
+cp(os.path.join(src, tag + "_stats", "kernel_stats_solo.csv"), tag + "_bench_kernel_stats_one_at_a_time.csv")
 cp(os.path.join(src, tag + "_stats", "bench_line.json"), tag + "_bench_line.json")
 cp(os.path.join(src, tag + "_bench_line_noprof.json"), tag + "_bench_line_noprof.json")
 cp(os.path.join(src, tag + "_multimatcher_cpp.jsonl"), tag + "_multimatcher_cpp.jsonl")

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
     local name=$1; shift
     rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -o p -- \
-        python "$ROOT/bench.py" --no-cpu-baseline --no-other-configs --steps 2 --warmup 1 > "$OUT/$name.log" 2>&1
+        python "$ROOT/bench.py" --no-cpu-baseline --no-other-configs --no-in-flight --steps 2 --warmup 1 > "$OUT/$name.log" 2>&1
     find "$OUT/$name" -name '*counter_collection.csv' | head -1 | xargs -I{} cp {} "$OUT/${name}_counters.csv"
     rm -rf "$OUT/$name"
 }

@@ -1,6 +1,12 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): per-dispatch TA / TCP / TLB counters of the correspondence
 # kernel over one registration (texture-addresser and L1 pressure of the gather).
+# The bench command is run WITHOUT its in-flight / host-cloud / other-config phases, so that the process's last 50
+# dispatches of the two search kernels ARE the one timed registration (round 5's captures took the last 50 of a run
+# that ended with interleaved contexts: 49 certificate launches of several registrations).  The rows are checked
+# against what a registration looks like -- full searches first (15 625 waves at 1M points, the first one the most
+# expensive), then certificate launches (3 9xx waves), as many of each as the bench line says -- and the script FAILS
+# (exit 3, no csv) when they do not.
 #   usage: scripts/gpu_pmc_detail.sh <tag>
 set -u
 TAG=${1:-pmcd}
@@ -11,7 +17,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {
     local name=$1; shift
     timeout 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -o p -- \
-        python "$ROOT/bench.py" --no-cpu-baseline --no-other-configs --steps 1 --warmup 1 > "$OUT/$name.log" 2>&1
+        python "$ROOT/bench.py" --no-cpu-baseline --no-other-configs --no-in-flight --no-host-clouds --steps 1 --warmup 1 > "$OUT/$name.log" 2>&1
     find "$OUT/$name" -name '*counter_collection.csv' | head -1 | xargs -I{} cp {} "$OUT/${name}_counters.csv"
     rm -rf "$OUT/$name"
 }
@@ -38,8 +44,41 @@ for name in ("sq1", "sq2", "sq3", "ta1", "ta2", "tcp1", "tcp2", "tlb"):
         d = per.setdefault(int(row["Dispatch_Id"]), {})
         d[row["Counter_Name"]] = float(row["Counter_Value"])
         d["is_cert"] = 1.0 if "k_nn_cert" in kn else 0.0
-    ids = sorted(per)[-50:]  # the last registration
+    line = {}
+    try:
+        import json
+        for l in open(os.path.join(out, name + ".log")):
+            if l.startswith("{"):
+                line = json.loads(l)
+    except Exception:
+        pass
+    iters = int(line.get("config", {}).get("iterations", 50))
+    want_cert = line.get("config", {}).get("cert_launches_per_registration")
+    ids = sorted(per)[-iters:]  # the last registration = the timed step (nothing runs behind it: see the flags above)
     names = sorted(per[ids[0]]) if ids else []
+    # ---- is this one registration?
+    seq = [int(per[i]["is_cert"]) for i in ids]
+    problems = []
+    if len(ids) != iters:
+        problems.append("%d dispatches of the search kernels, wanted %d" % (len(ids), iters))
+    if seq and seq[0] != 0:
+        problems.append("iteration 0 is not a full search")
+    if want_cert is not None and sum(seq) != int(want_cert):
+        problems.append("%d certificate launches, the bench line says %s" % (sum(seq), want_cert))
+    if "SQ_WAVES" in names:
+        for k, i in enumerate(ids):
+            w = per[i]["SQ_WAVES"]
+            ok = (3000 <= w <= 4200) if seq[k] else (15000 <= w <= 16500)
+            if not ok and int(line.get("config", {}).get("points_per_gpu", 1000000)) == 1000000:
+                problems.append("iteration %d: %s with %d waves" % (k, "k_nn_cert" if seq[k] else "k_nn_grid", int(w)))
+                break
+    if "SQ_INSTS_VALU" in names and ids:
+        v = [per[i]["SQ_INSTS_VALU"] for i in ids]
+        if v[0] < max(v) * 0.999:
+            problems.append("iteration 0 is not the most expensive launch (%.3g vs max %.3g VALU): not an unseeded search" % (v[0], max(v)))
+    if problems:
+        print("NOT ONE REGISTRATION (%s): %s" % (name, "; ".join(problems)))
+        sys.exit(3)
     with open(os.path.join(out, name + "_per_dispatch.csv"), "w") as f:
         f.write("iteration," + ",".join(names) + "\n")
         for k, i in enumerate(ids):

@@ -21,7 +21,7 @@ KEYS = ("rc", "converged", "iterations", "inner_total", "evaluations", "n_corr")
 
 # both forms of the objective (include/wavematch.h: wm_gicp_params::objective), each against the oracle's restatement
 # of it (oracle/gicp.c: wmo_gicp_set_objective) and against the one-pair path in the same form
-OBJECTIVES = [("statistics", 0, 1), ("pcl_sums", 1, 0)]   # (name, wm_gicp_params::objective, oracle objective mode)
+OBJECTIVES = [("statistics", 1, 1), ("pcl_sums", 0, 0)]   # (name, wm_gicp_params::objective, oracle objective mode)
 
 
 @pytest.fixture(params=OBJECTIVES, ids=[o[0] for o in OBJECTIVES])

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 # 74 sufficient statistics formed once per outer iteration (csrc/wm_gicp_quad.hpp), and PCL's per-pair sums through the
 # float transform.  The oracle restates both (oracle/gicp.c: wmo_gicp_set_objective); the HIP path is held to each
 # BIT FOR BIT.  How far the two objectives' registrations are apart: tests/test_gicp_quad_gpu.py.
-OBJECTIVES = [("statistics", 0, 1), ("pcl_sums", 1, 0)]   # (name, wm_gicp_params::objective, oracle objective mode)
+OBJECTIVES = [("statistics", 1, 1), ("pcl_sums", 0, 0)]   # (name, wm_gicp_params::objective, oracle objective mode)
 
 
 @pytest.fixture(params=OBJECTIVES, ids=[o[0] for o in OBJECTIVES])

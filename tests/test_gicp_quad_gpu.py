@@ -1,5 +1,5 @@
 """GICP's objective as sufficient statistics (libwave_amd/csrc/wm_gicp_quad.hpp; wm_gicp_params::objective =
-WM_GICP_OBJECTIVE_STATISTICS, the default) against PCL's per-pair sums (WM_GICP_OBJECTIVE_PCL_SUMS -- what
+WM_GICP_OBJECTIVE_STATISTICS, an explicit opt-in) against PCL's per-pair sums (WM_GICP_OBJECTIVE_PCL_SUMS, the default -- what
 OptimizationFunctorWithIndices::fdf does; the reference reaches it through wave_matching/src/gicp.cpp:58).
 
 Bit-level parity of EACH objective with the oracle's restatement of it: tests/test_gicp_gpu.py.  Here: how far the two
@@ -29,7 +29,7 @@ def test_reference_cases_both_objectives(wm, ctx, oracle, testscan, name, res, t
     P = np.eye(4)
     P[0, 3] = tx
     target = oracle.transform_cloud_d(testscan, P)
-    a = ctx.gicp_match(testscan, target, res=res)
+    a = ctx.gicp_match(testscan, target, res=res, objective=wm.WM_GICP_OBJECTIVE_STATISTICS)
     b = ctx.gicp_match(testscan, target, res=res, objective=wm.WM_GICP_OBJECTIVE_PCL_SUMS)
     assert a["rc"] == 0 and b["rc"] == 0
     assert np.linalg.norm(a["T"] - P) < 0.1 and np.linalg.norm(b["T"] - P) < 0.1
@@ -47,7 +47,7 @@ def test_spread_between_the_objectives_on_noisy_pairs(wm, ctx):
         ref, tgt, T_gt = synth.pair(n, seed=seed)
         ctx.set_source(ref)
         ctx.set_target(tgt)
-        a = ctx.gicp_align()
+        a = ctx.gicp_align(objective=wm.WM_GICP_OBJECTIVE_STATISTICS)
         b = ctx.gicp_align(objective=wm.WM_GICP_OBJECTIVE_PCL_SUMS)
         assert a["rc"] == 0 and b["rc"] == 0 and a["n_corr"] > 0.9 * n
         dt, ang = pose_error(a["T"], b["T"])
@@ -75,7 +75,7 @@ def test_statistics_objective_needs_no_pass_per_evaluation(wm, ctx):
     try:
         prof.set_source(ref)
         prof.set_target(tgt)
-        a = prof.gicp_align()
+        a = prof.gicp_align(objective=wm.WM_GICP_OBJECTIVE_STATISTICS)
         b = prof.gicp_align(objective=wm.WM_GICP_OBJECTIVE_PCL_SUMS)
     finally:
         prof.close()
@@ -102,7 +102,7 @@ def test_both_objectives_against_the_independent_fixed_point(wm, ctx, testscan):
         else:
             target, P = G.shifted(testscan, c["tx"])
             bar = (1e-4, 1e-4)
-        a = ctx.gicp_match(testscan, target, res=c["res"])
+        a = ctx.gicp_match(testscan, target, res=c["res"], objective=wm.WM_GICP_OBJECTIVE_STATISTICS)
         b = ctx.gicp_match(testscan, target, res=c["res"], objective=wm.WM_GICP_OBJECTIVE_PCL_SUMS)
         assert a["rc"] == 0 and b["rc"] == 0
         da, ra = pose_error(a["T"], np.array(c["fixed_point_T"]))
@@ -134,3 +134,22 @@ def test_one_context_alternating_between_the_objectives(wm):
         assert got["rc"] == fresh[obj]["rc"] == 0
         assert np.array_equal(got["T"], fresh[obj]["T"]) and got["iterations"] == fresh[obj]["iterations"]
     c.close()
+
+
+def test_the_default_objective_is_pcls(wm, ctx, oracle, testscan):
+    """The drop-in default is the REFERENCE's algorithm (wave_matching/src/gicp.cpp:58 -> PCL's per-pair objective): a
+    registration with default parameters equals, bit for bit, one that asks for WM_GICP_OBJECTIVE_PCL_SUMS, and the
+    oracle's default mode; the statistics objective is only ever run when asked for."""
+    assert wm.WM_GICP_OBJECTIVE_PCL_SUMS == 0 and wm.gicp_params().objective == wm.WM_GICP_OBJECTIVE_PCL_SUMS
+    P = np.eye(4)
+    P[0, 3] = 0.2
+    target = oracle.transform_cloud_d(testscan, P)
+    a = ctx.gicp_match(testscan, target, res=0.05)
+    b = ctx.gicp_match(testscan, target, res=0.05, objective=wm.WM_GICP_OBJECTIVE_PCL_SUMS)
+    oracle.gicp_set_objective(0)
+    want = oracle.gicp_align(oracle.voxel_grid(testscan, 0.05), oracle.voxel_grid(target, 0.05))
+    assert a["rc"] == b["rc"] == 0
+    assert np.array_equal(a["T"], b["T"]) and a["evaluations"] == b["evaluations"] and a["served_evaluations"] > 0
+    assert np.array_equal(a["T"], want["T"]) and a["iterations"] == want["iterations"]
+    with pytest.raises(wm.WmError):
+        ctx.gicp_align(params=wm.gicp_params(objective=7))
