@@ -14,6 +14,7 @@
 //      the RCCL all-reduce carries between (2) and (3).
 #include "wm_internal.hpp"
 #include "wm_icp_step.hpp"
+#include "wm_solve_tail.hpp"
 #include "wm_xchg.hpp"
 
 #include <algorithm>
@@ -168,23 +169,39 @@ __global__ void __launch_bounds__(kBlock)
     }
 }
 
-// What the host steers by while it runs ahead of the device (wm_icp_align): one 8-byte word in pinned memory -- done
-// flag, iterations finished, the step's size -- in ONE system-scope store (pub[0]: the latest; pub[k]: iteration k's
-// own record, so that what the host decides from does not depend on when it looks).
-__device__ __forceinline__ void publish_step(const IcpDevState *s, unsigned long long *pub, int pub_slots) {
-    if (!pub) return;
-    // [iteration : 16 | step size as bfloat16 : 16 | changed matches : 16 | searched by the certificate kernel : 16]
-    // -- fractions in 1 / 65535
-    const unsigned f_ch = (unsigned) (fminf(fmaxf(s->frac_changed, 0.f), 1.f) * 65535.f + 0.5f);
-    const unsigned f_un = (unsigned) (fminf(fmaxf(s->frac_unsettled, 0.f), 1.f) * 65535.f + 0.5f);
-    const unsigned long long w = ((unsigned long long) ((unsigned) s->iter & 0xFFFFu) << 48) |
-                                 ((unsigned long long) (__float_as_uint(s->step_disp) >> 16) << 32) |
-                                 ((unsigned long long) f_ch << 16) | (unsigned long long) f_un;
-    if (s->iter >= 1 && s->iter <= pub_slots) __hip_atomic_store(pub + s->iter, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    // ([0]: bit 0 = done, above it the number of iterations finished by then -- ONE word, so that a host that sees
-    // `done` before the last record knows whether that record is still to come)
-    __hip_atomic_store(pub, s->done ? (1ull | ((unsigned long long) (unsigned) s->iter << 1)) : 0ull, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
+// k_reduce_rows + the iteration's solve in ONE launch (wm_solve_tail.hpp): every workgroup adds its 128 rows as above and
+// stores the result at agent scope; the last one to finish adds the ~123 results and runs the solve, the stopping
+// rules and the record -- what k_reduce_solve<3> did in a dependent launch of its own behind each of a registration's
+// full searches.  (Same additions in the same order per workgroup as k_reduce_rows; the final sum over the workgroups'
+// rows runs in tail_add_rows' order.)
+__global__ void __launch_bounds__(kBlock)
+    k_reduce_rows_solve(const double *__restrict__ partials, int rows, IcpDevState *st, double *out, TailArgs ta) {
+    if (st->done) return;  // (uniform over the grid: the state is only written by the last workgroup, after every ticket)
+    constexpr int kLanes = kBlock / kAcc;  // 14 row-lanes x kAcc components
+    __shared__ double lds[kLanes][kAcc];
+    __shared__ TailLds<kBlock> S;
+    const int c = threadIdx.x % kAcc, r = threadIdx.x / kAcc;
+    const int r0 = blockIdx.x * kPreRows, r1 = min(r0 + kPreRows, rows);
+    if (r < kLanes) {
+        double v[(kPreRows + kLanes - 1) / kLanes];
+#pragma unroll
+        for (int b = r0 + r, u = 0; u < (kPreRows + kLanes - 1) / kLanes; b += kLanes, ++u)
+            v[u] = b < r1 ? partials[(size_t) b * kAcc + c] : 0.0;
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < (kPreRows + kLanes - 1) / kLanes; ++u) s += v[u];
+        lds[r][c] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned) kTailRow) {
+        double t = 0.0;
+        if (threadIdx.x < (unsigned) kAcc) {
+#pragma unroll
+            for (int l = 0; l < kLanes; ++l) t += lds[l][threadIdx.x];
+        }
+        st_agent_f64(out + (size_t) blockIdx.x * kTailRow + threadIdx.x, t);  // ([kAcc]: nothing searched by a certificate, 0)
+    }
+    tail_finish<kBlock>(out, blockIdx.x, gridDim.x, false, st, ta, S);
 }
 
 // PHASE 1: sum partials -> st->stats.   PHASE 2: solve + criteria from st->stats.
@@ -430,6 +447,26 @@ static int launch_stats(wm_ctx *ctx, int mode) {
     return WM_OK;
 }
 
+// what a kernel with a solve tail needs (wm_solve_tail.hpp): the ticket words -- zeroed when first allocated, kept at
+// zero by the tails themselves -- and room for the groups' rows of a two-level tail over `rows` workgroups
+int tail_args(wm_ctx *ctx, unsigned rows, unsigned long long *pub, int pub_slots, TailArgs *ta) {
+    if (!ctx->tail_ticket.p || ctx->tail_dirty) {
+        // (dirty: the last loop that used tails did not end normally -- a failed launch, an error return -- and may
+        // have left tickets drawn)
+        WM_HIP(ctx, ctx->tail_ticket.reserve(kTailTickets * sizeof(unsigned)));
+        WM_HIP(ctx, hipMemsetAsync(ctx->tail_ticket.p, 0, kTailTickets * sizeof(unsigned), ctx->stream));
+        ctx->tail_dirty = false;
+    }
+    const unsigned groups = (rows + kTailGroup - 1u) / kTailGroup;
+    if (groups + 1u > kTailTickets) return WM_ERR_ARG;
+    WM_HIP(ctx, ctx->tail_grows.reserve((size_t) (groups + 1u) * kTailRow * sizeof(double)));
+    ta->ticket = ctx->tail_ticket.as<unsigned>();
+    ta->grows = ctx->tail_grows.as<double>();
+    ta->pub = pub;
+    ta->pub_slots = pub_slots;
+    return WM_OK;
+}
+
 // Sum `rows` partial rows (ctx->partials) and run the requested phases of the iteration's solve.
 template <int PHASES>
 static int launch_reduce_solve(wm_ctx *ctx, unsigned rows, double *stats_io, unsigned long long *pub = nullptr,
@@ -437,6 +474,18 @@ static int launch_reduce_solve(wm_ctx *ctx, unsigned rows, double *stats_io, uns
     const XchgDev xd = xchg ? *xchg : XchgDev{nullptr, nullptr, 0, 0, 0u};
     IcpDevState *st = ctx->d_state.as<IcpDevState>();
     const double *part = ctx->partials.as<double>();
+    if (rows > 2048u && PHASES == 3 && !stats_io && ctx->tune_tail) {
+        // the unsharded loop behind a full search: 128 rows -> 1 per workgroup, and the LAST workgroup adds those and
+        // runs the solve -- one launch where k_reduce_rows + k_reduce_solve were two (wm_solve_tail.hpp)
+        const unsigned rows2 = (rows + kPreRows - 1) / kPreRows;
+        TailArgs ta;
+        WM_TRY(tail_args(ctx, rows2, pub, pub_slots, &ta));
+        WM_HIP(ctx, ctx->partials2.reserve((size_t) rows2 * kTailRow * sizeof(double)));
+        hipLaunchKernelGGL(k_reduce_rows_solve, dim3(rows2), dim3(kBlock), 0, ctx->stream, part, (int) rows, st,
+                           ctx->partials2.as<double>(), ta);
+        WM_HIP(ctx, hipGetLastError());
+        return WM_OK;
+    }
     if (rows > 2048u) {  // one workgroup cannot add that many rows quickly: 128 rows -> 1 first
         const unsigned rows2 = (rows + kPreRows - 1) / kPreRows;
         WM_HIP(ctx, ctx->partials2.reserve((size_t) rows2 * kAcc * sizeof(double)));
@@ -957,6 +1006,8 @@ int wm_ctx_create(wm_ctx **out, int device) {
     if (const char *e = getenv("WM_TUNE_NDT_FUSED_FETCH")) ctx->tune_ndt_fused_fetch = atoi(e);
     if (const char *e = getenv("WM_TUNE_LAG")) ctx->tune_lag = atoi(e);
     if (const char *e = getenv("WM_TUNE_LATE")) ctx->tune_late = atoi(e);
+    if (const char *e = getenv("WM_TUNE_TAIL")) ctx->tune_tail = atoi(e);
+    if (const char *e = getenv("WM_TUNE_GRID_VARIANT")) ctx->tune_grid_variant = atoi(e);
     if (const char *e = getenv("WM_TUNE_EARLY_SOURCE")) ctx->tune_early_source = atoi(e);
     if (const char *e = getenv("WM_TUNE_COV_DBG")) ctx->tune_cov_dbg = atoi(e) & 768;
     if (const char *e = getenv("WM_TUNE_R0")) {
@@ -992,7 +1043,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
                       &ctx->src_grid.cell_start, &ctx->vg_idx, &ctx->vg_idx2, &ctx->vg_perm,
                       &ctx->vg_perm2, &ctx->vg_tmp, &ctx->vg_seg, &ctx->io_a, &ctx->io_b, &ctx->ds_ref,
                       &ctx->ds_tgt, &ctx->match_ref, &ctx->match_tgt,
-                      &ctx->partials, &ctx->partials2, &ctx->nn_bound, &ctx->late_ctl, &ctx->cert_count, &ctx->cert_prof, &ctx->cost_log, &ctx->phase_log, &ctx->shard_ref, &ctx->shard_tgt,
+                      &ctx->partials, &ctx->partials2, &ctx->tail_ticket, &ctx->tail_grows, &ctx->nn_bound, &ctx->late_ctl, &ctx->cert_count, &ctx->cert_prof, &ctx->cost_log, &ctx->phase_log, &ctx->shard_ref, &ctx->shard_tgt,
                       &ctx->shard_ref_band, &ctx->shard_tgt_band, &ctx->shard_misc, &ctx->shard_flags, &ctx->shard_pos_t,
                       &ctx->shard_pos_s, &ctx->shard_stats, &ctx->ndt_sum_dev, &ctx->corr_tmp_idx, &ctx->corr_tmp_d2, &ctx->d_state};
     for (DevBuf *b : bufs) b->release();
@@ -1197,6 +1248,11 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
     XchgDev xchg{nullptr, nullptr, 0, 0, 0u};
     const bool in_kernel_exchange = blk && comm_exchange_args(comm, &xchg) == WM_OK;
     ctx->cert_launches = 0;
+    const bool tail_was_dirty = ctx->tail_dirty;
+    if (tail_was_dirty && ctx->tail_ticket.p) {
+        WM_HIP(ctx, hipMemsetAsync(ctx->tail_ticket.p, 0, kTailTickets * sizeof(unsigned), ctx->stream));
+    }
+    ctx->tail_dirty = true;  // (until this loop has ended normally)
     std::vector<unsigned char> was_cert;
     std::vector<unsigned char> kind((size_t) max_it, 0);  // which search kernel iteration k got (1: certificate, 2: its first launch)
     std::vector<int> ev_slot((size_t) max_it, -1);        // profile: the iteration's first event in the pool
@@ -1411,7 +1467,9 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
                 WM_HIP(ctx, ctx->nn_bound.reserve(((size_t) ctx->n_src + 64) * sizeof(float4)));
                 WM_HIP(ctx, hipMemsetAsync(ctx->nn_bound.p, 0, ((size_t) ctx->n_src + 64) * sizeof(float4), ctx->stream));
             }
-            WM_TRY(launch_nn_cert(ctx, thr, e0, e1, e1b, p->mode, &rows, bounds_valid || slab));
+            // (unsharded: the kernel's last workgroup runs the solve too -- rows comes back 0, nothing more to launch)
+            WM_TRY(launch_nn_cert(ctx, thr, e0, e1, e1b, p->mode, &rows, bounds_valid || slab, !blk && ctx->tune_tail != 0,
+                                  ctx->h_pub, ctx->h_pub_slots));
             kind[(size_t) it] = bounds_valid ? 1 : 2;
             bounds_valid = true;
             ctx->cert_launches++;
@@ -1441,7 +1499,7 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
             WM_TRY(comm_allreduce(ctx, comm, blk, kBlkLen));
             if (eb) WM_HIP(ctx, hipEventRecord(eb, ctx->stream));
             WM_TRY(launch_reduce_solve<2>(ctx, 0, blk, ctx->h_pub, ctx->h_pub_slots, 1));
-        } else {
+        } else if (rows > 0) {
             WM_TRY(launch_reduce_solve<3>(ctx, rows, nullptr, ctx->h_pub, ctx->h_pub_slots));
         }
         if (e3) WM_HIP(ctx, hipEventRecord(e3, ctx->stream));
@@ -1458,6 +1516,7 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
                           "(a peer failed or fell behind by more than the exchange's time limit)";
         return WM_ERR_RCCL;
     }
+    ctx->tail_dirty = false;
     ctx->prev_mse = s.prev_mse;
     ctx->have_corr = true;
     ctx->last_align_valid = true;
@@ -1902,6 +1961,7 @@ int wm_set_option(wm_ctx *ctx, const char *name, double value) {
     else if (k == "cert_pad_mul" && value >= 0) ctx->tune_cert_pad_mul = (float) value;
     else if (k == "cert_pad_frac" && value >= 0) ctx->tune_cert_pad_frac = (float) value;
     else if (k == "late") ctx->tune_late = value != 0 ? 1 : 0;
+    else if (k == "tail") ctx->tune_tail = (int) value;
     else if (k == "gicp_served") ctx->tune_gicp_served = value == 2 ? 2 : (value != 0 ? 1 : 0);
     else if (k == "gicp_serve_test_stall_ms") ctx->gicp_serve_test_stall_ms = (int) value;
     else return WM_ERR_ARG;

@@ -9,7 +9,7 @@ from libwave_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-# The objective of the minimisations comes in two forms (include/wavematch.h: wm_gicp_params::objective): the default,
+# The objective of the minimisations comes in two forms (include/wavematch.h: wm_gicp_params::objective): the opt-in,
 # 74 sufficient statistics formed once per outer iteration (csrc/wm_gicp_quad.hpp), and PCL's per-pair sums through the
 # float transform.  The oracle restates both (oracle/gicp.c: wmo_gicp_set_objective); the HIP path is held to each
 # BIT FOR BIT.  How far the two objectives' registrations are apart: tests/test_gicp_quad_gpu.py.
@@ -107,8 +107,8 @@ def test_gicp_objective_and_gradient_match_oracle(wm, ctx, oracle):
     of, og = oracle.gicp_fdf(ref, tgt, si, oi[si], M, np.eye(4), x)
     assert abs(f - of) <= 1e-12 * abs(of)   # (M through numpy's inverse here: last-bit differences in the terms)
     np.testing.assert_allclose(g, og, rtol=1e-10, atol=1e-10 * np.abs(og).max())
-    # ... and the statistics objective (the default): the 74 sums of the same pairs, found under T_pair, evaluated at x
-    f2, g2, m2 = ctx.gicp_eval(T_pair, x)
+    # ... and the statistics objective (opt-in): the 74 sums of the same pairs, found under T_pair, evaluated at x
+    f2, g2, m2 = ctx.gicp_eval(T_pair, x, objective=wm.WM_GICP_OBJECTIVE_STATISTICS)
     qf, qg, Q = oracle.gicp_fdf_statistics(ref, tgt, si, oi[si], M, np.eye(4), T_pair.astype(np.float32), x)
     assert m2 == m and Q[73] == m
     assert abs(f2 - qf) <= 1e-12 * abs(qf)
@@ -121,7 +121,7 @@ def test_gicp_objective_and_gradient_match_oracle(wm, ctx, oracle):
     x0 = np.array([T_pair[0, 3], T_pair[1, 3], T_pair[2, 3], np.arctan2(np.float32(T_pair[2, 1]), np.float32(T_pair[2, 2])),
                    np.arcsin(-np.float32(T_pair[2, 0])), np.arctan2(np.float32(T_pair[1, 0]), np.float32(T_pair[0, 0]))])
     fa, _, _ = ctx.gicp_eval(T_pair, x0, objective=wm.WM_GICP_OBJECTIVE_PCL_SUMS)
-    fb, _, _ = ctx.gicp_eval(T_pair, x0)
+    fb, _, _ = ctx.gicp_eval(T_pair, x0, objective=wm.WM_GICP_OBJECTIVE_STATISTICS)
     assert abs(fa - fb) <= 2e-5 * abs(fa)   # (x0 -> float matrix reproduces T_pair to an ulp or two of its entries)
 
 
