@@ -51,10 +51,18 @@ __device__ __forceinline__ void bins_split(double x, long long (&l)[kBinLimbs]) 
 }
 
 // component `comp` of bin `bin` += x  (three fire-and-forget atomics; the caller does not wait for them)
+// (a sum the format cannot hold -- not finite, or 2^62 and beyond: coordinates of ~1e7 m on millions of points --
+// raises the bin's POISON word instead, and the solve ends the registration with "no correspondences": loud, not wrong)
+constexpr unsigned kBinPoison = kBinStride - 1;  // word of limb row 0
 __device__ __forceinline__ void bins_add(long long *bins, unsigned bin, unsigned comp, double x) {
     long long l[kBinLimbs];
-    bins_split(x, l);
     long long *p = bins + (size_t) bin * (kBinLimbs * kBinStride) + comp;
+    if (!(fabs(x) < 4611686018427387904.0)) {
+        (void) __hip_atomic_fetch_add(bins + (size_t) bin * (kBinLimbs * kBinStride) + kBinPoison, 1ll, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    bins_split(x, l);
 #pragma unroll
     for (int k = 0; k < kBinLimbs; ++k)
         (void) __hip_atomic_fetch_add(p + k * kBinStride, l[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -14,7 +14,7 @@
 //      the RCCL all-reduce carries between (2) and (3).
 #include "wm_internal.hpp"
 #include "wm_icp_step.hpp"
-#include "wm_solve_tail.hpp"
+#include "wm_bins.hpp"
 #include "wm_xchg.hpp"
 
 #include <algorithm>
@@ -169,39 +169,114 @@ __global__ void __launch_bounds__(kBlock)
     }
 }
 
-// k_reduce_rows + the iteration's solve in ONE launch (wm_solve_tail.hpp): every workgroup adds its 128 rows as above and
-// stores the result at agent scope; the last one to finish adds the ~123 results and runs the solve, the stopping
-// rules and the record -- what k_reduce_solve<3> did in a dependent launch of its own behind each of a registration's
-// full searches.  (Same additions in the same order per workgroup as k_reduce_rows; the final sum over the workgroups'
-// rows runs in tail_add_rows' order.)
+// What the host steers by while it runs ahead of the device (wm_icp_align): one 8-byte word in pinned memory -- done
+// flag, iterations finished, the step's size -- in ONE system-scope store (pub[0]: the latest; pub[k]: iteration k's
+// own record, so that what the host decides from does not depend on when it looks).
+__device__ __forceinline__ void publish_step(const IcpDevState *s, unsigned long long *pub, int pub_slots) {
+    if (!pub) return;
+    // [iteration : 16 | step size as bfloat16 : 16 | changed matches : 16 | searched by the certificate kernel : 16]
+    // -- fractions in 1 / 65535
+    const unsigned f_ch = (unsigned) (fminf(fmaxf(s->frac_changed, 0.f), 1.f) * 65535.f + 0.5f);
+    const unsigned f_un = (unsigned) (fminf(fmaxf(s->frac_unsettled, 0.f), 1.f) * 65535.f + 0.5f);
+    const unsigned long long w = ((unsigned long long) ((unsigned) s->iter & 0xFFFFu) << 48) |
+                                 ((unsigned long long) (__float_as_uint(s->step_disp) >> 16) << 32) |
+                                 ((unsigned long long) f_ch << 16) | (unsigned long long) f_un;
+    if (s->iter >= 1 && s->iter <= pub_slots) __hip_atomic_store(pub + s->iter, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // ([0]: bit 0 = done, above it the number of iterations finished by then -- ONE word, so that a host that sees
+    // `done` before the last record knows whether that record is still to come)
+    __hip_atomic_store(pub, s->done ? (1ull | ((unsigned long long) (unsigned) s->iter << 1)) : 0ull, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The iteration's solve from the BINS the search kernel's waves added their sums into (wm_bins.hpp): the unsharded
+// loop's replacement for k_reduce_rows + k_reduce_solve<3>.  One workgroup: thread (g, j) adds word j (limb, component)
+// of bins g, g + kGroups, ... -- integers: exact in any order --, the kGroups partial totals meet in LDS, one thread per
+// component turns its three limb totals back into a double (bins_value), thread 0 runs the solve, PCL's stopping rules
+// and publishes the record exactly as k_reduce_solve does; the words read are set back to zero for the next iteration.
 __global__ void __launch_bounds__(kBlock)
-    k_reduce_rows_solve(const double *__restrict__ partials, int rows, IcpDevState *st, double *out, TailArgs ta) {
-    if (st->done) return;  // (uniform over the grid: the state is only written by the last workgroup, after every ticket)
-    constexpr int kLanes = kBlock / kAcc;  // 14 row-lanes x kAcc components
-    __shared__ double lds[kLanes][kAcc];
-    __shared__ TailLds<kBlock> S;
-    const int c = threadIdx.x % kAcc, r = threadIdx.x / kAcc;
-    const int r0 = blockIdx.x * kPreRows, r1 = min(r0 + kPreRows, rows);
-    if (r < kLanes) {
-        double v[(kPreRows + kLanes - 1) / kLanes];
+    k_bins_solve(long long *__restrict__ bins, IcpDevState *st, unsigned long long *pub, int pub_slots) {
+    __shared__ IcpDevState s_st;
+    constexpr int kWordsPerBin = kBinLimbs * kBinComps;       // 57 words of a bin are in use
+    constexpr int kGroups = kBlock / kWordsPerBin;            // 4 groups of threads, 16 bins each
+    static_assert(kGroups >= 1 && kBinCount % kGroups == 0, "bins per thread group");
+    constexpr int kPer = kBinCount / kGroups;
+    __shared__ long long s_part[kGroups][kWordsPerBin];
+    __shared__ double s_tot[kBinComps];
+    __shared__ unsigned s_poison;
+    const unsigned long long t_start = clock64();
+    static_assert(sizeof(IcpDevState) % 4 == 0, "word-wise staging");
+    constexpr unsigned kWords = sizeof(IcpDevState) / 4;
+    constexpr unsigned kStage = (kWords + kBlock - 1) / kBlock;
+    unsigned stage[kStage];
 #pragma unroll
-        for (int b = r0 + r, u = 0; u < (kPreRows + kLanes - 1) / kLanes; b += kLanes, ++u)
-            v[u] = b < r1 ? partials[(size_t) b * kAcc + c] : 0.0;
-        double s = 0.0;
+    for (unsigned k = 0; k < kStage; ++k) {  // (the state's loads and the bins' in ONE round trip)
+        const unsigned w = threadIdx.x + k * kBlock;
+        stage[k] = w < kWords ? reinterpret_cast<const unsigned *>(st)[w] : 0u;
+    }
+    const unsigned g = threadIdx.x / (unsigned) kWordsPerBin, j = threadIdx.x % (unsigned) kWordsPerBin;
+    const unsigned limb = j / (unsigned) kBinComps, comp = j % (unsigned) kBinComps;
+    if (threadIdx.x == 0) s_poison = 0u;
+    if (g < (unsigned) kGroups) {
+        long long v[kPer];
 #pragma unroll
-        for (int u = 0; u < (kPreRows + kLanes - 1) / kLanes; ++u) s += v[u];
-        lds[r][c] = s;
+        for (int b = 0; b < kPer; ++b)
+            v[b] = bins[((size_t) (g * kPer + b) * kBinLimbs + limb) * kBinStride + comp];
+        long long t = 0;
+#pragma unroll
+        for (int b = 0; b < kPer; ++b) t += v[b];
+        s_part[g][j] = t;
+    }
+    __syncthreads();  // (s_poison's zero)
+    if (threadIdx.x < (unsigned) kBinCount) {  // a sum that the limbs could not hold?
+        long long *pw = bins + (size_t) threadIdx.x * (kBinLimbs * kBinStride) + kBinPoison;
+        if (*pw != 0ll) {
+            atomicOr(&s_poison, 1u);
+            *pw = 0ll;
+        }
+    }
+#pragma unroll
+    for (unsigned k = 0; k < kStage; ++k) {
+        const unsigned w = threadIdx.x + k * kBlock;
+        if (w < kWords) reinterpret_cast<unsigned *>(&s_st)[w] = stage[k];
     }
     __syncthreads();
-    if (threadIdx.x < (unsigned) kTailRow) {
-        double t = 0.0;
-        if (threadIdx.x < (unsigned) kAcc) {
+    if (s_st.done) return;  // (uniform; a launch queued behind a `done`: the bins are all zero and stay so)
+    if (g < (unsigned) kGroups) {  // zeros for the next iteration
 #pragma unroll
-            for (int l = 0; l < kLanes; ++l) t += lds[l][threadIdx.x];
-        }
-        st_agent_f64(out + (size_t) blockIdx.x * kTailRow + threadIdx.x, t);  // ([kAcc]: nothing searched by a certificate, 0)
+        for (int b = 0; b < kPer; ++b)
+            bins[((size_t) (g * kPer + b) * kBinLimbs + limb) * kBinStride + comp] = 0ll;
     }
-    tail_finish<kBlock>(out, blockIdx.x, gridDim.x, false, st, ta, S);
+    if (threadIdx.x < (unsigned) kBinComps) {
+        long long L[kBinLimbs];
+#pragma unroll
+        for (int l = 0; l < kBinLimbs; ++l) {
+            long long t = 0;
+#pragma unroll
+            for (int gg = 0; gg < kGroups; ++gg) t += s_part[gg][l * kBinComps + threadIdx.x];
+            L[l] = t;
+        }
+        // ([kAcc]: the searched-queries count, added unscaled into limb 0)
+        s_tot[threadIdx.x] = threadIdx.x < (unsigned) kAcc ? bins_value(L[0], L[1], L[2]) : (double) L[0];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_st.dbg[0] = t_start;
+        s_st.dbg[1] = clock64();
+        double a[kAcc], ex[kStatsLen];
+#pragma unroll
+        for (int k = 0; k < kAcc; ++k) a[k] = s_poison ? 0.0 : s_tot[k];  // (poisoned: "no correspondences", icp_apply_stats)
+        expand_stats(s_st.mode, a, ex, s_st.changed_mask);
+        s_st.local_handled = ex[kStatsLen - 1];
+#pragma unroll
+        for (int k = 0; k < kStatsLen; ++k) s_st.stats[k] = ex[k];
+        s_st.dbg[2] = clock64();
+        icp_apply_stats(&s_st, ex, (long long) s_tot[kAcc]);
+        publish_step(&s_st, pub, pub_slots);
+        s_st.dbg[3] = clock64();
+    }
+    __syncthreads();
+    for (unsigned w = threadIdx.x; w < kWords; w += kBlock)
+        reinterpret_cast<unsigned *>(st)[w] = reinterpret_cast<const unsigned *>(&s_st)[w];
 }
 
 // PHASE 1: sum partials -> st->stats.   PHASE 2: solve + criteria from st->stats.
@@ -447,23 +522,21 @@ static int launch_stats(wm_ctx *ctx, int mode) {
     return WM_OK;
 }
 
-// what a kernel with a solve tail needs (wm_solve_tail.hpp): the ticket words -- zeroed when first allocated, kept at
-// zero by the tails themselves -- and room for the groups' rows of a two-level tail over `rows` workgroups
-int tail_args(wm_ctx *ctx, unsigned rows, unsigned long long *pub, int pub_slots, TailArgs *ta) {
-    if (!ctx->tail_ticket.p || ctx->tail_dirty) {
-        // (dirty: the last loop that used tails did not end normally -- a failed launch, an error return -- and may
-        // have left tickets drawn)
-        WM_HIP(ctx, ctx->tail_ticket.reserve(kTailTickets * sizeof(unsigned)));
-        WM_HIP(ctx, hipMemsetAsync(ctx->tail_ticket.p, 0, kTailTickets * sizeof(unsigned), ctx->stream));
-        ctx->tail_dirty = false;
+// the iteration's bins (wm_bins.hpp): allocated, and all zero -- zeroed here when first allocated or when the last loop
+// that used them did not end normally; kept at zero by k_bins_solve otherwise
+int bins_ready(wm_ctx *ctx) {
+    if (!ctx->bins.p || ctx->bins_dirty) {
+        WM_HIP(ctx, ctx->bins.reserve(kBinWords * sizeof(long long)));
+        WM_HIP(ctx, hipMemsetAsync(ctx->bins.p, 0, kBinWords * sizeof(long long), ctx->stream));
+        ctx->bins_dirty = false;
     }
-    const unsigned groups = (rows + kTailGroup - 1u) / kTailGroup;
-    if (groups + 1u > kTailTickets) return WM_ERR_ARG;
-    WM_HIP(ctx, ctx->tail_grows.reserve((size_t) (groups + 1u) * kTailRow * sizeof(double)));
-    ta->ticket = ctx->tail_ticket.as<unsigned>();
-    ta->grows = ctx->tail_grows.as<double>();
-    ta->pub = pub;
-    ta->pub_slots = pub_slots;
+    return WM_OK;
+}
+
+static int launch_bins_solve(wm_ctx *ctx, unsigned long long *pub, int pub_slots) {
+    hipLaunchKernelGGL(k_bins_solve, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->bins.as<long long>(),
+                       ctx->d_state.as<IcpDevState>(), pub, pub_slots);
+    WM_HIP(ctx, hipGetLastError());
     return WM_OK;
 }
 
@@ -474,18 +547,6 @@ static int launch_reduce_solve(wm_ctx *ctx, unsigned rows, double *stats_io, uns
     const XchgDev xd = xchg ? *xchg : XchgDev{nullptr, nullptr, 0, 0, 0u};
     IcpDevState *st = ctx->d_state.as<IcpDevState>();
     const double *part = ctx->partials.as<double>();
-    if (rows > 2048u && PHASES == 3 && !stats_io && ctx->tune_tail) {
-        // the unsharded loop behind a full search: 128 rows -> 1 per workgroup, and the LAST workgroup adds those and
-        // runs the solve -- one launch where k_reduce_rows + k_reduce_solve were two (wm_solve_tail.hpp)
-        const unsigned rows2 = (rows + kPreRows - 1) / kPreRows;
-        TailArgs ta;
-        WM_TRY(tail_args(ctx, rows2, pub, pub_slots, &ta));
-        WM_HIP(ctx, ctx->partials2.reserve((size_t) rows2 * kTailRow * sizeof(double)));
-        hipLaunchKernelGGL(k_reduce_rows_solve, dim3(rows2), dim3(kBlock), 0, ctx->stream, part, (int) rows, st,
-                           ctx->partials2.as<double>(), ta);
-        WM_HIP(ctx, hipGetLastError());
-        return WM_OK;
-    }
     if (rows > 2048u) {  // one workgroup cannot add that many rows quickly: 128 rows -> 1 first
         const unsigned rows2 = (rows + kPreRows - 1) / kPreRows;
         WM_HIP(ctx, ctx->partials2.reserve((size_t) rows2 * kAcc * sizeof(double)));
@@ -507,8 +568,8 @@ static int launch_reduce_solve(wm_ctx *ctx, unsigned rows, double *stats_io, uns
 // one iteration's correspondence search + statistics on the grid: fused (the search kernel leaves
 // the partial rows) or as two passes; *rows = partial rows to add up
 static int launch_search_and_stats(wm_ctx *ctx, float thr, int mode, hipEvent_t e0, hipEvent_t e1,
-                                   hipEvent_t e1b, unsigned *rows) {
-    if (ctx->tune_fuse_stats) return launch_nn_grid(ctx, thr, e0, e1, e1b, mode, rows);
+                                   hipEvent_t e1b, unsigned *rows, bool use_bins = false) {
+    if (ctx->tune_fuse_stats) return launch_nn_grid(ctx, thr, e0, e1, e1b, mode, rows, use_bins);
     WM_TRY(launch_nn_grid(ctx, thr, e0, e1, e1b));
     WM_TRY(launch_stats(ctx, mode));
     *rows = (unsigned) stat_blocks(ctx->n_src);
@@ -1006,7 +1067,7 @@ int wm_ctx_create(wm_ctx **out, int device) {
     if (const char *e = getenv("WM_TUNE_NDT_FUSED_FETCH")) ctx->tune_ndt_fused_fetch = atoi(e);
     if (const char *e = getenv("WM_TUNE_LAG")) ctx->tune_lag = atoi(e);
     if (const char *e = getenv("WM_TUNE_LATE")) ctx->tune_late = atoi(e);
-    if (const char *e = getenv("WM_TUNE_TAIL")) ctx->tune_tail = atoi(e);
+    if (const char *e = getenv("WM_TUNE_BINS")) ctx->tune_bins = atoi(e);
     if (const char *e = getenv("WM_TUNE_GRID_VARIANT")) ctx->tune_grid_variant = atoi(e);
     if (const char *e = getenv("WM_TUNE_EARLY_SOURCE")) ctx->tune_early_source = atoi(e);
     if (const char *e = getenv("WM_TUNE_COV_DBG")) ctx->tune_cov_dbg = atoi(e) & 768;
@@ -1043,7 +1104,7 @@ void wm_ctx_destroy(wm_ctx *ctx) {
                       &ctx->src_grid.cell_start, &ctx->vg_idx, &ctx->vg_idx2, &ctx->vg_perm,
                       &ctx->vg_perm2, &ctx->vg_tmp, &ctx->vg_seg, &ctx->io_a, &ctx->io_b, &ctx->ds_ref,
                       &ctx->ds_tgt, &ctx->match_ref, &ctx->match_tgt,
-                      &ctx->partials, &ctx->partials2, &ctx->tail_ticket, &ctx->tail_grows, &ctx->nn_bound, &ctx->late_ctl, &ctx->cert_count, &ctx->cert_prof, &ctx->cost_log, &ctx->phase_log, &ctx->shard_ref, &ctx->shard_tgt,
+                      &ctx->partials, &ctx->partials2, &ctx->bins, &ctx->nn_bound, &ctx->late_ctl, &ctx->cert_count, &ctx->cert_prof, &ctx->cost_log, &ctx->phase_log, &ctx->shard_ref, &ctx->shard_tgt,
                       &ctx->shard_ref_band, &ctx->shard_tgt_band, &ctx->shard_misc, &ctx->shard_flags, &ctx->shard_pos_t,
                       &ctx->shard_pos_s, &ctx->shard_stats, &ctx->ndt_sum_dev, &ctx->corr_tmp_idx, &ctx->corr_tmp_d2, &ctx->d_state};
     for (DevBuf *b : bufs) b->release();
@@ -1248,11 +1309,12 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
     XchgDev xchg{nullptr, nullptr, 0, 0, 0u};
     const bool in_kernel_exchange = blk && comm_exchange_args(comm, &xchg) == WM_OK;
     ctx->cert_launches = 0;
-    const bool tail_was_dirty = ctx->tail_dirty;
-    if (tail_was_dirty && ctx->tail_ticket.p) {
-        WM_HIP(ctx, hipMemsetAsync(ctx->tail_ticket.p, 0, kTailTickets * sizeof(unsigned), ctx->stream));
+    // the unsharded grid path adds its sums into bins (wm_bins.hpp) and solves from them: no k_reduce_rows, no rows
+    const bool use_bins = !brute && !blk && ctx->tune_fuse_stats && ctx->tune_bins != 0 && !ctx->cost_log.p;
+    if (use_bins) {
+        WM_TRY(bins_ready(ctx));  // (zeroes them if the last loop left them dirty)
+        ctx->bins_dirty = true;   // (until this loop has ended normally)
     }
-    ctx->tail_dirty = true;  // (until this loop has ended normally)
     std::vector<unsigned char> was_cert;
     std::vector<unsigned char> kind((size_t) max_it, 0);  // which search kernel iteration k got (1: certificate, 2: its first launch)
     std::vector<int> ev_slot((size_t) max_it, -1);        // profile: the iteration's first event in the pool
@@ -1467,9 +1529,7 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
                 WM_HIP(ctx, ctx->nn_bound.reserve(((size_t) ctx->n_src + 64) * sizeof(float4)));
                 WM_HIP(ctx, hipMemsetAsync(ctx->nn_bound.p, 0, ((size_t) ctx->n_src + 64) * sizeof(float4), ctx->stream));
             }
-            // (unsharded: the kernel's last workgroup runs the solve too -- rows comes back 0, nothing more to launch)
-            WM_TRY(launch_nn_cert(ctx, thr, e0, e1, e1b, p->mode, &rows, bounds_valid || slab, !blk && ctx->tune_tail != 0,
-                                  ctx->h_pub, ctx->h_pub_slots));
+            WM_TRY(launch_nn_cert(ctx, thr, e0, e1, e1b, p->mode, &rows, bounds_valid || slab, use_bins));
             kind[(size_t) it] = bounds_valid ? 1 : 2;
             bounds_valid = true;
             ctx->cert_launches++;
@@ -1478,7 +1538,7 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
                 was_cert[(size_t) it] = 1;
             }
         } else {
-            WM_TRY(launch_search_and_stats(ctx, thr, p->mode, e0, e1, e1b, &rows));
+            WM_TRY(launch_search_and_stats(ctx, thr, p->mode, e0, e1, e1b, &rows, use_bins));
             bounds_valid = false;
         }
         if (e2) WM_HIP(ctx, hipEventRecord(e2, ctx->stream));
@@ -1499,7 +1559,9 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
             WM_TRY(comm_allreduce(ctx, comm, blk, kBlkLen));
             if (eb) WM_HIP(ctx, hipEventRecord(eb, ctx->stream));
             WM_TRY(launch_reduce_solve<2>(ctx, 0, blk, ctx->h_pub, ctx->h_pub_slots, 1));
-        } else if (rows > 0) {
+        } else if (use_bins) {
+            WM_TRY(launch_bins_solve(ctx, ctx->h_pub, ctx->h_pub_slots));
+        } else {
             WM_TRY(launch_reduce_solve<3>(ctx, rows, nullptr, ctx->h_pub, ctx->h_pub_slots));
         }
         if (e3) WM_HIP(ctx, hipEventRecord(e3, ctx->stream));
@@ -1516,7 +1578,7 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
                           "(a peer failed or fell behind by more than the exchange's time limit)";
         return WM_ERR_RCCL;
     }
-    ctx->tail_dirty = false;
+    if (use_bins) ctx->bins_dirty = false;
     ctx->prev_mse = s.prev_mse;
     ctx->have_corr = true;
     ctx->last_align_valid = true;
@@ -1961,7 +2023,7 @@ int wm_set_option(wm_ctx *ctx, const char *name, double value) {
     else if (k == "cert_pad_mul" && value >= 0) ctx->tune_cert_pad_mul = (float) value;
     else if (k == "cert_pad_frac" && value >= 0) ctx->tune_cert_pad_frac = (float) value;
     else if (k == "late") ctx->tune_late = value != 0 ? 1 : 0;
-    else if (k == "tail") ctx->tune_tail = (int) value;
+    else if (k == "bins") ctx->tune_bins = (int) value;
     else if (k == "gicp_served") ctx->tune_gicp_served = value == 2 ? 2 : (value != 0 ? 1 : 0);
     else if (k == "gicp_serve_test_stall_ms") ctx->gicp_serve_test_stall_ms = (int) value;
     else return WM_ERR_ARG;

@@ -189,12 +189,12 @@ struct wm_ctx {
     wm::DevBuf cost_log;                    // developer: per-query search cost of every iteration (wm_debug_cost_log)
     int cost_log_iter = 0, cost_log_cap = 0;
     wm::DevBuf keys, partials, partials2, corr_tmp_idx, corr_tmp_d2, d_levels;
-    // the iteration's solve by the search's / row reduction's last workgroup (wm_solve_tail.hpp): ticket words (zero
-    // between launches) and the groups' rows
-    wm::DevBuf tail_ticket, tail_grows;
-    bool tail_dirty = false;     // an iteration loop is running or ended abnormally: tickets may be drawn
+    // the iteration's sums as exact integer limbs (wm_bins.hpp): all zero between iterations (the solve puts the
+    // zeros back)
+    wm::DevBuf bins;
+    bool bins_dirty = false;     // an iteration loop is running or ended abnormally: the bins may hold sums
     int tune_grid_variant = 0;   // developer: k_nn_grid<SVD, balanced> at other register budgets (wm_nn.hip: launch_nn_grid)
-    int tune_tail = 1;           // 0: the solve as a launch of its own (k_reduce_solve), as up to round 5
+    int tune_bins = 1;           // 0: rows of partial sums + k_reduce_rows + k_reduce_solve, as up to round 5
     wm::DevBuf nn_bound;                    // float4 per (sorted) source point, written by k_nn_cert's searches: where the query was (xyz) and a lower bound (w) on its distance, there, to every target point but its match
     wm::DevBuf cert_count;                  // developer: unsettled queries per launch of k_nn_cert ([launch][64] partial counts)
     wm::DevBuf cert_prof;                   // developer: phase cycle sums per launch of k_nn_cert ([launch][8][8])
@@ -400,7 +400,8 @@ int transform_cloud_dev(wm_ctx *ctx, const float4 *in, size_t n, const double T[
 // stats_mode < 0: search only; WM_ICP_SVD / WM_ICP_GN6: the search kernel also reduces the ICP
 // statistics of the iteration to *rows_out rows of kAcc doubles in ctx->partials
 int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2,
-                   int stats_mode = -1, unsigned *rows_out = nullptr);
+                   int stats_mode = -1, unsigned *rows_out = nullptr, bool use_bins = false);
+int bins_ready(wm_ctx *ctx);  // wm_icp.hip: the iteration's bins (wm_bins.hpp) allocated and all zero
 int launch_nn_brute(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1);
 // the resident form of the certificate kernel (wm_nn.hip: k_nn_cert<.., LATE>): the late iterations in one launch
 bool late_possible(wm_ctx *ctx, int stats_mode, unsigned *blocks_out);
@@ -428,8 +429,7 @@ int launch_fix_keys(wm_ctx *ctx, float thr_d2);  // after certified iterations: 
 // the certificate kernel (late iterations): stats_mode as above; bounds_valid = the previous search of
 // this align was launch_nn_cert too (its per-query bounds are still in ctx->nn_bound)
 int launch_nn_cert(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2, int stats_mode,
-                   unsigned *rows_out, bool bounds_valid, bool solve_inside = false, unsigned long long *pub = nullptr,
-                   int pub_slots = 0);
+                   unsigned *rows_out, bool bounds_valid, bool use_bins = false);
 // pinned host staging of the batched paths (wm_small.hip, wm_gicp_small.hip, wm_ndt_small.hip): grows, never shrinks
 inline int pinned_reserve(wm_ctx *ctx, void **p, size_t *cap, size_t bytes) {
     if (bytes <= *cap) return WM_OK;
@@ -478,8 +478,6 @@ float threshold_d2_strict(double max_corr);
 // ---- wm_icp.hip
 int shard_begin(wm_ctx *ctx, const wm_icp_params *p, double x_lo, double x_hi, double expect, double stripe_finite,
                 bool *brute_out, float *thr_out, double prev_mse0);
-struct TailArgs;
-int tail_args(wm_ctx *ctx, unsigned rows, unsigned long long *pub, int pub_slots, TailArgs *ta);  // wm_solve_tail.hpp
 // the iteration loop of one registration (state already uploaded); blk != nullptr: sharded (see wm_icp.hip)
 int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, struct wm_comm *comm, double *blk,
                  double T_out[16], wm_icp_stats *stats);

@@ -20,7 +20,7 @@
 //   k_nn_brute  LDS-tiled all-pairs search (small clouds / cross-check).
 #include "wm_internal.hpp"
 #include "wm_icp_step.hpp"
-#include "wm_solve_tail.hpp"
+#include "wm_bins.hpp"
 #include "wm_wave.hpp"
 
 #include <atomic>
@@ -910,7 +910,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
               float4 *__restrict__ match_pt, const float4 *__restrict__ tgt_orig,
               float r_light_cells, float lane_lf, float coop_lf, float r0_cells, unsigned xcd_chunk,
               double *__restrict__ partials, unsigned *__restrict__ cost_out,
-              unsigned long long *__restrict__ phase_out) {
+              unsigned long long *__restrict__ phase_out, long long *__restrict__ bins) {
+    // (bins != nullptr: the wave's sums are ADDED into the iteration's bins -- exact integer limbs, any order:
+    // wm_bins.hpp -- instead of being stored as a row of `partials` for k_reduce_rows to add up)
     // (the wave's life is a chain of memory round trips; the three streams of its chunk -- source
     // point, previous key, previous match -- need nothing but the block number for their addresses
     // and are requested before the state is looked at.  Before the first search keys / match_pt hold
@@ -1127,7 +1129,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                          (unsigned) best != (unsigned) seeded && (i_e & st->changed_mask) == 0u);
         acc_halve<kAcc, 32>(a, lane);
         const int comp = acc_comp_of_lane(lane);
-        if (comp >= 0) st_f64(&partials[(size_t) row * kAcc + comp], a[0], nt);
+        if (comp >= 0) {
+            if (bins) bins_add(bins, row % (unsigned) kBinCount, (unsigned) comp, a[0]);
+            else st_f64(&partials[(size_t) row * kAcc + comp], a[0], nt);
+        }
     }
     if constexpr (COST) {
         if (lane_e == 0 && phase_out) {
@@ -1358,9 +1363,10 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
               float4 *__restrict__ match_pt, float4 *__restrict__ bound, const float4 *__restrict__ tgt_orig,
               float r_light_cells, float lane_lf, float coop_lf, float r0_cells, unsigned xflags,
               double *__restrict__ partials, int bounds_valid, float pad_mul, float pad_frac,
-              unsigned *__restrict__ uns_count, unsigned long long *__restrict__ prof_out, LateArgs la, TailArgs ta) {
-    // (ta.ticket != nullptr, launched form only: the workgroups' rows are kTailRow doubles, stored at agent scope, and
-    // the LAST workgroup to finish adds them -- two levels -- and runs the iteration's solve: wm_solve_tail.hpp)
+              unsigned *__restrict__ uns_count, unsigned long long *__restrict__ prof_out, LateArgs la,
+              long long *__restrict__ bins) {
+    // (bins != nullptr, launched form only: the workgroup's sums and its count of searched queries are ADDED into
+    // the iteration's bins -- exact integer limbs, any order: wm_bins.hpp -- instead of stored as a row of `partials`)
     // (a wave's life is a chain of memory round trips: the phase's three streams are requested before
     // anything else is looked at -- their addresses need nothing but the block number)
     const unsigned lane = threadIdx.x & 63u;
@@ -1617,8 +1623,8 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
     if (uns_count && threadIdx.x == 0 && U) atomicAdd(&uns_count[blockIdx.x & 63u], U);  // developer statistics
     // how many queries this launch had to search: the solve kernel hands it to the host (one atomic per
     // workgroup, spread over 64 words)
-    // (with a solve tail the count travels in the workgroup's row: nobody touches the state while the kernel runs)
-    if (!LATE && !ta.ticket && threadIdx.x == 0 && U) atomicAdd(&st->cert_unsettled[blockIdx.x & 63u], U);
+    // (with bins the count is one of their components)
+    if (!LATE && !bins && threadIdx.x == 0 && U) atomicAdd(&st->cert_unsettled[blockIdx.x & 63u], U);
     const unsigned U_searched = U;
     if (dbg_skip == 1u && valid) U = 0;
     const unsigned nchunks = (U + 63u) / 64u;
@@ -1872,21 +1878,15 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
         // the four waves' sums, added in wave order
         if (comp >= 0) s_rows[wave][comp] = rowacc;
         __syncthreads();
-        if (ta.ticket) {
-            if (threadIdx.x < (unsigned) kTailRow) {
-                double t = 0.0;
-                if (threadIdx.x < (unsigned) kAcc) {
-                    t = s_rows[0][threadIdx.x];
+        if (bins) {
+            if (threadIdx.x < (unsigned) kAcc) {
+                double t = s_rows[0][threadIdx.x];
 #pragma unroll
-                    for (int w = 1; w < kCertWaves; ++w) t += s_rows[w][threadIdx.x];
-                } else if (threadIdx.x == (unsigned) kAcc) {
-                    t = (double) U_searched;
-                }
-                st_agent_f64(partials + (size_t) row * kTailRow + threadIdx.x, t);
+                for (int w = 1; w < kCertWaves; ++w) t += s_rows[w][threadIdx.x];
+                bins_add(bins, row % (unsigned) kBinCount, threadIdx.x, t);
+            } else if (threadIdx.x == (unsigned) kAcc && U_searched) {
+                bins_add_count(bins, row % (unsigned) kBinCount, (unsigned) kAcc, (long long) U_searched);
             }
-            // (the walks' LDS is free by now: every wave is past its last chunk)
-            static_assert(sizeof(TailLds<64 * kCertWaves>) <= sizeof(BalLds) * kCertWaves, "the tail's LDS overlays the walks'");
-            tail_finish<64 * kCertWaves>(partials, row, gridDim.x, true, st, ta, *reinterpret_cast<TailLds<64 * kCertWaves> *>(&s_L[0]));
         } else if (threadIdx.x < (unsigned) kAcc) {
             double t = s_rows[0][threadIdx.x];
 #pragma unroll
@@ -2006,20 +2006,22 @@ float threshold_d2_strict(double max_corr) {
 }
 
 template <int STATS, bool BAL, bool COST = false, int RC = kBalRowChunk, int WPE = 5>
-static void launch_nn_grid_t(wm_ctx *ctx, unsigned blocks, float thr_d2, unsigned xcd_chunk) {
+static void launch_nn_grid_t(wm_ctx *ctx, unsigned blocks, float thr_d2, unsigned xcd_chunk, long long *bins = nullptr) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_grid<STATS, BAL, COST, RC, WPE>), dim3(blocks), dim3(64), 0, ctx->stream,
                        ctx->d_levels.as<LevelsDev>(), ctx->src_sorted.as<float4>(), (unsigned) ctx->n_src,
                        ctx->d_state.as<IcpDevState>(), thr_d2, ctx->keys.as<unsigned long long>(),
                        ctx->match_pt.as<float4>(), ctx->tgt_orig.as<float4>(), ctx->tune_r_light,
                        ctx->tune_lane_lf, ctx->tune_coop_lf, ctx->tune_r0, xcd_chunk, ctx->partials.as<double>(),
                        ctx->cost_log.p ? ctx->cost_log.as<unsigned>() + (size_t) ctx->cost_log_iter * ctx->n_src : nullptr,
-                       ctx->phase_log.p ? ctx->phase_log.as<unsigned long long>() + 8 * (size_t) ctx->cost_log_iter : nullptr);
+                       ctx->phase_log.p ? ctx->phase_log.as<unsigned long long>() + 8 * (size_t) ctx->cost_log_iter : nullptr, bins);
 }
 
 // stats_mode < 0: search only.  WM_ICP_SVD / WM_ICP_GN6: the search kernel also leaves the ICP
 // statistics of this iteration as *rows_out rows of kAcc doubles in ctx->partials.
+// use_bins (with a stats_mode): the sums go into the iteration's bins (wm_bins.hpp) -- *rows_out is 0 then, and the
+// solve is launch_bins_solve
 int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2,
-                   int stats_mode, unsigned *rows_out) {
+                   int stats_mode, unsigned *rows_out, bool use_bins) {
     const unsigned n = (unsigned) ctx->n_src;
     if (rows_out) *rows_out = 0;
     if (n == 0) return WM_OK;
@@ -2032,7 +2034,11 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
         const unsigned m = 8u * xcd_chunk;
         blocks = (blocks + m - 1u) / m * m;
     }
-    if (stats_mode >= 0) {
+    long long *bins = nullptr;
+    if (stats_mode >= 0 && use_bins) {
+        WM_TRY(bins_ready(ctx));
+        bins = ctx->bins.as<long long>();
+    } else if (stats_mode >= 0) {
         WM_HIP(ctx, ctx->partials.reserve((size_t) blocks * kAcc * sizeof(double)));
         if (rows_out) *rows_out = blocks;
     }
@@ -2044,23 +2050,23 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
     const bool bal = ctx->tune_nn_balanced && ctx->n_tgt_input < (1u << 26) - 8u;
     if (ev0) WM_HIP(ctx, hipEventRecord(ev0, ctx->stream));
     if (stats_mode == WM_ICP_SVD && ctx->cost_log.p && ctx->cost_log_iter < ctx->cost_log_cap) {
-        if (bal) launch_nn_grid_t<WM_ICP_SVD, true, true>(ctx, blocks, thr_d2, xcd_chunk);  // developer statistics
-        else launch_nn_grid_t<WM_ICP_SVD, false, true>(ctx, blocks, thr_d2, xcd_chunk);
+        if (bal) launch_nn_grid_t<WM_ICP_SVD, true, true>(ctx, blocks, thr_d2, xcd_chunk, bins);  // developer statistics
+        else launch_nn_grid_t<WM_ICP_SVD, false, true>(ctx, blocks, thr_d2, xcd_chunk, bins);
         ctx->cost_log_iter++;
     } else if (stats_mode < 0) {
         if (bal) launch_nn_grid_t<-1, true>(ctx, blocks, thr_d2, xcd_chunk);
         else launch_nn_grid_t<-1, false>(ctx, blocks, thr_d2, xcd_chunk);
     } else if (stats_mode == WM_ICP_SVD) {
         // (developer: registers per wave of the production instantiation -- waves per SIMD 4 / 6 and rows per step 2)
-        if (bal && ctx->tune_grid_variant == 1) launch_nn_grid_t<WM_ICP_SVD, true, false, 3, 4>(ctx, blocks, thr_d2, xcd_chunk);
-        else if (bal && ctx->tune_grid_variant == 2) launch_nn_grid_t<WM_ICP_SVD, true, false, 3, 6>(ctx, blocks, thr_d2, xcd_chunk);
-        else if (bal && ctx->tune_grid_variant == 3) launch_nn_grid_t<WM_ICP_SVD, true, false, 2, 5>(ctx, blocks, thr_d2, xcd_chunk);
-        else if (bal && ctx->tune_grid_variant == 4) launch_nn_grid_t<WM_ICP_SVD, true, false, 2, 6>(ctx, blocks, thr_d2, xcd_chunk);
-        else if (bal) launch_nn_grid_t<WM_ICP_SVD, true>(ctx, blocks, thr_d2, xcd_chunk);
-        else launch_nn_grid_t<WM_ICP_SVD, false>(ctx, blocks, thr_d2, xcd_chunk);
+        if (bal && ctx->tune_grid_variant == 1) launch_nn_grid_t<WM_ICP_SVD, true, false, 3, 4>(ctx, blocks, thr_d2, xcd_chunk, bins);
+        else if (bal && ctx->tune_grid_variant == 2) launch_nn_grid_t<WM_ICP_SVD, true, false, 3, 6>(ctx, blocks, thr_d2, xcd_chunk, bins);
+        else if (bal && ctx->tune_grid_variant == 3) launch_nn_grid_t<WM_ICP_SVD, true, false, 2, 5>(ctx, blocks, thr_d2, xcd_chunk, bins);
+        else if (bal && ctx->tune_grid_variant == 4) launch_nn_grid_t<WM_ICP_SVD, true, false, 2, 6>(ctx, blocks, thr_d2, xcd_chunk, bins);
+        else if (bal) launch_nn_grid_t<WM_ICP_SVD, true>(ctx, blocks, thr_d2, xcd_chunk, bins);
+        else launch_nn_grid_t<WM_ICP_SVD, false>(ctx, blocks, thr_d2, xcd_chunk, bins);
     } else {
-        if (bal) launch_nn_grid_t<WM_ICP_GN6, true>(ctx, blocks, thr_d2, xcd_chunk);
-        else launch_nn_grid_t<WM_ICP_GN6, false>(ctx, blocks, thr_d2, xcd_chunk);
+        if (bal) launch_nn_grid_t<WM_ICP_GN6, true>(ctx, blocks, thr_d2, xcd_chunk, bins);
+        else launch_nn_grid_t<WM_ICP_GN6, false>(ctx, blocks, thr_d2, xcd_chunk, bins);
     }
     if (ev1) WM_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     if (ev2) WM_HIP(ctx, hipEventRecord(ev2, ctx->stream));
@@ -2069,7 +2075,7 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
 }
 
 template <int STATS, int NB, int RC>
-static void launch_nn_cert_t(wm_ctx *ctx, unsigned blocks, float thr_d2, unsigned xcd_chunk, bool bounds_valid, const TailArgs &ta) {
+static void launch_nn_cert_t(wm_ctx *ctx, unsigned blocks, float thr_d2, unsigned xcd_chunk, bool bounds_valid, long long *bins) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_cert<STATS, NB, RC, false>), dim3(blocks), dim3(64 * kCertWaves), 0, ctx->stream,
                        ctx->d_levels.as<LevelsDev>(), ctx->src_sorted.as<float4>(), (unsigned) ctx->n_src,
                        ctx->d_state.as<IcpDevState>(), thr_d2, ctx->keys.as<unsigned long long>(),
@@ -2081,21 +2087,21 @@ static void launch_nn_cert_t(wm_ctx *ctx, unsigned blocks, float thr_d2, unsigne
                            ? ctx->cert_count.as<unsigned>() + 64 * (size_t) ctx->cert_log_iter : nullptr,
                        ctx->cert_prof.p && ctx->cert_log_iter < ctx->cert_log_cap
                            ? ctx->cert_prof.as<unsigned long long>() + 64 * (size_t) ctx->cert_log_iter : nullptr,
-                       LateArgs{}, ta);
+                       LateArgs{}, bins);
 }
 
 template <int NB, int RC>
 static void launch_nn_cert_nb(wm_ctx *ctx, unsigned blocks, float thr_d2, unsigned xcd_chunk, bool bounds_valid,
-                              int stats_mode, const TailArgs &ta) {
-    if (stats_mode < 0) launch_nn_cert_t<-1, NB, RC>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid, TailArgs{});
-    else if (stats_mode == WM_ICP_SVD) launch_nn_cert_t<WM_ICP_SVD, NB, RC>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid, ta);
-    else launch_nn_cert_t<WM_ICP_GN6, NB, RC>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid, ta);
+                              int stats_mode, long long *bins) {
+    if (stats_mode < 0) launch_nn_cert_t<-1, NB, RC>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid, nullptr);
+    else if (stats_mode == WM_ICP_SVD) launch_nn_cert_t<WM_ICP_SVD, NB, RC>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid, bins);
+    else launch_nn_cert_t<WM_ICP_GN6, NB, RC>(ctx, blocks, thr_d2, xcd_chunk, bounds_valid, bins);
 }
 
-// solve_inside: the kernel's last workgroup adds the rows and runs the iteration's solve (wm_solve_tail.hpp; pub /
-// pub_slots: where it publishes the iteration's record) -- *rows_out is 0 then: nothing is left to launch
+// use_bins (with a stats_mode): sums and the searched-queries count go into the iteration's bins (wm_bins.hpp) --
+// *rows_out is 0 then, and the solve is launch_bins_solve
 int launch_nn_cert(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2, int stats_mode,
-                   unsigned *rows_out, bool bounds_valid, bool solve_inside, unsigned long long *pub, int pub_slots) {
+                   unsigned *rows_out, bool bounds_valid, bool use_bins) {
     const unsigned n = (unsigned) ctx->n_src;
     if (rows_out) *rows_out = 0;
     if (n == 0) return WM_OK;
@@ -2104,16 +2110,18 @@ int launch_nn_cert(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
     unsigned blocks = (n + per - 1u) / per;
     blocks = (blocks + 7u) & ~7u;  // xcd_remap needs a multiple of 8
     WM_HIP(ctx, ctx->nn_bound.reserve(((size_t) n + 64) * sizeof(float4)));
-    TailArgs ta{};
-    if (stats_mode >= 0) {
-        WM_HIP(ctx, ctx->partials.reserve((size_t) blocks * (solve_inside ? kTailRow : kAcc) * sizeof(double)));
-        if (rows_out) *rows_out = solve_inside ? 0u : blocks;
-        if (solve_inside) WM_TRY(tail_args(ctx, blocks, pub, pub_slots, &ta));
+    long long *bins = nullptr;
+    if (stats_mode >= 0 && use_bins) {
+        WM_TRY(bins_ready(ctx));
+        bins = ctx->bins.as<long long>();
+    } else if (stats_mode >= 0) {
+        WM_HIP(ctx, ctx->partials.reserve((size_t) blocks * kAcc * sizeof(double)));
+        if (rows_out) *rows_out = blocks;
     }
     const unsigned xflags = (ctx->tune_nn_nt_stores ? 0x10000000u : 0u) | (((unsigned) ctx->tune_cert_dbg_skip & 3u) << 26);
     if (ev0) WM_HIP(ctx, hipEventRecord(ev0, ctx->stream));
-    if (nb == 2) launch_nn_cert_nb<2, 3>(ctx, blocks, thr_d2, xflags, bounds_valid, stats_mode, ta);
-    else launch_nn_cert_nb<4, 3>(ctx, blocks, thr_d2, xflags, bounds_valid, stats_mode, ta);
+    if (nb == 2) launch_nn_cert_nb<2, 3>(ctx, blocks, thr_d2, xflags, bounds_valid, stats_mode, bins);
+    else launch_nn_cert_nb<4, 3>(ctx, blocks, thr_d2, xflags, bounds_valid, stats_mode, bins);
     if (ctx->cert_count.p && ctx->cert_log_iter < ctx->cert_log_cap) ctx->cert_log_iter++;
     if (ev1) WM_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     if (ev2) WM_HIP(ctx, hipEventRecord(ev2, ctx->stream));
@@ -2220,7 +2228,7 @@ int launch_nn_late(wm_ctx *ctx, float thr_d2, int stats_mode, unsigned blocks, b
                        ctx->match_pt.as<float4>(), ctx->nn_bound.as<float4>(), ctx->tgt_orig.as<float4>(),                \
                        ctx->tune_r_light, ctx->tune_lane_lf, ctx->tune_coop_lf, ctx->tune_r0, xflags,                     \
                        ctx->partials.as<double>(), bounds_valid ? 1 : 0, ctx->tune_cert_pad_mul, ctx->tune_cert_pad_frac, \
-                       (unsigned *) nullptr, (unsigned long long *) nullptr, la, TailArgs{})
+                       (unsigned *) nullptr, (unsigned long long *) nullptr, la, (long long *) nullptr)
     if (stats_mode == WM_ICP_SVD) WM_LATE_LAUNCH(WM_ICP_SVD);
     else WM_LATE_LAUNCH(WM_ICP_GN6);
 #undef WM_LATE_LAUNCH
