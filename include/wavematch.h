@@ -526,6 +526,12 @@ void wm_comm_destroy(wm_comm *comm);
 int wm_comm_allreduce_probe(wm_ctx *ctx, wm_comm *comm, int reps, double *us_out);
 int wm_comm_rank(const wm_comm *comm);
 int wm_comm_world(const wm_comm *comm);
+/* 1 while the group's sharded ICP loop exchanges through the ranks' mailboxes, 0 once it uses ncclAllReduce (never set
+ * up, WM_COMM_P2P=0, or dropped after an exchange that failed -- on EVERY rank alike: the loop's commit round makes the
+ * ranks agree).  wm_comm_set_exchange_timeout_ms: how long a solve kernel waits for a peer's block (default 5000 ms;
+ * 0 = a block that is not there at once counts as never coming: tests). */
+int wm_comm_mailboxes(const wm_comm *comm);
+int wm_comm_set_exchange_timeout_ms(wm_comm *comm, int ms);
 
 /* pcl::IterativeClosestPoint::align (wave_matching/src/icp.cpp:126-129) as ONE registration over
  * all ranks of `comm`.  Collective: every rank calls it with the same two (full) clouds and

@@ -181,6 +181,8 @@ def lib():
         L.wm_comm_rank.argtypes = [C.c_void_p]
         L.wm_comm_allreduce_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _dp]
         L.wm_comm_world.argtypes = [C.c_void_p]
+        L.wm_comm_mailboxes.argtypes = [C.c_void_p]
+        L.wm_comm_set_exchange_timeout_ms.argtypes = [C.c_void_p, C.c_int]
         L.wm_icp_align_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                            C.c_size_t, C.c_size_t, C.c_int, C.POINTER(IcpParams), _dp,
                                            C.POINTER(IcpStats)]
@@ -811,6 +813,16 @@ class Comm:
     @property
     def world(self):
         return lib().wm_comm_world(self.handle)
+
+    @property
+    def mailboxes(self):
+        """True while the sharded loop's exchange goes through the ranks' mailboxes (wm_comm_mailboxes)."""
+        return bool(lib().wm_comm_mailboxes(self.handle))
+
+    def set_exchange_timeout_ms(self, ms):
+        rc = lib().wm_comm_set_exchange_timeout_ms(self.handle, int(ms))
+        if rc != 0:
+            raise WmError("wm_comm_set_exchange_timeout_ms: %d" % rc)
 
     def close(self):
         if self.handle:

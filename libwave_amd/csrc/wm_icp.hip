@@ -391,11 +391,14 @@ __global__ void __launch_bounds__(THREADS)
             s_blk[kStatsLen + 1] = 0.0;
         }
         __syncthreads();
-        const bool arrived = xchg_allreduce<THREADS>(xd, s_blk, s_sum, s_half, s_ctl);
+        // ([kStatsLen + 1]: 0 in an iteration's block, 1 in the block of a rank's COMMIT round (k_xchg_commit): a rank
+        // that gave up on an earlier round is a round behind and sends its commit where the others expect an
+        // iteration -- they then fail at once instead of solving from it)
+        const bool arrived = xchg_allreduce<THREADS>(xd, s_blk, s_sum, s_half, s_ctl) && s_sum[kStatsLen + 1] == 0.0;
         if (threadIdx.x == 0) {
             s_st.dbg[0] = t_start;
             s_st.dbg[1] = clock64();
-            if (!arrived) {  // a peer never delivered: the registration ends here, on this rank, with an error
+            if (!arrived) {  // a peer never delivered (or has given up): the registration ends here, on this rank, with an error
                 s_st.xchg_failed = 1;
                 s_st.done = 1;
                 s_st.converged = 0;
@@ -460,6 +463,29 @@ __global__ void __launch_bounds__(THREADS)
     __syncthreads();
     for (unsigned w = threadIdx.x; w < kWords; w += THREADS)
         reinterpret_cast<unsigned *>(st)[w] = reinterpret_cast<const unsigned *>(&s_st)[w];
+}
+
+// The COMMIT round of a sharded registration whose exchange ran through the mailboxes (wm_xchg.hpp): after the last
+// iteration every rank sends {did every round of mine arrive in time?, 1} and adds up what the others sent.  A rank
+// whose wait timed out in the LAST executed round would otherwise end with an error while a slow peer that still got
+// every block ends well -- and the next registration would find one of them in ncclAllReduce and the other polling its
+// mailbox.  With this round the verdict is the same on every rank: all of them ended well, or all of them fail this
+// registration (and all of them leave the mailboxes for the collective, wm_shard.hip).
+__global__ void __launch_bounds__(kBlock) k_xchg_commit(IcpDevState *st, XchgDev xd) {
+    __shared__ double s_blk[kBlkLen], s_sum[kBlkLen];
+    __shared__ unsigned s_half[kXMaxWorld * kXWords], s_ctl[2];
+    if (threadIdx.x < (unsigned) kBlkLen) s_blk[threadIdx.x] = 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_blk[0] = st->xchg_failed ? 0.0 : 1.0;
+        s_blk[kStatsLen + 1] = 1.0;
+    }
+    __syncthreads();
+    const bool arrived = xchg_allreduce<kBlock>(xd, s_blk, s_sum, s_half, s_ctl);
+    if (threadIdx.x == 0 && (!arrived || s_sum[0] != (double) xd.world || s_sum[kStatsLen + 1] != (double) xd.world)) {
+        st->xchg_failed = 1;
+        st->converged = 0;
+    }
 }
 
 // keys (source-sorted order) -> caller-order (match index, d2)
@@ -1567,6 +1593,10 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
         if (e3) WM_HIP(ctx, hipEventRecord(e3, ctx->stream));
         WM_HIP(ctx, hipGetLastError());
     }
+    if (in_kernel_exchange) {  // every rank, whatever it saw: the ranks agree on how the exchange went (k_xchg_commit)
+        hipLaunchKernelGGL(k_xchg_commit, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->d_state.as<IcpDevState>(), xchg);
+        WM_HIP(ctx, hipGetLastError());
+    }
     if (ctx->cert_launches > 0) WM_TRY(launch_fix_keys(ctx, thr));
     WM_TRY(download_state(ctx));
     WM_HIP(ctx, hipEventRecord(ctx->ev_b, ctx->stream));
@@ -1574,8 +1604,9 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
     const IcpDevState &s = *ctx->h_state;
     if (s.xchg_failed) {
         ctx->xchg_timed_out = true;
-        ctx->last_error = "sharded registration: a rank's block did not arrive in this rank's mailbox in time "
-                          "(a peer failed or fell behind by more than the exchange's time limit)";
+        ctx->last_error = "sharded registration: a rank's block did not arrive in a mailbox in time, on this rank or -- as "
+                          "the commit round told -- on a peer (a rank failed or fell behind by more than the exchange's "
+                          "time limit); every rank of the group fails this registration alike";
         return WM_ERR_RCCL;
     }
     if (use_bins) ctx->bins_dirty = false;

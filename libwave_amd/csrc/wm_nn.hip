@@ -2036,7 +2036,7 @@ int launch_nn_grid(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
     }
     long long *bins = nullptr;
     if (stats_mode >= 0 && use_bins) {
-        WM_TRY(bins_ready(ctx));
+        if (!ctx->bins.p) return WM_ERR_STATE;  // (the caller's loop made them ready: bins_ready, wm_icp.hip)
         bins = ctx->bins.as<long long>();
     } else if (stats_mode >= 0) {
         WM_HIP(ctx, ctx->partials.reserve((size_t) blocks * kAcc * sizeof(double)));
@@ -2112,7 +2112,7 @@ int launch_nn_cert(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
     WM_HIP(ctx, ctx->nn_bound.reserve(((size_t) n + 64) * sizeof(float4)));
     long long *bins = nullptr;
     if (stats_mode >= 0 && use_bins) {
-        WM_TRY(bins_ready(ctx));
+        if (!ctx->bins.p) return WM_ERR_STATE;  // (the caller's loop made them ready: bins_ready, wm_icp.hip)
         bins = ctx->bins.as<long long>();
     } else if (stats_mode >= 0) {
         WM_HIP(ctx, ctx->partials.reserve((size_t) blocks * kAcc * sizeof(double)));

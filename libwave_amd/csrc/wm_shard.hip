@@ -91,7 +91,7 @@ static int mailbox_alloc(wm_comm *c) {
     c->mail = static_cast<unsigned long long *>(p);
     if (const char *e = getenv("WM_COMM_P2P_TIMEOUT_MS")) {
         const int v = atoi(e);
-        if (v >= 0) c->p2p_timeout_ms = (unsigned) v;  // (0: a block that is not there within 64 looks is "late" -- tests)
+        if (v >= 0) c->p2p_timeout_ms = (unsigned) v;  // (0: a block that is not there at the first look is "late" -- tests)
     }
     return WM_OK;
 }
@@ -810,6 +810,12 @@ int wm_comm_allreduce_probe(wm_ctx *ctx, wm_comm *comm, int reps, double *us_out
 
 int wm_comm_rank(const wm_comm *c) { return c ? c->rank : -1; }
 int wm_comm_world(const wm_comm *c) { return c ? c->world : 0; }
+int wm_comm_mailboxes(const wm_comm *c) { return c && c->p2p ? 1 : 0; }
+int wm_comm_set_exchange_timeout_ms(wm_comm *c, int ms) {
+    if (!c || ms < 0) return WM_ERR_ARG;
+    c->p2p_timeout_ms = (unsigned) ms;
+    return WM_OK;
+}
 
 // One registration, sharded.  Collective: every rank calls it with the same two clouds and the
 // same parameters.  Everything that depends on the clouds -- slab edges, the rank's slab + halo of
@@ -987,11 +993,18 @@ int wm_icp_align_sharded(wm_ctx *ctx, wm_comm *comm, const void *ref, size_t n_r
     // peers' pending collectives too.  The communicator is finished after that; argument errors are
     // returned before anything collective has started and abort nothing.
     if (ctx && ctx->xchg_timed_out) {
-        // ... except when what failed is the exchange through the mailboxes (a peer's block did not arrive): the
-        // communicator itself is intact, and this rank stops using its mailboxes -- its next registration exchanges
-        // by ncclAllReduce (all ranks of a group whose exchange failed time out alike; wm_multi_icp_match retries)
+        // ... except when what failed is the exchange through the mailboxes (a block did not arrive somewhere in the
+        // group): this rank stops using its mailboxes, and SO DOES EVERY OTHER RANK -- the commit round at the end of a
+        // registration's loop (k_xchg_commit, wm_icp.hip) hands every rank the same verdict, so the group's next
+        // registration exchanges by ncclAllReduce on all ranks (wm_multi_icp_match retries).  Whether the peer that
+        // was late is still alive this rank cannot know: a peer that has died or aborted its communicator makes that
+        // collective fail or block as any RCCL collective would -- callers that see WM_ERR_RCCL here should rebuild
+        // communicator and contexts if it happens again (bench.py does on the first registration).
         ctx->xchg_timed_out = false;
-        if (comm) comm->p2p = false;
+        if (comm) {
+            comm->p2p = false;
+            comm->last_error = "mailbox exchange failed in a sharded registration: the group exchanges by ncclAllReduce from now on";
+        }
         return rc;
     }
     if ((rc == WM_ERR_HIP || rc == WM_ERR_RCCL || rc == WM_ERR_NOMEM) && comm && comm->nccl && comm->world > 1) {

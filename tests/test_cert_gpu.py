@@ -49,6 +49,16 @@ def _cases():
     rng = np.random.Generator(np.random.PCG64(3))
     q = (lat[rng.permutation(len(lat))[:5000]] + np.float32(0.125)).astype(np.float32)
     out.append(("lattice-ties", q, lat, 1.0))
+    # UTM-like coordinates: the pair of the first case 1e4 .. 5e4 m from the origin -- 4 mm float
+    # spacing in y, where the grid search had its stress case (test_nn_stress_gpu.py) and the certificate's cushions
+    # (1e-4 relative + 1e-6 m on either side of the comparison) had only been argued
+    ref, tgt, T = synth.pair(30000, seed=5, mode="resample")
+    off = np.array([12345.0, -54321.0, 250.0])
+    ref_o = (ref.astype(np.float64) + off).astype(np.float32)
+    # (the same rigid motion about the shifted scene's own centre: x -> R (x - off) + t + off)
+    other = (tgt.astype(np.float64) - T[:3, 3]) @ T[:3, :3]          # undo T: the re-sampled, noisy scene
+    tgt_o = ((other @ T[:3, :3].T) + T[:3, 3] + off).astype(np.float32)
+    out.append(("utm-offset", ref_o, tgt_o, 3.0))
     return out
 
 

@@ -214,6 +214,61 @@ def test_multi_goes_back_to_the_collective_exchange_when_the_mailboxes_fail():
     assert out.returncode == 0 and "FALLBACK OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
 
 
+_MAILBOX_DISAGREE = r"""
+import os, sys, threading
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+os.environ["WM_COMM_P2P_LOCAL"] = "1"
+os.environ["WM_COMM_P2P_TIMEOUT_MS"] = "4000"
+from libwave_amd import capi as wm, synth
+ref, tgt, _ = synth.pair(40000, seed=17)
+world = 2
+ctxs = [wm.Context(0) for _ in range(world)]
+comms = wm.Comm.init_local(world, 0)
+assert all(c.mailboxes for c in comms)
+def run_group(iters):
+    outs = [None] * world
+    def run(r):
+        try:
+            outs[r] = ctxs[r].icp_align_sharded(comms[r], ref, tgt, max_corr=3.0, force_iterations=iters, nn_method=wm.WM_NN_GRID)
+        except wm.WmError as e:
+            outs[r] = e
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    return outs
+warm = run_group(3)          # (buffers grown: no first-call allocation stalls the exchange below)
+assert all(isinstance(o, dict) and o["rc"] == 0 and o["exchange_in_kernel"] == 1 for o in warm), warm
+# ONE rank gives up at once (a time limit of zero), the other would wait 4 s: without the commit round rank 1 could
+# end its registration with an error and rank 0 well -- and the next registration would find them on different exchanges
+comms[1].set_exchange_timeout_ms(0)
+bad = run_group(40)          # (40 rounds: rank 1 is the first to reach one of them, finds nothing, gives up)
+assert all(isinstance(o, wm.WmError) for o in bad), bad        # BOTH ranks fail this registration ...
+assert not any(c.mailboxes for c in comms)                      # ... and BOTH have left the mailboxes
+good = run_group(8)                                             # the group goes on with the collective exchange
+assert all(isinstance(o, dict) and o["rc"] == 0 and o["exchange_in_kernel"] == 0 for o in good), good
+assert np.array_equal(good[0]["T"], good[1]["T"])
+for c in reversed(comms):
+    c.close()
+print("DISAGREE OK")
+"""
+
+
+def test_ranks_agree_on_a_failed_mailbox_exchange():
+    """a mailbox time-out used to be every rank's private affair -- one rank could fail a
+    registration and fall back to ncclAllReduce while its peer, which had still received every block, ended well and
+    kept polling mailboxes: the next registration hung.  The commit round at the end of the loop (k_xchg_commit) makes
+    the verdict the group's: here one of two ranks gets a time limit of zero -- both fail that registration, both leave
+    the mailboxes, and the next registration runs on the collective exchange on both."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    out = subprocess.run([sys.executable, "-c", _MAILBOX_DISAGREE, root], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "DISAGREE OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
 def test_icp_8m_in_8_slabs_full_registration(wm):
     """BASELINE configs[4]: ICP 8M<->8M as ONE registration in 8 slabs, all 50 iterations, equal to
     the unsharded registration of the same pair."""
