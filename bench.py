@@ -928,6 +928,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # N > 1 (or the one-rank plumbing check): north_star names "RCCL all-reduce over xGMI" as the exchange, the library's
+    # default is its own mailbox exchange inside the solve kernel.  When mailboxes ran, the SAME registration is timed
+    # once more, shortly, with the group rebuilt on ncclAllReduce (WM_COMM_P2P=0): the line carries both.
+    other_exchange = None
+    if comm is not None and not exchange_fallback and bool(r.get("exchange_in_kernel")) and os.environ.get("WM_COMM_P2P", "1") != "0":
+        try:
+            rebuild_collective()
+            ctx, comm = box["ctx"], box["comm"]
+            for _ in range(2):
+                one(0)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t1 = time.perf_counter()
+            k2 = max(3, min(a.steps, 5))
+            for _ in range(k2):
+                r2 = one(0)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            other_exchange = {"exchange": "ncclAllReduce(34 f64) on the context's stream between a rank's sums and its solve",
+                              "steps": k2, "ms_per_step": float(tt.item()) / k2 * 1e3,
+                              "exchange_in_kernel": int(r2.get("exchange_in_kernel", 0)),
+                              "same_transform_as_the_mailbox_run": bool(np.array_equal(r2["T"], r["T"]))}
+        except Exception as ex:  # (never lose the line over the extra measurement)
+            other_exchange = {"error": str(ex)}
+
     if rank == 0:
         pmc = pmc_summary() if world == 1 else {}
         peak_copy = ctx.copy_bandwidth() if world == 1 else None
@@ -935,6 +962,14 @@ def main():
                             pmc=pmc, peak_copy=peak_copy, sharded=comm is not None, ar_us=ar_us)
         if comm is not None:
             out["config"]["sharding"]["exchange_fell_back_to_collective"] = bool(exchange_fallback)
+            out["config"]["sharding"]["exchange_that_ran"] = "mailboxes" if r.get("exchange_in_kernel") else "ncclAllReduce"
+            out["config"]["sharding"]["ms_per_step_this_exchange"] = elapsed / a.steps * 1e3
+            if other_exchange is not None:
+                out["config"]["sharding"]["collective_exchange"] = other_exchange
+                if "ms_per_step" in other_exchange:
+                    # (scalar keys of `config`: the driver's record keeps those)
+                    out["config"]["ms_per_step_mailbox_exchange"] = elapsed / a.steps * 1e3
+                    out["config"]["ms_per_step_rccl_allreduce_exchange"] = other_exchange["ms_per_step"]
         value = out["value"]
         if world == 1 and dist is None and not a.no_host_clouds:
             # the same registration from HOST clouds: H2D of both clouds inside the step

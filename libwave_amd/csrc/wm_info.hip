@@ -53,8 +53,8 @@ struct InfoArgs {
     float Tf[12];      // float transform giving PCL's `final` cloud from the source
     double D[6];       // LUM pose-difference estimate (second pass)
     double X[3];       // Censi: translation of the result
-    double cr, sr, cp, sp, cy, sy;
-    double sph[6];     // Censi: diag(lin, ang, ang, lin, ang, ang)
+    double Rk[3][9];   // Censi: dR/dr, dR/dp, dR/dy of R = Rz(y) Ry(p) Rx(r) at the result's angles (row-major)
+    double sd[6];      // Censi: square roots of diag(lin, ang, ang, lin, ang, ang)
     // sharded registration: only the pairs of the queries this rank OWNED when they were searched count
     // (transformed x, under the pose of that search, inside the rank's slab); the ranks' sums are added
     float Tg[12];
@@ -129,196 +129,181 @@ __global__ void __launch_bounds__(kBlock)
     block_reduce_store<1>(a, partials);
 }
 
-// Censi: a[0..20] = upper triangle of d2J_dX2, a[21..41] = upper triangle of `middle`
-__global__ void __launch_bounds__(kBlock)
-    k_censi(const float4 *__restrict__ src, unsigned n, const unsigned long long *__restrict__ keys,
-            const float4 *__restrict__ tgt, InfoArgs A, double *__restrict__ partials) {
-    double a[42];
+// ---- Censi's covariance (estimateCensi, icp.cpp:167-397), from the STRUCTURE of its cost, not from its expanded text.
+// The reference's J = sum |e|^2, e = t + R(r, p, y) a - b  over the pairs (a = matched target point Z1..Z3, b = source
+// point Z4..Z6, x = (t, r, p, y), R = Rz(y) Ry(p) Rx(r)).  It carries machine-expanded expressions of d2J/dx2 and
+// d2J/dz dx (130 lines of products of sines and cosines).  Differentiating e instead, with R_k = dR/d theta_k and
+// R_kl = d2R/d theta_k d theta_l (nine + eighteen numbers per launch, formed once on the host):
+//     d2J/dx2   = 2 [[ n I,  R_k (sum a) ], [ . ,  Theta ]],   Theta_kl = sum (t - b) . (R_kl a)
+//                 (the a-quadratic terms of 2 d_k.d_l + 2 e.(R_kl a) cancel identically: differentiate R^T R = I twice)
+//     d2J/dz dx = [ P | Q ],   P = [2 R^T ; -2 I]  (the same for every pair),
+//                 Q = [ 2 (R_r^T c, R_p^T c, R_y^T c) ; -2 (R_r a, R_p a, R_y a) ],  c = t - b
+//                 (again R^T R_k + R_k^T R = 0 removes every a-dependent term of the upper block)
+//     middle    = sum G cov_Z G^T = P (sum C_a) P^T + sum Q C_b Q^T,   cov_Z = diag(C_a, C_b) (spherical Jacobians)
+// so the Hessian needs only the sums n, sum a, sum b a^T (thirteen: ICP's own statistics), the constant block only
+// sum C_a (six), and the per-pair work is Q C_b Q^T = (Q K_b)(Q K_b)^T with K_b = J_b sqrt(diag): ~250 f64 operations
+// on forty accumulators and no 36-element temporaries -- 394 registers (one wave per SIMD) before.  Against the oracle's
+// literal restatement of the reference's text: 5e-10 of the largest entry on both matrices (its float sub-products, e.g.
+// 2 * Z3 * Z4 formed in float, are double here), 1e-6 relative on the information matrix (tests/test_info_gpu.py).
+// sums: [0] n, [1..3] sum a, [4..12] sum b_i a_j, [13..18] sum C_a (upper), [19..39] sum (Q/2) C_b (Q/2)^T (upper)
+constexpr int kCensiSums = 40;
+
+__device__ __forceinline__ void censi_sph_jacobian(float x, float y, float z, const double *sd /* sqrt of 3 variances */,
+                                                   double (&K)[3][3]) {
+    // d(point)/d(range, bearing, azimuth) as the reference forms it (icp.cpp:217-247: float range / angles from the
+    // float coordinates, double sines and cosines of them), columns scaled by the standard deviations
+    const double rg = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+    const double br = atan2f(y, x);
+    const double az = atanf(__fdiv_rn(z, sqrtf(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)))));
+    const double cb = cos(br), sb = sin(br), ca = cos(az), sa = sin(az);
+    K[0][0] = cb * sa * sd[0];
+    K[1][0] = sb * sa * sd[0];
+    K[2][0] = ca * sd[0];
+    K[0][1] = -rg * sb * sa * sd[1];
+    K[1][1] = rg * cb * sa * sd[1];
+    K[2][1] = 0.0;
+    K[0][2] = rg * cb * ca * sd[2];
+    K[1][2] = rg * ca * sb * sd[2];
+    K[2][2] = -rg * sa * sd[2];
+}
+
+// (two halves, blockIdx.y says which: the statistics and sum C_a -- the target points' trigonometry --, or the per-pair
+// products -- the source points' --: forty accumulators plus a pair's temporaries in one body took 173 registers)
+template <int PART>
+__device__ __forceinline__ void censi_part(const float4 *__restrict__ src, unsigned n, const unsigned long long *__restrict__ keys,
+                                           const float4 *__restrict__ tgt, const InfoArgs &A, double *__restrict__ partials) {
+    constexpr int kN = PART == 0 ? 19 : 21;
+    double acc[kN];
 #pragma unroll
-    for (int k = 0; k < 42; ++k) a[k] = 0.0;
-    const double cr = A.cr, sr = A.sr, cp = A.cp, sp = A.sp, cy = A.cy, sy = A.sy;
-    const double X1 = A.X[0], X2 = A.X[1], X3 = A.X[2];
+    for (int k = 0; k < kN; ++k) acc[k] = 0.0;
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const unsigned idx = (unsigned) keys[i];
         if (idx == kNoIdx || !info_owned(A, src[i])) continue;
         const float4 t4 = tgt[idx], s4 = src[i];
-        const float Z1 = t4.x, Z2 = t4.y, Z3 = t4.z, Z4 = s4.x, Z5 = s4.y, Z6 = s4.z;
-        // spherical-coordinate Jacobians of both points (icp.cpp:225-247)
-        double j[36];
+        const double a[3] = {t4.x, t4.y, t4.z}, b[3] = {s4.x, s4.y, s4.z};
+        double K[3][3];
+        if constexpr (PART == 0) {
+            acc[0] += 1.0;
 #pragma unroll
-        for (int k = 0; k < 36; ++k) j[k] = 0.0;
-        {
-            double rg = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(Z1, Z1), __fmul_rn(Z2, Z2)), __fmul_rn(Z3, Z3)));
-            double br = atan2f(Z2, Z1);
-            double az = atanf(__fdiv_rn(Z3, sqrtf(__fadd_rn(__fmul_rn(Z1, Z1), __fmul_rn(Z2, Z2)))));
-            const double cb = cos(br), sb = sin(br), ca = cos(az), sa = sin(az);
-            j[0 * 6 + 0] = cb * sa;
-            j[1 * 6 + 0] = sb * sa;
-            j[2 * 6 + 0] = ca;
-            j[0 * 6 + 1] = -rg * sb * sa;
-            j[1 * 6 + 1] = rg * cb * sa;
-            j[0 * 6 + 2] = rg * cb * ca;
-            j[1 * 6 + 2] = rg * ca * sb;
-            j[2 * 6 + 2] = -rg * sa;
-        }
-        {
-            double rg = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(Z4, Z4), __fmul_rn(Z5, Z5)), __fmul_rn(Z6, Z6)));
-            double br = atan2f(Z5, Z4);
-            double az = atanf(__fdiv_rn(Z6, sqrtf(__fadd_rn(__fmul_rn(Z4, Z4), __fmul_rn(Z5, Z5)))));
-            const double cb = cos(br), sb = sin(br), ca = cos(az), sa = sin(az);
-            j[3 * 6 + 3] = cb * sa;
-            j[4 * 6 + 3] = sb * sa;
-            j[5 * 6 + 3] = ca;
-            j[3 * 6 + 4] = -rg * sb * sa;
-            j[4 * 6 + 4] = rg * cb * sa;
-            j[3 * 6 + 5] = rg * cb * ca;
-            j[4 * 6 + 5] = rg * ca * sb;
-            j[5 * 6 + 5] = -rg * sa;
-        }
-        // cov_Z = j * diag(sph) * j^T: block diagonal (two 3x3 blocks)
-        double cz[36];
+            for (int j = 0; j < 3; ++j) acc[1 + j] += a[j];
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                double s = 0;
+                for (int j = 0; j < 3; ++j) acc[4 + 3 * r + j] += b[r] * a[j];
+            censi_sph_jacobian(t4.x, t4.y, t4.z, A.sd, K);
+            int u = 13;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) s += j[r * 6 + k] * A.sph[k] * j[c * 6 + k];
-                cz[r * 6 + c] = s;
-            }
-        // d2J_dX2, upper triangle (icp.cpp:258-312); float operands keep the
-        // reference's float sub-products (e.g. 2 * Z3 * Z4 is formed in float)
-        const double w1 = sr * sy + cr * cy * sp, w2 = cr * sy - cy * sr * sp;
-        const double w3 = cy * sr - cr * sp * sy, w4 = cr * cy + sr * sp * sy;
-        int u = 0;
-        // row 0
-        a[u++] += 2;
-        u += 2;  // (0,1), (0,2) stay zero
-        a[u++] += 2 * Z2 * w1 + 2 * Z3 * w2;
-        a[u++] += 2 * cy * (Z3 * cr * cp - Z1 * sp + Z2 * cp * sr);
-        a[u++] += 2 * Z3 * w3 - 2 * Z2 * w4 - 2 * Z1 * cp * sy;
-        // row 1
-        a[u++] += 2;
-        u += 1;  // (1,2)
-        a[u++] += -2 * Z2 * w3 - 2 * Z3 * w4;
-        a[u++] += 2 * sy * (Z3 * cr * cp - Z1 * sp + Z2 * cp * sr);
-        a[u++] += 2 * Z3 * w1 - 2 * Z2 * w2 + 2 * Z1 * cp * cy;
-        // row 2
-        a[u++] += 2;
-        a[u++] += 2 * cp * (Z2 * cr - Z3 * sr);
-        a[u++] += -2 * Z1 * cp - 2 * Z3 * cr * sp - 2 * Z2 * sr * sp;
-        u += 1;  // (2,5) is zero
-        // row 3
-        a[u++] += (2 * Z2 * w2 - 2 * Z3 * w1) * (X1 - Z4 - Z2 * w2 + Z3 * w1 + Z1 * cp * cy) -
-                  (2 * Z2 * w4 - 2 * Z3 * w3) * (X2 - Z5 + Z2 * w4 - Z3 * w3 + Z1 * cp * sy) -
-                  (2 * Z3 * cr * cp + 2 * Z2 * cp * sr) * (X3 - Z6 - Z1 * sp + Z3 * cr * cp + Z2 * cp * sr) +
-                  (Z2 * w1 + Z3 * w2) * (2 * Z2 * w1 + 2 * Z3 * w2) +
-                  (Z2 * w3 + Z3 * w4) * (2 * Z2 * w3 + 2 * Z3 * w4) +
-                  (Z2 * cr * cp - Z3 * cp * sr) * (2 * Z2 * cr * cp - 2 * Z3 * cp * sr);
-        a[u++] += -2 * (Z2 * cr - Z3 * sr) *
-                  (X3 * sp - Z6 * sp - X1 * cp * cy + Z4 * cp * cy - X2 * cp * sy + Z5 * cp * sy);
-        a[u++] += 2 * X1 * Z3 * cr * cy - 2 * Z3 * Z4 * cr * cy + 2 * X1 * Z2 * cy * sr +
-                  2 * X2 * Z3 * cr * sy - 2 * Z2 * Z4 * cy * sr - 2 * Z3 * Z5 * cr * sy +
-                  2 * X2 * Z2 * sr * sy - 2 * Z2 * Z5 * sr * sy + 2 * X2 * Z2 * cr * cy * sp -
-                  2 * Z2 * Z5 * cr * cy * sp - 2 * X1 * Z2 * cr * sp * sy - 2 * X2 * Z3 * cy * sr * sp +
-                  2 * Z2 * Z4 * cr * sp * sy + 2 * Z3 * Z5 * cy * sr * sp + 2 * X1 * Z3 * sr * sp * sy -
-                  2 * Z3 * Z4 * sr * sp * sy;
-        // row 4
-        {
-            const double k1 = Z3 * cr * cp - Z1 * sp + Z2 * cp * sr;
-            const double k2 = Z1 * cp + Z3 * cr * sp + Z2 * sr * sp;
-            a[u++] += k2 * (2 * Z1 * cp + 2 * Z3 * cr * sp + 2 * Z2 * sr * sp) -
-                      (2 * Z3 * cr * cp - 2 * Z1 * sp + 2 * Z2 * cp * sr) *
-                          (X3 - Z6 - Z1 * sp + Z3 * cr * cp + Z2 * cp * sr) +
-                      2 * cy * cy * pow(k1, 2) + 2 * sy * sy * pow(k1, 2) -
-                      2 * cy * k2 *
-                          (X1 - Z4 + Z1 * cp * cy - Z2 * cr * sy + Z3 * sr * sy + Z2 * cy * sr * sp +
-                           Z3 * cr * cy * sp) -
-                      2 * sy * k2 *
-                          (X2 - Z5 + Z2 * cr * cy + Z1 * cp * sy - Z3 * cy * sr + Z3 * cr * sp * sy +
-                           Z2 * sr * sp * sy);
-            a[u++] += 2 * k1 * (X2 * cy - Z5 * cy - X1 * sy + Z4 * sy);
-        }
-        // row 5
-        a[u++] += 2 * Z1 * Z4 * cp * cy - 2 * X2 * Z2 * cr * cy - 2 * X1 * Z1 * cp * cy +
-                  2 * Z2 * Z5 * cr * cy + 2 * X1 * Z2 * cr * sy - 2 * X2 * Z1 * cp * sy +
-                  2 * X2 * Z3 * cy * sr - 2 * Z2 * Z4 * cr * sy + 2 * Z1 * Z5 * cp * sy -
-                  2 * Z3 * Z5 * cy * sr - 2 * X1 * Z3 * sr * sy + 2 * Z3 * Z4 * sr * sy -
-                  2 * X1 * Z3 * cr * cy * sp + 2 * Z3 * Z4 * cr * cy * sp - 2 * X1 * Z2 * cy * sr * sp -
-                  2 * X2 * Z3 * cr * sp * sy + 2 * Z2 * Z4 * cy * sr * sp + 2 * Z3 * Z5 * cr * sp * sy -
-                  2 * X2 * Z2 * sr * sp * sy + 2 * Z2 * Z5 * sr * sp * sy;
-
-        // d2J_dZdX (icp.cpp:322-386)
-        double G[36];
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int k = 0; k < 36; ++k) G[k] = 0.0;
-#define G_(r, c) G[(r) * 6 + (c)]
-        G_(3, 0) = -2;
-        G_(4, 1) = -2;
-        G_(5, 2) = -2;
-        G_(0, 0) = 2 * cp * cy;
-        G_(1, 0) = 2 * cy * sr * sp - 2 * cr * sy;
-        G_(2, 0) = 2 * sr * sy + 2 * cr * cy * sp;
-        G_(0, 1) = 2 * cp * sy;
-        G_(1, 1) = 2 * cr * cy + 2 * sr * sp * sy;
-        G_(2, 1) = 2 * cr * sp * sy - 2 * cy * sr;
-        G_(0, 2) = -2 * sp;
-        G_(1, 2) = 2 * cp * sr;
-        G_(2, 2) = 2 * cr * cp;
-        G_(1, 3) = 2 * X3 * cr * cp - 2 * Z6 * cr * cp - 2 * X2 * cy * sr + 2 * Z5 * cy * sr +
-                   2 * X1 * sr * sy - 2 * Z4 * sr * sy + 2 * X2 * cr * sp * sy - 2 * Z5 * cr * sp * sy +
-                   2 * X1 * cr * cy * sp - 2 * Z4 * cr * cy * sp;
-        G_(2, 3) = 2 * Z5 * cr * cy - 2 * X2 * cr * cy + 2 * X1 * cr * sy - 2 * X3 * cp * sr -
-                   2 * Z4 * cr * sy + 2 * Z6 * cp * sr - 2 * X1 * cy * sr * sp + 2 * Z4 * cy * sr * sp -
-                   2 * X2 * sr * sp * sy + 2 * Z5 * sr * sp * sy;
-        G_(3, 3) = -2 * Z2 * w1 - 2 * Z3 * w2;
-        G_(4, 3) = 2 * Z2 * w3 + 2 * Z3 * w4;
-        G_(5, 3) = -2 * cp * (Z2 * cr - Z3 * sr);
-        G_(0, 4) = 2 * Z6 * cp - 2 * X3 * cp - 2 * X1 * cy * sp + 2 * Z4 * cy * sp - 2 * X2 * sp * sy +
-                   2 * Z5 * sp * sy;
-        {
-            const double k3 = X3 * sp - Z6 * sp - X1 * cp * cy + Z4 * cp * cy - X2 * cp * sy + Z5 * cp * sy;
-            const double k1 = Z3 * cr * cp - Z1 * sp + Z2 * cp * sr;
-            G_(1, 4) = -2 * sr * k3;
-            G_(2, 4) = -2 * cr * k3;
-            G_(3, 4) = -2 * cy * k1;
-            G_(4, 4) = -2 * sy * k1;
-        }
-        G_(5, 4) = 2 * Z1 * cp + 2 * Z3 * cr * sp + 2 * Z2 * sr * sp;
-        G_(0, 5) = 2 * cp * (X2 * cy - Z5 * cy - X1 * sy + Z4 * sy);
-        G_(1, 5) = 2 * Z4 * cr * cy - 2 * X1 * cr * cy - 2 * X2 * cr * sy + 2 * Z5 * cr * sy +
-                   2 * X2 * cy * sr * sp - 2 * Z5 * cy * sr * sp - 2 * X1 * sr * sp * sy +
-                   2 * Z4 * sr * sp * sy;
-        G_(2, 5) = 2 * X1 * cy * sr - 2 * Z4 * cy * sr + 2 * X2 * sr * sy - 2 * Z5 * sr * sy -
-                   2 * X1 * cr * sp * sy + 2 * Z4 * cr * sp * sy + 2 * X2 * cr * cy * sp -
-                   2 * Z5 * cr * cy * sp;
-        G_(3, 5) = 2 * Z2 * w4 - 2 * Z3 * w3 + 2 * Z1 * cp * sy;
-        G_(4, 5) = 2 * Z2 * w2 - 2 * Z3 * w1 - 2 * Z1 * cp * cy;
-#undef G_
-        // middle += G covZ G^T (upper triangle)
-        double t[36];
+                for (int c = r; c < 3; ++c) acc[u++] += K[r][0] * K[c][0] + K[r][1] * K[c][1] + K[r][2] * K[c][2];
+        } else {
+            censi_sph_jacobian(s4.x, s4.y, s4.z, A.sd + 3, K);
+            // Q / 2: rows 0..2 = R_k^T c, rows 3..5 = -R_k a (column k), then V = (Q / 2) K_b
+            const double c[3] = {A.X[0] - b[0], A.X[1] - b[1], A.X[2] - b[2]};
+            double V[6][3];
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+            for (int m = 0; m < 3; ++m) {
+                double q1[3], q2[3];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                double s = 0;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) s += G[r * 6 + k] * cz[k * 6 + c];
-                t[r * 6 + c] = s;
-            }
-        int v = 21;
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = 0; c < 6; ++c)
-                if (c >= r) {
-                    double s = 0;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) s += t[r * 6 + k] * G[c * 6 + k];
-                    a[v++] += s;
+                for (int k = 0; k < 3; ++k) {
+                    const double *Rk = A.Rk[k];
+                    q1[k] = Rk[0 * 3 + m] * c[0] + Rk[1 * 3 + m] * c[1] + Rk[2 * 3 + m] * c[2];
+                    q2[k] = -(Rk[m * 3 + 0] * a[0] + Rk[m * 3 + 1] * a[1] + Rk[m * 3 + 2] * a[2]);
                 }
+#pragma unroll
+                for (int sidx = 0; sidx < 3; ++sidx) {
+                    V[m][sidx] = q1[0] * K[0][sidx] + q1[1] * K[1][sidx] + q1[2] * K[2][sidx];
+                    V[3 + m][sidx] = q2[0] * K[0][sidx] + q2[1] * K[1][sidx] + q2[2] * K[2][sidx];
+                }
+            }
+            int u = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int cc = r; cc < 6; ++cc) acc[u++] += V[r][0] * V[cc][0] + V[r][1] * V[cc][1] + V[r][2] * V[cc][2];
+        }
     }
-    block_reduce_store<42>(a, partials);
+    block_reduce_store<kN>(acc, partials + (PART == 0 ? 0 : 19));
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_censi(const float4 *__restrict__ src, unsigned n, const unsigned long long *__restrict__ keys,
+            const float4 *__restrict__ tgt, InfoArgs A, double *__restrict__ partials) {
+    if (blockIdx.y == 0) censi_part<0>(src, n, keys, tgt, A, partials);
+    else censi_part<1>(src, n, keys, tgt, A, partials);
+}
+
+// the rotation of estimateCensi's parametrisation, R = Rz(y) Ry(p) Rx(r), with its first and second derivatives in
+// (r, p, y): Rk[k] = dR/d theta_k, Rkl[k][l] (k <= l) = d2R/d theta_k d theta_l, row-major 3 x 3
+static void censi_rotation_derivatives(const double e[3], double R[9], double Rk[3][9], double Rkl[3][3][9]) {
+    auto mul = [](const double *a, const double *b, double *o) {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) o[i * 3 + j] = a[i * 3] * b[j] + a[i * 3 + 1] * b[3 + j] + a[i * 3 + 2] * b[6 + j];
+    };
+    // order d of the elementary rotation about axis ax (0: x, 1: y, 2: z): d/dt twice = minus the rotating part
+    auto elem = [](int ax, double t, int d, double *o) {
+        const double c = cos(t), s = sin(t);
+        const double c0 = d == 0 ? c : (d == 1 ? -s : -c), s0 = d == 0 ? s : (d == 1 ? c : -s);  // (cos, sin)^(d)
+        const double one = d == 0 ? 1.0 : 0.0;
+        const double X[9] = {one, 0, 0, 0, c0, -s0, 0, s0, c0};
+        const double Y[9] = {c0, 0, s0, 0, one, 0, -s0, 0, c0};
+        const double Z[9] = {c0, -s0, 0, s0, c0, 0, 0, 0, one};
+        const double *m = ax == 0 ? X : (ax == 1 ? Y : Z);
+        for (int k = 0; k < 9; ++k) o[k] = m[k];
+    };
+    auto compose = [&](int dx, int dy, int dz, double *o) {  // Rz^(dz)(y) Ry^(dy)(p) Rx^(dx)(r)
+        double x[9], y[9], z[9], zy[9];
+        elem(0, e[0], dx, x);
+        elem(1, e[1], dy, y);
+        elem(2, e[2], dz, z);
+        mul(z, y, zy);
+        mul(zy, x, o);
+    };
+    compose(0, 0, 0, R);
+    for (int k = 0; k < 3; ++k) compose(k == 0, k == 1, k == 2, Rk[k]);
+    for (int k = 0; k < 3; ++k)
+        for (int l = k; l < 3; ++l) compose((k == 0) + (l == 0), (k == 1) + (l == 1), (k == 2) + (l == 2), Rkl[k][l]);
+}
+
+// d2J_dX2 and `middle` (full symmetric 6 x 6) from the kernel's forty sums
+static void censi_assemble(const double *s, const double t[3], const double R[9], const double Rk[3][9],
+                           const double Rkl[3][3][9], double H[36], double Mid[36]) {
+    for (int k = 0; k < 36; ++k) H[k] = Mid[k] = 0.0;
+    const double n = s[0], *Sa = s + 1, *Sba = s + 4;
+    for (int i = 0; i < 3; ++i) H[i * 6 + i] = 2.0 * n;
+    for (int k = 0; k < 3; ++k)
+        for (int i = 0; i < 3; ++i)
+            H[i * 6 + 3 + k] = 2.0 * (Rk[k][i * 3] * Sa[0] + Rk[k][i * 3 + 1] * Sa[1] + Rk[k][i * 3 + 2] * Sa[2]);
+    for (int k = 0; k < 3; ++k)
+        for (int l = k; l < 3; ++l) {
+            const double *M = Rkl[k][l];
+            double th = 0.0;
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) th += M[i * 3 + j] * (t[i] * Sa[j] - Sba[i * 3 + j]);
+            H[(3 + k) * 6 + 3 + l] = 2.0 * th;
+        }
+    for (int r = 0; r < 6; ++r)
+        for (int c = r + 1; c < 6; ++c) H[c * 6 + r] = H[r * 6 + c];
+    // middle = P (sum C_a) P^T + 4 sum (Q/2) C_b (Q/2)^T,   P = [2 R^T ; -2 I]
+    double Ca[9], P[18], PC[18];
+    {
+        int u = 13;
+        for (int r = 0; r < 3; ++r)
+            for (int c = r; c < 3; ++c) Ca[r * 3 + c] = Ca[c * 3 + r] = s[u++];
+    }
+    for (int m = 0; m < 3; ++m)
+        for (int j = 0; j < 3; ++j) {
+            P[m * 3 + j] = 2.0 * R[j * 3 + m];
+            P[(3 + m) * 3 + j] = m == j ? -2.0 : 0.0;
+        }
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 3; ++c) PC[r * 3 + c] = P[r * 3] * Ca[c] + P[r * 3 + 1] * Ca[3 + c] + P[r * 3 + 2] * Ca[6 + c];
+    int u = 19;
+    for (int r = 0; r < 6; ++r)
+        for (int c = r; c < 6; ++c) {
+            const double pcp = PC[r * 3] * P[c * 3] + PC[r * 3 + 1] * P[c * 3 + 1] + PC[r * 3 + 2] * P[c * 3 + 2];
+            Mid[r * 6 + c] = Mid[c * 6 + r] = pcp + 4.0 * s[u++];
+        }
 }
 
 static int reduce_partials(wm_ctx *ctx, int nblocks, int nacc, double *out, wm_comm *comm = nullptr) {
@@ -487,36 +472,27 @@ static int icp_info_impl(wm_ctx *ctx, wm_comm *comm, int method, const double T_
     // Censi
     if (!T_result) return WM_ERR_ARG;
     if (!ctx->last_align_converged) return WM_NOT_CONVERGED;
-    double e[3];
+    double e[3], R[9], Rk[3][9], Rkl[3][3][9];
     euler_012(T_result, e);
-    args.cr = cos(e[0]);
-    args.sr = sin(e[0]);
-    args.cp = cos(e[1]);
-    args.sp = sin(e[1]);
-    args.cy = cos(e[2]);
-    args.sy = sin(e[2]);
+    censi_rotation_derivatives(e, R, Rk, Rkl);
+    for (int k = 0; k < 3; ++k)
+        for (int j = 0; j < 9; ++j) args.Rk[k][j] = Rk[k][j];
     args.X[0] = T_result[3];
     args.X[1] = T_result[7];
     args.X[2] = T_result[11];
     const double sph[6] = {lin_covar, ang_covar, ang_covar, lin_covar, ang_covar, ang_covar};
-    for (int k = 0; k < 6; ++k) args.sph[k] = sph[k];
+    for (int k = 0; k < 6; ++k) args.sd[k] = sqrt(sph[k]);
     const unsigned n = (unsigned) ctx->n_src;
     const int nb = info_blocks(n);
     WM_HIP(ctx, ctx->partials.reserve((size_t) kInfoBlocks * kInfoAcc * sizeof(double)));
-    hipLaunchKernelGGL(k_censi, dim3(nb), dim3(kBlock), 0, ctx->stream,
+    hipLaunchKernelGGL(k_censi, dim3(nb, 2), dim3(kBlock), 0, ctx->stream,
                        ctx->src_sorted.as<float4>(), n, ctx->keys.as<unsigned long long>(),
                        ctx->tgt_orig.as<float4>(), args, ctx->partials.as<double>());
     WM_HIP(ctx, hipGetLastError());
-    double a[42];
-    WM_TRY(reduce_partials(ctx, nb, 42, a, sharded ? comm : nullptr));
+    double a[kCensiSums];
+    WM_TRY(reduce_partials(ctx, nb, kCensiSums, a, sharded ? comm : nullptr));
     double H[36], Mid[36], Hinv[36], t1[36], t2[36];
-    int u = 0;
-    for (int r = 0; r < 6; ++r)
-        for (int c = r; c < 6; ++c) {
-            H[r * 6 + c] = H[c * 6 + r] = a[u];
-            Mid[r * 6 + c] = Mid[c * 6 + r] = a[21 + u];
-            ++u;
-        }
+    censi_assemble(a, args.X, R, Rk, Rkl, H, Mid);
     inverse<6>(H, Hinv);
     mat_mul<6>(Hinv, Mid, t1);
     mat_mul<6>(t1, Hinv, t2);
