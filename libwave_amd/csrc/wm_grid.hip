@@ -481,10 +481,7 @@ __global__ void __launch_bounds__(kBlock) k_gather(const float4 *pts, const unsi
 }
 
 int morton_sort(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, size_t n_valid,
-                float4 *out, hipStream_t on_stream) {
-    // (on_stream: where to enqueue -- the context's stream unless given; the helper thread of finalize_clouds names
-    // the side stream and must not touch ctx->stream, which the calling thread is enqueueing on meanwhile)
-    const hipStream_t stream = on_stream ? on_stream : ctx->stream;
+                float4 *out) {
     if (n == 0 || n_valid == 0) return WM_OK;
     int bits = (int) ceil(log2(cbrt((double) n)));
     if (bits < 3) bits = 3;
@@ -501,16 +498,16 @@ int morton_sort(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, size_t
     unsigned *k1 = ctx->vg_idx.as<unsigned>(), *k2 = ctx->vg_idx2.as<unsigned>();
     unsigned *v1 = ctx->vg_perm.as<unsigned>(), *v2 = ctx->vg_perm2.as<unsigned>();
     const unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_morton_keys, dim3(blocks), dim3(kBlock), 0, stream, pts, (unsigned) n,
+    hipLaunchKernelGGL(k_morton_keys, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, (unsigned) n,
                        key, 1u << (3 * bits), k1, v1);
     size_t tmp_bytes = 0;
-    WM_HIP(ctx, sort_pairs_low_bits(nullptr, tmp_bytes, k1, k2, v1, v2, n, 3 * bits + 1, stream,
+    WM_HIP(ctx, sort_pairs_low_bits(nullptr, tmp_bytes, k1, k2, v1, v2, n, 3 * bits + 1, ctx->stream,
                                     (size_t) ctx->tune_radix_min));
     WM_HIP(ctx, ctx->vg_tmp.reserve(tmp_bytes));
-    WM_HIP(ctx, sort_pairs_low_bits(ctx->vg_tmp.p, tmp_bytes, k1, k2, v1, v2, n, 3 * bits + 1, stream,
+    WM_HIP(ctx, sort_pairs_low_bits(ctx->vg_tmp.p, tmp_bytes, k1, k2, v1, v2, n, 3 * bits + 1, ctx->stream,
                                     (size_t) ctx->tune_radix_min));
     const unsigned gblocks = (unsigned) ((n_valid + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_gather, dim3(gblocks), dim3(kBlock), 0, stream, pts, v2,
+    hipLaunchKernelGGL(k_gather, dim3(gblocks), dim3(kBlock), 0, ctx->stream, pts, v2,
                        (unsigned) n_valid, out);
     WM_HIP(ctx, hipGetLastError());
     return WM_OK;

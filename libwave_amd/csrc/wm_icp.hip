@@ -18,10 +18,7 @@
 #include "wm_xchg.hpp"
 
 #include <algorithm>
-#include <atomic>
 #include <chrono>
-#include <condition_variable>
-#include <mutex>
 #include <thread>
 
 #include <float.h>
@@ -917,86 +914,6 @@ int join_source_sort(wm_ctx *ctx) {
     return WM_OK;
 }
 
-// ---- the enqueue helper thread (wm_internal.hpp: PrepHelper)
-struct PrepHelper {
-    // state: 0 asleep, 1 armed (spinning for a task), 2 task posted, 3 task done (rc valid), -1 leave
-    std::atomic<int> state{0};
-    std::mutex mu;
-    std::condition_variable cv;
-    std::thread th;
-    // the task: morton_sort of the source on the side stream + the join event
-    wm_ctx *ctx = nullptr;
-    size_t src_valid = 0;
-    int rc = WM_OK;
-};
-
-static void prep_helper_main(PrepHelper *h) {
-    for (;;) {
-        {  // asleep until armed (or told to leave)
-            std::unique_lock<std::mutex> lk(h->mu);
-            h->cv.wait(lk, [&] { const int s = h->state.load(std::memory_order_acquire); return s == 1 || s == -1; });
-            if (h->state.load(std::memory_order_acquire) == -1) return;
-        }
-        // armed: spin for the task a registration's preparation will post within ~0.1 ms; back to sleep when none
-        // comes (a caller that set a source and never registered)
-        const auto t0 = std::chrono::steady_clock::now();
-        for (unsigned spins = 1;; ++spins) {
-            const int s = h->state.load(std::memory_order_acquire);
-            if (s == 2) {
-                wm_ctx *ctx = h->ctx;
-                int rc = hipSetDevice(ctx->device) == hipSuccess ? WM_OK : WM_ERR_HIP;
-                if (rc == WM_OK)
-                    rc = morton_sort(ctx, ctx->src_orig.as<float4>(), ctx->n_src_input, ctx->src_bbox, h->src_valid,
-                                     ctx->src_sorted.as<float4>(), ctx->side_stream);
-                if (rc == WM_OK && hipEventRecord(ctx->ev_join, ctx->side_stream) != hipSuccess) rc = WM_ERR_HIP;
-                h->rc = rc;
-                h->state.store(3, std::memory_order_release);
-                break;  // (one task per arming)
-            }
-            if (s == -1) return;
-            cpu_relax();
-            if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(3)) {
-                int expect = 1;
-                if (h->state.compare_exchange_strong(expect, 0)) break;  // (unless a task was posted just now)
-            }
-        }
-    }
-}
-
-void prep_helper_arm(wm_ctx *ctx) {
-    if (!ctx->tune_prep_thread || !ctx->tune_two_streams || !ctx->side_stream) return;
-    if (!ctx->prep_helper) {
-        ctx->prep_helper = new (std::nothrow) PrepHelper();
-        if (!ctx->prep_helper) return;
-        ctx->prep_helper->th = std::thread(prep_helper_main, ctx->prep_helper);
-    }
-    PrepHelper *h = ctx->prep_helper;
-    int expect = 0;
-    if (h->state.compare_exchange_strong(expect, 1)) {
-        std::lock_guard<std::mutex> lk(h->mu);  // (so that the notification cannot fall between its test and its wait)
-        h->cv.notify_one();
-    } else if (expect == 3) {
-        h->state.store(1, std::memory_order_release);  // (a finished task nobody collected: an error path; re-arm)
-        std::lock_guard<std::mutex> lk(h->mu);
-        h->cv.notify_one();
-    }
-}
-
-void prep_helper_destroy(wm_ctx *ctx) {
-    PrepHelper *h = ctx->prep_helper;
-    if (!h) return;
-    // (a task in flight finishes first: state 2 -> 3)
-    for (int k = 0; k < 200000 && h->state.load(std::memory_order_acquire) == 2; ++k) std::this_thread::yield();
-    h->state.store(-1, std::memory_order_release);
-    {
-        std::lock_guard<std::mutex> lk(h->mu);
-        h->cv.notify_one();
-    }
-    if (h->th.joinable()) h->th.join();
-    delete h;
-    ctx->prep_helper = nullptr;
-}
-
 int finalize_clouds(wm_ctx *ctx, double max_corr, int nn_method, bool sort_aside) {
     WM_TRY(join_source_sort(ctx));  // (left behind by a call that failed before its own join)
     if (ctx->src_pending || ctx->tgt_pending) {
@@ -1048,25 +965,7 @@ int finalize_clouds(wm_ctx *ctx, double max_corr, int nn_method, bool sort_aside
         WM_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
     }
     int rc = WM_OK;
-    // two chains, two enqueueing threads: the helper (armed by wm_set_source, spinning by now) issues the sort's
-    // launches on the side stream while this thread issues the grid ladder's on the main one
-    PrepHelper *h = (side && !aside) ? ctx->prep_helper : nullptr;
-    bool helped = false;
-    if (h && ctx->n_src_input >= kPrepHelperMinPoints) {
-        h->ctx = ctx;
-        h->src_valid = src_valid;
-        int expect = 1;
-        helped = h->state.compare_exchange_strong(expect, 2);  // (not armed in time: this thread does it all, as before)
-    }
     if (max_corr > 0 && ctx->n_src > 0 && ctx->n_tgt > 0 && !use_brute(ctx, nn_method)) rc = ensure_levels(ctx, max_corr);
-    if (helped) {
-        while (h->state.load(std::memory_order_acquire) != 3) cpu_relax();
-        const int rc2 = h->rc;
-        h->state.store(0, std::memory_order_release);
-        if (rc2 != WM_OK) return rc2;
-        WM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-        return rc;
-    }
     if (sort_src) {
         if (side) ctx->stream = ctx->side_stream;
         const int rc2 = morton_sort(ctx, ctx->src_orig.as<float4>(), ctx->n_src_input, ctx->src_bbox, src_valid,
@@ -1195,7 +1094,6 @@ int wm_ctx_create(wm_ctx **out, int device) {
     if (const char *e = getenv("WM_TUNE_LAG")) ctx->tune_lag = atoi(e);
     if (const char *e = getenv("WM_TUNE_LATE")) ctx->tune_late = atoi(e);
     if (const char *e = getenv("WM_TUNE_BINS")) ctx->tune_bins = atoi(e);
-    if (const char *e = getenv("WM_TUNE_PREP_THREAD")) ctx->tune_prep_thread = atoi(e);
     if (const char *e = getenv("WM_TUNE_GRID_VARIANT")) ctx->tune_grid_variant = atoi(e);
     if (const char *e = getenv("WM_TUNE_EARLY_SOURCE")) ctx->tune_early_source = atoi(e);
     if (const char *e = getenv("WM_TUNE_COV_DBG")) ctx->tune_cov_dbg = atoi(e) & 768;
@@ -1223,7 +1121,6 @@ int wm_ctx_set_stream(wm_ctx *ctx, void *hip_stream, int external) {
 
 void wm_ctx_destroy(wm_ctx *ctx) {
     if (!ctx) return;
-    prep_helper_destroy(ctx);
     (void) hipSetDevice(ctx->device);
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->src_sorted, &ctx->tgt_orig, &ctx->staging, &ctx->staging2, &ctx->cell_of, &ctx->counts,
@@ -1293,9 +1190,6 @@ int wm_set_source(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem
     ctx->n_src = 0;
     ctx->src_pending = false;
     if (n == 0) return WM_OK;
-    // (a big cloud: wake the enqueue helper now -- it needs ~50 us to come out of its sleep, and its task, the
-    // Morton sort, is posted by finalize_clouds ~80 us from here)
-    if (n >= kPrepHelperMinPoints) prep_helper_arm(ctx);
     // pack (caller order, kept for GICP's k-NN covariances) and launch the bounding-box reduction;
     // the Morton order is produced by finalize_clouds once the box has been fetched
     ctx->gicp_cov_src_valid = false;

@@ -138,8 +138,6 @@ struct Bbox {
     float lo[3], hi[3];
 };
 
-struct PrepHelper;  // (wm_icp.hip)
-
 }  // namespace wm
 
 // The opaque C handle.
@@ -147,7 +145,6 @@ struct wm_ctx {
     int device = 0;
     hipStream_t stream = nullptr, own_stream = nullptr;
     hipStream_t side_stream = nullptr;      // the source's Morton sort runs here, beside the target's grid build
-    wm::PrepHelper *prep_helper = nullptr;  // ... enqueued there by a thread of its own (finalize_clouds)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // wm_set_source / wm_set_target only pack the cloud and LAUNCH its bounding-box reduction; the
     // host fetches both results in one round trip when the first consumer needs them (finalize_clouds)
@@ -197,7 +194,6 @@ struct wm_ctx {
     wm::DevBuf bins;
     bool bins_dirty = false;     // an iteration loop is running or ended abnormally: the bins may hold sums
     int tune_grid_variant = 0;   // developer: k_nn_grid<SVD, balanced> at other register budgets (wm_nn.hip: launch_nn_grid)
-    int tune_prep_thread = 1;    // the enqueue helper thread of finalize_clouds (above)
     int tune_bins = 1;           // 0: rows of partial sums + k_reduce_rows + k_reduce_solve, as up to round 5
     wm::DevBuf nn_bound;                    // float4 per (sorted) source point, written by k_nn_cert's searches: where the query was (xyz) and a lower bound (w) on its distance, there, to every target point but its match
     wm::DevBuf cert_count;                  // developer: unsettled queries per launch of k_nn_cert ([launch][64] partial counts)
@@ -340,15 +336,7 @@ int join_source_sort(wm_ctx *ctx);
 int build_grid_level(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, float h,
                      GridLevel *lvl, double *avg_occupancy);
 int morton_sort(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, size_t n_valid,
-                float4 *out, hipStream_t on_stream = nullptr);
-// The context's enqueue helper (wm_icp.hip: finalize_clouds): a second host thread that enqueues the source's Morton
-// sort on the side stream WHILE the calling thread enqueues the target's grid ladder on the main one.  Cloud
-// preparation is bound by how fast ONE thread can issue its ~55 small launches (~7 us each), not by the device; two
-// threads issue the two independent chains side by side.  Made for big clouds only (kPrepHelperMinPoints), woken by
-// wm_set_source a registration ahead of its task, asleep between registrations; WM_TUNE_PREP_THREAD=0 turns it off.
-constexpr size_t kPrepHelperMinPoints = 200000;
-void prep_helper_arm(wm_ctx *ctx);      // wake it (creates it on first use): it spins for its task for a few milliseconds
-void prep_helper_destroy(wm_ctx *ctx);
+                float4 *out);
 int ensure_levels(wm_ctx *ctx, double max_corr);
 // fetch a small result from device memory into pinned host memory and wait for it (copy, fence
 // and completion flag by one wavefront; see k_fetch_signal)

@@ -9,7 +9,7 @@ for setting in "$@"; do
     name=$(echo "$setting" | tr ' =' '__')
     if [ "$setting" = "-" ]; then setting=""; name=default; fi
     for rep in 1 2; do
-        env $setting python bench.py --no-cpu-baseline --no-other-configs --no-in-flight --steps 20 --warmup 5 \
+        env $setting timeout 150 python bench.py --no-cpu-baseline --no-other-configs --no-in-flight --steps 20 --warmup 5 \
             > "gpurun_out/$TAG/${name}_$rep.json" 2> "gpurun_out/$TAG/${name}_$rep.err"
         python - "gpurun_out/$TAG/${name}_$rep.json" "$name" <<'PY'
 import json, sys

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-env "$@" rocprofv3 --kernel-trace --output-format csv -d "$OUT/raw" -o t -- \
+env "$@" timeout 200 rocprofv3 --kernel-trace --output-format csv -d "$OUT/raw" -o t -- \
     python "$ROOT/bench.py" --no-cpu-baseline --no-other-configs --no-in-flight --no-host-clouds --steps 4 --warmup 2 > "$OUT/stdout.log" 2>&1
 cd "$ROOT"
 f=$(find "$OUT/raw" -name '*kernel_trace.csv' | head -1)
