@@ -1356,8 +1356,10 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-template <int STATS, int NB, int RC, bool LATE = false>
-__global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// (P1: developer timing experiment, WRONG results -- phase 2 compiled OUT: what the certificate phase costs in a kernel
+// whose registers, scalar registers and LDS are not set by the searches; launched for bounds-valid launches only)
+template <int STATS, int NB, int RC, bool LATE = false, bool P1 = false>
+__global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_per_eu(P1 ? 6 : 4, P1 ? 6 : 4)))
     k_nn_cert(const LevelsDev *__restrict__ lv, const float4 *__restrict__ src, unsigned n,
               IcpDevState *__restrict__ st, float thr_d2, unsigned long long *__restrict__ keys,
               float4 *__restrict__ match_pt, float4 *__restrict__ bound, const float4 *__restrict__ tgt_orig,
@@ -1411,7 +1413,7 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
         if (st->done) return;  // (a launch queued behind a `done`; the solver tells the host)
     }
     BalLds &L = s_L[wave];
-    s_win[wave][lane] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoIdx));  // (no winner recorded)
+    if constexpr (!P1) s_win[wave][lane] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoIdx));  // (no winner recorded)
     const int Ln = lv->n;
     float hl[kMaxLevels];  // the levels' cell sizes (wave-uniform: scalar registers)
 #pragma unroll
@@ -1594,7 +1596,7 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
             }
             const bool uns = owned && !settled;
             const unsigned long long umask = __ballot(uns);
-            if (uns) {
+            if (!P1 && uns) {
                 const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned) (umask >> 32),
                                                                   __builtin_amdgcn_mbcnt_lo((unsigned) umask, 0u));
                 const unsigned e = n_uns + before;
@@ -1627,13 +1629,14 @@ __global__ void __launch_bounds__(64 * kCertWaves) __attribute__((amdgpu_waves_p
     if (!LATE && !bins && threadIdx.x == 0 && U) atomicAdd(&st->cert_unsettled[blockIdx.x & 63u], U);
     const unsigned U_searched = U;
     if (dbg_skip == 1u && valid) U = 0;
+    if constexpr (P1) U = 0;
     const unsigned nchunks = (U + 63u) / 64u;
     unsigned cost = 0;
     unsigned long long prof[3] = {0ull, 0ull, 0ull};
     // The wave's first chunk is gathered from the four waves' parked entries BEFORE any wave scans (a
     // scan overwrites its wave's parking area), and set down again in the wave's own area after the
     // barrier: query (pose applied), its index, its match.
-    {
+    if constexpr (!P1) {
         float gx = 0.f, gy = 0.f, gz = 0.f;
         float4 gtp = make_float4(0.f, 0.f, 0.f, __uint_as_float(kNoIdx));
         unsigned gi = kNoIdx;
@@ -2120,7 +2123,15 @@ int launch_nn_cert(wm_ctx *ctx, float thr_d2, hipEvent_t ev0, hipEvent_t ev1, hi
     }
     const unsigned xflags = (ctx->tune_nn_nt_stores ? 0x10000000u : 0u) | (((unsigned) ctx->tune_cert_dbg_skip & 3u) << 26);
     if (ev0) WM_HIP(ctx, hipEventRecord(ev0, ctx->stream));
-    if (nb == 2) launch_nn_cert_nb<2, 3>(ctx, blocks, thr_d2, xflags, bounds_valid, stats_mode, bins);
+    if (ctx->tune_cert_dbg_skip == 3 && bounds_valid && stats_mode == WM_ICP_SVD && nb == 4) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_cert<WM_ICP_SVD, 4, 3, false, true>), dim3(blocks), dim3(64 * kCertWaves), 0, ctx->stream,
+                           ctx->d_levels.as<LevelsDev>(), ctx->src_sorted.as<float4>(), (unsigned) ctx->n_src,
+                           ctx->d_state.as<IcpDevState>(), thr_d2, ctx->keys.as<unsigned long long>(),
+                           ctx->match_pt.as<float4>(), ctx->nn_bound.as<float4>(), ctx->tgt_orig.as<float4>(),
+                           ctx->tune_r_light, ctx->tune_lane_lf, ctx->tune_coop_lf, ctx->tune_r0, xflags,
+                           ctx->partials.as<double>(), 1, ctx->tune_cert_pad_mul, ctx->tune_cert_pad_frac,
+                           (unsigned *) nullptr, (unsigned long long *) nullptr, LateArgs{}, bins);
+    } else if (nb == 2) launch_nn_cert_nb<2, 3>(ctx, blocks, thr_d2, xflags, bounds_valid, stats_mode, bins);
     else launch_nn_cert_nb<4, 3>(ctx, blocks, thr_d2, xflags, bounds_valid, stats_mode, bins);
     if (ctx->cert_count.p && ctx->cert_log_iter < ctx->cert_log_cap) ctx->cert_log_iter++;
     if (ev1) WM_HIP(ctx, hipEventRecord(ev1, ctx->stream));
