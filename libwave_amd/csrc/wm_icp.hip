@@ -1185,6 +1185,7 @@ int wm_cloud_sizes(const wm_ctx *ctx, size_t *n_source, size_t *n_target) {
 int wm_set_source(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem) {
     if (!ctx || (n > 0 && !pts) || stride < 12 || (stride & 3) || n > 0x7FFFFFF0u) return WM_ERR_ARG;
     WM_HIP(ctx, hipSetDevice(ctx->device));
+    WM_TRY(join_source_sort(ctx));  // (a sort left running aside by a call that ended early: it reads what is replaced here)
     ctx->have_corr = false;
     ctx->n_src_input = n;
     ctx->n_src = 0;

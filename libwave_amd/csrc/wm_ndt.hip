@@ -1038,6 +1038,12 @@ int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *prm, double T_out[16], wm_ndt
     // built on this one meanwhile, and the passes wait for both
     const bool will_build = !ctx->ndt_built || ctx->ndt_res != prm->res;
     WM_TRY(finalize_clouds(ctx, -1.0, 0, will_build));
+    // (from here on the source's sort may be running on the side stream: whatever ends this call early joins it
+    // first -- a later wm_set_source / pack on the main stream must not overwrite what the sort still reads)
+    struct JoinOnExit {
+        wm_ctx *c;
+        ~JoinOnExit() { (void) join_source_sort(c); }
+    } join_on_exit{ctx};
     WM_HIP(ctx, ctx->partials.reserve((size_t) (kNdtBlocks + 256) * kNdtAcc * sizeof(double)));
     if (!ctx->ndt_built || ctx->ndt_res != prm->res) {
         WM_TRY(ndt_build(ctx, prm->res));

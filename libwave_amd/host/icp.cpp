@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 
 #include "shim.hpp"
@@ -25,7 +26,13 @@ int benchForceIterations() {
     if (n >= 0) return n;
     static const int from_env = [] {
         const char *e = std::getenv("WAVE_ICP_BENCH_FORCE_ITERATIONS");
-        return e ? std::max(0, std::atoi(e)) : 0;
+        const int v = e ? std::max(0, std::atoi(e)) : 0;
+        // (a bench-only knob with no counterpart in the reference: say so ONCE when it is active -- a stray variable in
+        // a production environment switches PCL's stopping rules off for every ICPMatcher of the process)
+        if (v > 0)
+            std::fprintf(stderr, "[INFO] WAVE_ICP_BENCH_FORCE_ITERATIONS=%d: every ICPMatcher::match() of this process runs exactly "
+                                 "that many iterations (PCL's stopping rules are OFF) -- a benchmark setting\n", v);
+        return v;
     }();
     return from_env;
 }
