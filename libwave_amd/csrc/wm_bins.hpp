@@ -72,6 +72,62 @@ __device__ __forceinline__ void bins_add_count(long long *bins, unsigned bin, un
     (void) __hip_atomic_fetch_add(bins + (size_t) bin * (kBinLimbs * kBinStride) + comp, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// the double nearest (to ~1e-32 relative) to L2 * 2^24 + L1 * 2^-16 + L0 * 2^-56 for int64 limb totals  (bins_value, below)
+__device__ __host__ inline double bins_value(long long L0, long long L1, long long L2);
+
+// ---- the reading side: the bins' words added up (integers: exact in any order) and set back to zero, by ALL THREADS
+// threads of ONE workgroup (THREADS >= 4 x 57); afterwards -- a barrier has been passed -- B.tot[c] is component c as a
+// double ([kAcc]: the searched-queries count) and B.poison says whether a sum did not fit the limbs.
+struct BinsLds {
+    long long part[4][kBinLimbs * kBinComps];
+    double tot[kBinComps];
+    unsigned poison;
+};
+template <int THREADS>
+__device__ __forceinline__ void bins_collect(long long *__restrict__ bins, BinsLds &B) {
+    constexpr int kWordsPerBin = kBinLimbs * kBinComps;  // 57 words of a bin are in use
+    constexpr int kGroups = 4;                            // groups of threads, kBinCount / 4 bins each
+    static_assert(THREADS >= kGroups * kWordsPerBin && kBinCount % kGroups == 0, "bins per thread group");
+    constexpr int kPer = kBinCount / kGroups;
+    const unsigned g = threadIdx.x / (unsigned) kWordsPerBin, j = threadIdx.x % (unsigned) kWordsPerBin;
+    const unsigned limb = j / (unsigned) kBinComps, comp = j % (unsigned) kBinComps;
+    if (threadIdx.x == 0) B.poison = 0u;
+    if (g < (unsigned) kGroups) {
+        long long v[kPer];
+#pragma unroll
+        for (int b = 0; b < kPer; ++b)  // (sixteen loads in flight: one round trip)
+            v[b] = bins[((size_t) (g * kPer + b) * kBinLimbs + limb) * kBinStride + comp];
+        long long t = 0;
+#pragma unroll
+        for (int b = 0; b < kPer; ++b) t += v[b];
+        B.part[g][j] = t;
+#pragma unroll
+        for (int b = 0; b < kPer; ++b)  // zeros for the next iteration
+            bins[((size_t) (g * kPer + b) * kBinLimbs + limb) * kBinStride + comp] = 0ll;
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned) kBinCount) {  // a sum that the limbs could not hold?
+        long long *pw = bins + (size_t) threadIdx.x * (kBinLimbs * kBinStride) + kBinPoison;
+        if (*pw != 0ll) {
+            atomicOr(&B.poison, 1u);
+            *pw = 0ll;
+        }
+    }
+    if (threadIdx.x < (unsigned) kBinComps) {
+        long long L[kBinLimbs];
+#pragma unroll
+        for (int l = 0; l < kBinLimbs; ++l) {
+            long long t = 0;
+#pragma unroll
+            for (int gg = 0; gg < kGroups; ++gg) t += B.part[gg][l * kBinComps + threadIdx.x];
+            L[l] = t;
+        }
+        // ([kAcc]: the searched-queries count, added unscaled into limb 0)
+        B.tot[threadIdx.x] = threadIdx.x < (unsigned) kAcc ? bins_value(L[0], L[1], L[2]) : (double) L[0];
+    }
+    __syncthreads();
+}
+
 // the double nearest (to ~1e-32 relative) to L2 * 2^24 + L1 * 2^-16 + L0 * 2^-56 for int64 limb totals: every limb total
 // is cut into two halves that a double holds exactly, the six terms are added largest first with an error-free TwoSum
 // cascade.  The same operations on the same integers give the same double on every device and on the host.

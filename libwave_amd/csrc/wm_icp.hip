@@ -196,13 +196,7 @@ __device__ __forceinline__ void publish_step(const IcpDevState *s, unsigned long
 __global__ void __launch_bounds__(kBlock)
     k_bins_solve(long long *__restrict__ bins, IcpDevState *st, unsigned long long *pub, int pub_slots) {
     __shared__ IcpDevState s_st;
-    constexpr int kWordsPerBin = kBinLimbs * kBinComps;       // 57 words of a bin are in use
-    constexpr int kGroups = kBlock / kWordsPerBin;            // 4 groups of threads, 16 bins each
-    static_assert(kGroups >= 1 && kBinCount % kGroups == 0, "bins per thread group");
-    constexpr int kPer = kBinCount / kGroups;
-    __shared__ long long s_part[kGroups][kWordsPerBin];
-    __shared__ double s_tot[kBinComps];
-    __shared__ unsigned s_poison;
+    __shared__ BinsLds s_b;
     const unsigned long long t_start = clock64();
     static_assert(sizeof(IcpDevState) % 4 == 0, "word-wise staging");
     constexpr unsigned kWords = sizeof(IcpDevState) / 4;
@@ -213,64 +207,26 @@ __global__ void __launch_bounds__(kBlock)
         const unsigned w = threadIdx.x + k * kBlock;
         stage[k] = w < kWords ? reinterpret_cast<const unsigned *>(st)[w] : 0u;
     }
-    const unsigned g = threadIdx.x / (unsigned) kWordsPerBin, j = threadIdx.x % (unsigned) kWordsPerBin;
-    const unsigned limb = j / (unsigned) kBinComps, comp = j % (unsigned) kBinComps;
-    if (threadIdx.x == 0) s_poison = 0u;
-    if (g < (unsigned) kGroups) {
-        long long v[kPer];
-#pragma unroll
-        for (int b = 0; b < kPer; ++b)
-            v[b] = bins[((size_t) (g * kPer + b) * kBinLimbs + limb) * kBinStride + comp];
-        long long t = 0;
-#pragma unroll
-        for (int b = 0; b < kPer; ++b) t += v[b];
-        s_part[g][j] = t;
-    }
-    __syncthreads();  // (s_poison's zero)
-    if (threadIdx.x < (unsigned) kBinCount) {  // a sum that the limbs could not hold?
-        long long *pw = bins + (size_t) threadIdx.x * (kBinLimbs * kBinStride) + kBinPoison;
-        if (*pw != 0ll) {
-            atomicOr(&s_poison, 1u);
-            *pw = 0ll;
-        }
-    }
+    bins_collect<kBlock>(bins, s_b);
 #pragma unroll
     for (unsigned k = 0; k < kStage; ++k) {
         const unsigned w = threadIdx.x + k * kBlock;
         if (w < kWords) reinterpret_cast<unsigned *>(&s_st)[w] = stage[k];
     }
     __syncthreads();
-    if (s_st.done) return;  // (uniform; a launch queued behind a `done`: the bins are all zero and stay so)
-    if (g < (unsigned) kGroups) {  // zeros for the next iteration
-#pragma unroll
-        for (int b = 0; b < kPer; ++b)
-            bins[((size_t) (g * kPer + b) * kBinLimbs + limb) * kBinStride + comp] = 0ll;
-    }
-    if (threadIdx.x < (unsigned) kBinComps) {
-        long long L[kBinLimbs];
-#pragma unroll
-        for (int l = 0; l < kBinLimbs; ++l) {
-            long long t = 0;
-#pragma unroll
-            for (int gg = 0; gg < kGroups; ++gg) t += s_part[gg][l * kBinComps + threadIdx.x];
-            L[l] = t;
-        }
-        // ([kAcc]: the searched-queries count, added unscaled into limb 0)
-        s_tot[threadIdx.x] = threadIdx.x < (unsigned) kAcc ? bins_value(L[0], L[1], L[2]) : (double) L[0];
-    }
-    __syncthreads();
+    if (s_st.done) return;  // (uniform; a launch queued behind a `done`: the bins were all zero and stay so)
     if (threadIdx.x == 0) {
         s_st.dbg[0] = t_start;
         s_st.dbg[1] = clock64();
         double a[kAcc], ex[kStatsLen];
 #pragma unroll
-        for (int k = 0; k < kAcc; ++k) a[k] = s_poison ? 0.0 : s_tot[k];  // (poisoned: "no correspondences", icp_apply_stats)
+        for (int k = 0; k < kAcc; ++k) a[k] = s_b.poison ? 0.0 : s_b.tot[k];  // (poisoned: "no correspondences", icp_apply_stats)
         expand_stats(s_st.mode, a, ex, s_st.changed_mask);
         s_st.local_handled = ex[kStatsLen - 1];
 #pragma unroll
         for (int k = 0; k < kStatsLen; ++k) s_st.stats[k] = ex[k];
         s_st.dbg[2] = clock64();
-        icp_apply_stats(&s_st, ex, (long long) s_tot[kAcc]);
+        icp_apply_stats(&s_st, ex, (long long) s_b.tot[kAcc]);
         publish_step(&s_st, pub, pub_slots);
         s_st.dbg[3] = clock64();
     }
@@ -289,7 +245,9 @@ __global__ void __launch_bounds__(kBlock)
 template <int PHASES, int THREADS>
 __global__ void __launch_bounds__(THREADS)
     k_reduce_solve(const double *__restrict__ partials, int nblocks, IcpDevState *st,
-                   double *stats_io, unsigned long long *pub, int pub_slots, int blk_ext, XchgDev xd) {
+                   double *stats_io, unsigned long long *pub, int pub_slots, int blk_ext, XchgDev xd, long long *bins) {
+    // (bins != nullptr, phases with bit 0: this rank's sums come out of the iteration's bins -- exact integer limbs the
+    // search kernel's waves added into, wm_bins.hpp -- instead of rows of partial sums: no k_reduce_rows in front)
     // (blk_ext: stats_io is the sharded loop's kBlkLen block, not a caller's WM_STATS_LEN one)
     // The solve runs in ONE lane and touches two dozen fields of the state: read from HBM one
     // dependent access at a time that is most of this kernel's ~10 us.  So the whole state is
@@ -312,7 +270,11 @@ __global__ void __launch_bounds__(THREADS)
     __shared__ double lds[kRows][kAcc];
     __shared__ double lds2[kGroups][kAcc];
     __shared__ double tot[kAcc];
-    if (PHASES & 1) {
+    __shared__ BinsLds s_b;
+    const bool from_bins = (PHASES & 1) && bins != nullptr;
+    if (from_bins) {
+        bins_collect<THREADS>(bins, s_b);
+    } else if (PHASES & 1) {
         // thread (r, c) adds rows r, r + kRows, ... of column c: a wave reads 64 consecutive
         // doubles per load; 16 independent accumulators keep 16 loads in flight (every dependent
         // load -> add would cost a memory latency)
@@ -344,7 +306,9 @@ __global__ void __launch_bounds__(THREADS)
         const unsigned w = threadIdx.x + k * THREADS;
         if (w < kWords) reinterpret_cast<unsigned *>(&s_st)[w] = stage[k];
     }
-    if (PHASES & 1) {
+    if (from_bins) {
+        if (threadIdx.x < (unsigned) kAcc) tot[threadIdx.x] = s_b.poison ? 0.0 : s_b.tot[threadIdx.x];
+    } else if (PHASES & 1) {
         const int c = threadIdx.x % kAcc;
         __syncthreads();
         if (threadIdx.x < kGroups * kAcc) {  // row-lanes g, g + 8, ... of column c
@@ -371,7 +335,7 @@ __global__ void __launch_bounds__(THREADS)
         s_st.cert_unsettled[threadIdx.x] = 0u;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += (unsigned) __shfl_xor((int) v, off);
-        if (threadIdx.x == 0) s_uns = v;
+        if (threadIdx.x == 0) s_uns = from_bins ? (unsigned) s_b.tot[kAcc] : v;  // (bins: the count is one of their components)
     }
     if constexpr (PHASES == 7) {
         // this rank's block -> every rank's mailbox; every rank's block -> the sum, in rank order (all threads)
@@ -569,7 +533,8 @@ static int launch_bins_solve(wm_ctx *ctx, unsigned long long *pub, int pub_slots
 // Sum `rows` partial rows (ctx->partials) and run the requested phases of the iteration's solve.
 template <int PHASES>
 static int launch_reduce_solve(wm_ctx *ctx, unsigned rows, double *stats_io, unsigned long long *pub = nullptr,
-                               int pub_slots = 0, int blk_ext = 0, const XchgDev *xchg = nullptr) {
+                               int pub_slots = 0, int blk_ext = 0, const XchgDev *xchg = nullptr, long long *bins = nullptr) {
+    if (bins) rows = 0;  // (the sums are in the bins: nothing to pre-reduce, the small instantiation)
     const XchgDev xd = xchg ? *xchg : XchgDev{nullptr, nullptr, 0, 0, 0u};
     IcpDevState *st = ctx->d_state.as<IcpDevState>();
     const double *part = ctx->partials.as<double>();
@@ -583,10 +548,10 @@ static int launch_reduce_solve(wm_ctx *ctx, unsigned rows, double *stats_io, uns
     }
     if (rows > 512u)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<PHASES, 1024>), dim3(1), dim3(1024), 0, ctx->stream,
-                           part, (int) rows, st, stats_io, pub, pub_slots, blk_ext, xd);
+                           part, (int) rows, st, stats_io, pub, pub_slots, blk_ext, xd, bins);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_solve<PHASES, kBlock>), dim3(1), dim3(kBlock), 0, ctx->stream,
-                           part, (int) rows, st, stats_io, pub, pub_slots, blk_ext, xd);
+                           part, (int) rows, st, stats_io, pub, pub_slots, blk_ext, xd, bins);
     WM_HIP(ctx, hipGetLastError());
     return WM_OK;
 }
@@ -1337,7 +1302,7 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
     const bool in_kernel_exchange = blk && comm_exchange_args(comm, &xchg) == WM_OK;
     ctx->cert_launches = 0;
     // the unsharded grid path adds its sums into bins (wm_bins.hpp) and solves from them: no k_reduce_rows, no rows
-    const bool use_bins = !brute && !blk && ctx->tune_fuse_stats && ctx->tune_bins != 0 && !ctx->cost_log.p;
+    const bool use_bins = !brute && ctx->tune_fuse_stats && ctx->tune_bins != 0 && !ctx->cost_log.p;
     if (use_bins) {
         WM_TRY(bins_ready(ctx));  // (zeroes them if the last loop left them dirty)
         ctx->bins_dirty = true;   // (until this loop has ended normally)
@@ -1572,11 +1537,11 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
         if (blk && in_kernel_exchange) {
             // sharded, mailboxes: this rank's sums, their exchange with the other ranks over xGMI and the same
             // solve on every rank in ONE launch
-            WM_TRY(launch_reduce_solve<7>(ctx, rows, blk, ctx->h_pub, ctx->h_pub_slots, 1, &xchg));
+            WM_TRY(launch_reduce_solve<7>(ctx, rows, blk, ctx->h_pub, ctx->h_pub_slots, 1, &xchg, use_bins ? ctx->bins.as<long long>() : nullptr));
         } else if (blk) {
             // sharded: this rank's sums -> all-reduce of the block over the ranks (RCCL on this stream) ->
             // the same solve on every rank
-            WM_TRY(launch_reduce_solve<1>(ctx, rows, blk, nullptr, 0, 1));
+            WM_TRY(launch_reduce_solve<1>(ctx, rows, blk, nullptr, 0, 1, nullptr, use_bins ? ctx->bins.as<long long>() : nullptr));
             hipEvent_t ea = nullptr, eb = nullptr;
             if (p->profile) {
                 ea = get_event(ctx, ev_ar++);

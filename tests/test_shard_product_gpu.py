@@ -414,6 +414,12 @@ def test_bench_sharded_under_torch_distributed_run():
     assert sh["allreduce_us_isolated"] > 0 and sh["exchange_in_kernel"] == 1 and sh["allreduce_ms"] == 0, sh
     assert sh["plan_ms"] > 0 and sh["compact_ms"] > 0 and sh["index_ms"] > 0 and sh["iter_ms"] > 0, sh
     assert d["config"]["final_translation_error_m"] < 2e-3, line
+    # ... and the line names the exchange that ran and carries a second, short timing of the SAME registration with
+    # north_star's exchange, ncclAllReduce: the first real multi-GPU record compares the two
+    assert sh["exchange_that_ran"] == "mailboxes" and sh["exchange_fell_back_to_collective"] is False, sh
+    ce = sh["collective_exchange"]
+    assert ce.get("ms_per_step", 0) > 0 and ce["exchange_in_kernel"] == 0 and ce["same_transform_as_the_mailbox_run"] is True, ce
+    assert d["config"]["ms_per_step_rccl_allreduce_exchange"] > 0 and d["config"]["ms_per_step_mailbox_exchange"] > 0
 
 
 @pytest.mark.parametrize("world", [2, 4])
