@@ -252,6 +252,12 @@ int wm_icp_info(wm_ctx *ctx, int method, const double T_result[16], double lin_c
  * copy kernel on the context's stream: the practical HBM ceiling to hold next to the 8 TB/s
  * specification (bench.py's roofline.peak_measured_copy). */
 int wm_debug_copy_bandwidth(wm_ctx *ctx, size_t bytes, int reps, double *gb_per_s);
+/* developer / tests, HOST ONLY (no device is touched): the arithmetic the ICP loop's sums go through on the device
+ * (libwave_amd/csrc/wm_bins.hpp) -- every x[i] cut into three signed 40-bit limbs of trunc(x * 2^56), the limbs added as
+ * 64-bit integers into 64 bins in the order perm[] names (NULL: as given), the totals turned back into one double.
+ * *out = that double; limbs_out (may be NULL): the three limb totals.  WM_ERR_ARG when an x[i] does not fit (not finite,
+ * |x| >= 2^62: the device poisons the bin for those). */
+int wm_debug_bins_sum(const double *x, size_t n, const unsigned *perm, double *out, long long limbs_out[3]);
 /* Tuning knobs by name (tests, benchmarks; the defaults are the product's): "cert_from" (-1: the
  * certificate kernel takes over once an ICP step is small, -2: never, k >= 0: from iteration k of
  * every align), "cert_disp" (that step size, in level-0 grid cells), "cert_pad_mul",

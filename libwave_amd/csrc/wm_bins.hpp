@@ -33,13 +33,15 @@ constexpr int kBinStride = 32;  // words per limb row of a bin (kBinComps used: 
 constexpr size_t kBinWords = (size_t) kBinCount * kBinLimbs * kBinStride;
 
 // an integer-valued double |v| < 2^51 -> int64 (the 1.5 * 2^52 trick: the sum's low mantissa bits ARE v + 2^51)
-__device__ __forceinline__ long long bins_to_i64(double v) {
+// (host + device: the splitting is checked on the CPU too, wm_debug_bins_sum / tests/test_bins_cpu.py)
+__device__ __host__ inline long long bins_to_i64(double v) {
     const double d = v + 6755399441055744.0;  // 2^52 + 2^51
-    const long long bits = __double_as_longlong(d);
+    long long bits;
+    __builtin_memcpy(&bits, &d, sizeof(bits));
     return (bits & 0x000FFFFFFFFFFFFFll) - 0x0008000000000000ll;
 }
 
-__device__ __forceinline__ void bins_split(double x, long long (&l)[kBinLimbs]) {
+__device__ __host__ inline void bins_split(double x, long long (&l)[kBinLimbs]) {
     const double t2 = trunc(x * 5.9604644775390625e-08);         // x * 2^-24
     const double r1 = fma(-t2, 16777216.0, x);                   // x - t2 * 2^24     (exact)
     const double t1 = trunc(r1 * 65536.0);                       // r1 * 2^16

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <chrono>
 #include <thread>
+#include <vector>
 
 #include <float.h>
 #include <math.h>
@@ -1968,6 +1969,28 @@ int wm_debug_phase_log(wm_ctx *ctx, unsigned long long *out, int iterations) {
 int wm_debug_solve_cycles(wm_ctx *ctx, unsigned long long out[8]) {
     if (!ctx || !out || !ctx->h_state) return WM_ERR_ARG;
     for (int k = 0; k < 8; ++k) out[k] = ctx->h_state->dbg[k];
+    return WM_OK;
+}
+
+int wm_debug_bins_sum(const double *x, size_t n, const unsigned *perm, double *out, long long limbs_out[3]) {
+    if (!out || (n > 0 && !x)) return WM_ERR_ARG;
+    std::vector<long long> bins(kBinWords, 0ll);
+    for (size_t k = 0; k < n; ++k) {
+        const size_t i = perm ? perm[k] : k;
+        if (i >= n) return WM_ERR_ARG;
+        const double v = x[i];
+        if (!(fabs(v) < 4611686018427387904.0)) return WM_ERR_ARG;
+        long long l[kBinLimbs];
+        bins_split(v, l);
+        const size_t bin = k % (size_t) kBinCount;  // (any assignment of addends to bins gives the same totals)
+        for (int j = 0; j < kBinLimbs; ++j) bins[(bin * kBinLimbs + (size_t) j) * kBinStride] += l[j];
+    }
+    long long L[kBinLimbs] = {0, 0, 0};
+    for (int b = 0; b < kBinCount; ++b)
+        for (int j = 0; j < kBinLimbs; ++j) L[j] += bins[((size_t) b * kBinLimbs + (size_t) j) * kBinStride];
+    *out = bins_value(L[0], L[1], L[2]);
+    if (limbs_out)
+        for (int j = 0; j < kBinLimbs; ++j) limbs_out[j] = L[j];
     return WM_OK;
 }
 
