@@ -1302,7 +1302,8 @@ int icp_run_loop(wm_ctx *ctx, const wm_icp_params *p, bool brute, float thr, wm_
     XchgDev xchg{nullptr, nullptr, 0, 0, 0u};
     const bool in_kernel_exchange = blk && comm_exchange_args(comm, &xchg) == WM_OK;
     ctx->cert_launches = 0;
-    // the unsharded grid path adds its sums into bins (wm_bins.hpp) and solves from them: no k_reduce_rows, no rows
+    // the grid path adds its sums into bins (wm_bins.hpp) and solves from them -- k_bins_solve, or, sharded, the
+    // k_reduce_solve that carries the exchange: no k_reduce_rows, no rows of partial sums
     const bool use_bins = !brute && ctx->tune_fuse_stats && ctx->tune_bins != 0 && !ctx->cost_log.p;
     if (use_bins) {
         WM_TRY(bins_ready(ctx));  // (zeroes them if the last loop left them dirty)

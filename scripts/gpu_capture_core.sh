@@ -14,4 +14,6 @@ bash scripts/gpu_pmc_other.sh ${TAG}_other > /dev/null 2>&1
 python scripts/pmc_to_json.py gpurun_out/${TAG}_pmc gpurun_out/${TAG}_pmc/pmc_latest.json gpurun_out/${TAG}_ndt gpurun_out/${TAG}_other > /dev/null
 cp gpurun_out/${TAG}_pmc/pmc_latest.json profiles/pmc_latest.json   # (so that the plain run below reports traffic + valu-issue)
 python bench.py > gpurun_out/${TAG}_bench_line_noprof.json 2> /dev/null
+# ... and the driver's own command
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_driver_cmd_bench_line.json 2> /dev/null
 ls gpurun_out/${TAG}_* | head -40
