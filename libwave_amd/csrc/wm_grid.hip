@@ -31,10 +31,39 @@ __global__ void __launch_bounds__(kBlock) k_pack(const unsigned char *in, size_t
     out[i] = make_float4(x, y, z, __uint_as_float((unsigned) i));
 }
 
-int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, float4 *out, int slot) {
+// A HOST cloud in PINNED memory (hipHostMalloc / hipHostRegister: what a caller that cares about the upload hands over)
+// can cross PCIe on a DMA engine while this thread does something else: the copy into the slot-1 staging buffer is
+// started here, asynchronously, on the side stream; pack_cloud(..., slot 1, staged = true) later waits for it -- on the
+// HOST, so that the caller's memory is not read after the call that was given it has returned -- and packs from there.
+// false: not pinned (or no side stream): the caller takes the blocking path.
+bool upload_begin_async(wm_ctx *ctx, const void *pts, size_t bytes) {
+    if (!ctx->side_stream || bytes == 0) return false;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, pts) != hipSuccess) {  // (plain pageable memory is unknown to the runtime: an error, cleared here)
+        (void) hipGetLastError();
+        return false;
+    }
+    if (at.type != hipMemoryTypeHost) return false;
+    DevBuf &stage = ctx->staging2;
+    if (stage.cap < bytes) {  // (growing it frees the old one: nothing of ours may still read it)
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess || stage.reserve(bytes) != hipSuccess) return false;
+    }
+    if (hipMemcpyAsync(stage.p, pts, bytes, hipMemcpyHostToDevice, ctx->side_stream) != hipSuccess) {
+        (void) hipGetLastError();
+        (void) hipStreamSynchronize(ctx->side_stream);
+        return false;
+    }
+    return true;
+}
+
+int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, float4 *out, int slot, bool staged) {
     if (n == 0) return WM_OK;
     const unsigned char *dptr = nullptr;
-    if (mem == WM_MEM_HOST) {
+    if (mem == WM_MEM_HOST && staged) {
+        // (upload_begin_async put the cloud on its way into the slot-1 staging buffer: wait for the copy engine)
+        WM_HIP(ctx, hipStreamSynchronize(ctx->side_stream));
+        dptr = ctx->staging2.as<unsigned char>();
+    } else if (mem == WM_MEM_HOST) {
         // Caller memory is pageable: a blocking copy.  Slot 0 (the source, and every other caller): after the
         // stream has drained -- the staging buffer may still feed the previous cloud's k_pack.  Slot 1 (the
         // target, when the source of the same registration was uploaded just before): a staging buffer of

@@ -1187,6 +1187,21 @@ int wm_set_target(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem
     WM_HIP(ctx, ctx->tgt_orig.reserve(n * sizeof(float4)));
     WM_HIP(ctx, ctx->cloud_bbox.reserve(2 * 8 * sizeof(float) * kBboxBlocks));
     int slot = 0;
+    bool staged = false;
+    if (mem == WM_MEM_HOST && ctx->src_pending && ctx->tune_early_source) {
+        // (pinned caller memory: the upload STARTS here, on a copy engine, and runs under the source's round trip and the
+        // ~150 us this thread needs to enqueue the source's sort -- a blocking copy behind those, round 3's order, left the
+        // device idle for the 0.2 ms of the copy: the sort's launches are issued faster than it could start)
+        if (ctx->tune_early_source >= 2) staged = upload_begin_async(ctx, pts, n * stride);
+    }
+    // (whatever ends this call early: the copy engine has finished with the caller's memory before it returns)
+    struct DrainCopy {
+        wm_ctx *c;
+        bool on;
+        ~DrainCopy() {
+            if (on) (void) hipStreamSynchronize(c->side_stream);
+        }
+    } drain_copy{ctx, staged};
     if (mem == WM_MEM_HOST && ctx->src_pending && ctx->tune_early_source) {
         // A HOST target right behind a new source: this cloud is about to spend ~0.25 ms per 16 MB on PCIe with
         // the device idle.  Everything the source still needs -- its bounding box (one short round trip), its
@@ -1203,7 +1218,8 @@ int wm_set_target(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem
                            ctx->src_sorted.as<float4>()));
         slot = 1;
     }
-    WM_TRY(pack_cloud(ctx, pts, n, stride, mem, ctx->tgt_orig.as<float4>(), slot));
+    WM_TRY(pack_cloud(ctx, pts, n, stride, mem, ctx->tgt_orig.as<float4>(), slot, staged));
+    drain_copy.on = false;  // (pack_cloud waited for it)
     WM_TRY(launch_bbox(ctx, ctx->tgt_orig.as<float4>(), n, ctx->cloud_bbox.as<float>() + 8 * kBboxBlocks,
                        &ctx->tgt_bbox_blocks));
     ctx->tgt_pending = true;

@@ -213,7 +213,8 @@ struct wm_ctx {
     // workgroup's searches end 10 us after the median one's, and the solver's chain (rows 3.8, solve 4.4, hand-out
     // 0.7 us) is serial behind them
     int tune_late = 0;
-    int tune_early_source = 1;              // a host target's upload overlaps the source's sort (wm_set_target)
+    int tune_early_source = 2;              // a host target's upload overlaps the source's sort (wm_set_target); 2: and, from
+                                            // pinned memory, starts on a copy engine before that sort is enqueued
     int tune_cov_dbg = 0;                   // developer timing experiment in k_gicp_cov (wrong results): see there
     unsigned long long *h_pub = nullptr;    // pinned: [0] (done << 63 | iterations finished << 32 | step size bits) of the latest solve, [k] iteration k's own record
     int h_pub_slots = 0;
@@ -319,7 +320,8 @@ struct wm_ctx {
 namespace wm {
 
 // ---- wm_grid.hip
-int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, float4 *out, int slot = 0);
+int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, float4 *out, int slot = 0, bool staged = false);
+bool upload_begin_async(wm_ctx *ctx, const void *pts, size_t bytes);  // (pinned host memory: the copy starts now, see wm_grid.hip)
 int compute_bbox(wm_ctx *ctx, const float4 *pts, size_t n, Bbox *out, size_t *n_valid);
 // the two halves of compute_bbox: enqueue the reduction into `partials_dev` (kBboxBlocks * 8 floats),
 // and finish it on the host from the fetched partials

@@ -7,10 +7,10 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 env "$@" timeout 200 rocprofv3 --kernel-trace --output-format csv -d "$OUT/raw" -o t -- \
-    python "$ROOT/bench.py" --no-cpu-baseline --no-other-configs --no-in-flight --no-host-clouds --steps 4 --warmup 2 > "$OUT/stdout.log" 2>&1
+    python "$ROOT/bench.py" --no-cpu-baseline --no-other-configs --no-in-flight ${TL_BENCH_FLAGS---no-host-clouds} --steps 4 --warmup 2 > "$OUT/stdout.log" 2>&1
 cd "$ROOT"
 f=$(find "$OUT/raw" -name '*kernel_trace.csv' | head -1)
-python3 - "$f" "$OUT/timeline.csv" <<'PY'
+python3 - "$f" "$OUT/timeline.csv" ${TL_WHICH:--2} <<'PY'
 import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
