@@ -994,6 +994,7 @@ int wm_ctx_create(wm_ctx **out, int device) {
     }
     ctx->stream = ctx->own_stream;
     if (const char *e = getenv("WM_TUNE_NDT_DENSE")) ctx->tune_ndt_dense = atoi(e);
+    if (const char *e = getenv("WM_TUNE_NDT_VOX_SPLIT")) ctx->tune_ndt_vox_split = atoi(e);
     if (const char *e = getenv("WM_TUNE_KNN_R0")) {
         const float v = (float) atof(e);
         if (v >= 0.25f && v <= 8.f) ctx->tune_knn_r0 = v;

@@ -124,105 +124,197 @@ __device__ inline void ndt_voxel_finish(unsigned slot, unsigned long long cell, 
     if (valid) atomicAdd(n_valid, 1u);
 }
 
-// one lane per voxel (compacted: every lane of a wave has a voxel, and the waves spread over
-// the whole device): statistics in ascending point order, then the PCL covariance conditioning.
-// (Grids with up to kVoxWaveAvg points per voxel on average; coarser ones: the wave kernel below.)
+// The voxels' statistics: 3 sums of p and 9 of p p^T, each formed in ASCENDING POINT ORDER (the model does not depend on
+// which of the two routines below forms a voxel's sums), then PCL's covariance conditioning (ndt_voxel_record: a Jacobi
+// eigen-decomposition, ~15 us of dependent scalar arithmetic whoever runs it).  Two launches:
+//   k_ndt_voxel_sums   a WAVE per voxel above `split` points: the twelve sums -> vsum[slot][12]
+//   k_ndt_voxel_stats  a LANE per voxel: up to `split` points it walks them itself, above it takes the wave's sums; then
+//                      the conditioning, 64 voxels of a wave side by side
+// (until round 5 the wave kernel conditioned its voxels itself, one lane of 64 at work, and converted its operands on the
+// chain: 102 us for the 2 952 crowded voxels of the 2M-point ring scan behind 34 us of the lane kernel; now 56 + 35 us at
+// a split of 128 points, 70 + 16 at 32 -- profiles/r06_experiments.md.)
+constexpr unsigned kVoxWaveAvg = 192;  // grids with more points per voxel on average than this: every voxel's sums are a wave's
+constexpr unsigned kVoxLaneMax = 128;  // finer grids: voxels with more points than this ...
+constexpr unsigned kVoxLaneMaxFew = 32;  // ... than this, when the grid has so few voxels (kVoxFew) that a wave each costs less than
+constexpr unsigned kVoxFew = 32768;      // the lanes' walks: a wave pays ~4 us of dependent round trips per voxel, a lane ~1 us per 4 points
+constexpr int kVoxDepth = 4;           // batches of 64 points a wave has in flight
+
+// One WAVE per voxel (PCL's default NDT resolution of 5 m puts thousands of points in a voxel; a lidar's rings put
+// 1 700 into a 0.5 m voxel next to the sensor).  The sums are still formed one point after the other, but kVoxDepth x 64
+// points are gathered at a time into LDS and the twelve sums advance in twelve lanes side by side, each adding the
+// points in order -- the same additions as the lane routine, in the same order.  The NEXT 256 points are requested
+// before this trip's additions start.
+__global__ void __launch_bounds__(kBlock)
+    k_ndt_voxel_sums(const float4 *__restrict__ pts, const unsigned *__restrict__ perm, const unsigned *__restrict__ heads,
+                     unsigned nvox, unsigned min_count, double *__restrict__ vsum) {
+    // A voxel's cost is its chain of dependent additions (3 343 points in the fullest voxel of the 2M-point ring scan:
+    // one wave, nothing to hide behind).  So nothing but the additions is ON the chain: the 64 gathering lanes convert
+    // their points to double and write doubles to LDS (float operands converted by the twelve adding lanes were 32
+    // converts per 16 points on the chain: 105 us for the launch on that scan, 56 now -- profiles/r06_experiments.md), a
+    // row of ones serves the three plain sums (fma(x, 1, acc) = acc + x exactly: one loop for all twelve lanes), and a
+    // chunk's operands are read while the previous chunk's additions run.
+    constexpr unsigned kTrip = 64u * (unsigned) kVoxDepth;
+    // (rows x, y, z, ones; two doubles of padding: the twelve adding lanes read the same position of three or four
+    // different rows in one instruction -- rows a multiple of 256 bytes apart would be the same LDS banks)
+    constexpr unsigned kRow = kTrip + 2u;
+    __shared__ __attribute__((aligned(16))) double s_all[kBlock / 64][4][kRow];
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    __shared__ unsigned s_ids[kBlock / 64][kTrip];  // the next trip's point numbers
+    double (*s_p)[kRow] = s_all[wave];
+    unsigned *s_id = s_ids[wave];
+#pragma unroll
+    for (int q = 0; q < kVoxDepth; ++q) s_p[3][64 * q + lane] = 1.0;
+    const unsigned waves_total = gridDim.x * (kBlock / 64);
+    // lane 0..2: sum of p[lane] (times the ones); lane 3..11: sum of p[a] * p[b]
+    const unsigned ia = lane < 3 ? lane : (lane < 12 ? (lane - 3) / 3 : 0);
+    const unsigned ib = lane < 3 ? 3 : (lane < 12 ? (lane - 3) % 3 : 0);
+    constexpr int kChunk = 8;  // points per chunk of the chain (eight 16-byte reads; a chunk's and the next one's stay countable in lgkmcnt)
+    auto operands = [&](unsigned u, double (&x)[kChunk], double (&y)[kChunk]) {
+#pragma unroll
+        for (int q = 0; q < kChunk / 2; ++q) {
+            const double2 a = *reinterpret_cast<const double2 *>(&s_p[ia][u + 2u * (unsigned) q]);
+            const double2 b = *reinterpret_cast<const double2 *>(&s_p[ib][u + 2u * (unsigned) q]);
+            x[2 * q] = a.x, x[2 * q + 1] = a.y;
+            y[2 * q] = b.x, y[2 * q + 1] = b.y;
+        }
+    };
+    for (unsigned slot = blockIdx.x * (kBlock / 64) + wave; slot < nvox; slot += waves_total) {
+        // (wave-uniform, and the compiler is told so: the loops below are then scalar loops, not exec-mask ones)
+        const unsigned i = (unsigned) __builtin_amdgcn_readfirstlane((int) heads[slot]);
+        const unsigned j = (unsigned) __builtin_amdgcn_readfirstlane((int) heads[slot + 1]);
+        if (j - i < min_count) continue;  // a small voxel: a lane's
+        double acc = 0.0;
+        // What goes from one trip to the next goes through LDS, not through registers: trip k gathers the points of trip
+        // k + 1 (their numbers came a trip earlier) and loads the numbers of trip k + 2 into registers that live within the
+        // trip; BEHIND its additions it waits for them, converts and writes them to LDS.  (With the gathered points carried
+        // in registers across the loop the compiler put its copies into the carried registers -- and the wait for the
+        // gather -- right behind the loads: gather, numbers and additions one after the other.)
+        auto numbers = [&](unsigned t, unsigned (&id)[kVoxDepth]) {
+#pragma unroll
+            for (int q = 0; q < kVoxDepth; ++q) id[q] = perm[min(t + 64u * (unsigned) q + lane, j - 1u)];
+        };
+        // (a point as three separate words, not one 12-byte load: the compiler splits a three-register result that lives
+        // across the additions into single registers -- and waits for the load to do so)
+        struct P3 {
+            float x, y, z;
+        };
+        auto gather = [&](const unsigned (&id)[kVoxDepth], P3 (&p)[kVoxDepth]) {
+            const float *f = reinterpret_cast<const float *>(pts);
+#pragma unroll
+            for (int q = 0; q < kVoxDepth; ++q) {
+                const float *fx = f + 4u * (size_t) id[q], *fy = fx + 1, *fz = fx + 2;
+                asm volatile("" : "+v"(fy), "+v"(fz));  // (three addresses the compiler cannot see to be adjacent: it would merge the loads again)
+                p[q].x = *fx;
+                p[q].y = *fy;
+                p[q].z = *fz;
+            }
+        };
+        auto stage = [&](const P3 (&p)[kVoxDepth]) {
+#pragma unroll
+            for (int q = 0; q < kVoxDepth; ++q) {
+                s_p[0][64 * q + lane] = (double) p[q].x;
+                s_p[1][64 * q + lane] = (double) p[q].y;
+                s_p[2][64 * q + lane] = (double) p[q].z;
+            }
+        };
+        {
+            unsigned id0[kVoxDepth], id1[kVoxDepth];
+            P3 p0[kVoxDepth];
+            numbers(i, id0);
+            numbers(i + kTrip, id1);  // (clamped to the voxel's last point: harmless past its end)
+            gather(id0, p0);
+            __builtin_amdgcn_wave_barrier();  // (the previous voxel's reads are done: LDS operations of a wave execute in order)
+#pragma unroll
+            for (int q = 0; q < kVoxDepth; ++q) s_id[64 * q + lane] = id1[q];
+            stage(p0);
+        }
+        for (unsigned t = i; t < j; t += kTrip) {
+            const bool more = t + kTrip < j;  // (wave-uniform)
+            P3 p1[kVoxDepth];
+            unsigned id2[kVoxDepth];
+            if (more) {
+                unsigned id1[kVoxDepth];
+#pragma unroll
+                for (int q = 0; q < kVoxDepth; ++q) id1[q] = s_id[64 * q + lane];
+                gather(id1, p1);
+                numbers(t + 2u * kTrip, id2);
+            }
+            // (a wave's LDS traffic is in order: no barrier between its own write and read)
+            if (lane < 12) {
+                const unsigned m = j - t < kTrip ? j - t : kTrip;
+                const unsigned mc = m & ~(unsigned) (kChunk - 1);
+                if (mc) {
+                    // (the next chunk's reads are issued UNCONDITIONALLY -- past the voxel's end they fetch what is not
+                    // used, the position clamped to the row -- so that no branch separates them from the additions they
+                    // hide behind: with the reads under an `if` the compiler's wait counts had to hold on both paths and
+                    // every chunk waited for its own reads)
+                    constexpr unsigned kLast = kTrip - (unsigned) kChunk;
+                    double xa[kChunk], ya[kChunk], xb[kChunk], yb[kChunk];
+                    operands(0u, xa, ya);
+                    // (the scheduling barriers keep that order: left alone, the compiler gathers both chunks' reads at the top
+                    // of the loop and runs sixteen additions behind them)
+                    for (unsigned u = 0;; u += 2u * kChunk) {
+                        operands(min(u + (unsigned) kChunk, kLast), xb, yb);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int q = 0; q < kChunk; ++q) acc = fma(xa[q], ya[q], acc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (u + kChunk >= mc) break;
+                        operands(min(u + 2u * kChunk, kLast), xa, ya);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int q = 0; q < kChunk; ++q) acc = fma(xb[q], yb[q], acc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (u + 2u * kChunk >= mc) break;
+                    }
+                }
+                for (unsigned u = mc; u < m; ++u) acc = fma(s_p[ia][u], s_p[ib][u], acc);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // (the waits for the gather stay behind the additions)
+            if (more) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int q = 0; q < kVoxDepth; ++q) s_id[64 * q + lane] = id2[q];
+                stage(p1);
+            }
+        }
+        if (lane < 12) vsum[(size_t) slot * 12u + lane] = acc;  // [0..2] sum p, [3..11] sum p p^T
+    }
+}
+
+// one lane per voxel (compacted: every lane of a wave has a voxel): the sums -- its own walk in ascending point order,
+// or k_ndt_voxel_sums' --, then the conditioning
 constexpr int kVoxStatBlock = 64;
-constexpr unsigned kVoxWaveAvg = 192;
-constexpr unsigned kVoxLaneMax = 128;  // voxels with more points than this always go to the wave kernel
 __global__ void __launch_bounds__(kVoxStatBlock)
     k_ndt_voxel_stats(const float4 *__restrict__ pts, const unsigned long long *__restrict__ keys,
                       const unsigned *__restrict__ perm, const unsigned *__restrict__ heads,
-                      unsigned nvox, unsigned max_count, NdtLattice L, NdtVoxel *__restrict__ vox,
-                      float4 *__restrict__ meanf, unsigned long long *__restrict__ vkey,
+                      unsigned nvox, unsigned max_count, const double *__restrict__ vsum, NdtLattice L,
+                      NdtVoxel *__restrict__ vox, float4 *__restrict__ meanf, unsigned long long *__restrict__ vkey,
                       unsigned *__restrict__ n_valid) {
     const unsigned slot = blockIdx.x * kVoxStatBlock + threadIdx.x;
     if (slot >= nvox) return;
     const unsigned i = heads[slot], j = heads[slot + 1];
-    if (j - i > max_count) return;  // a crowded voxel: the wave kernel's
     const unsigned long long key = keys[i];
     double s[3] = {0, 0, 0}, pp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (j - i > max_count) {  // a crowded voxel: a wave formed its sums
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s[k] = vsum[(size_t) slot * 12u + k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) pp[k] = vsum[(size_t) slot * 12u + 3u + k];
+    } else {
 #pragma unroll 4
-    for (unsigned t = i; t < j; ++t) {
-        const float4 p = pts[perm[t]];
-        const double d[3] = {(double) p.x, (double) p.y, (double) p.z};
+        for (unsigned t = i; t < j; ++t) {
+            const float4 p = pts[perm[t]];
+            const double d[3] = {(double) p.x, (double) p.y, (double) p.z};
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            s[a] += d[a];
+            for (int a = 0; a < 3; ++a) {
+                s[a] += d[a];
 #pragma unroll
-            for (int b = 0; b < 3; ++b) pp[a * 3 + b] = fma(d[a], d[b], pp[a * 3 + b]);
+                for (int b = 0; b < 3; ++b) pp[a * 3 + b] = fma(d[a], d[b], pp[a * 3 + b]);
+            }
         }
     }
     ndt_voxel_finish(slot, key, L, j - i, s, pp, vox, meanf, vkey, n_valid);
-}
-
-// Coarse grids (PCL's default NDT resolution of 5 m puts thousands of points in a voxel): one WAVE
-// per voxel.  The sums are still formed one point after the other, but 64 points are gathered at a
-// time into LDS and the twelve sums (3 of p, 9 of p p^T) advance in twelve lanes side by side,
-// each adding the points in order -- the same additions as the lane kernel, in the same order.
-// (One lane per voxel took 0.9-1.2 ms for the 5 m grid of a 1M-point cloud: a few hundred lanes
-// each walking thousands of points.)
-__global__ void __launch_bounds__(kBlock)
-    k_ndt_voxel_stats_wave(const float4 *__restrict__ pts, const unsigned long long *__restrict__ keys,
-                           const unsigned *__restrict__ perm, const unsigned *__restrict__ heads,
-                           unsigned nvox, unsigned min_count, NdtLattice L, NdtVoxel *__restrict__ vox,
-                           float4 *__restrict__ meanf, unsigned long long *__restrict__ vkey,
-                           unsigned *__restrict__ n_valid) {
-    __shared__ __attribute__((aligned(16))) float s_p[kBlock / 64][3][64];
-    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned waves_total = gridDim.x * (kBlock / 64);
-    // lane 0..2: sum of p[lane] (times 1); lane 3..11: sum of p[a] * p[b]
-    const unsigned ia = lane < 3 ? lane : (lane < 12 ? (lane - 3) / 3 : 0);
-    const unsigned ib = lane < 3 ? 0 : (lane < 12 ? (lane - 3) % 3 : 0);
-    const bool product = lane >= 3;
-    for (unsigned slot = blockIdx.x * (kBlock / 64) + wave; slot < nvox; slot += waves_total) {
-        const unsigned i = heads[slot], j = heads[slot + 1];
-        if (j - i < min_count) continue;  // (wave-uniform) a small voxel: the lane kernel's
-        double acc = 0.0;
-        // (the NEXT 64 points are requested before this batch's 64 dependent additions start: the additions
-        // of a crowded voxel -- thousands of points next to the sensor of a ring scan, one batch after the
-        // other -- are the kernel's critical path, and two dependent gathers per batch were three quarters of it)
-        float4 pn = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i + lane < j) pn = pts[perm[i + lane]];
-        for (unsigned t = i; t < j; t += 64) {
-            __builtin_amdgcn_wave_barrier();  // (the previous batch's reads are done: LDS operations of a wave execute in order)
-            s_p[wave][0][lane] = pn.x;
-            s_p[wave][1][lane] = pn.y;
-            s_p[wave][2][lane] = pn.z;
-            if (t + 64u + lane < j) pn = pts[perm[t + 64u + lane]];
-            // (a wave's LDS traffic is in order: no barrier between its own write and read)
-            if (lane < 12) {
-                const unsigned m = j - t < 64u ? j - t : 64u;
-                unsigned u = 0;
-                // sixteen points at a time: their operands are read from LDS together (eight 16-byte reads), then
-                // the sixteen dependent additions follow -- one element per trip (read, wait, convert, add) was
-                // ~100 cycles per point, and a crowded voxel's thousands of points are the kernel's critical path
-                for (; u + 16u <= m; u += 16u) {
-                    float xs[16], ys[16];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 a = *reinterpret_cast<const float4 *>(&s_p[wave][ia][u + 4u * (unsigned) q]);
-                        const float4 b = *reinterpret_cast<const float4 *>(&s_p[wave][ib][u + 4u * (unsigned) q]);
-                        xs[4 * q] = a.x, xs[4 * q + 1] = a.y, xs[4 * q + 2] = a.z, xs[4 * q + 3] = a.w;
-                        ys[4 * q] = b.x, ys[4 * q + 1] = b.y, ys[4 * q + 2] = b.z, ys[4 * q + 3] = b.w;
-                    }
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) acc = fma((double) xs[q], product ? (double) ys[q] : 1.0, acc);  // y = 1: exactly acc + x
-                }
-                for (; u < m; ++u) {
-                    const double x = (double) s_p[wave][ia][u];
-                    const double y = product ? (double) s_p[wave][ib][u] : 1.0;
-                    acc = fma(x, y, acc);
-                }
-            }
-        }
-        double s[3], pp[9];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) s[k] = __shfl(acc, k);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) pp[k] = __shfl(acc, 3 + k);
-        if (lane == 0) ndt_voxel_finish(slot, keys[i], L, j - i, s, pp, vox, meanf, vkey, n_valid);
-    }
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -752,21 +844,20 @@ static int ndt_build(wm_ctx *ctx, double res) {
         unsigned *heads = p1;  // the sort's input permutation is dead by now
         hipLaunchKernelGGL(k_ndt_heads, dim3(blocks), dim3(kBlock), 0, ctx->stream, k2, flags, seg, (unsigned) n,
                            L.cells, heads);
-        // Coarse grids go to the wave kernel whole.  Finer ones go to the lane kernel -- except their
-        // crowded voxels: a lidar's rings put thousands of points into the voxels next to the sensor
-        // (1 700 in a 0.5 m voxel of a 2M-point 64-ring scan whose average is 100), and one lane
-        // walking those alone held the whole launch back (552 us; both kernels form the same sums in
-        // the same order, so who takes a voxel does not change the model).
+        // Coarse grids: every voxel a wave's.  Finer ones: a lane's -- except their crowded voxels: a lidar's
+        // rings put thousands of points into the voxels next to the sensor (1 700 in a 0.5 m voxel of a
+        // 2M-point 64-ring scan whose average is 100), and one lane walking those alone held the whole launch
+        // back (552 us; both routines form the same sums in the same order, so who takes a voxel does not
+        // change the model).
         const bool coarse = (unsigned long long) n > (unsigned long long) kVoxWaveAvg * nvox;
-        const unsigned split = coarse ? 0u : kVoxLaneMax;
-        if (!coarse)
-            hipLaunchKernelGGL(k_ndt_voxel_stats, dim3((nvox + kVoxStatBlock - 1) / kVoxStatBlock),
-                               dim3(kVoxStatBlock), 0, ctx->stream, pts, k2, p2, heads, nvox, split, L,
-                               ctx->ndt_vox.as<NdtVoxel>(), ctx->ndt_meanf.as<float4>(),
-                               ctx->ndt_vkey.as<unsigned long long>(), d_nvalid);
-        hipLaunchKernelGGL(k_ndt_voxel_stats_wave, dim3(nvox < 8192u ? (nvox + 3u) / 4u : 2048u), dim3(kBlock), 0,
-                           ctx->stream, pts, k2, p2, heads, nvox, split + 1u, L, ctx->ndt_vox.as<NdtVoxel>(),
-                           ctx->ndt_meanf.as<float4>(), ctx->ndt_vkey.as<unsigned long long>(), d_nvalid);
+        const unsigned split = coarse ? 0u : ctx->tune_ndt_vox_split >= 0 ? (unsigned) ctx->tune_ndt_vox_split : (nvox <= kVoxFew ? kVoxLaneMaxFew : kVoxLaneMax);
+        WM_HIP(ctx, ctx->ndt_vsum.reserve((size_t) nvox * 12 * sizeof(double)));
+        hipLaunchKernelGGL(k_ndt_voxel_sums, dim3(nvox < 8192u ? (nvox + 3u) / 4u : 2048u), dim3(kBlock), 0, ctx->stream, pts,
+                           p2, heads, nvox, split + 1u, ctx->ndt_vsum.as<double>());
+        hipLaunchKernelGGL(k_ndt_voxel_stats, dim3((nvox + kVoxStatBlock - 1) / kVoxStatBlock), dim3(kVoxStatBlock), 0,
+                           ctx->stream, pts, k2, p2, heads, nvox, split, ctx->ndt_vsum.as<double>(), L,
+                           ctx->ndt_vox.as<NdtVoxel>(), ctx->ndt_meanf.as<float4>(),
+                           ctx->ndt_vkey.as<unsigned long long>(), d_nvalid);
         hipLaunchKernelGGL(k_ndt_hash_insert, dim3((nvox + kBlock - 1) / kBlock), dim3(kBlock), 0,
                            ctx->stream, ctx->ndt_vkey.as<unsigned long long>(), nvox,
                            ctx->ndt_hkeys.as<unsigned long long>(), ctx->ndt_hvals.as<unsigned>(),
