@@ -19,6 +19,9 @@
 #include "wm_gicp_dev.hpp"
 #include "wm_bfgs.hpp"
 #include "wm_gicp_quad.hpp"
+#ifndef WM_COV_BLOCK
+#define WM_COV_BLOCK 64
+#endif
 
 #include <float.h>
 #include <stddef.h>
@@ -37,13 +40,20 @@ constexpr int kGicpBlocksMax = 4096;  // partial rows per objective evaluation (
 
 // computeCovariances for every point of `qpts` (any order); neighbours come from grid g
 // (built over the same cloud), coordinates are gathered from `orig` by caller index.
+// ONE wave per workgroup, six waves per SIMD at PCL's k = 10 (80 registers, three of them spilled outside the loops): the search is a chain of
+// dependent look-ups and gathers per wave (a wave issues for an eighth of its life), so what counts is how many waves are
+// resident and how soon a finished one is replaced -- a 256-thread workgroup waits for four free slots, one per SIMD,
+// i.e. for its predecessor's slowest wave.  231 -> 209 us per launch at 500k points, k = 10 (profiles/r06_experiments.md,
+// where the two things that did NOT pay are logged too: dealing a workgroup's queries out to its waves by the size of
+// their first box -- 20 % fewer wave trips, 2 % less time -- and regrouping the unsettled queries after the first pass).
+constexpr int kCovBlock = WM_COV_BLOCK;  // queries (threads) of a workgroup of k_gicp_cov
 template <int K>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kCovBlock) __attribute__((amdgpu_waves_per_eu(K <= 10 ? 6 : (K <= 12 ? 5 : 1))))
     k_gicp_cov(GridDev g, const float4 *__restrict__ qpts, unsigned n,
                const float4 *__restrict__ orig, int k, double eps, double *__restrict__ cov_out,
                int by_w, float r0_cells) {
-    __shared__ uint2 s_runs[kKnnRows * kBlock];  // per-lane run lists of knn_search (lane-private)
-    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ uint2 s_runs[kKnnRows * kCovBlock];  // per-lane run lists of knn_search (lane-private)
+    const unsigned i = blockIdx.x * kCovBlock + threadIdx.x;
     if (i >= n) return;
     const float4 q = qpts[i];
     const unsigned slot = (by_w & 1) ? __float_as_uint(q.w) : i;
@@ -61,7 +71,7 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
         for (int j = 0; j < K; ++j) best[j] = (unsigned long long) min(i + (unsigned) j, n - 1u);
     } else
-    knn_search<K>(g, q.x, q.y, q.z, k, r0_cells, best, s_runs, threadIdx.x, kBlock);
+    knn_search<K>(g, q.x, q.y, q.z, k, r0_cells, best, s_runs, threadIdx.x, kCovBlock);
     gicp_cov_of_list<K>(best, k, eps, [&](unsigned idx) { return orig[idx]; }, out, (by_w & 256) != 0);
 }
 
@@ -855,8 +865,8 @@ template <int K>
 static int launch_cov(wm_ctx *ctx, const GridDev &g, const float4 *q, size_t n, const float4 *orig,
                       int k, double eps, double *out, int by_w) {
     if (n == 0) return WM_OK;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gicp_cov<K>), dim3((unsigned) ((n + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, ctx->stream, g, q, (unsigned) n, orig, k, eps, out, by_w | ctx->tune_cov_dbg,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gicp_cov<K>), dim3((unsigned) ((n + kCovBlock - 1) / kCovBlock)),
+                       dim3(kCovBlock), 0, ctx->stream, g, q, (unsigned) n, orig, k, eps, out, by_w | ctx->tune_cov_dbg,
                        ctx->tune_knn_r0 > 0 ? ctx->tune_knn_r0 : (k <= 12 ? 1.0f : 1.5f));
     WM_HIP(ctx, hipGetLastError());
 #ifdef WM_COV_COUNT
