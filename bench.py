@@ -54,8 +54,8 @@ F64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector FP64 (half the 157.3 TFLOP/s FP32 v
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=1_000_000, help="points per cloud PER GPU")
     ap.add_argument("--iters", type=int, default=50, help="forced ICP iterations per registration")
     ap.add_argument("--max-corr", type=float, default=3.0)
