@@ -2062,6 +2062,10 @@ int wm_set_option(wm_ctx *ctx, const char *name, double value) {
     else if (k == "cert_pad_frac" && value >= 0) ctx->tune_cert_pad_frac = (float) value;
     else if (k == "late") ctx->tune_late = value != 0 ? 1 : 0;
     else if (k == "bins") ctx->tune_bins = (int) value;
+    else if (k == "ndt_vox_split") {  // developer: who forms a voxel's sums (wm_ndt.hip); the model is rebuilt
+        ctx->tune_ndt_vox_split = (int) value;
+        ctx->ndt_built = false;
+    }
     else if (k == "gicp_served") ctx->tune_gicp_served = value == 2 ? 2 : (value != 0 ? 1 : 0);
     else if (k == "gicp_serve_test_stall_ms") ctx->gicp_serve_test_stall_ms = (int) value;
     else return WM_ERR_ARG;

@@ -105,6 +105,32 @@ def test_ndt_hash_grid_and_dense_table_agree_bit_for_bit(wm, testscan, oracle):
         assert a1["iterations"] == a0["iterations"] and a1["evaluations"] == a0["evaluations"], other
 
 
+@pytest.mark.parametrize("res", [0.5, 2.0])
+def test_ndt_model_does_not_depend_on_who_forms_a_voxels_sums(wm, ctx, testscan, oracle, res):
+    """A voxel's twelve sums are formed in ascending point order by a lane (small voxels) or by a wave
+    (crowded ones: the chain of additions in twelve lanes, operands through LDS) -- the same additions in
+    the same order, so the model, and with it every derivative and the registration, must be the same bit for
+    bit wherever the split between the two lies (0 = every voxel a wave's; 1 << 30 = every voxel a lane's)."""
+    P = np.eye(4)
+    P[0, 3] = 0.2
+    target = oracle.transform_cloud_d(testscan, P)
+    pose = np.array([0.05, -0.02, 0.01, 0.004, -0.003, 0.006])
+    ctx.set_source(testscan)
+    ctx.set_target(target)
+    out = []
+    for split in (0, 3, 8, 32, 128, 1 << 30):
+        ctx.set_option("ndt_vox_split", split)
+        out.append((split, ctx.ndt_derivatives(pose, res=res), ctx.ndt_align(res=res)))
+    ctx.set_option("ndt_vox_split", -1)
+    _, (s0, g0, H0, n0), a0 = out[0]
+    assert n0 > 0
+    for split, (s, g, H, n), a in out[1:]:
+        assert n == n0 and s == s0, split
+        assert np.array_equal(g, g0) and np.array_equal(H, H0), split
+        assert a["rc"] == a0["rc"] and np.array_equal(a["T"], a0["T"]), split
+        assert a["iterations"] == a0["iterations"] and a["evaluations"] == a0["evaluations"], split
+
+
 def test_ndt_sums_added_inside_the_pass_or_by_a_launch_behind_it(wm, testscan, oracle):
     """A pass's rows are added by its own last-finishing workgroups and handed to the host as 16-byte slots (the
     default), or by k_sum_fetch in a launch of its own (WM_TUNE_NDT_FUSED_FETCH=0): the same terms in another
