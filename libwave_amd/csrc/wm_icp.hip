@@ -880,7 +880,23 @@ int join_source_sort(wm_ctx *ctx) {
     return WM_OK;
 }
 
-int finalize_clouds(wm_ctx *ctx, double max_corr, int nn_method, bool sort_aside) {
+// the source's Morton sort that finalize_clouds (mode 2) left for later: on the side stream, behind ev_fork
+int enqueue_deferred_sort(wm_ctx *ctx) {
+    if (!ctx->sort_deferred) return WM_OK;
+    ctx->sort_deferred = false;
+    hipStream_t main_stream = ctx->stream;
+    ctx->stream = ctx->side_stream;
+    const int rc = morton_sort(ctx, ctx->src_orig.as<float4>(), ctx->n_src_input, ctx->src_bbox, ctx->n_src,
+                               ctx->src_sorted.as<float4>());
+    ctx->stream = main_stream;
+    if (rc != WM_OK) return rc;
+    WM_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
+    ctx->sort_join_pending = true;
+    return WM_OK;
+}
+
+int finalize_clouds(wm_ctx *ctx, double max_corr, int nn_method, int sort_aside) {
+    WM_TRY(enqueue_deferred_sort(ctx));  // (left behind by a call that failed before it got there)
     WM_TRY(join_source_sort(ctx));  // (left behind by a call that failed before its own join)
     if (ctx->src_pending || ctx->tgt_pending) {
         // ONE round trip for both clouds' partials (they sit in one device buffer)
@@ -924,7 +940,7 @@ int finalize_clouds(wm_ctx *ctx, double max_corr, int nn_method, bool sort_aside
     if (sort_src) ctx->n_src = src_valid;  // (the count of finite points: what the sort will leave in src_sorted)
     hipStream_t main_stream = ctx->stream;
     // the Morton sort of the source is independent of the target's grid build: side stream
-    const bool aside = sort_aside && sort_src && ctx->tune_two_streams && ctx->side_stream != nullptr;
+    const bool aside = sort_aside != 0 && sort_src && ctx->tune_two_streams && ctx->side_stream != nullptr;
     const bool side = aside || (sort_src && ctx->tune_two_streams && ctx->side_stream && tgt_new && max_corr > 0);
     if (side) {  // (the sort may start as soon as what is on the main stream NOW -- the packed clouds -- is done)
         WM_HIP(ctx, hipEventRecord(ctx->ev_fork, main_stream));
@@ -932,6 +948,10 @@ int finalize_clouds(wm_ctx *ctx, double max_corr, int nn_method, bool sort_aside
     }
     int rc = WM_OK;
     if (max_corr > 0 && ctx->n_src > 0 && ctx->n_tgt > 0 && !use_brute(ctx, nn_method)) rc = ensure_levels(ctx, max_corr);
+    if (sort_src && aside && sort_aside == 2) {
+        ctx->sort_deferred = true;  // (enqueue_deferred_sort: the caller's own chain goes to the main stream first)
+        return rc;
+    }
     if (sort_src) {
         if (side) ctx->stream = ctx->side_stream;
         const int rc2 = morton_sort(ctx, ctx->src_orig.as<float4>(), ctx->n_src_input, ctx->src_bbox, src_valid,
@@ -1152,6 +1172,7 @@ int wm_cloud_sizes(const wm_ctx *ctx, size_t *n_source, size_t *n_target) {
 int wm_set_source(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem) {
     if (!ctx || (n > 0 && !pts) || stride < 12 || (stride & 3) || n > 0x7FFFFFF0u) return WM_ERR_ARG;
     WM_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->sort_deferred = false;  // (a sort of the cloud that is replaced here, never enqueued: dropped)
     WM_TRY(join_source_sort(ctx));  // (a sort left running aside by a call that ended early: it reads what is replaced here)
     ctx->have_corr = false;
     ctx->n_src_input = n;

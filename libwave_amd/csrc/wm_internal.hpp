@@ -300,6 +300,7 @@ struct wm_ctx {
     wm::DevBuf ndt_perm, ndt_perm2, ndt_flags, ndt_seg, ndt_tmp;  // ndt_build's scratch (its own: see there)
     bool xchg_timed_out = false;  // the last sharded loop ended because a peer's block did not arrive (wm_shard.hip)
     bool sort_join_pending = false;  // the source's Morton sort runs on the side stream, ev_join recorded, nobody waits yet
+    bool sort_deferred = false;      // ... is still to be enqueued there (finalize_clouds mode 2: ev_fork recorded, n_src = the finite points' count)
     unsigned ndt_seq = 0;
     int tune_gicp_blocks = 256;  // workgroups (= partial rows) of one GICP objective evaluation (double-double sums: 512 / 256 / 128 / 64 -> 6.9 / 6.4 / 7.3 / 9.6 ms per 500k registration)
     bool ndt_built = false;
@@ -334,8 +335,11 @@ void finish_bbox(const float *partials_host, unsigned blocks, Bbox *out, size_t 
 // grid -- the target's level ladder is built on the main stream; both are joined before returning.
 // sort_aside: the source's Morton sort goes to the side stream and the call does NOT wait for it (ctx->sort_join_pending;
 // join_source_sort makes the context's stream wait) -- for a caller with work of its own to enqueue meanwhile
-int finalize_clouds(wm_ctx *ctx, double max_corr = -1.0, int nn_method = 0, bool sort_aside = false);
+// sort_aside = 2: ... and the sort is not even ENQUEUED yet (ctx->sort_deferred): the caller enqueues what is on its own
+// critical path first and calls enqueue_deferred_sort when it comes to its first wait for the device (wm_ndt_align)
+int finalize_clouds(wm_ctx *ctx, double max_corr = -1.0, int nn_method = 0, int sort_aside = 0);
 int join_source_sort(wm_ctx *ctx);
+int enqueue_deferred_sort(wm_ctx *ctx);
 int build_grid_level(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, float h,
                      GridLevel *lvl, double *avg_occupancy);
 int morton_sort(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, size_t n_valid,

@@ -818,6 +818,10 @@ static int ndt_build(wm_ctx *ctx, double res) {
     WM_HIP(ctx, ctx->ndt_tmp.reserve(tmp));
     WM_HIP(ctx, sort_pairs_low_bits(ctx->ndt_tmp.p, tmp, k1, k2, p1, p2, n, key_bits, ctx->stream,
                                     (size_t) ctx->tune_radix_min));
+    // (a source's Morton sort that wm_ndt_align held back goes to the side stream NOW: behind this model's key kernel and
+    // radix sort -- the registration's critical path, ~150 us of device time that this thread's ~15 launches of the other
+    // sort fit into -- and before the launches below, the last of which this thread then waits for)
+    WM_TRY(enqueue_deferred_sort(ctx));
     hipLaunchKernelGGL(k_ndt_flags, dim3(blocks), dim3(kBlock), 0, ctx->stream, k2, (unsigned) n, L.cells,
                        flags);
     WM_TRY(exclusive_scan(ctx, flags, n, seg));
@@ -1124,11 +1128,14 @@ int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *prm, double T_out[16], wm_ndt
     if (stats) memset(stats, 0, sizeof(*stats));
     if (ctx->n_src_input == 0 || ctx->n_tgt_input == 0) return WM_ERR_STATE;
     WM_HIP(ctx, hipSetDevice(ctx->device));
-    // a new source's Morton sort and a new target's voxel model are independent chains of small launches (230 + 410 us
+    // a new source's Morton sort and a new target's voxel model are independent chains of small launches (230 + 370 us
     // at 2M points, one behind the other on one stream in rounds 1-4): the sort goes to the side stream, the model is
-    // built on this one meanwhile, and the passes wait for both
+    // built on this one meanwhile, and the passes wait for both.  The MODEL's chain is the longer one and has a wait for
+    // the device in its middle (the number of voxels): its first part is enqueued first, the sort right before that wait
+    // (finalize_clouds mode 2 + ndt_build's enqueue_deferred_sort; with the sort's ~15 launches enqueued first, round
+    // 5's order, the model's first kernel started 210 us into the call: this thread was still enqueueing the sort)
     const bool will_build = !ctx->ndt_built || ctx->ndt_res != prm->res;
-    WM_TRY(finalize_clouds(ctx, -1.0, 0, will_build));
+    WM_TRY(finalize_clouds(ctx, -1.0, 0, will_build ? 2 : 0));
     // (from here on the source's sort may be running on the side stream: whatever ends this call early joins it
     // first -- a later wm_set_source / pack on the main stream must not overwrite what the sort still reads)
     struct JoinOnExit {
@@ -1140,6 +1147,7 @@ int wm_ndt_align(wm_ctx *ctx, const wm_ndt_params *prm, double T_out[16], wm_ndt
         WM_TRY(ndt_build(ctx, prm->res));
         ctx->ndt_model_builds++;
     }
+    WM_TRY(enqueue_deferred_sort(ctx));  // (ndt_build has done it)
     WM_TRY(join_source_sort(ctx));
     NdtEval E;
     E.ctx = ctx;
