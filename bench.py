@@ -261,8 +261,11 @@ def other_configs(torch, dev, capi, synth, pmc, with_cpu, copy_peak=None):
     del os.environ["WM_GICP_PROFILE"], os.environ["WM_NDT_PROFILE"]
     ctx = capi.Context(0)
 
-    def median_ms(fn, reps=3):
-        fn()
+    def median_ms(fn, reps=7, warm=3):
+        # (the first registrations of a workload in a process are 5-8 % slower than the ones behind them -- buffers growing
+        # to size, clocks: scripts/bench_configs.py lists every repetition --; the median is over the ones behind them)
+        for _ in range(warm):
+            fn()
         torch.cuda.synchronize()
         ts = []
         for _ in range(reps):
