@@ -100,6 +100,13 @@ def lib():
     """Load the shared library (raises if it has not been built)."""
     global _LIB
     if _LIB is None:
+        # ONE HIP runtime per process: torch brings its own libamdhip64 and loads it by path -- behind this library's
+        # (/opt/rocm's) the process would hold two runtimes that do not know each other's devices, streams or
+        # allocations (wm_ctx_create then fails).  With torch loaded first this library binds to torch's copy.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise WmError("libwavematch_hip.so is not built: run `python -c 'import "
                           "__graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950)")
