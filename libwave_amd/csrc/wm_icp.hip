@@ -1015,6 +1015,7 @@ int wm_ctx_create(wm_ctx **out, int device) {
     ctx->stream = ctx->own_stream;
     if (const char *e = getenv("WM_TUNE_NDT_DENSE")) ctx->tune_ndt_dense = atoi(e);
     if (const char *e = getenv("WM_TUNE_NDT_VOX_SPLIT")) ctx->tune_ndt_vox_split = atoi(e);
+    if (const char *e = getenv("WM_TUNE_NDT_KEYS64")) ctx->tune_ndt_keys64 = atoi(e);
     if (const char *e = getenv("WM_TUNE_KNN_R0")) {
         const float v = (float) atof(e);
         if (v >= 0.25f && v <= 8.f) ctx->tune_knn_r0 = v;
@@ -2083,7 +2084,10 @@ int wm_set_option(wm_ctx *ctx, const char *name, double value) {
     else if (k == "cert_pad_frac" && value >= 0) ctx->tune_cert_pad_frac = (float) value;
     else if (k == "late") ctx->tune_late = value != 0 ? 1 : 0;
     else if (k == "bins") ctx->tune_bins = (int) value;
-    else if (k == "ndt_vox_split") {  // developer: who forms a voxel's sums (wm_ndt.hip); the model is rebuilt
+    else if (k == "ndt_keys64") {
+        ctx->tune_ndt_keys64 = value != 0 ? 1 : 0;
+        ctx->ndt_built = false;
+    } else if (k == "ndt_vox_split") {  // developer: who forms a voxel's sums (wm_ndt.hip); the model is rebuilt
         ctx->tune_ndt_vox_split = (int) value;
         ctx->ndt_built = false;
     }

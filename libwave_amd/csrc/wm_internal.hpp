@@ -266,6 +266,7 @@ struct wm_ctx {
     wm::DevBuf ndt_keys, ndt_keys2, ndt_vox, ndt_vkey, ndt_hkeys, ndt_hvals, ndt_dense, ndt_meanf, ndt_vsum;
     bool ndt_dense_on = false;  // dense cell -> voxel-slot table built (small lattices)
     int ndt_dense_lo[3] = {0, 0, 0}, ndt_dense_dim[3] = {0, 0, 0};
+    int tune_ndt_keys64 = 0;      // developer: 64-bit voxel sort keys whatever the lattice's size (WM_TUNE_NDT_KEYS64)
     int tune_ndt_vox_split = -1;  // developer: points per voxel up to which a LANE forms a voxel's sums (-1: ndt_build's choice)
     int tune_ndt_dense = 2;  // 0: hash grid; 1: dense cell -> slot table; 2: + the float4 cell lattice (wm_ndt.hip)
     bool ndt_cells4_on = false;

@@ -60,8 +60,11 @@ struct NdtLattice {
     unsigned long long cells;   // nx * ny * nz = the "no cell" key of non-finite points (sorts last)
 };
 
+// (KT: the key's type -- 32 bits while the lattice has fewer than 2^32 cells: the sort then moves 8 bytes per point and
+// pass instead of 12)
+template <class KT>
 __global__ void __launch_bounds__(kBlock)
-    k_ndt_key(const float4 *__restrict__ pts, unsigned n, float inv, NdtLattice L, unsigned long long *keys,
+    k_ndt_key(const float4 *__restrict__ pts, unsigned n, float inv, NdtLattice L, KT *keys,
               unsigned *perm) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -73,7 +76,7 @@ __global__ void __launch_bounds__(kBlock)
         const long long c = (long long) floorf(__fmul_rn(p.z, inv)) - L.lo[2];
         key = ((unsigned long long) c * L.ny + (unsigned long long) b) * L.nx + (unsigned long long) a;
     }
-    keys[i] = key;
+    keys[i] = (KT) key;
     perm[i] = i;
 }
 
@@ -86,21 +89,23 @@ __device__ __forceinline__ unsigned long long ndt_key_of_cell(unsigned long long
     return ndt_key(c, b, a);  // k in the top bits
 }
 
+template <class KT>
 __global__ void __launch_bounds__(kBlock)
-    k_ndt_flags(const unsigned long long *__restrict__ keys, unsigned n, unsigned long long invalid,
+    k_ndt_flags(const KT *__restrict__ keys, unsigned n, KT invalid,
                 unsigned *flags) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const unsigned long long k = keys[i];
+    const KT k = keys[i];
     flags[i] = (k != invalid && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
 }
 
 
 // heads[slot] = first sorted position of voxel `slot`; heads[n_voxels] = one past the last
 // finite point (seg[n] = n_voxels, the scan's total)
+template <class KT>
 __global__ void __launch_bounds__(kBlock)
-    k_ndt_heads(const unsigned long long *__restrict__ keys, const unsigned *__restrict__ flags,
-                const unsigned *__restrict__ seg, unsigned n, unsigned long long invalid,
+    k_ndt_heads(const KT *__restrict__ keys, const unsigned *__restrict__ flags,
+                const unsigned *__restrict__ seg, unsigned n, KT invalid,
                 unsigned *__restrict__ heads) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -285,8 +290,9 @@ __global__ void __launch_bounds__(kBlock)
 // one lane per voxel (compacted: every lane of a wave has a voxel): the sums -- its own walk in ascending point order,
 // or k_ndt_voxel_sums' --, then the conditioning
 constexpr int kVoxStatBlock = 64;
+template <class KT>
 __global__ void __launch_bounds__(kVoxStatBlock)
-    k_ndt_voxel_stats(const float4 *__restrict__ pts, const unsigned long long *__restrict__ keys,
+    k_ndt_voxel_stats(const float4 *__restrict__ pts, const KT *__restrict__ keys,
                       const unsigned *__restrict__ perm, const unsigned *__restrict__ heads,
                       unsigned nvox, unsigned max_count, const double *__restrict__ vsum, NdtLattice L,
                       NdtVoxel *__restrict__ vox, float4 *__restrict__ meanf, unsigned long long *__restrict__ vkey,
@@ -294,7 +300,7 @@ __global__ void __launch_bounds__(kVoxStatBlock)
     const unsigned slot = blockIdx.x * kVoxStatBlock + threadIdx.x;
     if (slot >= nvox) return;
     const unsigned i = heads[slot], j = heads[slot + 1];
-    const unsigned long long key = keys[i];
+    const unsigned long long key = (unsigned long long) keys[i];
     double s[3] = {0, 0, 0}, pp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (j - i > max_count) {  // a crowded voxel: a wave formed its sums
 #pragma unroll
@@ -773,7 +779,8 @@ struct NdtModel {
     unsigned nvox = 0, nvalid = 0, hmask = 0;
 };
 
-static int ndt_build(wm_ctx *ctx, double res) {
+template <class KT>
+static int ndt_build_t(wm_ctx *ctx, double res) {
     const size_t n = ctx->n_tgt_input;
     const float4 *pts = ctx->tgt_orig.as<float4>();
     const unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
@@ -785,7 +792,7 @@ static int ndt_build(wm_ctx *ctx, double res) {
     WM_HIP(ctx, ctx->ndt_perm2.reserve(n * 4));
     WM_HIP(ctx, ctx->ndt_flags.reserve(n * 4));
     WM_HIP(ctx, ctx->ndt_seg.reserve((n + 1) * 4));
-    unsigned long long *k1 = ctx->ndt_keys.as<unsigned long long>(), *k2 = ctx->ndt_keys2.as<unsigned long long>();
+    KT *k1 = ctx->ndt_keys.as<KT>(), *k2 = ctx->ndt_keys2.as<KT>();
     unsigned *p1 = ctx->ndt_perm.as<unsigned>(), *p2 = ctx->ndt_perm2.as<unsigned>();
     unsigned *flags = ctx->ndt_flags.as<unsigned>(), *seg = ctx->ndt_seg.as<unsigned>();
     // the lattice of voxels over the target's bounding box (cell numbers from the same float
@@ -810,7 +817,7 @@ static int ndt_build(wm_ctx *ctx, double res) {
     }
     unsigned key_bits = 1;
     while (key_bits < 64 && (L.cells >> key_bits) != 0ull) ++key_bits;
-    hipLaunchKernelGGL(k_ndt_key, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, (unsigned) n,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_key<KT>), dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, (unsigned) n,
                        1.0f / (float) res, L, k1, p1);
     size_t tmp = 0;
     WM_HIP(ctx, sort_pairs_low_bits(nullptr, tmp, k1, k2, p1, p2, n, key_bits, ctx->stream,
@@ -822,7 +829,7 @@ static int ndt_build(wm_ctx *ctx, double res) {
     // radix sort -- the registration's critical path, ~150 us of device time that this thread's ~15 launches of the other
     // sort fit into -- and before the launches below, the last of which this thread then waits for)
     WM_TRY(enqueue_deferred_sort(ctx));
-    hipLaunchKernelGGL(k_ndt_flags, dim3(blocks), dim3(kBlock), 0, ctx->stream, k2, (unsigned) n, L.cells,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_flags<KT>), dim3(blocks), dim3(kBlock), 0, ctx->stream, (const KT *) k2, (unsigned) n, (KT) L.cells,
                        flags);
     WM_TRY(exclusive_scan(ctx, flags, n, seg));
     unsigned *h_word = (unsigned *) pinned_scratch(ctx, 0);
@@ -846,8 +853,8 @@ static int ndt_build(wm_ctx *ctx, double res) {
     WM_HIP(ctx, hipMemsetAsync(d_nvalid, 0, 4, ctx->stream));
     if (nvox > 0) {
         unsigned *heads = p1;  // the sort's input permutation is dead by now
-        hipLaunchKernelGGL(k_ndt_heads, dim3(blocks), dim3(kBlock), 0, ctx->stream, k2, flags, seg, (unsigned) n,
-                           L.cells, heads);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_heads<KT>), dim3(blocks), dim3(kBlock), 0, ctx->stream, (const KT *) k2, (const unsigned *) flags, (const unsigned *) seg, (unsigned) n,
+                           (KT) L.cells, heads);
         // Coarse grids: every voxel a wave's.  Finer ones: a lane's -- except their crowded voxels: a lidar's
         // rings put thousands of points into the voxels next to the sensor (1 700 in a 0.5 m voxel of a
         // 2M-point 64-ring scan whose average is 100), and one lane walking those alone held the whole launch
@@ -858,8 +865,8 @@ static int ndt_build(wm_ctx *ctx, double res) {
         WM_HIP(ctx, ctx->ndt_vsum.reserve((size_t) nvox * 12 * sizeof(double)));
         hipLaunchKernelGGL(k_ndt_voxel_sums, dim3(nvox < 8192u ? (nvox + 3u) / 4u : 2048u), dim3(kBlock), 0, ctx->stream, pts,
                            p2, heads, nvox, split + 1u, ctx->ndt_vsum.as<double>());
-        hipLaunchKernelGGL(k_ndt_voxel_stats, dim3((nvox + kVoxStatBlock - 1) / kVoxStatBlock), dim3(kVoxStatBlock), 0,
-                           ctx->stream, pts, k2, p2, heads, nvox, split, ctx->ndt_vsum.as<double>(), L,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ndt_voxel_stats<KT>), dim3((nvox + kVoxStatBlock - 1) / kVoxStatBlock), dim3(kVoxStatBlock), 0,
+                           ctx->stream, pts, (const KT *) k2, (const unsigned *) p2, (const unsigned *) heads, nvox, split, (const double *) ctx->ndt_vsum.as<double>(), L,
                            ctx->ndt_vox.as<NdtVoxel>(), ctx->ndt_meanf.as<float4>(),
                            ctx->ndt_vkey.as<unsigned long long>(), d_nvalid);
         hipLaunchKernelGGL(k_ndt_hash_insert, dim3((nvox + kBlock - 1) / kBlock), dim3(kBlock), 0,
@@ -913,6 +920,20 @@ static int ndt_build(wm_ctx *ctx, double res) {
     ctx->ndt_res = res;
     ctx->ndt_built = true;
     return WM_OK;
+}
+
+// the voxel model of the target at resolution res (32-bit sort keys while the lattice over its bounding box has fewer than
+// 2^32 cells -- every grid a scan's bounding box and a sane resolution give)
+static int ndt_build(wm_ctx *ctx, double res) {
+    const float inv = 1.0f / (float) res;
+    const Bbox &bb = ctx->tgt_bbox;
+    double cells = 1.0;
+    for (int d = 0; d < 3; ++d) {
+        const double dd = (double) floorf(bb.hi[d] * inv) - (double) floorf(bb.lo[d] * inv) + 1.0;
+        cells *= dd > 1.0 ? dd : 1.0;
+    }
+    if (ctx->n_tgt > 0 && cells < 4294967295.0 && !ctx->tune_ndt_keys64) return ndt_build_t<unsigned>(ctx, res);
+    return ndt_build_t<unsigned long long>(ctx, res);
 }
 
 

@@ -122,6 +122,10 @@ def test_ndt_model_does_not_depend_on_who_forms_a_voxels_sums(wm, ctx, testscan,
         ctx.set_option("ndt_vox_split", split)
         out.append((split, ctx.ndt_derivatives(pose, res=res), ctx.ndt_align(res=res)))
     ctx.set_option("ndt_vox_split", -1)
+    # ... nor on the width of the keys its points are sorted by (32 bits while the lattice has fewer than 2^32 cells)
+    ctx.set_option("ndt_keys64", 1)
+    out.append(("keys64", ctx.ndt_derivatives(pose, res=res), ctx.ndt_align(res=res)))
+    ctx.set_option("ndt_keys64", 0)
     _, (s0, g0, H0, n0), a0 = out[0]
     assert n0 > 0
     for split, (s, g, H, n), a in out[1:]:
