@@ -531,10 +531,10 @@ int morton_sort(wm_ctx *ctx, const float4 *pts, size_t n, const Bbox &bb, size_t
                        key, 1u << (3 * bits), k1, v1);
     size_t tmp_bytes = 0;
     WM_HIP(ctx, sort_pairs_low_bits(nullptr, tmp_bytes, k1, k2, v1, v2, n, 3 * bits + 1, ctx->stream,
-                                    (size_t) ctx->tune_radix_min));
+                                    (size_t) ctx->tune_radix_min, ctx->tune_sort));
     WM_HIP(ctx, ctx->vg_tmp.reserve(tmp_bytes));
     WM_HIP(ctx, sort_pairs_low_bits(ctx->vg_tmp.p, tmp_bytes, k1, k2, v1, v2, n, 3 * bits + 1, ctx->stream,
-                                    (size_t) ctx->tune_radix_min));
+                                    (size_t) ctx->tune_radix_min, ctx->tune_sort));
     const unsigned gblocks = (unsigned) ((n_valid + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_gather, dim3(gblocks), dim3(kBlock), 0, ctx->stream, pts, v2,
                        (unsigned) n_valid, out);

@@ -1057,6 +1057,7 @@ int wm_ctx_create(wm_ctx **out, int device) {
     }
     if (const char *e = getenv("WM_TUNE_XCD_CHUNK")) ctx->tune_xcd_chunk = atoi(e);
     if (const char *e = getenv("WM_TUNE_RADIX_MIN")) ctx->tune_radix_min = atoi(e);
+    if (const char *e = getenv("WM_TUNE_SORT")) ctx->tune_sort = atoi(e);
     if (const char *e = getenv("WM_TUNE_NDT_BLOCKS")) {
         const int v = atoi(e);
         if (v >= 0 && v <= 4096) ctx->tune_ndt_blocks = v;

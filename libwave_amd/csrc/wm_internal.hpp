@@ -272,7 +272,8 @@ struct wm_ctx {
     bool ndt_cells4_on = false;
     wm::DevBuf ndt_cells4;
     float tune_knn_r0 = 0.f;     // first radius of the k-NN (covariance) scan in cells; 0 = by k (1.0 up to k = 12, else 1.5)
-    int tune_radix_min = 256 << 10;  // sorts of more items take rocPRIM's onesweep radix path (wm_sort.hpp)
+    int tune_radix_min = 256 << 10;  // sorts of more items take the radix path (wm_sort.hpp) ...
+    int tune_sort = 1;               // ... 1: the library's own three-launches-per-pass sort, 0: rocPRIM's onesweep (WM_TUNE_SORT)
     int tune_xcd_chunk = 32;     // search kernel: XCDs take turns in chunks of this many workgroups (0: one eighth each)
     int tune_scan = 1;           // exclusive scans: rocPRIM look-back scan (1) or the three-kernel scan (0)
     int tune_nn_walk_filter = 1;  // balanced walk: LDS atomic only for trips that can improve the owner's best

@@ -821,10 +821,10 @@ static int ndt_build_t(wm_ctx *ctx, double res) {
                        1.0f / (float) res, L, k1, p1);
     size_t tmp = 0;
     WM_HIP(ctx, sort_pairs_low_bits(nullptr, tmp, k1, k2, p1, p2, n, key_bits, ctx->stream,
-                                    (size_t) ctx->tune_radix_min));
+                                    (size_t) ctx->tune_radix_min, ctx->tune_sort));
     WM_HIP(ctx, ctx->ndt_tmp.reserve(tmp));
     WM_HIP(ctx, sort_pairs_low_bits(ctx->ndt_tmp.p, tmp, k1, k2, p1, p2, n, key_bits, ctx->stream,
-                                    (size_t) ctx->tune_radix_min));
+                                    (size_t) ctx->tune_radix_min, ctx->tune_sort));
     // (a source's Morton sort that wm_ndt_align held back goes to the side stream NOW: behind this model's key kernel and
     // radix sort -- the registration's critical path, ~150 us of device time that this thread's ~15 launches of the other
     // sort fit into -- and before the launches below, the last of which this thread then waits for)

@@ -193,10 +193,10 @@ int voxel_downsample_dev(wm_ctx *ctx, const float4 *in, size_t n, float leaf, fl
                        inv, mb[0], mb[1], mb[2], db[0], db[0] * db[1], invalid, idx, perm);
     size_t tmp_bytes = 0;
     WM_HIP(ctx, sort_pairs_low_bits(nullptr, tmp_bytes, idx, idx2, perm, perm2, n, bits, ctx->stream,
-                                    (size_t) ctx->tune_radix_min));
+                                    (size_t) ctx->tune_radix_min, ctx->tune_sort));
     WM_HIP(ctx, ctx->vg_tmp.reserve(tmp_bytes));
     WM_HIP(ctx, sort_pairs_low_bits(ctx->vg_tmp.p, tmp_bytes, idx, idx2, perm, perm2, n, bits, ctx->stream,
-                                    (size_t) ctx->tune_radix_min));
+                                    (size_t) ctx->tune_radix_min, ctx->tune_sort));
     // head flags -> exclusive scan -> output slot per leaf; total = number of leaves
     hipLaunchKernelGGL(k_vg_flags, dim3(blocks), dim3(kBlock), 0, ctx->stream, idx2, (unsigned) n,
                        invalid, idx /* reuse as flags */);
