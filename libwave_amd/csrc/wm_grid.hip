@@ -36,6 +36,9 @@ __global__ void __launch_bounds__(kBlock) k_pack(const unsigned char *in, size_t
 // started here, asynchronously, on the side stream; pack_cloud(..., slot 1, staged = true) later waits for it -- on the
 // HOST, so that the caller's memory is not read after the call that was given it has returned -- and packs from there.
 // false: not pinned (or no side stream): the caller takes the blocking path.
+template <bool PACK>
+__global__ void k_bbox(float4 *pts, size_t n, float *out, const unsigned char *raw, size_t rstride);  // (below)
+
 bool upload_begin_async(wm_ctx *ctx, const void *pts, size_t bytes) {
     if (!ctx->side_stream || bytes == 0) return false;
     hipPointerAttribute_t at;
@@ -56,7 +59,12 @@ bool upload_begin_async(wm_ctx *ctx, const void *pts, size_t bytes) {
     return true;
 }
 
-int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, float4 *out, int slot, bool staged) {
+int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, float4 *out, int slot, bool staged,
+               float *bbox_partials, unsigned *bbox_blocks) {
+    if (bbox_blocks) {
+        unsigned b = (unsigned) ((n + kBlock - 1) / kBlock);
+        *bbox_blocks = b > (unsigned) kBboxBlocks ? (unsigned) kBboxBlocks : b;
+    }
     if (n == 0) return WM_OK;
     const unsigned char *dptr = nullptr;
     if (mem == WM_MEM_HOST && staged) {
@@ -81,15 +89,25 @@ int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, f
         dptr = static_cast<const unsigned char *>(pts);
     }
     unsigned blocks = (unsigned) ((n + kBlock - 1) / kBlock);
+    if (bbox_partials && bbox_blocks && ctx->tune_pack_bbox) {  // (the cloud's box in the same launch: k_bbox<true>)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bbox<true>), dim3(*bbox_blocks), dim3(kBlock), 0, ctx->stream, out, n, bbox_partials, dptr, stride);
+        WM_HIP(ctx, hipGetLastError());
+        return WM_OK;
+    }
     hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(kBlock), 0, ctx->stream, dptr, n, stride, out);
     WM_HIP(ctx, hipGetLastError());
+    if (bbox_partials && bbox_blocks) return launch_bbox(ctx, out, n, bbox_partials, bbox_blocks);
     return WM_OK;
 }
 
 // ------------------------------------------------------------------ bbox
 // One partial per workgroup: out[8 b + 0..2] = min, [3..5] = max (as floats), [6] = valid count.
 // The host reduces the partials (it waits for the result anyway); no same-address atomics.
-__global__ void __launch_bounds__(kBlock) k_bbox(const float4 *pts, size_t n, float *out) {
+// PACK: the cloud is packed on the way (k_pack's conversion of the caller's records at `raw`, byte stride `rstride`, into
+// pts) -- one launch instead of two at the head of every registration's chain of dependent launches; the box and the count
+// are the same numbers either way (minima, maxima and an integer do not care about the order they are formed in).
+template <bool PACK>
+__global__ void __launch_bounds__(kBlock) k_bbox(float4 *pts, size_t n, float *out, const unsigned char *raw, size_t rstride) {
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     unsigned cnt = 0;
     const size_t stride = (size_t) gridDim.x * kBlock;
@@ -98,7 +116,24 @@ __global__ void __launch_bounds__(kBlock) k_bbox(const float4 *pts, size_t n, fl
 #pragma unroll
         for (int u = 0; u < 4; ++u) {  // four loads in flight
             const size_t i = i0 + u * stride;
-            p[u] = i < n ? pts[i] : make_float4(NAN, 0.f, 0.f, 0.f);
+            if (PACK) {
+                p[u] = make_float4(NAN, 0.f, 0.f, 0.f);
+                if (i < n) {
+                    const float *q = reinterpret_cast<const float *>(raw + i * rstride);
+                    float x = q[0], y = q[1], z = q[2];
+                    if (!(isfinite(x) && isfinite(y) && isfinite(z))) x = y = z = __builtin_nanf("");
+                    p[u] = make_float4(x, y, z, __uint_as_float((unsigned) i));
+                }
+            } else {
+                p[u] = i < n ? pts[i] : make_float4(NAN, 0.f, 0.f, 0.f);
+            }
+        }
+        if (PACK) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t i = i0 + u * stride;
+                if (i < n) pts[i] = p[u];
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -153,7 +188,8 @@ int launch_bbox(wm_ctx *ctx, const float4 *pts, size_t n, float *partials_dev, u
     if (blocks > (unsigned) kBboxBlocks) blocks = kBboxBlocks;
     *blocks_out = blocks;
     if (n == 0) return WM_OK;
-    hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(kBlock), 0, ctx->stream, pts, n, partials_dev);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bbox<false>), dim3(blocks), dim3(kBlock), 0, ctx->stream, const_cast<float4 *>(pts), n, partials_dev,
+                       (const unsigned char *) nullptr, (size_t) 0);
     WM_HIP(ctx, hipGetLastError());
     return WM_OK;
 }

@@ -1058,6 +1058,7 @@ int wm_ctx_create(wm_ctx **out, int device) {
     if (const char *e = getenv("WM_TUNE_XCD_CHUNK")) ctx->tune_xcd_chunk = atoi(e);
     if (const char *e = getenv("WM_TUNE_RADIX_MIN")) ctx->tune_radix_min = atoi(e);
     if (const char *e = getenv("WM_TUNE_SORT")) ctx->tune_sort = atoi(e);
+    if (const char *e = getenv("WM_TUNE_PACK_BBOX")) ctx->tune_pack_bbox = atoi(e);
     if (const char *e = getenv("WM_TUNE_NDT_BLOCKS")) {
         const int v = atoi(e);
         if (v >= 0 && v <= 4096) ctx->tune_ndt_blocks = v;
@@ -1188,9 +1189,8 @@ int wm_set_source(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem
     WM_HIP(ctx, ctx->src_sorted.reserve(n * sizeof(float4)));
     WM_HIP(ctx, ctx->cloud_bbox.reserve(2 * 8 * sizeof(float) * kBboxBlocks));
     if (ctx->trace) fprintf(stderr, "[wm] set_source: n=%zu stride=%zu mem=%d ptr=%p\n", n, stride, mem, pts);
-    WM_TRY(pack_cloud(ctx, pts, n, stride, mem, ctx->src_orig.as<float4>()));
+    WM_TRY(pack_cloud(ctx, pts, n, stride, mem, ctx->src_orig.as<float4>(), 0, false, ctx->cloud_bbox.as<float>(), &ctx->src_bbox_blocks));
     WM_TRACE(ctx, "set_source: packed");
-    WM_TRY(launch_bbox(ctx, ctx->src_orig.as<float4>(), n, ctx->cloud_bbox.as<float>(), &ctx->src_bbox_blocks));
     ctx->src_pending = true;
     return WM_OK;
 }
@@ -1242,10 +1242,9 @@ int wm_set_target(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem
                            ctx->src_sorted.as<float4>()));
         slot = 1;
     }
-    WM_TRY(pack_cloud(ctx, pts, n, stride, mem, ctx->tgt_orig.as<float4>(), slot, staged));
+    WM_TRY(pack_cloud(ctx, pts, n, stride, mem, ctx->tgt_orig.as<float4>(), slot, staged, ctx->cloud_bbox.as<float>() + 8 * kBboxBlocks,
+                      &ctx->tgt_bbox_blocks));
     drain_copy.on = false;  // (pack_cloud waited for it)
-    WM_TRY(launch_bbox(ctx, ctx->tgt_orig.as<float4>(), n, ctx->cloud_bbox.as<float>() + 8 * kBboxBlocks,
-                       &ctx->tgt_bbox_blocks));
     ctx->tgt_pending = true;
     // the search grid is built by the first caller that searches (finalize_clouds / ensure_levels in
     // the ICP / GICP / search entry points): an NDT registration never needs it

@@ -273,6 +273,7 @@ struct wm_ctx {
     wm::DevBuf ndt_cells4;
     float tune_knn_r0 = 0.f;     // first radius of the k-NN (covariance) scan in cells; 0 = by k (1.0 up to k = 12, else 1.5)
     int tune_radix_min = 256 << 10;  // sorts of more items take the radix path (wm_sort.hpp) ...
+    int tune_pack_bbox = 1;          // a cloud's bounding box is formed by the launch that packs it (WM_TUNE_PACK_BBOX)
     int tune_sort = 1;               // ... 1: the library's own three-launches-per-pass sort, 0: rocPRIM's onesweep (WM_TUNE_SORT)
     int tune_xcd_chunk = 32;     // search kernel: XCDs take turns in chunks of this many workgroups (0: one eighth each)
     int tune_scan = 1;           // exclusive scans: rocPRIM look-back scan (1) or the three-kernel scan (0)
@@ -324,7 +325,9 @@ struct wm_ctx {
 namespace wm {
 
 // ---- wm_grid.hip
-int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, float4 *out, int slot = 0, bool staged = false);
+// (bbox_partials / bbox_blocks: the packed cloud's bounding-box partials as launch_bbox leaves them, in the same launch)
+int pack_cloud(wm_ctx *ctx, const void *pts, size_t n, size_t stride, int mem, float4 *out, int slot = 0, bool staged = false,
+               float *bbox_partials = nullptr, unsigned *bbox_blocks = nullptr);
 bool upload_begin_async(wm_ctx *ctx, const void *pts, size_t bytes);  // (pinned host memory: the copy starts now, see wm_grid.hip)
 int compute_bbox(wm_ctx *ctx, const float4 *pts, size_t n, Bbox *out, size_t *n_valid);
 // the two halves of compute_bbox: enqueue the reduction into `partials_dev` (kBboxBlocks * 8 floats),
