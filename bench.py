@@ -892,6 +892,10 @@ def main():
     # ones, profiles/r05m_bench_line_noprof.json; the interpreter's collector is the one pause this script can rule
     # out.  Collected BEFORE the warm-up: a collection between warm-up and timing leaves the GPU idle for tens of
     # milliseconds and the first timed step 0.3 ms slower, gpurun_out/r05n_jitter)
+    # (the device's copy rate -- what `roofline.hbm_util` is a fraction of -- is measured BEFORE the registrations: it is the
+    # bench's one other device-wide measurement, and a device that has just moved 40 GB enters the warm-up at its working
+    # clocks rather than from idle)
+    peak_copy_early = ctx.copy_bandwidth() if (world == 1 and rank == 0) else None
     import gc
     gc.collect()
     gc.disable()
@@ -960,7 +964,7 @@ def main():
 
     if rank == 0:
         pmc = pmc_summary() if world == 1 else {}
-        peak_copy = ctx.copy_bandwidth() if world == 1 else None
+        peak_copy = peak_copy_early if world == 1 else None
         out = assemble_line(a, world, r, T_gt, elapsed, step_ms, nn_ms, nn_launches, cert_ms, cert_launches, parallelism,
                             pmc=pmc, peak_copy=peak_copy, sharded=comm is not None, ar_us=ar_us)
         if comm is not None:
