@@ -264,8 +264,11 @@ int wm_debug_bins_sum(const double *x, size_t n, const unsigned *perm, double *o
  * "cert_pad_frac", "cert_nb", "gicp_served" (0 / 1 / 2: GICP's objective evaluations launched / served by the
  * resident evaluator / served without the on-chip pair cache), "late" (1: the late ICP iterations -- certificate,
  * searches, sums, solve, stopping rules -- in ONE resident launch, k_nn_cert<.., LATE> + k_late_solver; 0, the
- * default: a launch per iteration, which measures the same or faster).  None of them changes a result.
- * WM_ERR_ARG for an unknown name. */
+ * default: a launch per iteration, which measures the same or faster), "bins" (0: an ICP iteration's sums as rows
+ * of partial sums and a reduction launch; 1, the default: as exact integer limbs in bins), "ndt_vox_split" (NDT model:
+ * the points per voxel up to which a lane, not a wave, forms a voxel's sums; -1: the library's choice) and "ndt_keys64"
+ * (1: 64-bit voxel sort keys whatever the lattice's size) -- both rebuild the model at the next NDT call.  None of them
+ * changes a result.  WM_ERR_ARG for an unknown name. */
 int wm_set_option(wm_ctx *ctx, const char *name, double value);
 /* developer: out == NULL arms a log of `iterations` launches (0 disarms); otherwise writes, per
  * launch of the certificate kernel since, how many queries it had to search; returns the count */
