@@ -258,6 +258,10 @@ int wm_debug_copy_bandwidth(wm_ctx *ctx, size_t bytes, int reps, double *gb_per_
  * *out = that double; limbs_out (may be NULL): the three limb totals.  WM_ERR_ARG when an x[i] does not fit (not finite,
  * |x| >= 2^62: the device poisons the bin for those). */
 int wm_debug_bins_sum(const double *x, size_t n, const unsigned *perm, double *out, long long limbs_out[3]);
+/* Developer / tests: the library's own stable radix sort (wm_sort.hpp: what every cloud's Morton order, the NDT voxel
+ * order and the voxel filter are built on above 256k points) on HOST arrays: values_out[i] = the input position of the
+ * i-th pair in ascending order of the low `bits` bits of the key (equal keys in input order).  key_bytes: 4 or 8. */
+int wm_debug_sort_pairs(wm_ctx *ctx, const void *keys, int key_bytes, size_t n, unsigned bits, unsigned *values_out);
 /* Tuning knobs by name (tests, benchmarks; the defaults are the product's): "cert_from" (-1: the
  * certificate kernel takes over once an ICP step is small, -2: never, k >= 0: from iteration k of
  * every align), "cert_disp" (that step size, in level-0 grid cells), "cert_pad_mul",

@@ -208,6 +208,7 @@ def lib():
         L.wm_multi_icp_info.argtypes = [C.c_void_p, C.c_int, _dp, C.c_double, C.c_double, C.c_double, _dp,
                                         C.POINTER(C.c_int)]
         L.wm_debug_solve_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.wm_debug_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_uint, C.c_void_p]
         L.wm_debug_cost_log.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.wm_debug_phase_log.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.wm_get_correspondences.argtypes = [C.c_void_p, _ip, _fp, C.c_size_t]
@@ -698,6 +699,16 @@ class Context:
         buf = np.zeros((iterations, 8), np.uint64)
         k = lib().wm_debug_phase_log(self._h, buf.ctypes.data_as(C.c_void_p), iterations)
         return buf[:max(k, 0)]
+
+    def sort_pairs(self, keys, bits):
+        """The library's own radix sort (wm_debug_sort_pairs): positions of `keys` (uint32 / uint64 numpy array) in
+        ascending order of their low `bits` bits, equal keys in input order."""
+        keys = np.ascontiguousarray(keys)
+        assert keys.dtype in (np.uint32, np.uint64) and keys.ndim == 1
+        out = np.zeros(keys.shape[0], np.uint32)
+        self._check(lib().wm_debug_sort_pairs(self._h, keys.ctypes.data, keys.dtype.itemsize, keys.shape[0], int(bits),
+                                              out.ctypes.data), "wm_debug_sort_pairs")
+        return out
 
     def solve_cycles(self):
         buf = (C.c_uint64 * 8)()

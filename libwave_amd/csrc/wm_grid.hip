@@ -14,6 +14,7 @@
 #include "wm_sort.hpp"
 
 #include <math.h>
+#include <vector>
 #include <string.h>
 
 namespace wm {
@@ -783,3 +784,32 @@ int ensure_levels(wm_ctx *ctx, double max_corr) {
 }
 
 }  // namespace wm
+
+extern "C" int wm_debug_sort_pairs(wm_ctx *ctx, const void *keys, int key_bytes, size_t n, unsigned bits, unsigned *values_out) {
+    using namespace wm;
+    if (!ctx || (n > 0 && (!keys || !values_out)) || (key_bytes != 4 && key_bytes != 8) || bits > 8u * (unsigned) key_bytes ||
+        n >= (size_t) 0xFFFF0000u)
+        return WM_ERR_ARG;
+    if (n == 0) return WM_OK;
+    WM_HIP(ctx, hipSetDevice(ctx->device));
+    struct Scoped : DevBuf {  // (DevBuf frees nothing by itself: the context owns its buffers; these are this call's)
+        ~Scoped() { release(); }
+    } k1, k2, v1, v2, tmp;
+    WM_HIP(ctx, k1.reserve(n * (size_t) key_bytes));
+    WM_HIP(ctx, k2.reserve(n * (size_t) key_bytes));
+    WM_HIP(ctx, v1.reserve(n * 4));
+    WM_HIP(ctx, v2.reserve(n * 4));
+    WM_HIP(ctx, tmp.reserve(rs_temp_bytes(n)));
+    std::vector<unsigned> iota(n);
+    for (size_t i = 0; i < n; ++i) iota[i] = (unsigned) i;
+    WM_HIP(ctx, hipMemcpy(k1.p, keys, n * (size_t) key_bytes, hipMemcpyHostToDevice));
+    WM_HIP(ctx, hipMemcpy(v1.p, iota.data(), n * 4, hipMemcpyHostToDevice));
+    if (key_bytes == 4)
+        WM_HIP(ctx, rs_sort_pairs(tmp.p, k1.as<unsigned>(), k2.as<unsigned>(), v1.as<unsigned>(), v2.as<unsigned>(), n, bits, ctx->stream));
+    else
+        WM_HIP(ctx, rs_sort_pairs(tmp.p, k1.as<unsigned long long>(), k2.as<unsigned long long>(), v1.as<unsigned>(), v2.as<unsigned>(), n,
+                                  bits, ctx->stream));
+    WM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    WM_HIP(ctx, hipMemcpy(values_out, v2.p, n * 4, hipMemcpyDeviceToHost));
+    return WM_OK;
+}

@@ -30,7 +30,7 @@ constexpr int kRsBins = 256;                       // eight bits per pass
 // hist[d * tiles + t] = number of items of tile t whose digit is d
 template <class K>
 __global__ void __launch_bounds__(kRsThreads)
-    k_rs_hist(const K *__restrict__ keys, unsigned n, unsigned shift, unsigned *__restrict__ hist, unsigned tiles) {
+    k_rs_hist(const K *__restrict__ keys, unsigned n, unsigned shift, unsigned dmask, unsigned *__restrict__ hist, unsigned tiles) {
     __shared__ unsigned h[kRsBins];
     const unsigned tid = threadIdx.x, tile = blockIdx.x;
     h[tid] = 0u;
@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(kRsThreads)
 #pragma unroll
     for (int r = 0; r < kRsRounds; ++r) {
         const unsigned i = base + (unsigned) r * kRsThreads + tid;
-        if (i < n) atomicAdd(&h[(unsigned) (keys[i] >> shift) & (kRsBins - 1u)], 1u);
+        if (i < n) atomicAdd(&h[(unsigned) (keys[i] >> shift) & dmask], 1u);
     }
     __syncthreads();
     hist[(size_t) tid * tiles + tile] = h[tid];
@@ -97,8 +97,8 @@ static __global__ void __launch_bounds__(kRsThreads) k_rs_scan(unsigned *__restr
 template <class K, class V>
 __global__ void __launch_bounds__(kRsThreads)
     k_rs_scatter(const K *__restrict__ keys_in, const V *__restrict__ vals_in, K *__restrict__ keys_out,
-                 V *__restrict__ vals_out, unsigned n, unsigned shift, const unsigned *__restrict__ hist, unsigned tiles,
-                 const unsigned *__restrict__ totals) {
+                 V *__restrict__ vals_out, unsigned n, unsigned shift, unsigned dmask, const unsigned *__restrict__ hist,
+                 unsigned tiles, const unsigned *__restrict__ totals) {
     constexpr int kWaves = kRsThreads / 64;
     __shared__ unsigned s_gbase[kRsBins];   // digit d's first place in the output, for this tile
     __shared__ unsigned s_lstart[kRsBins];  // ... within the tile
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(kRsThreads)
 #pragma unroll
     for (int r = 0; r < kRsRounds; ++r) {
         const unsigned i = base + (unsigned) r * kRsThreads + tid;
-        if (i < n) atomicAdd(&s_run[(unsigned) (key[r] >> shift) & (kRsBins - 1u)], 1u);
+        if (i < n) atomicAdd(&s_run[(unsigned) (key[r] >> shift) & dmask], 1u);
     }
     __syncthreads();
     {
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(kRsThreads)
     for (int r = 0; r < kRsRounds; ++r) {  // (unrolled: key[r] / val[r] stay in registers)
         const unsigned i = base + (unsigned) r * kRsThreads + tid;
         const bool live = i < n;
-        const unsigned d = (unsigned) (key[r] >> shift) & (kRsBins - 1u);
+        const unsigned d = (unsigned) (key[r] >> shift) & dmask;
         unsigned long long peers = __ballot(live);
 #pragma unroll
         for (int bit = 0; bit < 8; ++bit) {
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(kRsThreads)
 #pragma unroll 4
     for (unsigned j = tid; j < count; j += kRsThreads) {
         const K k = s_key[j];
-        const unsigned d = (unsigned) (k >> shift) & (kRsBins - 1u);
+        const unsigned d = (unsigned) (k >> shift) & dmask;
         const unsigned pos = s_gbase[d] + (j - s_lstart[d]);
         keys_out[pos] = k;
         vals_out[pos] = s_val[j];
@@ -210,10 +210,13 @@ inline hipError_t rs_sort_pairs(void *tmp, K *keys_in, K *keys_out, V *vals_in, 
     }
     for (unsigned p = 0; p < passes; ++p) {
         const unsigned shift = 8u * p;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rs_hist<K>), dim3(tiles), dim3(kRsThreads), 0, stream, (const K *) ki, (unsigned) n, shift, hist, tiles);
+        // (the last pass of a key whose width is not a multiple of the digit looks at the bits that are left, no further)
+        const unsigned left = bits > shift ? bits - shift : 0u;
+        const unsigned dmask = left >= 8u ? (unsigned) kRsBins - 1u : (1u << left) - 1u;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rs_hist<K>), dim3(tiles), dim3(kRsThreads), 0, stream, (const K *) ki, (unsigned) n, shift, dmask, hist, tiles);
         hipLaunchKernelGGL(k_rs_scan, dim3(kRsBins), dim3(kRsThreads), 0, stream, hist, tiles, totals);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rs_scatter<K, V>), dim3(tiles), dim3(kRsThreads), 0, stream, (const K *) ki, (const V *) vi, ko, vo,
-                           (unsigned) n, shift, (const unsigned *) hist, tiles, (const unsigned *) totals);
+                           (unsigned) n, shift, dmask, (const unsigned *) hist, tiles, (const unsigned *) totals);
         K *tk = ki;
         ki = ko, ko = tk;
         V *tv = vi;
